@@ -1,0 +1,302 @@
+"""Pin the CPU oracle against every known answer the reference's own tests/docs hold for the
+hot path.  The reference has no stored golden vectors: all pins are analytic.
+Each test cites the reference test it restates."""
+import math
+
+import numpy as np
+import pytest
+from scipy import integrate, special
+
+import abz_oracle as orc
+
+
+# ---------------------------------------------------------------- GK table / 1-D quadrature
+def test_gk15_table_exactness():
+    # Kronrod-15 exact through degree 22, embedded Gauss-7 through degree 13
+    x = np.concatenate([orc.GK_X[:7], [0.0], -orc.GK_X[:7]])
+    w = np.concatenate([orc.GK_W[:7], [orc.GK_W[7]], orc.GK_W[:7]])
+    xg = np.concatenate([orc.GK_X[1:7:2], [0.0], -orc.GK_X[1:7:2]])
+    wg = np.concatenate([orc.GK_GW[:3], [orc.GK_GW[3]], orc.GK_GW[:3]])
+    for k in range(0, 23, 2):
+        assert abs(np.dot(w, x**k) - 2 / (k + 1)) < 3e-16
+    for k in range(0, 14, 2):
+        assert abs(np.dot(wg, xg**k) - 2 / (k + 1)) < 3e-16
+    gx, gw = np.polynomial.legendre.leggauss(7)
+    assert np.allclose(np.sort(xg), gx, atol=1e-15) and np.allclose(wg[np.argsort(xg)], gw, atol=1e-15)
+
+
+def test_evalcounter_constant_gk7_is_15():
+    # ref: test/interface_tests.jl:143-158 (QuadGKJL(order=7) on a constant -> numevals == 15)
+    I, E, n = orc.auxquadgk(lambda xs: np.ones(len(xs)), (0.0, 1.0))
+    assert n == 15 and abs(I - 1.0) < 1e-15
+    I, E, n = orc.auxquadgk(lambda xs: np.ones(len(xs)), (0.0, 1.0), batch=True)
+    assert n == 15
+
+
+@pytest.mark.parametrize("batch", [False, True])
+def test_quadrature_known_answers(batch):
+    # ref: test/interface_tests.jl:27-43 and :90-111 (AuxQuadGKJL, plain and BatchIntegrand)
+    a, b, p, atol = 0.0, 2 * np.pi, 3.0, 1e-5
+    for f, ref in ((lambda x: p * np.sin(x), 0.0), (lambda x: p * np.ones_like(x), p * (b - a)),
+                   (lambda x: 1 / (p - np.cos(x)), (b - a) / math.sqrt(p * p - 1))):
+        I, E, n = orc.auxquadgk(f, (a, b), atol=atol, batch=batch)
+        assert abs(I - ref) < atol
+
+
+def test_docstring_values():
+    # ref: src/AutoBZCore.jl:14-17, docs/src/problems.md:18-25
+    I, _, _ = orc.auxquadgk(lambda x: np.sin(0.3 * x), (0.0, 1.0))
+    assert abs(I - 0.14887836958131329) < 1e-12
+    I, _, _ = orc.auxquadgk(lambda x: np.sin(0.4 * x), (0.0, 1.0))
+    assert abs(I - 0.1973475149927873) < 1e-12
+
+
+# ---------------------------------------------------------------- series evaluation
+def test_series_definition_cos():
+    # ref: docs/src/examples.md:26-42: [0.5,0,0.5], offset=-2 is cos(2 pi k)
+    s = orc.FourierSeries([0.5, 0.0, 0.5], period=1.0, offset=-2)
+    for k in (0.0, 0.1, 0.37, 0.9):
+        assert abs(orc.evaluate(s, [k]) - math.cos(2 * math.pi * k)) < 1e-15
+
+
+def test_hierarchical_equals_direct():
+    rng = np.random.default_rng(1)
+    c = rng.standard_normal((3, 4, 5, 2, 2)) + 1j * rng.standard_normal((3, 4, 5, 2, 2))
+    s = orc.FourierSeries(c, period=(1.0, 2.0, 0.5), first=(-1, -2, 0), ndim=3)
+    x = np.array([0.13, 0.71, 0.29])
+    assert np.allclose(orc.evaluate(s, x), orc.evaluate_direct(s, x), atol=1e-13)
+    assert np.allclose(orc.evaluate_many(s, x[None])[0], orc.evaluate_direct(s, x), atol=1e-13)
+    s1 = orc.FourierSeries(c, period=1.0, first=(-1, -2, 0), ndim=3)
+    vals = orc.fourier_ptr(s1, 4)
+    u = orc.ptrpoints(4)
+    for idx in ((0, 0, 0), (1, 2, 3), (3, 1, 2)):
+        assert np.allclose(vals[idx], orc.evaluate_direct(s1, u[list(idx)]), atol=1e-13)
+
+
+# ---------------------------------------------------------------- BZ + symmetric rule integers
+def test_load_bz_pins():
+    # ref: test/brillouin.jl:7-31
+    A = np.eye(3)
+    fbz = orc.load_bz("FBZ", A)
+    assert np.allclose(fbz.B, 2 * np.pi * np.eye(3)) and fbz.nsyms == 1
+    ibz = orc.load_bz("InversionSymIBZ", A)
+    assert ibz.nsyms == 8 and all(np.count_nonzero(S - np.diag(np.diag(S))) == 0 for S in ibz.syms)
+    assert np.allclose(ibz.lims.b, 0.5)
+    cbz = orc.load_bz("CubicSymIBZ", A)
+    assert cbz.nsyms == 48 and len({S.tobytes() for S in cbz.syms}) == 48
+    assert isinstance(cbz.lims, orc.TetrahedralLimits)
+
+
+@pytest.mark.parametrize("npt", [7, 8])
+@pytest.mark.parametrize("d", [1, 2, 3])
+def test_symptr_rule_integer_pins(npt, d):
+    # SURVEY 8c integer pins: irreducible counts, sum of weights, flags consistency
+    for kind, count in (("InversionSymIBZ", (npt // 2 + 1) ** d),
+                        ("CubicSymIBZ", math.comb(npt // 2 + d, d))):
+        bz = orc.load_bz(kind, np.eye(d))
+        wsym, flags, nsym = orc.symptr_rule(npt, d, bz.syms)
+        assert nsym == count
+        assert wsym.sum() == npt**d
+        assert int(flags[d - 1]) == 1
+        if d > 1:
+            # offsets of non-empty slabs are strictly increasing in column-major order
+            f = flags[0].reshape(-1, order="F")
+            nz = f[f > 0]
+            assert np.all(np.diff(nz) > 0) and nz[0] == 1
+
+
+def test_symptr_counts_large():
+    bz = orc.load_bz("CubicSymIBZ", np.eye(3))
+    _, _, nsym = orc.symptr_rule(50, 3, bz.syms)
+    assert nsym == 3276
+    bz = orc.load_bz("InversionSymIBZ", np.eye(3))
+    _, _, nsym = orc.symptr_rule(50, 3, bz.syms)
+    assert nsym == 17576
+
+
+def test_symmetric_rule_matches_full_grid():
+    # the symmetric traversal must reproduce full-grid values at the irreducible nodes
+    s = orc.tb_integer(3)
+    bz = orc.load_bz("CubicSymIBZ", np.eye(3))
+    w, xs, vals, idx = orc.fourier_symptr(s, 6, bz.syms)
+    full = orc.fourier_ptr(s, 6)
+    assert np.allclose(vals[:, 0, 0], full[idx[:, 0], idx[:, 1], idx[:, 2], 0, 0], atol=1e-13)
+    # column-major ordering of the output
+    lin = idx[:, 0] + 6 * idx[:, 1] + 36 * idx[:, 2]
+    assert np.all(np.diff(lin) > 0)
+
+
+# ---------------------------------------------------------------- BZ algorithms on FourierIntegrand
+@pytest.mark.parametrize("d", [1, 2, 3])
+@pytest.mark.parametrize("kind", ["FBZ", "InversionSymIBZ"])
+def test_bz_algorithms_linear_integrand(d, kind):
+    # ref: test/fourier.jl:40-56: f = 1.3 s + 1 integrates to (2 pi)^d, abstol 1e-6, reltol 0
+    s = orc.integer_lattice(d)
+    bz = orc.load_bz(kind, np.eye(d))
+    f = orc.f_linear(1.3, 1.0)
+    vol = (2 * np.pi) ** d
+    sol = orc.solve_ptr(s, bz, f, npt=50)
+    assert abs(sol.u - vol) < 1e-6
+    sol = orc.solve_autoptr(s, bz, f, abstol=1e-6, reltol=0.0)
+    assert abs(sol.u - vol) < 1e-6 and sol.extra["grids"] == [50, 100]
+    sol = orc.solve_iai(s, bz, f, abstol=1e-6, reltol=0.0)
+    assert abs(sol.u - vol) < 1e-6 and sol.numevals > 0
+
+
+@pytest.mark.parametrize("kind", ["FBZ", "InversionSymIBZ"])
+def test_unit_measure_volume(kind):
+    # ref: test/brillouin.jl:33-44
+    s = orc.integer_lattice(3)
+    bz = orc.load_bz(kind, np.eye(3))
+    vol = (2 * np.pi) ** 3
+    assert abs(orc.solve_ptr(s, bz, orc.f_one(), npt=50).u - vol) < 1e-9
+    assert abs(orc.solve_autoptr(s, bz, orc.f_one()).u - vol) < 1e-9
+    sol = orc.solve_iai(s, bz, orc.f_one())
+    assert abs(sol.u - vol) < 1e-9 and sol.numevals == 15**3
+
+
+def test_cubic_ibz_iai_volume():
+    s = orc.integer_lattice(3)
+    bz = orc.load_bz("CubicSymIBZ", np.eye(3))
+    assert abs(orc.solve_iai(s, bz, orc.f_one()).u - (2 * np.pi) ** 3) < 1e-9
+    assert abs(orc.solve_ptr(s, bz, orc.f_linear(1.3, 1.0), npt=50).u - (2 * np.pi) ** 3) < 1e-6
+
+
+def test_vector_integrand_analytic():
+    # ref: test/fourier.jl:9-22: f = a*s*x .+ b has integral b per component over [0,1]^d... plus
+    # a * int s x_j; for s = (1/d) sum cos 2 pi x_i that extra term vanishes -> 4.2 per component
+    for d in (1, 2, 3):
+        s = orc.integer_lattice(d)
+        bz = orc.load_bz("FBZ", 2 * np.pi * np.eye(d))  # |det B| = 1
+        sol = orc.solve_iai(s, bz, orc.f_linear_x(1.3, 4.2), abstol=1e-8, reltol=0.0)
+        assert np.allclose(sol.u, 4.2, atol=1e-7)
+        sol = orc.solve_ptr(s, bz, orc.f_linear_x(1.3, 4.2), npt=50)
+        # PTR of x*cos is not spectrally accurate; a*mean(s*x) = -1.3/(d*npt) * 1/2 ... just finite
+        assert np.all(np.isfinite(sol.u))
+
+
+@pytest.mark.parametrize("d", [1, 2, 3])
+def test_nested_quad_period_2pi(d):
+    # ref: test/interface_tests.jl:113-130: int (1 + 7 sum cos x_i) over [0, 2pi]^d = (2 pi)^d
+    C = np.zeros((3,) * d)
+    C[(1,) * d] = 1.0
+    for i in range(d):
+        for jj in (0, 2):
+            idx = [1] * d
+            idx[i] = jj
+            C[tuple(idx)] = 3.5
+    s = orc.FourierSeries(C, period=2 * np.pi, first=-1, ndim=d)
+    lims = orc.CubicLimits(np.zeros(d), np.full(d, 2 * np.pi))
+    for batch in (False, True):
+        u, err, _ = orc.nested_quad(s, lims, lambda x, v: np.real(v), abstol=1e-3, batch=batch)
+        assert abs(u - (2 * np.pi) ** d) < 1e-3
+
+
+def test_greens_function_doc_values():
+    # ref: docs/src/examples.md:58-61 (1-D, QuadGK abstol 1e-3) and :103-106 (2-D, IAI abstol 1e-3)
+    s1 = orc.FourierSeries([0.5, 0.0, 0.5], period=1.0, offset=-2)
+    bz1 = orc.load_bz("FBZ", [[2 * np.pi]])
+    sol = orc.solve_iai(s1, bz1, orc.f_gloc(0.1, 0.0), abstol=1e-3)
+    assert abs(sol.u - (-0.9950375451895513j)) < 1e-3
+    assert abs(sol.u - (-1j / math.sqrt(1 + 0.1**2))) < 1e-3  # closed form 1/sqrt(z^2-1)
+    c2 = np.array([[0.0, 0.5, 0.0], [0.5, 0.0, 0.5], [0.0, 0.5, 0.0]])
+    s2 = orc.FourierSeries(c2, period=1.0, offset=-2)
+    bz2 = orc.load_bz("FBZ", 2 * np.pi * np.eye(2))
+    sol = orc.solve_iai(s2, bz2, orc.f_gloc(0.1, 0.0), abstol=1e-3)
+    assert abs(sol.u - (-1.3941704019631334j)) < 2e-3
+
+
+def test_tolerance_scaling_and_panels():
+    # ref: src/brillouin.jl:340-342: abstol is divided by |det B| nsyms before the nested solve;
+    # the panel tree is deterministic -> integer pin (dyadic panels)
+    s = orc.integer_lattice(1)
+    bz = orc.load_bz("FBZ", np.eye(1))
+    rec = []
+    orc.solve_iai(s, bz, orc.f_linear(1.3, 1.0), abstol=1e-6, reltol=0.0, record=rec)
+    # all panels dyadic and tiling [0,1]
+    assert abs(sum(b - a for a, b in rec) - 1.0) < 1e-15
+    for a, b in rec:
+        k = round(math.log2(1 / (b - a)))
+        assert abs((b - a) - 2.0**-k) < 1e-15 and abs(a * 2**k - round(a * 2**k)) < 1e-12
+
+
+def test_batchparam_round_robin():
+    # ref: src/interfaces.jl:199-208
+    assert orc.batchparam(7, 3) == [[0, 3, 6], [1, 4], [2, 5]]
+    assert orc.batchparam(2, 8) == [[0], [1]]
+
+
+# ---------------------------------------------------------------- GGR DOS vs closed forms
+def dos_graphene_exact(E, t=1.0):
+    # ref: test/dos.jl:17-29
+    E = abs(E)
+    x = abs(E / t)
+    if x <= 1:
+        f = (1 + x) ** 2 - (x * x - 1) ** 2 / 4
+        return 2 * E / ((np.pi * t) ** 2 * math.sqrt(f)) * special.ellipk(4 * x / f)
+    if 1 < x < 3:
+        f = (1 + x) ** 2 - (x * x - 1) ** 2 / 4
+        return 2 * E / ((np.pi * t) ** 2 * math.sqrt(4 * x)) * special.ellipk(f / (4 * x))
+    return 0.0
+
+
+def dos_integer_1d_exact(E, t=1.0):
+    x = abs(E / (2 * t))  # ref: test/dos.jl:45-52
+    return 1 / math.sqrt(1 - x * x) / (np.pi * 2 * t) if x <= 1 else 0.0
+
+
+def dos_integer_2d_exact(E, t=1.0):
+    x = abs(E / (4 * t))  # ref: test/dos.jl:56-64
+    return 1 / (np.pi**2 * 2 * t) * special.ellipk(1 - x * x) if x <= 1 else 0.0
+
+
+def dos_integer_3d_exact(E, t=1.0):
+    x = abs(E / (6 * t))  # ref: test/dos.jl:69-86
+
+    def f(u):
+        return special.ellipk(1 - ((3 * x - math.cos(u)) / 2) ** 2)
+    if 3 * x < 1:
+        up = math.acos(3 * x)
+        I1 = integrate.quad(f, 0, up, limit=200)[0]
+        I2 = integrate.quad(f, up, np.pi, limit=200)[0]
+        return (I1 + I2) / (np.pi**3 * 2 * t)
+    if x < 1:
+        return integrate.quad(f, 0, math.acos(3 * x - 2), limit=200)[0] / (np.pi**3 * 2 * t)
+    return 0.0
+
+
+@pytest.mark.parametrize("case", [
+    ("graphene", dos_graphene_exact, 4, "FBZ"),
+    ("int1", dos_integer_1d_exact, 2, "FBZ"),
+    ("int2", dos_integer_2d_exact, 4, "FBZ"),
+    ("int1", dos_integer_1d_exact, 2, "InversionSymIBZ"),
+    ("int2", dos_integer_2d_exact, 4, "InversionSymIBZ"),
+    ("int3", dos_integer_3d_exact, 6, "InversionSymIBZ"),
+    ("int1", dos_integer_1d_exact, 2, "CubicSymIBZ"),
+    ("int2", dos_integer_2d_exact, 4, "CubicSymIBZ"),
+    ("int3", dos_integer_3d_exact, 6, "CubicSymIBZ"),
+])
+def test_ggr_vs_exact_dos(case):
+    # ref: test/dos.jl:88-111: GGR(npt=200), 10 energies incl. outside the band, atol 1e-2
+    name, exact, B, kind = case
+    s = {"graphene": orc.tb_graphene, "int1": lambda: orc.tb_integer(1), "int2": lambda: orc.tb_integer(2),
+         "int3": lambda: orc.tb_integer(3)}[name]()
+    bz = orc.load_bz(kind, np.eye(s.d))
+    Es = [-B - 1, -0.8 * B, -0.6 * B, -0.2 * B, 0.1 * B, 0.3 * B, 0.5 * B, 0.7 * B, 0.9 * B, B + 2]
+    got = orc.dos_ggr(s, bz, Es, npt=200)
+    for e, g in zip(Es, got):
+        assert abs(g - exact(e)) < 1e-2, (name, kind, e, g, exact(e))
+
+
+def test_ggr_cache_linearity():
+    # ref: test/dos.jl:114-132 (literal pin: both sides are 0 at E = 0 with npt = 50) and the
+    # non-vacuous form D_{2H}(2E) = D_H(E) / 2
+    h = orc.FourierSeries(np.array([0.5, 0.0, 0.5]).reshape(3, 1, 1), period=1.0, offset=-2, ndim=1)
+    bz = orc.load_bz("FBZ", [[2 * np.pi]])
+    sol1 = orc.dos_ggr(h, bz, [0.0], npt=50)[0]
+    h2 = orc.FourierSeries(2 * h.c, period=1.0, first=h.first, ndim=1)
+    sol2 = orc.dos_ggr(h2, bz, [0.0], npt=50)[0]
+    assert abs(sol1 * 2 - sol2) < 1e-12
+    a = orc.dos_ggr(h, bz, [0.3], npt=100)[0]
+    b = orc.dos_ggr(h2, bz, [0.6], npt=100)[0]
+    assert a > 0 and abs(a / 2 - b) < 1e-12
