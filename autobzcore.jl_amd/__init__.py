@@ -1,0 +1,22 @@
+"""autobzcore.jl_amd -- MI355X-native hot path of AutoBZCore.jl (v0.3.8 API shapes).
+
+Fourier/Wannier interpolation H(k), Hermitian eigensolves and integrand scans run in
+libabzhip.so (hand-written HIP for gfx950, C ABI in include/abzhip.h); this package is the
+host-side mirror of the reference's integrand/algorithm interface for that path.  There is no CPU
+fallback: without the built library and a gfx950 device the compute calls raise.
+"""
+from . import _lib
+from ._lib import AbzError, Context
+from .bz import (FBZ, IBZ, Basis, CubicLimits, CubicSymIBZ, HyperCube, InversionSymIBZ, PuncturedInterval,
+                 SymmetricBZ, TetrahedralLimits, canonical_reciprocal_basis, load_bz, nsyms)
+from .dos import DOSProblem, DOSSolution, GGR
+from . import dos
+from .io_w90 import load_w90_series, read_w90_hrdat
+from .series import DeviceRule, DeviceSeries, FourierSeries, symptr_rule
+from .solver import (IAI, PTR, TAI, AutoPTR, AutoSymPTRJL, AuxQuadGKJL, BatchIntegrand, DOSIntegrand, DeviceIntegrand,
+                     EvalCounter, FourierIntegrand, FourierValue, GlocIntegrand, IntegralProblem, IntegralSolution,
+                     IntegralSolver, LinearIntegrand, LinearXIntegrand, MixedParameters, MonkhorstPack, NestedQuad,
+                     NullParameters, ParameterIntegrand, TrGlocIntegrand, UnitIntegrand, batchparam, batchsolve,
+                     do_solve, init, paramproduct, paramzip, solve, solve_)
+
+__all__ = [n for n in dir() if not n.startswith("_")]

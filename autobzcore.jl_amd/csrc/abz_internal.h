@@ -1,0 +1,197 @@
+// Internal declarations shared by the HIP translation units of libabzhip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <string>
+#include <vector>
+
+#include "../../include/abzhip.h"
+
+namespace abz {
+
+void set_error(const char* fmt, ...);
+
+#define ABZ_HIP(call)                                                                      \
+    do {                                                                                   \
+        hipError_t e_ = (call);                                                            \
+        if (e_ != hipSuccess) {                                                            \
+            abz::set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, \
+                           __LINE__);                                                      \
+            return ABZ_ERR_HIP;                                                            \
+        }                                                                                  \
+    } while (0)
+
+#define ABZ_REQUIRE(cond, ...)            \
+    do {                                  \
+        if (!(cond)) {                    \
+            abz::set_error(__VA_ARGS__);  \
+            return ABZ_ERR_ARG;           \
+        }                                 \
+    } while (0)
+
+// Device buffer that grows but never shrinks (scratch); freed with its owner.
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    int reserve(size_t bytes);
+    void release();
+    template <class T>
+    T* as() const { return static_cast<T*>(p); }
+};
+
+struct ProfSlot {
+    double ms = 0.0;
+    int64_t launches = 0;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
+};
+
+}  // namespace abz
+
+struct abz_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool prof = false;
+    abz::ProfSlot prof_slots[ABZ_K_COUNT];
+    std::vector<hipEvent_t> event_pool;
+    abz::DevBuf scratch[6];  // phases, partials, staging...
+    abz::DevBuf pinned_dummy;
+};
+
+struct abz_series {
+    abz_ctx* ctx = nullptr;
+    int d = 0, n = 0;
+    int dims[ABZ_MAX_DIM] = {1, 1, 1};
+    int first[ABZ_MAX_DIM] = {0, 0, 0};
+    double period[ABZ_MAX_DIM] = {1, 1, 1};
+    double2* coef = nullptr;  // level d: [M_d]...[M_1][n*n] complex, i_1 fastest (Julia order)
+    // pools of contracted coefficient sets: level j (1 <= j < d) holds (j)-dim series of
+    // elems(j) = M_1*...*M_j*n*n complex numbers per slot.
+    abz::DevBuf pool[ABZ_MAX_DIM + 1];      // rule builds / abz_eval_nodes
+    abz::DevBuf iai_pool[ABZ_MAX_DIM + 1];  // IAI: contracted sets per level, slot-addressed
+    int64_t iai_used[ABZ_MAX_DIM + 1] = {0, 0, 0, 0};
+    abz::DevBuf iai_io[6];                  // parents / x / tail / values / phases staging
+    int64_t elems(int level) const {
+        int64_t e = (int64_t)n * n;
+        for (int j = 0; j < level; ++j) e *= dims[j];
+        return e;
+    }
+};
+
+struct abz_rule {
+    abz_series* s = nullptr;
+    int npt = 0, want = 0;
+    int64_t nk = 0;       // number of nodes
+    int64_t stride = 0;   // plane stride (>= nk, multiple of 64)
+    bool full = true;     // full grid (implicit nodes/weights) or explicit irreducible list
+    double* H = nullptr;   // [2*n*n][stride]: plane 2*(a + n*b) + {0: re, 1: im}
+    double* E = nullptr;   // [n][stride]
+    double* V = nullptr;   // [d][n][stride]
+    double* w = nullptr;   // [nk] weights (symmetric rules)
+    int32_t* idx = nullptr;  // [d][nk] grid indices (symmetric rules)
+    void* plan = nullptr;    // abz::RulePlan (api.cpp): contraction plan + phase table, device resident
+};
+
+namespace abz {
+
+// RAII-ish profiling bracket around launches of one logical kernel.
+struct ProfScope {
+    abz_ctx* ctx;
+    int id;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    ProfScope(abz_ctx* c, int kernel_id);
+    ~ProfScope();
+};
+int prof_collect(abz_ctx* ctx);
+
+// ---- launchers (kernels.hip) ------------------------------------------------------------
+// phase table tab[i] = (cos, sin)(2 pi i / npt), computed on the host in long double
+int make_phase_table(abz_ctx* ctx, int npt, DevBuf& buf);
+
+struct PhaseSpec {
+    // phs[b][m] for b < B, m < M.  Grid mode (x == nullptr): grid index gi[b] (or b % npt when
+    // gi == nullptr), phase = tab[(freq * gi) mod npt].  Node mode: phase = exp(2 pi i freq x[b] / period).
+    int64_t B;
+    int M;
+    int first;
+    const int32_t* gi;
+    const double* x;
+    const double2* tab;
+    int npt;
+    double period;
+    bool deriv;  // multiply by i * 2 pi * freq  (d/dx_j * period_j, src/dos_ggr.jl:20,35)
+};
+int launch_phases(abz_ctx* ctx, const PhaseSpec& ps, double2* phs);
+
+// out[b][l] = sum_m phs[b][m] * src[parent(b)][m*L + l];  parent(b) = parents ? parents[b] : b / per_parent
+int launch_contract(abz_ctx* ctx, const double2* src, int64_t src_slot_elems, const int64_t* parents,
+                    int64_t per_parent, const double2* phs, double2* out, int64_t B, int64_t L, int M);
+
+struct EvalSpec {
+    int n;              // bands
+    int M, first;       // innermost dim
+    double period;
+    const double2* src;  // level-1 coefficient sets, slot stride M*n*n
+    // grid mode (full PTR grid): nodes k = line*npt + i1, slot = line
+    bool grid;
+    int npt;
+    int64_t nlines;
+    const double2* tab;
+    // node mode: explicit parents (slot per node), and either grid index gi or coordinate x
+    int64_t nk;
+    const int64_t* parents;
+    const int32_t* gi;
+    const double* x;
+    bool deriv;
+    // outputs (planar, stride), any may be null
+    double* H;
+    double* E;
+    double* U;   // eigenvectors planes [2*n*n][stride] (col-major: plane 2*(a + n*b): component a of vector b)
+    int64_t stride;
+};
+int launch_eval(abz_ctx* ctx, const EvalSpec& es);
+
+int launch_eig_planes(abz_ctx* ctx, int n, const double* H, double* E, double* U, int64_t nk, int64_t stride);
+// V[j][b][k] = Re sum_{a,c} conj(U[a,b]) dH[a,c] U[c,b]
+int launch_velocity(abz_ctx* ctx, int n, const double* U, const double* dH, double* Vj, int64_t nk, int64_t stride);
+
+struct ReduceSpec {
+    int n, d, npt;
+    int integrand;
+    const double* H;
+    const double* E;
+    int64_t nk, stride;
+    const double* w;      // null: uniform weight 1
+    const int32_t* idx;   // null: full grid (k -> grid indices implicitly)
+    double params[4];
+    const double* sweep_dev;  // device [n_sweep]
+    int n_sweep;
+    double scale;
+};
+int integrand_ncomp(int integrand, int n, int d);
+// result: host out_reim [n_sweep][ncomp][2]
+int launch_reduce(abz_ctx* ctx, const ReduceSpec& rs, double* out_reim);
+
+int launch_ggr(abz_ctx* ctx, int n, int d, int npt, const double* E, const double* V, const double* w,
+               int64_t nk, int64_t stride, const double* Es_host, int nE, double* out_host);
+
+// planar [ncomp][stride] -> AoS [nk][ncomp] on the host
+int export_planes(abz_ctx* ctx, const double* planes, int ncomp, int64_t nk, int64_t stride, double* host_out);
+
+// IAI innermost nodes: values[node][ncomp] complex
+struct NodeEvalSpec {
+    int n, d, M, first;
+    double period;
+    const double2* src;
+    const int64_t* parents;  // device
+    const double* x;         // device
+    const double* tail;      // device [nnodes][d-1] or null
+    int64_t nnodes;
+    int integrand;
+    double params[4];
+    double sweep;
+};
+int launch_node_integrand(abz_ctx* ctx, const NodeEvalSpec& ns, double2* values_dev);
+
+}  // namespace abz

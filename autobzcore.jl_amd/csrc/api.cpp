@@ -1,0 +1,777 @@
+// Host side of the C ABI (include/abzhip.h): handles, rule construction plans, exports.
+#include <algorithm>
+#include <cstdarg>
+#include <cstring>
+#include <map>
+#include <numeric>
+
+#include "abz_internal.h"
+
+namespace abz {
+
+static thread_local std::string g_err;
+
+void set_error(const char* fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_err = buf;
+}
+
+int DevBuf::reserve(size_t bytes) {
+    if (bytes <= cap) return ABZ_OK;
+    if (p) {
+        hipError_t e = hipFree(p);
+        p = nullptr;
+        cap = 0;
+        if (e != hipSuccess) {
+            set_error("hipFree failed: %s", hipGetErrorString(e));
+            return ABZ_ERR_HIP;
+        }
+    }
+    size_t want = bytes + (bytes >> 2) + 256;  // grow geometrically
+    hipError_t e = hipMalloc(&p, want);
+    if (e != hipSuccess) {
+        e = hipMalloc(&p, bytes);
+        want = bytes;
+    }
+    if (e != hipSuccess) {
+        p = nullptr;
+        set_error("hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+        return ABZ_ERR_NOMEM;
+    }
+    cap = want;
+    return ABZ_OK;
+}
+
+void DevBuf::release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+}
+
+ProfScope::ProfScope(abz_ctx* c, int kernel_id) : ctx(c), id(kernel_id) {
+    if (!ctx->prof) return;
+    auto get = [&]() {
+        hipEvent_t e = nullptr;
+        if (!ctx->event_pool.empty()) {
+            e = ctx->event_pool.back();
+            ctx->event_pool.pop_back();
+        } else if (hipEventCreate(&e) != hipSuccess) {
+            e = nullptr;
+        }
+        return e;
+    };
+    e0 = get();
+    e1 = get();
+    if (e0) (void)hipEventRecord(e0, ctx->stream);
+}
+
+ProfScope::~ProfScope() {
+    if (!ctx->prof || !e0 || !e1) return;
+    (void)hipEventRecord(e1, ctx->stream);
+    ctx->prof_slots[id].pending.emplace_back(e0, e1);
+}
+
+int prof_collect(abz_ctx* ctx) {
+    for (int i = 0; i < ABZ_K_COUNT; ++i) {
+        auto& sl = ctx->prof_slots[i];
+        for (auto& pr : sl.pending) {
+            ABZ_HIP(hipEventSynchronize(pr.second));
+            float ms = 0.f;
+            ABZ_HIP(hipEventElapsedTime(&ms, pr.first, pr.second));
+            sl.ms += ms;
+            sl.launches += 1;
+            ctx->event_pool.push_back(pr.first);
+            ctx->event_pool.push_back(pr.second);
+        }
+        sl.pending.clear();
+    }
+    return ABZ_OK;
+}
+
+template <class T>
+static int upload(abz_ctx* ctx, DevBuf& buf, const T* host, size_t count) {
+    int rc = buf.reserve(sizeof(T) * std::max<size_t>(count, 1));
+    if (rc) return rc;
+    if (count) {
+        ABZ_HIP(hipMemcpyAsync(buf.p, host, sizeof(T) * count, hipMemcpyHostToDevice, ctx->stream));
+        ABZ_HIP(hipStreamSynchronize(ctx->stream));
+    }
+    return ABZ_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// Evaluation plan: which contracted coefficient sets are needed at every level.
+//   level L (1 <= L < d) items: (grid index or coordinate of variable L+1, parent item at level L+1)
+//   nodes: (grid index / coordinate of variable 1, parent item at level 1)
+// Full grids are implicit (parent = item / npt, grid index = item % npt).
+// ------------------------------------------------------------------------------------------
+struct Plan {
+    int d = 0;
+    bool full = false;
+    bool coords = false;  // explicit coordinates (x) instead of grid indices
+    int npt = 0;
+    int64_t nk = 0;
+    int64_t nitems[ABZ_MAX_DIM + 1] = {0, 0, 0, 0};  // per level 1..d-1
+    std::vector<int32_t> gi[ABZ_MAX_DIM + 1];   // level L: grid index of variable L+1; [0]: nodes' i_1
+    std::vector<double> xs[ABZ_MAX_DIM + 1];    // same with coordinates
+    std::vector<int64_t> parent[ABZ_MAX_DIM + 1];  // level L item -> item at level L+1; [0]: node -> level-1 item
+};
+
+static void plan_full(Plan& p, int d, int npt) {
+    p.d = d;
+    p.full = true;
+    p.npt = npt;
+    p.nk = 1;
+    for (int j = 0; j < d; ++j) p.nk *= npt;
+    for (int L = 1; L < d; ++L) {
+        int64_t c = 1;
+        for (int j = L; j < d; ++j) c *= npt;  // variables L+1..d
+        p.nitems[L] = c;
+    }
+}
+
+// pts: either idx [nk][d] (int32 grid indices) or x [nk][d] (coords).  Consecutive nodes sharing the
+// outer coordinates share the contracted sets (runs); no sorting is done here.
+template <class T>
+static void plan_runs(Plan& p, int d, int npt, const T* pts, int64_t nk, bool coords) {
+    p.d = d;
+    p.full = false;
+    p.coords = coords;
+    p.npt = npt;
+    p.nk = nk;
+    auto push = [&](int L, T v) {
+        if (coords)
+            p.xs[L].push_back((double)v);
+        else
+            p.gi[L].push_back((int32_t)v);
+    };
+    for (int L = 0; L < d; ++L) {
+        p.gi[L].clear();
+        p.xs[L].clear();
+        p.parent[L].clear();
+    }
+    for (int64_t k = 0; k < nk; ++k) {
+        const T* q = pts + k * d;
+        // find the highest level whose tuple (q[L..d-1]) differs from the previous node's
+        int newfrom = 0;  // levels >= newfrom... we create items for levels L where tuple changed
+        if (k == 0) {
+            newfrom = d - 1;
+        } else {
+            const T* r = pts + (k - 1) * d;
+            newfrom = 0;
+            for (int j = d - 1; j >= 1; --j) {
+                if (q[j] != r[j]) {
+                    newfrom = j;
+                    break;
+                }
+            }
+        }
+        // create items top-down for levels L = newfrom .. 1 (level L item fixes variables L+1..d)
+        for (int L = std::min(newfrom, d - 1); L >= 1; --L) {
+            push(L, q[L]);
+            const int64_t par = (L == d - 1) ? 0 : (int64_t)(coords ? p.xs[L + 1].size() : p.gi[L + 1].size()) - 1;
+            p.parent[L].push_back(par);
+        }
+        push(0, q[0]);
+        const int64_t par0 = (d == 1) ? 0 : (int64_t)(coords ? p.xs[1].size() : p.gi[1].size()) - 1;
+        p.parent[0].push_back(par0);
+    }
+    for (int L = 1; L < d; ++L) p.nitems[L] = (int64_t)(coords ? p.xs[L].size() : p.gi[L].size());
+}
+
+struct PlanDev {
+    DevBuf gi[ABZ_MAX_DIM + 1], xs[ABZ_MAX_DIM + 1], parent[ABZ_MAX_DIM + 1];
+    void release() {
+        for (int i = 0; i <= ABZ_MAX_DIM; ++i) {
+            gi[i].release();
+            xs[i].release();
+            parent[i].release();
+        }
+    }
+};
+
+static int plan_upload(abz_ctx* ctx, const Plan& p, PlanDev& pd) {
+    if (p.full) return ABZ_OK;
+    for (int L = 0; L < p.d; ++L) {
+        int rc;
+        if (p.coords)
+            rc = upload(ctx, pd.xs[L], p.xs[L].data(), p.xs[L].size());
+        else
+            rc = upload(ctx, pd.gi[L], p.gi[L].data(), p.gi[L].size());
+        if (rc) return rc;
+        rc = upload(ctx, pd.parent[L], p.parent[L].data(), p.parent[L].size());
+        if (rc) return rc;
+    }
+    return ABZ_OK;
+}
+
+// Build the level-1 coefficient sets for a plan.  deriv_dim (1-based, 0 = none) applies the
+// derivative factor to that variable's phases.  Returns pointer to level-1 sets (or coef if d == 1).
+static int build_chain(abz_series* s, const Plan& p, const PlanDev& pd, const double2* tab, int deriv_dim,
+                       const double2** level1) {
+    abz_ctx* ctx = s->ctx;
+    const int d = s->d;
+    const double2* src = s->coef;
+    int64_t src_elems = s->elems(d);
+    for (int L = d - 1; L >= 1; --L) {
+        // contract variable L+1 (0-based dim index L)
+        const int64_t B = p.nitems[L];
+        const int M = s->dims[L];
+        const int64_t Lrow = s->elems(L);
+        int rc = ctx->scratch[0].reserve(sizeof(double2) * (size_t)std::max<int64_t>(B * M, 1));
+        if (rc) return rc;
+        double2* phs = ctx->scratch[0].as<double2>();
+        PhaseSpec ps;
+        ps.B = B;
+        ps.M = M;
+        ps.first = s->first[L];
+        ps.gi = (p.full || p.coords) ? nullptr : pd.gi[L].as<int32_t>();
+        ps.x = p.coords ? pd.xs[L].as<double>() : nullptr;
+        ps.tab = tab;
+        ps.npt = p.npt;
+        ps.period = s->period[L];
+        ps.deriv = (deriv_dim == L + 1);
+        rc = launch_phases(ctx, ps, phs);
+        if (rc) return rc;
+        rc = s->pool[L].reserve(sizeof(double2) * (size_t)std::max<int64_t>(B * Lrow, 1));
+        if (rc) return rc;
+        double2* out = s->pool[L].as<double2>();
+        const int64_t* parents = p.full ? nullptr : pd.parent[L].as<int64_t>();
+        rc = launch_contract(ctx, src, src_elems, parents, p.full ? p.npt : 1, phs, out, B, Lrow, M);
+        if (rc) return rc;
+        src = out;
+        src_elems = Lrow;
+    }
+    *level1 = src;
+    return ABZ_OK;
+}
+
+static int check_series(const abz_series* s) {
+    if (!s || !s->ctx) {
+        set_error("null series handle");
+        return ABZ_ERR_ARG;
+    }
+    return ABZ_OK;
+}
+
+}  // namespace abz
+
+using namespace abz;
+
+extern "C" {
+
+const char* abz_last_error(void) { return g_err.c_str(); }
+int abz_version(void) { return ABZ_VERSION; }
+
+int abz_device_count(int* n) {
+    int c = 0;
+    hipError_t e = hipGetDeviceCount(&c);
+    if (n) *n = (e == hipSuccess) ? c : 0;
+    if (e != hipSuccess || c == 0) {
+        set_error("no HIP device visible (%s): the product path has no CPU fallback",
+                  e == hipSuccess ? "count = 0" : hipGetErrorString(e));
+        return ABZ_ERR_NOGPU;
+    }
+    return ABZ_OK;
+}
+
+int abz_ctx_create(int device, abz_ctx** out) {
+    ABZ_REQUIRE(out != nullptr, "abz_ctx_create: null out");
+    *out = nullptr;
+    int n = 0;
+    int rc = abz_device_count(&n);
+    if (rc) return rc;
+    ABZ_REQUIRE(device >= 0 && device < n, "device %d out of range (%d visible)", device, n);
+    ABZ_HIP(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    ABZ_HIP(hipGetDeviceProperties(&prop, device));
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        set_error("device %d is %s; this library carries gfx950 code objects only", device, prop.gcnArchName);
+        return ABZ_ERR_NOGPU;
+    }
+    abz_ctx* ctx = new abz_ctx();
+    ctx->device = device;
+    ABZ_HIP(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+    *out = ctx;
+    return ABZ_OK;
+}
+
+int abz_ctx_destroy(abz_ctx* ctx) {
+    if (!ctx) return ABZ_OK;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    for (auto& b : ctx->scratch) b.release();
+    for (auto& sl : ctx->prof_slots)
+        for (auto& pr : sl.pending) {
+            (void)hipEventDestroy(pr.first);
+            (void)hipEventDestroy(pr.second);
+        }
+    for (auto e : ctx->event_pool) (void)hipEventDestroy(e);
+    (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+    return ABZ_OK;
+}
+
+int abz_ctx_sync(abz_ctx* ctx) {
+    ABZ_REQUIRE(ctx, "null ctx");
+    ABZ_HIP(hipStreamSynchronize(ctx->stream));
+    return ABZ_OK;
+}
+
+int abz_prof_enable(abz_ctx* ctx, int on) {
+    ABZ_REQUIRE(ctx, "null ctx");
+    ctx->prof = on != 0;
+    return ABZ_OK;
+}
+
+int abz_prof_reset(abz_ctx* ctx) {
+    ABZ_REQUIRE(ctx, "null ctx");
+    int rc = prof_collect(ctx);
+    for (auto& sl : ctx->prof_slots) {
+        sl.ms = 0;
+        sl.launches = 0;
+    }
+    return rc;
+}
+
+int abz_prof_read(abz_ctx* ctx, int kernel_id, double* total_ms, int64_t* launches) {
+    ABZ_REQUIRE(ctx && kernel_id >= 0 && kernel_id < ABZ_K_COUNT, "bad profile slot");
+    int rc = prof_collect(ctx);
+    if (rc) return rc;
+    if (total_ms) *total_ms = ctx->prof_slots[kernel_id].ms;
+    if (launches) *launches = ctx->prof_slots[kernel_id].launches;
+    return ABZ_OK;
+}
+
+// ---------------------------------------------------------------- series
+int abz_series_create(abz_ctx* ctx, const double* coef_reim, int d, const int32_t* dims, const int32_t* first,
+                      const double* period, int n, abz_series** out) {
+    ABZ_REQUIRE(ctx && coef_reim && dims && first && period && out, "abz_series_create: null argument");
+    ABZ_REQUIRE(d >= 1 && d <= ABZ_MAX_DIM, "series dimension d = %d not in 1..%d", d, ABZ_MAX_DIM);
+    ABZ_REQUIRE(n >= 1 && n <= ABZ_MAX_BANDS, "n = %d bands not in 1..%d", n, ABZ_MAX_BANDS);
+    *out = nullptr;
+    ABZ_HIP(hipSetDevice(ctx->device));
+    abz_series* s = new abz_series();
+    s->ctx = ctx;
+    s->d = d;
+    s->n = n;
+    for (int j = 0; j < d; ++j) {
+        if (dims[j] < 1 || !(period[j] > 0)) {
+            delete s;
+            set_error("dims[%d] = %d / period = %g invalid", j, dims[j], period[j]);
+            return ABZ_ERR_ARG;
+        }
+        s->dims[j] = dims[j];
+        s->first[j] = first[j];
+        s->period[j] = period[j];
+    }
+    const size_t bytes = sizeof(double2) * (size_t)s->elems(d);
+    hipError_t e = hipMalloc((void**)&s->coef, bytes);
+    if (e != hipSuccess) {
+        delete s;
+        set_error("hipMalloc(%zu) for coefficients failed: %s", bytes, hipGetErrorString(e));
+        return ABZ_ERR_NOMEM;
+    }
+    e = hipMemcpy(s->coef, coef_reim, bytes, hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        (void)hipFree(s->coef);
+        delete s;
+        set_error("coefficient upload failed: %s", hipGetErrorString(e));
+        return ABZ_ERR_HIP;
+    }
+    *out = s;
+    return ABZ_OK;
+}
+
+int abz_series_update(abz_series* s, const double* coef_reim) {
+    int rc = check_series(s);
+    if (rc) return rc;
+    ABZ_REQUIRE(coef_reim, "null coefficients");
+    ABZ_HIP(hipSetDevice(s->ctx->device));
+    ABZ_HIP(hipMemcpyAsync(s->coef, coef_reim, sizeof(double2) * (size_t)s->elems(s->d), hipMemcpyHostToDevice,
+                           s->ctx->stream));
+    ABZ_HIP(hipStreamSynchronize(s->ctx->stream));
+    return ABZ_OK;
+}
+
+int abz_series_destroy(abz_series* s) {
+    if (!s) return ABZ_OK;
+    (void)hipSetDevice(s->ctx->device);
+    (void)hipStreamSynchronize(s->ctx->stream);
+    for (auto& b : s->pool) b.release();
+    for (auto& b : s->iai_pool) b.release();
+    if (s->coef) (void)hipFree(s->coef);
+    delete s;
+    return ABZ_OK;
+}
+
+// ---------------------------------------------------------------- rules
+namespace abz {
+struct RulePlan {
+    Plan plan;
+    PlanDev pd;
+    DevBuf tab;
+    DevBuf tmpU, tmpD;  // eigenvector / derivative planes while velocities are built
+};
+}  // namespace abz
+
+static void rule_free(abz_rule* r) {
+    if (!r) return;
+    if (r->H) (void)hipFree(r->H);
+    if (r->E) (void)hipFree(r->E);
+    if (r->V) (void)hipFree(r->V);
+    if (r->w) (void)hipFree(r->w);
+    if (r->idx) (void)hipFree(r->idx);
+    if (r->plan) {
+        RulePlan* rp = static_cast<RulePlan*>(r->plan);
+        rp->pd.release();
+        rp->tab.release();
+        rp->tmpU.release();
+        rp->tmpD.release();
+        delete rp;
+    }
+    delete r;
+}
+
+int abz_rule_destroy(abz_rule* r) {
+    if (!r) return ABZ_OK;
+    (void)hipSetDevice(r->s->ctx->device);
+    (void)hipStreamSynchronize(r->s->ctx->stream);
+    rule_free(r);
+    return ABZ_OK;
+}
+
+// launches only: contraction chain(s) + innermost evaluation (+ velocities)
+static int rule_fill(abz_rule* r) {
+    abz_series* s = r->s;
+    abz_ctx* ctx = s->ctx;
+    RulePlan* rp = static_cast<RulePlan*>(r->plan);
+    const Plan& plan = rp->plan;
+    const int d = s->d, n = s->n;
+    const double2* tab = rp->tab.as<double2>();
+    double* Uplanes = (r->want & ABZ_WANT_VEL) ? rp->tmpU.as<double>() : nullptr;
+    auto run_eval = [&](const double2* level1, bool deriv, double* Hout, double* Eout, double* Uout) -> int {
+        EvalSpec es;
+        es.n = n;
+        es.M = s->dims[0];
+        es.first = s->first[0];
+        es.period = s->period[0];
+        es.src = level1;
+        es.grid = r->full;
+        es.npt = r->npt;
+        es.nlines = r->full ? (d == 1 ? 1 : plan.nitems[1]) : 0;
+        es.tab = tab;
+        es.nk = r->nk;
+        es.parents = r->full ? nullptr : rp->pd.parent[0].as<int64_t>();
+        es.gi = r->full ? nullptr : rp->pd.gi[0].as<int32_t>();
+        es.x = nullptr;
+        es.deriv = deriv;
+        es.H = Hout;
+        es.E = Eout;
+        es.U = Uout;
+        es.stride = r->stride;
+        return launch_eval(ctx, es);
+    };
+    const double2* level1 = nullptr;
+    int rc = build_chain(s, plan, rp->pd, tab, 0, &level1);
+    if (rc) return rc;
+    if ((rc = run_eval(level1, false, r->H, r->E, Uplanes))) return rc;
+    if (r->want & ABZ_WANT_VEL) {
+        // d/dx_1 reuses the level-1 sets; d/dx_j (j >= 2) rebuilds the chain with the derivative
+        // factor on variable j (JacobianSeries, ref src/dos_ggr.jl:6-7)
+        for (int j = 1; j <= d; ++j) {
+            if (j >= 2)
+                if ((rc = build_chain(s, plan, rp->pd, tab, j, &level1))) return rc;
+            if ((rc = run_eval(level1, j == 1, rp->tmpD.as<double>(), nullptr, nullptr))) return rc;
+            if ((rc = launch_velocity(ctx, n, Uplanes, rp->tmpD.as<double>(), r->V + (size_t)(j - 1) * n * r->stride,
+                                      r->nk, r->stride)))
+                return rc;
+        }
+    }
+    return ABZ_OK;
+}
+
+#define RULE_TRY(expr)        \
+    do {                      \
+        int rc_ = (expr);     \
+        if (rc_) {            \
+            rule_free(r);     \
+            return rc_;       \
+        }                     \
+    } while (0)
+#define RULE_HIP(call)                                                                   \
+    do {                                                                                 \
+        hipError_t e_ = (call);                                                          \
+        if (e_ != hipSuccess) {                                                          \
+            set_error("%s failed: %s", #call, hipGetErrorString(e_));                    \
+            rule_free(r);                                                                \
+            return e_ == hipErrorOutOfMemory ? ABZ_ERR_NOMEM : ABZ_ERR_HIP;              \
+        }                                                                                \
+    } while (0)
+
+int abz_ptr_rule_build(abz_series* s, int npt, int64_t nirr, const int32_t* irr_idx, const int64_t* wsym, int want,
+                       abz_rule** out) {
+    int rc = check_series(s);
+    if (rc) return rc;
+    ABZ_REQUIRE(out, "null out");
+    *out = nullptr;
+    ABZ_REQUIRE(npt >= 1, "npt = %d must be positive", npt);
+    ABZ_REQUIRE((want & (ABZ_WANT_H | ABZ_WANT_EIG | ABZ_WANT_VEL)) != 0, "want = %d selects nothing", want);
+    ABZ_REQUIRE((irr_idx == nullptr) == (wsym == nullptr), "irr_idx and wsym must be given together");
+    if (want & ABZ_WANT_VEL) want |= ABZ_WANT_EIG;
+    if (s->n > 4) {
+        set_error("n = %d bands: only n <= 4 is built in this round", s->n);
+        return ABZ_ERR_UNSUPPORTED;
+    }
+    abz_ctx* ctx = s->ctx;
+    ABZ_HIP(hipSetDevice(ctx->device));
+    const int d = s->d, n = s->n;
+    abz_rule* r = new abz_rule();
+    RulePlan* rp = new RulePlan();
+    r->plan = rp;
+    r->s = s;
+    r->npt = npt;
+    r->want = want;
+    r->full = irr_idx == nullptr;
+    Plan& plan = rp->plan;
+    if (r->full) {
+        plan_full(plan, d, npt);
+    } else {
+        for (int64_t k = 0; k < nirr * d; ++k) {
+            if (irr_idx[k] < 0 || irr_idx[k] >= npt) {
+                set_error("irr_idx[%lld] = %d outside the grid", (long long)k, irr_idx[k]);
+                rule_free(r);
+                return ABZ_ERR_ARG;
+            }
+        }
+        plan_runs<int32_t>(plan, d, npt, irr_idx, nirr, false);
+    }
+    r->nk = plan.nk;
+    r->stride = (plan.nk + 63) / 64 * 64;
+    if (r->stride == 0) r->stride = 64;
+    RULE_TRY(plan_upload(ctx, plan, rp->pd));
+    RULE_TRY(make_phase_table(ctx, npt, rp->tab));
+    const size_t plane = sizeof(double) * (size_t)r->stride;
+    if (want & ABZ_WANT_H) RULE_HIP(hipMalloc((void**)&r->H, plane * 2 * n * n));
+    if (want & ABZ_WANT_EIG) RULE_HIP(hipMalloc((void**)&r->E, plane * n));
+    if (want & ABZ_WANT_VEL) RULE_HIP(hipMalloc((void**)&r->V, plane * d * n));
+    if (!r->full) {
+        std::vector<double> wd(std::max<int64_t>(nirr, 1));
+        for (int64_t k = 0; k < nirr; ++k) wd[k] = (double)wsym[k];
+        RULE_HIP(hipMalloc((void**)&r->w, sizeof(double) * wd.size()));
+        RULE_HIP(hipMemcpy(r->w, wd.data(), sizeof(double) * (size_t)nirr, hipMemcpyHostToDevice));
+        std::vector<int32_t> it((size_t)std::max<int64_t>(nirr * d, 1));
+        for (int64_t k = 0; k < nirr; ++k)
+            for (int j = 0; j < d; ++j) it[(size_t)j * nirr + k] = irr_idx[k * d + j];
+        RULE_HIP(hipMalloc((void**)&r->idx, sizeof(int32_t) * it.size()));
+        RULE_HIP(hipMemcpy(r->idx, it.data(), sizeof(int32_t) * (size_t)(nirr * d), hipMemcpyHostToDevice));
+    }
+    if (want & ABZ_WANT_VEL) {
+        RULE_TRY(rp->tmpU.reserve(plane * 2 * n * n));
+        RULE_TRY(rp->tmpD.reserve(plane * 2 * n * n));
+    }
+    RULE_TRY(rule_fill(r));
+    RULE_HIP(hipStreamSynchronize(ctx->stream));
+    if (want & ABZ_WANT_VEL) {  // keep the big temporaries only while a rebuild needs them
+        rp->tmpU.release();
+        rp->tmpD.release();
+    }
+    *out = r;
+    return ABZ_OK;
+}
+#undef RULE_TRY
+#undef RULE_HIP
+
+int abz_rule_rebuild(abz_rule* r) {
+    ABZ_REQUIRE(r && r->plan, "null rule");
+    abz_ctx* ctx = r->s->ctx;
+    ABZ_HIP(hipSetDevice(ctx->device));
+    RulePlan* rp = static_cast<RulePlan*>(r->plan);
+    if (r->want & ABZ_WANT_VEL) {
+        const size_t plane = sizeof(double) * (size_t)r->stride;
+        int rc = rp->tmpU.reserve(plane * 2 * r->s->n * r->s->n);
+        if (rc) return rc;
+        if ((rc = rp->tmpD.reserve(plane * 2 * r->s->n * r->s->n))) return rc;
+    }
+    return rule_fill(r);
+}
+
+int abz_rule_info(const abz_rule* r, int64_t* nk, int* n, int* d, int* npt, int* want) {
+    ABZ_REQUIRE(r, "null rule");
+    if (nk) *nk = r->nk;
+    if (n) *n = r->s->n;
+    if (d) *d = r->s->d;
+    if (npt) *npt = r->npt;
+    if (want) *want = r->want;
+    return ABZ_OK;
+}
+
+int abz_rule_export(abz_rule* r, double* x, double* w, double* H, double* eig, double* vel) {
+    ABZ_REQUIRE(r, "null rule");
+    abz_ctx* ctx = r->s->ctx;
+    ABZ_HIP(hipSetDevice(ctx->device));
+    const int d = r->s->d, n = r->s->n;
+    if (x || w) {
+        std::vector<int32_t> it;
+        std::vector<double> wd;
+        if (!r->full) {
+            it.resize((size_t)(r->nk * d));
+            wd.resize((size_t)r->nk);
+            ABZ_HIP(hipMemcpy(it.data(), r->idx, sizeof(int32_t) * it.size(), hipMemcpyDeviceToHost));
+            ABZ_HIP(hipMemcpy(wd.data(), r->w, sizeof(double) * wd.size(), hipMemcpyDeviceToHost));
+        }
+        for (int64_t k = 0; k < r->nk; ++k) {
+            int64_t rem = k;
+            for (int j = 0; j < d; ++j) {
+                int gi;
+                if (r->full) {
+                    gi = (int)(rem % r->npt);
+                    rem /= r->npt;
+                } else {
+                    gi = it[(size_t)j * r->nk + k];
+                }
+                if (x) x[k * d + j] = (double)gi / (double)r->npt;
+            }
+            if (w) w[k] = r->full ? 1.0 : wd[(size_t)k];
+        }
+    }
+    if (H) {
+        ABZ_REQUIRE(r->H, "rule holds no H(k) (want lacked ABZ_WANT_H)");
+        int rc = export_planes(ctx, r->H, 2 * n * n, r->nk, r->stride, H);
+        if (rc) return rc;
+    }
+    if (eig) {
+        ABZ_REQUIRE(r->E, "rule holds no eigenvalues (want lacked ABZ_WANT_EIG)");
+        int rc = export_planes(ctx, r->E, n, r->nk, r->stride, eig);
+        if (rc) return rc;
+    }
+    if (vel) {
+        ABZ_REQUIRE(r->V, "rule holds no velocities (want lacked ABZ_WANT_VEL)");
+        int rc = export_planes(ctx, r->V, d * n, r->nk, r->stride, vel);
+        if (rc) return rc;
+    }
+    return ABZ_OK;
+}
+
+int abz_rule_reduce(abz_rule* r, int integrand, const double* params, int nparams, const double* sweep, int n_sweep,
+                    int nsyms, double* out_reim) {
+    ABZ_REQUIRE(r && out_reim, "null rule / out");
+    ABZ_REQUIRE(nparams >= 0 && nparams <= 4, "nparams = %d not in 0..4", nparams);
+    ABZ_REQUIRE(nsyms >= 1, "nsyms must be >= 1");
+    abz_ctx* ctx = r->s->ctx;
+    ABZ_HIP(hipSetDevice(ctx->device));
+    const bool use_eig = integrand == ABZ_F_DOS_EIG;
+    if (use_eig)
+        ABZ_REQUIRE(r->E, "integrand needs cached eigenvalues: build the rule with ABZ_WANT_EIG");
+    else if (integrand != ABZ_F_ONE)
+        ABZ_REQUIRE(r->H, "integrand needs cached H(k): build the rule with ABZ_WANT_H");
+    const bool swept = integrand == ABZ_F_DOS || integrand == ABZ_F_TRGLOC || integrand == ABZ_F_GLOC ||
+                       integrand == ABZ_F_DOS_EIG;
+    int ns = swept ? n_sweep : 1;
+    ABZ_REQUIRE(ns >= 1 && (!swept || sweep), "sweep values required for integrand %d", integrand);
+    const int need = (integrand == ABZ_F_LINEAR || integrand == ABZ_F_LINEAR_X) ? 2 : (swept ? 1 : 0);
+    ABZ_REQUIRE(nparams >= need && (need == 0 || params), "integrand %d needs %d parameters", integrand, need);
+    ReduceSpec rs;
+    rs.n = r->s->n;
+    rs.d = r->s->d;
+    rs.npt = r->npt;
+    rs.integrand = integrand;
+    rs.H = r->H ? r->H : r->E;  // ABZ_F_ONE never dereferences it
+    rs.E = r->E;
+    rs.nk = r->nk;
+    rs.stride = r->stride;
+    rs.w = r->w;
+    rs.idx = r->idx;
+    for (int i = 0; i < 4; ++i) rs.params[i] = (i < nparams) ? params[i] : 0.0;
+    rs.n_sweep = ns;
+    rs.sweep_dev = nullptr;
+    if (swept) {
+        int rc = upload(ctx, ctx->scratch[5], sweep, (size_t)ns);
+        if (rc) return rc;
+        rs.sweep_dev = ctx->scratch[5].as<double>();
+    }
+    double vol = 1.0;
+    for (int j = 0; j < rs.d; ++j) vol *= (double)r->npt;
+    rs.scale = 1.0 / (vol * (double)nsyms);
+    return launch_reduce(ctx, rs, out_reim);
+}
+
+int abz_rule_ggr(abz_rule* r, const double* E, int nE, double* out) {
+    ABZ_REQUIRE(r && E && out && nE >= 1, "abz_rule_ggr: bad arguments");
+    ABZ_REQUIRE(r->V && r->E, "GGR needs a rule built with ABZ_WANT_VEL");
+    abz_ctx* ctx = r->s->ctx;
+    ABZ_HIP(hipSetDevice(ctx->device));
+    return launch_ggr(ctx, r->s->n, r->s->d, r->npt, r->E, r->V, r->w, r->nk, r->stride, E, nE, out);
+}
+
+// ---------------------------------------------------------------- arbitrary nodes
+int abz_eval_nodes(abz_series* s, const double* k, int64_t nk, int want, double* H_out, double* eig_out) {
+    int rc = check_series(s);
+    if (rc) return rc;
+    ABZ_REQUIRE(k || nk == 0, "null nodes");
+    ABZ_REQUIRE(nk >= 0, "negative node count");
+    ABZ_REQUIRE(!(want & ABZ_WANT_VEL), "abz_eval_nodes: velocities are only available through PTR rules");
+    ABZ_REQUIRE(!(want & ABZ_WANT_H) || H_out, "want H but H_out is null");
+    ABZ_REQUIRE(!(want & ABZ_WANT_EIG) || eig_out, "want eigenvalues but eig_out is null");
+    if (nk == 0) return ABZ_OK;
+    if (s->n > 4) {
+        set_error("n = %d bands: only n <= 4 is built in this round", s->n);
+        return ABZ_ERR_UNSUPPORTED;
+    }
+    abz_ctx* ctx = s->ctx;
+    ABZ_HIP(hipSetDevice(ctx->device));
+    const int d = s->d, n = s->n;
+    // bound the contracted-set pools: chunk so the largest level stays under ~1 GiB
+    int64_t per = s->elems(d > 1 ? d - 1 : 1) * (int64_t)sizeof(double2);
+    int64_t chunk = std::max<int64_t>(256, std::min<int64_t>(nk, ((int64_t)1 << 30) / std::max<int64_t>(per, 1)));
+    DevBuf Hd, Ed;
+    PlanDev pd;
+    int status = ABZ_OK;
+    for (int64_t k0 = 0; k0 < nk && status == ABZ_OK; k0 += chunk) {
+        const int64_t m = std::min(chunk, nk - k0);
+        const int64_t stride = (m + 63) / 64 * 64;
+        Plan plan;
+        plan_runs<double>(plan, d, 0, k + k0 * d, m, true);
+        if ((status = plan_upload(ctx, plan, pd))) break;
+        const double2* level1 = nullptr;
+        if ((status = build_chain(s, plan, pd, nullptr, 0, &level1))) break;
+        if (want & ABZ_WANT_H)
+            if ((status = Hd.reserve(sizeof(double) * (size_t)stride * 2 * n * n))) break;
+        if (want & ABZ_WANT_EIG)
+            if ((status = Ed.reserve(sizeof(double) * (size_t)stride * n))) break;
+        EvalSpec es;
+        es.n = n;
+        es.M = s->dims[0];
+        es.first = s->first[0];
+        es.period = s->period[0];
+        es.src = level1;
+        es.grid = false;
+        es.npt = 0;
+        es.nlines = 0;
+        es.tab = nullptr;
+        es.nk = m;
+        es.parents = pd.parent[0].as<int64_t>();
+        es.gi = nullptr;
+        es.x = pd.xs[0].as<double>();
+        es.deriv = false;
+        es.H = (want & ABZ_WANT_H) ? Hd.as<double>() : nullptr;
+        es.E = (want & ABZ_WANT_EIG) ? Ed.as<double>() : nullptr;
+        es.U = nullptr;
+        es.stride = stride;
+        if ((status = launch_eval(ctx, es))) break;
+        if (want & ABZ_WANT_H)
+            if ((status = export_planes(ctx, Hd.as<double>(), 2 * n * n, m, stride, H_out + k0 * 2 * n * n))) break;
+        if (want & ABZ_WANT_EIG)
+            if ((status = export_planes(ctx, Ed.as<double>(), n, m, stride, eig_out + k0 * n))) break;
+    }
+    Hd.release();
+    Ed.release();
+    pd.release();
+    return status;
+}
+
+}  // extern "C"

@@ -1,0 +1,538 @@
+// IAI: iterated adaptive integration with the adaptive Gauss-Kronrod loops on the host and every
+// batch of nodes on the GPU.
+//
+// Reference shape (src/fourier.jl:432-510, src/algorithms.jl:215-239): a depth-first recursion in
+// which an outer GK(7,15) node x contracts the Fourier coefficients (workspace_contract!) and
+// launches a complete inner adaptive integral with abstol/len.  Here the same 1-D integrals exist,
+// with the same tolerances and the same scalar refinement rule (pop the worst panel, bisect), but
+// all sibling integrals of one outer round advance in lockstep so that every round is one batched
+// contraction / evaluation launch.  A 1-D integral's decisions depend only on its own node values,
+// so its panel tree is the one the depth-first traversal builds.
+#include <algorithm>
+#include <cmath>
+#include <complex>
+#include <cstring>
+#include <vector>
+
+#include "abz_internal.h"
+
+namespace abz {
+
+typedef std::complex<double> cd;
+
+// Kronrod-15 abscissae on [-1, 0] (QuadGK ordering), weights, embedded Gauss-7 weights (QUADPACK qk15)
+static const double GK_X[8] = {-0.991455371120812639206854697526329, -0.949107912342758524526189684047851,
+                               -0.864864423359769072789712788640926, -0.741531185599394439863864773280788,
+                               -0.586087235467691130294144838258730, -0.405845151377397166906606412076961,
+                               -0.207784955007898467600689403773245, 0.0};
+static const double GK_W[8] = {0.022935322010529224963732008058970, 0.063092092629978553290700663189204,
+                               0.104790010322250183839876322541518, 0.140653259715525918745189590510238,
+                               0.169004726639267902826583426598550, 0.190350578064785409913256402421014,
+                               0.204432940075298892414161999234649, 0.209482141084727828012999174891714};
+static const double GK_GW[4] = {0.129484966168869693270611432679082, 0.279705391489276667901467771423780,
+                                0.381830050505118944950369775488975, 0.417959183673469387755102040816327};
+
+void gk15_nodes(double a, double b, double* x) {
+    const double s = 0.5 * (b - a);
+    for (int i = 0; i < 7; ++i) {
+        x[2 * i] = a + (1 + GK_X[i]) * s;
+        x[2 * i + 1] = a + (1 - GK_X[i]) * s;
+    }
+    x[14] = a + s;
+}
+
+// QuadGK.evalrule for order 7 on one panel: fv [15][ncomp] in gk15_nodes order.
+void gk15_evalrule(const cd* fv, int ncomp, double a, double b, cd* I, double* E) {
+    const double s = 0.5 * (b - a);
+    double e2 = 0.0;
+    for (int c = 0; c < ncomp; ++c) {
+        auto F = [&](int i) { return fv[(size_t)i * ncomp + c]; };
+        cd fg = F(2) + F(3);
+        cd fk = F(0) + F(1);
+        cd Ig = fg * GK_GW[0];
+        cd Ik = fg * GK_W[1] + fk * GK_W[0];
+        for (int i = 2; i < 4; ++i) {
+            fg = F(2 * (2 * i - 1)) + F(2 * (2 * i - 1) + 1);
+            fk = F(2 * (2 * i - 2)) + F(2 * (2 * i - 2) + 1);
+            Ig = Ig + fg * GK_GW[i - 1];
+            Ik = Ik + fg * GK_W[2 * i - 1] + fk * GK_W[2 * i - 2];
+        }
+        const cd f0 = F(14);
+        Ig = Ig + f0 * GK_GW[3];
+        Ik = Ik + f0 * GK_W[7] + (F(12) + F(13)) * GK_W[6];
+        const cd Iks = Ik * s, Igs = Ig * s;
+        I[c] = Iks;
+        e2 += std::norm(Iks - Igs);
+    }
+    *E = std::sqrt(e2);
+}
+
+struct Seg {
+    double a, b, E;
+    int64_t ioff;  // offset of I[ncomp] in the owner's value store
+};
+
+struct Lims {
+    int kind;
+    double a[ABZ_MAX_DIM], b[ABZ_MAX_DIM];
+    double s;
+    void segs(int L, double& lo, double& hi) const {  // range of variable L (1-based)
+        if (kind == ABZ_LIMS_CUBIC) {
+            lo = a[L - 1];
+            hi = b[L - 1];
+        } else {
+            lo = 0.0;
+            hi = a[L - 1] * s;
+        }
+    }
+    Lims fix(int L, double x) const {  // limits of variables 1..L-1 once variable L is fixed
+        Lims r = *this;
+        if (kind == ABZ_LIMS_TETRAHEDRAL) r.s = x / a[L - 1];
+        return r;
+    }
+};
+
+// One adaptive 1-D integral (QuadGK do_quadgk/adapt state with DataStructures heap semantics).
+struct Quad1D {
+    int64_t slot = 0;  // coefficient set of this integral's series
+    double tail[ABZ_MAX_DIM] = {0, 0, 0};  // fixed outer coordinates x_{L+1}.. (tail[0] = x_{L+1})
+    Lims lims;
+    bool has_atol = false;
+    double atol = 0.0, rtol = 0.0;
+    std::vector<Seg> heap;
+    std::vector<cd> store;  // segment integrals, ncomp each
+    std::vector<cd> I;
+    double E = 0.0;
+    int64_t numevals = 0;
+    bool done = false, started = false;
+    // pending work of the current round
+    int npending = 0;
+    Seg pend[2];
+    Seg popped;
+};
+
+static inline bool heap_lt(const Seg& x, const Seg& y) { return y.E < x.E; }  // lt(Reverse, x, y)
+
+static void percolate_down(std::vector<Seg>& xs, size_t i, Seg x, size_t len) {
+    while (true) {
+        const size_t l = 2 * i + 1;
+        if (l >= len) break;
+        const size_t r = l + 1;
+        const size_t j = (r >= len || heap_lt(xs[l], xs[r])) ? l : r;
+        if (!heap_lt(xs[j], x)) break;
+        xs[i] = xs[j];
+        i = j;
+    }
+    xs[i] = x;
+}
+static void percolate_up(std::vector<Seg>& xs, size_t i, Seg x) {
+    while (i > 0) {
+        const size_t j = (i - 1) / 2;
+        if (!heap_lt(x, xs[j])) break;
+        xs[i] = xs[j];
+        i = j;
+    }
+    xs[i] = x;
+}
+static void heapify(std::vector<Seg>& xs) {
+    const size_t n = xs.size();
+    for (size_t i = n / 2; i-- > 0;) percolate_down(xs, i, xs[i], n);
+}
+static void heap_push(std::vector<Seg>& xs, Seg x) {
+    xs.push_back(x);
+    percolate_up(xs, xs.size() - 1, x);
+}
+static Seg heap_pop(std::vector<Seg>& xs) {
+    Seg x = xs[0];
+    Seg y = xs.back();
+    xs.pop_back();
+    if (!xs.empty()) percolate_down(xs, 0, y, xs.size());
+    return x;
+}
+
+static double vnorm(const std::vector<cd>& v) {
+    double s = 0.0;
+    for (auto& z : v) s += std::norm(z);
+    return std::sqrt(s);
+}
+
+struct IaiDriver {
+    abz_series* s;
+    abz_ctx* ctx;
+    int d, n, ncomp, integrand;
+    double params[4];
+    double sweep;
+    bool has_rtol;
+    double rtol_user;
+    int64_t maxevals;
+    int64_t total_evals = 0;
+    std::vector<int64_t> h_parents;
+    std::vector<double> h_x, h_tail;
+    std::vector<cd> h_values;
+
+    double tol_r(const Quad1D& q) const {
+        // quadgk defaults: rtol = (atol > 0 ? 0 : sqrt(eps)) when not given
+        if (has_rtol) return rtol_user;
+        return (q.has_atol && q.atol > 0) ? 0.0 : std::sqrt(2.220446049250313e-16);
+    }
+
+    int contract_nodes(int L, int64_t nn, int64_t base_slot);
+    int eval_nodes(int64_t nn);
+    int solve_level(int L, std::vector<Quad1D>& quads);
+};
+
+// upload h_parents/h_x, contract level-L sets into level-(L-1) pool slots base_slot..base_slot+nn-1
+int IaiDriver::contract_nodes(int L, int64_t nn, int64_t base_slot) {
+    const int M = s->dims[L - 1];
+    const int64_t Lrow = s->elems(L - 1);
+    int rc;
+    if ((rc = s->iai_io[0].reserve(sizeof(int64_t) * (size_t)nn))) return rc;
+    if ((rc = s->iai_io[1].reserve(sizeof(double) * (size_t)nn))) return rc;
+    if ((rc = s->iai_io[4].reserve(sizeof(double2) * (size_t)(nn * M)))) return rc;
+    if ((rc = s->iai_pool[L - 1].reserve(sizeof(double2) * (size_t)((base_slot + nn) * Lrow)))) return rc;
+    ABZ_HIP(hipMemcpyAsync(s->iai_io[0].p, h_parents.data(), sizeof(int64_t) * (size_t)nn, hipMemcpyHostToDevice,
+                           ctx->stream));
+    ABZ_HIP(hipMemcpyAsync(s->iai_io[1].p, h_x.data(), sizeof(double) * (size_t)nn, hipMemcpyHostToDevice, ctx->stream));
+    PhaseSpec ps;
+    ps.B = nn;
+    ps.M = M;
+    ps.first = s->first[L - 1];
+    ps.gi = nullptr;
+    ps.x = s->iai_io[1].as<double>();
+    ps.tab = nullptr;
+    ps.npt = 0;
+    ps.period = s->period[L - 1];
+    ps.deriv = false;
+    if ((rc = launch_phases(ctx, ps, s->iai_io[4].as<double2>()))) return rc;
+    const double2* src = (L == d) ? s->coef : s->iai_pool[L].as<double2>();
+    double2* out = s->iai_pool[L - 1].as<double2>() + base_slot * Lrow;
+    return launch_contract(ctx, src, s->elems(L), s->iai_io[0].as<int64_t>(), 1, s->iai_io[4].as<double2>(), out, nn,
+                           Lrow, M);
+}
+
+// innermost: h_parents / h_x / h_tail -> h_values [nn][ncomp]
+int IaiDriver::eval_nodes(int64_t nn) {
+    int rc;
+    if ((rc = s->iai_io[0].reserve(sizeof(int64_t) * (size_t)nn))) return rc;
+    if ((rc = s->iai_io[1].reserve(sizeof(double) * (size_t)nn))) return rc;
+    if ((rc = s->iai_io[3].reserve(sizeof(double2) * (size_t)(nn * ncomp)))) return rc;
+    ABZ_HIP(hipMemcpyAsync(s->iai_io[0].p, h_parents.data(), sizeof(int64_t) * (size_t)nn, hipMemcpyHostToDevice,
+                           ctx->stream));
+    ABZ_HIP(hipMemcpyAsync(s->iai_io[1].p, h_x.data(), sizeof(double) * (size_t)nn, hipMemcpyHostToDevice, ctx->stream));
+    const bool need_tail = integrand == ABZ_F_LINEAR_X && d > 1;
+    if (need_tail) {
+        if ((rc = s->iai_io[2].reserve(sizeof(double) * (size_t)(nn * (d - 1))))) return rc;
+        ABZ_HIP(hipMemcpyAsync(s->iai_io[2].p, h_tail.data(), sizeof(double) * (size_t)(nn * (d - 1)),
+                               hipMemcpyHostToDevice, ctx->stream));
+    }
+    NodeEvalSpec ns;
+    ns.n = n;
+    ns.d = d;
+    ns.M = s->dims[0];
+    ns.first = s->first[0];
+    ns.period = s->period[0];
+    ns.src = (d == 1) ? s->coef : s->iai_pool[1].as<double2>();
+    ns.parents = s->iai_io[0].as<int64_t>();
+    ns.x = s->iai_io[1].as<double>();
+    ns.tail = need_tail ? s->iai_io[2].as<double>() : nullptr;
+    ns.nnodes = nn;
+    ns.integrand = integrand;
+    for (int i = 0; i < 4; ++i) ns.params[i] = params[i];
+    ns.sweep = sweep;
+    if ((rc = launch_node_integrand(ctx, ns, s->iai_io[3].as<double2>()))) return rc;
+    h_values.resize((size_t)(nn * ncomp));
+    ABZ_HIP(hipMemcpyAsync(h_values.data(), s->iai_io[3].p, sizeof(double2) * (size_t)(nn * ncomp),
+                           hipMemcpyDeviceToHost, ctx->stream));
+    ABZ_HIP(hipStreamSynchronize(ctx->stream));
+    total_evals += nn;
+    return ABZ_OK;
+}
+
+// Run every integral of `quads` (all integrate variable L) to completion.
+int IaiDriver::solve_level(int L, std::vector<Quad1D>& quads) {
+    std::vector<size_t> active;
+    for (size_t i = 0; i < quads.size(); ++i) {
+        Quad1D& q = quads[i];
+        double lo, hi;
+        q.lims.segs(L, lo, hi);
+        q.npending = 1;
+        q.pend[0] = Seg{lo, hi, 0.0, 0};
+        q.started = false;
+        q.done = false;
+        q.I.assign((size_t)ncomp, cd(0, 0));
+        active.push_back(i);
+    }
+    std::vector<cd> vals;      // [node][ncomp] of this round
+    std::vector<Quad1D> kids;  // inner integrals of this round (L > 1)
+    double xs15[15];
+    while (!active.empty()) {
+        // ---- gather the nodes of all pending panels
+        int64_t nn = 0;
+        for (size_t qi : active) nn += 15 * quads[qi].npending;
+        h_parents.resize((size_t)nn);
+        h_x.resize((size_t)nn);
+        if (d > 1) h_tail.resize((size_t)(nn * (d - 1)));
+        int64_t t = 0;
+        for (size_t qi : active) {
+            Quad1D& q = quads[qi];
+            for (int p = 0; p < q.npending; ++p) {
+                gk15_nodes(q.pend[p].a, q.pend[p].b, xs15);
+                for (int i = 0; i < 15; ++i, ++t) {
+                    h_parents[(size_t)t] = q.slot;
+                    h_x[(size_t)t] = xs15[i];
+                    if (d > 1 && L == 1)
+                        for (int j = 0; j < d - 1; ++j) h_tail[(size_t)(t * (d - 1) + j)] = q.tail[j];
+                }
+            }
+        }
+        // ---- evaluate them
+        if (L == 1) {
+            int rc = eval_nodes(nn);
+            if (rc) return rc;
+            vals.assign(h_values.begin(), h_values.end());
+        } else {
+            s->iai_used[L - 1] = 0;  // sets of the previous round are dead
+            int rc = contract_nodes(L, nn, 0);
+            if (rc) return rc;
+            kids.assign((size_t)nn, Quad1D());
+            t = 0;
+            for (size_t qi : active) {
+                Quad1D& q = quads[qi];
+                for (int p = 0; p < q.npending; ++p) {
+                    for (int i = 0; i < 15; ++i, ++t) {
+                        Quad1D& k = kids[(size_t)t];
+                        const double x = h_x[(size_t)t];
+                        k.slot = t;
+                        k.tail[0] = x;
+                        for (int j = 1; j < ABZ_MAX_DIM; ++j) k.tail[j] = q.tail[j - 1];
+                        k.lims = q.lims.fix(L, x);
+                        double lo, hi;
+                        k.lims.segs(L - 1, lo, hi);
+                        const double len = hi - lo;
+                        k.has_atol = q.has_atol;
+                        k.atol = q.has_atol ? q.atol / len : 0.0;  // ref src/fourier.jl:479-480
+                    }
+                }
+            }
+            std::vector<double> save_x;  // solve_level below reuses the staging vectors
+            rc = solve_level(L - 1, kids);
+            if (rc) return rc;
+            vals.resize((size_t)(nn * ncomp));
+            for (int64_t i = 0; i < nn; ++i)
+                for (int c = 0; c < ncomp; ++c) vals[(size_t)(i * ncomp + c)] = kids[(size_t)i].I[(size_t)c];
+        }
+        // ---- deliver: GK sums, heap bookkeeping, next refinement (QuadGK adapt, scalar mode)
+        std::vector<size_t> next;
+        t = 0;
+        std::vector<cd> Iseg((size_t)ncomp);
+        for (size_t qi : active) {
+            Quad1D& q = quads[qi];
+            const double rt = tol_r(q);
+            const double at = q.has_atol ? q.atol : 0.0;
+            Seg got[2];
+            for (int p = 0; p < q.npending; ++p, t += 15) {
+                Seg sg = q.pend[p];
+                gk15_evalrule(&vals[(size_t)(t * ncomp)], ncomp, sg.a, sg.b, Iseg.data(), &sg.E);
+                if (!std::isfinite(sg.E)) {
+                    set_error("IAI: integrand produced a non-finite value in (%g, %g) at level %d", sg.a, sg.b, L);
+                    return ABZ_ERR_ARG;
+                }
+                sg.ioff = (int64_t)q.store.size();
+                q.store.insert(q.store.end(), Iseg.begin(), Iseg.end());
+                got[p] = sg;
+            }
+            if (!q.started) {
+                q.started = true;
+                q.heap.clear();
+                q.heap.push_back(got[0]);
+                for (int c = 0; c < ncomp; ++c) q.I[(size_t)c] = q.store[(size_t)(got[0].ioff + c)];
+                q.E = got[0].E;
+                q.numevals = 15;
+                if (q.E <= std::max(at, rt * vnorm(q.I)) || q.numevals >= maxevals) {
+                    q.done = true;
+                    q.npending = 0;
+                    continue;
+                }
+                heapify(q.heap);
+            } else {
+                for (int c = 0; c < ncomp; ++c)
+                    q.I[(size_t)c] = (q.I[(size_t)c] - q.store[(size_t)(q.popped.ioff + c)]) +
+                                     q.store[(size_t)(got[0].ioff + c)] + q.store[(size_t)(got[1].ioff + c)];
+                q.E = (q.E - q.popped.E) + got[0].E + got[1].E;
+                q.numevals += 30;
+                heap_push(q.heap, got[0]);
+                heap_push(q.heap, got[1]);
+            }
+            if (q.E > std::max(at, rt * vnorm(q.I)) && q.numevals < maxevals) {
+                q.popped = heap_pop(q.heap);
+                const double mid = (q.popped.a + q.popped.b) / 2;
+                q.npending = 2;
+                q.pend[0] = Seg{q.popped.a, mid, 0.0, 0};
+                q.pend[1] = Seg{mid, q.popped.b, 0.0, 0};
+                next.push_back(qi);
+            } else {
+                // re-sum over the heap in storage order (QuadGK does this after adapt)
+                for (int c = 0; c < ncomp; ++c) q.I[(size_t)c] = q.store[(size_t)(q.heap[0].ioff + c)];
+                q.E = q.heap[0].E;
+                for (size_t h = 1; h < q.heap.size(); ++h) {
+                    for (int c = 0; c < ncomp; ++c) q.I[(size_t)c] += q.store[(size_t)(q.heap[h].ioff + c)];
+                    q.E += q.heap[h].E;
+                }
+                q.done = true;
+                q.npending = 0;
+            }
+        }
+        active.swap(next);
+    }
+    return ABZ_OK;
+}
+
+}  // namespace abz
+
+using namespace abz;
+
+extern "C" {
+
+int abz_gk15_nodes(double a, double b, double* x15) {
+    ABZ_REQUIRE(x15, "null output");
+    gk15_nodes(a, b, x15);
+    return ABZ_OK;
+}
+
+int abz_gk15_batch(const double* ab, const double* values_reim, int64_t npanels, int ncomp, double* I_reim, double* E) {
+    ABZ_REQUIRE(ab && values_reim && I_reim && E && npanels >= 0 && ncomp >= 1, "abz_gk15_batch: bad arguments");
+    const cd* fv = reinterpret_cast<const cd*>(values_reim);
+    cd* I = reinterpret_cast<cd*>(I_reim);
+    for (int64_t p = 0; p < npanels; ++p)
+        gk15_evalrule(fv + (size_t)p * 15 * ncomp, ncomp, ab[2 * p], ab[2 * p + 1], I + (size_t)p * ncomp, E + p);
+    return ABZ_OK;
+}
+
+int abz_iai_solve(abz_series* s, int lims_kind, const double* lim_a, const double* lim_b, int integrand,
+                  const double* params, int nparams, double sweep, double abstol, double reltol, int64_t maxevals,
+                  double* out_reim, double* err, int64_t* numevals, double* panels, int64_t max_panels,
+                  int64_t* npanels) {
+    ABZ_REQUIRE(s && s->ctx && lim_a && out_reim, "abz_iai_solve: null argument");
+    ABZ_REQUIRE(lims_kind == ABZ_LIMS_CUBIC || lims_kind == ABZ_LIMS_TETRAHEDRAL, "unknown limits kind %d", lims_kind);
+    ABZ_REQUIRE(lims_kind != ABZ_LIMS_CUBIC || lim_b, "CubicLimits need lim_b");
+    ABZ_REQUIRE(nparams >= 0 && nparams <= 4, "nparams = %d not in 0..4", nparams);
+    if (s->n > 4) {
+        set_error("n = %d bands: only n <= 4 is built in this round", s->n);
+        return ABZ_ERR_UNSUPPORTED;
+    }
+    ABZ_HIP(hipSetDevice(s->ctx->device));
+    IaiDriver drv;
+    drv.s = s;
+    drv.ctx = s->ctx;
+    drv.d = s->d;
+    drv.n = s->n;
+    drv.integrand = integrand;
+    drv.ncomp = integrand_ncomp(integrand, s->n, s->d);
+    ABZ_REQUIRE(drv.ncomp > 0, "unknown integrand id %d", integrand);
+    for (int i = 0; i < 4; ++i) drv.params[i] = (i < nparams && params) ? params[i] : 0.0;
+    drv.sweep = sweep;
+    drv.has_rtol = reltol >= 0;
+    drv.rtol_user = reltol;
+    drv.maxevals = maxevals > 0 ? maxevals : (int64_t)1 << 62;
+    std::vector<Quad1D> top(1);
+    Quad1D& q = top[0];
+    q.slot = 0;
+    q.lims.kind = lims_kind;
+    q.lims.s = 1.0;
+    for (int j = 0; j < s->d; ++j) {
+        q.lims.a[j] = lim_a[j];
+        q.lims.b[j] = lim_b ? lim_b[j] : 0.0;
+    }
+    q.has_atol = abstol >= 0;
+    q.atol = abstol >= 0 ? abstol : 0.0;
+    int rc = drv.solve_level(s->d, top);
+    if (rc) return rc;
+    for (int c = 0; c < drv.ncomp; ++c) {
+        out_reim[2 * c] = top[0].I[(size_t)c].real();
+        out_reim[2 * c + 1] = top[0].I[(size_t)c].imag();
+    }
+    if (err) *err = top[0].E;
+    if (numevals) *numevals = drv.total_evals;
+    if (npanels) *npanels = (int64_t)top[0].heap.size();
+    if (panels) {
+        std::vector<std::pair<double, double>> pn;
+        for (auto& sg : top[0].heap) pn.emplace_back(sg.a, sg.b);
+        std::sort(pn.begin(), pn.end());
+        for (int64_t i = 0; i < (int64_t)pn.size() && i < max_panels; ++i) {
+            panels[2 * i] = pn[(size_t)i].first;
+            panels[2 * i + 1] = pn[(size_t)i].second;
+        }
+    }
+    return ABZ_OK;
+}
+
+// ---- building blocks for a host-language (Julia) adaptive loop -------------------------------
+int abz_contract_nodes(abz_series* s, int src_level, const int64_t* parents, const double* x, int64_t nnodes,
+                       int64_t* slots_out) {
+    ABZ_REQUIRE(s && s->ctx && parents && x && slots_out, "abz_contract_nodes: null argument");
+    ABZ_REQUIRE(src_level >= 2 && src_level <= s->d, "src_level = %d must be in 2..d", src_level);
+    ABZ_HIP(hipSetDevice(s->ctx->device));
+    IaiDriver drv;
+    drv.s = s;
+    drv.ctx = s->ctx;
+    drv.d = s->d;
+    drv.n = s->n;
+    drv.h_parents.assign(parents, parents + nnodes);
+    drv.h_x.assign(x, x + nnodes);
+    const int64_t base = s->iai_used[src_level - 1];
+    // growing the pool must keep earlier slots: reserve with copy
+    const int64_t Lrow = s->elems(src_level - 1);
+    DevBuf& pool = s->iai_pool[src_level - 1];
+    const size_t need = sizeof(double2) * (size_t)((base + nnodes) * Lrow);
+    if (need > pool.cap && base > 0) {
+        DevBuf bigger;
+        int rc = bigger.reserve(need * 2);
+        if (rc) return rc;
+        ABZ_HIP(hipMemcpy(bigger.p, pool.p, sizeof(double2) * (size_t)(base * Lrow), hipMemcpyDeviceToDevice));
+        pool.release();
+        pool = bigger;
+    }
+    int rc = drv.contract_nodes(src_level, nnodes, base);
+    if (rc) return rc;
+    ABZ_HIP(hipStreamSynchronize(s->ctx->stream));
+    for (int64_t i = 0; i < nnodes; ++i) slots_out[i] = base + i;
+    s->iai_used[src_level - 1] = base + nnodes;
+    return ABZ_OK;
+}
+
+int abz_eval_line_nodes(abz_series* s, const int64_t* parents, const double* x, const double* tail, int64_t nnodes,
+                        int integrand, const double* params, int nparams, double sweep, double* values_reim) {
+    ABZ_REQUIRE(s && s->ctx && parents && x && values_reim, "abz_eval_line_nodes: null argument");
+    ABZ_REQUIRE(nparams >= 0 && nparams <= 4, "nparams = %d not in 0..4", nparams);
+    if (s->n > 4) {
+        set_error("n = %d bands: only n <= 4 is built in this round", s->n);
+        return ABZ_ERR_UNSUPPORTED;
+    }
+    ABZ_HIP(hipSetDevice(s->ctx->device));
+    IaiDriver drv;
+    drv.s = s;
+    drv.ctx = s->ctx;
+    drv.d = s->d;
+    drv.n = s->n;
+    drv.integrand = integrand;
+    drv.ncomp = integrand_ncomp(integrand, s->n, s->d);
+    ABZ_REQUIRE(drv.ncomp > 0, "unknown integrand id %d", integrand);
+    ABZ_REQUIRE(integrand != ABZ_F_LINEAR_X || s->d == 1 || tail, "ABZ_F_LINEAR_X needs the outer coordinates (tail)");
+    for (int i = 0; i < 4; ++i) drv.params[i] = (i < nparams && params) ? params[i] : 0.0;
+    drv.sweep = sweep;
+    drv.h_parents.assign(parents, parents + nnodes);
+    drv.h_x.assign(x, x + nnodes);
+    if (tail && s->d > 1) drv.h_tail.assign(tail, tail + nnodes * (s->d - 1));
+    int rc = drv.eval_nodes(nnodes);
+    if (rc) return rc;
+    std::memcpy(values_reim, drv.h_values.data(), sizeof(double2) * (size_t)(nnodes * drv.ncomp));
+    return ABZ_OK;
+}
+
+int abz_release_level(abz_series* s, int level) {
+    ABZ_REQUIRE(s && level >= 1 && level <= s->d, "abz_release_level: bad level");
+    for (int L = 1; L < level && L <= ABZ_MAX_DIM; ++L) s->iai_used[L] = 0;
+    return ABZ_OK;
+}
+
+}  // extern "C"

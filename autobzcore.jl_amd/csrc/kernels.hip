@@ -1,0 +1,974 @@
+// HIP kernels of the hot path, written for gfx950 (MI355X, wave64) only.
+//
+//   phase_kernel      e^{2 pi i f x / t} tables for a batch of nodes            (tiny)
+//   contract_kernel   outer-dimension contraction  C'[b][l] = sum_m ph[b][m] C[parent(b)][m][l]
+//                     = workspace_contract!  (ref src/fourier.jl:152,158,242,252,468,478)
+//   eval_grid_kernel  innermost 1-D series on a full PTR grid, one wavefront per line (i2,i3),
+//                     one lane per node i1, coefficients of the line read through the scalar
+//                     cache (wave-uniform), fused Hermitian eigensolve, planar coalesced stores
+//                     = workspace_evaluate! in fourier_ptr!  (ref src/fourier.jl:132-147)
+//   eval_node_kernel  same at explicit nodes (symmetric rules, IAI panels, BatchIntegrand)
+//   reduce_kernel     sum_k w_k f(H(k); omega_i) for all omega_i of a sweep in one pass over the
+//                     cached rule = quadsum (ref src/fourier.jl:204-207,289-292)
+//   ggr_kernel        GGR formula scan (ref src/dos_ggr.jl:58-104)
+#include "abz_internal.h"
+#include "device_math.h"
+
+#include <cmath>
+
+namespace abz {
+
+static inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// ------------------------------------------------------------------------------------------
+// phases
+// ------------------------------------------------------------------------------------------
+struct PhaseArgs {
+    int64_t B;
+    int M, first, npt, deriv;
+    const int32_t* gi;
+    const double* x;
+    const double2* tab;
+    double inv_period;
+};
+
+__global__ void phase_kernel(PhaseArgs a, double2* __restrict__ phs) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= a.B * a.M) return;
+    const int64_t b = t / a.M;
+    const int m = (int)(t - b * a.M);
+    const int f = a.first + m;
+    double c, s;
+    if (a.x == nullptr) {
+        const int64_t gi = a.gi ? (int64_t)a.gi[b] : (b % a.npt);
+        int64_t fm = f % a.npt;
+        if (fm < 0) fm += a.npt;
+        const double2 ph = a.tab[(fm * gi) % a.npt];
+        c = ph.x;
+        s = ph.y;
+    } else {
+        sincospi(2.0 * ((double)f * a.x[b] * a.inv_period), &s, &c);
+    }
+    if (a.deriv) {
+        const double w = 6.283185307179586476925286766559 * (double)f;
+        const double c2 = -w * s, s2 = w * c;
+        c = c2;
+        s = s2;
+    }
+    phs[t] = make_double2(c, s);
+}
+
+int make_phase_table(abz_ctx* ctx, int npt, DevBuf& buf) {
+    std::vector<double2> tab(npt);
+    const long double twopi = 6.283185307179586476925286766559005768L;
+    for (int i = 0; i < npt; ++i) {
+        // reduce to the first octant-ish range for accuracy: angle = 2 pi i / npt
+        long double ang = twopi * (long double)i / (long double)npt;
+        tab[i] = make_double2((double)cosl(ang), (double)sinl(ang));
+    }
+    int rc = buf.reserve(sizeof(double2) * (size_t)npt);
+    if (rc) return rc;
+    ABZ_HIP(hipMemcpyAsync(buf.p, tab.data(), sizeof(double2) * (size_t)npt, hipMemcpyHostToDevice, ctx->stream));
+    ABZ_HIP(hipStreamSynchronize(ctx->stream));  // tab is a stack-lifetime host vector
+    return ABZ_OK;
+}
+
+int launch_phases(abz_ctx* ctx, const PhaseSpec& ps, double2* phs) {
+    PhaseArgs a;
+    a.B = ps.B;
+    a.M = ps.M;
+    a.first = ps.first;
+    a.npt = ps.npt > 0 ? ps.npt : 1;
+    a.deriv = ps.deriv ? 1 : 0;
+    a.gi = ps.gi;
+    a.x = ps.x;
+    a.tab = ps.tab;
+    a.inv_period = 1.0 / ps.period;
+    const int64_t total = ps.B * ps.M;
+    if (total == 0) return ABZ_OK;
+    hipLaunchKernelGGL(phase_kernel, dim3((unsigned)cdiv(total, 256)), dim3(256), 0, ctx->stream, a, phs);
+    ABZ_HIP(hipGetLastError());
+    return ABZ_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// contraction of the outermost remaining dimension
+// ------------------------------------------------------------------------------------------
+__global__ void contract_kernel(const double2* __restrict__ src, int64_t slot_elems,
+                                const int64_t* __restrict__ parents, int64_t per_parent,
+                                const double2* __restrict__ phs, double2* __restrict__ out, int64_t B,
+                                int64_t L, int M) {
+    const int64_t b = blockIdx.x;
+    const int64_t l = (int64_t)blockIdx.y * blockDim.x + threadIdx.x;
+    if (l >= L) return;
+    const int64_t parent = parents ? parents[b] : (b / per_parent);
+    const double2* __restrict__ s = src + parent * slot_elems + l;
+    const double2* __restrict__ p = phs + b * M;
+    double ar = 0.0, ai = 0.0;
+    for (int m = 0; m < M; ++m) {
+        const double2 c = s[(int64_t)m * L];
+        const double2 ph = p[m];
+        ar = fma(c.x, ph.x, ar);
+        ar = fma(-c.y, ph.y, ar);
+        ai = fma(c.x, ph.y, ai);
+        ai = fma(c.y, ph.x, ai);
+    }
+    out[b * L + l] = make_double2(ar, ai);
+}
+
+int launch_contract(abz_ctx* ctx, const double2* src, int64_t src_slot_elems, const int64_t* parents,
+                    int64_t per_parent, const double2* phs, double2* out, int64_t B, int64_t L, int M) {
+    if (B == 0 || L == 0) return ABZ_OK;
+    ProfScope ps(ctx, ABZ_K_CONTRACT);
+    const int bs = L <= 64 ? 64 : (L <= 128 ? 128 : 256);
+    const int64_t gy = cdiv(L, bs);
+    if (gy > 65535) {
+        set_error("contract: row length %lld too large", (long long)L);
+        return ABZ_ERR_UNSUPPORTED;
+    }
+    hipLaunchKernelGGL(contract_kernel, dim3((unsigned)B, (unsigned)gy), dim3(bs), 0, ctx->stream, src,
+                       src_slot_elems, parents, per_parent > 0 ? per_parent : 1, phs, out, B, L, M);
+    ABZ_HIP(hipGetLastError());
+    return ABZ_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// innermost evaluation
+// ------------------------------------------------------------------------------------------
+// Constant-address-space view of read-only coefficient sets: a wave-uniform address in this address
+// space is fetched through the scalar cache (s_load_dwordx4/x8) and reaches v_fma_f64 as an SGPR
+// operand; a divergent address still becomes an ordinary global_load.  Legal because the sets are
+// written by an EARLIER kernel on the same stream and never inside the kernel that reads them.
+struct cplx_pod {
+    double x, y;
+};
+typedef const cplx_pod __attribute__((address_space(4))) * cptr_t;
+__device__ __forceinline__ cptr_t as_const(const double2* p) {
+    return (cptr_t)(unsigned long long)p;
+}
+
+// H = sum_m c1[m] * (w z^m)  (optionally times i 2 pi f_m).
+template <int N>
+__device__ __forceinline__ void series_lane(cptr_t c1, int M, int first, double zr,
+                                            double zi, double wr, double wi, bool deriv, CMat<N>& H) {
+#pragma unroll
+    for (int a = 0; a < N; ++a) {
+#pragma unroll
+        for (int b = 0; b < N; ++b) {
+            H.re[a][b] = 0.0;
+            H.im[a][b] = 0.0;
+        }
+    }
+    double pr = wr, pi = wi;
+    for (int m = 0; m < M; ++m) {
+        double qr = pr, qi = pi;
+        if (deriv) {
+            const double f = 6.283185307179586476925286766559 * (double)(first + m);
+            qr = -f * pi;
+            qi = f * pr;
+        }
+        cptr_t cm = c1 + (int64_t)m * (N * N);
+#pragma unroll
+        for (int b = 0; b < N; ++b) {
+#pragma unroll
+            for (int a = 0; a < N; ++a) {
+                const double cx = cm[a + N * b].x, cy = cm[a + N * b].y;  // column-major block
+                H.re[a][b] = fma(cx, qr, H.re[a][b]);
+                H.re[a][b] = fma(-cy, qi, H.re[a][b]);
+                H.im[a][b] = fma(cx, qi, H.im[a][b]);
+                H.im[a][b] = fma(cy, qr, H.im[a][b]);
+            }
+        }
+        const double nr = pr * zr - pi * zi;
+        const double ni = pr * zi + pi * zr;
+        pr = nr;
+        pi = ni;
+    }
+}
+
+template <int N>
+__device__ __forceinline__ void store_planes(const CMat<N>& H, double* __restrict__ out, int64_t stride, int64_t k) {
+#pragma unroll
+    for (int b = 0; b < N; ++b) {
+#pragma unroll
+        for (int a = 0; a < N; ++a) {
+            out[(int64_t)(2 * (a + N * b)) * stride + k] = H.re[a][b];
+            out[(int64_t)(2 * (a + N * b) + 1) * stride + k] = H.im[a][b];
+        }
+    }
+}
+
+template <int N>
+__device__ __forceinline__ void load_planes(CMat<N>& H, const double* __restrict__ in, int64_t stride, int64_t k) {
+#pragma unroll
+    for (int b = 0; b < N; ++b) {
+#pragma unroll
+        for (int a = 0; a < N; ++a) {
+            H.re[a][b] = in[(int64_t)(2 * (a + N * b)) * stride + k];
+            H.im[a][b] = in[(int64_t)(2 * (a + N * b) + 1) * stride + k];
+        }
+    }
+}
+
+struct EvalArgs {
+    const double2* src;
+    const double2* tab;
+    const int64_t* parents;
+    const int32_t* gi;
+    const double* x;
+    double* H;
+    double* E;
+    double* U;
+    int64_t nlines, nk, stride;
+    int M, first, npt, deriv;
+    double inv_period;
+};
+
+template <int N>
+__device__ __forceinline__ void eval_epilogue(const EvalArgs& a, CMat<N>& H, int64_t k) {
+    if (a.H) store_planes<N>(H, a.H, a.stride, k);
+    if (a.E || a.U) {
+        double e[N];
+        CMat<N> V;
+        if (a.U) {
+            herm_eig<N, true>(H, e, V);
+            store_planes<N>(V, a.U, a.stride, k);
+        } else {
+            herm_eig<N, false>(H, e, V);
+        }
+        if (a.E) {
+#pragma unroll
+            for (int b = 0; b < N; ++b) a.E[(int64_t)b * a.stride + k] = e[b];
+        }
+    }
+}
+
+// One wavefront per line; lanes sweep i1.  The line's coefficients c1[M][N*N] are addressed with a
+// wave-uniform pointer so the compiler fetches them through the scalar cache (s_load) and the
+// v_fma_f64 stream takes them as SGPR operands: no LDS, no vector-memory traffic for operands.
+template <int N>
+__global__ __launch_bounds__(256) void eval_grid_kernel(EvalArgs a) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    int fm = a.first % a.npt;
+    if (fm < 0) fm += a.npt;
+    for (int64_t line = (int64_t)blockIdx.x * 4 + wave; line < a.nlines; line += (int64_t)gridDim.x * 4) {
+        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)(line & 0xffffffffu));
+        const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)((unsigned long long)line >> 32));
+        const int64_t line_u = (int64_t)(((unsigned long long)hi << 32) | lo);
+        cptr_t c1 = as_const(a.src + line_u * ((int64_t)a.M * N * N));
+        for (int i0 = 0; i0 < a.npt; i0 += 64) {
+            const int i1 = i0 + lane;
+            if (i1 < a.npt) {
+                const double2 z = a.tab[i1];
+                const double2 w = a.tab[(int)(((int64_t)fm * i1) % a.npt)];
+                CMat<N> H;
+                series_lane<N>(c1, a.M, a.first, z.x, z.y, w.x, w.y, a.deriv != 0, H);
+                eval_epilogue<N>(a, H, line_u * a.npt + i1);
+            }
+        }
+    }
+}
+
+template <int N>
+__global__ __launch_bounds__(256) void eval_node_kernel(EvalArgs a) {
+    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= a.nk) return;
+    const int64_t slot = a.parents ? a.parents[k] : 0;
+    cptr_t c1 = as_const(a.src + slot * ((int64_t)a.M * N * N));
+    double zr, zi, wr, wi;
+    if (a.x == nullptr) {
+        const int i1 = a.gi[k];
+        int fm = a.first % a.npt;
+        if (fm < 0) fm += a.npt;
+        const double2 z = a.tab[i1];
+        const double2 w = a.tab[(int)(((int64_t)fm * i1) % a.npt)];
+        zr = z.x;
+        zi = z.y;
+        wr = w.x;
+        wi = w.y;
+    } else {
+        const double xx = a.x[k] * a.inv_period;
+        sincospi(2.0 * xx, &zi, &zr);
+        sincospi(2.0 * ((double)a.first * xx), &wi, &wr);
+    }
+    CMat<N> H;
+    series_lane<N>(c1, a.M, a.first, zr, zi, wr, wi, a.deriv != 0, H);
+    eval_epilogue<N>(a, H, k);
+}
+
+#define ABZ_DISPATCH_N(n, FN)                                       \
+    switch (n) {                                                    \
+        case 1: FN(1); break;                                       \
+        case 2: FN(2); break;                                       \
+        case 3: FN(3); break;                                       \
+        case 4: FN(4); break;                                       \
+        default:                                                    \
+            set_error("n = %d bands: only n <= 4 is built in this round", n); \
+            return ABZ_ERR_UNSUPPORTED;                             \
+    }
+
+int launch_eval(abz_ctx* ctx, const EvalSpec& es) {
+    EvalArgs a;
+    a.src = es.src;
+    a.tab = es.tab;
+    a.parents = es.parents;
+    a.gi = es.gi;
+    a.x = es.x;
+    a.H = es.H;
+    a.E = es.E;
+    a.U = es.U;
+    a.nlines = es.nlines;
+    a.nk = es.nk;
+    a.stride = es.stride;
+    a.M = es.M;
+    a.first = es.first;
+    a.npt = es.npt > 0 ? es.npt : 1;
+    a.deriv = es.deriv ? 1 : 0;
+    a.inv_period = 1.0 / es.period;
+    ProfScope ps(ctx, ABZ_K_EVAL);
+    if (es.grid) {
+        if (es.nlines == 0) return ABZ_OK;
+        const int64_t blocks = std::min<int64_t>(cdiv(es.nlines, 4), 256 * 8);
+#define FN(NN) hipLaunchKernelGGL(eval_grid_kernel<NN>, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, a)
+        ABZ_DISPATCH_N(es.n, FN)
+#undef FN
+    } else {
+        if (es.nk == 0) return ABZ_OK;
+        const int64_t blocks = cdiv(es.nk, 256);
+#define FN(NN) hipLaunchKernelGGL(eval_node_kernel<NN>, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, a)
+        ABZ_DISPATCH_N(es.n, FN)
+#undef FN
+    }
+    ABZ_HIP(hipGetLastError());
+    return ABZ_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// stand-alone eigensolve on planes, velocities
+// ------------------------------------------------------------------------------------------
+template <int N>
+__global__ __launch_bounds__(256) void eig_planes_kernel(const double* __restrict__ Hp, double* __restrict__ E,
+                                                         double* __restrict__ U, int64_t nk, int64_t stride) {
+    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= nk) return;
+    CMat<N> H, V;
+    load_planes<N>(H, Hp, stride, k);
+    double e[N];
+    if (U) {
+        herm_eig<N, true>(H, e, V);
+        store_planes<N>(V, U, stride, k);
+    } else {
+        herm_eig<N, false>(H, e, V);
+    }
+#pragma unroll
+    for (int b = 0; b < N; ++b) E[(int64_t)b * stride + k] = e[b];
+}
+
+int launch_eig_planes(abz_ctx* ctx, int n, const double* H, double* E, double* U, int64_t nk, int64_t stride) {
+    if (nk == 0) return ABZ_OK;
+    ProfScope ps(ctx, ABZ_K_EIG);
+#define FN(NN) hipLaunchKernelGGL(eig_planes_kernel<NN>, dim3((unsigned)cdiv(nk, 256)), dim3(256), 0, ctx->stream, H, E, U, nk, stride)
+    ABZ_DISPATCH_N(n, FN)
+#undef FN
+    ABZ_HIP(hipGetLastError());
+    return ABZ_OK;
+}
+
+template <int N>
+__global__ __launch_bounds__(256) void velocity_kernel(const double* __restrict__ Up, const double* __restrict__ dHp,
+                                                       double* __restrict__ Vj, int64_t nk, int64_t stride) {
+    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= nk) return;
+    CMat<N> U, D;
+    load_planes<N>(U, Up, stride, k);
+    load_planes<N>(D, dHp, stride, k);
+#pragma unroll
+    for (int b = 0; b < N; ++b) {
+        // v_b = Re sum_{a,c} conj(U[a][b]) D[a][c] U[c][b]
+        double v = 0.0;
+#pragma unroll
+        for (int a = 0; a < N; ++a) {
+            double tr = 0.0, ti = 0.0;  // t = sum_c D[a][c] U[c][b]
+#pragma unroll
+            for (int c = 0; c < N; ++c) {
+                tr += D.re[a][c] * U.re[c][b] - D.im[a][c] * U.im[c][b];
+                ti += D.re[a][c] * U.im[c][b] + D.im[a][c] * U.re[c][b];
+            }
+            v += U.re[a][b] * tr + U.im[a][b] * ti;
+        }
+        Vj[(int64_t)b * stride + k] = v;
+    }
+}
+
+int launch_velocity(abz_ctx* ctx, int n, const double* U, const double* dH, double* Vj, int64_t nk, int64_t stride) {
+    if (nk == 0) return ABZ_OK;
+#define FN(NN) hipLaunchKernelGGL(velocity_kernel<NN>, dim3((unsigned)cdiv(nk, 256)), dim3(256), 0, ctx->stream, U, dH, Vj, nk, stride)
+    ABZ_DISPATCH_N(n, FN)
+#undef FN
+    ABZ_HIP(hipGetLastError());
+    return ABZ_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// integrands
+// ------------------------------------------------------------------------------------------
+int integrand_ncomp(int integrand, int n, int d) {
+    switch (integrand) {
+        case ABZ_F_ONE:
+        case ABZ_F_LINEAR:
+        case ABZ_F_DOS:
+        case ABZ_F_TRGLOC:
+        case ABZ_F_DOS_EIG: return 1;
+        case ABZ_F_LINEAR_X: return d;
+        case ABZ_F_GLOC: return n * n;
+        default: return -1;
+    }
+}
+
+constexpr int MAXC = 16;  // max components per integrand value (n <= 4: n*n)
+
+// value of integrand FID at one node; out[c] complex components.
+template <int N, int FID>
+__device__ __forceinline__ void integrand_value(const CMat<N>& H, const double (&e)[N], const double* xk, int d,
+                                                const double* p, double sw, double (&vr)[MAXC], double (&vi)[MAXC]) {
+    if constexpr (FID == ABZ_F_ONE) {
+        vr[0] = 1.0;
+        vi[0] = 0.0;
+    } else if constexpr (FID == ABZ_F_LINEAR) {
+        vr[0] = p[0] * H.re[0][0] + p[1];
+        vi[0] = p[0] * H.im[0][0];
+    } else if constexpr (FID == ABZ_F_LINEAR_X) {
+#pragma unroll
+        for (int j = 0; j < ABZ_MAX_DIM; ++j) {
+            vr[j] = (j < d) ? p[0] * H.re[0][0] * xk[j] + p[1] : 0.0;
+            vi[j] = (j < d) ? p[0] * H.im[0][0] * xk[j] : 0.0;
+        }
+    } else if constexpr (FID == ABZ_F_DOS || FID == ABZ_F_TRGLOC || FID == ABZ_F_GLOC) {
+        CMat<N> G;
+        gloc<N>(H, sw, p[0], G);
+        if constexpr (FID == ABZ_F_GLOC) {
+#pragma unroll
+            for (int b = 0; b < N; ++b) {
+#pragma unroll
+                for (int a = 0; a < N; ++a) {
+                    vr[a + N * b] = G.re[a][b];
+                    vi[a + N * b] = G.im[a][b];
+                }
+            }
+        } else {
+            double tr = 0.0, ti = 0.0;
+#pragma unroll
+            for (int a = 0; a < N; ++a) {
+                tr += G.re[a][a];
+                ti += G.im[a][a];
+            }
+            if constexpr (FID == ABZ_F_DOS) {
+                vr[0] = -ti * 0.31830988618379067153776752674503;  // -Im tr G / pi
+                vi[0] = 0.0;
+            } else {
+                vr[0] = tr;
+                vi[0] = ti;
+            }
+        }
+    } else if constexpr (FID == ABZ_F_DOS_EIG) {
+        double acc = 0.0;
+        const double eta = p[0];
+#pragma unroll
+        for (int b = 0; b < N; ++b) {
+            const double de = sw - e[b];
+            acc += eta / (de * de + eta * eta);
+        }
+        vr[0] = acc * 0.31830988618379067153776752674503;
+        vi[0] = 0.0;
+    }
+}
+
+template <int FID>
+struct NComp {
+    template <int N>
+    static constexpr int value() {
+        return FID == ABZ_F_GLOC ? N * N : (FID == ABZ_F_LINEAR_X ? ABZ_MAX_DIM : 1);
+    }
+};
+
+struct ReduceArgs {
+    const double* H;
+    const double* E;
+    const double* w;
+    const int32_t* idx;
+    const double* sweep;
+    int64_t nk, stride;
+    int d, npt, n_sweep, ncomp;
+    double p[4];
+};
+
+// Block tile = 256 * KT nodes held in registers; loop over the whole sweep; per omega one wave
+// reduction, wave partials parked in LDS, one barrier at the end of each sweep chunk.
+template <int N, int FID, int KT>
+__global__ __launch_bounds__(256) void reduce_kernel(ReduceArgs a, double2* __restrict__ partial) {
+    constexpr int NC = NComp<FID>::template value<N>();
+    extern __shared__ double2 lds[];  // [chunk][4 waves][NC]
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int64_t base = (int64_t)blockIdx.x * (256 * KT);
+    CMat<N> H[KT];
+    double e[KT][N];
+    double wk[KT];
+    double xk[KT][ABZ_MAX_DIM];
+    constexpr bool needH = (FID == ABZ_F_LINEAR || FID == ABZ_F_LINEAR_X || FID == ABZ_F_DOS ||
+                            FID == ABZ_F_TRGLOC || FID == ABZ_F_GLOC);
+#pragma unroll
+    for (int j = 0; j < KT; ++j) {
+        const int64_t k = base + threadIdx.x + 256 * j;
+        const bool ok = k < a.nk;
+        const int64_t kk = ok ? k : 0;
+        wk[j] = ok ? (a.w ? a.w[kk] : 1.0) : 0.0;
+        if constexpr (needH) {
+            load_planes<N>(H[j], a.H, a.stride, kk);
+        }
+        if constexpr (FID == ABZ_F_DOS_EIG) {
+#pragma unroll
+            for (int b = 0; b < N; ++b) e[j][b] = a.E[(int64_t)b * a.stride + kk];
+        }
+        if constexpr (FID == ABZ_F_LINEAR_X) {
+            int64_t r = kk;
+            for (int t = 0; t < a.d; ++t) {
+                int gi;
+                if (a.idx) {
+                    gi = a.idx[(int64_t)t * a.nk + kk];
+                } else {
+                    gi = (int)(r % a.npt);
+                    r /= a.npt;
+                }
+                xk[j][t] = (double)gi / (double)a.npt;
+            }
+        }
+    }
+    const int chunk = 512 / NC;  // sweep values per LDS pass (<= 32 KiB)
+    for (int s0 = 0; s0 < a.n_sweep; s0 += chunk) {
+        const int s1 = min(a.n_sweep, s0 + chunk);
+        for (int s = s0; s < s1; ++s) {
+            const double sw = a.sweep ? a.sweep[s] : 0.0;
+            double ar[NC], ai[NC];
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                ar[c] = 0.0;
+                ai[c] = 0.0;
+            }
+#pragma unroll
+            for (int j = 0; j < KT; ++j) {
+                double vr[MAXC], vi[MAXC];
+                integrand_value<N, FID>(H[j], e[j], xk[j], a.d, a.p, sw, vr, vi);
+#pragma unroll
+                for (int c = 0; c < NC; ++c) {
+                    ar[c] = fma(wk[j], vr[c], ar[c]);
+                    ai[c] = fma(wk[j], vi[c], ai[c]);
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                const double sr = wave_sum(ar[c]);
+                const double si = wave_sum(ai[c]);
+                if (lane == 0) lds[((s - s0) * 4 + wave) * NC + c] = make_double2(sr, si);
+            }
+        }
+        __syncthreads();
+        const int cols = (s1 - s0) * NC;
+        for (int t = threadIdx.x; t < cols; t += 256) {
+            const int s = t / NC, c = t - s * NC;
+            double2 acc = lds[(s * 4 + 0) * NC + c];
+#pragma unroll
+            for (int w2 = 1; w2 < 4; ++w2) {
+                const double2 v = lds[(s * 4 + w2) * NC + c];
+                acc.x += v.x;
+                acc.y += v.y;
+            }
+            if (c < a.ncomp) partial[(int64_t)blockIdx.x * ((int64_t)a.n_sweep * a.ncomp) + (int64_t)(s0 + s) * a.ncomp + c] = acc;
+        }
+        __syncthreads();
+    }
+}
+
+// out[col] = scale * sum_blocks partial[block][col]   (fixed order: reproducible)
+__global__ void final_reduce_kernel(const double2* __restrict__ partial, int64_t nblocks, int64_t ncols,
+                                    double scale, double2* __restrict__ out) {
+    const int64_t col = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (col >= ncols) return;
+    double sr = 0.0, si = 0.0;
+    for (int64_t b = 0; b < nblocks; ++b) {
+        const double2 v = partial[b * ncols + col];
+        sr += v.x;
+        si += v.y;
+    }
+    out[col] = make_double2(sr * scale, si * scale);
+}
+
+template <int N, int FID>
+static int launch_reduce_t(abz_ctx* ctx, const ReduceSpec& rs, const ReduceArgs& a, double2* partial,
+                           int64_t nblocks) {
+    constexpr int KT = (FID == ABZ_F_GLOC || N >= 4) ? 1 : 2;
+    constexpr int NC = NComp<FID>::template value<N>();
+    const int chunk = 512 / NC;
+    const size_t lds = sizeof(double2) * (size_t)std::min(chunk, rs.n_sweep) * 4 * NC;
+    hipLaunchKernelGGL((reduce_kernel<N, FID, KT>), dim3((unsigned)nblocks), dim3(256), lds, ctx->stream, a, partial);
+    return ABZ_OK;
+}
+
+template <int FID>
+static constexpr int reduce_kt(int n) {
+    return (FID == ABZ_F_GLOC || n >= 4) ? 1 : 2;
+}
+
+int launch_reduce(abz_ctx* ctx, const ReduceSpec& rs, double* out_reim) {
+    const int ncomp = integrand_ncomp(rs.integrand, rs.n, rs.d);
+    if (ncomp < 0) {
+        set_error("unknown integrand id %d", rs.integrand);
+        return ABZ_ERR_ARG;
+    }
+    if ((rs.integrand == ABZ_F_LINEAR || rs.integrand == ABZ_F_LINEAR_X) && rs.n != 1) {
+        set_error("ABZ_F_LINEAR(_X) needs a scalar (n = 1) series");
+        return ABZ_ERR_ARG;
+    }
+    ReduceArgs a;
+    a.H = rs.H;
+    a.E = rs.E;
+    a.w = rs.w;
+    a.idx = rs.idx;
+    a.sweep = rs.sweep_dev;
+    a.nk = rs.nk;
+    a.stride = rs.stride;
+    a.d = rs.d;
+    a.npt = rs.npt;
+    a.n_sweep = rs.n_sweep;
+    a.ncomp = ncomp;
+    for (int i = 0; i < 4; ++i) a.p[i] = rs.params[i];
+    int kt = 1;
+    switch (rs.integrand) {
+        case ABZ_F_GLOC: kt = 1; break;
+        default: kt = rs.n >= 4 ? 1 : 2;
+    }
+    const int64_t nblocks = cdiv(rs.nk, 256 * kt);
+    const int64_t ncols = (int64_t)rs.n_sweep * ncomp;
+    int rc = ctx->scratch[1].reserve(sizeof(double2) * (size_t)(nblocks * ncols));
+    if (rc) return rc;
+    rc = ctx->scratch[2].reserve(sizeof(double2) * (size_t)ncols);
+    if (rc) return rc;
+    double2* partial = ctx->scratch[1].as<double2>();
+    double2* outd = ctx->scratch[2].as<double2>();
+    {
+        ProfScope ps(ctx, ABZ_K_REDUCE);
+#define CASE(FID)                                                                   \
+    case FID:                                                                       \
+        switch (rs.n) {                                                             \
+            case 1: launch_reduce_t<1, FID>(ctx, rs, a, partial, nblocks); break;   \
+            case 2: launch_reduce_t<2, FID>(ctx, rs, a, partial, nblocks); break;   \
+            case 3: launch_reduce_t<3, FID>(ctx, rs, a, partial, nblocks); break;   \
+            case 4: launch_reduce_t<4, FID>(ctx, rs, a, partial, nblocks); break;   \
+            default:                                                                \
+                set_error("n = %d bands: only n <= 4 is built in this round", rs.n); \
+                return ABZ_ERR_UNSUPPORTED;                                         \
+        }                                                                           \
+        break;
+        switch (rs.integrand) {
+            CASE(ABZ_F_ONE)
+            CASE(ABZ_F_LINEAR)
+            CASE(ABZ_F_LINEAR_X)
+            CASE(ABZ_F_DOS)
+            CASE(ABZ_F_TRGLOC)
+            CASE(ABZ_F_GLOC)
+            CASE(ABZ_F_DOS_EIG)
+        }
+#undef CASE
+        ABZ_HIP(hipGetLastError());
+        hipLaunchKernelGGL(final_reduce_kernel, dim3((unsigned)cdiv(ncols, 256)), dim3(256), 0, ctx->stream, partial,
+                           nblocks, ncols, rs.scale, outd);
+        ABZ_HIP(hipGetLastError());
+    }
+    ABZ_HIP(hipMemcpyAsync(out_reim, outd, sizeof(double2) * (size_t)ncols, hipMemcpyDeviceToHost, ctx->stream));
+    ABZ_HIP(hipStreamSynchronize(ctx->stream));
+    return ABZ_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// GGR
+// ------------------------------------------------------------------------------------------
+// ref: src/dos_ggr.jl:75-104 (same branch order)
+__device__ __forceinline__ double ggr1(double b, double E, double e, double v1) {
+    v1 = fabs(v1);
+    const double dw = fabs(E - e);
+    return (dw <= b * v1) ? 1.0 / v1 : 0.0;
+}
+__device__ __forceinline__ double ggr2(double b, double E, double e, double va, double vb) {
+    va = fabs(va);
+    vb = fabs(vb);
+    const double v1 = fmax(va, vb), v2 = fmin(va, vb);
+    const double dw = fabs(E - e);
+    const double w1 = b * fabs(v1 - v2), w3 = b * (v1 + v2);
+    if (dw <= w1) return 2.0 * b / v1;
+    if (dw <= w3) return (b * (v1 + v2) - dw) / (v1 * v2);
+    return 0.0;
+}
+__device__ __forceinline__ double ggr3(double b, double E, double e, double va, double vb, double vc) {
+    va = fabs(va);
+    vb = fabs(vb);
+    vc = fabs(vc);
+    const double v1 = fmax(va, fmax(vb, vc));
+    const double v3 = fmin(va, fmin(vb, vc));
+    const double v2 = (va + vb + vc) - v1 - v3;
+    const double dw = fabs(E - e);
+    const double w1 = b * fabs(v1 - v2 - v3);
+    const double w2 = b * (v1 - v2 + v3);
+    const double w3 = b * (v1 + v2 - v3);
+    const double w4 = b * (v1 + v2 + v3);
+    const double vn2 = v1 * v1 + v2 * v2 + v3 * v3;
+    const double p = v1 * v2 * v3;
+    if (v1 >= v2 + v3 && dw <= w1) return 4.0 * b * b / v1;
+    if (v1 <= v2 + v3 && dw <= w1) return (2.0 * b * b * (v1 * v2 + v2 * v3 + v3 * v1) - (dw * dw + vn2 * b * b)) / p;
+    if (w1 <= dw && dw <= w2)
+        return (b * b * (v1 * v2 + 3.0 * v2 * v3 + v3 * v1) - b * dw * (-v1 + v2 + v3) - (dw * dw + vn2 * b * b) * 0.5) / p;
+    if (w2 <= dw && dw <= w3) return 2.0 * b * (b * (v1 + v2) - dw) / (v1 * v2);
+    if (w3 <= dw && dw <= w4) {
+        const double t = b * (v1 + v2 + v3) - dw;
+        return t * t / (2.0 * p);
+    }
+    return 0.0;
+}
+
+struct GgrArgs {
+    const double* E;
+    const double* V;
+    const double* w;
+    const double* Es;
+    int64_t nk, stride;
+    int n, d, nE;
+    double b;
+};
+
+template <int N, int D>
+__global__ __launch_bounds__(256) void ggr_kernel(GgrArgs a, double* __restrict__ partial) {
+    extern __shared__ double ldsd[];  // [nE chunk][4]
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const bool ok = k < a.nk;
+    const int64_t kk = ok ? k : 0;
+    const double wk = ok ? (a.w ? a.w[kk] : 1.0) : 0.0;
+    double e[N];
+    double v[D][N];
+#pragma unroll
+    for (int bnd = 0; bnd < N; ++bnd) {
+        e[bnd] = a.E[(int64_t)bnd * a.stride + kk];
+#pragma unroll
+        for (int j = 0; j < D; ++j) v[j][bnd] = a.V[((int64_t)j * N + bnd) * a.stride + kk];
+    }
+    const int chunk = 1024;
+    for (int s0 = 0; s0 < a.nE; s0 += chunk) {
+        const int s1 = min(a.nE, s0 + chunk);
+        for (int s = s0; s < s1; ++s) {
+            const double En = a.Es[s];
+            double acc = 0.0;
+#pragma unroll
+            for (int bnd = 0; bnd < N; ++bnd) {
+                double f;
+                if constexpr (D == 1)
+                    f = ggr1(a.b, En, e[bnd], v[0][bnd]);
+                else if constexpr (D == 2)
+                    f = ggr2(a.b, En, e[bnd], v[0][bnd], v[1][bnd]);
+                else
+                    f = ggr3(a.b, En, e[bnd], v[0][bnd], v[1][bnd], v[2][bnd]);
+                acc += f;
+            }
+            acc = wave_sum(wk * acc);
+            if (lane == 0) ldsd[(s - s0) * 4 + wave] = acc;
+        }
+        __syncthreads();
+        for (int t = threadIdx.x; t < s1 - s0; t += 256)
+            partial[(int64_t)blockIdx.x * a.nE + s0 + t] = ldsd[t * 4] + ldsd[t * 4 + 1] + ldsd[t * 4 + 2] + ldsd[t * 4 + 3];
+        __syncthreads();
+    }
+}
+
+__global__ void final_reduce_real_kernel(const double* __restrict__ partial, int64_t nblocks, int64_t ncols,
+                                         double* __restrict__ out) {
+    const int64_t col = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (col >= ncols) return;
+    double s = 0.0;
+    for (int64_t b = 0; b < nblocks; ++b) s += partial[b * ncols + col];
+    out[col] = s;
+}
+
+int launch_ggr(abz_ctx* ctx, int n, int d, int npt, const double* E, const double* V, const double* w, int64_t nk,
+               int64_t stride, const double* Es_host, int nE, double* out_host) {
+    if (n > 4) {
+        set_error("GGR: n = %d bands: only n <= 4 is built in this round", n);
+        return ABZ_ERR_UNSUPPORTED;
+    }
+    const int64_t nblocks = cdiv(nk, 256);
+    int rc = ctx->scratch[1].reserve(sizeof(double) * (size_t)(nblocks * nE));
+    if (rc) return rc;
+    rc = ctx->scratch[2].reserve(sizeof(double) * (size_t)nE * 2);
+    if (rc) return rc;
+    double* partial = ctx->scratch[1].as<double>();
+    double* Es_dev = ctx->scratch[2].as<double>();
+    double* outd = Es_dev + nE;
+    ABZ_HIP(hipMemcpyAsync(Es_dev, Es_host, sizeof(double) * (size_t)nE, hipMemcpyHostToDevice, ctx->stream));
+    GgrArgs a;
+    a.E = E;
+    a.V = V;
+    a.w = w;
+    a.Es = Es_dev;
+    a.nk = nk;
+    a.stride = stride;
+    a.n = n;
+    a.d = d;
+    a.nE = nE;
+    a.b = 1.0 / (2.0 * (double)npt);
+    {
+        ProfScope ps(ctx, ABZ_K_GGR);
+        const size_t lds = sizeof(double) * 4 * (size_t)std::min(nE, 1024);
+#define GG(NN, DD) hipLaunchKernelGGL((ggr_kernel<NN, DD>), dim3((unsigned)nblocks), dim3(256), lds, ctx->stream, a, partial)
+#define GD(NN)                     \
+    switch (d) {                   \
+        case 1: GG(NN, 1); break;  \
+        case 2: GG(NN, 2); break;  \
+        default: GG(NN, 3); break; \
+    }
+        switch (n) {
+            case 1: GD(1) break;
+            case 2: GD(2) break;
+            case 3: GD(3) break;
+            default: GD(4) break;
+        }
+#undef GD
+#undef GG
+        ABZ_HIP(hipGetLastError());
+        hipLaunchKernelGGL(final_reduce_real_kernel, dim3((unsigned)cdiv(nE, 256)), dim3(256), 0, ctx->stream, partial,
+                           nblocks, (int64_t)nE, outd);
+        ABZ_HIP(hipGetLastError());
+    }
+    ABZ_HIP(hipMemcpyAsync(out_host, outd, sizeof(double) * (size_t)nE, hipMemcpyDeviceToHost, ctx->stream));
+    ABZ_HIP(hipStreamSynchronize(ctx->stream));
+    return ABZ_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// export planar -> AoS
+// ------------------------------------------------------------------------------------------
+__global__ void export_kernel(const double* __restrict__ planes, int ncomp, int64_t nk, int64_t stride,
+                              double* __restrict__ out) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nk * ncomp) return;
+    const int64_t k = t / ncomp;
+    const int c = (int)(t - k * ncomp);
+    out[t] = planes[(int64_t)c * stride + k];
+}
+
+int export_planes(abz_ctx* ctx, const double* planes, int ncomp, int64_t nk, int64_t stride, double* host_out) {
+    if (nk == 0) return ABZ_OK;
+    const size_t bytes = sizeof(double) * (size_t)nk * ncomp;
+    int rc = ctx->scratch[3].reserve(bytes);
+    if (rc) return rc;
+    double* stg = ctx->scratch[3].as<double>();
+    hipLaunchKernelGGL(export_kernel, dim3((unsigned)cdiv(nk * ncomp, 256)), dim3(256), 0, ctx->stream, planes, ncomp,
+                       nk, stride, stg);
+    ABZ_HIP(hipGetLastError());
+    ABZ_HIP(hipMemcpyAsync(host_out, stg, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    ABZ_HIP(hipStreamSynchronize(ctx->stream));
+    return ABZ_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// IAI innermost nodes: series + integrand, one lane per node
+// ------------------------------------------------------------------------------------------
+struct NodeArgs {
+    const double2* src;
+    const int64_t* parents;
+    const double* x;
+    const double* tail;
+    int64_t nnodes;
+    int M, first, d, ncomp;
+    double inv_period, sweep;
+    double p[4];
+};
+
+template <int N, int FID>
+__global__ __launch_bounds__(256) void node_integrand_kernel(NodeArgs a, double2* __restrict__ values) {
+    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= a.nnodes) return;
+    cptr_t c1 = as_const(a.src + a.parents[k] * ((int64_t)a.M * N * N));
+    const double xx = a.x[k] * a.inv_period;
+    double zr, zi, wr, wi;
+    sincospi(2.0 * xx, &zi, &zr);
+    sincospi(2.0 * ((double)a.first * xx), &wi, &wr);
+    CMat<N> H;
+    series_lane<N>(c1, a.M, a.first, zr, zi, wr, wi, false, H);
+    double e[N];
+    if constexpr (FID == ABZ_F_DOS_EIG) {
+        CMat<N> V;
+        herm_eig<N, false>(H, e, V);
+    }
+    double xk[ABZ_MAX_DIM] = {0.0, 0.0, 0.0};
+    if constexpr (FID == ABZ_F_LINEAR_X) {
+        xk[0] = a.x[k];
+        for (int j = 1; j < a.d; ++j) xk[j] = a.tail[k * (a.d - 1) + (j - 1)];
+    }
+    double vr[MAXC], vi[MAXC];
+    integrand_value<N, FID>(H, e, xk, a.d, a.p, a.sweep, vr, vi);
+    constexpr int NC = NComp<FID>::template value<N>();
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        if (c < a.ncomp) values[k * a.ncomp + c] = make_double2(vr[c], vi[c]);
+    }
+}
+
+int launch_node_integrand(abz_ctx* ctx, const NodeEvalSpec& ns, double2* values_dev) {
+    if (ns.nnodes == 0) return ABZ_OK;
+    const int ncomp = integrand_ncomp(ns.integrand, ns.n, ns.d);
+    if (ncomp < 0) {
+        set_error("unknown integrand id %d", ns.integrand);
+        return ABZ_ERR_ARG;
+    }
+    if ((ns.integrand == ABZ_F_LINEAR || ns.integrand == ABZ_F_LINEAR_X) && ns.n != 1) {
+        set_error("ABZ_F_LINEAR(_X) needs a scalar (n = 1) series");
+        return ABZ_ERR_ARG;
+    }
+    NodeArgs a;
+    a.src = ns.src;
+    a.parents = ns.parents;
+    a.x = ns.x;
+    a.tail = ns.tail;
+    a.nnodes = ns.nnodes;
+    a.M = ns.M;
+    a.first = ns.first;
+    a.d = ns.d;
+    a.ncomp = ncomp;
+    a.inv_period = 1.0 / ns.period;
+    a.sweep = ns.sweep;
+    for (int i = 0; i < 4; ++i) a.p[i] = ns.params[i];
+    ProfScope ps(ctx, ABZ_K_EVAL);
+    const unsigned blocks = (unsigned)cdiv(ns.nnodes, 256);
+#define CASE(FID)                                                                                                  \
+    case FID:                                                                                                      \
+        switch (ns.n) {                                                                                            \
+            case 1: hipLaunchKernelGGL((node_integrand_kernel<1, FID>), dim3(blocks), dim3(256), 0, ctx->stream, a, values_dev); break; \
+            case 2: hipLaunchKernelGGL((node_integrand_kernel<2, FID>), dim3(blocks), dim3(256), 0, ctx->stream, a, values_dev); break; \
+            case 3: hipLaunchKernelGGL((node_integrand_kernel<3, FID>), dim3(blocks), dim3(256), 0, ctx->stream, a, values_dev); break; \
+            case 4: hipLaunchKernelGGL((node_integrand_kernel<4, FID>), dim3(blocks), dim3(256), 0, ctx->stream, a, values_dev); break; \
+            default:                                                                                               \
+                set_error("n = %d bands: only n <= 4 is built in this round", ns.n);                               \
+                return ABZ_ERR_UNSUPPORTED;                                                                        \
+        }                                                                                                          \
+        break;
+    switch (ns.integrand) {
+        CASE(ABZ_F_ONE)
+        CASE(ABZ_F_LINEAR)
+        CASE(ABZ_F_LINEAR_X)
+        CASE(ABZ_F_DOS)
+        CASE(ABZ_F_TRGLOC)
+        CASE(ABZ_F_GLOC)
+        CASE(ABZ_F_DOS_EIG)
+    }
+#undef CASE
+    ABZ_HIP(hipGetLastError());
+    return ABZ_OK;
+}
+
+}  // namespace abz

@@ -1,0 +1,288 @@
+"""Fourier series container + its device-resident twin and cached PTR rules.
+
+Mirrors FourierSeries / FourierWorkspace as the reference uses them (FourierSeriesEvaluators v1
+semantics, ref docs/src/examples.md:26-42, src/fourier.jl:56-86): all arithmetic happens in
+libabzhip.so on the GPU.
+"""
+import ctypes as C
+import weakref
+
+import numpy as np
+
+from . import _lib as L
+
+
+class FourierSeries:
+    """s(x) = sum_i c[i] exp(2 pi i sum_j (i_j + o_j) x_j / t_j), i_j 1-based like Julia.
+
+    `c`: array of shape (M_1..M_d) (scalar series) or (M_1..M_d, n, n) (matrix valued);
+    `period`: scalar or d-tuple; `offset`: FourierSeriesEvaluators' offset (index shift), or give
+    `first` = the integer frequency of c[0] along each dim (an OffsetArray's first axis value).
+    ref: test/dos.jl:114 (`period=, offset=`), test/utils.jl:3-9, aps_example/aps_example.jl:15-27.
+    """
+
+    def __init__(self, c, period=1.0, offset=0, *, first=None, ndim=None):
+        c = np.asarray(c)
+        if ndim is None:
+            ndim = c.ndim - 2 if (c.ndim >= 3 and c.shape[-1] == c.shape[-2]) else c.ndim
+        self.d = int(ndim)
+        if not 1 <= self.d <= 3:
+            raise ValueError("FourierSeries: 1 <= ndim <= 3 supported")
+        self.scalar = c.ndim == self.d
+        if self.scalar:
+            c = c.reshape(c.shape + (1, 1))
+        if c.ndim != self.d + 2 or c.shape[-1] != c.shape[-2]:
+            raise ValueError("coefficient array must be (M_1..M_d) or (M_1..M_d, n, n)")
+        self.c = np.array(c, dtype=np.complex128)
+        self.n = int(c.shape[-1])
+        self.t = tuple(float(p) for p in (period if np.ndim(period) else (period,) * self.d))
+        if first is not None:
+            self.first = tuple(int(v) for v in (first if np.ndim(first) else (first,) * self.d))
+        else:
+            off = offset if np.ndim(offset) else (offset,) * self.d
+            self.first = tuple(int(o) + 1 for o in off)
+        self._dev = {}
+
+    # fields named like the reference (test/dos.jl:122,129)
+    @property
+    def o(self):
+        return tuple(f - 1 for f in self.first)
+
+    @property
+    def dims(self):
+        return self.c.shape[: self.d]
+
+    def invalidate(self):
+        """Drop device copies after mutating `c` in place (ref: DOSCache.isfresh, test/dos.jl:123-124)."""
+        for dev in self._dev.values():
+            dev.close()
+        self._dev = {}
+
+    def device(self, ctx=None):
+        ctx = ctx or L.Context.default()
+        dev = self._dev.get(id(ctx))
+        if dev is None:
+            dev = DeviceSeries(self, ctx)
+            self._dev[id(ctx)] = dev
+        return dev
+
+    def __call__(self, x):
+        """Evaluate at one point (the fallback evaluator, ref src/fourier.jl:120-122)."""
+        v = self.device().eval_nodes(np.atleast_2d(np.asarray(x, dtype=np.float64)))[0]
+        return v
+
+
+def julia_coefficient_order(c, d):
+    """(M_1..M_d, n, n) numpy array -> flat complex array in the reference's memory order
+    (block column-major, i_1 fastest ... i_d slowest)."""
+    axes = tuple(range(d - 1, -1, -1)) + (d + 1, d)
+    return np.ascontiguousarray(np.transpose(c, axes)).reshape(-1)
+
+
+class DeviceSeries:
+    """abz_series handle + cache of device-resident rules keyed by (npt, symmetry set, want)."""
+
+    def __init__(self, s: FourierSeries, ctx):
+        self.s = s
+        self.ctx = ctx
+        flat = julia_coefficient_order(s.c, s.d)
+        buf = np.ascontiguousarray(flat.view(np.float64))
+        _, pbuf = L.f64(buf)
+        dims, pdims = L.i32(np.array(s.dims, dtype=np.int32))
+        first, pfirst = L.i32(np.array(s.first, dtype=np.int32))
+        per, pper = L.f64(np.array(s.t))
+        h = C.c_void_p()
+        L.check(L.lib().abz_series_create(ctx.h, pbuf, s.d, pdims, pfirst, pper, s.n, C.byref(h)))
+        self.h = h
+        self.rules = {}
+        self.rule_bytes = 0
+        self.max_rule_bytes = 96 << 30  # keep rules resident in the 288 GB of HBM, LRU beyond this
+        self._fin = weakref.finalize(self, DeviceSeries._destroy, h, self.rules)
+
+    @staticmethod
+    def _destroy(h, rules):
+        try:
+            for r in list(rules.values()):
+                r.close()
+            rules.clear()
+            if h:
+                L.lib().abz_series_destroy(h)
+        except Exception:
+            pass
+
+    def close(self):
+        self._fin()
+
+    def update(self, c=None):
+        """Upload new coefficients of the same shape (cached rules become stale: rebuild them)."""
+        if c is not None:
+            c = np.asarray(c, dtype=np.complex128)
+            if c.shape != self.s.c.shape:
+                c = c.reshape(self.s.c.shape)
+            self.s.c = np.array(c)
+        buf = np.ascontiguousarray(julia_coefficient_order(self.s.c, self.s.d).view(np.float64))
+        L.check(L.lib().abz_series_update(self.h, buf.ctypes.data_as(L.c_f64p)))
+
+    # ---- arbitrary nodes (BatchIntegrand body / fallback evaluator)
+    def eval_nodes(self, k, want=L.WANT_H):
+        k = np.ascontiguousarray(np.asarray(k, dtype=np.float64).reshape(-1, self.s.d))
+        nk = len(k)
+        n = self.s.n
+        H = np.empty((nk, n * n, 2)) if want & L.WANT_H else None
+        E = np.empty((nk, n)) if want & L.WANT_EIG else None
+        pk = k.ctypes.data_as(L.c_f64p)
+        pH = H.ctypes.data_as(L.c_f64p) if H is not None else None
+        pE = E.ctypes.data_as(L.c_f64p) if E is not None else None
+        L.check(L.lib().abz_eval_nodes(self.h, pk, nk, want, pH, pE))
+        out = []
+        if H is not None:
+            Hc = H.view(np.complex128).reshape(nk, n, n).transpose(0, 2, 1)  # column-major blocks
+            out.append(Hc[:, 0, 0] if self.s.scalar else np.ascontiguousarray(Hc))
+        if E is not None:
+            out.append(E)
+        return out[0] if len(out) == 1 else tuple(out)
+
+    # ---- cached PTR rules
+    def rule(self, npt, syms=None, want=L.WANT_H):
+        key = (int(npt), _syms_key(syms), int(want))
+        r = self.rules.pop(key, None)
+        if r is None:
+            # a cached superset also serves
+            for (n2, s2, w2), r2 in list(self.rules.items()):
+                if n2 == key[0] and s2 == key[1] and (w2 & want) == want:
+                    r = self.rules.pop((n2, s2, w2))
+                    key = (n2, s2, w2)
+                    break
+        if r is None:
+            r = DeviceRule(self, npt, syms, want)
+            self.rule_bytes += r.nbytes
+            while self.rule_bytes > self.max_rule_bytes and self.rules:
+                old_key = next(iter(self.rules))
+                old = self.rules.pop(old_key)
+                self.rule_bytes -= old.nbytes
+                old.close()
+        self.rules[key] = r  # most recently used last
+        return r
+
+    def drop_rules(self):
+        for r in self.rules.values():
+            r.close()
+        self.rules.clear()
+        self.rule_bytes = 0
+
+
+def _syms_key(syms):
+    if syms is None:
+        return None
+    return np.ascontiguousarray(np.rint(np.asarray(syms)).astype(np.int32)).tobytes()
+
+
+def symptr_rule(npt, d, syms):
+    """Irreducible grid nodes (0-based indices, column-major order) and integer weights.
+    ref: AutoSymPTR.symptr_rule as called at src/fourier.jl:271."""
+    S = np.ascontiguousarray(np.rint(np.asarray(syms)).astype(np.int32).reshape(-1, d, d))
+    if not np.allclose(S, np.asarray(syms).reshape(-1, d, d)):
+        raise ValueError("symmetries must be integer matrices in the lattice basis")
+    _, pS = L.i32(S)
+    n = C.c_int64(0)
+    L.check(L.lib().abz_symptr_rule(npt, d, pS, len(S), C.byref(n), None, None))
+    idx = np.empty((n.value, d), dtype=np.int32)
+    w = np.empty(n.value, dtype=np.int64)
+    L.check(L.lib().abz_symptr_rule(npt, d, pS, len(S), C.byref(n), idx.ctypes.data_as(L.c_i32p),
+                                    w.ctypes.data_as(L.c_i64p)))
+    return idx, w
+
+
+class DeviceRule:
+    """abz_rule handle: FourierPTR (syms None) or FourierMonkhorstPack values resident in HBM.
+    ref: src/fourier.jl:127-174,210-277."""
+
+    def __init__(self, dev: DeviceSeries, npt, syms, want):
+        self.dev = dev
+        self.npt = int(npt)
+        self.want = int(want)
+        self.syms = syms
+        self.nsyms = 1 if syms is None else len(syms)
+        h = C.c_void_p()
+        d, n = dev.s.d, dev.s.n
+        if syms is None:
+            L.check(L.lib().abz_ptr_rule_build(dev.h, self.npt, 0, None, None, want, C.byref(h)))
+            self.nk = self.npt ** d
+        else:
+            idx, w = symptr_rule(self.npt, d, syms)
+            L.check(L.lib().abz_ptr_rule_build(dev.h, self.npt, len(w), idx.ctypes.data_as(L.c_i32p),
+                                               w.ctypes.data_as(L.c_i64p), want, C.byref(h)))
+            self.nk = len(w)
+        self.h = h
+        per = (2 * n * n if want & L.WANT_H else 0) + (n if want & (L.WANT_EIG | L.WANT_VEL) else 0) + \
+              (d * n if want & L.WANT_VEL else 0)
+        self.nbytes = 8 * per * self.nk
+        self._fin = weakref.finalize(self, DeviceRule._destroy, h)
+
+    @staticmethod
+    def _destroy(h):
+        try:
+            L.lib().abz_rule_destroy(h)
+        except Exception:
+            pass
+
+    def close(self):
+        self._fin()
+
+    def __len__(self):
+        return self.nk
+
+    def rebuild(self):
+        """Re-evaluate all cached values in place from the series' current coefficients (async)."""
+        L.check(L.lib().abz_rule_rebuild(self.h))
+
+    def reduce(self, fid, params=(), sweep=None, nsyms=None):
+        """(sum_k w_k f(k, H(k); sweep_i)) / (npt^d nsyms) for every sweep value -> complex array
+        [n_sweep, ncomp].  ref: rule(f, B) = quadsum(...), src/fourier.jl:204-207,289-292."""
+        s = self.dev.s
+        ncomp = {L.F_GLOC: s.n * s.n, L.F_LINEAR_X: s.d}.get(fid, 1)
+        params = np.ascontiguousarray(np.asarray(params, dtype=np.float64).reshape(-1))
+        swept = fid in (L.F_DOS, L.F_TRGLOC, L.F_GLOC, L.F_DOS_EIG)
+        if swept:
+            sw = np.ascontiguousarray(np.asarray(sweep, dtype=np.float64).reshape(-1))
+            ns = len(sw)
+            psw = sw.ctypes.data_as(L.c_f64p)
+        else:
+            ns, psw = 1, None
+        out = np.empty((ns, ncomp, 2))
+        pp = params.ctypes.data_as(L.c_f64p) if len(params) else None
+        L.check(L.lib().abz_rule_reduce(self.h, fid, pp, len(params), psw, ns,
+                                        self.nsyms if nsyms is None else nsyms, out.ctypes.data_as(L.c_f64p)))
+        return out.view(np.complex128).reshape(ns, ncomp)
+
+    def export(self, x=True, w=True, H=False, eig=False, vel=False):
+        """Host copies in the reference's layout: x [nk,d], w [nk], H [nk,n,n], eig [nk,n], vel [nk,d,n]."""
+        s = self.dev.s
+        nk, n, d = self.nk, s.n, s.d
+        X = np.empty((nk, d)) if x else None
+        W = np.empty(nk) if w else None
+        Hb = np.empty((nk, n * n, 2)) if H else None
+        E = np.empty((nk, n)) if eig else None
+        V = np.empty((nk, d, n)) if vel else None
+        ptr = lambda a: a.ctypes.data_as(L.c_f64p) if a is not None else None
+        L.check(L.lib().abz_rule_export(self.h, ptr(X), ptr(W), ptr(Hb), ptr(E), ptr(V)))
+        out = {}
+        if x:
+            out["x"] = X
+        if w:
+            out["w"] = W
+        if H:
+            Hc = Hb.view(np.complex128).reshape(nk, n, n).transpose(0, 2, 1)
+            out["H"] = Hc[:, 0, 0] if s.scalar else np.ascontiguousarray(Hc)
+        if eig:
+            out["eig"] = E
+        if vel:
+            out["vel"] = V
+        return out
+
+    def ggr(self, Es):
+        """sum_k w_k sum_bands ggr_formula(1/(2 npt), E, e, v...).  ref: src/dos_ggr.jl:58-65."""
+        Es = np.ascontiguousarray(np.asarray(Es, dtype=np.float64).reshape(-1))
+        out = np.empty(len(Es))
+        L.check(L.lib().abz_rule_ggr(self.h, Es.ctypes.data_as(L.c_f64p), len(Es), out.ctypes.data_as(L.c_f64p)))
+        return out

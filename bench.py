@@ -1,0 +1,208 @@
+#!/usr/bin/env python3
+"""Hot-path benchmark (driver contract: `python bench.py --gpus N --steps K --warmup W`).
+
+Workload (BASELINE.json configs[3] / its per-GPU share, named in `config.workload`): SVO 3-band
+Wannier Hamiltonian (aps_example/svo_hr.dat, 1331 R vectors), full-BZ PTR grid npt^3.
+  Phase A (primary metric, "k-point evals/sec (H(k)+eig)"): one STEP = re-evaluate H(k) and its
+     Hermitian eigenvalues at all npt^3 nodes from the device-resident coefficients into the
+     device-resident rule (abz_rule_rebuild: contract, contract, eval+eig kernels).
+  Phase B (secondary, "DOS(omega) points/sec"): the DOS integrand scan+reduce over the cached rule
+     for this rank's share of the 256-omega sweep (256/8 = 32 per GPU), fused in one pass.
+Multi-GPU: omega sweep sharded round-robin like batchparam (src/interfaces.jl:199-208), every rank
+holds a replica of the coefficients and builds its own rule (no data-path collective), one
+all_gather of the per-rank results => scaling "weak".
+Inputs are resident in HBM when the timed region starts; all timing is bracketed by a barrier and a
+device synchronize on both sides; kernel durations come from HIP events on the library's stream.
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 measured copy)
+
+
+def cpu_baseline(npt_sample, n_omega_sample, s):
+    """Time the C restatement of the reference's CPU path (oracle/abz_oracle.c, kind 'port') on the
+    host cores on a BOUNDED sample of the same workload: the same SVO series on a smaller PTR grid."""
+    lib_path = os.path.join(ROOT, "oracle", "_build", "liboracle.so")
+    if not os.path.exists(lib_path):
+        return None
+    lib = ctypes.CDLL(lib_path)
+    lib.orc_num_threads.restype = ctypes.c_int
+    cores = lib.orc_num_threads()
+    from autobzcore.jl_amd.series import julia_coefficient_order
+    coef = np.ascontiguousarray(julia_coefficient_order(s.c, 3))
+    dims = np.array(s.dims, dtype=np.int32)
+    first = np.array(s.first, dtype=np.int32)
+    nk = npt_sample**3
+    vals = np.empty(nk * 9, dtype=np.complex128)
+    eig = np.empty(nk * 3)
+    P = ctypes.c_void_p
+    args = (coef.ctypes.data_as(P), 3, dims.ctypes.data_as(P), first.ctypes.data_as(P), 3, npt_sample,
+            vals.ctypes.data_as(P), eig.ctypes.data_as(P))
+    lib.orc_fourier_ptr(*args)  # warm-up (page faults, thread pool)
+    t0 = time.perf_counter()
+    reps = 0
+    while reps < 3 or time.perf_counter() - t0 < 6.0:
+        lib.orc_fourier_ptr(*args)
+        reps += 1
+    tA = (time.perf_counter() - t0) / reps
+    omegas = np.linspace(10, 15, n_omega_sample)
+    out = np.empty(n_omega_sample)
+    lib.orc_dos_scan.argtypes = [P, ctypes.c_int64, ctypes.c_int, ctypes.c_double, P, ctypes.c_int, P]
+    t0 = time.perf_counter()
+    lib.orc_dos_scan(vals.ctypes.data_as(P), nk, 3, 0.1, omegas.ctypes.data_as(P), n_omega_sample, out.ctypes.data_as(P))
+    tB = time.perf_counter() - t0
+    return {"value": nk / tA, "unit": "k-point evals/s (H(k)+eig)", "cores": cores, "kind": "port",
+            "sample": f"SVO 3-band, PTR npt={npt_sample} FBZ ({nk} k-points), {reps} reps; "
+                      f"C restatement of the reference loops (not Julia), gcc -O3 -march=native -fopenmp",
+            "dos_kpoint_omega_per_sec": nk * n_omega_sample / tB,
+            "dos_sample": f"{n_omega_sample} omegas over the same {nk} cached H(k)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--npt", type=int, default=150)
+    ap.add_argument("--omegas-per-rank", type=int, default=32)
+    ap.add_argument("--eta", type=float, default=0.1)
+    ap.add_argument("--cpu-npt", type=int, default=64)
+    ap.add_argument("--no-cpu", action="store_true")
+    a = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    import torch
+    import torch.distributed as dist
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the product path has no CPU fallback")
+    torch.cuda.set_device(local)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    import autobzcore.jl_amd as abz
+    from autobzcore.jl_amd import _lib as L
+    ctx = abz.Context(local)
+    abz.Context._default = ctx
+    s = abz.load_w90_series(os.path.join(ROOT, "tests", "golden", "svo_hr.dat.gz"))
+    dev = s.device(ctx)
+    npt = a.npt
+    nk = npt**3
+    rule = dev.rule(npt, None, L.WANT_H | L.WANT_EIG)  # inputs + rule buffers resident before timing
+    # omega sweep: 256 points in [10, 15] eV at 8 GPUs; round-robin shard like batchparam
+    n_total = a.omegas_per_rank * world
+    omegas_all = np.linspace(10.0, 15.0, n_total)
+    mine = omegas_all[rank::world]
+
+    # ---------------- Phase A: K rebuilds
+    for _ in range(a.warmup):
+        rule.rebuild()
+    ctx.sync()
+    ctx.prof_enable(True)
+    ctx.prof_reset()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        rule.rebuild()
+    ctx.sync()
+    barrier()
+    tA = time.perf_counter() - t0
+    eval_ms, eval_n = ctx.prof_read(L.K_EVAL)
+    con_ms, con_n = ctx.prof_read(L.K_CONTRACT)
+    ctx.prof_enable(False)
+
+    # ---------------- Phase B: K fused sweeps over this rank's omegas (matrix-cached, reference-faithful)
+    for _ in range(max(1, a.warmup // 2)):
+        rule.reduce(L.F_DOS, [a.eta], mine)
+    ctx.prof_enable(True)
+    ctx.prof_reset()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        dos = rule.reduce(L.F_DOS, [a.eta], mine)[:, 0].real
+    ctx.sync()
+    barrier()
+    tB = time.perf_counter() - t0
+    red_ms, red_n = ctx.prof_read(L.K_REDUCE)
+    ctx.prof_enable(False)
+    # eigenvalue-cached variant of the same sweep (24 B per k instead of 144 B)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        dos_e = rule.reduce(L.F_DOS_EIG, [a.eta], mine)[:, 0].real
+    ctx.sync()
+    barrier()
+    tBe = time.perf_counter() - t0
+
+    # gather of the sweep (C1: one tiny all_gather) and max-over-ranks timing
+    times = torch.tensor([tA, tB, tBe], dtype=torch.float64, device="cuda")
+    res = torch.tensor(dos, dtype=torch.float64, device="cuda")
+    if world > 1:
+        dist.all_reduce(times, op=dist.ReduceOp.MAX)
+        parts = [torch.empty_like(res) for _ in range(world)]
+        dist.all_gather(parts, res)
+        full = np.empty(n_total)
+        for r, p in enumerate(parts):
+            full[r::world] = p.cpu().numpy()
+    else:
+        full = dos
+    tA, tB, tBe = (float(v) for v in times.cpu())
+    assert np.all(np.isfinite(full)) and np.abs(dos - dos_e).max() < 1e-9 * np.abs(dos).max()
+
+    if rank == 0:
+        n = 3
+        bytes_per_k = 16 * n * n + 8 * n + 16 * n * n * 1331 / nk  # B_A = H out + eig out + coefficients once
+        kps = world * nk * a.steps / tA
+        eval_avg_s = (eval_ms / max(eval_n, 1)) * 1e-3
+        achieved = nk * (16 * n * n + 8 * n) / eval_avg_s / 1e9 if eval_avg_s > 0 else 0.0
+        out = {
+            "metric": "k-point evals/sec (H(k)+eig)", "value": kps, "unit": "k-points/s",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * tA / a.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
+            "data": "synthetic PTR grid over the reference's svo_hr.dat example coefficients (device resident)",
+            "config": {"workload": f"BASELINE configs[3] per-GPU share: SVO 3-band Wannier H(k)+eig on a {npt}^3 PTR grid (FBZ) "
+                                   f"+ fused DOS sweep of {a.omegas_per_rank} omega per GPU (256 at 8 GPUs), eta={a.eta}",
+                       "npt": npt, "nk_per_gpu": nk, "n_bands": 3, "n_R": 1331, "omegas_per_gpu": a.omegas_per_rank,
+                       "parallelism": f"omega-sharded x{world}, coefficient+rule replicas"},
+            "dos_points_per_sec": world * len(mine) * a.steps / tB,
+            "dos_points_per_sec_eigcached": world * len(mine) * a.steps / tBe,
+            "ms_per_sweep": 1e3 * tB / a.steps,
+            "kpoint_omega_per_sec": world * len(mine) * nk * a.steps / tB,
+            "job_seconds_256_omega_est": tA / a.steps + (tB / a.steps) * (256 / max(len(mine) * world, 1)) / 1.0 if world == 1 else None,
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "eval_grid_kernel<3> (Fourier-eval + fused eig)",
+                         "algorithmic_bytes_per_kpoint": 16 * n * n + 8 * n,
+                         "avg_launch_ms": eval_ms / max(eval_n, 1), "launches": eval_n,
+                         "contract_avg_ms": con_ms / max(con_n, 1),
+                         "reduce_avg_ms": red_ms / max(red_n, 1),
+                         "reduce_read_GBs": nk * (16 * n * n) / ((red_ms / max(red_n, 1)) * 1e-3) / 1e9 if red_n else None},
+        }
+        if not a.no_cpu:
+            try:
+                out["cpu_baseline"] = cpu_baseline(a.cpu_npt, 4, s)
+            except Exception as e:  # the baseline never blocks the GPU number
+                out["cpu_baseline"] = {"error": str(e)}
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,187 @@
+/*
+ * abzhip.h -- C ABI of libabzhip.so: the MI355X (gfx950) hot path behind AutoBZCore.jl's
+ * integrand/algorithm dispatch boundary.
+ *
+ * Every entry point is `extern "C"`, takes plain pointers and sizes, and returns an int status
+ * (0 = ok, negative = error; abz_last_error() gives the message).  No C++ exceptions cross the
+ * boundary.  Host arrays are owned by the caller (Julia must GC.@preserve them for the ccall);
+ * device memory lives behind opaque handles owned by the library.  Handles are NOT thread-safe:
+ * use one abz_ctx (one HIP stream) per host thread, like the reference gives every thread its own
+ * workspace and deep-copied solver (src/fourier.jl:60-86, src/interfaces.jl:213).
+ *
+ * Citations `ref:` are file:line into lxvm/AutoBZCore.jl v0.3.8 -- the reference interface each
+ * entry point replaces.  The reference-side binding (Julia ccall shim) is in INTEGRATION.md and
+ * julia/AutoBZCoreHIP.jl.
+ *
+ * Coefficient memory order is the reference's own (Julia, column-major): interleaved (re, im)
+ * doubles; inside one coefficient the n x n block is column-major (row index fastest); blocks are
+ * ordered with i_1 fastest ... i_d slowest, i.e. exactly `Array{SMatrix{n,n,ComplexF64},d}`
+ * (aps_example/aps_example.jl:15-27).  A scalar series is n = 1.
+ */
+#ifndef ABZHIP_H
+#define ABZHIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ABZ_VERSION 100
+
+/* status codes */
+#define ABZ_OK 0
+#define ABZ_ERR_ARG (-1)     /* ref: ArgumentError sites src/fourier.jl:167,267,506 */
+#define ABZ_ERR_HIP (-2)     /* a HIP runtime call failed */
+#define ABZ_ERR_NOGPU (-3)   /* no usable gfx950 device: the product has NO CPU fallback */
+#define ABZ_ERR_UNSUPPORTED (-4)
+#define ABZ_ERR_NOMEM (-5)
+
+#define ABZ_MAX_DIM 3        /* BZ dimension d = 1..3 (ref tests: test/fourier.jl:10,43) */
+#define ABZ_MAX_BANDS 32     /* n x n Hamiltonians up to n = 32 */
+
+typedef struct abz_ctx abz_ctx;       /* device + stream + scratch + profiling */
+typedef struct abz_series abz_series; /* device-resident Fourier coefficients (FourierSeries / FourierWorkspace) */
+typedef struct abz_rule abz_rule;     /* device-resident cached rule values (FourierPTR / FourierMonkhorstPack / GGR data) */
+
+/* what a rule / node evaluation materialises (bit mask) */
+#define ABZ_WANT_H 1    /* series values H(k): FourierValue.s, ref src/fourier.jl:111-114 */
+#define ABZ_WANT_EIG 2  /* ascending eigenvalues of Hermitian(H(k)) (upper triangle), ref src/dos_ggr.jl:19,34 */
+#define ABZ_WANT_VEL 4  /* band velocities Re diag(U' dH/dk_j U) * t_j, ref src/dos_ggr.jl:20,35 (implies EIG) */
+
+/* built-in device integrands f(FourierValue(k, H(k)), params...; sweep) -- the integrands that
+ * appear in the reference's tests, docs and example (user closures cannot cross a C ABI; they get
+ * H(k) batches through abz_rule_export / abz_eval_nodes instead).  Values are complex. */
+#define ABZ_F_ONE 0        /* 1                                   ref test/brillouin.jl:38        ncomp 1  */
+#define ABZ_F_LINEAR 1     /* a*s + b, scalar s = H[1,1]          ref test/fourier.jl:41          ncomp 1; params {a, b} */
+#define ABZ_F_LINEAR_X 2   /* a*s*x .+ b                          ref test/fourier.jl:16          ncomp d; params {a, b} */
+#define ABZ_F_DOS 3        /* -Im tr inv((w+i eta)I - H)/pi       ref aps_example/aps_example.jl:30  ncomp 1; params {eta}; sweep w */
+#define ABZ_F_TRGLOC 4     /* tr inv((w+i eta)I - H)              ref docs/src/examples.md:21    ncomp 1; params {eta}; sweep w */
+#define ABZ_F_GLOC 5       /* inv((w+i eta)I - H)  (n x n, col-major) ref docs/src/examples.md:90  ncomp n*n; params {eta}; sweep w */
+#define ABZ_F_DOS_EIG 6    /* (eta/pi) sum_b 1/((w-e_b)^2+eta^2) from cached eigenvalues == ABZ_F_DOS  ncomp 1 */
+
+/* iterated limits for IAI (ref: src/brillouin.jl:2-5,267,304) */
+#define ABZ_LIMS_CUBIC 0        /* CubicLimits(a, b) */
+#define ABZ_LIMS_TETRAHEDRAL 1  /* TetrahedralLimits(a): 0 <= x_1 <= ... <= x_d <= a_d (scaled) */
+
+/* profiled kernels (abz_prof_read) */
+#define ABZ_K_CONTRACT 0   /* outer-dimension contraction (workspace_contract!)      */
+#define ABZ_K_EVAL 1       /* innermost 1-D evaluation (+ fused eig)  (workspace_evaluate!) -- the Fourier-eval kernel */
+#define ABZ_K_REDUCE 2     /* integrand scan + reduce over a cached rule (quadsum)   */
+#define ABZ_K_GGR 3        /* GGR formula scan (sum_ggr)                             */
+#define ABZ_K_EIG 4        /* stand-alone Hermitian eigensolve                        */
+#define ABZ_K_COUNT 8
+
+/* ---------------------------------------------------------------- library / context */
+const char* abz_last_error(void);
+int abz_version(void);
+/* Number of visible HIP devices; ABZ_ERR_NOGPU (and *n = 0) if there is none. */
+int abz_device_count(int* n);
+/* One context per host thread / rank: binds `device`, creates its stream. */
+int abz_ctx_create(int device, abz_ctx** out);
+int abz_ctx_destroy(abz_ctx* ctx);
+int abz_ctx_sync(abz_ctx* ctx);
+/* HIP-event timing of the library's own launches on the context's stream. */
+int abz_prof_enable(abz_ctx* ctx, int on);
+int abz_prof_reset(abz_ctx* ctx);
+int abz_prof_read(abz_ctx* ctx, int kernel_id, double* total_ms, int64_t* launches);
+
+/* ---------------------------------------------------------------- series
+ * Replaces: FourierSeries(c; period, offset) + workspace_allocate_vec (src/fourier.jl:56-86).
+ * dims[j] = M_j, first[j] = integer frequency of the first coefficient along dim j
+ * (= 1 + offset_j of FourierSeriesEvaluators, or the OffsetArray's first axis value),
+ * s(x) = sum_i c[i] exp(2 pi i sum_j (first_j + i_j) x_j / period_j), i_j = 0..M_j-1. */
+int abz_series_create(abz_ctx* ctx, const double* coef_reim, int d, const int32_t* dims,
+                      const int32_t* first, const double* period, int n, abz_series** out);
+int abz_series_destroy(abz_series* s);
+/* Replace the coefficients in place (same shape).  Replaces: mutating `h.c` / assigning cache.H
+ * (test/dos.jl:122-129); rules built from the series become stale until abz_rule_rebuild. */
+int abz_series_update(abz_series* s, const double* coef_reim);
+
+/* ---------------------------------------------------------------- arbitrary nodes
+ * Replaces: the fallback evaluator f.w(x) (src/fourier.jl:120-122) and the body of a
+ * BatchIntegrand f!(y, x, p) (src/batch.jl:1-38) for FourierValue batches.
+ * k is [nk][d] (x_1 first).  Outputs (host, nullable per `want`):
+ *   H_out   [nk][n*n][2]  column-major blocks (reference layout)
+ *   eig_out [nk][n]
+ * Evaluation is hierarchical when nodes share outer coordinates; results do not depend on it. */
+int abz_eval_nodes(abz_series* s, const double* k, int64_t nk, int want, double* H_out,
+                   double* eig_out);
+
+/* ---------------------------------------------------------------- PTR rules
+ * Replaces: FourierPTR ctor + fourier_ptr! (src/fourier.jl:132-174), FourierMonkhorstPack ctor +
+ * _fourier_symptr! (:216-277), nextrule (:315-321), and get_ggr_data (src/dos_ggr.jl:14-44).
+ * Full grid:  irr_idx = wsym = NULL, nirr = 0  -> nodes are all npt^d grid points, i_1 fastest.
+ * Symmetric:  irr_idx [nirr][d] 0-based grid indices in column-major order and their integer
+ *             weights wsym [nirr] (from abz_symptr_rule).
+ * The values stay resident in HBM (planar layout). */
+int abz_ptr_rule_build(abz_series* s, int npt, int64_t nirr, const int32_t* irr_idx,
+                       const int64_t* wsym, int want, abz_rule** out);
+int abz_rule_destroy(abz_rule* r);
+/* Re-evaluate every cached value of the rule from the series' current coefficients, in place and
+ * without host synchronisation (launches only).  Replaces: the re-init of a stale cache,
+ * solve!(::DOSCache) with isfresh (src/dos_interfaces.jl:104-109), and nextrule rebuilding a grid
+ * (src/fourier.jl:315-321) when the buffers can be reused. */
+int abz_rule_rebuild(abz_rule* r);
+int abz_rule_info(const abz_rule* r, int64_t* nk, int* n, int* d, int* npt, int* want);
+/* Copy rule contents to the host in the reference's layout (any pointer may be NULL):
+ *   x [nk][d], w [nk] (1 on a full grid), H [nk][n*n][2], eig [nk][n], vel [nk][d][n]. */
+int abz_rule_export(abz_rule* r, double* x, double* w, double* H, double* eig, double* vel);
+
+/* Replaces: rule(f, B) = quadsum(AffineQuad(rule, B), f, vol/N) (src/fourier.jl:204-207,289-292)
+ * for a built-in integrand, for n_sweep parameter values in one pass (batchsolve's omega sweep,
+ * src/interfaces.jl:210-222, fused).  out_reim [n_sweep][ncomp][2] receives
+ *   (sum_k w_k f(k, H(k); sweep_i)) / (npt^d * nsyms)        (nsyms = 1 on a full grid)
+ * -- the caller applies |det B| and symmetrisation like do_solve_autobz (src/brillouin.jl:337-355). */
+int abz_rule_reduce(abz_rule* r, int integrand, const double* params, int nparams,
+                    const double* sweep, int n_sweep, int nsyms, double* out_reim);
+
+/* Replaces: sum_ggr / ggr_formula (src/dos_ggr.jl:58-104) for nE energies; rule must hold VEL. */
+int abz_rule_ggr(abz_rule* r, const double* E, int nE, double* out);
+
+/* Replaces: AutoSymPTR.symptr_rule as called at src/fourier.jl:271 (host, integer-exact).
+ * syms [nsyms][d][d] row-major integer matrices acting on fractional coordinates.
+ * First call with irr_idx = NULL to get *nirr; then with buffers irr_idx [nirr][d], wsym [nirr]. */
+int abz_symptr_rule(int npt, int d, const int32_t* syms, int nsyms, int64_t* nirr,
+                    int32_t* irr_idx, int64_t* wsym);
+
+/* ---------------------------------------------------------------- IAI building blocks + driver
+ * Replaces: workspace_contract!(w, x) on a batch of nodes (src/fourier.jl:468,478):
+ * contracts the outermost remaining variable of `src_level` coefficient sets.  The library keeps
+ * contracted sets in its own device pool; `slots_out[i]` identifies the set made from parent slot
+ * `parents[i]` (slot 0 at level d = the series itself) at coordinate x[i]. */
+int abz_contract_nodes(abz_series* s, int src_level, const int64_t* parents, const double* x,
+                       int64_t nnodes, int64_t* slots_out);
+/* Replaces: workspace_evaluate!(w, x) + integrand at a batch of innermost nodes
+ * (src/fourier.jl:445-446,454-455): values_reim [nnodes][ncomp][2].  tail [nnodes][d-1] gives the
+ * outer coordinates (x_2..x_d) of each node's line (needed by ABZ_F_LINEAR_X only; may be NULL). */
+int abz_eval_line_nodes(abz_series* s, const int64_t* parents, const double* x, const double* tail,
+                        int64_t nnodes, int integrand, const double* params, int nparams,
+                        double sweep, double* values_reim);
+int abz_release_level(abz_series* s, int level); /* drop all contracted sets below `level` */
+
+/* Whole IAI solve with the adaptive GK(7,15) loops on the host and every node batch on the GPU.
+ * Replaces: do_solve(::FourierIntegrand, lims, p, ::NestedQuad, cacheval) (src/fourier.jl:493-510)
+ * with init_nest (:432-486) and AuxQuadGKJL (src/algorithms.jl:215-239).  Sibling 1-D integrals
+ * advance in lockstep so each round is one batch; every 1-D integral makes exactly the scalar
+ * refinement decisions of the reference (pop worst panel, bisect), so panel trees are identical.
+ * lim_a/lim_b: CubicLimits a, b (len d) or TetrahedralLimits a (lim_b ignored).
+ * abstol < 0 / reltol < 0 mean `nothing`.  out_reim [ncomp][2]; err = the outermost GK error
+ * estimate; panels (nullable, [max_panels][2]) receives the outermost integral's final panels. */
+int abz_iai_solve(abz_series* s, int lims_kind, const double* lim_a, const double* lim_b,
+                  int integrand, const double* params, int nparams, double sweep, double abstol,
+                  double reltol, int64_t maxevals, double* out_reim, double* err, int64_t* numevals,
+                  double* panels, int64_t max_panels, int64_t* npanels);
+
+/* Replaces: QuadGK.evalrule on a batch of panels (reached from src/algorithms.jl:227-233):
+ * values [npanels][15][ncomp][2] in gk node order -> I_reim [npanels][ncomp][2], E [npanels]
+ * with I = I_K * h, E = ||I_K - I_G|| * h (2-norm over components). */
+int abz_gk15_nodes(double a, double b, double* x15);
+int abz_gk15_batch(const double* ab, const double* values_reim, int64_t npanels, int ncomp,
+                   double* I_reim, double* E);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ABZHIP_H */

@@ -1,0 +1,121 @@
+"""CPU-side checks: the C-ABI library loads, exports every symbol include/abzhip.h declares, fails
+loudly without a GPU, and its host-only entry points (integer tables, GK rule) match the oracle."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+import abz_oracle as orc
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def abz():
+    import autobzcore.jl_amd as m
+    return m
+
+
+def test_header_symbols_exported_and_bound(abz):
+    from autobzcore.jl_amd import _lib
+    hdr = open(os.path.join(ROOT, "include", "abzhip.h")).read()
+    declared = set(re.findall(r"^(?:const char\*|int) (abz_\w+)\(", hdr, flags=re.M))
+    assert len(declared) >= 27
+    assert declared == set(_lib.PROTOTYPES)
+    h = _lib.lib()
+    for name in declared:
+        assert hasattr(h, name)
+    assert h.abz_version() == 100
+
+
+def test_fails_loudly_without_gpu(abz):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(abz.AbzError):
+        abz.Context()
+    s = abz.FourierSeries([0.5, 0.0, 0.5], offset=-2)
+    with pytest.raises(abz.AbzError):
+        s(0.1)  # no CPU fallback for series evaluation
+
+
+@pytest.mark.parametrize("kind,d,npt", [("InversionSymIBZ", 1, 9), ("InversionSymIBZ", 3, 7), ("CubicSymIBZ", 2, 9),
+                                        ("CubicSymIBZ", 3, 8), ("CubicSymIBZ", 3, 50)])
+def test_symptr_rule_bit_exact_vs_oracle(abz, kind, d, npt):
+    bzo = orc.load_bz(kind, np.eye(d))
+    idx, w = abz.symptr_rule(npt, d, bzo.syms)
+    wsym, flags, nsym = orc.symptr_rule(npt, d, bzo.syms)
+    assert len(w) == nsym and w.sum() == npt**d
+    lin = np.flatnonzero(wsym.reshape(-1, order="F"))
+    strides = npt ** np.arange(d)
+    assert np.array_equal(idx @ strides, lin)
+    assert np.array_equal(w, wsym.reshape(-1, order="F")[lin])
+    # product-side symmetry generators equal the oracle's (same order)
+    bz = abz.load_bz({"InversionSymIBZ": abz.InversionSymIBZ(), "CubicSymIBZ": abz.CubicSymIBZ()}[kind], np.eye(d))
+    assert all(np.array_equal(a, b) for a, b in zip(bz.syms, bzo.syms))
+
+
+def test_load_bz_pins(abz):
+    # ref: test/brillouin.jl:7-31
+    A = np.eye(3)
+    fbz = abz.load_bz(abz.FBZ(), A)
+    assert np.allclose(fbz.B, 2 * np.pi * np.eye(3)) and abz.nsyms(fbz) == 1
+    assert fbz.lims == abz.CubicLimits(np.zeros(3), np.ones(3))
+    ibz = abz.load_bz(abz.InversionSymIBZ(), A)
+    assert abz.nsyms(ibz) == 8 and ibz.lims == abz.CubicLimits(np.zeros(3), 0.5 * np.ones(3))
+    cbz = abz.load_bz(abz.CubicSymIBZ(), A)
+    assert abz.nsyms(cbz) == 48 and cbz.lims == abz.TetrahedralLimits(np.full(3, 0.5))
+    with pytest.raises(ValueError):
+        abz.load_bz(abz.FBZ(), A, 2 * A)
+
+
+def test_gk15_host_entry_points_match_oracle(abz):
+    from autobzcore.jl_amd import _lib as L
+    x = np.empty(15)
+    L.check(L.lib().abz_gk15_nodes(0.25, 1.5, x.ctypes.data_as(L.c_f64p)))
+    assert np.array_equal(x, orc.gk_nodes(0.25, 1.5))
+    rng = np.random.default_rng(0)
+    vals = rng.standard_normal((3, 15, 2)) + 1j * rng.standard_normal((3, 15, 2))
+    ab = np.array([[0.0, 1.0], [0.5, 0.75], [-1.0, 2.0]])
+    I = np.empty((3, 2, 2))
+    E = np.empty(3)
+    L.check(L.lib().abz_gk15_batch(ab.ctypes.data_as(L.c_f64p), np.ascontiguousarray(vals).view(np.float64).ctypes.data_as(L.c_f64p),
+                                   3, 2, I.ctypes.data_as(L.c_f64p), E.ctypes.data_as(L.c_f64p)))
+    for p in range(3):
+        Io, Eo = orc.gk_evalrule(vals[p], ab[p, 0], ab[p, 1])
+        assert np.allclose(I[p].view(np.complex128).reshape(2), Io, rtol=1e-15, atol=1e-15)
+        assert abs(E[p] - Eo) <= 1e-15 * max(1.0, Eo)
+
+
+def test_parameters_and_batchparam(abz):
+    # ref: test/brillouin.jl:46-60 (MixedParameters merge rules), src/interfaces.jl:199-208
+    p = abz.MixedParameters(1, 2)
+    q = abz.MixedParameters(a="a", b="b")
+    for pq in (p.merge(q), p.merge(dict(a="a", b="b")), q.merge((1, 2))):
+        assert pq[0] == 1 and pq[1] == 2 and pq.a == "a" and pq.b == "b"
+    assert p.merge(3)[2] == 3 and q.merge(3)[0] == 3
+    assert p.merge(dict(a="c")).a == "c" and q.merge(dict(a="c")).a == "c"
+    groups = abz.batchparam(list(range(7)), 3)
+    assert [[i[0] for i, _ in g] for g in groups] == orc.batchparam(7, 3)
+    ps = abz.paramzip([1, 2, 3], b=[4, 5, 6])
+    assert ps[1][0] == 2 and ps[1].b == 5
+    pp = abz.paramproduct([1, 2], b=[4, 5, 6])
+    assert pp.shape == (2, 3) and pp[1, 2][0] == 2 and pp[1, 2].b == 6
+
+
+def test_autoptr_sequence_defaults(abz):
+    assert abz.AutoPTR().npt_sequence() == orc.npt_sequence_params() == (50, 50)
+
+
+def test_w90_reader(abz):
+    s = abz.load_w90_series(os.path.join(ROOT, "tests", "golden", "svo_hr.dat.gz"))
+    assert s.c.shape == (11, 11, 11, 3, 3) and s.first == (-5, -5, -5)
+    c = s.c
+    flip = c[::-1, ::-1, ::-1]
+    assert np.abs(c - np.conj(np.swapaxes(flip, -1, -2))).max() == 0.0  # H(-R) = H(R)^dagger exactly
+    assert np.allclose(np.diag(c[6, 5, 5]).real, [-0.255871, -0.026000, -0.255871])
+    # known eigenvalues through the ORACLE: pins the fixture + reader
+    so = orc.FourierSeries(c, period=1.0, first=s.first, ndim=3)
+    e = np.linalg.eigvalsh(orc.evaluate(so, [0.1, 0.2, 0.3]))
+    assert np.abs(e - [12.351303, 12.824980, 12.909626]).max() < 2e-6
