@@ -148,6 +148,171 @@ __device__ __forceinline__ void herm_eig(const CMat<N>& h, double (&e)[N], CMat<
     }
 }
 
+// Eigenvalues (ascending) of a 3 x 3 Hermitian matrix (upper triangle of h), LAPACK-grade accuracy
+// at ~1/4 of the Jacobi cost.  (1) trigonometric root of the characteristic polynomial for the
+// eigenvalue that is best separated from the other two (the only one the closed form gives to full
+// precision); (2) its eigenvector as the largest cross product of two rows of A - lambda I;
+// (3) the other two eigenvalues from the 2 x 2 projection of A on the orthogonal complement, which
+// is stable for (near-)degenerate pairs where the closed form alone loses half the digits.
+__device__ __forceinline__ void herm_eig3_values(const CMat<3>& h, double (&e)[3]) {
+    const double a00 = h.re[0][0], a11 = h.re[1][1], a22 = h.re[2][2];
+    const double br = h.re[0][1], bi = h.im[0][1];  // a01
+    const double cr = h.re[0][2], ci = h.im[0][2];  // a02
+    const double dr = h.re[1][2], di = h.im[1][2];  // a12
+    const double q = (a00 + a11 + a22) * (1.0 / 3.0);
+    const double d0 = a00 - q, d1 = a11 - q, d2 = a22 - q;
+    const double nb = br * br + bi * bi, nc = cr * cr + ci * ci, nd = dr * dr + di * di;
+    const double p2 = d0 * d0 + d1 * d1 + d2 * d2 + 2.0 * (nb + nc + nd);
+    if (!(p2 > 0.0)) {
+        e[0] = q;
+        e[1] = q;
+        e[2] = q;
+        return;
+    }
+    const double ip = rsqrt(p2 * (1.0 / 6.0));
+    const double p = p2 * (1.0 / 6.0) * ip;
+    // det(A - qI) = d0 d1 d2 + 2 Re(a01 a12 conj(a02)) - d0 |a12|^2 - d1 |a02|^2 - d2 |a01|^2
+    const double bdr = br * dr - bi * di, bdi = br * di + bi * dr;
+    const double det = d0 * d1 * d2 + 2.0 * (bdr * cr + bdi * ci) - d0 * nd - d1 * nc - d2 * nb;
+    double r = 0.5 * det * ip * ip * ip;
+    // Largest root x = 2 cos(acos(t)/3) of x^3 - 3x - 2t, t = |r| in [0,1] (x in [sqrt 3, 2], always
+    // simple): quartic initial guess (8.9e-6) + 2 Newton steps (2e-16), no acos/cos.  r >= 0: the
+    // largest eigenvalue q + p x is the isolated one; r < 0: the smallest, q - p x.
+    const double t = fmin(1.0, fabs(r));
+    double x = fma(fma(fma(fma(-0.008198810912827986, t, 0.03528472977563877), t, -0.09201052271579181), t,
+                       0.33285803676124615), t, 1.732059706718476);
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        const double x2 = x * x;
+        const double f = fma(x2 - 3.0, x, -2.0 * t);
+        x -= f / (3.0 * x2 - 3.0);
+    }
+    const double l1 = (r >= 0.0) ? q + p * x : q - p * x;
+    // rows of B = A - l1 I
+    const double b00 = a00 - l1, b11 = a11 - l1, b22 = a22 - l1;
+    // r0 = (b00, a01, a02), r1 = (conj a01, b11, a12), r2 = (conj a02, conj a12, b22)
+    // cross products (bilinear): w = ri x rj solves ri.w = rj.w = 0
+    // w01 = r0 x r1
+    double w01r[3], w01i[3], w02r[3], w02i[3], w12r[3], w12i[3];
+    // r0 x r1: ( a01*a12 - a02*b11, a02*conj(a01) - b00*a12, b00*b11 - a01*conj(a01) )
+    w01r[0] = (br * dr - bi * di) - cr * b11;
+    w01i[0] = (br * di + bi * dr) - ci * b11;
+    w01r[1] = (cr * br + ci * bi) - b00 * dr;
+    w01i[1] = (ci * br - cr * bi) - b00 * di;
+    w01r[2] = b00 * b11 - nb;
+    w01i[2] = 0.0;
+    // r0 x r2: ( a01*b22 - a02*conj(a12), a02*conj(a02) - b00*b22, b00*conj(a12) - a01*conj(a02) )
+    w02r[0] = br * b22 - (cr * dr + ci * di);
+    w02i[0] = bi * b22 - (ci * dr - cr * di);
+    w02r[1] = nc - b00 * b22;
+    w02i[1] = 0.0;
+    w02r[2] = b00 * dr - (br * cr + bi * ci);
+    w02i[2] = -b00 * di - (bi * cr - br * ci);
+    // r1 x r2: ( b11*b22 - a12*conj(a12), a12*conj(a02) - conj(a01)*b22, conj(a01)*conj(a12) - b11*conj(a02) )
+    w12r[0] = b11 * b22 - nd;
+    w12i[0] = 0.0;
+    w12r[1] = (dr * cr + di * ci) - br * b22;
+    w12i[1] = (di * cr - dr * ci) + bi * b22;
+    w12r[2] = (br * dr - bi * di) - b11 * cr;
+    w12i[2] = -(br * di + bi * dr) + b11 * ci;
+    double n01 = 0.0, n02 = 0.0, n12 = 0.0;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        n01 += w01r[j] * w01r[j] + w01i[j] * w01i[j];
+        n02 += w02r[j] * w02r[j] + w02i[j] * w02i[j];
+        n12 += w12r[j] * w12r[j] + w12i[j] * w12i[j];
+    }
+    const bool s02 = n02 > n01;
+    double nv = s02 ? n02 : n01;
+    double vr[3], vi[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        vr[j] = s02 ? w02r[j] : w01r[j];
+        vi[j] = s02 ? w02i[j] : w01i[j];
+    }
+    const bool s12 = n12 > nv;
+    nv = s12 ? n12 : nv;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        vr[j] = s12 ? w12r[j] : vr[j];
+        vi[j] = s12 ? w12i[j] : vi[j];
+    }
+    if (!(nv > 0.0)) {  // A - l1 I has rank <= 1: (numerically) a triple eigenvalue
+        e[0] = q;
+        e[1] = q;
+        e[2] = q;
+        return;
+    }
+    const double inv_nv = rsqrt(nv);
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        vr[j] *= inv_nv;
+        vi[j] *= inv_nv;
+    }
+    // u2 = normalised (e_k - conj(v_k) v) for the axis k with the smallest |v_k| (norm^2 = 1 - |v_k|^2
+    // >= 2/3: unconditionally well conditioned, also when v is only a rough eigenvector)
+    const double g0 = vr[0] * vr[0] + vi[0] * vi[0], g1 = vr[1] * vr[1] + vi[1] * vi[1],
+                 g2 = vr[2] * vr[2] + vi[2] * vi[2];
+    const bool k1 = g1 < g0;
+    const double gm01 = k1 ? g1 : g0;
+    const bool k2 = g2 < gm01;
+    const double gk = k2 ? g2 : gm01;
+    const double kr = k2 ? vr[2] : (k1 ? vr[1] : vr[0]);
+    const double ki = k2 ? vi[2] : (k1 ? vi[1] : vi[0]);
+    double ur[3], ui[3];
+    const double inv_mu = rsqrt(1.0 - gk);
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        // -conj(v_k) v_j = -(kr - i ki)(vr + i vi)
+        ur[j] = -(kr * vr[j] + ki * vi[j]);
+        ui[j] = -(kr * vi[j] - ki * vr[j]);
+    }
+    ur[0] += (!k1 && !k2) ? 1.0 : 0.0;
+    ur[1] += (k1 && !k2) ? 1.0 : 0.0;
+    ur[2] += k2 ? 1.0 : 0.0;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        ur[j] *= inv_mu;
+        ui[j] *= inv_mu;
+    }
+    // u3 = conj(v x u2)
+    double xr[3], xi[3];
+    xr[0] = (vr[1] * ur[2] - vi[1] * ui[2]) - (vr[2] * ur[1] - vi[2] * ui[1]);
+    xi[0] = -((vr[1] * ui[2] + vi[1] * ur[2]) - (vr[2] * ui[1] + vi[2] * ur[1]));
+    xr[1] = (vr[2] * ur[0] - vi[2] * ui[0]) - (vr[0] * ur[2] - vi[0] * ui[2]);
+    xi[1] = -((vr[2] * ui[0] + vi[2] * ur[0]) - (vr[0] * ui[2] + vi[0] * ur[2]));
+    xr[2] = (vr[0] * ur[1] - vi[0] * ui[1]) - (vr[1] * ur[0] - vi[1] * ui[0]);
+    xi[2] = -((vr[0] * ui[1] + vi[0] * ur[1]) - (vr[1] * ui[0] + vi[1] * ur[0]));
+    // y2 = A u2, y3 = A u3 with A Hermitian from the upper triangle
+    double y2r[3], y2i[3], y3r[3], y3i[3];
+#define ABZ_HMUL(ur_, ui_, yr_, yi_)                                                                   \
+    yr_[0] = a00 * ur_[0] + (br * ur_[1] - bi * ui_[1]) + (cr * ur_[2] - ci * ui_[2]);                 \
+    yi_[0] = a00 * ui_[0] + (br * ui_[1] + bi * ur_[1]) + (cr * ui_[2] + ci * ur_[2]);                 \
+    yr_[1] = (br * ur_[0] + bi * ui_[0]) + a11 * ur_[1] + (dr * ur_[2] - di * ui_[2]);                 \
+    yi_[1] = (br * ui_[0] - bi * ur_[0]) + a11 * ui_[1] + (dr * ui_[2] + di * ur_[2]);                 \
+    yr_[2] = (cr * ur_[0] + ci * ui_[0]) + (dr * ur_[1] + di * ui_[1]) + a22 * ur_[2];                 \
+    yi_[2] = (cr * ui_[0] - ci * ur_[0]) + (dr * ui_[1] - di * ur_[1]) + a22 * ui_[2];
+    ABZ_HMUL(ur, ui, y2r, y2i)
+    ABZ_HMUL(xr, xi, y3r, y3i)
+#undef ABZ_HMUL
+    double t22 = 0.0, t33 = 0.0, t23r = 0.0, t23i = 0.0;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        t22 += ur[j] * y2r[j] + ui[j] * y2i[j];
+        t33 += xr[j] * y3r[j] + xi[j] * y3i[j];
+        t23r += ur[j] * y3r[j] + ui[j] * y3i[j];  // <u2, y3>
+        t23i += ur[j] * y3i[j] - ui[j] * y3r[j];
+    }
+    const double mm = 0.5 * (t22 + t33), hh = 0.5 * (t22 - t33);
+    const double rad = sqrt(hh * hh + t23r * t23r + t23i * t23i);
+    const double lo = mm - rad, hi = mm + rad;
+    // l1 is the extreme one by construction; order defensively anyway
+    const double x0 = fmin(l1, lo), x2 = fmax(l1, hi);
+    e[0] = x0;
+    e[2] = x2;
+    e[1] = (l1 + lo + hi) - x0 - x2;
+}
+
 // Inverse of the general complex matrix A by Gauss-Jordan with partial pivoting; row exchanges are
 // done with selects so every index stays a compile-time constant.
 template <int N>
@@ -235,6 +400,76 @@ __device__ __forceinline__ void gloc(const CMat<N>& H, double w, double eta, CMa
             }
         }
         cinv<N>(A, G);
+    }
+}
+
+// tr inv((w + i eta) I - H) without forming the inverse (cofactor expansion for n <= 3)
+template <int N>
+__device__ __forceinline__ void gloc_trace(const CMat<N>& H, double w, double eta, double& tr, double& ti) {
+    if constexpr (N == 1) {
+        const double ar = w - H.re[0][0], ai = eta - H.im[0][0];
+        const double inv = 1.0 / (ar * ar + ai * ai);
+        tr = ar * inv;
+        ti = -ai * inv;
+    } else if constexpr (N == 2) {
+        const double a0r = w - H.re[0][0], a0i = eta - H.im[0][0];
+        const double a3r = w - H.re[1][1], a3i = eta - H.im[1][1];
+        double dr, di, xr, xi;
+        cmul(a0r, a0i, a3r, a3i, dr, di);
+        cmul(H.re[0][1], H.im[0][1], H.re[1][0], H.im[1][0], xr, xi);  // (-a01)(-a10)
+        dr -= xr;
+        di -= xi;
+        const double nr = a0r + a3r, ni = a0i + a3i;  // trace of the adjugate
+        const double inv = 1.0 / (dr * dr + di * di);
+        tr = (nr * dr + ni * di) * inv;
+        ti = (ni * dr - nr * di) * inv;
+    } else if constexpr (N == 3) {
+        double ar[3][3], ai[3][3];
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+#pragma unroll
+            for (int b = 0; b < 3; ++b) {
+                ar[a][b] = ((a == b) ? w : 0.0) - H.re[a][b];
+                ai[a][b] = ((a == b) ? eta : 0.0) - H.im[a][b];
+            }
+        }
+#define ABZ_M2(i, j, k, l, outr, outi)                                  \
+    {                                                                   \
+        double p_r, p_i, q_r, q_i;                                      \
+        cmul(ar[i][j], ai[i][j], ar[k][l], ai[k][l], p_r, p_i);         \
+        cmul(ar[i][l], ai[i][l], ar[k][j], ai[k][j], q_r, q_i);         \
+        outr = p_r - q_r;                                               \
+        outi = p_i - q_i;                                               \
+    }
+        double c00r, c00i, c01r, c01i, c02r, c02i, c11r, c11i, c22r, c22i;
+        ABZ_M2(1, 1, 2, 2, c00r, c00i)  // a11 a22 - a12 a21
+        ABZ_M2(1, 2, 2, 0, c01r, c01i)  // a12 a20 - a10 a22  (= -(a10 a22 - a12 a20))
+        ABZ_M2(1, 0, 2, 1, c02r, c02i)  // a10 a21 - a11 a20
+        ABZ_M2(0, 0, 2, 2, c11r, c11i)  // a00 a22 - a02 a20
+        ABZ_M2(0, 0, 1, 1, c22r, c22i)  // a00 a11 - a01 a10
+#undef ABZ_M2
+        double dr, di, t_r, t_i;
+        cmul(ar[0][0], ai[0][0], c00r, c00i, dr, di);
+        cmul(ar[0][1], ai[0][1], c01r, c01i, t_r, t_i);
+        dr += t_r;
+        di += t_i;
+        cmul(ar[0][2], ai[0][2], c02r, c02i, t_r, t_i);
+        dr += t_r;
+        di += t_i;
+        const double nr = c00r + c11r + c22r, ni = c00i + c11i + c22i;
+        const double inv = 1.0 / (dr * dr + di * di);
+        tr = (nr * dr + ni * di) * inv;
+        ti = (ni * dr - nr * di) * inv;
+    } else {
+        CMat<N> G;
+        gloc<N>(H, w, eta, G);
+        tr = 0.0;
+        ti = 0.0;
+#pragma unroll
+        for (int a = 0; a < N; ++a) {
+            tr += G.re[a][a];
+            ti += G.im[a][a];
+        }
     }
 }
 

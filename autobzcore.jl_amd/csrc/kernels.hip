@@ -234,7 +234,10 @@ __device__ __forceinline__ void eval_epilogue(const EvalArgs& a, CMat<N>& H, int
             herm_eig<N, true>(H, e, V);
             store_planes<N>(V, a.U, a.stride, k);
         } else {
-            herm_eig<N, false>(H, e, V);
+            if constexpr (N == 3)
+                herm_eig3_values(H, e);
+            else
+                herm_eig<N, false>(H, e, V);
         }
         if (a.E) {
 #pragma unroll
@@ -243,11 +246,130 @@ __device__ __forceinline__ void eval_epilogue(const EvalArgs& a, CMat<N>& H, int
     }
 }
 
-// One wavefront per line; lanes sweep i1.  The line's coefficients c1[M][N*N] are addressed with a
-// wave-uniform pointer so the compiler fetches them through the scalar cache (s_load) and the
-// v_fma_f64 stream takes them as SGPR operands: no LDS, no vector-memory traffic for operands.
-template <int N>
+// One wavefront per line (i2,i3); each lane owns KPL nodes i1 = i0 + lane + 64 j of that line.
+// The line's coefficients c1[M][N*N] are staged in a wave-private LDS buffer (double-buffered: the
+// next line's set is fetched into registers while the current one is consumed), read back with
+// broadcast ds_read_b128 and reused for the KPL nodes of every lane; phases w z^m by recurrence.
+// No block-level barrier: a wave only ever reads the LDS bytes it wrote itself.
+constexpr int EVAL_MAX_MNN = 256;  // complex coefficients per line held in LDS (M * N * N)
+
+template <int N, int KPL>
 __global__ __launch_bounds__(256) void eval_grid_kernel(EvalArgs a) {
+    extern __shared__ double2 lds_c[];  // [4 waves][2 buffers][MNN]
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int MNN = a.M * N * N;
+    double2* const mybuf = lds_c + (size_t)wave * 2 * MNN;
+    int fm = a.first % a.npt;
+    if (fm < 0) fm += a.npt;
+    const int64_t lstride = (int64_t)gridDim.x * 4;
+    int64_t line = (int64_t)blockIdx.x * 4 + wave;
+    if (line >= a.nlines) return;
+    // stage the first line
+    {
+        const double2* __restrict__ src = a.src + line * MNN;
+#pragma unroll
+        for (int t = 0; t < EVAL_MAX_MNN / 64; ++t) {
+            const int idx = lane + 64 * t;
+            if (idx < MNN) mybuf[idx] = src[idx];
+        }
+    }
+    int cur = 0;
+    for (; line < a.nlines; line += lstride) {
+        // prefetch the next line's coefficients into registers
+        const int64_t nline = line + lstride;
+        const bool have_next = nline < a.nlines;
+        double2 pre[EVAL_MAX_MNN / 64];
+        {
+            const double2* __restrict__ src = a.src + (have_next ? nline : line) * MNN;
+#pragma unroll
+            for (int t = 0; t < EVAL_MAX_MNN / 64; ++t) {
+                const int idx = lane + 64 * t;
+                pre[t] = (idx < MNN) ? src[idx] : make_double2(0.0, 0.0);
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const double2* __restrict__ c1 = mybuf + (size_t)cur * MNN;
+        for (int i0 = 0; i0 < a.npt; i0 += 64 * KPL) {
+            double zr[KPL], zi[KPL], pr[KPL], pi[KPL];
+            CMat<N> H[KPL];
+#pragma unroll
+            for (int j = 0; j < KPL; ++j) {
+                const int i1 = i0 + lane + 64 * j;
+                const int ic = i1 < a.npt ? i1 : 0;
+                const double2 z = a.tab[ic];
+                const double2 w = a.tab[(int)(((int64_t)fm * ic) % a.npt)];
+                zr[j] = z.x;
+                zi[j] = z.y;
+                pr[j] = w.x;
+                pi[j] = w.y;
+#pragma unroll
+                for (int aa = 0; aa < N; ++aa) {
+#pragma unroll
+                    for (int bb = 0; bb < N; ++bb) {
+                        H[j].re[aa][bb] = 0.0;
+                        H[j].im[aa][bb] = 0.0;
+                    }
+                }
+            }
+            for (int m = 0; m < a.M; ++m) {
+                double qr[KPL], qi[KPL];
+#pragma unroll
+                for (int j = 0; j < KPL; ++j) {
+                    qr[j] = pr[j];
+                    qi[j] = pi[j];
+                    if (a.deriv) {
+                        const double f = 6.283185307179586476925286766559 * (double)(a.first + m);
+                        qr[j] = -f * pi[j];
+                        qi[j] = f * pr[j];
+                    }
+                }
+                const double2* __restrict__ cm = c1 + m * (N * N);
+#pragma unroll
+                for (int bb = 0; bb < N; ++bb) {
+#pragma unroll
+                    for (int aa = 0; aa < N; ++aa) {
+                        const double2 c = cm[aa + N * bb];
+#pragma unroll
+                        for (int j = 0; j < KPL; ++j) {
+                            H[j].re[aa][bb] = fma(c.x, qr[j], H[j].re[aa][bb]);
+                            H[j].re[aa][bb] = fma(-c.y, qi[j], H[j].re[aa][bb]);
+                            H[j].im[aa][bb] = fma(c.x, qi[j], H[j].im[aa][bb]);
+                            H[j].im[aa][bb] = fma(c.y, qr[j], H[j].im[aa][bb]);
+                        }
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < KPL; ++j) {
+                    const double nr = pr[j] * zr[j] - pi[j] * zi[j];
+                    const double ni = pr[j] * zi[j] + pi[j] * zr[j];
+                    pr[j] = nr;
+                    pi[j] = ni;
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < KPL; ++j) {
+                const int i1 = i0 + lane + 64 * j;
+                if (i1 < a.npt) eval_epilogue<N>(a, H[j], line * a.npt + i1);
+            }
+        }
+        // hand the prefetched set to the other buffer
+        if (have_next) {
+            double2* dst = mybuf + (size_t)(cur ^ 1) * MNN;
+#pragma unroll
+            for (int t = 0; t < EVAL_MAX_MNN / 64; ++t) {
+                const int idx = lane + 64 * t;
+                if (idx < MNN) dst[idx] = pre[t];
+            }
+        }
+        cur ^= 1;
+    }
+}
+
+// Fallback for coefficient sets too large for the LDS staging above: wave-uniform scalar loads.
+template <int N>
+__global__ __launch_bounds__(256) void eval_grid_kernel_scalar(EvalArgs a) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     int fm = a.first % a.npt;
     if (fm < 0) fm += a.npt;
@@ -329,9 +451,23 @@ int launch_eval(abz_ctx* ctx, const EvalSpec& es) {
     if (es.grid) {
         if (es.nlines == 0) return ABZ_OK;
         const int64_t blocks = std::min<int64_t>(cdiv(es.nlines, 4), 256 * 8);
-#define FN(NN) hipLaunchKernelGGL(eval_grid_kernel<NN>, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, a)
-        ABZ_DISPATCH_N(es.n, FN)
+        const int mnn = es.M * es.n * es.n;
+        if (mnn <= EVAL_MAX_MNN) {
+            const size_t lds = sizeof(double2) * 4 * 2 * (size_t)mnn;
+            const int kpl = es.npt <= 64 ? 1 : (es.npt <= 128 ? 2 : 3);
+#define FN(NN)                                                                                                      \
+    switch (kpl) {                                                                                                  \
+        case 1: hipLaunchKernelGGL((eval_grid_kernel<NN, 1>), dim3((unsigned)blocks), dim3(256), lds, ctx->stream, a); break; \
+        case 2: hipLaunchKernelGGL((eval_grid_kernel<NN, 2>), dim3((unsigned)blocks), dim3(256), lds, ctx->stream, a); break; \
+        default: hipLaunchKernelGGL((eval_grid_kernel<NN, 3>), dim3((unsigned)blocks), dim3(256), lds, ctx->stream, a); break; \
+    }
+            ABZ_DISPATCH_N(es.n, FN)
 #undef FN
+        } else {
+#define FN(NN) hipLaunchKernelGGL(eval_grid_kernel_scalar<NN>, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, a)
+            ABZ_DISPATCH_N(es.n, FN)
+#undef FN
+        }
     } else {
         if (es.nk == 0) return ABZ_OK;
         const int64_t blocks = cdiv(es.nk, 256);
@@ -358,7 +494,10 @@ __global__ __launch_bounds__(256) void eig_planes_kernel(const double* __restric
         herm_eig<N, true>(H, e, V);
         store_planes<N>(V, U, stride, k);
     } else {
-        herm_eig<N, false>(H, e, V);
+        if constexpr (N == 3)
+            herm_eig3_values(H, e);
+        else
+            herm_eig<N, false>(H, e, V);
     }
 #pragma unroll
     for (int b = 0; b < N; ++b) E[(int64_t)b * stride + k] = e[b];
@@ -444,9 +583,9 @@ __device__ __forceinline__ void integrand_value(const CMat<N>& H, const double (
             vi[j] = (j < d) ? p[0] * H.im[0][0] * xk[j] : 0.0;
         }
     } else if constexpr (FID == ABZ_F_DOS || FID == ABZ_F_TRGLOC || FID == ABZ_F_GLOC) {
-        CMat<N> G;
-        gloc<N>(H, sw, p[0], G);
         if constexpr (FID == ABZ_F_GLOC) {
+            CMat<N> G;
+            gloc<N>(H, sw, p[0], G);
 #pragma unroll
             for (int b = 0; b < N; ++b) {
 #pragma unroll
@@ -456,12 +595,8 @@ __device__ __forceinline__ void integrand_value(const CMat<N>& H, const double (
                 }
             }
         } else {
-            double tr = 0.0, ti = 0.0;
-#pragma unroll
-            for (int a = 0; a < N; ++a) {
-                tr += G.re[a][a];
-                ti += G.im[a][a];
-            }
+            double tr, ti;
+            gloc_trace<N>(H, sw, p[0], tr, ti);
             if constexpr (FID == ABZ_F_DOS) {
                 vr[0] = -ti * 0.31830988618379067153776752674503;  // -Im tr G / pi
                 vi[0] = 0.0;
@@ -588,18 +723,30 @@ __global__ __launch_bounds__(256) void reduce_kernel(ReduceArgs a, double2* __re
     }
 }
 
-// out[col] = scale * sum_blocks partial[block][col]   (fixed order: reproducible)
-__global__ void final_reduce_kernel(const double2* __restrict__ partial, int64_t nblocks, int64_t ncols,
-                                    double scale, double2* __restrict__ out) {
-    const int64_t col = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (col >= ncols) return;
+// out[col] = scale * sum_blocks partial[block][col]; one workgroup per column, fixed summation
+// tree (reproducible run to run).
+__global__ __launch_bounds__(256) void final_reduce_kernel(const double2* __restrict__ partial, int64_t nblocks,
+                                                           int64_t ncols, double scale, double2* __restrict__ out) {
+    __shared__ double2 sh[4];
+    const int64_t col = blockIdx.x;
     double sr = 0.0, si = 0.0;
-    for (int64_t b = 0; b < nblocks; ++b) {
+    for (int64_t b = threadIdx.x; b < nblocks; b += 256) {
         const double2 v = partial[b * ncols + col];
         sr += v.x;
         si += v.y;
     }
-    out[col] = make_double2(sr * scale, si * scale);
+    sr = wave_sum(sr);
+    si = wave_sum(si);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = make_double2(sr, si);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double ar = 0.0, ai = 0.0;
+        for (int w = 0; w < 4; ++w) {
+            ar += sh[w].x;
+            ai += sh[w].y;
+        }
+        out[col] = make_double2(ar * scale, ai * scale);
+    }
 }
 
 template <int N, int FID>
@@ -679,8 +826,8 @@ int launch_reduce(abz_ctx* ctx, const ReduceSpec& rs, double* out_reim) {
         }
 #undef CASE
         ABZ_HIP(hipGetLastError());
-        hipLaunchKernelGGL(final_reduce_kernel, dim3((unsigned)cdiv(ncols, 256)), dim3(256), 0, ctx->stream, partial,
-                           nblocks, ncols, rs.scale, outd);
+        hipLaunchKernelGGL(final_reduce_kernel, dim3((unsigned)ncols), dim3(256), 0, ctx->stream, partial, nblocks, ncols,
+                           rs.scale, outd);
         ABZ_HIP(hipGetLastError());
     }
     ABZ_HIP(hipMemcpyAsync(out_reim, outd, sizeof(double2) * (size_t)ncols, hipMemcpyDeviceToHost, ctx->stream));
@@ -902,8 +1049,12 @@ __global__ __launch_bounds__(256) void node_integrand_kernel(NodeArgs a, double2
     series_lane<N>(c1, a.M, a.first, zr, zi, wr, wi, false, H);
     double e[N];
     if constexpr (FID == ABZ_F_DOS_EIG) {
-        CMat<N> V;
-        herm_eig<N, false>(H, e, V);
+        if constexpr (N == 3) {
+            herm_eig3_values(H, e);
+        } else {
+            CMat<N> V;
+            herm_eig<N, false>(H, e, V);
+        }
     }
     double xk[ABZ_MAX_DIM] = {0.0, 0.0, 0.0};
     if constexpr (FID == ABZ_F_LINEAR_X) {

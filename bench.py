@@ -37,6 +37,9 @@ def cpu_baseline(npt_sample, n_omega_sample, s):
         return None
     lib = ctypes.CDLL(lib_path)
     lib.orc_num_threads.restype = ctypes.c_int
+    # a 1-GPU box owns a 16-core share of the host: more OpenMP threads only get throttled
+    share = min(len(os.sched_getaffinity(0)), int(os.environ.get("ABZ_CPU_THREADS", "16")))
+    lib.orc_set_threads(share)
     cores = lib.orc_num_threads()
     from autobzcore.jl_amd.series import julia_coefficient_order
     coef = np.ascontiguousarray(julia_coefficient_order(s.c, 3))
@@ -63,7 +66,8 @@ def cpu_baseline(npt_sample, n_omega_sample, s):
     tB = time.perf_counter() - t0
     return {"value": nk / tA, "unit": "k-point evals/s (H(k)+eig)", "cores": cores, "kind": "port",
             "sample": f"SVO 3-band, PTR npt={npt_sample} FBZ ({nk} k-points), {reps} reps; "
-                      f"C restatement of the reference loops (not Julia), gcc -O3 -march=native -fopenmp",
+                      f"C restatement of the reference loops (not Julia), gcc -O3 -march=native -fopenmp, "
+                      f"{cores} threads of {os.cpu_count()} logical CPUs",
             "dos_kpoint_omega_per_sec": nk * n_omega_sample / tB,
             "dos_sample": f"{n_omega_sample} omegas over the same {nk} cached H(k)"}
 

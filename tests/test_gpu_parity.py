@@ -61,6 +61,29 @@ def test_eval_nodes_matches_oracle(abz, d, n):
     assert np.abs(E - Eo).max() <= 1e-12 * scale
 
 
+def test_eig3_degenerate_and_clustered(abz):
+    """3x3 Hermitian eigenvalues at LAPACK accuracy also for exactly / nearly degenerate spectra
+    (the closed form alone would lose half the digits there).  Constant series: H(k) = c[0]."""
+    rng = np.random.default_rng(42)
+    mats = []
+    for gap in (0.0, 1e-14, 1e-10, 1e-7, 1e-4, 1e-2, 1.0):
+        for trip in range(6):
+            q, _ = np.linalg.qr(rng.standard_normal((3, 3)) + 1j * rng.standard_normal((3, 3)))
+            base = rng.uniform(-5, 5)
+            for ev in ([base, base + gap, base + 3.0], [base - 2.0, base, base + gap], [base, base + gap, base + 2 * gap],
+                       [base, base, base]):
+                mats.append((q * np.array(ev)) @ q.conj().T)
+    mats.append(np.diag([1.0, 1.0, 2.0]).astype(complex))
+    mats.append(np.diag([3.0, -1.0, -1.0]).astype(complex))
+    mats.append(np.zeros((3, 3), dtype=complex))
+    for A in mats:
+        A = 0.5 * (A + A.conj().T)
+        s = abz.FourierSeries(A.reshape(1, 3, 3), first=0, ndim=1)
+        H, E = s.device().eval_nodes(np.array([[0.3]]), want=3)
+        ref = np.linalg.eigvalsh(A)
+        assert np.abs(E[0] - ref).max() <= 4e-15 * max(1.0, np.abs(A).max()), (E[0], ref)
+
+
 def test_eval_nodes_edge_cases(abz):
     rng = np.random.default_rng(0)
     c, first = rand_series(rng, (3, 3), 2)
