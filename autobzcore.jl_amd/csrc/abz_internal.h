@@ -65,6 +65,7 @@ struct abz_series {
     int dims[ABZ_MAX_DIM] = {1, 1, 1};
     int first[ABZ_MAX_DIM] = {0, 0, 0};
     double period[ABZ_MAX_DIM] = {1, 1, 1};
+    bool hermitian = false;   // c(-R) == c(R)^dagger exactly  =>  H(k) Hermitian: half the Fourier work
     double2* coef = nullptr;  // level d: [M_d]...[M_1][n*n] complex, i_1 fastest (Julia order)
     // pools of contracted coefficient sets: level j (1 <= j < d) holds (j)-dim series of
     // elems(j) = M_1*...*M_j*n*n complex numbers per slot.
@@ -144,6 +145,7 @@ struct EvalSpec {
     const int32_t* gi;
     const double* x;
     bool deriv;
+    bool herm;  // series is Hermitian-symmetric and deriv is false: evaluate the upper triangle only
     // outputs (planar, stride), any may be null
     double* H;
     double* E;

@@ -348,6 +348,8 @@ int abz_prof_read(abz_ctx* ctx, int kernel_id, double* total_ms, int64_t* launch
 }
 
 // ---------------------------------------------------------------- series
+static bool detect_hermitian(const abz_series* s, const double* coef_reim);
+
 int abz_series_create(abz_ctx* ctx, const double* coef_reim, int d, const int32_t* dims, const int32_t* first,
                       const double* period, int n, abz_series** out) {
     ABZ_REQUIRE(ctx && coef_reim && dims && first && period && out, "abz_series_create: null argument");
@@ -383,8 +385,38 @@ int abz_series_create(abz_ctx* ctx, const double* coef_reim, int d, const int32_
         set_error("coefficient upload failed: %s", hipGetErrorString(e));
         return ABZ_ERR_HIP;
     }
+    s->hermitian = detect_hermitian(s, coef_reim);
     *out = s;
     return ABZ_OK;
+}
+
+// c(-R) == c(R)^dagger for every R (exact comparison) and symmetric frequency ranges
+static bool detect_hermitian(const abz_series* s, const double* coef_reim) {
+    const int d = s->d, n = s->n;
+    for (int j = 0; j < d; ++j)
+        if (s->first[j] != -(s->dims[j] - 1) - s->first[j]) return false;  // first = -(M-1)/2, M odd
+    int64_t nR = 1;
+    for (int j = 0; j < d; ++j) nR *= s->dims[j];
+    const int nn = n * n;
+    for (int64_t r = 0; r < nR; ++r) {
+        int64_t rem = r, mr = 0, mul = 1;
+        for (int j = 0; j < d; ++j) {
+            const int64_t i = rem % s->dims[j];
+            rem /= s->dims[j];
+            mr += (s->dims[j] - 1 - i) * mul;
+            mul *= s->dims[j];
+        }
+        if (mr < r) continue;
+        const double* A = coef_reim + 2 * r * nn;
+        const double* B = coef_reim + 2 * mr * nn;
+        for (int b = 0; b < n; ++b)
+            for (int a = 0; a < n; ++a) {
+                // A[a,b] == conj(B[b,a]); blocks are column-major
+                if (A[2 * (a + n * b)] != B[2 * (b + n * a)] || A[2 * (a + n * b) + 1] != -B[2 * (b + n * a) + 1])
+                    return false;
+            }
+    }
+    return true;
 }
 
 int abz_series_update(abz_series* s, const double* coef_reim) {
@@ -395,6 +427,7 @@ int abz_series_update(abz_series* s, const double* coef_reim) {
     ABZ_HIP(hipMemcpyAsync(s->coef, coef_reim, sizeof(double2) * (size_t)s->elems(s->d), hipMemcpyHostToDevice,
                            s->ctx->stream));
     ABZ_HIP(hipStreamSynchronize(s->ctx->stream));
+    s->hermitian = detect_hermitian(s, coef_reim);
     return ABZ_OK;
 }
 
@@ -470,6 +503,7 @@ static int rule_fill(abz_rule* r) {
         es.gi = r->full ? nullptr : rp->pd.gi[0].as<int32_t>();
         es.x = nullptr;
         es.deriv = deriv;
+        es.herm = s->hermitian;
         es.H = Hout;
         es.E = Eout;
         es.U = Uout;
@@ -758,6 +792,7 @@ int abz_eval_nodes(abz_series* s, const double* k, int64_t nk, int want, double*
         es.gi = nullptr;
         es.x = pd.xs[0].as<double>();
         es.deriv = false;
+        es.herm = false;
         es.H = (want & ABZ_WANT_H) ? Hd.as<double>() : nullptr;
         es.E = (want & ABZ_WANT_EIG) ? Ed.as<double>() : nullptr;
         es.U = nullptr;

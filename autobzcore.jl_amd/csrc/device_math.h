@@ -188,6 +188,20 @@ __device__ __forceinline__ void herm_eig3_values(const CMat<3>& h, double (&e)[3
         x -= f / (3.0 * x2 - 3.0);
     }
     const double l1 = (r >= 0.0) ? q + p * x : q - p * x;
+    // The other two roots of the (shifted, scaled) cubic are -x/2 +- sqrt(3 - 3 x^2 / 4).  When the
+    // discriminant is not tiny this is accurate to ~1e-15 / sqrt(disc) * p and we are done; only
+    // (near-)degenerate pairs take the deflation path below.
+    const double disc = fma(-0.75 * x, x, 3.0);
+    if (disc > 1e-6) {
+        const double sq = sqrt(disc);
+        const double sgn = (r >= 0.0) ? 1.0 : -1.0;
+        const double mid = q - sgn * 0.5 * p * x;
+        const double lo = mid - p * sq, hi = mid + p * sq;
+        e[0] = (r >= 0.0) ? lo : l1;
+        e[1] = (r >= 0.0) ? hi : lo;
+        e[2] = (r >= 0.0) ? l1 : hi;
+        return;
+    }
     // rows of B = A - l1 I
     const double b00 = a00 - l1, b11 = a11 - l1, b22 = a22 - l1;
     // r0 = (b00, a01, a02), r1 = (conj a01, b11, a12), r2 = (conj a02, conj a12, b22)

@@ -220,7 +220,7 @@ struct EvalArgs {
     double* E;
     double* U;
     int64_t nlines, nk, stride;
-    int M, first, npt, deriv;
+    int M, first, npt, deriv, herm;
     double inv_period;
 };
 
@@ -253,7 +253,7 @@ __device__ __forceinline__ void eval_epilogue(const EvalArgs& a, CMat<N>& H, int
 // No block-level barrier: a wave only ever reads the LDS bytes it wrote itself.
 constexpr int EVAL_MAX_MNN = 256;  // complex coefficients per line held in LDS (M * N * N)
 
-template <int N, int KPL>
+template <int N, int KPL, bool HERM>
 __global__ __launch_bounds__(256) void eval_grid_kernel(EvalArgs a) {
     extern __shared__ double2 lds_c[];  // [4 waves][2 buffers][MNN]
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -272,6 +272,21 @@ __global__ __launch_bounds__(256) void eval_grid_kernel(EvalArgs a) {
             const int idx = lane + 64 * t;
             if (idx < MNN) mybuf[idx] = src[idx];
         }
+    }
+    // phase seeds z = e^{2 pi i i1/npt}, w = z^first depend on the lane only: load them once (a load
+    // inside the line loop would wait, through the in-order vmcnt, for the previous line's stores)
+    const bool single = a.npt <= 64 * KPL;
+    double zr0[KPL], zi0[KPL], wr0[KPL], wi0[KPL];
+#pragma unroll
+    for (int j = 0; j < KPL; ++j) {
+        const int i1 = lane + 64 * j;
+        const int ic = i1 < a.npt ? i1 : 0;
+        const double2 z = a.tab[ic];
+        const double2 w = a.tab[(int)(((int64_t)fm * ic) % a.npt)];
+        zr0[j] = z.x;
+        zi0[j] = z.y;
+        wr0[j] = w.x;
+        wi0[j] = w.y;
     }
     int cur = 0;
     for (; line < a.nlines; line += lstride) {
@@ -296,14 +311,21 @@ __global__ __launch_bounds__(256) void eval_grid_kernel(EvalArgs a) {
             CMat<N> H[KPL];
 #pragma unroll
             for (int j = 0; j < KPL; ++j) {
-                const int i1 = i0 + lane + 64 * j;
-                const int ic = i1 < a.npt ? i1 : 0;
-                const double2 z = a.tab[ic];
-                const double2 w = a.tab[(int)(((int64_t)fm * ic) % a.npt)];
-                zr[j] = z.x;
-                zi[j] = z.y;
-                pr[j] = w.x;
-                pi[j] = w.y;
+                if (single) {
+                    zr[j] = zr0[j];
+                    zi[j] = zi0[j];
+                    pr[j] = wr0[j];
+                    pi[j] = wi0[j];
+                } else {
+                    const int i1 = i0 + lane + 64 * j;
+                    const int ic = i1 < a.npt ? i1 : 0;
+                    const double2 z = a.tab[ic];
+                    const double2 w = a.tab[(int)(((int64_t)fm * ic) % a.npt)];
+                    zr[j] = z.x;
+                    zi[j] = z.y;
+                    pr[j] = w.x;
+                    pi[j] = w.y;
+                }
 #pragma unroll
                 for (int aa = 0; aa < N; ++aa) {
 #pragma unroll
@@ -330,13 +352,16 @@ __global__ __launch_bounds__(256) void eval_grid_kernel(EvalArgs a) {
                 for (int bb = 0; bb < N; ++bb) {
 #pragma unroll
                     for (int aa = 0; aa < N; ++aa) {
+                        if (HERM && aa > bb) continue;  // upper triangle only; mirrored below
                         const double2 c = cm[aa + N * bb];
 #pragma unroll
                         for (int j = 0; j < KPL; ++j) {
                             H[j].re[aa][bb] = fma(c.x, qr[j], H[j].re[aa][bb]);
                             H[j].re[aa][bb] = fma(-c.y, qi[j], H[j].re[aa][bb]);
-                            H[j].im[aa][bb] = fma(c.x, qi[j], H[j].im[aa][bb]);
-                            H[j].im[aa][bb] = fma(c.y, qr[j], H[j].im[aa][bb]);
+                            if (!(HERM && aa == bb)) {
+                                H[j].im[aa][bb] = fma(c.x, qi[j], H[j].im[aa][bb]);
+                                H[j].im[aa][bb] = fma(c.y, qr[j], H[j].im[aa][bb]);
+                            }
                         }
                     }
                 }
@@ -350,6 +375,16 @@ __global__ __launch_bounds__(256) void eval_grid_kernel(EvalArgs a) {
             }
 #pragma unroll
             for (int j = 0; j < KPL; ++j) {
+                if constexpr (HERM) {
+#pragma unroll
+                    for (int bb = 0; bb < N; ++bb) {
+#pragma unroll
+                        for (int aa = bb + 1; aa < N; ++aa) {
+                            H[j].re[aa][bb] = H[j].re[bb][aa];
+                            H[j].im[aa][bb] = -H[j].im[bb][aa];
+                        }
+                    }
+                }
                 const int i1 = i0 + lane + 64 * j;
                 if (i1 < a.npt) eval_epilogue<N>(a, H[j], line * a.npt + i1);
             }
@@ -446,6 +481,7 @@ int launch_eval(abz_ctx* ctx, const EvalSpec& es) {
     a.first = es.first;
     a.npt = es.npt > 0 ? es.npt : 1;
     a.deriv = es.deriv ? 1 : 0;
+    a.herm = (es.herm && !es.deriv) ? 1 : 0;
     a.inv_period = 1.0 / es.period;
     ProfScope ps(ctx, ABZ_K_EVAL);
     if (es.grid) {
@@ -455,14 +491,20 @@ int launch_eval(abz_ctx* ctx, const EvalSpec& es) {
         if (mnn <= EVAL_MAX_MNN) {
             const size_t lds = sizeof(double2) * 4 * 2 * (size_t)mnn;
             const int kpl = es.npt <= 64 ? 1 : (es.npt <= 128 ? 2 : 3);
-#define FN(NN)                                                                                                      \
-    switch (kpl) {                                                                                                  \
-        case 1: hipLaunchKernelGGL((eval_grid_kernel<NN, 1>), dim3((unsigned)blocks), dim3(256), lds, ctx->stream, a); break; \
-        case 2: hipLaunchKernelGGL((eval_grid_kernel<NN, 2>), dim3((unsigned)blocks), dim3(256), lds, ctx->stream, a); break; \
-        default: hipLaunchKernelGGL((eval_grid_kernel<NN, 3>), dim3((unsigned)blocks), dim3(256), lds, ctx->stream, a); break; \
+#define LK(NN, KK)                                                                                                  \
+    if (a.herm)                                                                                                     \
+        hipLaunchKernelGGL((eval_grid_kernel<NN, KK, true>), dim3((unsigned)blocks), dim3(256), lds, ctx->stream, a); \
+    else                                                                                                            \
+        hipLaunchKernelGGL((eval_grid_kernel<NN, KK, false>), dim3((unsigned)blocks), dim3(256), lds, ctx->stream, a);
+#define FN(NN)                    \
+    switch (kpl) {                \
+        case 1: LK(NN, 1) break;  \
+        case 2: LK(NN, 2) break;  \
+        default: LK(NN, 3) break; \
     }
             ABZ_DISPATCH_N(es.n, FN)
 #undef FN
+#undef LK
         } else {
 #define FN(NN) hipLaunchKernelGGL(eval_grid_kernel_scalar<NN>, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, a)
             ABZ_DISPATCH_N(es.n, FN)
