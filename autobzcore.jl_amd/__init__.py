@@ -12,10 +12,12 @@ from .bz import (FBZ, IBZ, Basis, CubicLimits, CubicSymIBZ, HyperCube, Inversion
 from .dos import DOSProblem, DOSSolution, GGR
 from . import dos
 from .io_w90 import load_w90_series, read_w90_hrdat
+from . import dist
+from .dist import batchsolve_sharded, sharded_map
 from .series import DeviceRule, DeviceSeries, FourierSeries, symptr_rule
 from .solver import (IAI, PTR, TAI, AutoPTR, AutoSymPTRJL, AuxQuadGKJL, BatchIntegrand, DOSIntegrand, DeviceIntegrand,
                      EvalCounter, FourierIntegrand, FourierValue, GlocIntegrand, IntegralProblem, IntegralSolution,
-                     IntegralSolver, LinearIntegrand, LinearXIntegrand, MixedParameters, MonkhorstPack, NestedQuad,
+                     IntegralSolver, LinearIntegrand, LinearXIntegrand, MixedParameters, MonkhorstPack, NestedBatchIntegrand, NestedQuad,
                      NullParameters, ParameterIntegrand, TrGlocIntegrand, UnitIntegrand, batchparam, batchsolve,
                      do_solve, init, paramproduct, paramzip, solve, solve_)
 

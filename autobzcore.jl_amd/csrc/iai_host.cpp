@@ -105,10 +105,9 @@ struct Quad1D {
     double E = 0.0;
     int64_t numevals = 0;
     bool done = false, started = false;
-    // pending work of the current round
-    int npending = 0;
-    Seg pend[2];
-    Seg popped;
+    // pending work of the current round: panels to evaluate, and the parents they replace
+    std::vector<Seg> pend;
+    std::vector<Seg> popped;
 };
 
 static inline bool heap_lt(const Seg& x, const Seg& y) { return y.E < x.E; }  // lt(Reverse, x, y)
@@ -165,6 +164,7 @@ struct IaiDriver {
     bool has_rtol;
     double rtol_user;
     int64_t maxevals;
+    int64_t max_batch = 0;  // 0: scalar refinement; > 0: BatchIntegrand refinement with this soft cap
     int64_t total_evals = 0;
     std::vector<int64_t> h_parents;
     std::vector<double> h_x, h_tail;
@@ -255,8 +255,8 @@ int IaiDriver::solve_level(int L, std::vector<Quad1D>& quads) {
         Quad1D& q = quads[i];
         double lo, hi;
         q.lims.segs(L, lo, hi);
-        q.npending = 1;
-        q.pend[0] = Seg{lo, hi, 0.0, 0};
+        q.pend.assign(1, Seg{lo, hi, 0.0, 0});
+        q.popped.clear();
         q.started = false;
         q.done = false;
         q.I.assign((size_t)ncomp, cd(0, 0));
@@ -268,14 +268,14 @@ int IaiDriver::solve_level(int L, std::vector<Quad1D>& quads) {
     while (!active.empty()) {
         // ---- gather the nodes of all pending panels
         int64_t nn = 0;
-        for (size_t qi : active) nn += 15 * quads[qi].npending;
+        for (size_t qi : active) nn += 15 * (int64_t)quads[qi].pend.size();
         h_parents.resize((size_t)nn);
         h_x.resize((size_t)nn);
         if (d > 1) h_tail.resize((size_t)(nn * (d - 1)));
         int64_t t = 0;
         for (size_t qi : active) {
             Quad1D& q = quads[qi];
-            for (int p = 0; p < q.npending; ++p) {
+            for (size_t p = 0; p < q.pend.size(); ++p) {
                 gk15_nodes(q.pend[p].a, q.pend[p].b, xs15);
                 for (int i = 0; i < 15; ++i, ++t) {
                     h_parents[(size_t)t] = q.slot;
@@ -298,7 +298,7 @@ int IaiDriver::solve_level(int L, std::vector<Quad1D>& quads) {
             t = 0;
             for (size_t qi : active) {
                 Quad1D& q = quads[qi];
-                for (int p = 0; p < q.npending; ++p) {
+                for (size_t p = 0; p < q.pend.size(); ++p) {
                     for (int i = 0; i < 15; ++i, ++t) {
                         Quad1D& k = kids[(size_t)t];
                         const double x = h_x[(size_t)t];
@@ -329,8 +329,8 @@ int IaiDriver::solve_level(int L, std::vector<Quad1D>& quads) {
             Quad1D& q = quads[qi];
             const double rt = tol_r(q);
             const double at = q.has_atol ? q.atol : 0.0;
-            Seg got[2];
-            for (int p = 0; p < q.npending; ++p, t += 15) {
+            std::vector<Seg> got(q.pend.size());
+            for (size_t p = 0; p < q.pend.size(); ++p, t += 15) {
                 Seg sg = q.pend[p];
                 gk15_evalrule(&vals[(size_t)(t * ncomp)], ncomp, sg.a, sg.b, Iseg.data(), &sg.E);
                 if (!std::isfinite(sg.E)) {
@@ -350,25 +350,48 @@ int IaiDriver::solve_level(int L, std::vector<Quad1D>& quads) {
                 q.numevals = 15;
                 if (q.E <= std::max(at, rt * vnorm(q.I)) || q.numevals >= maxevals) {
                     q.done = true;
-                    q.npending = 0;
+                    q.pend.clear();
                     continue;
                 }
                 heapify(q.heap);
             } else {
-                for (int c = 0; c < ncomp; ++c)
-                    q.I[(size_t)c] = (q.I[(size_t)c] - q.store[(size_t)(q.popped.ioff + c)]) +
-                                     q.store[(size_t)(got[0].ioff + c)] + q.store[(size_t)(got[1].ioff + c)];
-                q.E = (q.E - q.popped.E) + got[0].E + got[1].E;
-                q.numevals += 30;
-                heap_push(q.heap, got[0]);
-                heap_push(q.heap, got[1]);
+                // children arrive in the order their parents were popped: (left, right) per parent
+                for (size_t k = 0; k < q.popped.size(); ++k) {
+                    const Seg& par = q.popped[k];
+                    const Seg& s1 = got[2 * k];
+                    const Seg& s2 = got[2 * k + 1];
+                    for (int c = 0; c < ncomp; ++c)
+                        q.I[(size_t)c] = (q.I[(size_t)c] - q.store[(size_t)(par.ioff + c)]) +
+                                         q.store[(size_t)(s1.ioff + c)] + q.store[(size_t)(s2.ioff + c)];
+                    q.E = (q.E - par.E) + s1.E + s2.E;
+                    heap_push(q.heap, s1);
+                    heap_push(q.heap, s2);
+                }
             }
-            if (q.E > std::max(at, rt * vnorm(q.I)) && q.numevals < maxevals) {
-                q.popped = heap_pop(q.heap);
-                const double mid = (q.popped.a + q.popped.b) / 2;
-                q.npending = 2;
-                q.pend[0] = Seg{q.popped.a, mid, 0.0, 0};
-                q.pend[1] = Seg{mid, q.popped.b, 0.0, 0};
+            q.pend.clear();
+            q.popped.clear();
+            double tol = std::max(at, rt * vnorm(q.I));
+            if (q.E > tol && q.numevals < maxevals) {
+                if (max_batch <= 0) {
+                    // scalar mode (QuadGK adapt): pop the worst panel, bisect
+                    q.popped.push_back(heap_pop(q.heap));
+                    q.numevals += 30;
+                } else {
+                    // BatchIntegrand refine: pop panels while the error of the REMAINING ones still
+                    // exceeds the tolerance (auxquadgk batch mode, src/algorithms.jl:227-233)
+                    while (!q.heap.empty() && 30 * ((int64_t)q.popped.size() + 1) <= max_batch && q.E > tol &&
+                           q.numevals < maxevals) {
+                        Seg sg = heap_pop(q.heap);
+                        tol += sg.E;
+                        q.numevals += 30;
+                        q.popped.push_back(sg);
+                    }
+                }
+                for (const Seg& par : q.popped) {
+                    const double mid = (par.a + par.b) / 2;
+                    q.pend.push_back(Seg{par.a, mid, 0.0, 0});
+                    q.pend.push_back(Seg{mid, par.b, 0.0, 0});
+                }
                 next.push_back(qi);
             } else {
                 // re-sum over the heap in storage order (QuadGK does this after adapt)
@@ -379,7 +402,6 @@ int IaiDriver::solve_level(int L, std::vector<Quad1D>& quads) {
                     q.E += q.heap[h].E;
                 }
                 q.done = true;
-                q.npending = 0;
             }
         }
         active.swap(next);
@@ -410,8 +432,8 @@ int abz_gk15_batch(const double* ab, const double* values_reim, int64_t npanels,
 
 int abz_iai_solve(abz_series* s, int lims_kind, const double* lim_a, const double* lim_b, int integrand,
                   const double* params, int nparams, double sweep, double abstol, double reltol, int64_t maxevals,
-                  double* out_reim, double* err, int64_t* numevals, double* panels, int64_t max_panels,
-                  int64_t* npanels) {
+                  int64_t max_batch, double* out_reim, double* err, int64_t* numevals, double* panels,
+                  int64_t max_panels, int64_t* npanels) {
     ABZ_REQUIRE(s && s->ctx && lim_a && out_reim, "abz_iai_solve: null argument");
     ABZ_REQUIRE(lims_kind == ABZ_LIMS_CUBIC || lims_kind == ABZ_LIMS_TETRAHEDRAL, "unknown limits kind %d", lims_kind);
     ABZ_REQUIRE(lims_kind != ABZ_LIMS_CUBIC || lim_b, "CubicLimits need lim_b");
@@ -434,6 +456,7 @@ int abz_iai_solve(abz_series* s, int lims_kind, const double* lim_a, const doubl
     drv.has_rtol = reltol >= 0;
     drv.rtol_user = reltol;
     drv.maxevals = maxevals > 0 ? maxevals : (int64_t)1 << 62;
+    drv.max_batch = max_batch;
     std::vector<Quad1D> top(1);
     Quad1D& q = top[0];
     q.slot = 0;

@@ -1,0 +1,71 @@
+"""Multi-GPU parameter sweeps: one process per GPU, omega/parameter shards with no data-path
+collective, one tiny all_gather of the results (RCCL over xGMI on GPUs, gloo in CPU tests).
+
+ref: batchsolve / batchparam (src/interfaces.jl:199-243): threads take parameters round-robin
+(group j gets ps[j], ps[j+n], ...) and every non-primary worker deep-copies the solver.  Here every
+rank holds its own replica of the coefficients and of the cached rule (its "deep copy") and solves
+ps[rank::world]; messages are <= a few hundred bytes per rank, so the collective is latency-bound
+and the per-link xGMI bandwidth never matters.
+"""
+import numpy as np
+
+
+def _dist():
+    import torch.distributed as dist
+    return dist
+
+
+def world_info(group=None):
+    dist = _dist()
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_world_size(group), dist.get_rank(group)
+    return 1, 0
+
+
+def shard_indices(n, world, rank):
+    """Round-robin shard of range(n), identical to batchparam's grouping (src/interfaces.jl:199-208)."""
+    return list(range(rank, n, world))
+
+
+def sharded_map(fn, ps, group=None, device=None):
+    """Evaluate fn(list_of_params) -> array [len, ...] on this rank's shard and all_gather.
+
+    Every rank returns the full result array ordered like `ps`.  Values travel as complex128.
+    `device`: torch device of the collective buffers ("cuda" for nccl/RCCL, None/"cpu" for gloo)."""
+    import torch
+    world, rank = world_info(group)
+    ps = list(ps)
+    n = len(ps)
+    idx = shard_indices(n, world, rank)
+    local = np.asarray(fn([ps[i] for i in idx])) if idx else np.zeros((0,))
+    if world == 1:
+        return local
+    dist = _dist()
+    # agree on the value shape (ranks with an empty shard do not know it)
+    tail = list(local.shape[1:]) if len(idx) else []
+    meta = [None] * world
+    dist.all_gather_object(meta, (len(idx), tail, bool(np.iscomplexobj(local))), group=group)
+    tail = next((m[1] for m in meta if m[0] > 0), [])
+    is_complex = any(m[2] for m in meta if m[0] > 0)
+    per = int(np.prod(tail)) if tail else 1
+    maxlen = max(m[0] for m in meta)
+    buf = np.zeros((maxlen, per), dtype=np.complex128)
+    if len(idx):
+        buf[: len(idx)] = np.asarray(local, dtype=np.complex128).reshape(len(idx), per)
+    dev = device if device is not None else ("cuda" if dist.get_backend(group) == "nccl" else "cpu")
+    t = torch.from_numpy(buf.view(np.float64)).to(dev)
+    parts = [torch.empty_like(t) for _ in range(world)]
+    dist.all_gather(parts, t, group=group)  # the one collective of the sweep (C1)
+    out = np.zeros((n, per), dtype=np.complex128)
+    for r, p in enumerate(parts):
+        ridx = shard_indices(n, world, r)
+        if ridx:
+            out[ridx] = p.cpu().numpy().view(np.complex128)[: len(ridx)]
+    out = out.reshape([n] + tail)
+    return out if is_complex else out.real
+
+
+def batchsolve_sharded(solver, ps, group=None, device=None, **kw):
+    """batchsolve over all ranks of the process group: rank r solves ps[r::world] on its own GPU."""
+    from .solver import batchsolve
+    return sharded_map(lambda chunk: batchsolve(solver, chunk, **kw), ps, group=group, device=device)

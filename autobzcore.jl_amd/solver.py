@@ -115,6 +115,20 @@ class BatchIntegrand:
         self.max_batch = int(max_batch)
 
 
+class NestedBatchIntegrand:
+    """Tuple of worker integrands + resizable buffers for (thread-)parallel nested quadrature.
+    ref: src/batch.jl:41-77.  On the GPU path the workers are not needed (every batch is one kernel
+    launch); what the type selects is the BatchIntegrand refinement rule of auxquadgk at every level
+    of NestedQuad (several panels popped per round, src/fourier.jl:441-473) and its max_batch."""
+
+    def __init__(self, f, y=None, x=None, max_batch=2**62):
+        if max_batch <= 0:
+            raise ValueError("maximum batch size must be positive")
+        self.f = tuple(f) if isinstance(f, (tuple, list)) else (f,)
+        self.y, self.x = y, x
+        self.max_batch = int(max_batch)
+
+
 class DeviceIntegrand:
     """A built-in integrand evaluated on the GPU, fused with the Fourier evaluation / reduction.
     Positional parameter names follow the reference functions they stand for."""
@@ -223,6 +237,10 @@ class FourierIntegrand:
     or any Python callable (H(k) batches come back to the host)."""
 
     def __init__(self, f, w, *args, **kwargs):
+        self.nest = None
+        if args and isinstance(args[0], NestedBatchIntegrand):  # FourierIntegrand(p, w, nest), src/fourier.jl:29-31
+            self.nest = args[0]
+            args = args[1:]
         if isinstance(f, ParameterIntegrand):
             self.f = f
         else:
@@ -471,6 +489,7 @@ def _redo_on_fbz(f, bz, p, alg, kws):
 
 def _iai_device(f: FourierIntegrand, dev, lims, p: MixedParameters, abstol, reltol, maxiters, want_panels=False):
     fi = f.f.f
+    max_batch = 0 if f.nest is None else min(f.nest.max_batch, 2**62)
     params, sw = fi.bind(p)
     d, n = f.w.d, f.w.n
     ncomp = {L.F_GLOC: n * n, L.F_LINEAR_X: d}.get(fi.fid, 1)
@@ -494,7 +513,7 @@ def _iai_device(f: FourierIntegrand, dev, lims, p: MixedParameters, abstol, relt
     L.check(L.lib().abz_iai_solve(
         dev.h, kind, pa, pb, fi.fid, par.ctypes.data_as(L.c_f64p) if len(par) else None, len(par),
         0.0 if sw is None else sw, -1.0 if abstol is None else float(abstol),
-        -1.0 if reltol is None else float(reltol), int(min(maxiters, 2**62)),
+        -1.0 if reltol is None else float(reltol), int(min(maxiters, 2**62)), int(max_batch),
         out.ctypes.data_as(L.c_f64p), C.byref(err), C.byref(nev),
         panels.ctypes.data_as(L.c_f64p) if want_panels else None, maxp, C.byref(npan)))
     vals = out.view(np.complex128).reshape(ncomp)

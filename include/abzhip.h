@@ -167,12 +167,15 @@ int abz_release_level(abz_series* s, int level); /* drop all contracted sets bel
  * advance in lockstep so each round is one batch; every 1-D integral makes exactly the scalar
  * refinement decisions of the reference (pop worst panel, bisect), so panel trees are identical.
  * lim_a/lim_b: CubicLimits a, b (len d) or TetrahedralLimits a (lim_b ignored).
- * abstol < 0 / reltol < 0 mean `nothing`.  out_reim [ncomp][2]; err = the outermost GK error
- * estimate; panels (nullable, [max_panels][2]) receives the outermost integral's final panels. */
+ * abstol < 0 / reltol < 0 mean `nothing`.  max_batch = 0: scalar refinement (the reference's default
+ * IAI()); max_batch > 0: the BatchIntegrand / NestedBatchIntegrand refinement at every level (pop
+ * panels while the error of the remaining ones exceeds the tolerance, 2*15*popped <= max_batch;
+ * ref src/batch.jl:41-77, src/fourier.jl:441-473).  out_reim [ncomp][2]; err = the outermost GK
+ * error estimate; panels (nullable, [max_panels][2]) receives the outermost integral's final panels. */
 int abz_iai_solve(abz_series* s, int lims_kind, const double* lim_a, const double* lim_b,
                   int integrand, const double* params, int nparams, double sweep, double abstol,
-                  double reltol, int64_t maxevals, double* out_reim, double* err, int64_t* numevals,
-                  double* panels, int64_t max_panels, int64_t* npanels);
+                  double reltol, int64_t maxevals, int64_t max_batch, double* out_reim, double* err,
+                  int64_t* numevals, double* panels, int64_t max_panels, int64_t* npanels);
 
 /* Replaces: QuadGK.evalrule on a batch of panels (reached from src/algorithms.jl:227-233):
  * values [npanels][15][ncomp][2] in gk node order -> I_reim [npanels][ncomp][2], E [npanels]

@@ -1,0 +1,58 @@
+"""N > 1 path on CPU: world_size-2 gloo run of the sharded sweep (the per-rank solve is a CPU stub
+built on the oracle, because this container has no GPU; the sharding, ordering and the all_gather
+are the product code under test)."""
+import os
+import subprocess
+import sys
+import textwrap
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+WORKER = textwrap.dedent("""
+    import os, sys
+    import numpy as np
+    sys.path.insert(0, {root!r}); sys.path.insert(0, os.path.join({root!r}, "oracle"))
+    import torch.distributed as dist
+    import abz_oracle as orc
+    from autobzcore.jl_amd import dist as adist
+    dist.init_process_group("gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    so = orc.tb_integer(2)
+    bz = orc.load_bz("FBZ", np.eye(2))
+    omegas = list(np.linspace(-3.0, 3.0, 7))          # 7 parameters on 2 ranks: ragged shards
+    calls = []
+    def solve_chunk(chunk):
+        calls.append(list(chunk))
+        return np.array([orc.solve_ptr(so, bz, orc.f_dos(0.3, w), npt=12).u for w in chunk])
+    full = adist.sharded_map(solve_chunk, omegas)
+    assert calls[0] == omegas[rank::world], (calls, rank)
+    ref = np.array([orc.solve_ptr(so, bz, orc.f_dos(0.3, w), npt=12).u for w in omegas])
+    assert np.array_equal(full, ref), (full, ref)
+    # matrix valued results and an empty shard (1 parameter on 2 ranks)
+    g = adist.sharded_map(lambda ch: np.array([np.eye(2) * (1 + 1j) * w for w in ch]), [2.0])
+    assert g.shape == (1, 2, 2) and np.allclose(g[0], np.eye(2) * (2 + 2j))
+    assert adist.shard_indices(7, 3, 1) == [1, 4]
+    dist.destroy_process_group()
+    print("rank", rank, "ok")
+""")
+
+
+def test_sharded_sweep_world2_gloo(tmp_path):
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER.format(root=ROOT))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29517")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                          "--master-addr", "127.0.0.1", "--master-port", "29517", str(script)],
+                         env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert out.stdout.count("ok") == 2
+
+
+def test_shard_indices_match_batchparam():
+    import autobzcore.jl_amd as abz
+    from autobzcore.jl_amd.dist import shard_indices
+    groups = abz.batchparam(list(range(11)), 4)
+    for r in range(4):
+        assert [i[0] for i, _ in groups[r]] == shard_indices(11, 4, r)

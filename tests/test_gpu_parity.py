@@ -249,6 +249,35 @@ def test_iai_panel_tree_bit_exact(abz):
         assert abs(sol.u - ref.u) <= 1e-10 * abs(ref.u)
 
 
+def test_nested_batch_integrand(abz):
+    """ref: test/fourier.jl:25-37 -- the nested-batch path agrees with the serial path for
+    NestedQuad(AuxQuadGKJL()) and MonkhorstPack(); and its BatchIntegrand refinement (several panels
+    popped per round) reproduces the oracle's batch-mode panel tree bit for bit."""
+    for d in (1, 2, 3):
+        so = orc.integer_lattice(d)
+        s = abz.FourierSeries(so.c[..., 0, 0], period=1.0, first=so.first, ndim=d)
+        p = abz.ParameterIntegrand(abz.LinearXIntegrand(), 1.3, b=4.2)
+        nest = abz.NestedBatchIntegrand(tuple(p for _ in range(3)))
+        for alg, dom in ((abz.NestedQuad(abz.AuxQuadGKJL()), abz.CubicLimits(np.zeros(d), np.ones(d))),
+                         (abz.MonkhorstPack(), abz.Basis(np.eye(d)))):
+            u1 = abz.solve(abz.IntegralProblem(abz.FourierIntegrand(p, s), dom), alg).u
+            u2 = abz.solve(abz.IntegralProblem(abz.FourierIntegrand(p, s, nest), dom), alg).u
+            assert np.allclose(u1, u2, rtol=1e-7, atol=1e-9)
+    rng = np.random.default_rng(12)
+    c, first = rand_series(rng, (5, 5), 2, hermitian=True)
+    s, so = both(abz, c, first)
+    bz = abz.load_bz(abz.FBZ(), np.eye(2))
+    pi = abz.ParameterIntegrand(abz.DOSIntegrand(), 0.25)
+    f = abz.FourierIntegrand(pi, s, abz.NestedBatchIntegrand((pi,)))
+    sol = abz.do_solve(f, bz, abz.MixedParameters(0.3), abz.EvalCounter(abz.IAI()), abstol=1e-4, _panels=True)
+    rec = []
+    ref = orc.solve_iai(so, orc.load_bz("FBZ", np.eye(2)), orc.f_dos(0.25, 0.3), abstol=1e-4, record=rec, batch=True)
+    assert np.array_equal(sol.extra["panels"], np.array(rec)) and sol.numevals == ref.numevals
+    assert abs(sol.u - ref.u) <= 1e-10 * abs(ref.u)
+    with pytest.raises(ValueError):
+        abz.NestedBatchIntegrand((pi,), max_batch=0)  # ref: src/batch.jl:16
+
+
 # ------------------------------------------------------------------ SVO (configs 3 / 4)
 @pytest.fixture(scope="module")
 def svo(abz):
