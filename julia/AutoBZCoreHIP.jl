@@ -1,0 +1,237 @@
+# AutoBZCoreHIP.jl -- reference-side binding of libabzhip.so (include/abzhip.h).
+#
+# UNTESTED SOURCE: there is no Julia toolchain in the build pipeline (SURVEY.md section 8c), so this
+# file shows the shim a maintainer of AutoBZCore.jl v0.3.8 would add; the same C ABI is exercised
+# by the Python ctypes mirror in autobzcore.jl_amd/ and by tests/.
+#
+# What it plugs into (file:line in lxvm/AutoBZCore.jl v0.3.8):
+#   * the dispatch pair init_cacheval / do_solve          src/interfaces.jl:59-62,116-118
+#   * FourierIntegrand / FourierValue                     src/fourier.jl:22-58,111-118
+#   * PTR / AutoPTR / IAI on a SymmetricBZ                src/brillouin.jl:337-444, src/fourier.jl:338-389,488-510
+#   * BatchIntegrand f!(y, x, p)                          src/batch.jl:1-38
+#   * batchsolve                                          src/interfaces.jl:199-243
+#   * DOSProblem + GGR                                    src/dos_ggr.jl:1-104
+module AutoBZCoreHIP
+
+using AutoBZCore
+using AutoBZCore: FourierIntegrand, FourierValue, ParameterIntegrand, MixedParameters, SymmetricBZ,
+    IntegralSolution, IntegralSolver, nsyms, PTR, AutoPTR, IAI, CubicLimits, TetrahedralLimits
+using FourierSeriesEvaluators: FourierSeries, period
+using LinearAlgebra, StaticArrays
+
+const libabz = "libabzhip"   # autobzcore.jl_amd/libabzhip.so on the loader path
+
+# ---------------------------------------------------------------- constants of abzhip.h
+const WANT_H, WANT_EIG, WANT_VEL = Cint(1), Cint(2), Cint(4)
+const F_ONE, F_LINEAR, F_LINEAR_X, F_DOS, F_TRGLOC, F_GLOC, F_DOS_EIG = Cint.(0:6)
+const LIMS_CUBIC, LIMS_TETRAHEDRAL = Cint(0), Cint(1)
+
+function check(rc::Cint)
+    rc == 0 && return nothing
+    msg = unsafe_string(ccall((:abz_last_error, libabz), Cstring, ()))
+    rc == -1 ? throw(ArgumentError(msg)) : error("libabzhip error $rc: $msg")
+end
+
+# ---------------------------------------------------------------- handles
+mutable struct HIPContext
+    h::Ptr{Cvoid}
+    function HIPContext(device::Integer=0)
+        ref = Ref{Ptr{Cvoid}}(C_NULL)
+        check(ccall((:abz_ctx_create, libabz), Cint, (Cint, Ptr{Ptr{Cvoid}}), device, ref))
+        ctx = new(ref[])
+        finalizer(c -> ccall((:abz_ctx_destroy, libabz), Cint, (Ptr{Cvoid},), c.h), ctx)
+    end
+end
+const CTX = Ref{HIPContext}()           # one context per Julia thread in a threaded build
+context() = isassigned(CTX) ? CTX[] : (CTX[] = HIPContext())
+
+"Device-resident coefficients: replaces workspace_allocate_vec (src/fourier.jl:61-86)."
+mutable struct HIPSeries{N}
+    h::Ptr{Cvoid}
+    n::Int
+    rules::Dict{Tuple{Int,UInt,Cint},Any}
+end
+function HIPSeries(s::FourierSeries{S,N}) where {S,N}
+    c = s.c                                   # Array{SMatrix{n,n,ComplexF64}} or Array{<:Number}
+    n = eltype(c) <: Number ? 1 : size(eltype(c), 1)
+    coef = reinterpret(Float64, vec(c))       # Julia memory order == the ABI's order
+    dims = Cint[size(c)...]
+    first = Cint[(1 .+ s.o)...]               # frequency of c[1]: offset + 1 (OffsetArray axes fold into s.o)
+    per = Float64[period(s)...]
+    ref = Ref{Ptr{Cvoid}}(C_NULL)
+    GC.@preserve coef dims first per begin
+        check(ccall((:abz_series_create, libabz), Cint,
+            (Ptr{Cvoid}, Ptr{Float64}, Cint, Ptr{Cint}, Ptr{Cint}, Ptr{Float64}, Cint, Ptr{Ptr{Cvoid}}),
+            context().h, coef, N, dims, first, per, n, ref))
+    end
+    hs = HIPSeries{N}(ref[], n, Dict())
+    finalizer(x -> ccall((:abz_series_destroy, libabz), Cint, (Ptr{Cvoid},), x.h), hs)
+end
+
+"Cached PTR rule: replaces FourierPTR / FourierMonkhorstPack (src/fourier.jl:127-174,210-277)."
+mutable struct HIPRule
+    h::Ptr{Cvoid}
+    nk::Int
+    npt::Int
+    nsyms::Int
+end
+function symptr_rule(npt, ::Val{d}, syms) where {d}   # replaces AutoSymPTR.symptr_rule (src/fourier.jl:271)
+    S = Cint[round(Int, M[a, b]) for M in syms for a in 1:d for b in 1:d]   # row-major per matrix
+    n = Ref{Int64}(0)
+    check(ccall((:abz_symptr_rule, libabz), Cint, (Cint, Cint, Ptr{Cint}, Cint, Ptr{Int64}, Ptr{Cint}, Ptr{Int64}),
+        npt, d, S, length(syms), n, C_NULL, C_NULL))
+    idx = Matrix{Cint}(undef, d, n[]); w = Vector{Int64}(undef, n[])
+    check(ccall((:abz_symptr_rule, libabz), Cint, (Cint, Cint, Ptr{Cint}, Cint, Ptr{Int64}, Ptr{Cint}, Ptr{Int64}),
+        npt, d, S, length(syms), n, idx, w))
+    return idx, w
+end
+function rule!(hs::HIPSeries{d}, npt::Integer, syms, want::Cint) where {d}
+    key = (Int(npt), hash(syms), want)
+    get!(hs.rules, key) do
+        ref = Ref{Ptr{Cvoid}}(C_NULL)
+        if syms === nothing
+            check(ccall((:abz_ptr_rule_build, libabz), Cint,
+                (Ptr{Cvoid}, Cint, Int64, Ptr{Cint}, Ptr{Int64}, Cint, Ptr{Ptr{Cvoid}}),
+                hs.h, npt, 0, C_NULL, C_NULL, want, ref))
+            nk, ns = npt^d, 1
+        else
+            idx, w = symptr_rule(npt, Val(d), syms)
+            check(ccall((:abz_ptr_rule_build, libabz), Cint,
+                (Ptr{Cvoid}, Cint, Int64, Ptr{Cint}, Ptr{Int64}, Cint, Ptr{Ptr{Cvoid}}),
+                hs.h, npt, length(w), idx, w, want, ref))
+            nk, ns = length(w), length(syms)
+        end
+        r = HIPRule(ref[], nk, npt, ns)
+        finalizer(x -> ccall((:abz_rule_destroy, libabz), Cint, (Ptr{Cvoid},), x.h), r)
+    end
+end
+
+# ---------------------------------------------------------------- device integrands
+"Integrands evaluated on the GPU; everything else goes through `FourierValue` batches."
+abstract type HIPIntegrand end
+struct DOSIntegrand <: HIPIntegrand end       # (h_k, eta, omega) -> -imag(tr(inv((omega+im*eta)I - h_k.s)))/pi
+struct TrGlocIntegrand <: HIPIntegrand end    # (h_k; eta, omega) -> tr(inv(complex(omega,eta)I - h_k.s))
+struct GlocIntegrand <: HIPIntegrand end      # (h_k; eta, omega) -> inv(complex(omega,eta)I - h_k.s)
+struct LinearIntegrand <: HIPIntegrand end    # (x, a; b) -> a*x.s + b
+struct UnitIntegrand <: HIPIntegrand end
+fid(::DOSIntegrand) = F_DOS; fid(::TrGlocIntegrand) = F_TRGLOC; fid(::GlocIntegrand) = F_GLOC
+fid(::LinearIntegrand) = F_LINEAR; fid(::UnitIntegrand) = F_ONE
+# host fall-backs keep the objects usable with every other AutoBZCore algorithm
+(::DOSIntegrand)(h::FourierValue, eta, omega) = -imag(tr(inv((omega + im * eta) * I - h.s))) / pi
+(::LinearIntegrand)(x::FourierValue, a; b) = a * x.s + b
+bind(::Union{DOSIntegrand,TrGlocIntegrand,GlocIntegrand}, p::MixedParameters) =
+    (Float64[get(getfield(p, :kwargs), :eta, p[1])], Float64(get(getfield(p, :kwargs), :omega, p[end])))
+bind(::LinearIntegrand, p::MixedParameters) = (Float64[p[1], getfield(p, :kwargs).b], 0.0)
+bind(::UnitIntegrand, p) = (Float64[], 0.0)
+
+const HIPFourierIntegrand = FourierIntegrand{<:HIPIntegrand}
+
+"rule(f, B) = quadsum(...) (src/fourier.jl:204-207,289-292) for all sweep values in one pass."
+function reduce_rule(r::HIPRule, f::HIPIntegrand, params::Vector{Float64}, sweep::Vector{Float64}, ncomp::Int)
+    out = Vector{ComplexF64}(undef, ncomp * length(sweep))
+    GC.@preserve params sweep out begin
+        check(ccall((:abz_rule_reduce, libabz), Cint,
+            (Ptr{Cvoid}, Cint, Ptr{Float64}, Cint, Ptr{Float64}, Cint, Cint, Ptr{ComplexF64}),
+            r.h, fid(f), params, length(params), sweep, length(sweep), r.nsyms, out))
+    end
+    return reshape(out, ncomp, :)
+end
+
+# ---------------------------------------------------------------- the dispatch pair
+# cacheval = the device series; rules are cached inside it by (npt, syms, want), so unlike
+# src/interfaces.jl:174-179 nothing is rebuilt per solver call.
+AutoBZCore.init_cacheval(f::HIPFourierIntegrand, bz::SymmetricBZ, p, ::Union{PTR,AutoPTR,IAI}) = HIPSeries(f.w.series)
+
+function AutoBZCore.do_solve(f::HIPFourierIntegrand, bz::SymmetricBZ, p, alg::PTR, hs::HIPSeries;
+    abstol=nothing, reltol=nothing, maxiters=typemax(Int))
+    j = abs(det(bz.B))                                   # src/brillouin.jl:340
+    r = rule!(hs, alg.npt, bz.syms, WANT_H)
+    params, omega = bind(f.f.f, merge(f.f.p, p))
+    u = reduce_rule(r, f.f.f, params, [omega], 1)[1, 1]
+    return IntegralSolution(j * nsyms(bz) * real(u), nothing, true, r.nk)   # TrivialRep: src/brillouin.jl:107
+end
+
+function AutoBZCore.do_solve(f::HIPFourierIntegrand, bz::SymmetricBZ, p, alg::AutoPTR, hs::HIPSeries;
+    abstol=nothing, reltol=nothing, maxiters=typemax(Int))
+    j = abs(det(bz.B))
+    atol = abstol === nothing ? 0.0 : abstol / j          # src/brillouin.jl:433
+    rtol = reltol === nothing ? (abstol === nothing ? sqrt(eps()) : 0.0) : reltol
+    n0 = clamp(round(Int, alg.n₀ / alg.a), alg.nmin, alg.nmax)
+    dn = clamp(round(Int, alg.Δn / alg.a), alg.nmin, alg.nmax)
+    params, omega = bind(f.f.f, merge(f.f.p, p))
+    npt = n0; numevals = 0
+    rule = rule!(hs, npt, bz.syms, WANT_H); numevals += rule.nk
+    I1 = nsyms(bz) * real(reduce_rule(rule, f.f.f, params, [omega], 1)[1, 1])
+    while true
+        npt += dn
+        rule = rule!(hs, npt, bz.syms, WANT_H); numevals += rule.nk
+        I2 = nsyms(bz) * real(reduce_rule(rule, f.f.f, params, [omega], 1)[1, 1])
+        err = abs(I2 - I1)
+        (err <= max(atol, rtol * abs(I2)) || numevals >= maxiters) && return IntegralSolution(I2 * j, err * j, true, numevals)
+        I1 = I2
+    end
+end
+
+function AutoBZCore.do_solve(f::HIPFourierIntegrand, bz::SymmetricBZ, p, alg::IAI, hs::HIPSeries{d};
+    abstol=nothing, reltol=nothing, maxiters=typemax(Int)) where {d}
+    j = abs(det(bz.B)); ns = nsyms(bz)
+    params, omega = bind(f.f.f, merge(f.f.p, p))
+    kind, a, b = bz.lims isa CubicLimits ? (LIMS_CUBIC, Float64[bz.lims.a...], Float64[bz.lims.b...]) :
+                 (LIMS_TETRAHEDRAL, Float64[bz.lims.a...], Float64[])
+    out = Ref{ComplexF64}(0); err = Ref{Float64}(0); nev = Ref{Int64}(0); npan = Ref{Int64}(0)
+    GC.@preserve params a b begin
+        check(ccall((:abz_iai_solve, libabz), Cint,
+            (Ptr{Cvoid}, Cint, Ptr{Float64}, Ptr{Float64}, Cint, Ptr{Float64}, Cint, Float64, Float64, Float64, Int64, Int64,
+             Ptr{ComplexF64}, Ptr{Float64}, Ptr{Int64}, Ptr{Float64}, Int64, Ptr{Int64}),
+            hs.h, kind, a, isempty(b) ? C_NULL : pointer(b), fid(f.f.f), params, length(params), omega,
+            abstol === nothing ? -1.0 : abstol / (j * ns),        # src/brillouin.jl:342
+            reltol === nothing ? -1.0 : Float64(reltol), min(maxiters, typemax(Int64) >> 1), 0,
+            out, err, nev, C_NULL, 0, npan))
+    end
+    return IntegralSolution(j * ns * real(out[]), j * ns * err[], true, nev[])
+end
+
+# ---------------------------------------------------------------- BatchIntegrand body for user closures
+"""
+    fourier_batch(g, s::FourierSeries)
+
+`BatchIntegrand` whose body evaluates H(k) for all nodes of a batch on the GPU and applies the user
+closure `g(FourierValue(k, H_k), p)` on the host (src/batch.jl:4-6 names this as the GPU hook).
+"""
+function fourier_batch(g, s::FourierSeries{S,N}, ::Type{Y}=ComplexF64) where {S,N,Y}
+    hs = HIPSeries(s); n = hs.n
+    return AutoBZCore.BatchIntegrand(Y, SVector{N,Float64}) do y, x, p
+        k = reinterpret(Float64, x); H = Vector{ComplexF64}(undef, n * n * length(x))
+        GC.@preserve k H check(ccall((:abz_eval_nodes, libabz), Cint,
+            (Ptr{Cvoid}, Ptr{Float64}, Int64, Cint, Ptr{ComplexF64}, Ptr{Float64}),
+            hs.h, k, length(x), WANT_H, H, C_NULL))
+        Hs = reinterpret(SMatrix{n,n,ComplexF64,n * n}, H)
+        @inbounds for i in eachindex(x)
+            y[i] = g(FourierValue(x[i], Hs[i]), p)
+        end
+        return nothing
+    end
+end
+
+# ---------------------------------------------------------------- fused parameter sweep
+"batchsolve for a HIP integrand under PTR: one pass over the cached rule for all parameters."
+function AutoBZCore.batchsolve(s::IntegralSolver{<:HIPFourierIntegrand,<:SymmetricBZ,<:PTR}, omegas::AbstractVector{<:Real})
+    f, bz = s.f, s.dom
+    hs = HIPSeries(f.w.series)
+    r = rule!(hs, s.alg.npt, bz.syms, WANT_H)
+    params, _ = bind(f.f.f, merge(f.f.p, MixedParameters(first(omegas))))
+    u = reduce_rule(r, f.f.f, params, Float64.(omegas), 1)
+    return abs(det(bz.B)) * nsyms(bz) .* real.(vec(u))
+end
+
+# ---------------------------------------------------------------- GGR
+"get_ggr_data + sum_ggr on the GPU (src/dos_ggr.jl:14-65)."
+function ggr(h::FourierSeries{S,N}, bz::SymmetricBZ, Es::Vector{Float64}; npt=50) where {S,N}
+    hs = HIPSeries(h)
+    r = rule!(hs, npt, bz.syms, WANT_EIG | WANT_VEL)
+    out = similar(Es)
+    check(ccall((:abz_rule_ggr, libabz), Cint, (Ptr{Cvoid}, Ptr{Float64}, Cint, Ptr{Float64}), r.h, Es, length(Es), out))
+    return out
+end
+
+end # module
