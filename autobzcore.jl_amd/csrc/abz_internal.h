@@ -196,4 +196,30 @@ struct NodeEvalSpec {
 };
 int launch_node_integrand(abz_ctx* ctx, const NodeEvalSpec& ns, double2* values_dev);
 
+// ---- generic n (5..32 bands): wave-per-node kernels (kernels_generic.hip)
+struct GenSpec {
+    int n, M, first, npt, d;
+    double period;
+    const double2* src;
+    bool grid;               // node k = (line = k / npt, i1 = k % npt), slot = line
+    const int64_t* parents;  // node mode
+    const int32_t* gi;
+    const double* x;
+    const double2* tab;
+    bool deriv;
+    int64_t nnodes, stride;
+    double* Hplanes;
+    double* Eplanes;
+    double2* Haos;
+    double* Eaos;
+    int integrand;
+    double params[4];
+    const double* sweep_dev;
+    double sweep0;
+    int n_sweep;
+    double2* values;  // [node][n_sweep][ncomp] or null
+};
+int launch_gen_nodes(abz_ctx* ctx, const GenSpec& gs);
+int launch_gen_reduce(abz_ctx* ctx, const ReduceSpec& rs, double* out_reim);
+
 }  // namespace abz

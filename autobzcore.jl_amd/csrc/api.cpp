@@ -557,8 +557,8 @@ int abz_ptr_rule_build(abz_series* s, int npt, int64_t nirr, const int32_t* irr_
     ABZ_REQUIRE((want & (ABZ_WANT_H | ABZ_WANT_EIG | ABZ_WANT_VEL)) != 0, "want = %d selects nothing", want);
     ABZ_REQUIRE((irr_idx == nullptr) == (wsym == nullptr), "irr_idx and wsym must be given together");
     if (want & ABZ_WANT_VEL) want |= ABZ_WANT_EIG;
-    if (s->n > 4) {
-        set_error("n = %d bands: only n <= 4 is built in this round", s->n);
+    if (s->n > 4 && (want & ABZ_WANT_VEL)) {
+        set_error("band velocities (GGR) for n = %d > 4 bands are not built in this round", s->n);
         return ABZ_ERR_UNSUPPORTED;
     }
     abz_ctx* ctx = s->ctx;
@@ -752,10 +752,6 @@ int abz_eval_nodes(abz_series* s, const double* k, int64_t nk, int want, double*
     ABZ_REQUIRE(!(want & ABZ_WANT_H) || H_out, "want H but H_out is null");
     ABZ_REQUIRE(!(want & ABZ_WANT_EIG) || eig_out, "want eigenvalues but eig_out is null");
     if (nk == 0) return ABZ_OK;
-    if (s->n > 4) {
-        set_error("n = %d bands: only n <= 4 is built in this round", s->n);
-        return ABZ_ERR_UNSUPPORTED;
-    }
     abz_ctx* ctx = s->ctx;
     ABZ_HIP(hipSetDevice(ctx->device));
     const int d = s->d, n = s->n;

@@ -438,10 +438,6 @@ int abz_iai_solve(abz_series* s, int lims_kind, const double* lim_a, const doubl
     ABZ_REQUIRE(lims_kind == ABZ_LIMS_CUBIC || lims_kind == ABZ_LIMS_TETRAHEDRAL, "unknown limits kind %d", lims_kind);
     ABZ_REQUIRE(lims_kind != ABZ_LIMS_CUBIC || lim_b, "CubicLimits need lim_b");
     ABZ_REQUIRE(nparams >= 0 && nparams <= 4, "nparams = %d not in 0..4", nparams);
-    if (s->n > 4) {
-        set_error("n = %d bands: only n <= 4 is built in this round", s->n);
-        return ABZ_ERR_UNSUPPORTED;
-    }
     ABZ_HIP(hipSetDevice(s->ctx->device));
     IaiDriver drv;
     drv.s = s;
@@ -527,10 +523,6 @@ int abz_eval_line_nodes(abz_series* s, const int64_t* parents, const double* x, 
                         int integrand, const double* params, int nparams, double sweep, double* values_reim) {
     ABZ_REQUIRE(s && s->ctx && parents && x && values_reim, "abz_eval_line_nodes: null argument");
     ABZ_REQUIRE(nparams >= 0 && nparams <= 4, "nparams = %d not in 0..4", nparams);
-    if (s->n > 4) {
-        set_error("n = %d bands: only n <= 4 is built in this round", s->n);
-        return ABZ_ERR_UNSUPPORTED;
-    }
     ABZ_HIP(hipSetDevice(s->ctx->device));
     IaiDriver drv;
     drv.s = s;

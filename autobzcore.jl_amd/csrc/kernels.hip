@@ -465,6 +465,39 @@ __global__ __launch_bounds__(256) void eval_node_kernel(EvalArgs a) {
     }
 
 int launch_eval(abz_ctx* ctx, const EvalSpec& es) {
+    if (es.n > 4) {
+        if (es.U) {
+            set_error("eigenvectors / velocities for n = %d > 4 bands are not built in this round", es.n);
+            return ABZ_ERR_UNSUPPORTED;
+        }
+        GenSpec gs;
+        gs.n = es.n;
+        gs.M = es.M;
+        gs.first = es.first;
+        gs.npt = es.npt;
+        gs.d = 0;
+        gs.period = es.period;
+        gs.src = es.src;
+        gs.grid = es.grid;
+        gs.parents = es.parents;
+        gs.gi = es.gi;
+        gs.x = es.x;
+        gs.tab = es.tab;
+        gs.deriv = es.deriv;
+        gs.nnodes = es.grid ? es.nlines * es.npt : es.nk;
+        gs.stride = es.stride;
+        gs.Hplanes = es.H;
+        gs.Eplanes = es.E;
+        gs.Haos = nullptr;
+        gs.Eaos = nullptr;
+        gs.integrand = ABZ_F_ONE;
+        for (int i = 0; i < 4; ++i) gs.params[i] = 0.0;
+        gs.sweep_dev = nullptr;
+        gs.sweep0 = 0.0;
+        gs.n_sweep = 0;
+        gs.values = nullptr;
+        return launch_gen_nodes(ctx, gs);
+    }
     EvalArgs a;
     a.src = es.src;
     a.tab = es.tab;
@@ -808,6 +841,7 @@ static constexpr int reduce_kt(int n) {
 }
 
 int launch_reduce(abz_ctx* ctx, const ReduceSpec& rs, double* out_reim) {
+    if (rs.n > 4) return launch_gen_reduce(ctx, rs, out_reim);
     const int ncomp = integrand_ncomp(rs.integrand, rs.n, rs.d);
     if (ncomp < 0) {
         set_error("unknown integrand id %d", rs.integrand);
@@ -1114,6 +1148,35 @@ __global__ __launch_bounds__(256) void node_integrand_kernel(NodeArgs a, double2
 
 int launch_node_integrand(abz_ctx* ctx, const NodeEvalSpec& ns, double2* values_dev) {
     if (ns.nnodes == 0) return ABZ_OK;
+    if (ns.n > 4) {
+        GenSpec gs;
+        gs.n = ns.n;
+        gs.M = ns.M;
+        gs.first = ns.first;
+        gs.npt = 0;
+        gs.d = ns.d;
+        gs.period = ns.period;
+        gs.src = ns.src;
+        gs.grid = false;
+        gs.parents = ns.parents;
+        gs.gi = nullptr;
+        gs.x = ns.x;
+        gs.tab = nullptr;
+        gs.deriv = false;
+        gs.nnodes = ns.nnodes;
+        gs.stride = 0;
+        gs.Hplanes = nullptr;
+        gs.Eplanes = nullptr;
+        gs.Haos = nullptr;
+        gs.Eaos = nullptr;
+        gs.integrand = ns.integrand;
+        for (int i = 0; i < 4; ++i) gs.params[i] = ns.params[i];
+        gs.sweep_dev = nullptr;
+        gs.sweep0 = ns.sweep;
+        gs.n_sweep = 1;
+        gs.values = values_dev;
+        return launch_gen_nodes(ctx, gs);
+    }
     const int ncomp = integrand_ncomp(ns.integrand, ns.n, ns.d);
     if (ncomp < 0) {
         set_error("unknown integrand id %d", ns.integrand);

@@ -1,0 +1,540 @@
+// Generic-n (5 <= n <= 32 bands) kernels: ONE WAVEFRONT PER NODE, the n x n matrices live in a
+// wave-private LDS slab (no block barriers: a wave only reads LDS bytes it wrote itself).
+//
+//   gen_node_kernel    series value H(k) = sum_m c1[m] w z^m at a node (lanes stride over the n^2
+//                      entries, coefficient reads coalesced), then per `mode`: store H / eigenvalues
+//                      (cooperative cyclic Jacobi on the upper triangle) / integrand value
+//                      (tr / full inverse of (omega + i eta) I - H by Gauss-Jordan in LDS).
+//                      Serves abz_eval_nodes, PTR rule builds and the IAI innermost nodes for n > 4.
+//   gen_reduce_kernel  sum_k w_k f(H(k); omega_i) over a cached rule for n > 4.
+//
+// A = (omega + i eta) I - H has a positive-definite anti-Hermitian part (eta > 0) whenever H is
+// Hermitian, so elimination without pivoting is backward stable up to a growth factor <= ||A||/eta;
+// that is what the Gauss-Jordan below relies on.
+#include "abz_internal.h"
+
+namespace abz {
+
+static inline int64_t cdiv2(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+__device__ __forceinline__ double wsum(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+// In-LDS Gauss-Jordan: X <- inv(A), A destroyed.  A, X: n*n double2, column-major (a + n*b).
+__device__ void wave_inverse(double2* A, double2* X, int n, int lane) {
+    const int nn = n * n;
+    for (int t = lane; t < nn; t += 64) {
+        const int a = t % n, b = t / n;
+        X[t] = make_double2(a == b ? 1.0 : 0.0, 0.0);
+    }
+    wave_sync();
+    for (int c = 0; c < n; ++c) {
+        const double2 p = A[c + n * c];
+        const double ipn = 1.0 / (p.x * p.x + p.y * p.y);
+        const double ipr = p.x * ipn, ipi = -p.y * ipn;  // 1 / pivot
+        // new values into registers (reads see the state before this column's update)
+        double2 na[16], nx[16];  // n*n / 64 <= 16 entries per lane for n <= 32 (unrolled: registers)
+#pragma unroll
+        for (int cnt = 0; cnt < 16; ++cnt) {
+            const int t = lane + 64 * cnt;
+            if (t < nn) {
+                const int r = t % n, cc = t / n;
+                const double2 arow = A[c + n * cc], xrow = X[c + n * cc];  // pivot row entries (old)
+                if (r == c) {
+                    na[cnt] = make_double2(arow.x * ipr - arow.y * ipi, arow.x * ipi + arow.y * ipr);
+                    nx[cnt] = make_double2(xrow.x * ipr - xrow.y * ipi, xrow.x * ipi + xrow.y * ipr);
+                } else {
+                    const double2 f0 = A[r + n * c];
+                    const double fr = f0.x * ipr - f0.y * ipi, fi = f0.x * ipi + f0.y * ipr;  // f / pivot
+                    const double2 av = A[t], xv = X[t];
+                    na[cnt] = make_double2(av.x - (fr * arow.x - fi * arow.y), av.y - (fr * arow.y + fi * arow.x));
+                    nx[cnt] = make_double2(xv.x - (fr * xrow.x - fi * xrow.y), xv.y - (fr * xrow.y + fi * xrow.x));
+                }
+            }
+        }
+        wave_sync();
+#pragma unroll
+        for (int cnt = 0; cnt < 16; ++cnt) {
+            const int t = lane + 64 * cnt;
+            if (t < nn) {
+                A[t] = na[cnt];
+                X[t] = nx[cnt];
+            }
+        }
+        wave_sync();
+    }
+}
+
+// Cooperative cyclic Jacobi on the Hermitian matrix given by the UPPER triangle of A (column-major,
+// destroyed).  Eigenvalues ascending into e[0..n) (LDS doubles).
+__device__ void wave_eig(double2* A, double* e, int n, int lane) {
+    const int nn = n * n;
+    // hermitise from the upper triangle, real diagonal
+    for (int t = lane; t < nn; t += 64) {
+        const int a = t % n, b = t / n;
+        if (a > b) {
+            const double2 u = A[b + n * a];
+            A[t] = make_double2(u.x, -u.y);
+        }
+    }
+    wave_sync();
+    for (int t = lane; t < n; t += 64) A[t + n * t].y = 0.0;
+    wave_sync();
+    double norm2 = 0.0;
+    for (int t = lane; t < nn; t += 64) norm2 += A[t].x * A[t].x + A[t].y * A[t].y;
+    norm2 = wsum(norm2);
+    const double tiny = 1e-34 * norm2;
+    for (int sweep = 0; sweep < 40; ++sweep) {
+        double off2 = 0.0;
+        for (int t = lane; t < nn; t += 64) {
+            const int a = t % n, b = t / n;
+            if (a < b) off2 += A[t].x * A[t].x + A[t].y * A[t].y;
+        }
+        off2 = wsum(off2);
+        if (!(off2 > tiny)) break;
+        for (int p = 0; p < n - 1; ++p) {
+            for (int q = p + 1; q < n; ++q) {
+                const double2 al = A[p + n * q];
+                const double b2 = al.x * al.x + al.y * al.y;
+                if (!(b2 > tiny)) continue;  // wave-uniform
+                const double rb = rsqrt(b2), b = b2 * rb;
+                const double gr = al.x * rb, gi = -al.y * rb;
+                const double app = A[p + n * p].x, aqq = A[q + n * q].x;
+                const double dd = aqq - app;
+                const double t = copysign(2.0 * b, dd) / (fabs(dd) + sqrt(dd * dd + 4.0 * b2));
+                const double c = rsqrt(1.0 + t * t), s = t * c;
+                const double sgr = s * gr, sgi = s * gi, cgr = c * gr, cgi = c * gi;
+                // lane r updates (r,p),(r,q) and the mirrored entries
+                double2 np_[1], nq_[1];
+                const int r = lane;
+                const bool act = r < n && r != p && r != q;
+                if (act) {
+                    const double2 x = A[r + n * p], y = A[r + n * q];
+                    np_[0] = make_double2(c * x.x - (sgr * y.x - sgi * y.y), c * x.y - (sgr * y.y + sgi * y.x));
+                    nq_[0] = make_double2(s * x.x + (cgr * y.x - cgi * y.y), s * x.y + (cgr * y.y + cgi * y.x));
+                }
+                wave_sync();
+                if (act) {
+                    A[r + n * p] = np_[0];
+                    A[r + n * q] = nq_[0];
+                    A[p + n * r] = make_double2(np_[0].x, -np_[0].y);
+                    A[q + n * r] = make_double2(nq_[0].x, -nq_[0].y);
+                }
+                if (lane == 0) {
+                    A[p + n * p] = make_double2(app - t * b, 0.0);
+                    A[q + n * q] = make_double2(aqq + t * b, 0.0);
+                    A[p + n * q] = make_double2(0.0, 0.0);
+                    A[q + n * p] = make_double2(0.0, 0.0);
+                }
+                wave_sync();
+            }
+        }
+    }
+    // ascending order by rank counting (n <= 64 lanes)
+    double v = 0.0;
+    if (lane < n) v = A[lane + n * lane].x;
+    wave_sync();
+    if (lane < n) {
+        int rank = 0;
+        for (int j = 0; j < n; ++j) {
+            const double u = A[j + n * j].x;
+            rank += (u < v || (u == v && j < lane)) ? 1 : 0;
+        }
+        e[rank] = v;
+    }
+    wave_sync();
+}
+
+struct GenArgs {
+    const double2* src;      // coefficient sets [slot][M][n*n]
+    const int64_t* parents;  // per node (null in grid mode)
+    const double* x;         // per node coordinate (null: grid index)
+    const int32_t* gi;       // per node grid index (null in grid mode / x mode)
+    const double2* tab;
+    const double* tail;
+    int64_t nnodes, stride;
+    int n, M, first, npt, d, grid, deriv;
+    double inv_period;
+    // outputs
+    double* Hplanes;
+    double* Eplanes;
+    double2* Haos;  // [node][n*n]
+    double* Eaos;   // [node][n]
+    // integrand
+    int integrand, n_sweep, ncomp;
+    double p[4];
+    const double* sweep;  // device [n_sweep] (null: use sweep0)
+    double sweep0;
+    double2* values;  // [node][n_sweep][ncomp]
+};
+
+// value of the integrand at the node whose H sits in LDS `H`; W, X: scratch n*n; out via lanes
+__device__ void gen_integrand(const GenArgs& a, const double2* H, double2* W, double2* X, double* ev, double sw,
+                              int lane, double2* out /* global, ncomp */) {
+    const int n = a.n, nn = n * n;
+    if (a.integrand == ABZ_F_ONE) {
+        if (lane == 0) out[0] = make_double2(1.0, 0.0);
+        return;
+    }
+    if (a.integrand == ABZ_F_DOS_EIG) {
+        double acc = 0.0;
+        for (int b = lane; b < n; b += 64) {
+            const double de = sw - ev[b];
+            acc += a.p[0] / (de * de + a.p[0] * a.p[0]);
+        }
+        acc = wsum(acc);
+        if (lane == 0) out[0] = make_double2(acc * 0.31830988618379067153776752674503, 0.0);
+        return;
+    }
+    for (int t = lane; t < nn; t += 64) {
+        const int r = t % n, c = t / n;
+        W[t] = make_double2((r == c ? sw : 0.0) - H[t].x, (r == c ? a.p[0] : 0.0) - H[t].y);
+    }
+    wave_sync();
+    wave_inverse(W, X, n, lane);
+    if (a.integrand == ABZ_F_GLOC) {
+        for (int t = lane; t < nn; t += 64) out[t] = X[t];
+    } else {
+        double tr = 0.0, ti = 0.0;
+        for (int t = lane; t < n; t += 64) {
+            tr += X[t + n * t].x;
+            ti += X[t + n * t].y;
+        }
+        tr = wsum(tr);
+        ti = wsum(ti);
+        if (lane == 0)
+            out[0] = (a.integrand == ABZ_F_DOS) ? make_double2(-ti * 0.31830988618379067153776752674503, 0.0)
+                                                : make_double2(tr, ti);
+    }
+    wave_sync();
+}
+
+__global__ __launch_bounds__(256) void gen_node_kernel(GenArgs a, int waves_per_block) {
+    extern __shared__ double2 lds_g[];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (wave >= waves_per_block) return;
+    const int n = a.n, nn = n * n;
+    // per-wave slab: H[nn] W[nn] X[nn] ph[M] ev[n doubles]
+    double2* H = lds_g + (size_t)wave * (3 * nn + a.M + (n + 1) / 2);
+    double2* W = H + nn;
+    double2* X = W + nn;
+    double2* ph = X + nn;
+    double* ev = reinterpret_cast<double*>(ph + a.M);
+    int fm = 0;
+    if (a.npt > 0) {
+        fm = a.first % a.npt;
+        if (fm < 0) fm += a.npt;
+    }
+    const int64_t wstride = (int64_t)gridDim.x * waves_per_block;
+    for (int64_t k = (int64_t)blockIdx.x * waves_per_block + wave; k < a.nnodes; k += wstride) {
+        int64_t slot;
+        double zr, zi, wr, wi;
+        if (a.grid) {
+            slot = k / a.npt;
+            const int i1 = (int)(k - slot * a.npt);
+            const double2 z = a.tab[i1];
+            const double2 w = a.tab[(int)(((int64_t)fm * i1) % a.npt)];
+            zr = z.x, zi = z.y, wr = w.x, wi = w.y;
+        } else {
+            slot = a.parents ? a.parents[k] : 0;
+            if (a.x) {
+                const double xx = a.x[k] * a.inv_period;
+                sincospi(2.0 * xx, &zi, &zr);
+                sincospi(2.0 * ((double)a.first * xx), &wi, &wr);
+            } else {
+                const int i1 = a.gi[k];
+                const double2 z = a.tab[i1];
+                const double2 w = a.tab[(int)(((int64_t)fm * i1) % a.npt)];
+                zr = z.x, zi = z.y, wr = w.x, wi = w.y;
+            }
+        }
+        // phases w z^m (every lane runs the short recurrence; lane m keeps its own)
+        {
+            double pr = wr, pi = wi;
+            for (int m = 0; m < a.M; ++m) {
+                if (lane == (m & 63)) {
+                    double qr = pr, qi = pi;
+                    if (a.deriv) {
+                        const double f = 6.283185307179586476925286766559 * (double)(a.first + m);
+                        qr = -f * pi;
+                        qi = f * pr;
+                    }
+                    ph[m] = make_double2(qr, qi);
+                }
+                const double nr = pr * zr - pi * zi, ni = pr * zi + pi * zr;
+                pr = nr;
+                pi = ni;
+            }
+        }
+        wave_sync();
+        const double2* __restrict__ c1 = a.src + slot * ((int64_t)a.M * nn);
+        for (int t = lane; t < nn; t += 64) {
+            double hr = 0.0, hi = 0.0;
+            for (int m = 0; m < a.M; ++m) {
+                const double2 c = c1[(int64_t)m * nn + t];
+                const double2 q = ph[m];
+                hr = fma(c.x, q.x, hr);
+                hr = fma(-c.y, q.y, hr);
+                hi = fma(c.x, q.y, hi);
+                hi = fma(c.y, q.x, hi);
+            }
+            H[t] = make_double2(hr, hi);
+            if (a.Hplanes) {
+                a.Hplanes[(int64_t)(2 * t) * a.stride + k] = hr;
+                a.Hplanes[(int64_t)(2 * t + 1) * a.stride + k] = hi;
+            }
+            if (a.Haos) a.Haos[k * nn + t] = make_double2(hr, hi);
+        }
+        wave_sync();
+        const bool need_eig = a.Eplanes || a.Eaos || (a.values && a.integrand == ABZ_F_DOS_EIG);
+        if (need_eig) {
+            for (int t = lane; t < nn; t += 64) W[t] = H[t];
+            wave_sync();
+            wave_eig(W, ev, n, lane);
+            for (int b = lane; b < n; b += 64) {
+                if (a.Eplanes) a.Eplanes[(int64_t)b * a.stride + k] = ev[b];
+                if (a.Eaos) a.Eaos[k * n + b] = ev[b];
+            }
+        }
+        if (a.values) {
+            for (int s = 0; s < a.n_sweep; ++s) {
+                const double sw = a.sweep ? a.sweep[s] : a.sweep0;
+                gen_integrand(a, H, W, X, ev, sw, lane, a.values + (k * a.n_sweep + s) * a.ncomp);
+            }
+        }
+        wave_sync();
+    }
+}
+
+static int gen_waves_per_block(int n, int M) {
+    const size_t per = sizeof(double2) * (size_t)(3 * n * n + M + (n + 1) / 2);
+    int w = (int)((150 * 1024) / per);
+    if (w > 4) w = 4;
+    if (w < 1) w = 1;
+    return w;
+}
+
+int launch_gen_nodes(abz_ctx* ctx, const GenSpec& gs) {
+    if (gs.nnodes == 0) return ABZ_OK;
+    if (gs.n > ABZ_MAX_BANDS) {
+        set_error("n = %d bands exceeds ABZ_MAX_BANDS", gs.n);
+        return ABZ_ERR_UNSUPPORTED;
+    }
+    GenArgs a;
+    a.src = gs.src;
+    a.parents = gs.parents;
+    a.x = gs.x;
+    a.gi = gs.gi;
+    a.tab = gs.tab;
+    a.tail = nullptr;
+    a.nnodes = gs.nnodes;
+    a.stride = gs.stride;
+    a.n = gs.n;
+    a.M = gs.M;
+    a.first = gs.first;
+    a.npt = gs.npt;
+    a.d = gs.d;
+    a.grid = gs.grid ? 1 : 0;
+    a.deriv = gs.deriv ? 1 : 0;
+    a.inv_period = 1.0 / gs.period;
+    a.Hplanes = gs.Hplanes;
+    a.Eplanes = gs.Eplanes;
+    a.Haos = gs.Haos;
+    a.Eaos = gs.Eaos;
+    a.integrand = gs.integrand;
+    a.n_sweep = gs.values ? (gs.n_sweep > 0 ? gs.n_sweep : 1) : 0;
+    a.ncomp = gs.values ? integrand_ncomp(gs.integrand, gs.n, gs.d) : 0;
+    for (int i = 0; i < 4; ++i) a.p[i] = gs.params[i];
+    a.sweep = gs.sweep_dev;
+    a.sweep0 = gs.sweep0;
+    a.values = gs.values;
+    if (gs.values && (gs.integrand == ABZ_F_LINEAR || gs.integrand == ABZ_F_LINEAR_X)) {
+        set_error("ABZ_F_LINEAR(_X) needs a scalar (n = 1) series");
+        return ABZ_ERR_ARG;
+    }
+    const int wpb = gen_waves_per_block(gs.n, gs.M);
+    const size_t lds = sizeof(double2) * (size_t)(3 * gs.n * gs.n + gs.M + (gs.n + 1) / 2) * wpb;
+    const int64_t blocks = std::min<int64_t>(cdiv2(gs.nnodes, wpb), 256 * 16);
+    ProfScope ps(ctx, ABZ_K_EVAL);
+    ABZ_HIP(hipFuncSetAttribute((const void*)gen_node_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(gen_node_kernel, dim3((unsigned)blocks), dim3(256), lds, ctx->stream, a, wpb);
+    ABZ_HIP(hipGetLastError());
+    return ABZ_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// reduce over a cached rule, n > 4: one wave per node chunk, per-omega partial sums in LDS
+// ------------------------------------------------------------------------------------------
+struct GenReduceArgs {
+    const double* Hplanes;
+    const double* Eplanes;
+    const double* w;
+    const double* sweep;
+    int64_t nk, stride, chunk;
+    int n, n_sweep, ncomp, integrand;
+    double p[4];
+};
+
+__global__ __launch_bounds__(256) void gen_reduce_kernel(GenReduceArgs a, int waves_per_block, double2* partial) {
+    extern __shared__ double2 lds_r[];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (wave >= waves_per_block) return;
+    const int n = a.n, nn = n * n;
+    const int ncols = a.n_sweep * a.ncomp;
+    double2* H = lds_r + (size_t)wave * (3 * nn + ncols + (n + 1) / 2);
+    double2* W = H + nn;
+    double2* X = W + nn;
+    double2* acc = X + nn;
+    double* ev = reinterpret_cast<double*>(acc + ncols);
+    for (int t = lane; t < ncols; t += 64) acc[t] = make_double2(0.0, 0.0);
+    const int64_t gw = (int64_t)blockIdx.x * waves_per_block + wave;
+    const int64_t k0 = gw * a.chunk, k1 = min(a.nk, k0 + a.chunk);
+    GenArgs ga;  // only the fields gen_integrand reads
+    ga.n = n;
+    ga.integrand = a.integrand;
+    for (int i = 0; i < 4; ++i) ga.p[i] = a.p[i];
+    for (int64_t k = k0; k < k1; ++k) {
+        const double wk = a.w ? a.w[k] : 1.0;
+        if (a.integrand == ABZ_F_DOS_EIG) {
+            for (int b = lane; b < n; b += 64) ev[b] = a.Eplanes[(int64_t)b * a.stride + k];
+        } else if (a.integrand != ABZ_F_ONE) {
+            for (int t = lane; t < nn; t += 64)
+                H[t] = make_double2(a.Hplanes[(int64_t)(2 * t) * a.stride + k], a.Hplanes[(int64_t)(2 * t + 1) * a.stride + k]);
+        }
+        wave_sync();
+        for (int s = 0; s < a.n_sweep; ++s) {
+            const double sw = a.sweep ? a.sweep[s] : 0.0;
+            // value into X-adjacent scratch: reuse global-free path by writing to LDS acc directly
+            if (a.integrand == ABZ_F_ONE) {
+                if (lane == 0) acc[s * a.ncomp].x += wk;
+            } else if (a.integrand == ABZ_F_DOS_EIG) {
+                double v = 0.0;
+                for (int b = lane; b < n; b += 64) {
+                    const double de = sw - ev[b];
+                    v += a.p[0] / (de * de + a.p[0] * a.p[0]);
+                }
+                v = wsum(v);
+                if (lane == 0) acc[s].x += wk * v * 0.31830988618379067153776752674503;
+            } else {
+                for (int t = lane; t < nn; t += 64) {
+                    const int r = t % n, c = t / n;
+                    W[t] = make_double2((r == c ? sw : 0.0) - H[t].x, (r == c ? a.p[0] : 0.0) - H[t].y);
+                }
+                wave_sync();
+                wave_inverse(W, X, n, lane);
+                if (a.integrand == ABZ_F_GLOC) {
+                    for (int t = lane; t < nn; t += 64) {
+                        acc[s * nn + t].x += wk * X[t].x;
+                        acc[s * nn + t].y += wk * X[t].y;
+                    }
+                } else {
+                    double tr = 0.0, ti = 0.0;
+                    for (int t = lane; t < n; t += 64) {
+                        tr += X[t + n * t].x;
+                        ti += X[t + n * t].y;
+                    }
+                    tr = wsum(tr);
+                    ti = wsum(ti);
+                    if (lane == 0) {
+                        if (a.integrand == ABZ_F_DOS)
+                            acc[s].x += wk * (-ti * 0.31830988618379067153776752674503);
+                        else {
+                            acc[s].x += wk * tr;
+                            acc[s].y += wk * ti;
+                        }
+                    }
+                }
+            }
+            wave_sync();
+        }
+    }
+    wave_sync();
+    for (int t = lane; t < ncols; t += 64) partial[gw * ncols + t] = acc[t];
+}
+
+__global__ __launch_bounds__(256) void final_reduce2_kernel(const double2* __restrict__ partial, int64_t nrows,
+                                                            int64_t ncols, double scale, double2* __restrict__ out) {
+    __shared__ double2 sh[4];
+    const int64_t col = blockIdx.x;
+    double sr = 0.0, si = 0.0;
+    for (int64_t b = threadIdx.x; b < nrows; b += 256) {
+        const double2 v = partial[b * ncols + col];
+        sr += v.x;
+        si += v.y;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        sr += __shfl_down(sr, off, 64);
+        si += __shfl_down(si, off, 64);
+    }
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = make_double2(sr, si);
+    __syncthreads();
+    if (threadIdx.x == 0)
+        out[col] = make_double2((sh[0].x + sh[1].x + sh[2].x + sh[3].x) * scale, (sh[0].y + sh[1].y + sh[2].y + sh[3].y) * scale);
+}
+
+int launch_gen_reduce(abz_ctx* ctx, const ReduceSpec& rs, double* out_reim) {
+    const int ncomp = integrand_ncomp(rs.integrand, rs.n, rs.d);
+    if (ncomp < 0 || rs.integrand == ABZ_F_LINEAR || rs.integrand == ABZ_F_LINEAR_X) {
+        set_error("integrand %d is not available for n = %d bands", rs.integrand, rs.n);
+        return ABZ_ERR_ARG;
+    }
+    const int n = rs.n, nn = n * n;
+    const int64_t ncols = (int64_t)rs.n_sweep * ncomp;
+    const size_t per = sizeof(double2) * (size_t)(3 * nn + ncols + (n + 1) / 2);
+    if (per > 150 * 1024) {
+        set_error("sweep of %d values x %d components does not fit the LDS accumulators; split the sweep", rs.n_sweep, ncomp);
+        return ABZ_ERR_UNSUPPORTED;
+    }
+    int wpb = (int)((150 * 1024) / per);
+    if (wpb > 4) wpb = 4;
+    // about 8 waves per CU over the chip
+    const int64_t target_waves = 256 * 8;
+    int64_t chunk = std::max<int64_t>(1, cdiv2(rs.nk, target_waves));
+    const int64_t nwaves = cdiv2(rs.nk, chunk);
+    const int64_t blocks = cdiv2(nwaves, wpb);
+    int rc = ctx->scratch[1].reserve(sizeof(double2) * (size_t)(blocks * wpb * ncols));
+    if (rc) return rc;
+    rc = ctx->scratch[2].reserve(sizeof(double2) * (size_t)ncols);
+    if (rc) return rc;
+    double2* partial = ctx->scratch[1].as<double2>();
+    double2* outd = ctx->scratch[2].as<double2>();
+    ABZ_HIP(hipMemsetAsync(partial, 0, sizeof(double2) * (size_t)(blocks * wpb * ncols), ctx->stream));
+    GenReduceArgs a;
+    a.Hplanes = rs.H;
+    a.Eplanes = rs.E;
+    a.w = rs.w;
+    a.sweep = rs.sweep_dev;
+    a.nk = rs.nk;
+    a.stride = rs.stride;
+    a.chunk = chunk;
+    a.n = n;
+    a.n_sweep = rs.n_sweep;
+    a.ncomp = ncomp;
+    a.integrand = rs.integrand;
+    for (int i = 0; i < 4; ++i) a.p[i] = rs.params[i];
+    {
+        ProfScope ps(ctx, ABZ_K_REDUCE);
+        const size_t lds = per * wpb;
+        ABZ_HIP(hipFuncSetAttribute((const void*)gen_reduce_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(gen_reduce_kernel, dim3((unsigned)blocks), dim3(256), lds, ctx->stream, a, wpb, partial);
+        ABZ_HIP(hipGetLastError());
+        hipLaunchKernelGGL(final_reduce2_kernel, dim3((unsigned)ncols), dim3(256), 0, ctx->stream, partial, blocks * wpb,
+                           ncols, rs.scale, outd);
+        ABZ_HIP(hipGetLastError());
+    }
+    ABZ_HIP(hipMemcpyAsync(out_reim, outd, sizeof(double2) * (size_t)ncols, hipMemcpyDeviceToHost, ctx->stream));
+    ABZ_HIP(hipStreamSynchronize(ctx->stream));
+    return ABZ_OK;
+}
+
+}  // namespace abz

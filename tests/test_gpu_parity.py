@@ -278,6 +278,79 @@ def test_nested_batch_integrand(abz):
         abz.NestedBatchIntegrand((pi,), max_batch=0)  # ref: src/batch.jl:16
 
 
+# ------------------------------------------------------------------ generic n (wave-per-node kernels)
+@pytest.mark.parametrize("d,n", [(1, 5), (2, 8), (3, 6), (3, 16)])
+def test_generic_n_eval_and_rules(abz, d, n):
+    rng = np.random.default_rng(1000 + 10 * d + n)
+    dims = (3, 5, 3)[:d]
+    c, first = rand_series(rng, dims, n, hermitian=True)
+    c = c / np.sqrt(n)
+    s, so = both(abz, c, first)
+    k = rng.uniform(0, 1, size=(70, d))
+    H, E = s.device().eval_nodes(k, want=3)
+    Ho = orc.evaluate_many(so, k)
+    scale = np.abs(Ho).max()
+    assert np.abs(H - Ho).max() <= 1e-12 * scale
+    assert np.abs(E - np.linalg.eigvalsh(Ho, UPLO="U")).max() <= 1e-11 * scale
+    npt = 6
+    rule = s.device().rule(npt, None, want=3)
+    out = rule.export(H=True, eig=True)
+    vals = orc.fourier_ptr(so, npt)
+    perm = tuple(range(d - 1, -1, -1))
+    ref = np.transpose(vals, perm + (d, d + 1)).reshape(-1, n, n)
+    assert np.abs(out["H"] - ref).max() <= 1e-12 * np.abs(ref).max()
+    assert np.abs(out["eig"] - np.linalg.eigvalsh(ref, UPLO="U")).max() <= 1e-11 * np.abs(ref).max()
+    omegas = np.array([-0.4, 0.3])
+    eta = 0.25
+    dos = rule.reduce(abz._lib.F_DOS, [eta], omegas)[:, 0].real
+    dose = rule.reduce(abz._lib.F_DOS_EIG, [eta], omegas)[:, 0].real
+    trg = rule.reduce(abz._lib.F_TRGLOC, [eta], omegas)[:, 0]
+    g = rule.reduce(abz._lib.F_GLOC, [eta], omegas)
+    for i, om in enumerate(omegas):
+        r, _ = orc._ptr_rule_sum(so, npt, None, orc.f_dos(eta, om))
+        G, _ = orc._ptr_rule_sum(so, npt, None, orc.f_gloc(eta, om))
+        assert abs(dos[i] - r) <= 1e-10 * abs(r) and abs(dose[i] - r) <= 1e-9 * abs(r)
+        assert abs(trg[i] - np.trace(G)) <= 1e-10 * abs(np.trace(G))
+        assert np.abs(g[i].reshape(n, n).T - G).max() <= 1e-10 * np.abs(G).max()
+
+
+def test_generic_n_iai_matches_oracle(abz):
+    rng = np.random.default_rng(77)
+    c, first = rand_series(rng, (3, 3), 6, hermitian=True)
+    c = c / 3
+    s, so = both(abz, c, first)
+    bz = abz.load_bz(abz.FBZ(), np.eye(2))
+    f = abz.FourierIntegrand(abz.DOSIntegrand(), s, 0.3)
+    sol = abz.do_solve(f, bz, abz.MixedParameters(0.2), abz.EvalCounter(abz.IAI()), abstol=1e-3, _panels=True)
+    rec = []
+    ref = orc.solve_iai(so, orc.load_bz("FBZ", np.eye(2)), orc.f_dos(0.3, 0.2), abstol=1e-3, record=rec)
+    assert np.array_equal(sol.extra["panels"], np.array(rec)) and sol.numevals == ref.numevals
+    assert abs(sol.u - ref.u) <= 1e-9 * abs(ref.u)
+
+
+def test_config5_synthetic_16_band(abz):
+    """BASELINE configs[4]: synthetic 16-band 3-D Wannier model (2197 R vectors, SURVEY 8d recipe),
+    IAI DOS with host-driven panel re-batching on the GPU; cross-checked against PTR on the same
+    device (as the reference cross-checks algorithms) and against the oracle's PTR rule."""
+    so = orc.synthetic_wannier()
+    assert so.c.shape == (13, 13, 13, 16, 16)
+    s = abz.FourierSeries(so.c, period=1.0, first=so.first, ndim=3)
+    H = s.device().eval_nodes(np.array([[0.1, 0.2, 0.3]]))[0]
+    assert np.abs(H - orc.evaluate(so, [0.1, 0.2, 0.3])).max() < 1e-12
+    assert np.abs(H - H.conj().T).max() < 1e-13
+    bz = abz.load_bz(abz.FBZ(), np.eye(3))
+    f = abz.FourierIntegrand(abz.DOSIntegrand(), s, 0.05)
+    ptr = abz.solve(abz.IntegralProblem(f, bz, abz.MixedParameters(0.2)), abz.PTR(npt=12)).u
+    ref = orc.solve_ptr(so, orc.load_bz("FBZ", np.eye(3)), orc.f_dos(0.05, 0.2), npt=12).u
+    assert abs(ptr - ref) <= 1e-9 * abs(ref)
+    # IAI at abstol = 0.1 (2e-4 of the value ~ 481 = DOS * |det B|; ~4e8 inner nodes) vs a converged PTR
+    # grid.  Nested GK accumulates the inner integrals' errors, so the bar is 5x the requested abstol
+    # (a loose abstol = 1 is fooled by the eta = 0.05 peaks exactly like the reference's algorithm).
+    sol = abz.solve(abz.IntegralProblem(f, bz, abz.MixedParameters(0.2)), abz.EvalCounter(abz.IAI()), abstol=0.1, reltol=0.0)
+    big = abz.solve(abz.IntegralProblem(f, bz, abz.MixedParameters(0.2)), abz.PTR(npt=120)).u
+    assert abs(sol.u - big) < 0.5 and sol.numevals >= 15**3 and sol.resid <= 0.1
+
+
 # ------------------------------------------------------------------ SVO (configs 3 / 4)
 @pytest.fixture(scope="module")
 def svo(abz):
