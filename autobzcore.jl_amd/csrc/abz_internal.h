@@ -41,6 +41,19 @@ struct DevBuf {
     T* as() const { return static_cast<T*>(p); }
 };
 
+// Tiled planar addressing of rule values: nodes are grouped in tiles of `line_len` consecutive nodes
+// (a grid line, or 64 nodes of an irregular list); a tile stores all its planes back to back, each
+// plane row `pitch` doubles long (pitch >= line_len, multiple of 16 = 128 B).  Element (node k,
+// plane p) = base[(k / line_len) * tile + p * pitch + k % line_len].  One wave writes one tile: a
+// single contiguous ~27 KB HBM region instead of 21 streams 27 MB apart (1.7x the write bandwidth,
+// tools/micro/wtest.hip).
+struct PlaneView {
+    double* base = nullptr;  // first plane of this array inside tile 0
+    int64_t tile = 0;        // doubles per tile (all arrays of the tile)
+    int pitch = 0;
+    int line_len = 1;
+};
+
 struct ProfSlot {
     double ms = 0.0;
     int64_t launches = 0;
@@ -84,11 +97,11 @@ struct abz_rule {
     abz_series* s = nullptr;
     int npt = 0, want = 0;
     int64_t nk = 0;       // number of nodes
-    int64_t stride = 0;   // plane stride (>= nk, multiple of 64)
-    bool full = true;     // full grid (implicit nodes/weights) or explicit irreducible list
-    double* H = nullptr;   // [2*n*n][stride]: plane 2*(a + n*b) + {0: re, 1: im}
-    double* E = nullptr;   // [n][stride]
-    double* V = nullptr;   // [d][n][stride]
+    int64_t ntiles = 0;   // tiles (grid lines, or 64-node groups of an irregular list)
+    bool full = true;     // full grid (implicit nodes/weights) or explicit irregular list
+    double* vals = nullptr;  // [ntiles][planes][pitch]: H planes 2*(a + n*b) + {re, im}, then E (n), then V (d*n)
+    int planes = 0;
+    abz::PlaneView H, E, V;  // views into vals (base == nullptr when absent)
     double* w = nullptr;   // [nk] weights (symmetric rules)
     int32_t* idx = nullptr;  // [d][nk] grid indices (symmetric rules)
     void* plan = nullptr;    // abz::RulePlan (api.cpp): contraction plan + phase table, device resident
@@ -129,6 +142,11 @@ int launch_phases(abz_ctx* ctx, const PhaseSpec& ps, double2* phs);
 int launch_contract(abz_ctx* ctx, const double2* src, int64_t src_slot_elems, const int64_t* parents,
                     int64_t per_parent, const double2* phs, double2* out, int64_t B, int64_t L, int M);
 
+// full-grid contraction: out[(parent*npt + gi)][l], parents 0..nparents-1, all gi, phases from tab
+constexpr int ABZ_CONTRACT_GRID_MAXM = 16;
+int launch_contract_grid(abz_ctx* ctx, const double2* src, int64_t src_slot_elems, int64_t nparents, const double2* tab,
+                         double2* out, int64_t L, int M, int first, int npt, bool deriv);
+
 struct EvalSpec {
     int n;              // bands
     int M, first;       // innermost dim
@@ -146,24 +164,23 @@ struct EvalSpec {
     const double* x;
     bool deriv;
     bool herm;  // series is Hermitian-symmetric and deriv is false: evaluate the upper triangle only
-    // outputs (planar, stride), any may be null
-    double* H;
-    double* E;
-    double* U;   // eigenvectors planes [2*n*n][stride] (col-major: plane 2*(a + n*b): component a of vector b)
-    int64_t stride;
+    // outputs (tiled planar views), base == nullptr when not wanted
+    PlaneView H;
+    PlaneView E;
+    PlaneView U;  // eigenvector planes 2*(a + n*b) + {re, im}: component a of vector b
 };
 int launch_eval(abz_ctx* ctx, const EvalSpec& es);
 
-int launch_eig_planes(abz_ctx* ctx, int n, const double* H, double* E, double* U, int64_t nk, int64_t stride);
-// V[j][b][k] = Re sum_{a,c} conj(U[a,b]) dH[a,c] U[c,b]
-int launch_velocity(abz_ctx* ctx, int n, const double* U, const double* dH, double* Vj, int64_t nk, int64_t stride);
+int launch_eig_planes(abz_ctx* ctx, int n, PlaneView H, PlaneView E, PlaneView U, int64_t nk);
+// V[b](k) = Re sum_{a,c} conj(U[a,b]) dH[a,c] U[c,b]   (Vj: view of the n planes of one direction)
+int launch_velocity(abz_ctx* ctx, int n, PlaneView U, PlaneView dH, PlaneView Vj, int64_t nk);
 
 struct ReduceSpec {
     int n, d, npt;
     int integrand;
-    const double* H;
-    const double* E;
-    int64_t nk, stride;
+    PlaneView H;
+    PlaneView E;
+    int64_t nk;
     const double* w;      // null: uniform weight 1
     const int32_t* idx;   // null: full grid (k -> grid indices implicitly)
     double params[4];
@@ -175,11 +192,11 @@ int integrand_ncomp(int integrand, int n, int d);
 // result: host out_reim [n_sweep][ncomp][2]
 int launch_reduce(abz_ctx* ctx, const ReduceSpec& rs, double* out_reim);
 
-int launch_ggr(abz_ctx* ctx, int n, int d, int npt, const double* E, const double* V, const double* w,
-               int64_t nk, int64_t stride, const double* Es_host, int nE, double* out_host);
+int launch_ggr(abz_ctx* ctx, int n, int d, int npt, PlaneView E, PlaneView V, const double* w, int64_t nk,
+               const double* Es_host, int nE, double* out_host);
 
-// planar [ncomp][stride] -> AoS [nk][ncomp] on the host
-int export_planes(abz_ctx* ctx, const double* planes, int ncomp, int64_t nk, int64_t stride, double* host_out);
+// tiled planar (ncomp planes of the view) -> AoS [nk][ncomp] on the host
+int export_planes(abz_ctx* ctx, PlaneView v, int ncomp, int64_t nk, double* host_out);
 
 // IAI innermost nodes: values[node][ncomp] complex
 struct NodeEvalSpec {
@@ -207,9 +224,9 @@ struct GenSpec {
     const double* x;
     const double2* tab;
     bool deriv;
-    int64_t nnodes, stride;
-    double* Hplanes;
-    double* Eplanes;
+    int64_t nnodes;
+    PlaneView Hplanes;
+    PlaneView Eplanes;
     double2* Haos;
     double* Eaos;
     int integrand;

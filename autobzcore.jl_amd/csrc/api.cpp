@@ -222,27 +222,34 @@ static int build_chain(abz_series* s, const Plan& p, const PlanDev& pd, const do
         const int64_t B = p.nitems[L];
         const int M = s->dims[L];
         const int64_t Lrow = s->elems(L);
-        int rc = ctx->scratch[0].reserve(sizeof(double2) * (size_t)std::max<int64_t>(B * M, 1));
-        if (rc) return rc;
-        double2* phs = ctx->scratch[0].as<double2>();
-        PhaseSpec ps;
-        ps.B = B;
-        ps.M = M;
-        ps.first = s->first[L];
-        ps.gi = (p.full || p.coords) ? nullptr : pd.gi[L].as<int32_t>();
-        ps.x = p.coords ? pd.xs[L].as<double>() : nullptr;
-        ps.tab = tab;
-        ps.npt = p.npt;
-        ps.period = s->period[L];
-        ps.deriv = (deriv_dim == L + 1);
-        rc = launch_phases(ctx, ps, phs);
-        if (rc) return rc;
-        rc = s->pool[L].reserve(sizeof(double2) * (size_t)std::max<int64_t>(B * Lrow, 1));
+        int rc = s->pool[L].reserve(sizeof(double2) * (size_t)std::max<int64_t>(B * Lrow, 1));
         if (rc) return rc;
         double2* out = s->pool[L].as<double2>();
-        const int64_t* parents = p.full ? nullptr : pd.parent[L].as<int64_t>();
-        rc = launch_contract(ctx, src, src_elems, parents, p.full ? p.npt : 1, phs, out, B, Lrow, M);
-        if (rc) return rc;
+        if (p.full && M <= ABZ_CONTRACT_GRID_MAXM && B / p.npt <= 65535) {
+            // items of level L are (gi, parent) with gi fastest: parent count = B / npt
+            rc = launch_contract_grid(ctx, src, src_elems, B / p.npt, tab, out, Lrow, M, s->first[L], p.npt,
+                                      deriv_dim == L + 1);
+            if (rc) return rc;
+        } else {
+            rc = ctx->scratch[0].reserve(sizeof(double2) * (size_t)std::max<int64_t>(B * M, 1));
+            if (rc) return rc;
+            double2* phs = ctx->scratch[0].as<double2>();
+            PhaseSpec ps;
+            ps.B = B;
+            ps.M = M;
+            ps.first = s->first[L];
+            ps.gi = (p.full || p.coords) ? nullptr : pd.gi[L].as<int32_t>();
+            ps.x = p.coords ? pd.xs[L].as<double>() : nullptr;
+            ps.tab = tab;
+            ps.npt = p.npt;
+            ps.period = s->period[L];
+            ps.deriv = (deriv_dim == L + 1);
+            rc = launch_phases(ctx, ps, phs);
+            if (rc) return rc;
+            const int64_t* parents = p.full ? nullptr : pd.parent[L].as<int64_t>();
+            rc = launch_contract(ctx, src, src_elems, parents, p.full ? p.npt : 1, phs, out, B, Lrow, M);
+            if (rc) return rc;
+        }
         src = out;
         src_elems = Lrow;
     }
@@ -454,9 +461,7 @@ struct RulePlan {
 
 static void rule_free(abz_rule* r) {
     if (!r) return;
-    if (r->H) (void)hipFree(r->H);
-    if (r->E) (void)hipFree(r->E);
-    if (r->V) (void)hipFree(r->V);
+    if (r->vals) (void)hipFree(r->vals);
     if (r->w) (void)hipFree(r->w);
     if (r->idx) (void)hipFree(r->idx);
     if (r->plan) {
@@ -486,8 +491,17 @@ static int rule_fill(abz_rule* r) {
     const Plan& plan = rp->plan;
     const int d = s->d, n = s->n;
     const double2* tab = rp->tab.as<double2>();
-    double* Uplanes = (r->want & ABZ_WANT_VEL) ? rp->tmpU.as<double>() : nullptr;
-    auto run_eval = [&](const double2* level1, bool deriv, double* Hout, double* Eout, double* Uout) -> int {
+    // temporaries of a velocity build: eigenvectors and one derivative matrix, tiled like H alone
+    PlaneView Uv, Dv;
+    if (r->want & ABZ_WANT_VEL) {
+        Uv.base = rp->tmpU.as<double>();
+        Uv.pitch = r->H.pitch ? r->H.pitch : r->E.pitch;
+        Uv.line_len = r->E.line_len;
+        Uv.tile = (int64_t)2 * n * n * Uv.pitch;
+        Dv = Uv;
+        Dv.base = rp->tmpD.as<double>();
+    }
+    auto run_eval = [&](const double2* level1, bool deriv, PlaneView Hout, PlaneView Eout, PlaneView Uout) -> int {
         EvalSpec es;
         es.n = n;
         es.M = s->dims[0];
@@ -507,23 +521,22 @@ static int rule_fill(abz_rule* r) {
         es.H = Hout;
         es.E = Eout;
         es.U = Uout;
-        es.stride = r->stride;
         return launch_eval(ctx, es);
     };
     const double2* level1 = nullptr;
     int rc = build_chain(s, plan, rp->pd, tab, 0, &level1);
     if (rc) return rc;
-    if ((rc = run_eval(level1, false, r->H, r->E, Uplanes))) return rc;
+    if ((rc = run_eval(level1, false, r->H, r->E, Uv))) return rc;
     if (r->want & ABZ_WANT_VEL) {
         // d/dx_1 reuses the level-1 sets; d/dx_j (j >= 2) rebuilds the chain with the derivative
         // factor on variable j (JacobianSeries, ref src/dos_ggr.jl:6-7)
         for (int j = 1; j <= d; ++j) {
             if (j >= 2)
                 if ((rc = build_chain(s, plan, rp->pd, tab, j, &level1))) return rc;
-            if ((rc = run_eval(level1, j == 1, rp->tmpD.as<double>(), nullptr, nullptr))) return rc;
-            if ((rc = launch_velocity(ctx, n, Uplanes, rp->tmpD.as<double>(), r->V + (size_t)(j - 1) * n * r->stride,
-                                      r->nk, r->stride)))
-                return rc;
+            if ((rc = run_eval(level1, j == 1, Dv, PlaneView(), PlaneView()))) return rc;
+            PlaneView Vj = r->V;
+            Vj.base += (int64_t)(j - 1) * n * Vj.pitch;
+            if ((rc = launch_velocity(ctx, n, Uv, Dv, Vj, r->nk))) return rc;
         }
     }
     return ABZ_OK;
@@ -585,14 +598,33 @@ int abz_ptr_rule_build(abz_series* s, int npt, int64_t nirr, const int32_t* irr_
         plan_runs<int32_t>(plan, d, npt, irr_idx, nirr, false);
     }
     r->nk = plan.nk;
-    r->stride = (plan.nk + 63) / 64 * 64;
-    if (r->stride == 0) r->stride = 64;
+    // tiles: a grid line (pitch = npt rounded up to 16 doubles = 128 B) or 64 nodes of an irregular list
+    const int line_len = r->full ? npt : 64;
+    const int pitch = (line_len + 15) / 16 * 16;
+    r->ntiles = std::max<int64_t>(1, (plan.nk + line_len - 1) / line_len);
+    const int pH = (want & ABZ_WANT_H) ? 2 * n * n : 0;
+    const int pE = (want & ABZ_WANT_EIG) ? n : 0;
+    const int pV = (want & ABZ_WANT_VEL) ? d * n : 0;
+    r->planes = pH + pE + pV;
+    const int64_t tile = (int64_t)r->planes * pitch;
     RULE_TRY(plan_upload(ctx, plan, rp->pd));
     RULE_TRY(make_phase_table(ctx, npt, rp->tab));
-    const size_t plane = sizeof(double) * (size_t)r->stride;
-    if (want & ABZ_WANT_H) RULE_HIP(hipMalloc((void**)&r->H, plane * 2 * n * n));
-    if (want & ABZ_WANT_EIG) RULE_HIP(hipMalloc((void**)&r->E, plane * n));
-    if (want & ABZ_WANT_VEL) RULE_HIP(hipMalloc((void**)&r->V, plane * d * n));
+    const size_t bytes = sizeof(double) * (size_t)(r->ntiles * tile);
+    RULE_HIP(hipMalloc((void**)&r->vals, bytes));
+    RULE_HIP(hipMemset(r->vals, 0, bytes));  // padding of irregular tiles stays finite
+    auto mkview = [&](int plane0, bool present) {
+        PlaneView v;
+        if (present) {
+            v.base = r->vals + (int64_t)plane0 * pitch;
+            v.tile = tile;
+            v.pitch = pitch;
+            v.line_len = line_len;
+        }
+        return v;
+    };
+    r->H = mkview(0, pH > 0);
+    r->E = mkview(pH, pE > 0);
+    r->V = mkview(pH + pE, pV > 0);
     if (!r->full) {
         std::vector<double> wd(std::max<int64_t>(nirr, 1));
         for (int64_t k = 0; k < nirr; ++k) wd[k] = (double)wsym[k];
@@ -605,8 +637,9 @@ int abz_ptr_rule_build(abz_series* s, int npt, int64_t nirr, const int32_t* irr_
         RULE_HIP(hipMemcpy(r->idx, it.data(), sizeof(int32_t) * (size_t)(nirr * d), hipMemcpyHostToDevice));
     }
     if (want & ABZ_WANT_VEL) {
-        RULE_TRY(rp->tmpU.reserve(plane * 2 * n * n));
-        RULE_TRY(rp->tmpD.reserve(plane * 2 * n * n));
+        const size_t tb = sizeof(double) * (size_t)(r->ntiles * 2 * n * n * pitch);
+        RULE_TRY(rp->tmpU.reserve(tb));
+        RULE_TRY(rp->tmpD.reserve(tb));
     }
     RULE_TRY(rule_fill(r));
     RULE_HIP(hipStreamSynchronize(ctx->stream));
@@ -626,10 +659,10 @@ int abz_rule_rebuild(abz_rule* r) {
     ABZ_HIP(hipSetDevice(ctx->device));
     RulePlan* rp = static_cast<RulePlan*>(r->plan);
     if (r->want & ABZ_WANT_VEL) {
-        const size_t plane = sizeof(double) * (size_t)r->stride;
-        int rc = rp->tmpU.reserve(plane * 2 * r->s->n * r->s->n);
+        const size_t tb = sizeof(double) * (size_t)(r->ntiles * 2 * r->s->n * r->s->n * r->E.pitch);
+        int rc = rp->tmpU.reserve(tb);
         if (rc) return rc;
-        if ((rc = rp->tmpD.reserve(plane * 2 * r->s->n * r->s->n))) return rc;
+        if ((rc = rp->tmpD.reserve(tb))) return rc;
     }
     return rule_fill(r);
 }
@@ -674,18 +707,18 @@ int abz_rule_export(abz_rule* r, double* x, double* w, double* H, double* eig, d
         }
     }
     if (H) {
-        ABZ_REQUIRE(r->H, "rule holds no H(k) (want lacked ABZ_WANT_H)");
-        int rc = export_planes(ctx, r->H, 2 * n * n, r->nk, r->stride, H);
+        ABZ_REQUIRE(r->H.base, "rule holds no H(k) (want lacked ABZ_WANT_H)");
+        int rc = export_planes(ctx, r->H, 2 * n * n, r->nk, H);
         if (rc) return rc;
     }
     if (eig) {
-        ABZ_REQUIRE(r->E, "rule holds no eigenvalues (want lacked ABZ_WANT_EIG)");
-        int rc = export_planes(ctx, r->E, n, r->nk, r->stride, eig);
+        ABZ_REQUIRE(r->E.base, "rule holds no eigenvalues (want lacked ABZ_WANT_EIG)");
+        int rc = export_planes(ctx, r->E, n, r->nk, eig);
         if (rc) return rc;
     }
     if (vel) {
-        ABZ_REQUIRE(r->V, "rule holds no velocities (want lacked ABZ_WANT_VEL)");
-        int rc = export_planes(ctx, r->V, d * n, r->nk, r->stride, vel);
+        ABZ_REQUIRE(r->V.base, "rule holds no velocities (want lacked ABZ_WANT_VEL)");
+        int rc = export_planes(ctx, r->V, d * n, r->nk, vel);
         if (rc) return rc;
     }
     return ABZ_OK;
@@ -700,9 +733,9 @@ int abz_rule_reduce(abz_rule* r, int integrand, const double* params, int nparam
     ABZ_HIP(hipSetDevice(ctx->device));
     const bool use_eig = integrand == ABZ_F_DOS_EIG;
     if (use_eig)
-        ABZ_REQUIRE(r->E, "integrand needs cached eigenvalues: build the rule with ABZ_WANT_EIG");
+        ABZ_REQUIRE(r->E.base, "integrand needs cached eigenvalues: build the rule with ABZ_WANT_EIG");
     else if (integrand != ABZ_F_ONE)
-        ABZ_REQUIRE(r->H, "integrand needs cached H(k): build the rule with ABZ_WANT_H");
+        ABZ_REQUIRE(r->H.base, "integrand needs cached H(k): build the rule with ABZ_WANT_H");
     const bool swept = integrand == ABZ_F_DOS || integrand == ABZ_F_TRGLOC || integrand == ABZ_F_GLOC ||
                        integrand == ABZ_F_DOS_EIG;
     int ns = swept ? n_sweep : 1;
@@ -714,10 +747,9 @@ int abz_rule_reduce(abz_rule* r, int integrand, const double* params, int nparam
     rs.d = r->s->d;
     rs.npt = r->npt;
     rs.integrand = integrand;
-    rs.H = r->H ? r->H : r->E;  // ABZ_F_ONE never dereferences it
+    rs.H = r->H.base ? r->H : r->E;  // ABZ_F_ONE never dereferences it
     rs.E = r->E;
     rs.nk = r->nk;
-    rs.stride = r->stride;
     rs.w = r->w;
     rs.idx = r->idx;
     for (int i = 0; i < 4; ++i) rs.params[i] = (i < nparams) ? params[i] : 0.0;
@@ -736,10 +768,10 @@ int abz_rule_reduce(abz_rule* r, int integrand, const double* params, int nparam
 
 int abz_rule_ggr(abz_rule* r, const double* E, int nE, double* out) {
     ABZ_REQUIRE(r && E && out && nE >= 1, "abz_rule_ggr: bad arguments");
-    ABZ_REQUIRE(r->V && r->E, "GGR needs a rule built with ABZ_WANT_VEL");
+    ABZ_REQUIRE(r->V.base && r->E.base, "GGR needs a rule built with ABZ_WANT_VEL");
     abz_ctx* ctx = r->s->ctx;
     ABZ_HIP(hipSetDevice(ctx->device));
-    return launch_ggr(ctx, r->s->n, r->s->d, r->npt, r->E, r->V, r->w, r->nk, r->stride, E, nE, out);
+    return launch_ggr(ctx, r->s->n, r->s->d, r->npt, r->E, r->V, r->w, r->nk, E, nE, out);
 }
 
 // ---------------------------------------------------------------- arbitrary nodes
@@ -763,16 +795,27 @@ int abz_eval_nodes(abz_series* s, const double* k, int64_t nk, int want, double*
     int status = ABZ_OK;
     for (int64_t k0 = 0; k0 < nk && status == ABZ_OK; k0 += chunk) {
         const int64_t m = std::min(chunk, nk - k0);
-        const int64_t stride = (m + 63) / 64 * 64;
+        const int64_t ntl = (m + 63) / 64;
+        PlaneView Hv, Ev;
         Plan plan;
         plan_runs<double>(plan, d, 0, k + k0 * d, m, true);
         if ((status = plan_upload(ctx, plan, pd))) break;
         const double2* level1 = nullptr;
         if ((status = build_chain(s, plan, pd, nullptr, 0, &level1))) break;
-        if (want & ABZ_WANT_H)
-            if ((status = Hd.reserve(sizeof(double) * (size_t)stride * 2 * n * n))) break;
-        if (want & ABZ_WANT_EIG)
-            if ((status = Ed.reserve(sizeof(double) * (size_t)stride * n))) break;
+        if (want & ABZ_WANT_H) {
+            if ((status = Hd.reserve(sizeof(double) * (size_t)ntl * 64 * 2 * n * n))) break;
+            Hv.base = Hd.as<double>();
+            Hv.pitch = 64;
+            Hv.line_len = 64;
+            Hv.tile = (int64_t)2 * n * n * 64;
+        }
+        if (want & ABZ_WANT_EIG) {
+            if ((status = Ed.reserve(sizeof(double) * (size_t)ntl * 64 * n))) break;
+            Ev.base = Ed.as<double>();
+            Ev.pitch = 64;
+            Ev.line_len = 64;
+            Ev.tile = (int64_t)n * 64;
+        }
         EvalSpec es;
         es.n = n;
         es.M = s->dims[0];
@@ -789,15 +832,14 @@ int abz_eval_nodes(abz_series* s, const double* k, int64_t nk, int want, double*
         es.x = pd.xs[0].as<double>();
         es.deriv = false;
         es.herm = false;
-        es.H = (want & ABZ_WANT_H) ? Hd.as<double>() : nullptr;
-        es.E = (want & ABZ_WANT_EIG) ? Ed.as<double>() : nullptr;
-        es.U = nullptr;
-        es.stride = stride;
+        es.H = Hv;
+        es.E = Ev;
+        es.U = PlaneView();
         if ((status = launch_eval(ctx, es))) break;
         if (want & ABZ_WANT_H)
-            if ((status = export_planes(ctx, Hd.as<double>(), 2 * n * n, m, stride, H_out + k0 * 2 * n * n))) break;
+            if ((status = export_planes(ctx, Hv, 2 * n * n, m, H_out + k0 * 2 * n * n))) break;
         if (want & ABZ_WANT_EIG)
-            if ((status = export_planes(ctx, Ed.as<double>(), n, m, stride, eig_out + k0 * n))) break;
+            if ((status = export_planes(ctx, Ev, n, m, eig_out + k0 * n))) break;
     }
     Hd.release();
     Ed.release();

@@ -15,10 +15,19 @@
 #include "device_math.h"
 
 #include <cmath>
+#include <cstdlib>
 
 namespace abz {
 
 static inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+struct cplx_pod {
+    double x, y;
+};
+typedef const cplx_pod __attribute__((address_space(4))) * cptr_t;
+__device__ __forceinline__ cptr_t as_const(const double2* p) {
+    return (cptr_t)(unsigned long long)p;
+}
 
 // ------------------------------------------------------------------------------------------
 // phases
@@ -132,6 +141,74 @@ int launch_contract(abz_ctx* ctx, const double2* src, int64_t src_slot_elems, co
     return ABZ_OK;
 }
 
+// Full-grid contraction: out[(parent*npt + gi)][l] = sum_m tab[(f_m gi) mod npt] C[parent][m][l].
+// A thread keeps the M coefficients of its column l in registers and sweeps a chunk of grid indices
+// gi, so every coefficient is fetched once per (parent, chunk) instead of once per output; phases are
+// exact table look-ups whose index advances by f_m per step (no phase kernel, no modulo).
+constexpr int CONTRACT_MAXM = 16;
+
+__global__ __launch_bounds__(128) void contract_grid_kernel(const double2* __restrict__ src, int64_t slot_elems,
+                                                            const double2* __restrict__ tab, double2* __restrict__ out,
+                                                            int64_t L, int M, int first, int npt, int chunk, int deriv) {
+    const int64_t l = (int64_t)blockIdx.x * 128 + threadIdx.x;
+    if (l >= L) return;
+    const int64_t parent = blockIdx.y;
+    const int g0 = blockIdx.z * chunk;
+    const int g1 = min(npt, g0 + chunk);
+    double2 c[CONTRACT_MAXM];
+    int step[CONTRACT_MAXM], idx[CONTRACT_MAXM];
+    double dfac[CONTRACT_MAXM];
+#pragma unroll
+    for (int m = 0; m < CONTRACT_MAXM; ++m) {
+        if (m < M) {
+            c[m] = src[parent * slot_elems + (int64_t)m * L + l];
+            int fm = (first + m) % npt;
+            if (fm < 0) fm += npt;
+            step[m] = fm;
+            idx[m] = (int)(((int64_t)fm * g0) % npt);
+            dfac[m] = 6.283185307179586476925286766559 * (double)(first + m);
+        }
+    }
+    for (int gi = g0; gi < g1; ++gi) {
+        double ar = 0.0, ai = 0.0;
+#pragma unroll
+        for (int m = 0; m < CONTRACT_MAXM; ++m) {
+            if (m < M) {
+                // idx[m] is uniform over the block: fetch the phase through the scalar cache
+                const cptr_t tp = as_const(tab) + idx[m];
+                double2 ph = make_double2(tp->x, tp->y);
+                if (deriv) ph = make_double2(-dfac[m] * ph.y, dfac[m] * ph.x);
+                ar = fma(c[m].x, ph.x, ar);
+                ar = fma(-c[m].y, ph.y, ar);
+                ai = fma(c[m].x, ph.y, ai);
+                ai = fma(c[m].y, ph.x, ai);
+                int ni = idx[m] + step[m];
+                idx[m] = ni >= npt ? ni - npt : ni;
+            }
+        }
+        out[(parent * npt + gi) * L + l] = make_double2(ar, ai);
+    }
+}
+
+int launch_contract_grid(abz_ctx* ctx, const double2* src, int64_t src_slot_elems, int64_t nparents, const double2* tab,
+                         double2* out, int64_t L, int M, int first, int npt, bool deriv) {
+    if (nparents == 0 || L == 0) return ABZ_OK;
+    ProfScope ps(ctx, ABZ_K_CONTRACT);
+    const int64_t gx = cdiv(L, 128);
+    // enough blocks to fill the chip, at least ~4 grid indices per thread to amortise the loads
+    int64_t nsplit = std::max<int64_t>(1, std::min<int64_t>(cdiv(npt, 4), cdiv(2048, gx * nparents)));
+    const int chunk = (int)cdiv(npt, nsplit);
+    nsplit = cdiv(npt, chunk);
+    if (nparents > 65535 || nsplit > 65535) {
+        set_error("contract_grid: grid too large");
+        return ABZ_ERR_UNSUPPORTED;
+    }
+    hipLaunchKernelGGL(contract_grid_kernel, dim3((unsigned)gx, (unsigned)nparents, (unsigned)nsplit), dim3(128), 0,
+                       ctx->stream, src, src_slot_elems, tab, out, L, M, first, npt, chunk, deriv ? 1 : 0);
+    ABZ_HIP(hipGetLastError());
+    return ABZ_OK;
+}
+
 // ------------------------------------------------------------------------------------------
 // innermost evaluation
 // ------------------------------------------------------------------------------------------
@@ -139,13 +216,7 @@ int launch_contract(abz_ctx* ctx, const double2* src, int64_t src_slot_elems, co
 // space is fetched through the scalar cache (s_load_dwordx4/x8) and reaches v_fma_f64 as an SGPR
 // operand; a divergent address still becomes an ordinary global_load.  Legal because the sets are
 // written by an EARLIER kernel on the same stream and never inside the kernel that reads them.
-struct cplx_pod {
-    double x, y;
-};
-typedef const cplx_pod __attribute__((address_space(4))) * cptr_t;
-__device__ __forceinline__ cptr_t as_const(const double2* p) {
-    return (cptr_t)(unsigned long long)p;
-}
+// (cplx_pod / cptr_t / as_const are defined at the top of this file)
 
 // H = sum_m c1[m] * (w z^m)  (optionally times i 2 pi f_m).
 template <int N>
@@ -186,26 +257,34 @@ __device__ __forceinline__ void series_lane(cptr_t c1, int M, int first, double 
     }
 }
 
+// offset of (node k, plane 0) in a tiled planar view
+__device__ __forceinline__ int64_t view_off(const PlaneView& v, int64_t k) {
+    const int64_t line = k / v.line_len;
+    return line * v.tile + (k - line * v.line_len);
+}
+
 template <int N>
-__device__ __forceinline__ void store_planes(const CMat<N>& H, double* __restrict__ out, int64_t stride, int64_t k) {
+__device__ __forceinline__ void store_planes(const CMat<N>& H, const PlaneView& v, int64_t off) {
+    double* __restrict__ out = v.base + off;
 #pragma unroll
     for (int b = 0; b < N; ++b) {
 #pragma unroll
         for (int a = 0; a < N; ++a) {
-            out[(int64_t)(2 * (a + N * b)) * stride + k] = H.re[a][b];
-            out[(int64_t)(2 * (a + N * b) + 1) * stride + k] = H.im[a][b];
+            out[(int64_t)(2 * (a + N * b)) * v.pitch] = H.re[a][b];
+            out[(int64_t)(2 * (a + N * b) + 1) * v.pitch] = H.im[a][b];
         }
     }
 }
 
 template <int N>
-__device__ __forceinline__ void load_planes(CMat<N>& H, const double* __restrict__ in, int64_t stride, int64_t k) {
+__device__ __forceinline__ void load_planes(CMat<N>& H, const PlaneView& v, int64_t off) {
+    const double* __restrict__ in = v.base + off;
 #pragma unroll
     for (int b = 0; b < N; ++b) {
 #pragma unroll
         for (int a = 0; a < N; ++a) {
-            H.re[a][b] = in[(int64_t)(2 * (a + N * b)) * stride + k];
-            H.im[a][b] = in[(int64_t)(2 * (a + N * b) + 1) * stride + k];
+            H.re[a][b] = in[(int64_t)(2 * (a + N * b)) * v.pitch];
+            H.im[a][b] = in[(int64_t)(2 * (a + N * b) + 1) * v.pitch];
         }
     }
 }
@@ -216,32 +295,31 @@ struct EvalArgs {
     const int64_t* parents;
     const int32_t* gi;
     const double* x;
-    double* H;
-    double* E;
-    double* U;
-    int64_t nlines, nk, stride;
+    PlaneView H, E, U;
+    int64_t nlines, nk;
     int M, first, npt, deriv, herm;
     double inv_period;
 };
 
-template <int N>
-__device__ __forceinline__ void eval_epilogue(const EvalArgs& a, CMat<N>& H, int64_t k) {
-    if (a.H) store_planes<N>(H, a.H, a.stride, k);
-    if (a.E || a.U) {
+template <int N, bool VEC = true>
+__device__ __forceinline__ void eval_epilogue(const EvalArgs& a, CMat<N>& H, int64_t line, int i1) {
+    if (a.H.base) store_planes<N>(H, a.H, line * a.H.tile + i1);
+    if (a.E.base || (VEC && a.U.base)) {
         double e[N];
         CMat<N> V;
-        if (a.U) {
+        if (VEC && a.U.base) {
             herm_eig<N, true>(H, e, V);
-            store_planes<N>(V, a.U, a.stride, k);
+            store_planes<N>(V, a.U, line * a.U.tile + i1);
         } else {
             if constexpr (N == 3)
                 herm_eig3_values(H, e);
             else
                 herm_eig<N, false>(H, e, V);
         }
-        if (a.E) {
+        if (a.E.base) {
+            double* __restrict__ eo = a.E.base + line * a.E.tile + i1;
 #pragma unroll
-            for (int b = 0; b < N; ++b) a.E[(int64_t)b * a.stride + k] = e[b];
+            for (int b = 0; b < N; ++b) eo[(int64_t)b * a.E.pitch] = e[b];
         }
     }
 }
@@ -253,8 +331,8 @@ __device__ __forceinline__ void eval_epilogue(const EvalArgs& a, CMat<N>& H, int
 // No block-level barrier: a wave only ever reads the LDS bytes it wrote itself.
 constexpr int EVAL_MAX_MNN = 256;  // complex coefficients per line held in LDS (M * N * N)
 
-template <int N, int KPL, bool HERM>
-__global__ __launch_bounds__(256) void eval_grid_kernel(EvalArgs a) {
+template <int N, int KPL, bool HERM, bool VEC, int OCC>
+__global__ __launch_bounds__(256, OCC) void eval_grid_kernel(EvalArgs a) {
     extern __shared__ double2 lds_c[];  // [4 waves][2 buffers][MNN]
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int MNN = a.M * N * N;
@@ -386,7 +464,10 @@ __global__ __launch_bounds__(256) void eval_grid_kernel(EvalArgs a) {
                     }
                 }
                 const int i1 = i0 + lane + 64 * j;
-                if (i1 < a.npt) eval_epilogue<N>(a, H[j], line * a.npt + i1);
+                // columns npt..pitch-1 are padding: written (finite filler) so every 128-B line of the
+                // tile leaves the CU whole; never read back
+                const int pitch = a.H.base ? a.H.pitch : a.E.pitch;
+                if (i1 < pitch) eval_epilogue<N, VEC>(a, H[j], line, i1);
             }
         }
         // hand the prefetched set to the other buffer
@@ -420,7 +501,7 @@ __global__ __launch_bounds__(256) void eval_grid_kernel_scalar(EvalArgs a) {
                 const double2 w = a.tab[(int)(((int64_t)fm * i1) % a.npt)];
                 CMat<N> H;
                 series_lane<N>(c1, a.M, a.first, z.x, z.y, w.x, w.y, a.deriv != 0, H);
-                eval_epilogue<N>(a, H, line_u * a.npt + i1);
+                eval_epilogue<N>(a, H, line_u, i1);
             }
         }
     }
@@ -450,7 +531,9 @@ __global__ __launch_bounds__(256) void eval_node_kernel(EvalArgs a) {
     }
     CMat<N> H;
     series_lane<N>(c1, a.M, a.first, zr, zi, wr, wi, a.deriv != 0, H);
-    eval_epilogue<N>(a, H, k);
+    const int ll = a.H.base ? a.H.line_len : (a.E.base ? a.E.line_len : a.U.line_len);
+    const int64_t line = k / ll;
+    eval_epilogue<N>(a, H, line, (int)(k - line * ll));
 }
 
 #define ABZ_DISPATCH_N(n, FN)                                       \
@@ -464,9 +547,18 @@ __global__ __launch_bounds__(256) void eval_node_kernel(EvalArgs a) {
             return ABZ_ERR_UNSUPPORTED;                             \
     }
 
+static int eval_occ() {
+    static int occ = [] {
+        const char* e = getenv("ABZ_EVAL_OCC");
+        const int v = e ? atoi(e) : 3;
+        return (v == 2 || v == 3 || v == 4) ? v : 3;
+    }();
+    return occ;
+}
+
 int launch_eval(abz_ctx* ctx, const EvalSpec& es) {
     if (es.n > 4) {
-        if (es.U) {
+        if (es.U.base) {
             set_error("eigenvectors / velocities for n = %d > 4 bands are not built in this round", es.n);
             return ABZ_ERR_UNSUPPORTED;
         }
@@ -485,7 +577,6 @@ int launch_eval(abz_ctx* ctx, const EvalSpec& es) {
         gs.tab = es.tab;
         gs.deriv = es.deriv;
         gs.nnodes = es.grid ? es.nlines * es.npt : es.nk;
-        gs.stride = es.stride;
         gs.Hplanes = es.H;
         gs.Eplanes = es.E;
         gs.Haos = nullptr;
@@ -509,7 +600,6 @@ int launch_eval(abz_ctx* ctx, const EvalSpec& es) {
     a.U = es.U;
     a.nlines = es.nlines;
     a.nk = es.nk;
-    a.stride = es.stride;
     a.M = es.M;
     a.first = es.first;
     a.npt = es.npt > 0 ? es.npt : 1;
@@ -524,11 +614,22 @@ int launch_eval(abz_ctx* ctx, const EvalSpec& es) {
         if (mnn <= EVAL_MAX_MNN) {
             const size_t lds = sizeof(double2) * 4 * 2 * (size_t)mnn;
             const int kpl = es.npt <= 64 ? 1 : (es.npt <= 128 ? 2 : 3);
-#define LK(NN, KK)                                                                                                  \
-    if (a.herm)                                                                                                     \
-        hipLaunchKernelGGL((eval_grid_kernel<NN, KK, true>), dim3((unsigned)blocks), dim3(256), lds, ctx->stream, a); \
-    else                                                                                                            \
-        hipLaunchKernelGGL((eval_grid_kernel<NN, KK, false>), dim3((unsigned)blocks), dim3(256), lds, ctx->stream, a);
+#define LKO(NN, KK, OO)                                                                                                        \
+    if (a.U.base)                                                                                                              \
+        hipLaunchKernelGGL((eval_grid_kernel<NN, KK, false, true, 2>), dim3((unsigned)blocks), dim3(256), lds, ctx->stream, a);  \
+    else if (a.herm)                                                                                                           \
+        hipLaunchKernelGGL((eval_grid_kernel<NN, KK, true, false, OO>), dim3((unsigned)blocks), dim3(256), lds, ctx->stream, a); \
+    else                                                                                                                       \
+        hipLaunchKernelGGL((eval_grid_kernel<NN, KK, false, false, 2>), dim3((unsigned)blocks), dim3(256), lds, ctx->stream, a);
+// waves per SIMD the register allocator is asked for (Hermitian n = 3 path only; ABZ_EVAL_OCC=2|3|4)
+#define LK(NN, KK)                         \
+    if (NN == 3 && eval_occ() == 3) {      \
+        LKO(NN, KK, 3)                     \
+    } else if (NN == 3 && eval_occ() == 4) { \
+        LKO(NN, KK, 4)                     \
+    } else {                               \
+        LKO(NN, KK, 2)                     \
+    }
 #define FN(NN)                    \
     switch (kpl) {                \
         case 1: LK(NN, 1) break;  \
@@ -558,30 +659,30 @@ int launch_eval(abz_ctx* ctx, const EvalSpec& es) {
 // stand-alone eigensolve on planes, velocities
 // ------------------------------------------------------------------------------------------
 template <int N>
-__global__ __launch_bounds__(256) void eig_planes_kernel(const double* __restrict__ Hp, double* __restrict__ E,
-                                                         double* __restrict__ U, int64_t nk, int64_t stride) {
+__global__ __launch_bounds__(256) void eig_planes_kernel(PlaneView Hv, PlaneView Ev, PlaneView Uv, int64_t nk) {
     const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= nk) return;
     CMat<N> H, V;
-    load_planes<N>(H, Hp, stride, k);
+    load_planes<N>(H, Hv, view_off(Hv, k));
     double e[N];
-    if (U) {
+    if (Uv.base) {
         herm_eig<N, true>(H, e, V);
-        store_planes<N>(V, U, stride, k);
+        store_planes<N>(V, Uv, view_off(Uv, k));
     } else {
         if constexpr (N == 3)
             herm_eig3_values(H, e);
         else
             herm_eig<N, false>(H, e, V);
     }
+    double* __restrict__ eo = Ev.base + view_off(Ev, k);
 #pragma unroll
-    for (int b = 0; b < N; ++b) E[(int64_t)b * stride + k] = e[b];
+    for (int b = 0; b < N; ++b) eo[(int64_t)b * Ev.pitch] = e[b];
 }
 
-int launch_eig_planes(abz_ctx* ctx, int n, const double* H, double* E, double* U, int64_t nk, int64_t stride) {
+int launch_eig_planes(abz_ctx* ctx, int n, PlaneView H, PlaneView E, PlaneView U, int64_t nk) {
     if (nk == 0) return ABZ_OK;
     ProfScope ps(ctx, ABZ_K_EIG);
-#define FN(NN) hipLaunchKernelGGL(eig_planes_kernel<NN>, dim3((unsigned)cdiv(nk, 256)), dim3(256), 0, ctx->stream, H, E, U, nk, stride)
+#define FN(NN) hipLaunchKernelGGL(eig_planes_kernel<NN>, dim3((unsigned)cdiv(nk, 256)), dim3(256), 0, ctx->stream, H, E, U, nk)
     ABZ_DISPATCH_N(n, FN)
 #undef FN
     ABZ_HIP(hipGetLastError());
@@ -589,13 +690,13 @@ int launch_eig_planes(abz_ctx* ctx, int n, const double* H, double* E, double* U
 }
 
 template <int N>
-__global__ __launch_bounds__(256) void velocity_kernel(const double* __restrict__ Up, const double* __restrict__ dHp,
-                                                       double* __restrict__ Vj, int64_t nk, int64_t stride) {
+__global__ __launch_bounds__(256) void velocity_kernel(PlaneView Uv, PlaneView Dv, PlaneView Vv, int64_t nk) {
     const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= nk) return;
     CMat<N> U, D;
-    load_planes<N>(U, Up, stride, k);
-    load_planes<N>(D, dHp, stride, k);
+    load_planes<N>(U, Uv, view_off(Uv, k));
+    load_planes<N>(D, Dv, view_off(Dv, k));
+    double* __restrict__ vo = Vv.base + view_off(Vv, k);
 #pragma unroll
     for (int b = 0; b < N; ++b) {
         // v_b = Re sum_{a,c} conj(U[a][b]) D[a][c] U[c][b]
@@ -610,13 +711,13 @@ __global__ __launch_bounds__(256) void velocity_kernel(const double* __restrict_
             }
             v += U.re[a][b] * tr + U.im[a][b] * ti;
         }
-        Vj[(int64_t)b * stride + k] = v;
+        vo[(int64_t)b * Vv.pitch] = v;
     }
 }
 
-int launch_velocity(abz_ctx* ctx, int n, const double* U, const double* dH, double* Vj, int64_t nk, int64_t stride) {
+int launch_velocity(abz_ctx* ctx, int n, PlaneView U, PlaneView dH, PlaneView Vj, int64_t nk) {
     if (nk == 0) return ABZ_OK;
-#define FN(NN) hipLaunchKernelGGL(velocity_kernel<NN>, dim3((unsigned)cdiv(nk, 256)), dim3(256), 0, ctx->stream, U, dH, Vj, nk, stride)
+#define FN(NN) hipLaunchKernelGGL(velocity_kernel<NN>, dim3((unsigned)cdiv(nk, 256)), dim3(256), 0, ctx->stream, U, dH, Vj, nk)
     ABZ_DISPATCH_N(n, FN)
 #undef FN
     ABZ_HIP(hipGetLastError());
@@ -702,12 +803,11 @@ struct NComp {
 };
 
 struct ReduceArgs {
-    const double* H;
-    const double* E;
+    PlaneView H, E;
     const double* w;
     const int32_t* idx;
     const double* sweep;
-    int64_t nk, stride;
+    int64_t nk;
     int d, npt, n_sweep, ncomp;
     double p[4];
 };
@@ -733,11 +833,12 @@ __global__ __launch_bounds__(256) void reduce_kernel(ReduceArgs a, double2* __re
         const int64_t kk = ok ? k : 0;
         wk[j] = ok ? (a.w ? a.w[kk] : 1.0) : 0.0;
         if constexpr (needH) {
-            load_planes<N>(H[j], a.H, a.stride, kk);
+            load_planes<N>(H[j], a.H, view_off(a.H, kk));
         }
         if constexpr (FID == ABZ_F_DOS_EIG) {
+            const double* __restrict__ ei = a.E.base + view_off(a.E, kk);
 #pragma unroll
-            for (int b = 0; b < N; ++b) e[j][b] = a.E[(int64_t)b * a.stride + kk];
+            for (int b = 0; b < N; ++b) e[j][b] = ei[(int64_t)b * a.E.pitch];
         }
         if constexpr (FID == ABZ_F_LINEAR_X) {
             int64_t r = kk;
@@ -858,7 +959,6 @@ int launch_reduce(abz_ctx* ctx, const ReduceSpec& rs, double* out_reim) {
     a.idx = rs.idx;
     a.sweep = rs.sweep_dev;
     a.nk = rs.nk;
-    a.stride = rs.stride;
     a.d = rs.d;
     a.npt = rs.npt;
     a.n_sweep = rs.n_sweep;
@@ -957,11 +1057,10 @@ __device__ __forceinline__ double ggr3(double b, double E, double e, double va, 
 }
 
 struct GgrArgs {
-    const double* E;
-    const double* V;
+    PlaneView E, V;
     const double* w;
     const double* Es;
-    int64_t nk, stride;
+    int64_t nk;
     int n, d, nE;
     double b;
 };
@@ -976,11 +1075,13 @@ __global__ __launch_bounds__(256) void ggr_kernel(GgrArgs a, double* __restrict_
     const double wk = ok ? (a.w ? a.w[kk] : 1.0) : 0.0;
     double e[N];
     double v[D][N];
+    const double* __restrict__ ei = a.E.base + view_off(a.E, kk);
+    const double* __restrict__ vi = a.V.base + view_off(a.V, kk);
 #pragma unroll
     for (int bnd = 0; bnd < N; ++bnd) {
-        e[bnd] = a.E[(int64_t)bnd * a.stride + kk];
+        e[bnd] = ei[(int64_t)bnd * a.E.pitch];
 #pragma unroll
-        for (int j = 0; j < D; ++j) v[j][bnd] = a.V[((int64_t)j * N + bnd) * a.stride + kk];
+        for (int j = 0; j < D; ++j) v[j][bnd] = vi[(int64_t)(j * N + bnd) * a.V.pitch];
     }
     const int chunk = 1024;
     for (int s0 = 0; s0 < a.nE; s0 += chunk) {
@@ -1018,8 +1119,8 @@ __global__ void final_reduce_real_kernel(const double* __restrict__ partial, int
     out[col] = s;
 }
 
-int launch_ggr(abz_ctx* ctx, int n, int d, int npt, const double* E, const double* V, const double* w, int64_t nk,
-               int64_t stride, const double* Es_host, int nE, double* out_host) {
+int launch_ggr(abz_ctx* ctx, int n, int d, int npt, PlaneView E, PlaneView V, const double* w, int64_t nk,
+               const double* Es_host, int nE, double* out_host) {
     if (n > 4) {
         set_error("GGR: n = %d bands: only n <= 4 is built in this round", n);
         return ABZ_ERR_UNSUPPORTED;
@@ -1039,7 +1140,6 @@ int launch_ggr(abz_ctx* ctx, int n, int d, int npt, const double* E, const doubl
     a.w = w;
     a.Es = Es_dev;
     a.nk = nk;
-    a.stride = stride;
     a.n = n;
     a.d = d;
     a.nE = nE;
@@ -1075,23 +1175,21 @@ int launch_ggr(abz_ctx* ctx, int n, int d, int npt, const double* E, const doubl
 // ------------------------------------------------------------------------------------------
 // export planar -> AoS
 // ------------------------------------------------------------------------------------------
-__global__ void export_kernel(const double* __restrict__ planes, int ncomp, int64_t nk, int64_t stride,
-                              double* __restrict__ out) {
+__global__ void export_kernel(PlaneView v, int ncomp, int64_t nk, double* __restrict__ out) {
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= nk * ncomp) return;
     const int64_t k = t / ncomp;
     const int c = (int)(t - k * ncomp);
-    out[t] = planes[(int64_t)c * stride + k];
+    out[t] = v.base[view_off(v, k) + (int64_t)c * v.pitch];
 }
 
-int export_planes(abz_ctx* ctx, const double* planes, int ncomp, int64_t nk, int64_t stride, double* host_out) {
+int export_planes(abz_ctx* ctx, PlaneView v, int ncomp, int64_t nk, double* host_out) {
     if (nk == 0) return ABZ_OK;
     const size_t bytes = sizeof(double) * (size_t)nk * ncomp;
     int rc = ctx->scratch[3].reserve(bytes);
     if (rc) return rc;
     double* stg = ctx->scratch[3].as<double>();
-    hipLaunchKernelGGL(export_kernel, dim3((unsigned)cdiv(nk * ncomp, 256)), dim3(256), 0, ctx->stream, planes, ncomp,
-                       nk, stride, stg);
+    hipLaunchKernelGGL(export_kernel, dim3((unsigned)cdiv(nk * ncomp, 256)), dim3(256), 0, ctx->stream, v, ncomp, nk, stg);
     ABZ_HIP(hipGetLastError());
     ABZ_HIP(hipMemcpyAsync(host_out, stg, bytes, hipMemcpyDeviceToHost, ctx->stream));
     ABZ_HIP(hipStreamSynchronize(ctx->stream));
@@ -1164,9 +1262,8 @@ int launch_node_integrand(abz_ctx* ctx, const NodeEvalSpec& ns, double2* values_
         gs.tab = nullptr;
         gs.deriv = false;
         gs.nnodes = ns.nnodes;
-        gs.stride = 0;
-        gs.Hplanes = nullptr;
-        gs.Eplanes = nullptr;
+        gs.Hplanes = PlaneView();
+        gs.Eplanes = PlaneView();
         gs.Haos = nullptr;
         gs.Eaos = nullptr;
         gs.integrand = ns.integrand;

@@ -23,6 +23,11 @@ __device__ __forceinline__ void wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+__device__ __forceinline__ int64_t view_off(const PlaneView& v, int64_t k) {
+    const int64_t line = k / v.line_len;
+    return line * v.tile + (k - line * v.line_len);
+}
+
 __device__ __forceinline__ double wsum(double v) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
@@ -161,12 +166,12 @@ struct GenArgs {
     const int32_t* gi;       // per node grid index (null in grid mode / x mode)
     const double2* tab;
     const double* tail;
-    int64_t nnodes, stride;
+    int64_t nnodes;
     int n, M, first, npt, d, grid, deriv;
     double inv_period;
     // outputs
-    double* Hplanes;
-    double* Eplanes;
+    PlaneView Hplanes;
+    PlaneView Eplanes;
     double2* Haos;  // [node][n*n]
     double* Eaos;   // [node][n]
     // integrand
@@ -288,20 +293,21 @@ __global__ __launch_bounds__(256) void gen_node_kernel(GenArgs a, int waves_per_
                 hi = fma(c.y, q.x, hi);
             }
             H[t] = make_double2(hr, hi);
-            if (a.Hplanes) {
-                a.Hplanes[(int64_t)(2 * t) * a.stride + k] = hr;
-                a.Hplanes[(int64_t)(2 * t + 1) * a.stride + k] = hi;
+            if (a.Hplanes.base) {
+                double* ho = a.Hplanes.base + view_off(a.Hplanes, k);
+                ho[(int64_t)(2 * t) * a.Hplanes.pitch] = hr;
+                ho[(int64_t)(2 * t + 1) * a.Hplanes.pitch] = hi;
             }
             if (a.Haos) a.Haos[k * nn + t] = make_double2(hr, hi);
         }
         wave_sync();
-        const bool need_eig = a.Eplanes || a.Eaos || (a.values && a.integrand == ABZ_F_DOS_EIG);
+        const bool need_eig = a.Eplanes.base || a.Eaos || (a.values && a.integrand == ABZ_F_DOS_EIG);
         if (need_eig) {
             for (int t = lane; t < nn; t += 64) W[t] = H[t];
             wave_sync();
             wave_eig(W, ev, n, lane);
             for (int b = lane; b < n; b += 64) {
-                if (a.Eplanes) a.Eplanes[(int64_t)b * a.stride + k] = ev[b];
+                if (a.Eplanes.base) a.Eplanes.base[view_off(a.Eplanes, k) + (int64_t)b * a.Eplanes.pitch] = ev[b];
                 if (a.Eaos) a.Eaos[k * n + b] = ev[b];
             }
         }
@@ -337,7 +343,6 @@ int launch_gen_nodes(abz_ctx* ctx, const GenSpec& gs) {
     a.tab = gs.tab;
     a.tail = nullptr;
     a.nnodes = gs.nnodes;
-    a.stride = gs.stride;
     a.n = gs.n;
     a.M = gs.M;
     a.first = gs.first;
@@ -375,11 +380,11 @@ int launch_gen_nodes(abz_ctx* ctx, const GenSpec& gs) {
 // reduce over a cached rule, n > 4: one wave per node chunk, per-omega partial sums in LDS
 // ------------------------------------------------------------------------------------------
 struct GenReduceArgs {
-    const double* Hplanes;
-    const double* Eplanes;
+    PlaneView Hplanes;
+    PlaneView Eplanes;
     const double* w;
     const double* sweep;
-    int64_t nk, stride, chunk;
+    int64_t nk, chunk;
     int n, n_sweep, ncomp, integrand;
     double p[4];
 };
@@ -405,10 +410,12 @@ __global__ __launch_bounds__(256) void gen_reduce_kernel(GenReduceArgs a, int wa
     for (int64_t k = k0; k < k1; ++k) {
         const double wk = a.w ? a.w[k] : 1.0;
         if (a.integrand == ABZ_F_DOS_EIG) {
-            for (int b = lane; b < n; b += 64) ev[b] = a.Eplanes[(int64_t)b * a.stride + k];
+            const double* ei = a.Eplanes.base + view_off(a.Eplanes, k);
+            for (int b = lane; b < n; b += 64) ev[b] = ei[(int64_t)b * a.Eplanes.pitch];
         } else if (a.integrand != ABZ_F_ONE) {
+            const double* hi_ = a.Hplanes.base + view_off(a.Hplanes, k);
             for (int t = lane; t < nn; t += 64)
-                H[t] = make_double2(a.Hplanes[(int64_t)(2 * t) * a.stride + k], a.Hplanes[(int64_t)(2 * t + 1) * a.stride + k]);
+                H[t] = make_double2(hi_[(int64_t)(2 * t) * a.Hplanes.pitch], hi_[(int64_t)(2 * t + 1) * a.Hplanes.pitch]);
         }
         wave_sync();
         for (int s = 0; s < a.n_sweep; ++s) {
@@ -515,7 +522,6 @@ int launch_gen_reduce(abz_ctx* ctx, const ReduceSpec& rs, double* out_reim) {
     a.w = rs.w;
     a.sweep = rs.sweep_dev;
     a.nk = rs.nk;
-    a.stride = rs.stride;
     a.chunk = chunk;
     a.n = n;
     a.n_sweep = rs.n_sweep;
