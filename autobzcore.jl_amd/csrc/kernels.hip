@@ -150,40 +150,39 @@ constexpr int CONTRACT_MAXM = 16;
 __global__ __launch_bounds__(128) void contract_grid_kernel(const double2* __restrict__ src, int64_t slot_elems,
                                                             const double2* __restrict__ tab, double2* __restrict__ out,
                                                             int64_t L, int M, int first, int npt, int chunk, int deriv) {
+    extern __shared__ double2 phs[];  // [chunk][M] phases of this block's grid indices
+    const int g0 = blockIdx.z * chunk;
+    const int g1 = min(npt, g0 + chunk);
+    for (int t = threadIdx.x; t < (g1 - g0) * M; t += 128) {
+        const int gi = g0 + t / M, m = t % M;
+        int fm = (first + m) % npt;
+        if (fm < 0) fm += npt;
+        double2 ph = tab[(int)(((int64_t)fm * gi) % npt)];
+        if (deriv) {
+            const double f = 6.283185307179586476925286766559 * (double)(first + m);
+            ph = make_double2(-f * ph.y, f * ph.x);
+        }
+        phs[t] = ph;
+    }
+    __syncthreads();
     const int64_t l = (int64_t)blockIdx.x * 128 + threadIdx.x;
     if (l >= L) return;
     const int64_t parent = blockIdx.y;
-    const int g0 = blockIdx.z * chunk;
-    const int g1 = min(npt, g0 + chunk);
     double2 c[CONTRACT_MAXM];
-    int step[CONTRACT_MAXM], idx[CONTRACT_MAXM];
-    double dfac[CONTRACT_MAXM];
 #pragma unroll
-    for (int m = 0; m < CONTRACT_MAXM; ++m) {
-        if (m < M) {
-            c[m] = src[parent * slot_elems + (int64_t)m * L + l];
-            int fm = (first + m) % npt;
-            if (fm < 0) fm += npt;
-            step[m] = fm;
-            idx[m] = (int)(((int64_t)fm * g0) % npt);
-            dfac[m] = 6.283185307179586476925286766559 * (double)(first + m);
-        }
-    }
+    for (int m = 0; m < CONTRACT_MAXM; ++m)
+        if (m < M) c[m] = src[parent * slot_elems + (int64_t)m * L + l];
     for (int gi = g0; gi < g1; ++gi) {
+        const double2* __restrict__ p = phs + (gi - g0) * M;
         double ar = 0.0, ai = 0.0;
 #pragma unroll
         for (int m = 0; m < CONTRACT_MAXM; ++m) {
             if (m < M) {
-                // idx[m] is uniform over the block: fetch the phase through the scalar cache
-                const cptr_t tp = as_const(tab) + idx[m];
-                double2 ph = make_double2(tp->x, tp->y);
-                if (deriv) ph = make_double2(-dfac[m] * ph.y, dfac[m] * ph.x);
+                const double2 ph = p[m];  // LDS broadcast
                 ar = fma(c[m].x, ph.x, ar);
                 ar = fma(-c[m].y, ph.y, ar);
                 ai = fma(c[m].x, ph.y, ai);
                 ai = fma(c[m].y, ph.x, ai);
-                int ni = idx[m] + step[m];
-                idx[m] = ni >= npt ? ni - npt : ni;
             }
         }
         out[(parent * npt + gi) * L + l] = make_double2(ar, ai);
@@ -196,15 +195,16 @@ int launch_contract_grid(abz_ctx* ctx, const double2* src, int64_t src_slot_elem
     ProfScope ps(ctx, ABZ_K_CONTRACT);
     const int64_t gx = cdiv(L, 128);
     // enough blocks to fill the chip, at least ~4 grid indices per thread to amortise the loads
-    int64_t nsplit = std::max<int64_t>(1, std::min<int64_t>(cdiv(npt, 4), cdiv(2048, gx * nparents)));
+    int64_t nsplit = std::max<int64_t>(1, std::min<int64_t>(cdiv(npt, 4), cdiv(4096, gx * nparents)));
     const int chunk = (int)cdiv(npt, nsplit);
     nsplit = cdiv(npt, chunk);
     if (nparents > 65535 || nsplit > 65535) {
         set_error("contract_grid: grid too large");
         return ABZ_ERR_UNSUPPORTED;
     }
-    hipLaunchKernelGGL(contract_grid_kernel, dim3((unsigned)gx, (unsigned)nparents, (unsigned)nsplit), dim3(128), 0,
-                       ctx->stream, src, src_slot_elems, tab, out, L, M, first, npt, chunk, deriv ? 1 : 0);
+    hipLaunchKernelGGL(contract_grid_kernel, dim3((unsigned)gx, (unsigned)nparents, (unsigned)nsplit), dim3(128),
+                       sizeof(double2) * (size_t)chunk * M, ctx->stream, src, src_slot_elems, tab, out, L, M, first, npt,
+                       chunk, deriv ? 1 : 0);
     ABZ_HIP(hipGetLastError());
     return ABZ_OK;
 }
