@@ -127,8 +127,10 @@ class Context:
     def sync(self):
         check(lib().abz_ctx_sync(self.h))
 
-    def prof_enable(self, on=True):
-        check(lib().abz_prof_enable(self.h, 1 if on else 0))
+    def prof_enable(self, on=True, kernels=None):
+        """Record HIP events around the library's launches; `kernels`: iterable of K_* ids to restrict to."""
+        mask = 0 if not on else (1 if kernels is None else sum(1 << (k + 1) for k in kernels))
+        check(lib().abz_prof_enable(self.h, mask))
 
     def prof_reset(self):
         check(lib().abz_prof_reset(self.h))

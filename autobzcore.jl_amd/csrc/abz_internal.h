@@ -65,7 +65,7 @@ struct ProfSlot {
 struct abz_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
-    bool prof = false;
+    unsigned prof = 0;  // bit k set: record HIP events around launches of kernel id k
     abz::ProfSlot prof_slots[ABZ_K_COUNT];
     std::vector<hipEvent_t> event_pool;
     abz::DevBuf scratch[6];  // phases, partials, staging...

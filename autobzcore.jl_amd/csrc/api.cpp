@@ -53,7 +53,7 @@ void DevBuf::release() {
 }
 
 ProfScope::ProfScope(abz_ctx* c, int kernel_id) : ctx(c), id(kernel_id) {
-    if (!ctx->prof) return;
+    if (!(ctx->prof & (1u << id))) return;
     auto get = [&]() {
         hipEvent_t e = nullptr;
         if (!ctx->event_pool.empty()) {
@@ -70,7 +70,7 @@ ProfScope::ProfScope(abz_ctx* c, int kernel_id) : ctx(c), id(kernel_id) {
 }
 
 ProfScope::~ProfScope() {
-    if (!ctx->prof || !e0 || !e1) return;
+    if (!(ctx->prof & (1u << id)) || !e0 || !e1) return;
     (void)hipEventRecord(e1, ctx->stream);
     ctx->prof_slots[id].pending.emplace_back(e0, e1);
 }
@@ -331,7 +331,8 @@ int abz_ctx_sync(abz_ctx* ctx) {
 
 int abz_prof_enable(abz_ctx* ctx, int on) {
     ABZ_REQUIRE(ctx, "null ctx");
-    ctx->prof = on != 0;
+    // on = 1: every kernel id; on > 1: bit mask (bit k+1 selects kernel id k), e.g. 1 << (ABZ_K_EVAL + 1)
+    ctx->prof = on == 0 ? 0u : (on == 1 ? 0xffffffffu : ((unsigned)on >> 1));
     return ABZ_OK;
 }
 

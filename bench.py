@@ -115,10 +115,15 @@ def main():
     mine = omegas_all[rank::world]
 
     # ---------------- Phase A: K rebuilds
-    for _ in range(a.warmup):
+    # contraction kernels: timed in the warm-up loop (events only around them)
+    ctx.prof_enable(True, kernels=[L.K_CONTRACT])
+    ctx.prof_reset()
+    for _ in range(max(a.warmup, 1)):
         rule.rebuild()
     ctx.sync()
-    ctx.prof_enable(True)
+    con_ms, con_n = ctx.prof_read(L.K_CONTRACT)
+    # timed region: HIP events only around the dominant (Fourier-eval) kernel
+    ctx.prof_enable(True, kernels=[L.K_EVAL])
     ctx.prof_reset()
     barrier()
     t0 = time.perf_counter()
@@ -128,13 +133,12 @@ def main():
     barrier()
     tA = time.perf_counter() - t0
     eval_ms, eval_n = ctx.prof_read(L.K_EVAL)
-    con_ms, con_n = ctx.prof_read(L.K_CONTRACT)
     ctx.prof_enable(False)
 
     # ---------------- Phase B: K fused sweeps over this rank's omegas (matrix-cached, reference-faithful)
     for _ in range(max(1, a.warmup // 2)):
         rule.reduce(L.F_DOS, [a.eta], mine)
-    ctx.prof_enable(True)
+    ctx.prof_enable(True, kernels=[L.K_REDUCE])
     ctx.prof_reset()
     barrier()
     t0 = time.perf_counter()

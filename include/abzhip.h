@@ -82,7 +82,9 @@ int abz_device_count(int* n);
 int abz_ctx_create(int device, abz_ctx** out);
 int abz_ctx_destroy(abz_ctx* ctx);
 int abz_ctx_sync(abz_ctx* ctx);
-/* HIP-event timing of the library's own launches on the context's stream. */
+/* HIP-event timing of the library's own launches on the context's stream.  on = 0: off; 1: every
+ * kernel id; otherwise a mask with bit (k+1) selecting ABZ_K_<k> (timing one kernel keeps the event
+ * records out of the gaps between the others). */
 int abz_prof_enable(abz_ctx* ctx, int on);
 int abz_prof_reset(abz_ctx* ctx);
 int abz_prof_read(abz_ctx* ctx, int kernel_id, double* total_ms, int64_t* launches);
