@@ -29,6 +29,21 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 measured copy)
 
 
+def pmc_traffic(npt):
+    """HBM bytes per launch of the Fourier-eval kernel from the committed rocprofv3 PMC passes
+    (profiles/r01_traffic.json, written by tools/collect_profiles.sh: WRITE_SIZE and FETCH_SIZE in
+    separate --pmc runs, FETCH_SIZE doubled per the gfx950 correction).  None if not collected for
+    this grid size: counters cannot be read from inside an un-profiled bench run."""
+    path = os.path.join(ROOT, "profiles", "r01_traffic.json")
+    try:
+        t = json.load(open(path))
+        if int(t.get("npt", -1)) == int(npt):
+            return float(t["hbm_bytes_per_launch"])
+    except Exception:
+        pass
+    return None
+
+
 def cpu_baseline(npt_sample, n_omega_sample, s):
     """Time the C restatement of the reference's CPU path (oracle/abz_oracle.c, kind 'port') on the
     host cores on a BOUNDED sample of the same workload: the same SVO series on a smaller PTR grid."""
@@ -194,7 +209,8 @@ def main():
             "kpoint_omega_per_sec": world * len(mine) * nk * a.steps / tB,
             "job_seconds_256_omega_est": tA / a.steps + (tB / a.steps) * (256 / max(len(mine) * world, 1)) / 1.0 if world == 1 else None,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(npt),
+                         "traffic_note": "HBM bytes per launch from rocprofv3 PMC passes (profiles/r01_traffic.json); algorithmic bytes per launch = nk*168",
                          "kernel": "eval_grid_kernel<3> (Fourier-eval + fused eig)",
                          "algorithmic_bytes_per_kpoint": 16 * n * n + 8 * n,
                          "avg_launch_ms": eval_ms / max(eval_n, 1), "launches": eval_n,

@@ -187,17 +187,23 @@ def symptr_rule(npt: int, d: int, syms: Sequence[np.ndarray]):
     N = npt**d
     strides = npt ** np.arange(d, dtype=np.int64)  # column-major: i1 fastest
     wflat = np.zeros(N, dtype=np.int64)
-    chunk = 1 << 18
+    chunk = 1 << 20
+    symsT = np.ascontiguousarray(np.transpose(symsi, (0, 2, 1)))
     for lo in range(0, N, chunk):
         lin = np.arange(lo, min(N, lo + chunk), dtype=np.int64)
         v = (lin[:, None] // strides[None, :]) % npt  # (n, d) grid indices i1..id
-        img = np.einsum("sab,nb->sna", symsi, v) % npt  # (ns, n, d)
-        ilin = img @ strides  # (ns, n) column-major linear index of every image
-        ilin.sort(axis=0)
-        rep = ilin[0]  # first member of the orbit in column-major order
-        osize = 1 + np.count_nonzero(np.diff(ilin, axis=0), axis=0)
+        # first member of the orbit in column-major order = min over the images' linear indices
+        rep = None
+        for ST in symsT:
+            il = ((v @ ST) % npt) @ strides
+            rep = il if rep is None else np.minimum(rep, il)
         isrep = rep == lin
-        wflat[lin[isrep]] = osize[isrep]
+        vr = v[isrep]
+        if len(vr):
+            img = np.einsum("sab,nb->sna", symsi, vr) % npt  # (ns, nrep, d): orbits of the representatives only
+            ilin = img @ strides
+            ilin.sort(axis=0)
+            wflat[lin[isrep]] = 1 + np.count_nonzero(np.diff(ilin, axis=0), axis=0)
     wsym = wflat.reshape((npt,) * d, order="F")
     nsym = int(np.count_nonzero(wflat))
     order_flat = np.where(wflat > 0, np.cumsum(wflat > 0), 0)  # 1-based output position
@@ -257,6 +263,22 @@ def fourier_symptr(s: FourierSeries, npt: int, syms):
     if nsym:
         rec(s, d, (), int(flags[d - 1]))
     return w, xs, (vals[:, 0, 0] if s.scalar else vals), idxs
+
+
+def fourier_symptr_fast(s: FourierSeries, npt: int, syms):
+    """Same output as fourier_symptr (order, weights, nodes, values) without the Python recursion:
+    irreducible nodes from symptr_rule in column-major order, values by evaluate_many.  Used for the
+    large grids of the GGR pins; equality with the traversal is tested on small grids."""
+    d = s.d
+    wsym, _, nsym = symptr_rule(npt, d, syms)
+    wf = wsym.reshape(-1, order="F")
+    lin = np.flatnonzero(wf)
+    strides = npt ** np.arange(d, dtype=np.int64)
+    idx = (lin[:, None] // strides[None, :]) % npt
+    u = ptrpoints(npt)
+    xs = u[idx]
+    vals = np.concatenate([np.asarray(evaluate_many(s, xs[i:i + 65536])) for i in range(0, len(xs), 65536)]) if len(xs) else np.zeros((0,))
+    return wf[lin], xs, vals, idx
 
 
 def npt_sequence_params(a=1.0, nmin=50, nmax=1000, n0=6.0, dn=math.log(10)):
@@ -773,7 +795,7 @@ def get_ggr_data(s: FourierSeries, npt: int, syms):
         Vl = [np.transpose(v, perm + (d, d + 1)).reshape(-1, s.n, s.n) for v in Vs]
         w = np.ones(len(Hl))
     else:
-        w, _, Hl, idx = fourier_symptr(s, npt, syms)
+        w, _, Hl, idx = fourier_symptr_fast(s, npt, syms)
         Vl = []
         u = ptrpoints(npt)
         for ds in ders:

@@ -124,6 +124,10 @@ def test_symmetric_rule_matches_full_grid():
     # column-major ordering of the output
     lin = idx[:, 0] + 6 * idx[:, 1] + 36 * idx[:, 2]
     assert np.all(np.diff(lin) > 0)
+    # the vectorised variant used for large grids gives the same list
+    w2, xs2, vals2, idx2 = orc.fourier_symptr_fast(s, 6, bz.syms)
+    assert np.array_equal(w, w2) and np.array_equal(idx, idx2) and np.array_equal(xs, xs2)
+    assert np.allclose(vals, vals2, atol=1e-14)
 
 
 # ---------------------------------------------------------------- BZ algorithms on FourierIntegrand

@@ -34,4 +34,10 @@ for k, ent in summary.items():
         ent["hbm_bytes_per_launch"] = 1024.0 * (ent["WRITE_SIZE"] + 2.0 * ent["FETCH_SIZE"])
         ent["hbm_bytes_note"] = "1024*(WRITE_SIZE + 2*FETCH_SIZE): gfx950 FETCH_SIZE reports half of wide coalesced reads (MI355X_MICROARCH.md)"
 json.dump(summary, open(os.path.join(dst, f"{tag}_pmc_summary.json"), "w"), indent=1, sort_keys=True)
+for k, ent in summary.items():
+    if "eval_grid_kernel" in k and "hbm_bytes_per_launch" in ent:
+        json.dump({"kernel": k, "npt": 150, "tag": tag, "hbm_bytes_per_launch": ent["hbm_bytes_per_launch"],
+                   "WRITE_SIZE_KB": ent["WRITE_SIZE"], "FETCH_SIZE_KB": ent["FETCH_SIZE"], "note": ent["hbm_bytes_note"],
+                   "algorithmic_bytes_per_launch": 150**3 * 168},
+                  open(os.path.join(dst, "r01_traffic.json"), "w"), indent=1)
 print(json.dumps({k: v for k, v in summary.items() if "eval_grid" in k}, indent=1))
