@@ -148,6 +148,21 @@ __device__ __forceinline__ void herm_eig(const CMat<N>& h, double (&e)[N], CMat<
     }
 }
 
+__device__ __forceinline__ void sort3(double a, double b, double c, double (&e)[3]) {
+    double t = fmin(a, b);
+    b = fmax(a, b);
+    a = t;
+    t = fmin(b, c);
+    c = fmax(b, c);
+    b = t;
+    t = fmin(a, b);
+    b = fmax(a, b);
+    a = t;
+    e[0] = a;
+    e[1] = b;
+    e[2] = c;
+}
+
 // Eigenvalues (ascending) of a 3 x 3 Hermitian matrix (upper triangle of h), LAPACK-grade accuracy
 // at ~1/4 of the Jacobi cost.  (1) trigonometric root of the characteristic polynomial for the
 // eigenvalue that is best separated from the other two (the only one the closed form gives to full
@@ -197,9 +212,7 @@ __device__ __forceinline__ void herm_eig3_values(const CMat<3>& h, double (&e)[3
         const double sgn = (r >= 0.0) ? 1.0 : -1.0;
         const double mid = q - sgn * 0.5 * p * x;
         const double lo = mid - p * sq, hi = mid + p * sq;
-        e[0] = (r >= 0.0) ? lo : l1;
-        e[1] = (r >= 0.0) ? hi : lo;
-        e[2] = (r >= 0.0) ? l1 : hi;
+        sort3(lo, hi, l1, e);
         return;
     }
     // rows of B = A - l1 I
@@ -320,11 +333,7 @@ __device__ __forceinline__ void herm_eig3_values(const CMat<3>& h, double (&e)[3
     const double mm = 0.5 * (t22 + t33), hh = 0.5 * (t22 - t33);
     const double rad = sqrt(hh * hh + t23r * t23r + t23i * t23i);
     const double lo = mm - rad, hi = mm + rad;
-    // l1 is the extreme one by construction; order defensively anyway
-    const double x0 = fmin(l1, lo), x2 = fmax(l1, hi);
-    e[0] = x0;
-    e[2] = x2;
-    e[1] = (l1 + lo + hi) - x0 - x2;
+    sort3(lo, hi, l1, e);  // l1 is the extreme one by construction; order exactly anyway
 }
 
 // Inverse of the general complex matrix A by Gauss-Jordan with partial pivoting; row exchanges are

@@ -405,6 +405,54 @@ def test_svo_autoptr_off_band_value(abz, svo):
     assert abs(sol_f.u - sol.u) < 1e-6
 
 
+def test_full_size_properties_config3(abz, svo):
+    """BASELINE full size (SVO, 150^3 = 3.375 M nodes, 567 MB of rule values): size-independent
+    properties instead of a node-by-node oracle comparison.
+      * checksum of checksums: the grid mean of sum_b e_b(k) equals Re tr H_{R=0} exactly (PTR kills every
+        R != 0 term), same for the mean of tr H(k) through the exported planes of one line;
+      * symmetry: the cubic-irreducible rule (76 076 nodes, integer weights summing to 150^3) gives the
+        same DOS sweep as the full grid;
+      * the two integrand forms (matrix inverse vs cached eigenvalues) agree; rebuild is idempotent."""
+    s, meta = svo
+    npt = 150
+    dev = s.device()
+    rule = dev.rule(npt, None, want=3)
+    omegas = np.linspace(10, 15, 9)
+    a = rule.reduce(abz._lib.F_DOS, [0.1], omegas)[:, 0].real
+    b = rule.reduce(abz._lib.F_DOS_EIG, [0.1], omegas)[:, 0].real
+    assert np.abs(a - b).max() <= 1e-11 * np.abs(a).max()
+    rule.rebuild()
+    a2 = rule.reduce(abz._lib.F_DOS, [0.1], omegas)[:, 0].real
+    assert np.array_equal(a, a2)
+    eig = rule.export(x=False, w=False, eig=True)["eig"]
+    assert eig.shape == (npt**3, 3) and np.all(np.diff(eig, axis=1) >= 0)
+    tr0 = np.trace(s.c[5, 5, 5]).real
+    assert abs(eig.sum(axis=1).mean() - tr0) <= 1e-11 * abs(tr0)
+    cub = abz.load_bz(abz.CubicSymIBZ(), meta["a_angstrom"] * np.eye(3))
+    rsym = dev.rule(npt, cub.syms, want=1)
+    assert rsym.nk == math.comb(75 + 3, 3)
+    w = rsym.export(x=False, w=True)["w"]
+    assert w.sum() == npt**3
+    c = rsym.reduce(abz._lib.F_DOS, [0.1], omegas)[:, 0].real * 48  # symmetrize: nsyms * u
+    assert np.abs(c - a).max() <= 1e-10 * np.abs(a).max()
+    dev.drop_rules()
+
+
+def test_config2_one_band_64cubed(abz):
+    """BASELINE configs[1]: 3-D 1-band tight binding, fixed 64^3 PTR grid, one omega:
+    against the oracle node for node and for the DOS value."""
+    so = orc.tb_integer(3)
+    s = abz.FourierSeries(so.c, period=1.0, first=so.first, ndim=3)
+    rule = s.device().rule(64, None, want=3)
+    out = rule.export(H=True, eig=True)
+    ref = np.transpose(orc.fourier_ptr(so, 64), (2, 1, 0, 3, 4)).reshape(-1, 1, 1)
+    assert np.abs(out["H"] - ref).max() < 1e-13 and np.abs(out["eig"][:, 0] - ref[:, 0, 0].real).max() < 1e-13
+    bz = abz.load_bz(abz.FBZ(), np.eye(3))
+    u = abz.solve(abz.IntegralProblem(abz.FourierIntegrand(abz.DOSIntegrand(), s, 0.1), bz, abz.MixedParameters(0.5)), abz.PTR(npt=64)).u
+    r = orc.solve_ptr(so, orc.load_bz("FBZ", np.eye(3)), orc.f_dos(0.1, 0.5), npt=64).u
+    assert abs(u - r) <= 1e-11 * abs(r)
+
+
 # ------------------------------------------------------------------ GGR
 def test_ggr_matches_oracle_and_exact(abz):
     """ref: test/dos.jl:88-111 at the reference's npt = 200 (1-D, 2-D) and vs the oracle (3-D)."""
