@@ -106,9 +106,15 @@ def main():
     import torch.distributed as dist
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the product path has no CPU fallback")
+    ndev = torch.cuda.device_count()
+    local = local % max(ndev, 1)  # rehearsal: several ranks may share one card (backend gloo)
     torch.cuda.set_device(local)
+    backend = os.environ.get("ABZ_DIST_BACKEND", "nccl")  # nccl = RCCL over xGMI
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend)
 
     def barrier():
         if world > 1:
@@ -174,8 +180,9 @@ def main():
     tBe = time.perf_counter() - t0
 
     # gather of the sweep (C1: one tiny all_gather) and max-over-ranks timing
-    times = torch.tensor([tA, tB, tBe], dtype=torch.float64, device="cuda")
-    res = torch.tensor(dos, dtype=torch.float64, device="cuda")
+    cdev = "cuda" if (world == 1 or backend == "nccl") else "cpu"
+    times = torch.tensor([tA, tB, tBe], dtype=torch.float64, device=cdev)
+    res = torch.tensor(dos, dtype=torch.float64, device=cdev)
     if world > 1:
         dist.all_reduce(times, op=dist.ReduceOp.MAX)
         parts = [torch.empty_like(res) for _ in range(world)]
