@@ -496,6 +496,112 @@ __device__ __forceinline__ void gloc_trace(const CMat<N>& H, double w, double et
     }
 }
 
+// Trace of the resolvent through the characteristic polynomial, n = 2, 3:
+//   tr inv(z I - H) = p'(z) / p(z),  p(z) = det(z I - H).
+// With q = tr H / n and B = H - q I the polynomial is depressed, p(w) = w^3 + p1 w + p0 (w = z - q),
+// p1 = sum of principal 2x2 minors of B, p0 = -det B, all of the size of the band spread (not of |z|),
+// so the evaluation is well conditioned: error ~ eps spread^n / |p(w)|.  The coefficients are computed
+// ONCE per node; every sweep value then costs ~40 flops instead of a 3x3 complex inversion.
+template <int N>
+struct CharPoly {
+    double qr, qi;    // q = tr H / N
+    double p1r, p1i;  // N = 3: coefficient of w ; N = 2: unused
+    double p0r, p0i;  // constant term
+};
+
+template <int N>
+__device__ __forceinline__ void charpoly_init(const CMat<N>& H, CharPoly<N>& cp) {
+    static_assert(N == 2 || N == 3, "charpoly: n = 2, 3");
+    double tr = 0.0, ti = 0.0;
+#pragma unroll
+    for (int a = 0; a < N; ++a) {
+        tr += H.re[a][a];
+        ti += H.im[a][a];
+    }
+    cp.qr = tr * (1.0 / N);
+    cp.qi = ti * (1.0 / N);
+    double br[N][N], bi[N][N];
+#pragma unroll
+    for (int a = 0; a < N; ++a) {
+#pragma unroll
+        for (int b = 0; b < N; ++b) {
+            br[a][b] = H.re[a][b] - ((a == b) ? cp.qr : 0.0);
+            bi[a][b] = H.im[a][b] - ((a == b) ? cp.qi : 0.0);
+        }
+    }
+    double xr, xi, yr, yi;
+    if constexpr (N == 2) {
+        // p(w) = w^2 + det B  (tr B = 0)
+        cmul(br[0][0], bi[0][0], br[1][1], bi[1][1], xr, xi);
+        cmul(br[0][1], bi[0][1], br[1][0], bi[1][0], yr, yi);
+        cp.p0r = xr - yr;
+        cp.p0i = xi - yi;
+        cp.p1r = 0.0;
+        cp.p1i = 0.0;
+    } else {
+#define ABZ_MIN2(i, j, outr, outi)                                  \
+    cmul(br[i][i], bi[i][i], br[j][j], bi[j][j], xr, xi);           \
+    cmul(br[i][j], bi[i][j], br[j][i], bi[j][i], yr, yi);           \
+    outr = xr - yr;                                                 \
+    outi = xi - yi;
+        double m01r, m01i, m02r, m02i, m12r, m12i;
+        ABZ_MIN2(0, 1, m01r, m01i)
+        ABZ_MIN2(0, 2, m02r, m02i)
+        ABZ_MIN2(1, 2, m12r, m12i)
+#undef ABZ_MIN2
+        cp.p1r = m01r + m02r + m12r;
+        cp.p1i = m01i + m02i + m12i;
+        // det B by the first row
+        double c0r, c0i, c1r, c1i, c2r, c2i;
+        cmul(br[1][1], bi[1][1], br[2][2], bi[2][2], xr, xi);
+        cmul(br[1][2], bi[1][2], br[2][1], bi[2][1], yr, yi);
+        c0r = xr - yr;
+        c0i = xi - yi;
+        cmul(br[1][2], bi[1][2], br[2][0], bi[2][0], xr, xi);
+        cmul(br[1][0], bi[1][0], br[2][2], bi[2][2], yr, yi);
+        c1r = xr - yr;
+        c1i = xi - yi;
+        cmul(br[1][0], bi[1][0], br[2][1], bi[2][1], xr, xi);
+        cmul(br[1][1], bi[1][1], br[2][0], bi[2][0], yr, yi);
+        c2r = xr - yr;
+        c2i = xi - yi;
+        double dr, di;
+        cmul(br[0][0], bi[0][0], c0r, c0i, dr, di);
+        cmul(br[0][1], bi[0][1], c1r, c1i, xr, xi);
+        dr += xr;
+        di += xi;
+        cmul(br[0][2], bi[0][2], c2r, c2i, xr, xi);
+        dr += xr;
+        di += xi;
+        cp.p0r = -dr;
+        cp.p0i = -di;
+    }
+}
+
+// tr inv((w + i eta) I - H) from the precomputed polynomial
+template <int N>
+__device__ __forceinline__ void charpoly_trace(const CharPoly<N>& cp, double w, double eta, double& tr, double& ti) {
+    const double zr = w - cp.qr, zi = eta - cp.qi;
+    const double z2r = zr * zr - zi * zi, z2i = 2.0 * zr * zi;
+    double nr, ni, dr, di;
+    if constexpr (N == 2) {
+        nr = 2.0 * zr;
+        ni = 2.0 * zi;
+        dr = z2r + cp.p0r;
+        di = z2i + cp.p0i;
+    } else {
+        // den = z^3 + p1 z + p0 = z (z^2 + p1) + p0 ; num = 3 z^2 + p1
+        const double ar = z2r + cp.p1r, ai = z2i + cp.p1i;
+        dr = fma(zr, ar, fma(-zi, ai, cp.p0r));
+        di = fma(zr, ai, fma(zi, ar, cp.p0i));
+        nr = fma(3.0, z2r, cp.p1r);
+        ni = fma(3.0, z2i, cp.p1i);
+    }
+    const double inv = 1.0 / (dr * dr + di * di);
+    tr = (nr * dr + ni * di) * inv;
+    ti = (ni * dr - nr * di) * inv;
+}
+
 // wave64 sum via DPP-free shuffles (6 steps)
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll

@@ -820,12 +820,16 @@ __global__ __launch_bounds__(256) void reduce_kernel(ReduceArgs a, double2* __re
     extern __shared__ double2 lds[];  // [chunk][4 waves][NC]
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int64_t base = (int64_t)blockIdx.x * (256 * KT);
-    CMat<N> H[KT];
+    constexpr bool usePoly0 = (N == 2 || N == 3) && (FID == ABZ_F_DOS || FID == ABZ_F_TRGLOC);
+    CMat<N> H[usePoly0 ? 1 : KT];  // poly mode: H is only a transient input of charpoly_init
     double e[KT][N];
     double wk[KT];
     double xk[KT][ABZ_MAX_DIM];
     constexpr bool needH = (FID == ABZ_F_LINEAR || FID == ABZ_F_LINEAR_X || FID == ABZ_F_DOS ||
                             FID == ABZ_F_TRGLOC || FID == ABZ_F_GLOC);
+    // n = 2, 3 resolvent traces: characteristic polynomial per node, ~40 flops per sweep value
+    constexpr bool usePoly = (N == 2 || N == 3) && (FID == ABZ_F_DOS || FID == ABZ_F_TRGLOC);
+    CharPoly<(usePoly ? N : 2)> cp[KT];
 #pragma unroll
     for (int j = 0; j < KT; ++j) {
         const int64_t k = base + threadIdx.x + 256 * j;
@@ -833,8 +837,9 @@ __global__ __launch_bounds__(256) void reduce_kernel(ReduceArgs a, double2* __re
         const int64_t kk = ok ? k : 0;
         wk[j] = ok ? (a.w ? a.w[kk] : 1.0) : 0.0;
         if constexpr (needH) {
-            load_planes<N>(H[j], a.H, view_off(a.H, kk));
+            load_planes<N>(H[usePoly0 ? 0 : j], a.H, view_off(a.H, kk));
         }
+        if constexpr (usePoly) charpoly_init<N>(H[0], cp[j]);
         if constexpr (FID == ABZ_F_DOS_EIG) {
             const double* __restrict__ ei = a.E.base + view_off(a.E, kk);
 #pragma unroll
@@ -868,17 +873,25 @@ __global__ __launch_bounds__(256) void reduce_kernel(ReduceArgs a, double2* __re
 #pragma unroll
             for (int j = 0; j < KT; ++j) {
                 double vr[MAXC], vi[MAXC];
-                integrand_value<N, FID>(H[j], e[j], xk[j], a.d, a.p, sw, vr, vi);
+                if constexpr (usePoly) {
+                    double tr, ti;
+                    charpoly_trace<N>(cp[j], sw, a.p[0], tr, ti);
+                    vr[0] = (FID == ABZ_F_DOS) ? -ti * 0.31830988618379067153776752674503 : tr;
+                    vi[0] = (FID == ABZ_F_DOS) ? 0.0 : ti;
+                } else {
+                    integrand_value<N, FID>(H[usePoly0 ? 0 : j], e[j], xk[j], a.d, a.p, sw, vr, vi);
+                }
 #pragma unroll
                 for (int c = 0; c < NC; ++c) {
                     ar[c] = fma(wk[j], vr[c], ar[c]);
                     ai[c] = fma(wk[j], vi[c], ai[c]);
                 }
             }
+            constexpr bool realValued = (FID == ABZ_F_DOS || FID == ABZ_F_DOS_EIG || FID == ABZ_F_ONE);
 #pragma unroll
             for (int c = 0; c < NC; ++c) {
                 const double sr = wave_sum(ar[c]);
-                const double si = wave_sum(ai[c]);
+                const double si = realValued ? 0.0 : wave_sum(ai[c]);
                 if (lane == 0) lds[((s - s0) * 4 + wave) * NC + c] = make_double2(sr, si);
             }
         }
@@ -925,10 +938,19 @@ __global__ __launch_bounds__(256) void final_reduce_kernel(const double2* __rest
     }
 }
 
+// nodes per thread: the wave reduction per sweep value is amortised over KT nodes; the cheap
+// per-node states (characteristic polynomial: 6 doubles, eigenvalues: n doubles) allow KT = 8
+template <int N, int FID>
+constexpr int reduce_kt_of() {
+    if (FID == ABZ_F_GLOC || N >= 4) return 1;
+    if (FID == ABZ_F_DOS_EIG || ((N == 2 || N == 3) && (FID == ABZ_F_DOS || FID == ABZ_F_TRGLOC))) return 8;
+    return 2;
+}
+
 template <int N, int FID>
 static int launch_reduce_t(abz_ctx* ctx, const ReduceSpec& rs, const ReduceArgs& a, double2* partial,
                            int64_t nblocks) {
-    constexpr int KT = (FID == ABZ_F_GLOC || N >= 4) ? 1 : 2;
+    constexpr int KT = reduce_kt_of<N, FID>();
     constexpr int NC = NComp<FID>::template value<N>();
     const int chunk = 512 / NC;
     const size_t lds = sizeof(double2) * (size_t)std::min(chunk, rs.n_sweep) * 4 * NC;
@@ -964,11 +986,11 @@ int launch_reduce(abz_ctx* ctx, const ReduceSpec& rs, double* out_reim) {
     a.n_sweep = rs.n_sweep;
     a.ncomp = ncomp;
     for (int i = 0; i < 4; ++i) a.p[i] = rs.params[i];
-    int kt = 1;
-    switch (rs.integrand) {
-        case ABZ_F_GLOC: kt = 1; break;
-        default: kt = rs.n >= 4 ? 1 : 2;
-    }
+    int kt = 2;
+    if (rs.integrand == ABZ_F_GLOC || rs.n >= 4)
+        kt = 1;
+    else if (rs.integrand == ABZ_F_DOS_EIG || ((rs.n == 2 || rs.n == 3) && (rs.integrand == ABZ_F_DOS || rs.integrand == ABZ_F_TRGLOC)))
+        kt = 8;
     const int64_t nblocks = cdiv(rs.nk, 256 * kt);
     const int64_t ncols = (int64_t)rs.n_sweep * ncomp;
     int rc = ctx->scratch[1].reserve(sizeof(double2) * (size_t)(nblocks * ncols));
