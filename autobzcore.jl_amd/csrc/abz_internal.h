@@ -213,6 +213,34 @@ struct NodeEvalSpec {
 };
 int launch_node_integrand(abz_ctx* ctx, const NodeEvalSpec& ns, double2* values_dev);
 
+// Innermost level of IAI entirely on the device: one half-wave (32 lanes) runs the globally adaptive
+// GK(7,15) loop of ONE 1-D integral (QuadGK adapt, scalar refinement, DataStructures heap semantics,
+// the shared gk15.h rule) -- 15 / 30 lanes evaluate the nodes of the new panels, lane 0 keeps the heap.
+struct InnerSpec {
+    int n, d, M, first;
+    double period;
+    const double2* src;      // level-1 coefficient sets
+    int64_t nint;            // number of 1-D integrals
+    const int64_t* slot;     // device [nint]
+    const double* lo;        // device [nint]
+    const double* hi;        // device [nint]
+    const double* atol;      // device [nint], < 0: none
+    const double* tail;      // device [nint][d-1] or null
+    int integrand;
+    double params[4];
+    double sweep;
+    bool has_rtol;
+    double rtol_user;
+    int64_t maxevals;
+    double2* I_out;          // device [nint][ncomp]
+    double* E_out;           // device [nint]
+    int64_t* nev_out;        // device [nint]
+    int* status_out;         // device [nint]: 0 ok, 1 = segment store overflow (redo on the host)
+};
+constexpr int ABZ_INNER_MAXSEG = 48;
+bool inner_adaptive_supported(int n, int integrand);
+int launch_inner_adaptive(abz_ctx* ctx, const InnerSpec& is);
+
 // ---- generic n (5..32 bands): wave-per-node kernels (kernels_generic.hip)
 struct GenSpec {
     int n, M, first, npt, d;

@@ -11,60 +11,24 @@
 #include <algorithm>
 #include <cmath>
 #include <complex>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
 #include "abz_internal.h"
+#include "gk15.h"
 
 namespace abz {
 
 typedef std::complex<double> cd;
 
-// Kronrod-15 abscissae on [-1, 0] (QuadGK ordering), weights, embedded Gauss-7 weights (QUADPACK qk15)
-static const double GK_X[8] = {-0.991455371120812639206854697526329, -0.949107912342758524526189684047851,
-                               -0.864864423359769072789712788640926, -0.741531185599394439863864773280788,
-                               -0.586087235467691130294144838258730, -0.405845151377397166906606412076961,
-                               -0.207784955007898467600689403773245, 0.0};
-static const double GK_W[8] = {0.022935322010529224963732008058970, 0.063092092629978553290700663189204,
-                               0.104790010322250183839876322541518, 0.140653259715525918745189590510238,
-                               0.169004726639267902826583426598550, 0.190350578064785409913256402421014,
-                               0.204432940075298892414161999234649, 0.209482141084727828012999174891714};
-static const double GK_GW[4] = {0.129484966168869693270611432679082, 0.279705391489276667901467771423780,
-                                0.381830050505118944950369775488975, 0.417959183673469387755102040816327};
-
 void gk15_nodes(double a, double b, double* x) {
-    const double s = 0.5 * (b - a);
-    for (int i = 0; i < 7; ++i) {
-        x[2 * i] = a + (1 + GK_X[i]) * s;
-        x[2 * i + 1] = a + (1 - GK_X[i]) * s;
-    }
-    x[14] = a + s;
+    for (int i = 0; i < 15; ++i) x[i] = gk15_node(a, b, i);
 }
 
-// QuadGK.evalrule for order 7 on one panel: fv [15][ncomp] in gk15_nodes order.
+// QuadGK.evalrule for order 7 on one panel: fv [15][ncomp] in gk15_nodes order (shared with the device)
 void gk15_evalrule(const cd* fv, int ncomp, double a, double b, cd* I, double* E) {
-    const double s = 0.5 * (b - a);
-    double e2 = 0.0;
-    for (int c = 0; c < ncomp; ++c) {
-        auto F = [&](int i) { return fv[(size_t)i * ncomp + c]; };
-        cd fg = F(2) + F(3);
-        cd fk = F(0) + F(1);
-        cd Ig = fg * GK_GW[0];
-        cd Ik = fg * GK_W[1] + fk * GK_W[0];
-        for (int i = 2; i < 4; ++i) {
-            fg = F(2 * (2 * i - 1)) + F(2 * (2 * i - 1) + 1);
-            fk = F(2 * (2 * i - 2)) + F(2 * (2 * i - 2) + 1);
-            Ig = Ig + fg * GK_GW[i - 1];
-            Ik = Ik + fg * GK_W[2 * i - 1] + fk * GK_W[2 * i - 2];
-        }
-        const cd f0 = F(14);
-        Ig = Ig + f0 * GK_GW[3];
-        Ik = Ik + f0 * GK_W[7] + (F(12) + F(13)) * GK_W[6];
-        const cd Iks = Ik * s, Igs = Ig * s;
-        I[c] = Iks;
-        e2 += std::norm(Iks - Igs);
-    }
-    *E = std::sqrt(e2);
+    *E = gk15_rule(reinterpret_cast<const gkc*>(fv), ncomp, a, b, reinterpret_cast<gkc*>(I));
 }
 
 struct Seg {
@@ -176,9 +140,12 @@ struct IaiDriver {
         return (q.has_atol && q.atol > 0) ? 0.0 : std::sqrt(2.220446049250313e-16);
     }
 
+    bool device_inner = false;  // innermost adaptive loops on the GPU (scalar refinement, n <= 4)
+
     int contract_nodes(int L, int64_t nn, int64_t base_slot);
     int eval_nodes(int64_t nn);
     int solve_level(int L, std::vector<Quad1D>& quads);
+    int solve_inner_device(std::vector<Quad1D>& kids);
 };
 
 // upload h_parents/h_x, contract level-L sets into level-(L-1) pool slots base_slot..base_slot+nn-1
@@ -248,6 +215,107 @@ int IaiDriver::eval_nodes(int64_t nn) {
     return ABZ_OK;
 }
 
+// All integrals of `kids` integrate variable 1: run their whole adaptive loops on the device
+// (inner_adaptive_kernel); an integral that overflows the device segment store is redone on the host.
+int IaiDriver::solve_inner_device(std::vector<Quad1D>& kids) {
+    const int64_t nq = (int64_t)kids.size();
+    if (nq == 0) return ABZ_OK;
+    std::vector<int64_t> slot((size_t)nq);
+    std::vector<double> lo((size_t)nq), hi((size_t)nq), at((size_t)nq), tl;
+    const bool need_tail = integrand == ABZ_F_LINEAR_X && d > 1;
+    if (need_tail) tl.resize((size_t)(nq * (d - 1)));
+    for (int64_t i = 0; i < nq; ++i) {
+        const Quad1D& k = kids[(size_t)i];
+        slot[(size_t)i] = k.slot;
+        k.lims.segs(1, lo[(size_t)i], hi[(size_t)i]);
+        at[(size_t)i] = k.has_atol ? k.atol : -1.0;
+        if (need_tail)
+            for (int j = 0; j < d - 1; ++j) tl[(size_t)(i * (d - 1) + j)] = k.tail[j];
+    }
+    // device staging: [slot | lo | hi | atol | tail] in iai_io[0..2], outputs in iai_io[3], iai_io[5]
+    int rc;
+    const size_t in_bytes = sizeof(int64_t) * (size_t)nq + sizeof(double) * (size_t)nq * 3;
+    if ((rc = s->iai_io[0].reserve(in_bytes))) return rc;
+    char* base = static_cast<char*>(s->iai_io[0].p);
+    int64_t* d_slot = reinterpret_cast<int64_t*>(base);
+    double* d_lo = reinterpret_cast<double*>(base + sizeof(int64_t) * (size_t)nq);
+    double* d_hi = d_lo + nq;
+    double* d_at = d_hi + nq;
+    ABZ_HIP(hipMemcpyAsync(d_slot, slot.data(), sizeof(int64_t) * (size_t)nq, hipMemcpyHostToDevice, ctx->stream));
+    ABZ_HIP(hipMemcpyAsync(d_lo, lo.data(), sizeof(double) * (size_t)nq, hipMemcpyHostToDevice, ctx->stream));
+    ABZ_HIP(hipMemcpyAsync(d_hi, hi.data(), sizeof(double) * (size_t)nq, hipMemcpyHostToDevice, ctx->stream));
+    ABZ_HIP(hipMemcpyAsync(d_at, at.data(), sizeof(double) * (size_t)nq, hipMemcpyHostToDevice, ctx->stream));
+    double* d_tail = nullptr;
+    if (need_tail) {
+        if ((rc = s->iai_io[2].reserve(sizeof(double) * tl.size()))) return rc;
+        d_tail = s->iai_io[2].as<double>();
+        ABZ_HIP(hipMemcpyAsync(d_tail, tl.data(), sizeof(double) * tl.size(), hipMemcpyHostToDevice, ctx->stream));
+    }
+    const size_t out_bytes = sizeof(double2) * (size_t)(nq * ncomp) + sizeof(double) * (size_t)nq + sizeof(int64_t) * (size_t)nq +
+                             sizeof(int) * (size_t)nq;
+    if ((rc = s->iai_io[3].reserve(out_bytes))) return rc;
+    char* ob = static_cast<char*>(s->iai_io[3].p);
+    double2* d_I = reinterpret_cast<double2*>(ob);
+    double* d_E = reinterpret_cast<double*>(ob + sizeof(double2) * (size_t)(nq * ncomp));
+    int64_t* d_nev = reinterpret_cast<int64_t*>(d_E + nq);
+    int* d_st = reinterpret_cast<int*>(d_nev + nq);
+    InnerSpec is;
+    is.n = n;
+    is.d = d;
+    is.M = s->dims[0];
+    is.first = s->first[0];
+    is.period = s->period[0];
+    is.src = (d == 1) ? s->coef : s->iai_pool[1].as<double2>();
+    is.nint = nq;
+    is.slot = d_slot;
+    is.lo = d_lo;
+    is.hi = d_hi;
+    is.atol = d_at;
+    is.tail = d_tail;
+    is.integrand = integrand;
+    for (int i = 0; i < 4; ++i) is.params[i] = params[i];
+    is.sweep = sweep;
+    is.has_rtol = has_rtol;
+    is.rtol_user = rtol_user;
+    is.maxevals = maxevals;
+    is.I_out = d_I;
+    is.E_out = d_E;
+    is.nev_out = d_nev;
+    is.status_out = d_st;
+    if ((rc = launch_inner_adaptive(ctx, is))) return rc;
+    std::vector<char> hb(out_bytes);
+    ABZ_HIP(hipMemcpyAsync(hb.data(), ob, out_bytes, hipMemcpyDeviceToHost, ctx->stream));
+    ABZ_HIP(hipStreamSynchronize(ctx->stream));
+    const cd* hI = reinterpret_cast<const cd*>(hb.data());
+    const double* hE = reinterpret_cast<const double*>(hb.data() + sizeof(double2) * (size_t)(nq * ncomp));
+    const int64_t* hN = reinterpret_cast<const int64_t*>(hE + nq);
+    const int* hS = reinterpret_cast<const int*>(hN + nq);
+    std::vector<Quad1D> redo;
+    std::vector<int64_t> redo_idx;
+    for (int64_t i = 0; i < nq; ++i) {
+        Quad1D& k = kids[(size_t)i];
+        if (hS[i] != 0) {
+            redo.push_back(k);
+            redo_idx.push_back(i);
+            continue;
+        }
+        k.I.assign(hI + (size_t)i * ncomp, hI + (size_t)(i + 1) * ncomp);
+        k.E = hE[i];
+        k.numevals = hN[i];
+        k.done = true;
+        total_evals += hN[i];
+    }
+    if (!redo.empty()) {
+        const bool keep = device_inner;
+        device_inner = false;
+        rc = solve_level(1, redo);
+        device_inner = keep;
+        if (rc) return rc;
+        for (size_t j = 0; j < redo.size(); ++j) kids[(size_t)redo_idx[j]] = redo[j];
+    }
+    return ABZ_OK;
+}
+
 // Run every integral of `quads` (all integrate variable L) to completion.
 int IaiDriver::solve_level(int L, std::vector<Quad1D>& quads) {
     std::vector<size_t> active;
@@ -314,8 +382,7 @@ int IaiDriver::solve_level(int L, std::vector<Quad1D>& quads) {
                     }
                 }
             }
-            std::vector<double> save_x;  // solve_level below reuses the staging vectors
-            rc = solve_level(L - 1, kids);
+            rc = (L - 1 == 1 && device_inner) ? solve_inner_device(kids) : solve_level(L - 1, kids);
             if (rc) return rc;
             vals.resize((size_t)(nn * ncomp));
             for (int64_t i = 0; i < nn; ++i)
@@ -453,6 +520,11 @@ int abz_iai_solve(abz_series* s, int lims_kind, const double* lim_a, const doubl
     drv.rtol_user = reltol;
     drv.maxevals = maxevals > 0 ? maxevals : (int64_t)1 << 62;
     drv.max_batch = max_batch;
+    {
+        const char* e = getenv("ABZ_IAI_DEVICE_INNER");  // 0 forces the host loop at every level
+        drv.device_inner = max_batch <= 0 && s->d >= 2 && inner_adaptive_supported(s->n, integrand) &&
+                           !(e && e[0] == '0');
+    }
     std::vector<Quad1D> top(1);
     Quad1D& q = top[0];
     q.slot = 0;

@@ -13,6 +13,7 @@
 //   ggr_kernel        GGR formula scan (ref src/dos_ggr.jl:58-104)
 #include "abz_internal.h"
 #include "device_math.h"
+#include "gk15.h"
 
 #include <cmath>
 #include <cstdlib>
@@ -1342,6 +1343,330 @@ int launch_node_integrand(abz_ctx* ctx, const NodeEvalSpec& ns, double2* values_
         CASE(ABZ_F_DOS_EIG)
     }
 #undef CASE
+    ABZ_HIP(hipGetLastError());
+    return ABZ_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// IAI innermost level on the device: adaptive GK(7,15) per 1-D integral, one half-wave each
+// ------------------------------------------------------------------------------------------
+struct InnerArgs {
+    const double2* src;
+    const int64_t* slot;
+    const double* lo;
+    const double* hi;
+    const double* atol;
+    const double* tail;
+    int64_t nint, maxevals;
+    int M, first, d, ncomp, has_rtol;
+    double inv_period, sweep, rtol_user;
+    double p[4];
+    double2* I_out;
+    double* E_out;
+    int64_t* nev_out;
+    int* status_out;
+};
+
+// LDS layout of one group (one integral in flight), in doubles:
+//   seg_a[MAXSEG] seg_b[MAXSEG] seg_E[MAXSEG] | seg_I[MAXSEG][ncomp] (complex) | vals[30][ncomp] (complex)
+//   | heap[MAXSEG] (int, packed 2 per double) | ctl[8]: np, pa0, pb0, pa1, pb1
+__host__ __device__ inline int inner_group_doubles(int ncomp) {
+    return 3 * ABZ_INNER_MAXSEG + 2 * ncomp * ABZ_INNER_MAXSEG + 2 * ncomp * 30 + ABZ_INNER_MAXSEG / 2 + 8;
+}
+
+template <int N, int FID>
+__global__ __launch_bounds__(256) void inner_adaptive_kernel(InnerArgs a) {
+    extern __shared__ double lds_in[];
+    constexpr int MS = ABZ_INNER_MAXSEG;
+    const int group = threadIdx.x >> 5, l = threadIdx.x & 31;
+    const int nc = a.ncomp;
+    double* g = lds_in + (size_t)group * inner_group_doubles(nc);
+    double* seg_a = g;
+    double* seg_b = seg_a + MS;
+    double* seg_E = seg_b + MS;
+    gkc* seg_I = reinterpret_cast<gkc*>(seg_E + MS);
+    gkc* vals = seg_I + (size_t)MS * nc;
+    int* heap = reinterpret_cast<int*>(vals + (size_t)30 * nc);
+    double* ctl = reinterpret_cast<double*>(heap + MS);
+    const int64_t gstride = (int64_t)gridDim.x * 8;
+    for (int64_t q0 = (int64_t)blockIdx.x * 8; q0 < a.nint; q0 += gstride) {
+        const int64_t q = q0 + group;
+        const bool live = q < a.nint;  // the whole group shares it; both groups of a wave loop together
+        // ---- lane 0 state
+        int nseg = 0, nheap = 0, popped = -1;
+        double E = 0.0, atol = 0.0, rtol = 0.0;
+        long long numevals = 0;
+        int status = 0;
+        bool done = !live;
+        cptr_t c1 = as_const(a.src);
+        double tailv[ABZ_MAX_DIM] = {0.0, 0.0, 0.0};
+        if (live) {
+            c1 = as_const(a.src + a.slot[q] * ((int64_t)a.M * N * N));
+            if (FID == ABZ_F_LINEAR_X && a.tail)
+                for (int j = 0; j < a.d - 1; ++j) tailv[j] = a.tail[q * (a.d - 1) + j];
+            if (l == 0) {
+                const double at = a.atol[q];
+                atol = at >= 0.0 ? at : 0.0;
+                rtol = a.has_rtol ? a.rtol_user : ((at > 0.0) ? 0.0 : 1.4901161193847656e-08);  // sqrt(eps)
+                ctl[0] = 1.0;
+                ctl[1] = a.lo[q];
+                ctl[2] = a.hi[q];
+            }
+        }
+        bool first = true;
+        // gkc accumulators of lane 0 live in LDS row MS-? : keep I in registers up to MAXC comps
+        double Ir[MAXC], Ii[MAXC];
+#pragma unroll
+        for (int c = 0; c < MAXC; ++c) {
+            Ir[c] = 0.0;
+            Ii[c] = 0.0;
+        }
+        while (true) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            const int grp_done = __shfl(done ? 1 : 0, (int)(threadIdx.x & 32u), 64);  // leader lane of this group
+            // all lanes of the WAVE must agree to leave: ballot over both groups' leaders
+            const unsigned long long alive = __ballot(!grp_done);
+            if (alive == 0ull) break;
+            if (!grp_done) {
+                // ---- evaluate the nodes of the pending panels: lanes 0-14 panel 0, 16-30 panel 1
+                const int np = (int)ctl[0];
+                const int pnl = l >> 4, i = l & 15;
+                if (pnl < np && i < 15) {
+                    const double pa = ctl[1 + 2 * pnl], pb = ctl[2 + 2 * pnl];
+                    const double x = gk15_node(pa, pb, i);
+                    const double xx = x * a.inv_period;
+                    double zr, zi, wr, wi;
+                    sincospi(2.0 * xx, &zi, &zr);
+                    sincospi(2.0 * ((double)a.first * xx), &wi, &wr);
+                    CMat<N> H;
+                    series_lane<N>(c1, a.M, a.first, zr, zi, wr, wi, false, H);
+                    double e[N];
+                    if constexpr (FID == ABZ_F_DOS_EIG) {
+                        if constexpr (N == 3) {
+                            herm_eig3_values(H, e);
+                        } else {
+                            CMat<N> V;
+                            herm_eig<N, false>(H, e, V);
+                        }
+                    }
+                    double xk[ABZ_MAX_DIM] = {x, tailv[0], tailv[1]};
+                    double vr[MAXC], vi[MAXC];
+                    integrand_value<N, FID>(H, e, xk, a.d, a.p, a.sweep, vr, vi);
+                    constexpr int NC = NComp<FID>::template value<N>();
+#pragma unroll
+                    for (int c = 0; c < NC; ++c) {
+                        if (c < nc) {
+                            vals[(size_t)(pnl * 15 + i) * nc + c].re = vr[c];
+                            vals[(size_t)(pnl * 15 + i) * nc + c].im = vi[c];
+                        }
+                    }
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            if (!grp_done && l == 0) {
+                // ---- QuadGK adapt bookkeeping (one lane): rule, heap, convergence, next bisection
+                const int np = (int)ctl[0];
+                int newseg[2] = {-1, -1};
+                for (int pnl = 0; pnl < np; ++pnl) {
+                    // slot for the new segment: reuse the popped parent's slot for the first child
+                    int sl;
+                    if (pnl == 0 && popped >= 0)
+                        sl = popped;
+                    else
+                        sl = nseg++;
+                    if (sl >= MS) {
+                        status = 1;
+                        sl = MS - 1;
+                    }
+                    const double pa = ctl[1 + 2 * pnl], pb = ctl[2 + 2 * pnl];
+                    // NOTE: the parent's I must be read before its slot is overwritten (done below)
+                    newseg[pnl] = sl;
+                    seg_a[sl] = pa;
+                    seg_b[sl] = pb;
+                }
+                if (first) {
+                    first = false;
+                    const int sl = newseg[0];
+                    seg_E[sl] = gk15_rule(vals, nc, seg_a[sl], seg_b[sl], seg_I + (size_t)sl * nc);
+                    for (int c = 0; c < nc; ++c) {
+                        Ir[c] = seg_I[(size_t)sl * nc + c].re;
+                        Ii[c] = seg_I[(size_t)sl * nc + c].im;
+                    }
+                    E = seg_E[sl];
+                    numevals = 15;
+                    heap[0] = sl;
+                    nheap = 1;
+                } else {
+                    // I = (I - I_parent) + I_1 + I_2 ; E likewise (parent's values still in slot `popped`)
+                    const int sp = popped;
+                    double pIr[MAXC], pIi[MAXC];
+                    for (int c = 0; c < nc; ++c) {
+                        pIr[c] = seg_I[(size_t)sp * nc + c].re;
+                        pIi[c] = seg_I[(size_t)sp * nc + c].im;
+                    }
+                    const double pE = seg_E[sp];
+                    const int s1 = newseg[0], s2 = newseg[1];
+                    seg_E[s1] = gk15_rule(vals, nc, seg_a[s1], seg_b[s1], seg_I + (size_t)s1 * nc);
+                    seg_E[s2] = gk15_rule(vals + (size_t)15 * nc, nc, seg_a[s2], seg_b[s2], seg_I + (size_t)s2 * nc);
+                    {
+#pragma clang fp contract(off)
+                        for (int c = 0; c < nc; ++c) {
+                            Ir[c] = ((Ir[c] - pIr[c]) + seg_I[(size_t)s1 * nc + c].re) + seg_I[(size_t)s2 * nc + c].re;
+                            Ii[c] = ((Ii[c] - pIi[c]) + seg_I[(size_t)s1 * nc + c].im) + seg_I[(size_t)s2 * nc + c].im;
+                        }
+                        E = ((E - pE) + seg_E[s1]) + seg_E[s2];
+                    }
+                    // heappush x2 (percolate_up, lt(Reverse, x, y) == y.E < x.E)
+                    for (int t = 0; t < 2; ++t) {
+                        const int x = t == 0 ? s1 : s2;
+                        int i = nheap++;
+                        while (i > 0) {
+                            const int j = (i - 1) / 2;
+                            if (!(seg_E[heap[j]] < seg_E[x])) break;
+                            heap[i] = heap[j];
+                            i = j;
+                        }
+                        heap[i] = x;
+                    }
+                }
+                double nrm = 0.0;
+                {
+#pragma clang fp contract(off)
+                    for (int c = 0; c < nc; ++c) {
+                        const double t1 = Ir[c] * Ir[c], t2 = Ii[c] * Ii[c];
+                        const double t3 = t1 + t2;
+                        nrm = nrm + t3;
+                    }
+                }
+                nrm = sqrt(nrm);
+                const double tol = fmax(atol, rtol * nrm);
+                if (E > tol && numevals < a.maxevals && status == 0) {
+                    // heappop: root out, last to root, percolate_down
+                    const int x = heap[0];
+                    const int y = heap[--nheap];
+                    if (nheap > 0) {
+                        int i = 0;
+                        while (true) {
+                            const int lc = 2 * i + 1;
+                            if (lc >= nheap) break;
+                            const int rc = lc + 1;
+                            const int j = (rc >= nheap || seg_E[heap[rc]] < seg_E[heap[lc]]) ? lc : rc;
+                            if (!(seg_E[y] < seg_E[heap[j]])) break;
+                            heap[i] = heap[j];
+                            i = j;
+                        }
+                        heap[i] = y;
+                    }
+                    popped = x;
+                    numevals += 30;
+                    const double pa = seg_a[x], pb = seg_b[x];
+                    const double mid = (pa + pb) / 2;
+                    ctl[0] = 2.0;
+                    ctl[1] = pa;
+                    ctl[2] = mid;
+                    ctl[3] = mid;
+                    ctl[4] = pb;
+                } else {
+                    // re-sum over the heap in storage order (QuadGK does this after adapt)
+                    if (numevals > 15 || nheap > 0) {
+#pragma clang fp contract(off)
+                        for (int c = 0; c < nc; ++c) {
+                            Ir[c] = seg_I[(size_t)heap[0] * nc + c].re;
+                            Ii[c] = seg_I[(size_t)heap[0] * nc + c].im;
+                        }
+                        E = seg_E[heap[0]];
+                        for (int h = 1; h < nheap; ++h) {
+                            for (int c = 0; c < nc; ++c) {
+                                Ir[c] = Ir[c] + seg_I[(size_t)heap[h] * nc + c].re;
+                                Ii[c] = Ii[c] + seg_I[(size_t)heap[h] * nc + c].im;
+                            }
+                            E = E + seg_E[heap[h]];
+                        }
+                    }
+                    for (int c = 0; c < nc; ++c) a.I_out[q * nc + c] = make_double2(Ir[c], Ii[c]);
+                    a.E_out[q] = E;
+                    a.nev_out[q] = numevals;
+                    a.status_out[q] = status;
+                    done = true;
+                }
+            }
+        }
+    }
+}
+
+bool inner_adaptive_supported(int n, int integrand) {
+    const int nc = integrand_ncomp(integrand, n, 3);
+    return n >= 1 && n <= 4 && nc > 0 && nc <= MAXC && sizeof(double) * (size_t)inner_group_doubles(nc) * 8 <= 150 * 1024;
+}
+
+int launch_inner_adaptive(abz_ctx* ctx, const InnerSpec& is) {
+    if (is.nint == 0) return ABZ_OK;
+    const int ncomp = integrand_ncomp(is.integrand, is.n, is.d);
+    if (ncomp < 0) {
+        set_error("unknown integrand id %d", is.integrand);
+        return ABZ_ERR_ARG;
+    }
+    if ((is.integrand == ABZ_F_LINEAR || is.integrand == ABZ_F_LINEAR_X) && is.n != 1) {
+        set_error("ABZ_F_LINEAR(_X) needs a scalar (n = 1) series");
+        return ABZ_ERR_ARG;
+    }
+    InnerArgs a;
+    a.src = is.src;
+    a.slot = is.slot;
+    a.lo = is.lo;
+    a.hi = is.hi;
+    a.atol = is.atol;
+    a.tail = is.tail;
+    a.nint = is.nint;
+    a.maxevals = is.maxevals;
+    a.M = is.M;
+    a.first = is.first;
+    a.d = is.d;
+    a.ncomp = ncomp;
+    a.has_rtol = is.has_rtol ? 1 : 0;
+    a.inv_period = 1.0 / is.period;
+    a.sweep = is.sweep;
+    a.rtol_user = is.rtol_user;
+    for (int i = 0; i < 4; ++i) a.p[i] = is.params[i];
+    a.I_out = is.I_out;
+    a.E_out = is.E_out;
+    a.nev_out = is.nev_out;
+    a.status_out = is.status_out;
+    ProfScope ps(ctx, ABZ_K_EVAL);
+    const size_t lds = sizeof(double) * (size_t)inner_group_doubles(ncomp) * 8;
+    const unsigned blocks = (unsigned)std::min<int64_t>(cdiv(is.nint, 8), 256 * 16);
+#define LAUNCH_INNER(NN, FID)                                                                                         \
+    {                                                                                                                 \
+        if (lds > 48 * 1024)                                                                                          \
+            ABZ_HIP(hipFuncSetAttribute((const void*)inner_adaptive_kernel<NN, FID>,                                  \
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                       \
+        hipLaunchKernelGGL((inner_adaptive_kernel<NN, FID>), dim3(blocks), dim3(256), lds, ctx->stream, a);           \
+    }
+#define CASE(FID)                                                                                                     \
+    case FID:                                                                                                         \
+        switch (is.n) {                                                                                               \
+            case 1: LAUNCH_INNER(1, FID) break;                                                                       \
+            case 2: LAUNCH_INNER(2, FID) break;                                                                       \
+            case 3: LAUNCH_INNER(3, FID) break;                                                                       \
+            case 4: LAUNCH_INNER(4, FID) break;                                                                       \
+            default: set_error("inner adaptive kernel: n = %d not supported", is.n); return ABZ_ERR_UNSUPPORTED;      \
+        }                                                                                                             \
+        break;
+    switch (is.integrand) {
+        CASE(ABZ_F_ONE)
+        CASE(ABZ_F_LINEAR)
+        CASE(ABZ_F_LINEAR_X)
+        CASE(ABZ_F_DOS)
+        CASE(ABZ_F_TRGLOC)
+        CASE(ABZ_F_GLOC)
+        CASE(ABZ_F_DOS_EIG)
+    }
+#undef CASE
+#undef LAUNCH_INNER
     ABZ_HIP(hipGetLastError());
     return ABZ_OK;
 }
