@@ -97,6 +97,7 @@ def main():
     ap.add_argument("--eta", type=float, default=0.1)
     ap.add_argument("--cpu-npt", type=int, default=64)
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-iai", action="store_true")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -225,6 +226,24 @@ def main():
                          "reduce_avg_ms": red_ms / max(red_n, 1),
                          "reduce_read_GBs": nk * (16 * n * n) / ((red_ms / max(red_n, 1)) * 1e-3) / 1e9 if red_n else None},
         }
+        if not a.no_iai and world == 1:
+            # extra (not the primary metric): one IAI solve of the reference's own example
+            # (aps_example/aps_example.jl:29-34, eta = 0.01 eV, abstol 1e-3) with host-driven outer
+            # panels and device-side innermost adaptive loops
+            try:
+                fiai = abz.FourierIntegrand(abz.DOSIntegrand(), s, 0.01)
+                out["iai_example"] = {}
+                for kind, bzk in (("CubicSymIBZ", abz.CubicSymIBZ()), ("FBZ", abz.FBZ())):
+                    bz = abz.load_bz(bzk, 3.85856 * np.eye(3))
+                    prob = abz.IntegralProblem(fiai, bz, abz.MixedParameters(12.5))
+                    abz.solve(prob, abz.IAI(), abstol=1e-3)  # warm-up (allocations)
+                    t0 = time.perf_counter()
+                    sol = abz.solve(prob, abz.EvalCounter(abz.IAI()), abstol=1e-3)
+                    dt = time.perf_counter() - t0
+                    out["iai_example"][kind] = {"u": sol.u, "resid": sol.resid, "numevals": sol.numevals, "seconds": dt,
+                                                "nodes_per_sec": sol.numevals / dt}
+            except Exception as e:
+                out["iai_example"] = {"error": str(e)}
         if not a.no_cpu:
             try:
                 out["cpu_baseline"] = cpu_baseline(a.cpu_npt, 4, s)
