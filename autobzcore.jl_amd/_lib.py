@@ -37,6 +37,7 @@ PROTOTYPES = {
     "abz_rule_reduce": (C.c_int, [C.c_void_p, C.c_int, c_f64p, C.c_int, c_f64p, C.c_int, C.c_int, c_f64p]),
     "abz_rule_ggr": (C.c_int, [C.c_void_p, c_f64p, C.c_int, c_f64p]),
     "abz_symptr_rule": (C.c_int, [C.c_int, C.c_int, c_i32p, C.c_int, c_i64p, c_i32p, c_i64p]),
+    "abz_symptr_rule_device": (C.c_int, [C.c_void_p, C.c_int, C.c_int, c_i32p, C.c_int, c_i64p, c_i32p, c_i64p]),
     "abz_contract_nodes": (C.c_int, [C.c_void_p, C.c_int, c_i64p, c_f64p, C.c_int64, c_i64p]),
     "abz_eval_line_nodes": (C.c_int, [C.c_void_p, c_i64p, c_f64p, c_f64p, C.c_int64, C.c_int, c_f64p, C.c_int,
                                       C.c_double, c_f64p]),

@@ -177,19 +177,24 @@ def _syms_key(syms):
     return np.ascontiguousarray(np.rint(np.asarray(syms)).astype(np.int32)).tobytes()
 
 
-def symptr_rule(npt, d, syms):
+def symptr_rule(npt, d, syms, ctx=None):
     """Irreducible grid nodes (0-based indices, column-major order) and integer weights.
-    ref: AutoSymPTR.symptr_rule as called at src/fourier.jl:271."""
+    ref: AutoSymPTR.symptr_rule as called at src/fourier.jl:271.  With a device context the orbit
+    tables are computed on the GPU (abz_symptr_rule_device), otherwise by the host routine; both give
+    bit-identical integers."""
     S = np.ascontiguousarray(np.rint(np.asarray(syms)).astype(np.int32).reshape(-1, d, d))
     if not np.allclose(S, np.asarray(syms).reshape(-1, d, d)):
         raise ValueError("symmetries must be integer matrices in the lattice basis")
     _, pS = L.i32(S)
     n = C.c_int64(0)
-    L.check(L.lib().abz_symptr_rule(npt, d, pS, len(S), C.byref(n), None, None))
+    if ctx is not None and len(S) <= 48:
+        fn = lambda *a: L.lib().abz_symptr_rule_device(ctx.h, *a)
+    else:
+        fn = L.lib().abz_symptr_rule
+    L.check(fn(npt, d, pS, len(S), C.byref(n), None, None))
     idx = np.empty((n.value, d), dtype=np.int32)
     w = np.empty(n.value, dtype=np.int64)
-    L.check(L.lib().abz_symptr_rule(npt, d, pS, len(S), C.byref(n), idx.ctypes.data_as(L.c_i32p),
-                                    w.ctypes.data_as(L.c_i64p)))
+    L.check(fn(npt, d, pS, len(S), C.byref(n), idx.ctypes.data_as(L.c_i32p), w.ctypes.data_as(L.c_i64p)))
     return idx, w
 
 
@@ -209,7 +214,7 @@ class DeviceRule:
             L.check(L.lib().abz_ptr_rule_build(dev.h, self.npt, 0, None, None, want, C.byref(h)))
             self.nk = self.npt ** d
         else:
-            idx, w = symptr_rule(self.npt, d, syms)
+            idx, w = symptr_rule(self.npt, d, syms, ctx=dev.ctx)
             L.check(L.lib().abz_ptr_rule_build(dev.h, self.npt, len(w), idx.ctypes.data_as(L.c_i32p),
                                                w.ctypes.data_as(L.c_i64p), want, C.byref(h)))
             self.nk = len(w)

@@ -132,6 +132,24 @@ def test_symmetric_rule_integers_and_values(abz, kind, d, npt):
     assert np.abs(out["H"] - valo).max() <= 1e-12 * np.abs(valo).max()
 
 
+def test_symptr_rule_device_bit_exact(abz):
+    """the orbit tables computed on the GPU equal the host routine bit for bit."""
+    ctx = abz.Context.default()
+    for kind, d, npt in (("InversionSymIBZ", 1, 9), ("InversionSymIBZ", 2, 10), ("CubicSymIBZ", 2, 9), ("CubicSymIBZ", 3, 8),
+                         ("CubicSymIBZ", 3, 50), ("InversionSymIBZ", 3, 33), ("CubicSymIBZ", 3, 150)):
+        syms = orc.load_bz(kind, np.eye(d)).syms
+        ih, wh = abz.symptr_rule(npt, d, syms)
+        ig, wg = abz.symptr_rule(npt, d, syms, ctx=ctx)
+        assert np.array_equal(ih, ig) and np.array_equal(wh, wg) and wg.sum() == npt**d
+    # a smaller point group (C4 about z with the mirror z -> -z): 8 elements, closed under products
+    r = np.array([[0, -1, 0], [1, 0, 0], [0, 0, 1]])
+    m = np.diag([1, 1, -1])
+    syms = [np.linalg.matrix_power(r, k) @ mm for k in range(4) for mm in (np.eye(3, dtype=int), m)]
+    ih, wh = abz.symptr_rule(9, 3, syms)
+    ig, wg = abz.symptr_rule(9, 3, syms, ctx=ctx)
+    assert np.array_equal(ih, ig) and np.array_equal(wh, wg) and wg.sum() == 9**3
+
+
 def test_rule_reduce_matches_oracle_dos(abz):
     rng = np.random.default_rng(5)
     c, first = rand_series(rng, (3, 3, 3), 3, hermitian=True)
