@@ -141,7 +141,12 @@ def cube_automorphisms(d):
 
 
 def load_bz(bz: AbstractBZ, A=None, B=None, atol=None) -> SymmetricBZ:
-    """ref: src/brillouin.jl:179-212,264-307."""
+    """ref: src/brillouin.jl:179-212,264-307; `A` may be the path of a Wannier90 `seedname.wout`
+    (ext/WannierIOExt.jl:12-17, default atol 1e-5 for the printed 6-digit lattice)."""
+    if isinstance(A, (str, bytes)) or hasattr(A, "__fspath__"):
+        from .io_w90 import read_w90_wout
+        A, B = read_w90_wout(A)
+        atol = 1e-5 if atol is None else atol
     if A is None:
         if bz.n is None:
             raise ValueError("BZ dimension must be integer")

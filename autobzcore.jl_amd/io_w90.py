@@ -36,3 +36,24 @@ def read_w90_hrdat(path):
 def load_w90_series(path, period=1.0):
     H, first = read_w90_hrdat(path)
     return FourierSeries(H, period=period, first=first, ndim=3)
+
+
+def read_w90_wout(path):
+    """Lattice (columns a_1..a_3, Angstrom) and reciprocal lattice (columns b_1..b_3, 1/Angstrom) from a
+    Wannier90 `seedname.wout`.  ref: WannierIO.read_wout as used by ext/WannierIOExt.jl:12-16."""
+    opener = gzip.open if str(path).endswith(".gz") else open
+    A = np.zeros((3, 3))
+    B = np.zeros((3, 3))
+    got = set()
+    with opener(path, "rt") as fh:
+        for line in fh:
+            t = line.split()
+            if len(t) == 4 and t[0] in ("a_1", "a_2", "a_3", "b_1", "b_2", "b_3"):
+                tgt = A if t[0][0] == "a" else B
+                tgt[:, int(t[0][2]) - 1] = [float(v) for v in t[1:]]
+                got.add(t[0])
+            if len(got) == 6:
+                break
+    if len(got) != 6:
+        raise ValueError(f"{path}: lattice vectors not found")
+    return A, B

@@ -119,3 +119,12 @@ def test_w90_reader(abz):
     so = orc.FourierSeries(c, period=1.0, first=s.first, ndim=3)
     e = np.linalg.eigvalsh(orc.evaluate(so, [0.1, 0.2, 0.3]))
     assert np.abs(e - [12.351303, 12.824980, 12.909626]).max() < 2e-6
+
+
+def test_w90_wout_reader(abz):
+    # ref: ext/WannierIOExt.jl:12-17 + aps_example/aps_example.jl:25 (load_bz(CubicSymIBZ(), "svo.wout"))
+    path = os.path.join(ROOT, "tests", "golden", "svo.wout.gz")
+    A, B = abz.read_w90_wout(path)
+    assert np.allclose(A, 3.858560 * np.eye(3)) and np.allclose(B, 1.628376 * np.eye(3))
+    bz = abz.load_bz(abz.CubicSymIBZ(), path)
+    assert abz.nsyms(bz) == 48 and abs(abs(np.linalg.det(bz.B)) - 4.31781) < 1e-4
