@@ -282,7 +282,7 @@ int IaiDriver::solve_inner_device(std::vector<Quad1D>& kids) {
     is.E_out = d_E;
     is.nev_out = d_nev;
     is.status_out = d_st;
-    if ((rc = launch_inner_adaptive(ctx, is))) return rc;
+    if ((rc = (n > 4 ? launch_gen_inner_adaptive(ctx, is) : launch_inner_adaptive(ctx, is)))) return rc;
     std::vector<char> hb(out_bytes);
     ABZ_HIP(hipMemcpyAsync(hb.data(), ob, out_bytes, hipMemcpyDeviceToHost, ctx->stream));
     ABZ_HIP(hipStreamSynchronize(ctx->stream));
@@ -522,8 +522,8 @@ int abz_iai_solve(abz_series* s, int lims_kind, const double* lim_a, const doubl
     drv.max_batch = max_batch;
     {
         const char* e = getenv("ABZ_IAI_DEVICE_INNER");  // 0 forces the host loop at every level
-        drv.device_inner = max_batch <= 0 && s->d >= 2 && inner_adaptive_supported(s->n, integrand) &&
-                           !(e && e[0] == '0');
+        const bool ok = s->n > 4 ? gen_inner_supported(s->n, s->dims[0], integrand) : inner_adaptive_supported(s->n, integrand);
+        drv.device_inner = max_batch <= 0 && s->d >= 2 && ok && !(e && e[0] == '0');
     }
     std::vector<Quad1D> top(1);
     Quad1D& q = top[0];

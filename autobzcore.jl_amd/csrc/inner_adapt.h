@@ -1,0 +1,179 @@
+// One step of QuadGK's globally adaptive loop for ONE 1-D integral, executed by a single lane of the
+// group that owns the integral (shared by the n <= 4 and the generic-n inner kernels).  Semantics =
+// iai_host.cpp / oracle auxquadgk scalar mode: DataStructures.jl heap (Base.Order.Reverse on E),
+// numevals += 30 at pop time, re-sum over the heap in storage order at the end, shared gk15.h rule.
+#pragma once
+#include "abz_internal.h"
+#include "gk15.h"
+
+namespace abz {
+
+constexpr int ADAPT_MAXC = 16;
+
+struct AdaptState {
+    int nseg = 0, nheap = 0, popped = -1, status = 0;
+    bool first = true;
+    double E = 0.0, atol = 0.0, rtol = 0.0;
+    long long numevals = 0;
+    double Ir[ADAPT_MAXC], Ii[ADAPT_MAXC];
+};
+
+struct InnerOut {
+    double2* I;
+    double* E;
+    int64_t* nev;
+    int* status;
+};
+
+// ctl: [0] number of pending panels, [1..4] their (a, b) pairs
+__device__ __forceinline__ void adapt_init(AdaptState& st, double at, bool has_rtol, double rtol_user, double lo, double hi,
+                                           double* ctl) {
+    st = AdaptState();
+#pragma unroll
+    for (int c = 0; c < ADAPT_MAXC; ++c) {
+        st.Ir[c] = 0.0;
+        st.Ii[c] = 0.0;
+    }
+    st.atol = at >= 0.0 ? at : 0.0;
+    st.rtol = has_rtol ? rtol_user : ((at > 0.0) ? 0.0 : 1.4901161193847656e-08);  // sqrt(eps)
+    ctl[0] = 1.0;
+    ctl[1] = lo;
+    ctl[2] = hi;
+}
+
+// Consumes the values of the pending panels (vals: [30][nc]), updates the heap and either schedules the
+// next bisection in ctl (returns false) or writes the result (returns true).
+__device__ inline bool adapt_step(AdaptState& st, int nc, double* seg_a, double* seg_b, double* seg_E, gkc* seg_I,
+                                  const gkc* vals, int* heap, double* ctl, long long maxevals, const InnerOut& out) {
+    constexpr int MS = ABZ_INNER_MAXSEG;
+    const int np = (int)ctl[0];
+    int newseg[2] = {-1, -1};
+    for (int pnl = 0; pnl < np; ++pnl) {
+        int sl;  // the popped parent's slot is reused for the first child
+        if (pnl == 0 && st.popped >= 0)
+            sl = st.popped;
+        else
+            sl = st.nseg++;
+        if (sl >= MS) {
+            st.status = 1;
+            sl = MS - 1;
+        }
+        newseg[pnl] = sl;
+    }
+    if (st.first) {
+        st.first = false;
+        const int sl = newseg[0];
+        seg_a[sl] = ctl[1];
+        seg_b[sl] = ctl[2];
+        seg_E[sl] = gk15_rule(vals, nc, seg_a[sl], seg_b[sl], seg_I + (size_t)sl * nc);
+        for (int c = 0; c < nc; ++c) {
+            st.Ir[c] = seg_I[(size_t)sl * nc + c].re;
+            st.Ii[c] = seg_I[(size_t)sl * nc + c].im;
+        }
+        st.E = seg_E[sl];
+        st.numevals = 15;
+        heap[0] = sl;
+        st.nheap = 1;
+    } else {
+        // I = (I - I_parent) + I_1 + I_2, E likewise; the parent's values are read before its slot is reused
+        const int sp = st.popped;
+        double pIr[ADAPT_MAXC], pIi[ADAPT_MAXC];
+        for (int c = 0; c < nc; ++c) {
+            pIr[c] = seg_I[(size_t)sp * nc + c].re;
+            pIi[c] = seg_I[(size_t)sp * nc + c].im;
+        }
+        const double pE = seg_E[sp];
+        const int s1 = newseg[0], s2 = newseg[1];
+        seg_a[s1] = ctl[1];
+        seg_b[s1] = ctl[2];
+        seg_a[s2] = ctl[3];
+        seg_b[s2] = ctl[4];
+        seg_E[s1] = gk15_rule(vals, nc, seg_a[s1], seg_b[s1], seg_I + (size_t)s1 * nc);
+        seg_E[s2] = gk15_rule(vals + (size_t)15 * nc, nc, seg_a[s2], seg_b[s2], seg_I + (size_t)s2 * nc);
+        {
+#pragma clang fp contract(off)
+            for (int c = 0; c < nc; ++c) {
+                st.Ir[c] = ((st.Ir[c] - pIr[c]) + seg_I[(size_t)s1 * nc + c].re) + seg_I[(size_t)s2 * nc + c].re;
+                st.Ii[c] = ((st.Ii[c] - pIi[c]) + seg_I[(size_t)s1 * nc + c].im) + seg_I[(size_t)s2 * nc + c].im;
+            }
+            st.E = ((st.E - pE) + seg_E[s1]) + seg_E[s2];
+        }
+        for (int t = 0; t < 2; ++t) {  // heappush (percolate_up)
+            const int x = t == 0 ? s1 : s2;
+            int i = st.nheap++;
+            while (i > 0) {
+                const int j = (i - 1) / 2;
+                if (!(seg_E[heap[j]] < seg_E[x])) break;
+                heap[i] = heap[j];
+                i = j;
+            }
+            heap[i] = x;
+        }
+    }
+    double nrm = 0.0;
+    {
+#pragma clang fp contract(off)
+        for (int c = 0; c < nc; ++c) {
+            const double t1 = st.Ir[c] * st.Ir[c], t2 = st.Ii[c] * st.Ii[c];
+            const double t3 = t1 + t2;
+            nrm = nrm + t3;
+        }
+    }
+    nrm = sqrt(nrm);
+    const double tol = fmax(st.atol, st.rtol * nrm);
+    if (st.E > tol && st.numevals < maxevals && st.status == 0) {
+        // heappop: root out, last to root, percolate_down
+        const int x = heap[0];
+        const int y = heap[--st.nheap];
+        if (st.nheap > 0) {
+            int i = 0;
+            while (true) {
+                const int lc = 2 * i + 1;
+                if (lc >= st.nheap) break;
+                const int rc = lc + 1;
+                const int j = (rc >= st.nheap || seg_E[heap[rc]] < seg_E[heap[lc]]) ? lc : rc;
+                if (!(seg_E[y] < seg_E[heap[j]])) break;
+                heap[i] = heap[j];
+                i = j;
+            }
+            heap[i] = y;
+        }
+        st.popped = x;
+        st.numevals += 30;
+        const double pa = seg_a[x], pb = seg_b[x];
+        const double mid = (pa + pb) / 2;
+        ctl[0] = 2.0;
+        ctl[1] = pa;
+        ctl[2] = mid;
+        ctl[3] = mid;
+        ctl[4] = pb;
+        return false;
+    }
+    {  // re-sum over the heap in storage order (QuadGK does this after adapt)
+#pragma clang fp contract(off)
+        for (int c = 0; c < nc; ++c) {
+            st.Ir[c] = seg_I[(size_t)heap[0] * nc + c].re;
+            st.Ii[c] = seg_I[(size_t)heap[0] * nc + c].im;
+        }
+        st.E = seg_E[heap[0]];
+        for (int h = 1; h < st.nheap; ++h) {
+            for (int c = 0; c < nc; ++c) {
+                st.Ir[c] = st.Ir[c] + seg_I[(size_t)heap[h] * nc + c].re;
+                st.Ii[c] = st.Ii[c] + seg_I[(size_t)heap[h] * nc + c].im;
+            }
+            st.E = st.E + seg_E[heap[h]];
+        }
+    }
+    for (int c = 0; c < nc; ++c) out.I[c] = make_double2(st.Ir[c], st.Ii[c]);
+    *out.E = st.E;
+    *out.nev = st.numevals;
+    *out.status = st.status;
+    return true;
+}
+
+// LDS doubles of one integral in flight: seg_a, seg_b, seg_E | seg_I | vals[30] | heap | ctl
+__host__ __device__ inline int inner_group_doubles(int ncomp) {
+    return 3 * ABZ_INNER_MAXSEG + 2 * ncomp * ABZ_INNER_MAXSEG + 2 * ncomp * 30 + ABZ_INNER_MAXSEG / 2 + 8;
+}
+
+}  // namespace abz

@@ -14,6 +14,7 @@
 #include "abz_internal.h"
 #include "device_math.h"
 #include "gk15.h"
+#include "inner_adapt.h"
 
 #include <cmath>
 #include <cstdlib>
@@ -1367,13 +1368,6 @@ struct InnerArgs {
     int* status_out;
 };
 
-// LDS layout of one group (one integral in flight), in doubles:
-//   seg_a[MAXSEG] seg_b[MAXSEG] seg_E[MAXSEG] | seg_I[MAXSEG][ncomp] (complex) | vals[30][ncomp] (complex)
-//   | heap[MAXSEG] (int, packed 2 per double) | ctl[8]: np, pa0, pb0, pa1, pb1
-__host__ __device__ inline int inner_group_doubles(int ncomp) {
-    return 3 * ABZ_INNER_MAXSEG + 2 * ncomp * ABZ_INNER_MAXSEG + 2 * ncomp * 30 + ABZ_INNER_MAXSEG / 2 + 8;
-}
-
 template <int N, int FID>
 __global__ __launch_bounds__(256) void inner_adaptive_kernel(InnerArgs a) {
     extern __shared__ double lds_in[];
@@ -1393,10 +1387,7 @@ __global__ __launch_bounds__(256) void inner_adaptive_kernel(InnerArgs a) {
         const int64_t q = q0 + group;
         const bool live = q < a.nint;  // the whole group shares it; both groups of a wave loop together
         // ---- lane 0 state
-        int nseg = 0, nheap = 0, popped = -1;
-        double E = 0.0, atol = 0.0, rtol = 0.0;
-        long long numevals = 0;
-        int status = 0;
+        AdaptState st;
         bool done = !live;
         cptr_t c1 = as_const(a.src);
         double tailv[ABZ_MAX_DIM] = {0.0, 0.0, 0.0};
@@ -1404,22 +1395,7 @@ __global__ __launch_bounds__(256) void inner_adaptive_kernel(InnerArgs a) {
             c1 = as_const(a.src + a.slot[q] * ((int64_t)a.M * N * N));
             if (FID == ABZ_F_LINEAR_X && a.tail)
                 for (int j = 0; j < a.d - 1; ++j) tailv[j] = a.tail[q * (a.d - 1) + j];
-            if (l == 0) {
-                const double at = a.atol[q];
-                atol = at >= 0.0 ? at : 0.0;
-                rtol = a.has_rtol ? a.rtol_user : ((at > 0.0) ? 0.0 : 1.4901161193847656e-08);  // sqrt(eps)
-                ctl[0] = 1.0;
-                ctl[1] = a.lo[q];
-                ctl[2] = a.hi[q];
-            }
-        }
-        bool first = true;
-        // gkc accumulators of lane 0 live in LDS row MS-? : keep I in registers up to MAXC comps
-        double Ir[MAXC], Ii[MAXC];
-#pragma unroll
-        for (int c = 0; c < MAXC; ++c) {
-            Ir[c] = 0.0;
-            Ii[c] = 0.0;
+            if (l == 0) adapt_init(st, a.atol[q], a.has_rtol != 0, a.rtol_user, a.lo[q], a.hi[q], ctl);
         }
         while (true) {
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -1468,131 +1444,12 @@ __global__ __launch_bounds__(256) void inner_adaptive_kernel(InnerArgs a) {
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             if (!grp_done && l == 0) {
-                // ---- QuadGK adapt bookkeeping (one lane): rule, heap, convergence, next bisection
-                const int np = (int)ctl[0];
-                int newseg[2] = {-1, -1};
-                for (int pnl = 0; pnl < np; ++pnl) {
-                    // slot for the new segment: reuse the popped parent's slot for the first child
-                    int sl;
-                    if (pnl == 0 && popped >= 0)
-                        sl = popped;
-                    else
-                        sl = nseg++;
-                    if (sl >= MS) {
-                        status = 1;
-                        sl = MS - 1;
-                    }
-                    const double pa = ctl[1 + 2 * pnl], pb = ctl[2 + 2 * pnl];
-                    // NOTE: the parent's I must be read before its slot is overwritten (done below)
-                    newseg[pnl] = sl;
-                    seg_a[sl] = pa;
-                    seg_b[sl] = pb;
-                }
-                if (first) {
-                    first = false;
-                    const int sl = newseg[0];
-                    seg_E[sl] = gk15_rule(vals, nc, seg_a[sl], seg_b[sl], seg_I + (size_t)sl * nc);
-                    for (int c = 0; c < nc; ++c) {
-                        Ir[c] = seg_I[(size_t)sl * nc + c].re;
-                        Ii[c] = seg_I[(size_t)sl * nc + c].im;
-                    }
-                    E = seg_E[sl];
-                    numevals = 15;
-                    heap[0] = sl;
-                    nheap = 1;
-                } else {
-                    // I = (I - I_parent) + I_1 + I_2 ; E likewise (parent's values still in slot `popped`)
-                    const int sp = popped;
-                    double pIr[MAXC], pIi[MAXC];
-                    for (int c = 0; c < nc; ++c) {
-                        pIr[c] = seg_I[(size_t)sp * nc + c].re;
-                        pIi[c] = seg_I[(size_t)sp * nc + c].im;
-                    }
-                    const double pE = seg_E[sp];
-                    const int s1 = newseg[0], s2 = newseg[1];
-                    seg_E[s1] = gk15_rule(vals, nc, seg_a[s1], seg_b[s1], seg_I + (size_t)s1 * nc);
-                    seg_E[s2] = gk15_rule(vals + (size_t)15 * nc, nc, seg_a[s2], seg_b[s2], seg_I + (size_t)s2 * nc);
-                    {
-#pragma clang fp contract(off)
-                        for (int c = 0; c < nc; ++c) {
-                            Ir[c] = ((Ir[c] - pIr[c]) + seg_I[(size_t)s1 * nc + c].re) + seg_I[(size_t)s2 * nc + c].re;
-                            Ii[c] = ((Ii[c] - pIi[c]) + seg_I[(size_t)s1 * nc + c].im) + seg_I[(size_t)s2 * nc + c].im;
-                        }
-                        E = ((E - pE) + seg_E[s1]) + seg_E[s2];
-                    }
-                    // heappush x2 (percolate_up, lt(Reverse, x, y) == y.E < x.E)
-                    for (int t = 0; t < 2; ++t) {
-                        const int x = t == 0 ? s1 : s2;
-                        int i = nheap++;
-                        while (i > 0) {
-                            const int j = (i - 1) / 2;
-                            if (!(seg_E[heap[j]] < seg_E[x])) break;
-                            heap[i] = heap[j];
-                            i = j;
-                        }
-                        heap[i] = x;
-                    }
-                }
-                double nrm = 0.0;
-                {
-#pragma clang fp contract(off)
-                    for (int c = 0; c < nc; ++c) {
-                        const double t1 = Ir[c] * Ir[c], t2 = Ii[c] * Ii[c];
-                        const double t3 = t1 + t2;
-                        nrm = nrm + t3;
-                    }
-                }
-                nrm = sqrt(nrm);
-                const double tol = fmax(atol, rtol * nrm);
-                if (E > tol && numevals < a.maxevals && status == 0) {
-                    // heappop: root out, last to root, percolate_down
-                    const int x = heap[0];
-                    const int y = heap[--nheap];
-                    if (nheap > 0) {
-                        int i = 0;
-                        while (true) {
-                            const int lc = 2 * i + 1;
-                            if (lc >= nheap) break;
-                            const int rc = lc + 1;
-                            const int j = (rc >= nheap || seg_E[heap[rc]] < seg_E[heap[lc]]) ? lc : rc;
-                            if (!(seg_E[y] < seg_E[heap[j]])) break;
-                            heap[i] = heap[j];
-                            i = j;
-                        }
-                        heap[i] = y;
-                    }
-                    popped = x;
-                    numevals += 30;
-                    const double pa = seg_a[x], pb = seg_b[x];
-                    const double mid = (pa + pb) / 2;
-                    ctl[0] = 2.0;
-                    ctl[1] = pa;
-                    ctl[2] = mid;
-                    ctl[3] = mid;
-                    ctl[4] = pb;
-                } else {
-                    // re-sum over the heap in storage order (QuadGK does this after adapt)
-                    if (numevals > 15 || nheap > 0) {
-#pragma clang fp contract(off)
-                        for (int c = 0; c < nc; ++c) {
-                            Ir[c] = seg_I[(size_t)heap[0] * nc + c].re;
-                            Ii[c] = seg_I[(size_t)heap[0] * nc + c].im;
-                        }
-                        E = seg_E[heap[0]];
-                        for (int h = 1; h < nheap; ++h) {
-                            for (int c = 0; c < nc; ++c) {
-                                Ir[c] = Ir[c] + seg_I[(size_t)heap[h] * nc + c].re;
-                                Ii[c] = Ii[c] + seg_I[(size_t)heap[h] * nc + c].im;
-                            }
-                            E = E + seg_E[heap[h]];
-                        }
-                    }
-                    for (int c = 0; c < nc; ++c) a.I_out[q * nc + c] = make_double2(Ir[c], Ii[c]);
-                    a.E_out[q] = E;
-                    a.nev_out[q] = numevals;
-                    a.status_out[q] = status;
-                    done = true;
-                }
+                InnerOut out;
+                out.I = a.I_out + q * nc;
+                out.E = a.E_out + q;
+                out.nev = a.nev_out + q;
+                out.status = a.status_out + q;
+                done = adapt_step(st, nc, seg_a, seg_b, seg_E, seg_I, vals, heap, ctl, a.maxevals, out);
             }
         }
     }

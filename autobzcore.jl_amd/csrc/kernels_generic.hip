@@ -12,6 +12,7 @@
 // Hermitian, so elimination without pivoting is backward stable up to a growth factor <= ||A||/eta;
 // that is what the Gauss-Jordan below relies on.
 #include "abz_internal.h"
+#include "inner_adapt.h"
 
 namespace abz {
 
@@ -540,6 +541,164 @@ int launch_gen_reduce(abz_ctx* ctx, const ReduceSpec& rs, double* out_reim) {
     }
     ABZ_HIP(hipMemcpyAsync(out_reim, outd, sizeof(double2) * (size_t)ncols, hipMemcpyDeviceToHost, ctx->stream));
     ABZ_HIP(hipStreamSynchronize(ctx->stream));
+    return ABZ_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// IAI innermost level on the device for n > 4: ONE WAVEFRONT per 1-D integral; the 15 / 30 nodes of a
+// round are evaluated one after the other by the whole wave (series value into LDS, Gauss-Jordan /
+// Jacobi as above), then lane 0 runs the shared adapt_step.
+// ------------------------------------------------------------------------------------------
+struct GenInnerArgs {
+    const double2* src;
+    const int64_t* slot;
+    const double* lo;
+    const double* hi;
+    const double* atol;
+    int64_t nint, maxevals;
+    int n, M, first, d, ncomp, integrand, has_rtol;
+    double inv_period, sweep, rtol_user;
+    double p[4];
+    double2* I_out;
+    double* E_out;
+    int64_t* nev_out;
+    int* status_out;
+};
+
+__host__ __device__ inline size_t gen_inner_wave_doubles(int n, int M, int ncomp) {
+    // H, W, X (complex n*n each), ph (complex M), ev (n) rounded to even, then the adapt group
+    return (size_t)2 * (3 * n * n + M) + (size_t)((n + 1) / 2) * 2 + (size_t)inner_group_doubles(ncomp);
+}
+
+__global__ __launch_bounds__(256) void gen_inner_adaptive_kernel(GenInnerArgs a, int waves_per_block) {
+    extern __shared__ double lds_gi[];
+    constexpr int MS = ABZ_INNER_MAXSEG;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (wave >= waves_per_block) return;
+    const int n = a.n, nn = n * n, nc = a.ncomp;
+    double* base = lds_gi + (size_t)wave * gen_inner_wave_doubles(n, a.M, nc);
+    double2* H = reinterpret_cast<double2*>(base);
+    double2* W = H + nn;
+    double2* X = W + nn;
+    double2* ph = X + nn;
+    double* ev = reinterpret_cast<double*>(ph + a.M);
+    double* g = ev + ((n + 1) / 2) * 2;
+    double* seg_a = g;
+    double* seg_b = seg_a + MS;
+    double* seg_E = seg_b + MS;
+    gkc* seg_I = reinterpret_cast<gkc*>(seg_E + MS);
+    gkc* vals = seg_I + (size_t)MS * nc;
+    int* heap = reinterpret_cast<int*>(vals + (size_t)30 * nc);
+    double* ctl = reinterpret_cast<double*>(heap + MS);
+    GenArgs ga;  // the fields gen_integrand reads
+    ga.n = n;
+    ga.integrand = a.integrand;
+    for (int i = 0; i < 4; ++i) ga.p[i] = a.p[i];
+    const int64_t wstride = (int64_t)gridDim.x * waves_per_block;
+    for (int64_t q = (int64_t)blockIdx.x * waves_per_block + wave; q < a.nint; q += wstride) {
+        AdaptState st;
+        if (lane == 0) {
+            adapt_init(st, a.atol[q], a.has_rtol != 0, a.rtol_user, a.lo[q], a.hi[q], ctl);
+            ctl[5] = 0.0;  // done flag
+        }
+        const double2* __restrict__ c1 = a.src + a.slot[q] * ((int64_t)a.M * nn);
+        while (true) {
+            wave_sync();
+            if (ctl[5] != 0.0) break;
+            const int np = (int)ctl[0];
+            for (int t = 0; t < 15 * np; ++t) {
+                const int pnl = t / 15, i = t - 15 * pnl;
+                const double x = gk15_node(ctl[1 + 2 * pnl], ctl[2 + 2 * pnl], i);
+                const double xx = x * a.inv_period;
+                double zr, zi, wr, wi;
+                sincospi(2.0 * xx, &zi, &zr);
+                sincospi(2.0 * ((double)a.first * xx), &wi, &wr);
+                {
+                    double pr = wr, pi = wi;
+                    for (int m = 0; m < a.M; ++m) {
+                        if (lane == (m & 63)) ph[m] = make_double2(pr, pi);
+                        const double nr = pr * zr - pi * zi, ni = pr * zi + pi * zr;
+                        pr = nr;
+                        pi = ni;
+                    }
+                }
+                wave_sync();
+                for (int e = lane; e < nn; e += 64) {
+                    double hr = 0.0, hi = 0.0;
+                    for (int m = 0; m < a.M; ++m) {
+                        const double2 c = c1[(int64_t)m * nn + e];
+                        const double2 qq = ph[m];
+                        hr = fma(c.x, qq.x, hr);
+                        hr = fma(-c.y, qq.y, hr);
+                        hi = fma(c.x, qq.y, hi);
+                        hi = fma(c.y, qq.x, hi);
+                    }
+                    H[e] = make_double2(hr, hi);
+                }
+                wave_sync();
+                if (a.integrand == ABZ_F_DOS_EIG) {
+                    for (int e = lane; e < nn; e += 64) W[e] = H[e];
+                    wave_sync();
+                    wave_eig(W, ev, n, lane);
+                }
+                gen_integrand(ga, H, W, X, ev, a.sweep, lane, reinterpret_cast<double2*>(vals + (size_t)t * nc));
+                wave_sync();
+            }
+            if (lane == 0) {
+                InnerOut out;
+                out.I = a.I_out + q * nc;
+                out.E = a.E_out + q;
+                out.nev = a.nev_out + q;
+                out.status = a.status_out + q;
+                if (adapt_step(st, nc, seg_a, seg_b, seg_E, seg_I, vals, heap, ctl, a.maxevals, out)) ctl[5] = 1.0;
+            }
+        }
+        wave_sync();
+    }
+}
+
+bool gen_inner_supported(int n, int M, int integrand) {
+    const int nc = integrand_ncomp(integrand, n, 3);
+    if (n <= 4 || n > ABZ_MAX_BANDS || nc <= 0 || nc > ADAPT_MAXC) return false;
+    if (integrand == ABZ_F_LINEAR || integrand == ABZ_F_LINEAR_X) return false;
+    return sizeof(double) * gen_inner_wave_doubles(n, M, nc) <= 150 * 1024;
+}
+
+int launch_gen_inner_adaptive(abz_ctx* ctx, const InnerSpec& is) {
+    if (is.nint == 0) return ABZ_OK;
+    GenInnerArgs a;
+    a.src = is.src;
+    a.slot = is.slot;
+    a.lo = is.lo;
+    a.hi = is.hi;
+    a.atol = is.atol;
+    a.nint = is.nint;
+    a.maxevals = is.maxevals;
+    a.n = is.n;
+    a.M = is.M;
+    a.first = is.first;
+    a.d = is.d;
+    a.ncomp = integrand_ncomp(is.integrand, is.n, is.d);
+    a.integrand = is.integrand;
+    a.has_rtol = is.has_rtol ? 1 : 0;
+    a.inv_period = 1.0 / is.period;
+    a.sweep = is.sweep;
+    a.rtol_user = is.rtol_user;
+    for (int i = 0; i < 4; ++i) a.p[i] = is.params[i];
+    a.I_out = is.I_out;
+    a.E_out = is.E_out;
+    a.nev_out = is.nev_out;
+    a.status_out = is.status_out;
+    const size_t per = sizeof(double) * gen_inner_wave_doubles(is.n, is.M, a.ncomp);
+    int wpb = (int)((150 * 1024) / per);
+    if (wpb > 4) wpb = 4;
+    if (wpb < 1) wpb = 1;
+    const size_t lds = per * wpb;
+    const int64_t blocks = std::min<int64_t>(cdiv2(is.nint, wpb), 256 * 16);
+    ProfScope ps(ctx, ABZ_K_EVAL);
+    ABZ_HIP(hipFuncSetAttribute((const void*)gen_inner_adaptive_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(gen_inner_adaptive_kernel, dim3((unsigned)blocks), dim3(256), lds, ctx->stream, a, wpb);
+    ABZ_HIP(hipGetLastError());
     return ABZ_OK;
 }
 
