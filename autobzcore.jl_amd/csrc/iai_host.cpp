@@ -522,7 +522,10 @@ int abz_iai_solve(abz_series* s, int lims_kind, const double* lim_a, const doubl
     drv.max_batch = max_batch;
     {
         const char* e = getenv("ABZ_IAI_DEVICE_INNER");  // 0 forces the host loop at every level
-        const bool ok = s->n > 4 ? gen_inner_supported(s->n, s->dims[0], integrand) : inner_adaptive_supported(s->n, integrand);
+        // n > 4: the wave-per-integral kernel is correct but (16 bands) not yet faster than the host loop:
+        // opt-in with ABZ_IAI_DEVICE_INNER=2
+        const bool ok = s->n > 4 ? (gen_inner_supported(s->n, s->dims[0], integrand) && e && e[0] == '2')
+                                 : inner_adaptive_supported(s->n, integrand);
         drv.device_inner = max_batch <= 0 && s->d >= 2 && ok && !(e && e[0] == '0');
     }
     std::vector<Quad1D> top(1);
