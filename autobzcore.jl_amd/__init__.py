@@ -11,6 +11,7 @@ from .bz import (FBZ, IBZ, Basis, CubicLimits, CubicSymIBZ, HyperCube, Inversion
                  SymmetricBZ, TetrahedralLimits, canonical_reciprocal_basis, load_bz, nsyms)
 from .dos import DOSProblem, DOSSolution, GGR
 from . import dos
+from .interp import ChebInterp, hchebinterp
 from .io_w90 import load_w90_series, read_w90_hrdat, read_w90_wout
 from . import dist
 from .dist import batchsolve_sharded, sharded_map

@@ -128,3 +128,20 @@ def test_w90_wout_reader(abz):
     assert np.allclose(A, 3.858560 * np.eye(3)) and np.allclose(B, 1.628376 * np.eye(3))
     bz = abz.load_bz(abz.CubicSymIBZ(), path)
     assert abz.nsyms(bz) == 48 and abs(abs(np.linalg.det(bz.B)) - 4.31781) < 1e-4
+
+
+def test_hchebinterp_driver(abz):
+    """The adaptive-in-omega driver of aps_example/aps_example.jl:36-39 on an analytic stand-in:
+    a Lorentzian comb (what a DOS with eta = 0.05 looks like), atol 1e-4; every new panel level is one
+    batch call."""
+    calls = []
+    f = lambda w: sum(0.05 / ((w - e) ** 2 + 0.05**2) for e in (10.7, 12.2, 12.25, 14.1)) / np.pi
+
+    def batch(xs):
+        calls.append(len(xs))
+        return np.array([f(x) for x in xs])
+    itp = abz.hchebinterp(None, 10.0, 15.0, atol=1e-4, batch=batch)
+    x = np.linspace(10, 15, 2001)
+    assert np.abs(itp(x) - np.array([f(t) for t in x])).max() < 5e-4
+    assert itp.numevals == sum(calls) and calls[0] == 16 and all(c % 16 == 0 for c in calls)
+    assert abs(itp(12.2) - f(12.2)) < 5e-4 and np.ndim(itp(12.2)) == 0
