@@ -81,7 +81,7 @@ def cpu_baseline(npt_sample, n_omega_sample, s):
     tB = time.perf_counter() - t0
     return {"value": nk / tA, "unit": "k-point evals/s (H(k)+eig)", "cores": cores, "kind": "port",
             "sample": f"SVO 3-band, PTR npt={npt_sample} FBZ ({nk} k-points), {reps} reps; "
-                      f"C restatement of the reference loops (not Julia), gcc -O3 -march=native -fopenmp, "
+                      f"C restatement of the reference loops (not Julia), gcc -O3 -march=x86-64-v3 -fopenmp, "
                       f"{cores} threads of {os.cpu_count()} logical CPUs",
             "dos_kpoint_omega_per_sec": nk * n_omega_sample / tB,
             "dos_sample": f"{n_omega_sample} omegas over the same {nk} cached H(k)"}
