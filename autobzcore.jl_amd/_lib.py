@@ -44,6 +44,9 @@ PROTOTYPES = {
     "abz_release_level": (C.c_int, [C.c_void_p, C.c_int]),
     "abz_iai_solve": (C.c_int, [C.c_void_p, C.c_int, c_f64p, c_f64p, C.c_int, c_f64p, C.c_int, C.c_double, C.c_double,
                                 C.c_double, C.c_int64, C.c_int64, c_f64p, c_f64p, c_i64p, c_f64p, C.c_int64, c_i64p]),
+    "abz_iai_solve_many": (C.c_int, [C.c_void_p, C.c_int, c_f64p, c_f64p, C.c_int, c_f64p, C.c_int, c_f64p, C.c_int,
+                                     C.c_double, C.c_double, C.c_int64, C.c_int64, c_f64p, c_f64p, c_i64p, c_f64p,
+                                     C.c_int64, c_i64p]),
     "abz_gk15_nodes": (C.c_int, [C.c_double, C.c_double, c_f64p]),
     "abz_gk15_batch": (C.c_int, [c_f64p, c_f64p, C.c_int64, C.c_int, c_f64p, c_f64p]),
 }

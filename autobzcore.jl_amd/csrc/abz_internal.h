@@ -210,6 +210,7 @@ struct NodeEvalSpec {
     int integrand;
     double params[4];
     double sweep;
+    const double* sweep_arr = nullptr;  // device [nnodes]: per-node sweep value (overrides `sweep`)
 };
 int launch_node_integrand(abz_ctx* ctx, const NodeEvalSpec& ns, double2* values_dev);
 
@@ -229,6 +230,7 @@ struct InnerSpec {
     int integrand;
     double params[4];
     double sweep;
+    const double* sweep_arr = nullptr;  // device [nint]: per-integral sweep value (overrides `sweep`)
     bool has_rtol;
     double rtol_user;
     int64_t maxevals;
@@ -264,6 +266,7 @@ struct GenSpec {
     const double* sweep_dev;
     double sweep0;
     int n_sweep;
+    const double* sweep_per_node = nullptr;  // device [nnodes]: one sweep value per node (n_sweep = 1)
     double2* values;  // [node][n_sweep][ncomp] or null
 };
 int launch_gen_nodes(abz_ctx* ctx, const GenSpec& gs);

@@ -59,6 +59,8 @@ struct Lims {
 // One adaptive 1-D integral (QuadGK do_quadgk/adapt state with DataStructures heap semantics).
 struct Quad1D {
     int64_t slot = 0;  // coefficient set of this integral's series
+    double sweep = 0.0;  // swept parameter of the solve this integral belongs to
+    int root = 0;        // index of that solve (abz_iai_solve_many)
     double tail[ABZ_MAX_DIM] = {0, 0, 0};  // fixed outer coordinates x_{L+1}.. (tail[0] = x_{L+1})
     Lims lims;
     bool has_atol = false;
@@ -130,8 +132,9 @@ struct IaiDriver {
     int64_t maxevals;
     int64_t max_batch = 0;  // 0: scalar refinement; > 0: BatchIntegrand refinement with this soft cap
     int64_t total_evals = 0;
+    std::vector<int64_t> evals_per_root;
     std::vector<int64_t> h_parents;
-    std::vector<double> h_x, h_tail;
+    std::vector<double> h_x, h_tail, h_sweep;
     std::vector<cd> h_values;
 
     double tol_r(const Quad1D& q) const {
@@ -192,7 +195,10 @@ int IaiDriver::eval_nodes(int64_t nn) {
         ABZ_HIP(hipMemcpyAsync(s->iai_io[2].p, h_tail.data(), sizeof(double) * (size_t)(nn * (d - 1)),
                                hipMemcpyHostToDevice, ctx->stream));
     }
+    if ((rc = s->iai_io[5].reserve(sizeof(double) * (size_t)nn))) return rc;
+    ABZ_HIP(hipMemcpyAsync(s->iai_io[5].p, h_sweep.data(), sizeof(double) * (size_t)nn, hipMemcpyHostToDevice, ctx->stream));
     NodeEvalSpec ns;
+    ns.sweep_arr = s->iai_io[5].as<double>();
     ns.n = n;
     ns.d = d;
     ns.M = s->dims[0];
@@ -221,7 +227,7 @@ int IaiDriver::solve_inner_device(std::vector<Quad1D>& kids) {
     const int64_t nq = (int64_t)kids.size();
     if (nq == 0) return ABZ_OK;
     std::vector<int64_t> slot((size_t)nq);
-    std::vector<double> lo((size_t)nq), hi((size_t)nq), at((size_t)nq), tl;
+    std::vector<double> lo((size_t)nq), hi((size_t)nq), at((size_t)nq), sw((size_t)nq), tl;
     const bool need_tail = integrand == ABZ_F_LINEAR_X && d > 1;
     if (need_tail) tl.resize((size_t)(nq * (d - 1)));
     for (int64_t i = 0; i < nq; ++i) {
@@ -229,18 +235,21 @@ int IaiDriver::solve_inner_device(std::vector<Quad1D>& kids) {
         slot[(size_t)i] = k.slot;
         k.lims.segs(1, lo[(size_t)i], hi[(size_t)i]);
         at[(size_t)i] = k.has_atol ? k.atol : -1.0;
+        sw[(size_t)i] = k.sweep;
         if (need_tail)
             for (int j = 0; j < d - 1; ++j) tl[(size_t)(i * (d - 1) + j)] = k.tail[j];
     }
     // device staging: [slot | lo | hi | atol | tail] in iai_io[0..2], outputs in iai_io[3], iai_io[5]
     int rc;
-    const size_t in_bytes = sizeof(int64_t) * (size_t)nq + sizeof(double) * (size_t)nq * 3;
+    const size_t in_bytes = sizeof(int64_t) * (size_t)nq + sizeof(double) * (size_t)nq * 4;
     if ((rc = s->iai_io[0].reserve(in_bytes))) return rc;
     char* base = static_cast<char*>(s->iai_io[0].p);
     int64_t* d_slot = reinterpret_cast<int64_t*>(base);
     double* d_lo = reinterpret_cast<double*>(base + sizeof(int64_t) * (size_t)nq);
     double* d_hi = d_lo + nq;
     double* d_at = d_hi + nq;
+    double* d_sw = d_at + nq;
+    ABZ_HIP(hipMemcpyAsync(d_sw, sw.data(), sizeof(double) * (size_t)nq, hipMemcpyHostToDevice, ctx->stream));
     ABZ_HIP(hipMemcpyAsync(d_slot, slot.data(), sizeof(int64_t) * (size_t)nq, hipMemcpyHostToDevice, ctx->stream));
     ABZ_HIP(hipMemcpyAsync(d_lo, lo.data(), sizeof(double) * (size_t)nq, hipMemcpyHostToDevice, ctx->stream));
     ABZ_HIP(hipMemcpyAsync(d_hi, hi.data(), sizeof(double) * (size_t)nq, hipMemcpyHostToDevice, ctx->stream));
@@ -275,6 +284,7 @@ int IaiDriver::solve_inner_device(std::vector<Quad1D>& kids) {
     is.integrand = integrand;
     for (int i = 0; i < 4; ++i) is.params[i] = params[i];
     is.sweep = sweep;
+    is.sweep_arr = d_sw;
     is.has_rtol = has_rtol;
     is.rtol_user = rtol_user;
     is.maxevals = maxevals;
@@ -304,6 +314,7 @@ int IaiDriver::solve_inner_device(std::vector<Quad1D>& kids) {
         k.numevals = hN[i];
         k.done = true;
         total_evals += hN[i];
+        evals_per_root[(size_t)k.root] += hN[i];
     }
     if (!redo.empty()) {
         const bool keep = device_inner;
@@ -339,6 +350,7 @@ int IaiDriver::solve_level(int L, std::vector<Quad1D>& quads) {
         for (size_t qi : active) nn += 15 * (int64_t)quads[qi].pend.size();
         h_parents.resize((size_t)nn);
         h_x.resize((size_t)nn);
+        if (L == 1) h_sweep.resize((size_t)nn);
         if (d > 1) h_tail.resize((size_t)(nn * (d - 1)));
         int64_t t = 0;
         for (size_t qi : active) {
@@ -348,9 +360,11 @@ int IaiDriver::solve_level(int L, std::vector<Quad1D>& quads) {
                 for (int i = 0; i < 15; ++i, ++t) {
                     h_parents[(size_t)t] = q.slot;
                     h_x[(size_t)t] = xs15[i];
+                    if (L == 1) h_sweep[(size_t)t] = q.sweep;
                     if (d > 1 && L == 1)
                         for (int j = 0; j < d - 1; ++j) h_tail[(size_t)(t * (d - 1) + j)] = q.tail[j];
                 }
+                if (L == 1) evals_per_root[(size_t)q.root] += 15;
             }
         }
         // ---- evaluate them
@@ -371,6 +385,8 @@ int IaiDriver::solve_level(int L, std::vector<Quad1D>& quads) {
                         Quad1D& k = kids[(size_t)t];
                         const double x = h_x[(size_t)t];
                         k.slot = t;
+                        k.sweep = q.sweep;
+                        k.root = q.root;
                         k.tail[0] = x;
                         for (int j = 1; j < ABZ_MAX_DIM; ++j) k.tail[j] = q.tail[j - 1];
                         k.lims = q.lims.fix(L, x);
@@ -497,11 +513,12 @@ int abz_gk15_batch(const double* ab, const double* values_reim, int64_t npanels,
     return ABZ_OK;
 }
 
-int abz_iai_solve(abz_series* s, int lims_kind, const double* lim_a, const double* lim_b, int integrand,
-                  const double* params, int nparams, double sweep, double abstol, double reltol, int64_t maxevals,
-                  int64_t max_batch, double* out_reim, double* err, int64_t* numevals, double* panels,
-                  int64_t max_panels, int64_t* npanels) {
+int abz_iai_solve_many(abz_series* s, int lims_kind, const double* lim_a, const double* lim_b, int integrand,
+                       const double* params, int nparams, const double* sweeps, int n_sweep, double abstol, double reltol,
+                       int64_t maxevals, int64_t max_batch, double* out_reim, double* err, int64_t* numevals,
+                       double* panels, int64_t max_panels, int64_t* npanels) {
     ABZ_REQUIRE(s && s->ctx && lim_a && out_reim, "abz_iai_solve: null argument");
+    ABZ_REQUIRE(n_sweep >= 1 && sweeps, "abz_iai_solve: at least one sweep value");
     ABZ_REQUIRE(lims_kind == ABZ_LIMS_CUBIC || lims_kind == ABZ_LIMS_TETRAHEDRAL, "unknown limits kind %d", lims_kind);
     ABZ_REQUIRE(lims_kind != ABZ_LIMS_CUBIC || lim_b, "CubicLimits need lim_b");
     ABZ_REQUIRE(nparams >= 0 && nparams <= 4, "nparams = %d not in 0..4", nparams);
@@ -515,11 +532,12 @@ int abz_iai_solve(abz_series* s, int lims_kind, const double* lim_a, const doubl
     drv.ncomp = integrand_ncomp(integrand, s->n, s->d);
     ABZ_REQUIRE(drv.ncomp > 0, "unknown integrand id %d", integrand);
     for (int i = 0; i < 4; ++i) drv.params[i] = (i < nparams && params) ? params[i] : 0.0;
-    drv.sweep = sweep;
+    drv.sweep = sweeps[0];
     drv.has_rtol = reltol >= 0;
     drv.rtol_user = reltol;
     drv.maxevals = maxevals > 0 ? maxevals : (int64_t)1 << 62;
     drv.max_batch = max_batch;
+    drv.evals_per_root.assign((size_t)n_sweep, 0);
     {
         const char* e = getenv("ABZ_IAI_DEVICE_INNER");  // 0 forces the host loop at every level
         // n > 4: the wave-per-integral kernel is correct but (16 bands) not yet faster than the host loop:
@@ -528,27 +546,34 @@ int abz_iai_solve(abz_series* s, int lims_kind, const double* lim_a, const doubl
                                  : inner_adaptive_supported(s->n, integrand);
         drv.device_inner = max_batch <= 0 && s->d >= 2 && ok && !(e && e[0] == '0');
     }
-    std::vector<Quad1D> top(1);
-    Quad1D& q = top[0];
-    q.slot = 0;
-    q.lims.kind = lims_kind;
-    q.lims.s = 1.0;
-    for (int j = 0; j < s->d; ++j) {
-        q.lims.a[j] = lim_a[j];
-        q.lims.b[j] = lim_b ? lim_b[j] : 0.0;
+    // one top-level integral per sweep value; they advance in lock-step like any other siblings
+    std::vector<Quad1D> top((size_t)n_sweep);
+    for (int r = 0; r < n_sweep; ++r) {
+        Quad1D& q = top[(size_t)r];
+        q.slot = 0;
+        q.sweep = sweeps[r];
+        q.root = r;
+        q.lims.kind = lims_kind;
+        q.lims.s = 1.0;
+        for (int j = 0; j < s->d; ++j) {
+            q.lims.a[j] = lim_a[j];
+            q.lims.b[j] = lim_b ? lim_b[j] : 0.0;
+        }
+        q.has_atol = abstol >= 0;
+        q.atol = abstol >= 0 ? abstol : 0.0;
     }
-    q.has_atol = abstol >= 0;
-    q.atol = abstol >= 0 ? abstol : 0.0;
     int rc = drv.solve_level(s->d, top);
     if (rc) return rc;
-    for (int c = 0; c < drv.ncomp; ++c) {
-        out_reim[2 * c] = top[0].I[(size_t)c].real();
-        out_reim[2 * c + 1] = top[0].I[(size_t)c].imag();
+    for (int r = 0; r < n_sweep; ++r) {
+        for (int c = 0; c < drv.ncomp; ++c) {
+            out_reim[2 * ((size_t)r * drv.ncomp + c)] = top[(size_t)r].I[(size_t)c].real();
+            out_reim[2 * ((size_t)r * drv.ncomp + c) + 1] = top[(size_t)r].I[(size_t)c].imag();
+        }
+        if (err) err[r] = top[(size_t)r].E;
+        if (numevals) numevals[r] = drv.evals_per_root[(size_t)r];
     }
-    if (err) *err = top[0].E;
-    if (numevals) *numevals = drv.total_evals;
     if (npanels) *npanels = (int64_t)top[0].heap.size();
-    if (panels) {
+    if (panels) {  // panels of the first solve
         std::vector<std::pair<double, double>> pn;
         for (auto& sg : top[0].heap) pn.emplace_back(sg.a, sg.b);
         std::sort(pn.begin(), pn.end());
@@ -558,6 +583,14 @@ int abz_iai_solve(abz_series* s, int lims_kind, const double* lim_a, const doubl
         }
     }
     return ABZ_OK;
+}
+
+int abz_iai_solve(abz_series* s, int lims_kind, const double* lim_a, const double* lim_b, int integrand,
+                  const double* params, int nparams, double sweep, double abstol, double reltol, int64_t maxevals,
+                  int64_t max_batch, double* out_reim, double* err, int64_t* numevals, double* panels,
+                  int64_t max_panels, int64_t* npanels) {
+    return abz_iai_solve_many(s, lims_kind, lim_a, lim_b, integrand, params, nparams, &sweep, 1, abstol, reltol, maxevals,
+                              max_batch, out_reim, err, numevals, panels, max_panels, npanels);
 }
 
 // ---- building blocks for a host-language (Julia) adaptive loop -------------------------------
@@ -612,6 +645,7 @@ int abz_eval_line_nodes(abz_series* s, const int64_t* parents, const double* x, 
     drv.sweep = sweep;
     drv.h_parents.assign(parents, parents + nnodes);
     drv.h_x.assign(x, x + nnodes);
+    drv.h_sweep.assign((size_t)nnodes, sweep);
     if (tail && s->d > 1) drv.h_tail.assign(tail, tail + nnodes * (s->d - 1));
     int rc = drv.eval_nodes(nnodes);
     if (rc) return rc;

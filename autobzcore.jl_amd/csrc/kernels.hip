@@ -1228,6 +1228,7 @@ struct NodeArgs {
     const int64_t* parents;
     const double* x;
     const double* tail;
+    const double* sweep_arr;
     int64_t nnodes;
     int M, first, d, ncomp;
     double inv_period, sweep;
@@ -1260,7 +1261,7 @@ __global__ __launch_bounds__(256) void node_integrand_kernel(NodeArgs a, double2
         for (int j = 1; j < a.d; ++j) xk[j] = a.tail[k * (a.d - 1) + (j - 1)];
     }
     double vr[MAXC], vi[MAXC];
-    integrand_value<N, FID>(H, e, xk, a.d, a.p, a.sweep, vr, vi);
+    integrand_value<N, FID>(H, e, xk, a.d, a.p, a.sweep_arr ? a.sweep_arr[k] : a.sweep, vr, vi);
     constexpr int NC = NComp<FID>::template value<N>();
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
@@ -1295,6 +1296,7 @@ int launch_node_integrand(abz_ctx* ctx, const NodeEvalSpec& ns, double2* values_
         gs.sweep_dev = nullptr;
         gs.sweep0 = ns.sweep;
         gs.n_sweep = 1;
+        gs.sweep_per_node = ns.sweep_arr;
         gs.values = values_dev;
         return launch_gen_nodes(ctx, gs);
     }
@@ -1319,6 +1321,7 @@ int launch_node_integrand(abz_ctx* ctx, const NodeEvalSpec& ns, double2* values_
     a.ncomp = ncomp;
     a.inv_period = 1.0 / ns.period;
     a.sweep = ns.sweep;
+    a.sweep_arr = ns.sweep_arr;
     for (int i = 0; i < 4; ++i) a.p[i] = ns.params[i];
     ProfScope ps(ctx, ABZ_K_EVAL);
     const unsigned blocks = (unsigned)cdiv(ns.nnodes, 256);
@@ -1358,6 +1361,7 @@ struct InnerArgs {
     const double* hi;
     const double* atol;
     const double* tail;
+    const double* sweep_arr;
     int64_t nint, maxevals;
     int M, first, d, ncomp, has_rtol;
     double inv_period, sweep, rtol_user;
@@ -1391,7 +1395,9 @@ __global__ __launch_bounds__(256) void inner_adaptive_kernel(InnerArgs a) {
         bool done = !live;
         cptr_t c1 = as_const(a.src);
         double tailv[ABZ_MAX_DIM] = {0.0, 0.0, 0.0};
+        double swq = a.sweep;
         if (live) {
+            if (a.sweep_arr) swq = a.sweep_arr[q];
             c1 = as_const(a.src + a.slot[q] * ((int64_t)a.M * N * N));
             if (FID == ABZ_F_LINEAR_X && a.tail)
                 for (int j = 0; j < a.d - 1; ++j) tailv[j] = a.tail[q * (a.d - 1) + j];
@@ -1429,7 +1435,7 @@ __global__ __launch_bounds__(256) void inner_adaptive_kernel(InnerArgs a) {
                     }
                     double xk[ABZ_MAX_DIM] = {x, tailv[0], tailv[1]};
                     double vr[MAXC], vi[MAXC];
-                    integrand_value<N, FID>(H, e, xk, a.d, a.p, a.sweep, vr, vi);
+                    integrand_value<N, FID>(H, e, xk, a.d, a.p, swq, vr, vi);
                     constexpr int NC = NComp<FID>::template value<N>();
 #pragma unroll
                     for (int c = 0; c < NC; ++c) {
@@ -1478,6 +1484,7 @@ int launch_inner_adaptive(abz_ctx* ctx, const InnerSpec& is) {
     a.hi = is.hi;
     a.atol = is.atol;
     a.tail = is.tail;
+    a.sweep_arr = is.sweep_arr;
     a.nint = is.nint;
     a.maxevals = is.maxevals;
     a.M = is.M;

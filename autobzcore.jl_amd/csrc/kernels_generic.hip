@@ -179,6 +179,7 @@ struct GenArgs {
     int integrand, n_sweep, ncomp;
     double p[4];
     const double* sweep;  // device [n_sweep] (null: use sweep0)
+    const double* sweep_per_node;  // device [nnodes] (n_sweep = 1)
     double sweep0;
     double2* values;  // [node][n_sweep][ncomp]
 };
@@ -314,7 +315,7 @@ __global__ __launch_bounds__(256) void gen_node_kernel(GenArgs a, int waves_per_
         }
         if (a.values) {
             for (int s = 0; s < a.n_sweep; ++s) {
-                const double sw = a.sweep ? a.sweep[s] : a.sweep0;
+                const double sw = a.sweep_per_node ? a.sweep_per_node[k] : (a.sweep ? a.sweep[s] : a.sweep0);
                 gen_integrand(a, H, W, X, ev, sw, lane, a.values + (k * a.n_sweep + s) * a.ncomp);
             }
         }
@@ -361,6 +362,7 @@ int launch_gen_nodes(abz_ctx* ctx, const GenSpec& gs) {
     a.ncomp = gs.values ? integrand_ncomp(gs.integrand, gs.n, gs.d) : 0;
     for (int i = 0; i < 4; ++i) a.p[i] = gs.params[i];
     a.sweep = gs.sweep_dev;
+    a.sweep_per_node = gs.sweep_per_node;
     a.sweep0 = gs.sweep0;
     a.values = gs.values;
     if (gs.values && (gs.integrand == ABZ_F_LINEAR || gs.integrand == ABZ_F_LINEAR_X)) {
@@ -555,6 +557,7 @@ struct GenInnerArgs {
     const double* lo;
     const double* hi;
     const double* atol;
+    const double* sweep_arr;
     int64_t nint, maxevals;
     int n, M, first, d, ncomp, integrand, has_rtol;
     double inv_period, sweep, rtol_user;
@@ -602,6 +605,7 @@ __global__ __launch_bounds__(256) void gen_inner_adaptive_kernel(GenInnerArgs a,
             ctl[5] = 0.0;  // done flag
         }
         const double2* __restrict__ c1 = a.src + a.slot[q] * ((int64_t)a.M * nn);
+        const double swq = a.sweep_arr ? a.sweep_arr[q] : a.sweep;
         while (true) {
             wave_sync();
             if (ctl[5] != 0.0) break;
@@ -641,7 +645,7 @@ __global__ __launch_bounds__(256) void gen_inner_adaptive_kernel(GenInnerArgs a,
                     wave_sync();
                     wave_eig(W, ev, n, lane);
                 }
-                gen_integrand(ga, H, W, X, ev, a.sweep, lane, reinterpret_cast<double2*>(vals + (size_t)t * nc));
+                gen_integrand(ga, H, W, X, ev, swq, lane, reinterpret_cast<double2*>(vals + (size_t)t * nc));
                 wave_sync();
             }
             if (lane == 0) {
@@ -672,6 +676,7 @@ int launch_gen_inner_adaptive(abz_ctx* ctx, const InnerSpec& is) {
     a.lo = is.lo;
     a.hi = is.hi;
     a.atol = is.atol;
+    a.sweep_arr = is.sweep_arr;
     a.nint = is.nint;
     a.maxevals = is.maxevals;
     a.n = is.n;

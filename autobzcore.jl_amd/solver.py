@@ -487,10 +487,11 @@ def _redo_on_fbz(f, bz, p, alg, kws):
     return do_solve(f, fbz, p, alg, init_cacheval(f, fbz, p, alg), **kws)
 
 
-def _iai_device(f: FourierIntegrand, dev, lims, p: MixedParameters, abstol, reltol, maxiters, want_panels=False):
+def _iai_device_many(f: FourierIntegrand, dev, lims, plist, abstol, reltol, maxiters, want_panels=False):
+    """IAI for several parameter sets at once (abz_iai_solve_many): solves that differ only in the
+    swept parameter share every launch.  Returns [(value, err, numevals, extra)] in plist order."""
     fi = f.f.f
     max_batch = 0 if f.nest is None else min(f.nest.max_batch, 2**62)
-    params, sw = fi.bind(p)
     d, n = f.w.d, f.w.n
     ncomp = {L.F_GLOC: n * n, L.F_LINEAR_X: d}.get(fi.fid, 1)
     if isinstance(lims, CubicLimits):
@@ -503,22 +504,36 @@ def _iai_device(f: FourierIntegrand, dev, lims, p: MixedParameters, abstol, relt
         raise ValueError("variables in Fourier series don't match domain")  # ref: src/fourier.jl:506
     _, pa = L.f64(a)
     pb = L.f64(b)[1] if b is not None else None
-    par = np.ascontiguousarray(params, dtype=np.float64)
-    out = np.empty((ncomp, 2))
-    err = C.c_double(0)
-    nev = C.c_int64(0)
-    npan = C.c_int64(0)
+    groups = {}  # fixed parameters -> [(position, sweep value)]
+    for i, p in enumerate(plist):
+        params, sw = fi.bind(p)
+        groups.setdefault(tuple(float(v) for v in params), []).append((i, 0.0 if sw is None else float(sw)))
+    res = [None] * len(plist)
     maxp = 1 << 16
-    panels = np.empty((maxp, 2)) if want_panels else None
-    L.check(L.lib().abz_iai_solve(
-        dev.h, kind, pa, pb, fi.fid, par.ctypes.data_as(L.c_f64p) if len(par) else None, len(par),
-        0.0 if sw is None else sw, -1.0 if abstol is None else float(abstol),
-        -1.0 if reltol is None else float(reltol), int(min(maxiters, 2**62)), int(max_batch),
-        out.ctypes.data_as(L.c_f64p), C.byref(err), C.byref(nev),
-        panels.ctypes.data_as(L.c_f64p) if want_panels else None, maxp, C.byref(npan)))
-    vals = out.view(np.complex128).reshape(ncomp)
-    extra = {"panels": panels[: npan.value].copy()} if want_panels else {}
-    return _shape_value(f, vals), err.value, nev.value, extra
+    for params, members in groups.items():
+        par = np.ascontiguousarray(params, dtype=np.float64)
+        sweeps = np.ascontiguousarray([sw for _, sw in members], dtype=np.float64)
+        m = len(members)
+        out = np.empty((m, ncomp, 2))
+        err = np.zeros(m)
+        nev = np.zeros(m, dtype=np.int64)
+        npan = C.c_int64(0)
+        panels = np.empty((maxp, 2)) if want_panels else None
+        L.check(L.lib().abz_iai_solve_many(
+            dev.h, kind, pa, pb, fi.fid, par.ctypes.data_as(L.c_f64p) if len(par) else None, len(par),
+            sweeps.ctypes.data_as(L.c_f64p), m, -1.0 if abstol is None else float(abstol),
+            -1.0 if reltol is None else float(reltol), int(min(maxiters, 2**62)), int(max_batch),
+            out.ctypes.data_as(L.c_f64p), err.ctypes.data_as(L.c_f64p), nev.ctypes.data_as(L.c_i64p),
+            panels.ctypes.data_as(L.c_f64p) if want_panels else None, maxp, C.byref(npan)))
+        vals = out.view(np.complex128).reshape(m, ncomp)
+        for r, (i, _) in enumerate(members):
+            extra = {"panels": panels[: npan.value].copy()} if want_panels and r == 0 else {}
+            res[i] = (_shape_value(f, vals[r].copy()), float(err[r]), int(nev[r]), extra)
+    return res
+
+
+def _iai_device(f: FourierIntegrand, dev, lims, p: MixedParameters, abstol, reltol, maxiters, want_panels=False):
+    return _iai_device_many(f, dev, lims, [p], abstol, reltol, maxiters, want_panels)[0]
 
 
 def _iai_host(f: FourierIntegrand, dev, lims, p: MixedParameters, abstol, reltol, maxiters):
@@ -709,7 +724,9 @@ def _to_params(p):
 def batchsolve(solver: IntegralSolver, ps, nthreads=1, callback=None):
     """Evaluate the solver at every parameter in ps -> array like ps.  ref: src/interfaces.jl:234-243.
     For device integrands under PTR / AutoPTR the whole sweep is fused on the GPU (one pass over the
-    cached rule for all parameters); otherwise parameters are solved one by one in batchparam order."""
+    cached rule for all parameters), and under IAI / NestedQuad the adaptive solves of all parameters
+    advance in lock-step sharing their launches (abz_iai_solve_many; each solve makes the decisions it
+    would make alone); otherwise parameters are solved one by one in batchparam order."""
     arr = ps if isinstance(ps, np.ndarray) and ps.dtype == object else None
     if arr is None:
         lst = list(ps)
@@ -718,8 +735,9 @@ def batchsolve(solver: IntegralSolver, ps, nthreads=1, callback=None):
     out = np.empty(arr.shape, dtype=object)
     f, alg = solver.f, solver.alg
     inner = alg.alg if isinstance(alg, EvalCounter) else alg
-    fused = (isinstance(f, FourierIntegrand) and isinstance(f.f.f, DeviceIntegrand) and
-             isinstance(solver.dom, SymmetricBZ) and isinstance(inner, (PTR, AutoPTR)))
+    isdev = isinstance(f, FourierIntegrand) and isinstance(f.f.f, DeviceIntegrand)
+    fused = isdev and isinstance(solver.dom, SymmetricBZ) and isinstance(inner, (PTR, AutoPTR, IAI))
+    fused = fused or (isdev and isinstance(inner, NestedQuad) and isinstance(solver.dom, (CubicLimits, TetrahedralLimits)))
     flat_idx = [i[::-1] for i in np.ndindex(*arr.shape[::-1])]
     t0 = time.time()
     if fused:
@@ -727,15 +745,26 @@ def batchsolve(solver: IntegralSolver, ps, nthreads=1, callback=None):
         plist = [f.f.p.merge(base.merge(_to_params(arr[i]))) for i in flat_idx]
         dev = f.w.device()
         bz = solver.dom
-        j = abs(np.linalg.det(bz.B))
-        if isinstance(inner, PTR):
+        abstol, reltol = solver.kwargs.get("abstol"), solver.kwargs.get("reltol")
+        maxiters = solver.kwargs.get("maxiters", 2**62)
+        if isinstance(inner, NestedQuad):
+            res = _iai_device_many(f, dev, bz, plist, abstol, reltol, maxiters)
+            sols = [IntegralSolution(u, e, True, nev) for u, e, nev, _ in res]
+        elif isinstance(inner, IAI):
+            j = abs(np.linalg.det(bz.B))
+            jn = j * nsyms(bz)
+            res = _iai_device_many(f, dev, bz.lims, plist, None if abstol is None else abstol / jn, reltol, maxiters)
+            sols = [IntegralSolution(jn * u, jn * e, True, nev) for u, e, nev, _ in res]
+            if bz.syms is not None and not _is_trivial(res[0][0]):
+                sols = None
+        elif isinstance(inner, PTR):
+            j = abs(np.linalg.det(bz.B))
             vals, nev = _ptr_rule_values(f, dev, inner.npt, bz.syms, plist)
             sols = [IntegralSolution(j * nsyms(bz) * v, None, True, nev) for v in vals]
             if bz.syms is not None and not _is_trivial(vals[0]):
                 sols = None
         else:
-            sols = _autoptr_many(f, dev, bz, plist, inner, solver.kwargs.get("abstol"), solver.kwargs.get("reltol"),
-                                 solver.kwargs.get("maxiters", 2**62))
+            sols = _autoptr_many(f, dev, bz, plist, inner, abstol, reltol, maxiters)
             if sols[0] is None:
                 sols = None
         if sols is not None:

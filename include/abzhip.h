@@ -185,6 +185,17 @@ int abz_iai_solve(abz_series* s, int lims_kind, const double* lim_a, const doubl
                   double reltol, int64_t maxevals, int64_t max_batch, double* out_reim, double* err,
                   int64_t* numevals, double* panels, int64_t max_panels, int64_t* npanels);
 
+/* The same for n_sweep values of the swept parameter at once (batchsolve over omega with IAI,
+ * src/interfaces.jl:210-222): the solves are independent adaptive integrals that advance in lock-step,
+ * so every contraction / evaluation launch carries the nodes of all of them.  Each solve makes exactly
+ * the decisions it would make alone.  out_reim [n_sweep][ncomp][2], err [n_sweep], numevals [n_sweep];
+ * panels: outermost panels of the first solve. */
+int abz_iai_solve_many(abz_series* s, int lims_kind, const double* lim_a, const double* lim_b,
+                       int integrand, const double* params, int nparams, const double* sweeps,
+                       int n_sweep, double abstol, double reltol, int64_t maxevals, int64_t max_batch,
+                       double* out_reim, double* err, int64_t* numevals, double* panels,
+                       int64_t max_panels, int64_t* npanels);
+
 /* Replaces: QuadGK.evalrule on a batch of panels (reached from src/algorithms.jl:227-233):
  * values [npanels][15][ncomp][2] in gk node order -> I_reim [npanels][ncomp][2], E [npanels]
  * with I = I_K * h, E = ||I_K - I_G|| * h (2-norm over components). */

@@ -296,6 +296,37 @@ def test_nested_batch_integrand(abz):
         abz.NestedBatchIntegrand((pi,), max_batch=0)  # ref: src/batch.jl:16
 
 
+def test_iai_batchsolve_lockstep_is_bit_identical(abz):
+    """batchsolve over omega with IAI (src/interfaces.jl:234-243) runs all solves in lock-step
+    (abz_iai_solve_many): each must make exactly the decisions it makes alone -- same value bits,
+    same error, same numevals -- for every depth, domain kind and for n <= 4 and the generic-n path."""
+    rng = np.random.default_rng(21)
+    om = np.array([-0.7, 0.05, 0.3, 0.31, 1.4, 0.3])  # includes a repeated and an off-band value
+    for d, n, shape in ((1, 3, (7,)), (2, 2, (5, 5)), (3, 3, (3, 3, 3)), (2, 6, (3, 3))):
+        c, first = rand_series(rng, shape, n, hermitian=True)
+        s, _ = both(abz, c, first)
+        for bzk in (abz.FBZ(), abz.CubicSymIBZ()):
+            bz = abz.load_bz(bzk, np.eye(d))
+            for integ in (abz.DOSIntegrand(), abz.TrGlocIntegrand()):
+                f = abz.FourierIntegrand(integ, s, 0.2)
+                solver = abz.IntegralSolver(f, bz, abz.EvalCounter(abz.IAI()), abstol=1e-3)
+                got, meta = [], []
+                many = abz.batchsolve(solver, om, callback=lambda sv, i, k, p, sol, t: meta.append((sol.resid, sol.numevals)))
+                for k, w in enumerate(om):
+                    one = solver.solve_p(abz.MixedParameters(w))
+                    assert many[k] == one.u, (d, n, type(bzk).__name__, type(integ).__name__, w)
+                    assert meta[k] == (one.resid, one.numevals)
+    # NestedQuad on plain limits, vector-valued integrand with fixed parameters in the group key
+    so = orc.integer_lattice(2)
+    s = abz.FourierSeries(so.c[..., 0, 0], period=1.0, first=so.first, ndim=2)
+    f = abz.FourierIntegrand(abz.LinearXIntegrand(), s, 1.3)
+    solver = abz.IntegralSolver(f, abz.CubicLimits(np.zeros(2), np.ones(2)), abz.NestedQuad(abz.AuxQuadGKJL()), abstol=1e-8)
+    bs = [4.2, -1.0, 0.0]
+    many = abz.batchsolve(solver, [abz.MixedParameters(b=b) for b in bs])
+    for k, b in enumerate(bs):
+        assert np.array_equal(np.asarray(many[k]), np.asarray(solver(b=b)))
+
+
 # ------------------------------------------------------------------ generic n (wave-per-node kernels)
 @pytest.mark.parametrize("d,n", [(1, 5), (2, 8), (3, 6), (3, 16)])
 def test_generic_n_eval_and_rules(abz, d, n):
