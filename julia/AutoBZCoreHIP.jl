@@ -224,6 +224,28 @@ function AutoBZCore.batchsolve(s::IntegralSolver{<:HIPFourierIntegrand,<:Symmetr
     return abs(det(bz.B)) * nsyms(bz) .* real.(vec(u))
 end
 
+"batchsolve for a HIP integrand under IAI: all solves advance in lock-step and share their launches."
+function AutoBZCore.batchsolve(s::IntegralSolver{<:HIPFourierIntegrand,<:SymmetricBZ,<:IAI}, omegas::AbstractVector{<:Real})
+    f, bz = s.f, s.dom
+    hs = HIPSeries(f.w.series)
+    j = abs(det(bz.B)); ns = nsyms(bz); m = length(omegas)
+    params, _ = bind(f.f.f, merge(f.f.p, MixedParameters(first(omegas))))
+    kind, a, b = bz.lims isa CubicLimits ? (LIMS_CUBIC, Float64[bz.lims.a...], Float64[bz.lims.b...]) :
+                 (LIMS_TETRAHEDRAL, Float64[bz.lims.a...], Float64[])
+    abstol = get(s.kwargs, :abstol, nothing); reltol = get(s.kwargs, :reltol, nothing)
+    sw = Float64.(omegas); out = Vector{ComplexF64}(undef, m); err = Vector{Float64}(undef, m); nev = Vector{Int64}(undef, m)
+    npan = Ref{Int64}(0)
+    GC.@preserve params a b sw out err nev begin
+        check(ccall((:abz_iai_solve_many, libabz), Cint,
+            (Ptr{Cvoid}, Cint, Ptr{Float64}, Ptr{Float64}, Cint, Ptr{Float64}, Cint, Ptr{Float64}, Cint, Float64, Float64,
+             Int64, Int64, Ptr{ComplexF64}, Ptr{Float64}, Ptr{Int64}, Ptr{Float64}, Int64, Ptr{Int64}),
+            hs.h, kind, a, isempty(b) ? C_NULL : pointer(b), fid(f.f.f), params, length(params), sw, m,
+            abstol === nothing ? -1.0 : abstol / (j * ns), reltol === nothing ? -1.0 : Float64(reltol),
+            typemax(Int64) >> 1, 0, out, err, nev, C_NULL, 0, npan))
+    end
+    return j * ns .* real.(out)
+end
+
 # ---------------------------------------------------------------- GGR
 "get_ggr_data + sum_ggr on the GPU (src/dos_ggr.jl:14-65)."
 function ggr(h::FourierSeries{S,N}, bz::SymmetricBZ, Es::Vector{Float64}; npt=50) where {S,N}
