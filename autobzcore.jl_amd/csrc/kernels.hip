@@ -336,11 +336,28 @@ constexpr int EVAL_MAX_MNN = 256;  // complex coefficients per line held in LDS 
 template <int N, int KPL, bool HERM, bool VEC, int OCC>
 __global__ __launch_bounds__(256, OCC) void eval_grid_kernel(EvalArgs a) {
     extern __shared__ double2 lds_c[];  // [4 waves][2 buffers][MNN]
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    // the wave index is made an SGPR value: every per-line quantity (tile base, coefficient row) is
+    // then scalar arithmetic and the stores use the saddr + 32-bit lane offset form
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int MNN = a.M * N * N;
+    // derivative series: coefficient m is scaled by 2 pi i (first + m) once, on its way into LDS
+    auto stage = [&](double2 c, int idx) -> double2 {
+        if (!a.deriv) return c;
+        const double f = 6.283185307179586476925286766559 * (double)(a.first + idx / (N * N));
+        return make_double2(-f * c.y, f * c.x);
+    };
     double2* const mybuf = lds_c + (size_t)wave * 2 * MNN;
     int fm = a.first % a.npt;
     if (fm < 0) fm += a.npt;
+    // Every global load issued inside the work loop shares the in-order vmcnt with the stores, and a
+    // wait on any of them is a wait on every older store of the wave.  So the loop body is straight
+    // line code with exactly one group of loads (the next unit's coefficients) and one wait, placed
+    // right after the m-loop when the previous unit's stores are a whole m-loop old; phase seeds
+    // come from an LDS copy of the table.  A unit of work is one pass (64 KPL nodes) of one line.
+    const int npass = (a.npt + 64 * KPL - 1) / (64 * KPL);
+    double2* const tab_l = lds_c + (size_t)4 * 2 * MNN;  // LDS copy of the phase table, shared by the block
+    for (int i = threadIdx.x; i < a.npt; i += 256) tab_l[i] = a.tab[i];
+    __syncthreads();
     const int64_t lstride = (int64_t)gridDim.x * 4;
     int64_t line = (int64_t)blockIdx.x * 4 + wave;
     if (line >= a.nlines) return;
@@ -350,28 +367,22 @@ __global__ __launch_bounds__(256, OCC) void eval_grid_kernel(EvalArgs a) {
 #pragma unroll
         for (int t = 0; t < EVAL_MAX_MNN / 64; ++t) {
             const int idx = lane + 64 * t;
-            if (idx < MNN) mybuf[idx] = src[idx];
+            if (idx < MNN) mybuf[idx] = stage(src[idx], idx);
         }
     }
-    // phase seeds z = e^{2 pi i i1/npt}, w = z^first depend on the lane only: load them once (a load
-    // inside the line loop would wait, through the in-order vmcnt, for the previous line's stores)
-    const bool single = a.npt <= 64 * KPL;
-    double zr0[KPL], zi0[KPL], wr0[KPL], wi0[KPL];
+    // table indices of z and of the seed w = z^first for the nodes of pass 0
+    int iz0[KPL], iw0[KPL];
 #pragma unroll
     for (int j = 0; j < KPL; ++j) {
         const int i1 = lane + 64 * j;
-        const int ic = i1 < a.npt ? i1 : 0;
-        const double2 z = a.tab[ic];
-        const double2 w = a.tab[(int)(((int64_t)fm * ic) % a.npt)];
-        zr0[j] = z.x;
-        zi0[j] = z.y;
-        wr0[j] = w.x;
-        wi0[j] = w.y;
+        iz0[j] = i1 < a.npt ? i1 : 0;
+        iw0[j] = (int)(((unsigned)fm * (unsigned)iz0[j]) % (unsigned)a.npt);
     }
-    int cur = 0;
-    for (; line < a.nlines; line += lstride) {
-        // prefetch the next line's coefficients into registers
-        const int64_t nline = line + lstride;
+    int cur = 0, pass = 0;
+    while (line < a.nlines) {
+        // fetch the next unit's coefficients into registers (the same line again if it has more passes)
+        const bool last_pass = pass + 1 >= npass;
+        const int64_t nline = last_pass ? line + lstride : line;
         const bool have_next = nline < a.nlines;
         double2 pre[EVAL_MAX_MNN / 64];
         {
@@ -379,109 +390,99 @@ __global__ __launch_bounds__(256, OCC) void eval_grid_kernel(EvalArgs a) {
 #pragma unroll
             for (int t = 0; t < EVAL_MAX_MNN / 64; ++t) {
                 const int idx = lane + 64 * t;
-                pre[t] = (idx < MNN) ? src[idx] : make_double2(0.0, 0.0);
+                pre[t] = src[idx < MNN ? idx : MNN - 1];  // unconditional: no select waits on the data
             }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         const double2* __restrict__ c1 = mybuf + (size_t)cur * MNN;
-        for (int i0 = 0; i0 < a.npt; i0 += 64 * KPL) {
-            double zr[KPL], zi[KPL], pr[KPL], pi[KPL];
-            CMat<N> H[KPL];
+        const int i0 = pass * (64 * KPL);
+        double zr[KPL], zi[KPL], pr[KPL], pi[KPL];
+        CMat<N> H[KPL];
 #pragma unroll
-            for (int j = 0; j < KPL; ++j) {
-                if (single) {
-                    zr[j] = zr0[j];
-                    zi[j] = zi0[j];
-                    pr[j] = wr0[j];
-                    pi[j] = wi0[j];
-                } else {
-                    const int i1 = i0 + lane + 64 * j;
-                    const int ic = i1 < a.npt ? i1 : 0;
-                    const double2 z = a.tab[ic];
-                    const double2 w = a.tab[(int)(((int64_t)fm * ic) % a.npt)];
-                    zr[j] = z.x;
-                    zi[j] = z.y;
-                    pr[j] = w.x;
-                    pi[j] = w.y;
-                }
-#pragma unroll
-                for (int aa = 0; aa < N; ++aa) {
-#pragma unroll
-                    for (int bb = 0; bb < N; ++bb) {
-                        H[j].re[aa][bb] = 0.0;
-                        H[j].im[aa][bb] = 0.0;
-                    }
-                }
+        for (int j = 0; j < KPL; ++j) {
+            int ic = iz0[j], iw = iw0[j];
+            if (npass > 1) {
+                const int i1 = i0 + lane + 64 * j;
+                ic = i1 < a.npt ? i1 : 0;
+                iw = (int)(((unsigned)fm * (unsigned)ic) % (unsigned)a.npt);
             }
-            for (int m = 0; m < a.M; ++m) {
-                double qr[KPL], qi[KPL];
+            const double2 z = tab_l[ic];
+            const double2 w = tab_l[iw];
+            zr[j] = z.x;
+            zi[j] = z.y;
+            pr[j] = w.x;
+            pi[j] = w.y;
 #pragma unroll
-                for (int j = 0; j < KPL; ++j) {
-                    qr[j] = pr[j];
-                    qi[j] = pi[j];
-                    if (a.deriv) {
-                        const double f = 6.283185307179586476925286766559 * (double)(a.first + m);
-                        qr[j] = -f * pi[j];
-                        qi[j] = f * pr[j];
-                    }
-                }
-                const double2* __restrict__ cm = c1 + m * (N * N);
+            for (int aa = 0; aa < N; ++aa) {
 #pragma unroll
                 for (int bb = 0; bb < N; ++bb) {
+                    H[j].re[aa][bb] = 0.0;
+                    H[j].im[aa][bb] = 0.0;
+                }
+            }
+        }
+        for (int m = 0; m < a.M; ++m) {
+            const double2* __restrict__ cm = c1 + m * (N * N);
 #pragma unroll
-                    for (int aa = 0; aa < N; ++aa) {
-                        if (HERM && aa > bb) continue;  // upper triangle only; mirrored below
-                        const double2 c = cm[aa + N * bb];
+            for (int bb = 0; bb < N; ++bb) {
 #pragma unroll
-                        for (int j = 0; j < KPL; ++j) {
-                            H[j].re[aa][bb] = fma(c.x, qr[j], H[j].re[aa][bb]);
-                            H[j].re[aa][bb] = fma(-c.y, qi[j], H[j].re[aa][bb]);
-                            if (!(HERM && aa == bb)) {
-                                H[j].im[aa][bb] = fma(c.x, qi[j], H[j].im[aa][bb]);
-                                H[j].im[aa][bb] = fma(c.y, qr[j], H[j].im[aa][bb]);
-                            }
+                for (int aa = 0; aa < N; ++aa) {
+                    if (HERM && aa > bb) continue;  // upper triangle only; mirrored below
+                    const double2 c = cm[aa + N * bb];
+#pragma unroll
+                    for (int j = 0; j < KPL; ++j) {
+                        H[j].re[aa][bb] = fma(c.x, pr[j], H[j].re[aa][bb]);
+                        H[j].re[aa][bb] = fma(-c.y, pi[j], H[j].re[aa][bb]);
+                        if (!(HERM && aa == bb)) {
+                            H[j].im[aa][bb] = fma(c.x, pi[j], H[j].im[aa][bb]);
+                            H[j].im[aa][bb] = fma(c.y, pr[j], H[j].im[aa][bb]);
                         }
                     }
-                }
-#pragma unroll
-                for (int j = 0; j < KPL; ++j) {
-                    const double nr = pr[j] * zr[j] - pi[j] * zi[j];
-                    const double ni = pr[j] * zi[j] + pi[j] * zr[j];
-                    pr[j] = nr;
-                    pi[j] = ni;
                 }
             }
 #pragma unroll
             for (int j = 0; j < KPL; ++j) {
-                if constexpr (HERM) {
-#pragma unroll
-                    for (int bb = 0; bb < N; ++bb) {
-#pragma unroll
-                        for (int aa = bb + 1; aa < N; ++aa) {
-                            H[j].re[aa][bb] = H[j].re[bb][aa];
-                            H[j].im[aa][bb] = -H[j].im[bb][aa];
-                        }
-                    }
-                }
-                const int i1 = i0 + lane + 64 * j;
-                // columns npt..pitch-1 are padding: written (finite filler) so every 128-B line of the
-                // tile leaves the CU whole; never read back
-                const int pitch = a.H.base ? a.H.pitch : a.E.pitch;
-                if (i1 < pitch) eval_epilogue<N, VEC>(a, H[j], line, i1);
+                const double nr = pr[j] * zr[j] - pi[j] * zi[j];
+                const double ni = pr[j] * zi[j] + pi[j] * zr[j];
+                pr[j] = nr;
+                pi[j] = ni;
             }
         }
-        // hand the prefetched set to the other buffer
+        // The one wait of the loop body: the fetched registers are consumed here, unconditionally and
+        // before this unit's stores are issued (the asm pins the point; nothing is hoisted above it).
+#pragma unroll
+        for (int t = 0; t < EVAL_MAX_MNN / 64; ++t) asm volatile("" : "+v"(pre[t].x), "+v"(pre[t].y));
         if (have_next) {
             double2* dst = mybuf + (size_t)(cur ^ 1) * MNN;
 #pragma unroll
             for (int t = 0; t < EVAL_MAX_MNN / 64; ++t) {
                 const int idx = lane + 64 * t;
-                if (idx < MNN) dst[idx] = pre[t];
+                if (idx < MNN) dst[idx] = stage(pre[t], idx);
             }
         }
+#pragma unroll
+        for (int j = 0; j < KPL; ++j) {
+            if constexpr (HERM) {
+#pragma unroll
+                for (int bb = 0; bb < N; ++bb) {
+#pragma unroll
+                    for (int aa = bb + 1; aa < N; ++aa) {
+                        H[j].re[aa][bb] = H[j].re[bb][aa];
+                        H[j].im[aa][bb] = -H[j].im[bb][aa];
+                    }
+                }
+            }
+            const int i1 = i0 + lane + 64 * j;
+            // columns npt..pitch-1 are padding: written (finite filler) so every 128-B line of the
+            // tile leaves the CU whole; never read back
+            const int pitch = a.H.base ? a.H.pitch : a.E.pitch;
+            if (i1 < pitch) eval_epilogue<N, VEC>(a, H[j], line, i1);
+        }
         cur ^= 1;
+        pass = last_pass ? 0 : pass + 1;
+        line = nline;
     }
 }
 
@@ -613,9 +614,10 @@ int launch_eval(abz_ctx* ctx, const EvalSpec& es) {
         if (es.nlines == 0) return ABZ_OK;
         const int64_t blocks = std::min<int64_t>(cdiv(es.nlines, 4), 256 * 8);
         const int mnn = es.M * es.n * es.n;
-        if (mnn <= EVAL_MAX_MNN) {
-            const size_t lds = sizeof(double2) * 4 * 2 * (size_t)mnn;
-            const int kpl = es.npt <= 64 ? 1 : (es.npt <= 128 ? 2 : 3);
+        const int kpl = es.npt <= 64 ? 1 : (es.npt <= 128 ? 2 : 3);
+        // + an LDS copy of the phase table (fm * i1 < npt^2 must fit 32 bits)
+        const size_t lds = sizeof(double2) * (4 * 2 * (size_t)mnn + (size_t)a.npt);
+        if (mnn <= EVAL_MAX_MNN && lds <= 64 * 1024 && a.npt < 65536) {
 #define LKO(NN, KK, OO)                                                                                                        \
     if (a.U.base)                                                                                                              \
         hipLaunchKernelGGL((eval_grid_kernel<NN, KK, false, true, 2>), dim3((unsigned)blocks), dim3(256), lds, ctx->stream, a);  \
