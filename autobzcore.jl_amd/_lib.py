@@ -6,7 +6,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libabzhip.so")
+# ABZ_LIB: another build of the same library (kernel A/B experiments, tools/); never a fallback
+LIB_PATH = os.environ.get("ABZ_LIB") or os.path.join(_HERE, "libabzhip.so")
 
 c_i32p = C.POINTER(C.c_int32)
 c_i64p = C.POINTER(C.c_int64)
@@ -30,6 +31,7 @@ PROTOTYPES = {
     "abz_series_update": (C.c_int, [C.c_void_p, c_f64p]),
     "abz_eval_nodes": (C.c_int, [C.c_void_p, c_f64p, C.c_int64, C.c_int, c_f64p, c_f64p]),
     "abz_ptr_rule_build": (C.c_int, [C.c_void_p, C.c_int, C.c_int64, c_i32p, c_i64p, C.c_int, c_vpp]),
+    "abz_ptr_rule_build_slab": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, c_vpp]),
     "abz_rule_destroy": (C.c_int, [C.c_void_p]),
     "abz_rule_rebuild": (C.c_int, [C.c_void_p]),
     "abz_rule_info": (C.c_int, [C.c_void_p, c_i64p, c_ip, c_ip, c_ip, c_ip]),

@@ -99,6 +99,7 @@ struct abz_rule {
     int64_t nk = 0;       // number of nodes
     int64_t ntiles = 0;   // tiles (grid lines, or 64-node groups of an irregular list)
     bool full = true;     // full grid (implicit nodes/weights) or explicit irregular list
+    int64_t k_offset = 0;  // full grids: flat grid index of node 0 (non-zero for a slab of the outermost variable)
     double* vals = nullptr;  // [ntiles][planes][pitch]: H planes 2*(a + n*b) + {re, im}, then E (n), then V (d*n)
     int planes = 0;
     abz::PlaneView H, E, V;  // views into vals (base == nullptr when absent)
@@ -133,6 +134,7 @@ struct PhaseSpec {
     const double* x;
     const double2* tab;
     int npt;
+    int g0 = 0, gcnt = 0;  // gi == nullptr: grid index of item b is g0 + b % gcnt (gcnt = 0: npt)
     double period;
     bool deriv;  // multiply by i * 2 pi * freq  (d/dx_j * period_j, src/dos_ggr.jl:20,35)
 };
@@ -145,7 +147,7 @@ int launch_contract(abz_ctx* ctx, const double2* src, int64_t src_slot_elems, co
 // full-grid contraction: out[(parent*npt + gi)][l], parents 0..nparents-1, all gi, phases from tab
 constexpr int ABZ_CONTRACT_GRID_MAXM = 16;
 int launch_contract_grid(abz_ctx* ctx, const double2* src, int64_t src_slot_elems, int64_t nparents, const double2* tab,
-                         double2* out, int64_t L, int M, int first, int npt, bool deriv);
+                         double2* out, int64_t L, int M, int first, int npt, bool deriv, int gbeg, int gcnt);
 
 struct EvalSpec {
     int n;              // bands
@@ -183,6 +185,7 @@ struct ReduceSpec {
     int64_t nk;
     const double* w;      // null: uniform weight 1
     const int32_t* idx;   // null: full grid (k -> grid indices implicitly)
+    int64_t k_offset = 0; // full grid: flat index of node 0
     double params[4];
     const double* sweep_dev;  // device [n_sweep]
     int n_sweep;

@@ -114,6 +114,7 @@ struct Plan {
     bool full = false;
     bool coords = false;  // explicit coordinates (x) instead of grid indices
     int npt = 0;
+    int outer0 = 0, outer_n = 0;  // full grids: range of the outermost variable (a slab; whole grid = 0, npt)
     int64_t nk = 0;
     int64_t nitems[ABZ_MAX_DIM + 1] = {0, 0, 0, 0};  // per level 1..d-1
     std::vector<int32_t> gi[ABZ_MAX_DIM + 1];   // level L: grid index of variable L+1; [0]: nodes' i_1
@@ -121,15 +122,17 @@ struct Plan {
     std::vector<int64_t> parent[ABZ_MAX_DIM + 1];  // level L item -> item at level L+1; [0]: node -> level-1 item
 };
 
-static void plan_full(Plan& p, int d, int npt) {
+static void plan_full(Plan& p, int d, int npt, int outer0, int outer_n) {
     p.d = d;
     p.full = true;
     p.npt = npt;
-    p.nk = 1;
-    for (int j = 0; j < d; ++j) p.nk *= npt;
+    p.outer0 = outer0;
+    p.outer_n = outer_n;
+    p.nk = outer_n;
+    for (int j = 0; j + 1 < d; ++j) p.nk *= npt;
     for (int L = 1; L < d; ++L) {
-        int64_t c = 1;
-        for (int j = L; j < d; ++j) c *= npt;  // variables L+1..d
+        int64_t c = outer_n;
+        for (int j = L; j + 1 < d; ++j) c *= npt;  // variables L+1..d-1, times the slab of variable d
         p.nitems[L] = c;
     }
 }
@@ -225,10 +228,13 @@ static int build_chain(abz_series* s, const Plan& p, const PlanDev& pd, const do
         int rc = s->pool[L].reserve(sizeof(double2) * (size_t)std::max<int64_t>(B * Lrow, 1));
         if (rc) return rc;
         double2* out = s->pool[L].as<double2>();
-        if (p.full && M <= ABZ_CONTRACT_GRID_MAXM && B / p.npt <= 65535) {
-            // items of level L are (gi, parent) with gi fastest: parent count = B / npt
-            rc = launch_contract_grid(ctx, src, src_elems, B / p.npt, tab, out, Lrow, M, s->first[L], p.npt,
-                                      deriv_dim == L + 1);
+        // full grids: items of level L are (gi, parent) with gi fastest; gi runs over the slab for the
+        // outermost variable and over the whole grid below it
+        const int gbeg = (p.full && L == d - 1) ? p.outer0 : 0;
+        const int gcnt = (p.full && L == d - 1) ? p.outer_n : p.npt;
+        if (p.full && M <= ABZ_CONTRACT_GRID_MAXM && gcnt > 0 && B / gcnt <= 65535) {
+            rc = launch_contract_grid(ctx, src, src_elems, B / gcnt, tab, out, Lrow, M, s->first[L], p.npt,
+                                      deriv_dim == L + 1, gbeg, gcnt);
             if (rc) return rc;
         } else {
             rc = ctx->scratch[0].reserve(sizeof(double2) * (size_t)std::max<int64_t>(B * M, 1));
@@ -242,12 +248,14 @@ static int build_chain(abz_series* s, const Plan& p, const PlanDev& pd, const do
             ps.x = p.coords ? pd.xs[L].as<double>() : nullptr;
             ps.tab = tab;
             ps.npt = p.npt;
+            ps.g0 = gbeg;
+            ps.gcnt = gcnt;
             ps.period = s->period[L];
             ps.deriv = (deriv_dim == L + 1);
             rc = launch_phases(ctx, ps, phs);
             if (rc) return rc;
             const int64_t* parents = p.full ? nullptr : pd.parent[L].as<int64_t>();
-            rc = launch_contract(ctx, src, src_elems, parents, p.full ? p.npt : 1, phs, out, B, Lrow, M);
+            rc = launch_contract(ctx, src, src_elems, parents, p.full ? gcnt : 1, phs, out, B, Lrow, M);
             if (rc) return rc;
         }
         src = out;
@@ -561,8 +569,8 @@ static int rule_fill(abz_rule* r) {
         }                                                                                \
     } while (0)
 
-int abz_ptr_rule_build(abz_series* s, int npt, int64_t nirr, const int32_t* irr_idx, const int64_t* wsym, int want,
-                       abz_rule** out) {
+static int rule_build(abz_series* s, int npt, int64_t nirr, const int32_t* irr_idx, const int64_t* wsym, int want,
+                      int outer0, int outer_n, abz_rule** out) {
     int rc = check_series(s);
     if (rc) return rc;
     ABZ_REQUIRE(out, "null out");
@@ -587,7 +595,9 @@ int abz_ptr_rule_build(abz_series* s, int npt, int64_t nirr, const int32_t* irr_
     r->full = irr_idx == nullptr;
     Plan& plan = rp->plan;
     if (r->full) {
-        plan_full(plan, d, npt);
+        plan_full(plan, d, npt, outer0, outer_n);
+        r->k_offset = (int64_t)outer0;
+        for (int j = 0; j + 1 < d; ++j) r->k_offset *= npt;
     } else {
         for (int64_t k = 0; k < nirr * d; ++k) {
             if (irr_idx[k] < 0 || irr_idx[k] >= npt) {
@@ -613,6 +623,7 @@ int abz_ptr_rule_build(abz_series* s, int npt, int64_t nirr, const int32_t* irr_
     const size_t bytes = sizeof(double) * (size_t)(r->ntiles * tile);
     RULE_HIP(hipMalloc((void**)&r->vals, bytes));
     RULE_HIP(hipMemset(r->vals, 0, bytes));  // padding of irregular tiles stays finite
+    if (getenv("ABZ_DEBUG_ALLOC")) fprintf(stderr, "[abz] rule values %p (%zu bytes)\n", (void*)r->vals, bytes);
     auto mkview = [&](int plane0, bool present) {
         PlaneView v;
         if (present) {
@@ -654,6 +665,20 @@ int abz_ptr_rule_build(abz_series* s, int npt, int64_t nirr, const int32_t* irr_
 #undef RULE_TRY
 #undef RULE_HIP
 
+int abz_ptr_rule_build(abz_series* s, int npt, int64_t nirr, const int32_t* irr_idx, const int64_t* wsym, int want,
+                       abz_rule** out) {
+    return rule_build(s, npt, nirr, irr_idx, wsym, want, 0, npt, out);
+}
+
+int abz_ptr_rule_build_slab(abz_series* s, int npt, int outer_begin, int outer_end, int want, abz_rule** out) {
+    int rc = check_series(s);
+    if (rc) return rc;
+    ABZ_REQUIRE(s->d >= 2, "a slab needs at least two variables (d = %d)", s->d);
+    ABZ_REQUIRE(0 <= outer_begin && outer_begin < outer_end && outer_end <= npt,
+                "slab [%d, %d) outside the grid of %d points", outer_begin, outer_end, npt);
+    return rule_build(s, npt, 0, nullptr, nullptr, want, outer_begin, outer_end - outer_begin, out);
+}
+
 int abz_rule_rebuild(abz_rule* r) {
     ABZ_REQUIRE(r && r->plan, "null rule");
     abz_ctx* ctx = r->s->ctx;
@@ -693,7 +718,7 @@ int abz_rule_export(abz_rule* r, double* x, double* w, double* H, double* eig, d
             ABZ_HIP(hipMemcpy(wd.data(), r->w, sizeof(double) * wd.size(), hipMemcpyDeviceToHost));
         }
         for (int64_t k = 0; k < r->nk; ++k) {
-            int64_t rem = k;
+            int64_t rem = k + r->k_offset;
             for (int j = 0; j < d; ++j) {
                 int gi;
                 if (r->full) {
@@ -753,6 +778,7 @@ int abz_rule_reduce(abz_rule* r, int integrand, const double* params, int nparam
     rs.nk = r->nk;
     rs.w = r->w;
     rs.idx = r->idx;
+    rs.k_offset = r->k_offset;
     for (int i = 0; i < 4; ++i) rs.params[i] = (i < nparams) ? params[i] : 0.0;
     rs.n_sweep = ns;
     rs.sweep_dev = nullptr;

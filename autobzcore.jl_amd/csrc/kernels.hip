@@ -37,6 +37,7 @@ __device__ __forceinline__ cptr_t as_const(const double2* p) {
 struct PhaseArgs {
     int64_t B;
     int M, first, npt, deriv;
+    int g0, gcnt;  // implicit grid index of item b: g0 + b % gcnt
     const int32_t* gi;
     const double* x;
     const double2* tab;
@@ -51,7 +52,7 @@ __global__ void phase_kernel(PhaseArgs a, double2* __restrict__ phs) {
     const int f = a.first + m;
     double c, s;
     if (a.x == nullptr) {
-        const int64_t gi = a.gi ? (int64_t)a.gi[b] : (b % a.npt);
+        const int64_t gi = a.gi ? (int64_t)a.gi[b] : (a.g0 + b % a.gcnt);
         int64_t fm = f % a.npt;
         if (fm < 0) fm += a.npt;
         const double2 ph = a.tab[(fm * gi) % a.npt];
@@ -92,6 +93,8 @@ int launch_phases(abz_ctx* ctx, const PhaseSpec& ps, double2* phs) {
     a.npt = ps.npt > 0 ? ps.npt : 1;
     a.deriv = ps.deriv ? 1 : 0;
     a.gi = ps.gi;
+    a.g0 = ps.g0;
+    a.gcnt = ps.gcnt > 0 ? ps.gcnt : a.npt;
     a.x = ps.x;
     a.tab = ps.tab;
     a.inv_period = 1.0 / ps.period;
@@ -151,10 +154,13 @@ constexpr int CONTRACT_MAXM = 16;
 
 __global__ __launch_bounds__(128) void contract_grid_kernel(const double2* __restrict__ src, int64_t slot_elems,
                                                             const double2* __restrict__ tab, double2* __restrict__ out,
-                                                            int64_t L, int M, int first, int npt, int chunk, int deriv) {
+                                                            int64_t L, int M, int first, int npt, int chunk, int deriv,
+                                                            int gbeg, int gcnt) {
     extern __shared__ double2 phs[];  // [chunk][M] phases of this block's grid indices
-    const int g0 = blockIdx.z * chunk;
-    const int g1 = min(npt, g0 + chunk);
+    // grid indices gbeg .. gbeg + gcnt - 1 of the contracted variable (a slab of the outermost
+    // variable, or the whole range); output item = parent * gcnt + (gi - gbeg)
+    const int g0 = gbeg + blockIdx.z * chunk;
+    const int g1 = min(gbeg + gcnt, g0 + chunk);
     for (int t = threadIdx.x; t < (g1 - g0) * M; t += 128) {
         const int gi = g0 + t / M, m = t % M;
         int fm = (first + m) % npt;
@@ -187,26 +193,26 @@ __global__ __launch_bounds__(128) void contract_grid_kernel(const double2* __res
                 ai = fma(c[m].y, ph.x, ai);
             }
         }
-        out[(parent * npt + gi) * L + l] = make_double2(ar, ai);
+        out[(parent * gcnt + (gi - gbeg)) * L + l] = make_double2(ar, ai);
     }
 }
 
 int launch_contract_grid(abz_ctx* ctx, const double2* src, int64_t src_slot_elems, int64_t nparents, const double2* tab,
-                         double2* out, int64_t L, int M, int first, int npt, bool deriv) {
-    if (nparents == 0 || L == 0) return ABZ_OK;
+                         double2* out, int64_t L, int M, int first, int npt, bool deriv, int gbeg, int gcnt) {
+    if (nparents == 0 || L == 0 || gcnt == 0) return ABZ_OK;
     ProfScope ps(ctx, ABZ_K_CONTRACT);
     const int64_t gx = cdiv(L, 128);
     // enough blocks to fill the chip, at least ~4 grid indices per thread to amortise the loads
-    int64_t nsplit = std::max<int64_t>(1, std::min<int64_t>(cdiv(npt, 4), cdiv(4096, gx * nparents)));
-    const int chunk = (int)cdiv(npt, nsplit);
-    nsplit = cdiv(npt, chunk);
+    int64_t nsplit = std::max<int64_t>(1, std::min<int64_t>(cdiv(gcnt, 4), cdiv(4096, gx * nparents)));
+    const int chunk = (int)cdiv(gcnt, nsplit);
+    nsplit = cdiv(gcnt, chunk);
     if (nparents > 65535 || nsplit > 65535) {
         set_error("contract_grid: grid too large");
         return ABZ_ERR_UNSUPPORTED;
     }
     hipLaunchKernelGGL(contract_grid_kernel, dim3((unsigned)gx, (unsigned)nparents, (unsigned)nsplit), dim3(128),
                        sizeof(double2) * (size_t)chunk * M, ctx->stream, src, src_slot_elems, tab, out, L, M, first, npt,
-                       chunk, deriv ? 1 : 0);
+                       chunk, deriv ? 1 : 0, gbeg, gcnt);
     ABZ_HIP(hipGetLastError());
     return ABZ_OK;
 }
@@ -423,6 +429,7 @@ __global__ __launch_bounds__(256, OCC) void eval_grid_kernel(EvalArgs a) {
                 }
             }
         }
+
         for (int m = 0; m < a.M; ++m) {
             const double2* __restrict__ cm = c1 + m * (N * N);
 #pragma unroll
@@ -811,7 +818,7 @@ struct ReduceArgs {
     const double* w;
     const int32_t* idx;
     const double* sweep;
-    int64_t nk;
+    int64_t nk, k_offset;
     int d, npt, n_sweep, ncomp;
     double p[4];
 };
@@ -850,7 +857,7 @@ __global__ __launch_bounds__(256) void reduce_kernel(ReduceArgs a, double2* __re
             for (int b = 0; b < N; ++b) e[j][b] = ei[(int64_t)b * a.E.pitch];
         }
         if constexpr (FID == ABZ_F_LINEAR_X) {
-            int64_t r = kk;
+            int64_t r = kk + a.k_offset;
             for (int t = 0; t < a.d; ++t) {
                 int gi;
                 if (a.idx) {
@@ -983,6 +990,7 @@ int launch_reduce(abz_ctx* ctx, const ReduceSpec& rs, double* out_reim) {
     a.E = rs.E;
     a.w = rs.w;
     a.idx = rs.idx;
+    a.k_offset = rs.k_offset;
     a.sweep = rs.sweep_dev;
     a.nk = rs.nk;
     a.d = rs.d;

@@ -69,3 +69,46 @@ def batchsolve_sharded(solver, ps, group=None, device=None, **kw):
     """batchsolve over all ranks of the process group: rank r solves ps[r::world] on its own GPU."""
     from .solver import batchsolve
     return sharded_map(lambda chunk: batchsolve(solver, chunk, **kw), ps, group=group, device=device)
+
+
+# ------------------------------------------------------------------------ k-sharding of one solve
+class kshard:
+    """Context manager: shard the *nodes* of every PTR rule of a series over the ranks of a process
+    group, for a single solve that is too big (or too urgent) for one GPU.
+
+    ref: SURVEY 8e (2) -- the recursion of fourier_ptr! is independent per outer index
+    (src/fourier.jl:148-164), so rank r builds and scans only its slab of the outermost variable of a
+    full grid (or its block of the irreducible nodes of a symmetric rule); every rule value
+    (abz_rule_reduce, abz_rule_ggr) is then one all-reduce(sum) of a few doubles.  The convergence
+    test of AutoPTR runs redundantly on every rank on the same summed numbers, so all ranks take the
+    same decisions.  IAI is not k-sharded (its panels are sharded by omega instead).
+
+        with kshard(h, group):                      # h: FourierSeries (or its DeviceSeries)
+            u = solver(omega)                       # PTR / AutoPTR / GGR as usual, same value on all ranks
+    """
+
+    def __init__(self, series, group=None, device=None):
+        self.dev = series.device() if hasattr(series, "device") else series
+        self.group = group
+        self.device = device
+
+    def _allreduce(self, a):
+        import torch
+        dist = _dist()
+        a = np.ascontiguousarray(a, dtype=np.float64)
+        dev = self.device if self.device is not None else ("cuda" if dist.get_backend(self.group) == "nccl" else "cpu")
+        t = torch.from_numpy(a.reshape(-1).copy()).to(dev)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)  # the one collective per rule value
+        return t.cpu().numpy().reshape(a.shape)
+
+    def __enter__(self):
+        world, rank = world_info(self.group)
+        self._saved = (self.dev.kshard, self.dev.allreduce)
+        if world > 1:
+            self.dev.kshard = (rank, world)
+            self.dev.allreduce = self._allreduce
+        return self
+
+    def __exit__(self, *exc):
+        self.dev.kshard, self.dev.allreduce = self._saved
+        return False

@@ -95,6 +95,8 @@ class DeviceSeries:
         L.check(L.lib().abz_series_create(ctx.h, pbuf, s.d, pdims, pfirst, pper, s.n, C.byref(h)))
         self.h = h
         self.rules = {}
+        self.kshard = None     # (rank, world): rules hold this rank's share of the nodes (dist.kshard)
+        self.allreduce = None  # callable summing a float64 array over the ranks of the shard group
         self.rule_bytes = 0
         self.max_rule_bytes = 96 << 30  # keep rules resident in the 288 GB of HBM, LRU beyond this
         self._fin = weakref.finalize(self, DeviceSeries._destroy, h, self.rules)
@@ -144,14 +146,17 @@ class DeviceSeries:
 
     # ---- cached PTR rules
     def rule(self, npt, syms=None, want=L.WANT_H):
-        key = (int(npt), _syms_key(syms), int(want))
+        """Cached rule.  With `self.kshard = (rank, world)` set (dist.kshard) the rule holds this rank's
+        share of the nodes only -- a slab of the outermost variable of a full grid, or every world-th
+        irreducible node -- and its reductions are summed over the ranks by `self.allreduce`."""
+        key = (int(npt), _syms_key(syms), int(want), self.kshard)
         r = self.rules.pop(key, None)
         if r is None:
             # a cached superset also serves
-            for (n2, s2, w2), r2 in list(self.rules.items()):
-                if n2 == key[0] and s2 == key[1] and (w2 & want) == want:
-                    r = self.rules.pop((n2, s2, w2))
-                    key = (n2, s2, w2)
+            for (n2, s2, w2, k2), r2 in list(self.rules.items()):
+                if n2 == key[0] and s2 == key[1] and (w2 & want) == want and k2 == self.kshard:
+                    r = self.rules.pop((n2, s2, w2, k2))
+                    key = (n2, s2, w2, k2)
                     break
         if r is None:
             r = DeviceRule(self, npt, syms, want)
@@ -169,6 +174,11 @@ class DeviceSeries:
             r.close()
         self.rules.clear()
         self.rule_bytes = 0
+
+
+def slab_range(n, rank, world):
+    """Balanced contiguous share [a, b) of range(n) for `rank` of `world`."""
+    return (n * rank) // world, (n * (rank + 1)) // world
 
 
 def _syms_key(syms):
@@ -210,26 +220,48 @@ class DeviceRule:
         self.nsyms = 1 if syms is None else len(syms)
         h = C.c_void_p()
         d, n = dev.s.d, dev.s.n
+        self.shard = dev.kshard
+        rank, world = self.shard if self.shard else (0, 1)
         if syms is None:
-            L.check(L.lib().abz_ptr_rule_build(dev.h, self.npt, 0, None, None, want, C.byref(h)))
-            self.nk = self.npt ** d
+            self.nk = self.npt ** d  # nodes of the whole rule (numevals counts these)
+            if world == 1:
+                L.check(L.lib().abz_ptr_rule_build(dev.h, self.npt, 0, None, None, want, C.byref(h)))
+                self.nk_local = self.nk
+            else:
+                if d < 2:
+                    raise ValueError("k-sharding needs at least two variables")
+                z0, z1 = slab_range(self.npt, rank, world)
+                self.nk_local = (z1 - z0) * self.npt ** (d - 1)
+                if z1 > z0:
+                    L.check(L.lib().abz_ptr_rule_build_slab(dev.h, self.npt, z0, z1, want, C.byref(h)))
         else:
             idx, w = symptr_rule(self.npt, d, syms, ctx=dev.ctx)
-            L.check(L.lib().abz_ptr_rule_build(dev.h, self.npt, len(w), idx.ctypes.data_as(L.c_i32p),
-                                               w.ctypes.data_as(L.c_i64p), want, C.byref(h)))
             self.nk = len(w)
-        self.h = h
+            if world > 1:  # consecutive blocks keep the runs of shared outer coordinates together
+                a, b = slab_range(len(w), rank, world)
+                idx, w = np.ascontiguousarray(idx[a:b]), np.ascontiguousarray(w[a:b])
+            self.nk_local = len(w)
+            if len(w):
+                L.check(L.lib().abz_ptr_rule_build(dev.h, self.npt, len(w), idx.ctypes.data_as(L.c_i32p),
+                                                   w.ctypes.data_as(L.c_i64p), want, C.byref(h)))
+        self.h = h if h.value else None
         per = (2 * n * n if want & L.WANT_H else 0) + (n if want & (L.WANT_EIG | L.WANT_VEL) else 0) + \
               (d * n if want & L.WANT_VEL else 0)
-        self.nbytes = 8 * per * self.nk
-        self._fin = weakref.finalize(self, DeviceRule._destroy, h)
+        self.nbytes = 8 * per * self.nk_local
+        self._fin = weakref.finalize(self, DeviceRule._destroy, self.h)
 
     @staticmethod
     def _destroy(h):
         try:
-            L.lib().abz_rule_destroy(h)
+            if h is not None:
+                L.lib().abz_rule_destroy(h)
         except Exception:
             pass
+
+    def _sum_over_ranks(self, a):
+        """Partial sums of this rank's share -> the value of the whole rule (the all-reduce of a
+        k-sharded solve)."""
+        return self.dev.allreduce(a) if self.shard and self.shard[1] > 1 else a
 
     def close(self):
         self._fin()
@@ -239,7 +271,8 @@ class DeviceRule:
 
     def rebuild(self):
         """Re-evaluate all cached values in place from the series' current coefficients (async)."""
-        L.check(L.lib().abz_rule_rebuild(self.h))
+        if self.h is not None:
+            L.check(L.lib().abz_rule_rebuild(self.h))
 
     def reduce(self, fid, params=(), sweep=None, nsyms=None):
         """(sum_k w_k f(k, H(k); sweep_i)) / (npt^d nsyms) for every sweep value -> complex array
@@ -254,23 +287,25 @@ class DeviceRule:
             psw = sw.ctypes.data_as(L.c_f64p)
         else:
             ns, psw = 1, None
-        out = np.empty((ns, ncomp, 2))
+        out = np.zeros((ns, ncomp, 2))
         pp = params.ctypes.data_as(L.c_f64p) if len(params) else None
-        L.check(L.lib().abz_rule_reduce(self.h, fid, pp, len(params), psw, ns,
-                                        self.nsyms if nsyms is None else nsyms, out.ctypes.data_as(L.c_f64p)))
-        return out.view(np.complex128).reshape(ns, ncomp)
+        if self.h is not None:
+            L.check(L.lib().abz_rule_reduce(self.h, fid, pp, len(params), psw, ns,
+                                            self.nsyms if nsyms is None else nsyms, out.ctypes.data_as(L.c_f64p)))
+        return self._sum_over_ranks(out).view(np.complex128).reshape(ns, ncomp)
 
     def export(self, x=True, w=True, H=False, eig=False, vel=False):
         """Host copies in the reference's layout: x [nk,d], w [nk], H [nk,n,n], eig [nk,n], vel [nk,d,n]."""
         s = self.dev.s
-        nk, n, d = self.nk, s.n, s.d
+        nk, n, d = self.nk_local, s.n, s.d  # a k-sharded rule exports this rank's nodes
         X = np.empty((nk, d)) if x else None
         W = np.empty(nk) if w else None
         Hb = np.empty((nk, n * n, 2)) if H else None
         E = np.empty((nk, n)) if eig else None
         V = np.empty((nk, d, n)) if vel else None
         ptr = lambda a: a.ctypes.data_as(L.c_f64p) if a is not None else None
-        L.check(L.lib().abz_rule_export(self.h, ptr(X), ptr(W), ptr(Hb), ptr(E), ptr(V)))
+        if self.h is not None:
+            L.check(L.lib().abz_rule_export(self.h, ptr(X), ptr(W), ptr(Hb), ptr(E), ptr(V)))
         out = {}
         if x:
             out["x"] = X
@@ -288,6 +323,7 @@ class DeviceRule:
     def ggr(self, Es):
         """sum_k w_k sum_bands ggr_formula(1/(2 npt), E, e, v...).  ref: src/dos_ggr.jl:58-65."""
         Es = np.ascontiguousarray(np.asarray(Es, dtype=np.float64).reshape(-1))
-        out = np.empty(len(Es))
-        L.check(L.lib().abz_rule_ggr(self.h, Es.ctypes.data_as(L.c_f64p), len(Es), out.ctypes.data_as(L.c_f64p)))
-        return out
+        out = np.zeros(len(Es))
+        if self.h is not None:
+            L.check(L.lib().abz_rule_ggr(self.h, Es.ctypes.data_as(L.c_f64p), len(Es), out.ctypes.data_as(L.c_f64p)))
+        return self._sum_over_ranks(out)

@@ -464,9 +464,17 @@ def _ptr_rule_values(f: FourierIntegrand, dev, npt, syms, plist):
     out = []
     for p in plist:
         acc = None
-        for k in range(rule.nk):
+        for k in range(rule.nk_local):
             v = data["w"][k] * np.asarray(f.f.f(FourierValue(data["x"][k], data["H"][k]), *p.args, **p.kwargs))
             acc = v if acc is None else acc + v
+        if rule.shard and rule.shard[1] > 1:  # k-sharded: sum the ranks' partial sums
+            if acc is None:
+                raise ValueError("k-sharded rule with an empty share on this rank (more ranks than nodes)")
+            part = np.asarray(acc)
+            tot = rule._sum_over_ranks(np.ascontiguousarray(part, dtype=np.complex128).reshape(-1).view(np.float64))
+            tot = tot.view(np.complex128).reshape(part.shape)
+            tot = tot if np.iscomplexobj(part) else tot.real
+            acc = tot if part.shape else tot[()]
         out.append(acc * scale)
     return out, rule.nk
 

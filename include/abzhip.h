@@ -120,6 +120,15 @@ int abz_eval_nodes(abz_series* s, const double* k, int64_t nk, int want, double*
  * The values stay resident in HBM (planar layout). */
 int abz_ptr_rule_build(abz_series* s, int npt, int64_t nirr, const int32_t* irr_idx,
                        const int64_t* wsym, int want, abz_rule** out);
+
+/* A slab of the full grid: only i_d in [outer_begin, outer_end) of the outermost variable (d >= 2),
+ * i.e. one rank's share when a single solve is sharded over k (the recursion of fourier_ptr! is
+ * independent per outer index, src/fourier.jl:148-164).  Weights and abz_rule_reduce's 1/npt^d
+ * normalisation are those of the whole grid, so the partial sums of disjoint slabs add up to the
+ * full rule value (one all-reduce).  A symmetric rule is sharded by passing a subset of
+ * the irreducible nodes to abz_ptr_rule_build instead. */
+int abz_ptr_rule_build_slab(abz_series* s, int npt, int outer_begin, int outer_end, int want,
+                            abz_rule** out);
 int abz_rule_destroy(abz_rule* r);
 /* Re-evaluate every cached value of the rule from the series' current coefficients, in place and
  * without host synchronisation (launches only).  Replaces: the re-init of a stale cache,

@@ -50,6 +50,55 @@ def test_sharded_sweep_world2_gloo(tmp_path):
     assert out.stdout.count("ok") == 2
 
 
+KWORKER = textwrap.dedent("""
+    import os, sys
+    import numpy as np
+    sys.path.insert(0, {root!r}); sys.path.insert(0, os.path.join({root!r}, "oracle"))
+    import torch.distributed as dist
+    import abz_oracle as orc
+    from autobzcore.jl_amd import dist as adist
+    from autobzcore.jl_amd.series import slab_range
+    dist.init_process_group("gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
+
+    class FakeDev:            # what dist.kshard drives on a DeviceSeries
+        kshard = None
+        allreduce = None
+    dev = FakeDev()
+    so = orc.tb_integer(3)
+    npt = 9                   # 9 outer planes on 2 ranks: slabs of 4 and 5
+    f = orc.f_dos(0.3, 0.5)
+    vals = orc.fourier_ptr(so, npt)                   # indexed [i1, i2, i3]
+    x = orc.ptrpoints(npt)
+    with adist.kshard(dev):
+        assert dev.kshard == (rank, world)
+        z0, z1 = slab_range(npt, *dev.kshard)
+        assert (z0, z1) == ((0, 4) if rank == 0 else (4, 9))
+        part = 0.0
+        for k in range(z0 * npt * npt, z1 * npt * npt):
+            i1, i2, i3 = k % npt, (k // npt) % npt, k // (npt * npt)
+            part += float(f(np.array([x[i1], x[i2], x[i3]]), vals[i1, i2, i3]))
+        tot = dev.allreduce(np.array([part / npt**3, 0.0]))
+    assert dev.kshard is None and dev.allreduce is None
+    ref = orc.solve_ptr(so, orc.load_bz("FBZ", np.eye(3)), f, npt=npt).u / (2 * np.pi) ** 3
+    assert abs(tot[0] - ref) <= 1e-13 * abs(ref), (tot, ref)
+    dist.destroy_process_group()
+    print("rank", rank, "ok")
+""")
+
+
+def test_kshard_allreduce_world2_gloo(tmp_path):
+    """k-sharding of one solve: slabs of the outermost variable + one all-reduce."""
+    script = tmp_path / "kworker.py"
+    script.write_text(KWORKER.format(root=ROOT))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29519")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                          "--master-addr", "127.0.0.1", "--master-port", "29519", str(script)],
+                         env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert out.stdout.count("ok") == 2
+
+
 def test_shard_indices_match_batchparam():
     import autobzcore.jl_amd as abz
     from autobzcore.jl_amd.dist import shard_indices

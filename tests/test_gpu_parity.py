@@ -327,6 +327,70 @@ def test_iai_batchsolve_lockstep_is_bit_identical(abz):
         assert np.array_equal(np.asarray(many[k]), np.asarray(solver(b=b)))
 
 
+def test_kshard_partial_rules_sum_to_the_full_rule(abz, svo):
+    """a solve sharded over k.  The W ranks' rules (slabs of the outermost variable of a
+    full grid / blocks of the irreducible nodes) are built one after another on this GPU; their partial
+    reductions must add up to the un-sharded rule value, for the matrix integrand, the coordinate
+    dependent one (grid indices of a slab carry its offset) and GGR; slab nodes = rows of the full export."""
+    L = abz._lib
+    rng = np.random.default_rng(31)
+    c, first = rand_series(rng, (3, 5, 3), 2, hermitian=True)
+    s, _ = both(abz, c, first)
+    dev = s.device()
+    npt, W = 10, 3
+    syms = abz.load_bz(abz.CubicSymIBZ(), np.eye(3)).syms
+    for sy in (None, syms):
+        full = dev.rule(npt, sy, L.WANT_H)
+        ref_dos = full.reduce(L.F_DOS, [0.2], [0.1, 0.7])
+        exp_full = full.export(x=True, w=True, H=True)
+        tot_dos, rows = 0, []
+        for r in range(W):
+            dev.kshard, dev.allreduce = (r, W), (lambda a: a)  # keep the partial sums
+            try:
+                part = dev.rule(npt, sy, L.WANT_H)
+                assert part.nk == full.nk and part is not full
+                tot_dos = tot_dos + part.reduce(L.F_DOS, [0.2], [0.1, 0.7])
+                rows.append(part.export(x=True, w=True, H=True))
+            finally:
+                dev.kshard, dev.allreduce = None, None
+        assert sum(len(e["w"]) for e in rows) == full.nk
+        for key in ("x", "w", "H"):
+            assert np.array_equal(np.concatenate([e[key] for e in rows]), exp_full[key]), key
+        assert np.allclose(tot_dos, ref_dos, rtol=1e-13, atol=1e-15)
+    # coordinate-dependent integrand on a scalar series: grid indices of a slab carry its offset
+    so = orc.integer_lattice(3)
+    s1 = abz.FourierSeries(so.c[..., 0, 0], period=1.0, first=so.first, ndim=3)
+    d1 = s1.device()
+    ref_x = d1.rule(7, None, L.WANT_H).reduce(L.F_LINEAR_X, [1.3, 0.25])
+    tot_x = 0
+    for r in range(W):
+        d1.kshard, d1.allreduce = (r, W), (lambda a: a)
+        try:
+            tot_x = tot_x + d1.rule(7, None, L.WANT_H).reduce(L.F_LINEAR_X, [1.3, 0.25])
+        finally:
+            d1.kshard, d1.allreduce = None, None
+    assert np.allclose(tot_x, ref_x, rtol=1e-13, atol=1e-15) and np.abs(ref_x).min() > 0.1
+    # GGR (eigenvalues + velocities of a slab) on the SVO model
+    svo = svo[0]
+    sdev = svo.device()
+    Es = np.array([11.8, 12.6, 13.4])
+    ref = sdev.rule(12, None, L.WANT_EIG | L.WANT_VEL).ggr(Es)
+    tot = 0
+    for r in range(4):
+        sdev.kshard, sdev.allreduce = (r, 4), (lambda a: a)
+        try:
+            tot = tot + sdev.rule(12, None, L.WANT_EIG | L.WANT_VEL).ggr(Es)
+        finally:
+            sdev.kshard, sdev.allreduce = None, None
+    assert np.allclose(tot, ref, rtol=1e-12)
+    # a whole AutoPTR solve under dist.kshard with a single-rank group degenerates to the plain solve
+    from autobzcore.jl_amd.dist import kshard
+    bz = abz.load_bz(abz.FBZ(), 3.85856 * np.eye(3))
+    solver = abz.IntegralSolver(abz.FourierIntegrand(abz.DOSIntegrand(), svo, 0.1), bz, abz.PTR(npt=24))
+    with kshard(svo):
+        assert solver(12.5) == solver(12.5)
+
+
 # ------------------------------------------------------------------ generic n (wave-per-node kernels)
 @pytest.mark.parametrize("d,n", [(1, 5), (2, 8), (3, 6), (3, 16)])
 def test_generic_n_eval_and_rules(abz, d, n):
