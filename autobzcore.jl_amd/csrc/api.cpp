@@ -611,7 +611,7 @@ static int rule_build(abz_series* s, int npt, int64_t nirr, const int32_t* irr_i
     r->nk = plan.nk;
     // tiles: a grid line (pitch = npt rounded up to 16 doubles = 128 B) or 64 nodes of an irregular list
     const int line_len = r->full ? npt : 64;
-    const int pitch = (line_len + 15) / 16 * 16;
+    const int pitch = (line_len + 15) / 16 * 16;  // whole 128-B lines: 64-B and 16-B quanta measured 25-40 % slower
     r->ntiles = std::max<int64_t>(1, (plan.nk + line_len - 1) / line_len);
     const int pH = (want & ABZ_WANT_H) ? 2 * n * n : 0;
     const int pE = (want & ABZ_WANT_EIG) ? n : 0;
