@@ -99,6 +99,7 @@ struct abz_rule {
     int64_t nk = 0;       // number of nodes
     int64_t ntiles = 0;   // tiles (grid lines, or 64-node groups of an irregular list)
     bool full = true;     // full grid (implicit nodes/weights) or explicit irregular list
+    bool herm = false;    // values come from a Hermitian series (set by every fill): H(k) = H(k)^dagger
     int64_t k_offset = 0;  // full grids: flat grid index of node 0 (non-zero for a slab of the outermost variable)
     double* vals = nullptr;  // [ntiles][planes][pitch]: H planes 2*(a + n*b) + {re, im}, then E (n), then V (d*n)
     int planes = 0;
@@ -186,6 +187,7 @@ struct ReduceSpec {
     const double* w;      // null: uniform weight 1
     const int32_t* idx;   // null: full grid (k -> grid indices implicitly)
     int64_t k_offset = 0; // full grid: flat index of node 0
+    bool herm = false;    // the cached H(k) are exactly Hermitian (rule of a Hermitian series)
     double params[4];
     const double* sweep_dev;  // device [n_sweep]
     int n_sweep;

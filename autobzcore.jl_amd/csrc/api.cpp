@@ -500,6 +500,7 @@ static int rule_fill(abz_rule* r) {
     const Plan& plan = rp->plan;
     const int d = s->d, n = s->n;
     const double2* tab = rp->tab.as<double2>();
+    r->herm = s->hermitian;
     // temporaries of a velocity build: eigenvectors and one derivative matrix, tiled like H alone
     PlaneView Uv, Dv;
     if (r->want & ABZ_WANT_VEL) {
@@ -779,6 +780,7 @@ int abz_rule_reduce(abz_rule* r, int integrand, const double* params, int nparam
     rs.w = r->w;
     rs.idx = r->idx;
     rs.k_offset = r->k_offset;
+    rs.herm = r->herm;
     for (int i = 0; i < 4; ++i) rs.params[i] = (i < nparams) ? params[i] : 0.0;
     rs.n_sweep = ns;
     rs.sweep_dev = nullptr;

@@ -794,13 +794,20 @@ __device__ __forceinline__ void integrand_value(const CMat<N>& H, const double (
         }
     } else if constexpr (FID == ABZ_F_DOS_EIG) {
         double acc = 0.0;
-        const double eta = p[0];
+        const double eta = p[0], eta2 = eta * eta;
+        if constexpr (N == 3) {  // sum of three fractions over one reciprocal
+            const double d0 = sw - e[0], d1 = sw - e[1], d2 = sw - e[2];
+            const double x0 = fma(d0, d0, eta2), x1 = fma(d1, d1, eta2), x2 = fma(d2, d2, eta2);
+            const double x12 = x1 * x2;
+            acc = fma(x0, x1 + x2, x12) * fast_rcp(x0 * x12);
+        } else {
 #pragma unroll
-        for (int b = 0; b < N; ++b) {
-            const double de = sw - e[b];
-            acc += eta / (de * de + eta * eta);
+            for (int b = 0; b < N; ++b) {
+                const double de = sw - e[b];
+                acc += fast_rcp(fma(de, de, eta2));
+            }
         }
-        vr[0] = acc * 0.31830988618379067153776752674503;
+        vr[0] = acc * (eta * 0.31830988618379067153776752674503);
         vi[0] = 0.0;
     }
 }
@@ -825,13 +832,16 @@ struct ReduceArgs {
 
 // Block tile = 256 * KT nodes held in registers; loop over the whole sweep; per omega one wave
 // reduction, wave partials parked in LDS, one barrier at the end of each sweep chunk.
-template <int N, int FID, int KT>
-__global__ __launch_bounds__(256) void reduce_kernel(ReduceArgs a, double2* __restrict__ partial) {
+// HERM (rules of a Hermitian series, resolvent traces of n = 2, 3): real polynomial, upper triangle of
+// H only (half of the planes are never read), ~21 instructions per (node, sweep value).
+template <int N, int FID, int KT, bool HERM>
+__global__ __launch_bounds__(256, (HERM || FID == ABZ_F_DOS_EIG) ? 3 : 1) void reduce_kernel(ReduceArgs a, double2* __restrict__ partial) {
     constexpr int NC = NComp<FID>::template value<N>();
     extern __shared__ double2 lds[];  // [chunk][4 waves][NC]
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int64_t base = (int64_t)blockIdx.x * (256 * KT);
-    constexpr bool usePoly0 = (N == 2 || N == 3) && (FID == ABZ_F_DOS || FID == ABZ_F_TRGLOC);
+    constexpr bool polyH = HERM && (N == 2 || N == 3) && (FID == ABZ_F_DOS || FID == ABZ_F_TRGLOC);
+    constexpr bool usePoly0 = !polyH && (N == 2 || N == 3) && (FID == ABZ_F_DOS || FID == ABZ_F_TRGLOC);
     CMat<N> H[usePoly0 ? 1 : KT];  // poly mode: H is only a transient input of charpoly_init
     double e[KT][N];
     double wk[KT];
@@ -839,20 +849,43 @@ __global__ __launch_bounds__(256) void reduce_kernel(ReduceArgs a, double2* __re
     constexpr bool needH = (FID == ABZ_F_LINEAR || FID == ABZ_F_LINEAR_X || FID == ABZ_F_DOS ||
                             FID == ABZ_F_TRGLOC || FID == ABZ_F_GLOC);
     // n = 2, 3 resolvent traces: characteristic polynomial per node, ~40 flops per sweep value
-    constexpr bool usePoly = (N == 2 || N == 3) && (FID == ABZ_F_DOS || FID == ABZ_F_TRGLOC);
-    CharPoly<(usePoly ? N : 2)> cp[KT];
+    constexpr bool usePoly = usePoly0;
+    CharPoly<(usePoly ? N : 2)> cp[usePoly ? KT : 1];
+    CharPolyH cph[polyH ? KT : 1];
+    // (line, column) of this thread's first node; the following ones are 256 apart, so one 64-bit
+    // division per thread and a 32-bit one per node (all views of a rule share line_len and tile)
+    const int LL = a.H.line_len;
+    int64_t vline = (base + threadIdx.x) / LL;
+    unsigned vcol = (unsigned)((base + threadIdx.x) - vline * LL);
 #pragma unroll
     for (int j = 0; j < KT; ++j) {
         const int64_t k = base + threadIdx.x + 256 * j;
         const bool ok = k < a.nk;
         const int64_t kk = ok ? k : 0;
+        const int64_t voff = ok ? vline * a.H.tile + vcol : 0;
+        {
+            vcol += 256u;
+            const unsigned qd = vcol / (unsigned)LL;
+            vline += qd;
+            vcol -= qd * (unsigned)LL;
+        }
         wk[j] = ok ? (a.w ? a.w[kk] : 1.0) : 0.0;
-        if constexpr (needH) {
-            load_planes<N>(H[usePoly0 ? 0 : j], a.H, view_off(a.H, kk));
+        if constexpr (polyH) {
+            const double* __restrict__ in = a.H.base + voff;
+            const int64_t pp = a.H.pitch;
+            // plane of Re H[r][c] is 2 (r + N c), Im the next one
+            if constexpr (N == 3) {
+                charpoly_init_h3(in[0], in[8 * pp], in[16 * pp], in[6 * pp], in[7 * pp], in[12 * pp], in[13 * pp],
+                                 in[14 * pp], in[15 * pp], cph[j]);
+            } else {
+                charpoly_init_h2(in[0], in[6 * pp], in[4 * pp], in[5 * pp], cph[j]);
+            }
+        } else if constexpr (needH) {
+            load_planes<N>(H[usePoly0 ? 0 : j], a.H, voff);
         }
         if constexpr (usePoly) charpoly_init<N>(H[0], cp[j]);
         if constexpr (FID == ABZ_F_DOS_EIG) {
-            const double* __restrict__ ei = a.E.base + view_off(a.E, kk);
+            const double* __restrict__ ei = a.E.base + voff;
 #pragma unroll
             for (int b = 0; b < N; ++b) e[j][b] = ei[(int64_t)b * a.E.pitch];
         }
@@ -873,6 +906,7 @@ __global__ __launch_bounds__(256) void reduce_kernel(ReduceArgs a, double2* __re
     const int chunk = 512 / NC;  // sweep values per LDS pass (<= 32 KiB)
     for (int s0 = 0; s0 < a.n_sweep; s0 += chunk) {
         const int s1 = min(a.n_sweep, s0 + chunk);
+        [[maybe_unused]] const double eta2 = a.p[0] * a.p[0], teta = 2.0 * a.p[0];
         for (int s = s0; s < s1; ++s) {
             const double sw = a.sweep ? a.sweep[s] : 0.0;
             double ar[NC], ai[NC];
@@ -884,7 +918,12 @@ __global__ __launch_bounds__(256) void reduce_kernel(ReduceArgs a, double2* __re
 #pragma unroll
             for (int j = 0; j < KT; ++j) {
                 double vr[MAXC], vi[MAXC];
-                if constexpr (usePoly) {
+                if constexpr (polyH) {
+                    double tr, ti;
+                    charpoly_trace_h<N, FID != ABZ_F_DOS>(cph[j], sw, a.p[0], eta2, teta, tr, ti);
+                    vr[0] = (FID == ABZ_F_DOS) ? -ti * 0.31830988618379067153776752674503 : tr;
+                    vi[0] = (FID == ABZ_F_DOS) ? 0.0 : ti;
+                } else if constexpr (usePoly) {
                     double tr, ti;
                     charpoly_trace<N>(cp[j], sw, a.p[0], tr, ti);
                     vr[0] = (FID == ABZ_F_DOS) ? -ti * 0.31830988618379067153776752674503 : tr;
@@ -965,7 +1004,11 @@ static int launch_reduce_t(abz_ctx* ctx, const ReduceSpec& rs, const ReduceArgs&
     constexpr int NC = NComp<FID>::template value<N>();
     const int chunk = 512 / NC;
     const size_t lds = sizeof(double2) * (size_t)std::min(chunk, rs.n_sweep) * 4 * NC;
-    hipLaunchKernelGGL((reduce_kernel<N, FID, KT>), dim3((unsigned)nblocks), dim3(256), lds, ctx->stream, a, partial);
+    constexpr bool canH = (N == 2 || N == 3) && (FID == ABZ_F_DOS || FID == ABZ_F_TRGLOC);
+    if (canH && rs.herm)
+        hipLaunchKernelGGL((reduce_kernel<N, FID, KT, canH>), dim3((unsigned)nblocks), dim3(256), lds, ctx->stream, a, partial);
+    else
+        hipLaunchKernelGGL((reduce_kernel<N, FID, KT, false>), dim3((unsigned)nblocks), dim3(256), lds, ctx->stream, a, partial);
     return ABZ_OK;
 }
 
