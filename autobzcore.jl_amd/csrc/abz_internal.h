@@ -216,6 +216,7 @@ struct NodeEvalSpec {
     double params[4];
     double sweep;
     const double* sweep_arr = nullptr;  // device [nnodes]: per-node sweep value (overrides `sweep`)
+    bool panels15 = false;  // every aligned run of 15 nodes is one GK(7,15) panel (same parent)
 };
 int launch_node_integrand(abz_ctx* ctx, const NodeEvalSpec& ns, double2* values_dev);
 
@@ -273,6 +274,7 @@ struct GenSpec {
     int n_sweep;
     const double* sweep_per_node = nullptr;  // device [nnodes]: one sweep value per node (n_sweep = 1)
     double2* values;  // [node][n_sweep][ncomp] or null
+    bool panels15 = false;  // nodes come as GK(7,15) panels: every aligned run of 15 shares its parent
 };
 int launch_gen_nodes(abz_ctx* ctx, const GenSpec& gs);
 int launch_gen_reduce(abz_ctx* ctx, const ReduceSpec& rs, double* out_reim);

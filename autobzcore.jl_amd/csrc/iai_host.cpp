@@ -132,6 +132,7 @@ struct IaiDriver {
     int64_t maxevals;
     int64_t max_batch = 0;  // 0: scalar refinement; > 0: BatchIntegrand refinement with this soft cap
     int64_t total_evals = 0;
+    bool panels15 = true;  // eval_nodes is fed whole GK panels (solve_level); the node-list ABI entry clears it
     std::vector<int64_t> evals_per_root;
     std::vector<int64_t> h_parents;
     std::vector<double> h_x, h_tail, h_sweep;
@@ -198,6 +199,7 @@ int IaiDriver::eval_nodes(int64_t nn) {
     if ((rc = s->iai_io[5].reserve(sizeof(double) * (size_t)nn))) return rc;
     ABZ_HIP(hipMemcpyAsync(s->iai_io[5].p, h_sweep.data(), sizeof(double) * (size_t)nn, hipMemcpyHostToDevice, ctx->stream));
     NodeEvalSpec ns;
+    ns.panels15 = panels15;
     ns.sweep_arr = s->iai_io[5].as<double>();
     ns.n = n;
     ns.d = d;
@@ -646,6 +648,7 @@ int abz_eval_line_nodes(abz_series* s, const int64_t* parents, const double* x, 
     drv.h_parents.assign(parents, parents + nnodes);
     drv.h_x.assign(x, x + nnodes);
     drv.h_sweep.assign((size_t)nnodes, sweep);
+    drv.panels15 = false;  // arbitrary node list
     if (tail && s->d > 1) drv.h_tail.assign(tail, tail + nnodes * (s->d - 1));
     int rc = drv.eval_nodes(nnodes);
     if (rc) return rc;

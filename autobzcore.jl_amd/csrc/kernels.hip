@@ -309,15 +309,31 @@ struct EvalArgs {
     double inv_period;
 };
 
+// planes of one node at column i1 of tile `line`; with a wave-uniform line every plane row is a scalar
+// base and the lane offset i1 is the same 32-bit register for all of them (saddr stores)
+template <int N>
+__device__ __forceinline__ void store_planes_at(const CMat<N>& H, const PlaneView& v, int64_t line, int i1) {
+    double* __restrict__ row = v.base + line * v.tile;
+    const unsigned u = (unsigned)i1;
+#pragma unroll
+    for (int b = 0; b < N; ++b) {
+#pragma unroll
+        for (int a = 0; a < N; ++a) {
+            (row + (int64_t)(2 * (a + N * b)) * v.pitch)[u] = H.re[a][b];
+            (row + (int64_t)(2 * (a + N * b) + 1) * v.pitch)[u] = H.im[a][b];
+        }
+    }
+}
+
 template <int N, bool VEC = true>
 __device__ __forceinline__ void eval_epilogue(const EvalArgs& a, CMat<N>& H, int64_t line, int i1) {
-    if (a.H.base) store_planes<N>(H, a.H, line * a.H.tile + i1);
+    if (a.H.base) store_planes_at<N>(H, a.H, line, i1);
     if (a.E.base || (VEC && a.U.base)) {
         double e[N];
         CMat<N> V;
         if (VEC && a.U.base) {
             herm_eig<N, true>(H, e, V);
-            store_planes<N>(V, a.U, line * a.U.tile + i1);
+            store_planes_at<N>(V, a.U, line, i1);
         } else {
             if constexpr (N == 3)
                 herm_eig3_values(H, e);
@@ -325,9 +341,10 @@ __device__ __forceinline__ void eval_epilogue(const EvalArgs& a, CMat<N>& H, int
                 herm_eig<N, false>(H, e, V);
         }
         if (a.E.base) {
-            double* __restrict__ eo = a.E.base + line * a.E.tile + i1;
+            double* __restrict__ row = a.E.base + line * a.E.tile;
+            const unsigned u = (unsigned)i1;
 #pragma unroll
-            for (int b = 0; b < N; ++b) eo[(int64_t)b * a.E.pitch] = e[b];
+            for (int b = 0; b < N; ++b) (row + (int64_t)b * a.E.pitch)[u] = e[b];
         }
     }
 }
@@ -1339,6 +1356,7 @@ int launch_node_integrand(abz_ctx* ctx, const NodeEvalSpec& ns, double2* values_
         gs.x = ns.x;
         gs.tab = nullptr;
         gs.deriv = false;
+        gs.panels15 = ns.panels15;
         gs.nnodes = ns.nnodes;
         gs.Hplanes = PlaneView();
         gs.Eplanes = PlaneView();

@@ -323,6 +323,164 @@ __global__ __launch_bounds__(256) void gen_node_kernel(GenArgs a, int waves_per_
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// IAI innermost nodes for n > 4, GK panel at a time.
+// One workgroup per panel (15 nodes of one 1-D integral = one coefficient set): the set is staged in
+// LDS once and shared by all nodes; a node is evaluated by NP lanes (NP = n rounded up to 8/16/32),
+// lane r owning ROW r of the matrix in registers:
+//   series     row_r(H) = sum_m c_m[r, :] p_m          (coefficient reads: LDS, 16 B per lane,
+//                                                        identical across the nodes of a wave)
+//   resolvent  in-place Gauss-Jordan inversion of A = (omega + i eta) I - H without pivoting (see the
+//              header of this file): per pivot c the lane that owns row c publishes it through a small
+//              LDS row buffer, every lane does one rank-1 row update  a_r += g_r u  with
+//              g_r = -a_rc / p (g_c = 1/p - 1), a_rc <- g_r (a_cc <- 1/p).  n^3 complex FMA per node in
+//              registers instead of the 2 n^3 LDS-resident updates of the wave-per-node kernel.
+// ------------------------------------------------------------------------------------------
+template <int NP>
+__global__ __launch_bounds__(256) void gen_panel_kernel(GenArgs a) {
+    extern __shared__ double2 lds_p[];
+    constexpr int SLOTS = 256 / NP;
+    const int n = a.n, nn = n * n, M = a.M;
+    double2* coef = lds_p;                    // [M][nn]
+    double2* prow = lds_p + (size_t)M * nn;   // [SLOTS][2][NP] pivot rows (double-buffered)
+    const int slot = threadIdx.x / NP, r = threadIdx.x % NP;
+    const int rr = r < n ? r : n - 1;  // padded rows read a valid row and are overwritten below
+    double2* myrow = prow + (size_t)slot * 2 * NP;
+    const int64_t ngroups = a.nnodes / 15;
+    for (int64_t g = blockIdx.x; g < ngroups; g += gridDim.x) {
+        const int64_t node0 = g * 15;
+        const int64_t parent = a.parents ? a.parents[node0] : 0;
+        __syncthreads();  // the previous panel's readers are done with `coef`
+        {
+            const double2* __restrict__ src = a.src + parent * ((int64_t)M * nn);
+            for (int t = threadIdx.x; t < M * nn; t += 256) coef[t] = src[t];
+        }
+        __syncthreads();
+        for (int q0 = 0; q0 < 15; q0 += SLOTS) {
+            const int q = q0 + slot;
+            const bool act = q < 15;
+            const int64_t k = node0 + (act ? q : 0);
+            double zr, zi, pr, pi;
+            {
+                const double xx = a.x[k] * a.inv_period;
+                sincospi(2.0 * xx, &zi, &zr);
+                sincospi(2.0 * ((double)a.first * xx), &pi, &pr);
+            }
+            double ar[NP], ai[NP];
+#pragma unroll
+            for (int j = 0; j < NP; ++j) {
+                ar[j] = 0.0;
+                ai[j] = 0.0;
+            }
+            for (int m = 0; m < M; ++m) {
+                const double2* __restrict__ cm = coef + (size_t)m * nn + rr;
+#pragma unroll
+                for (int j = 0; j < NP; ++j) {
+                    if (j < n) {  // uniform
+                        const double2 c = cm[n * j];
+                        // A = z I - H: accumulate -H
+                        ar[j] = fma(-c.x, pr, ar[j]);
+                        ar[j] = fma(c.y, pi, ar[j]);
+                        ai[j] = fma(-c.x, pi, ai[j]);
+                        ai[j] = fma(-c.y, pr, ai[j]);
+                    }
+                }
+                const double nr = pr * zr - pi * zi, ni = pr * zi + pi * zr;
+                pr = nr;
+                pi = ni;
+            }
+            const double sw = a.sweep_per_node ? a.sweep_per_node[k] : a.sweep0;
+#pragma unroll
+            for (int j = 0; j < NP; ++j) {
+                if (r >= n) {  // padding rows: identity, decoupled from the n x n block
+                    ar[j] = 0.0;
+                    ai[j] = 0.0;
+                }
+                if (j == r) {
+                    ar[j] += (r < n) ? sw : 1.0;
+                    ai[j] += (r < n) ? a.p[0] : 0.0;
+                }
+            }
+            // in-place inversion, pivots 0..n-1
+#pragma unroll
+            for (int c = 0; c < NP; ++c) {
+                if (c < n) {  // uniform
+                    double2* buf = myrow + (c & 1) * NP;
+                    if (r == c) {
+#pragma unroll
+                        for (int j = 0; j < NP; ++j)
+                            if (j < n) buf[j] = make_double2(ar[j], ai[j]);
+                    }
+                    wave_sync();  // a node's NP lanes live in one wave
+                    const double2 p = buf[c];
+                    const double inv = 1.0 / (p.x * p.x + p.y * p.y);
+                    const double ipr = p.x * inv, ipi = -p.y * inv;  // 1 / pivot
+                    const double fr = ar[c], fi = ai[c];
+                    // g = -f / p for the other rows, 1/p - 1 for the pivot row itself
+                    double gr = -(fr * ipr - fi * ipi), gi = -(fr * ipi + fi * ipr);
+                    if (r == c) {
+                        gr = ipr - 1.0;
+                        gi = ipi;
+                    }
+#pragma unroll
+                    for (int j = 0; j < NP; ++j) {
+                        if (j < n && j != c) {
+                            const double2 u = buf[j];
+                            ar[j] = fma(gr, u.x, ar[j]);
+                            ar[j] = fma(-gi, u.y, ar[j]);
+                            ai[j] = fma(gr, u.y, ai[j]);
+                            ai[j] = fma(gi, u.x, ai[j]);
+                        }
+                    }
+                    ar[c] = (r == c) ? ipr : gr;
+                    ai[c] = (r == c) ? ipi : gi;
+                }
+            }
+            wave_sync();
+            // row r now holds row r of inv(A)
+            if (a.integrand == ABZ_F_GLOC) {
+                if (act && r < n) {
+                    double2* out = a.values + k * a.ncomp;
+#pragma unroll
+                    for (int j = 0; j < NP; ++j)
+                        if (j < n) out[r + n * j] = make_double2(ar[j], ai[j]);
+                }
+            } else {
+                double tr = 0.0, ti = 0.0;
+#pragma unroll
+                for (int j = 0; j < NP; ++j) {
+                    if (j == r && r < n) {
+                        tr = ar[j];
+                        ti = ai[j];
+                    }
+                }
+#pragma unroll
+                for (int off = NP / 2; off > 0; off >>= 1) {
+                    tr += __shfl_xor(tr, off, 64);
+                    ti += __shfl_xor(ti, off, 64);
+                }
+                if (act && r == 0)
+                    a.values[k * a.ncomp] = (a.integrand == ABZ_F_DOS)
+                                                ? make_double2(-ti * 0.31830988618379067153776752674503, 0.0)
+                                                : make_double2(tr, ti);
+            }
+        }
+    }
+}
+
+static bool gen_panel_supported(const GenSpec& gs, int* np_out, size_t* lds_out) {
+    if (!gs.values || !gs.panels15 || gs.grid || !gs.x || gs.deriv || gs.nnodes % 15 != 0) return false;
+    if (gs.n_sweep > 1 || gs.sweep_dev) return false;
+    if (!(gs.integrand == ABZ_F_DOS || gs.integrand == ABZ_F_TRGLOC || gs.integrand == ABZ_F_GLOC)) return false;
+    if (gs.Hplanes.base || gs.Eplanes.base || gs.Haos || gs.Eaos) return false;
+    const int np = gs.n <= 8 ? 8 : (gs.n <= 16 ? 16 : 32);
+    const size_t lds = sizeof(double2) * ((size_t)gs.M * gs.n * gs.n + (size_t)(256 / np) * 2 * np);
+    if (lds > 150 * 1024) return false;
+    *np_out = np;
+    *lds_out = lds;
+    return true;
+}
+
 static int gen_waves_per_block(int n, int M) {
     const size_t per = sizeof(double2) * (size_t)(3 * n * n + M + (n + 1) / 2);
     int w = (int)((150 * 1024) / per);
@@ -368,6 +526,28 @@ int launch_gen_nodes(abz_ctx* ctx, const GenSpec& gs) {
     if (gs.values && (gs.integrand == ABZ_F_LINEAR || gs.integrand == ABZ_F_LINEAR_X)) {
         set_error("ABZ_F_LINEAR(_X) needs a scalar (n = 1) series");
         return ABZ_ERR_ARG;
+    }
+    {
+        int np = 0;
+        size_t plds = 0;
+        static const bool off = [] { const char* e = getenv("ABZ_GEN_PANEL"); return e && e[0] == '0'; }();
+        if (!off && gen_panel_supported(gs, &np, &plds)) {
+            const int64_t blocks = std::min<int64_t>(gs.nnodes / 15, 256 * 8);
+            ProfScope ps(ctx, ABZ_K_EVAL);
+#define ABZ_PANEL(NPV)                                                                                                   \
+    ABZ_HIP(hipFuncSetAttribute((const void*)gen_panel_kernel<NPV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)plds)); \
+    hipLaunchKernelGGL(gen_panel_kernel<NPV>, dim3((unsigned)blocks), dim3(256), plds, ctx->stream, a);
+            if (np == 8) {
+                ABZ_PANEL(8)
+            } else if (np == 16) {
+                ABZ_PANEL(16)
+            } else {
+                ABZ_PANEL(32)
+            }
+#undef ABZ_PANEL
+            ABZ_HIP(hipGetLastError());
+            return ABZ_OK;
+        }
     }
     const int wpb = gen_waves_per_block(gs.n, gs.M);
     const size_t lds = sizeof(double2) * (size_t)(3 * gs.n * gs.n + gs.M + (gs.n + 1) / 2) * wpb;

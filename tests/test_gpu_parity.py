@@ -427,10 +427,12 @@ def test_generic_n_eval_and_rules(abz, d, n):
         assert np.abs(g[i].reshape(n, n).T - G).max() <= 1e-10 * np.abs(G).max()
 
 
-def test_generic_n_iai_matches_oracle(abz):
+@pytest.mark.parametrize("n", [6, 12, 20])
+def test_generic_n_iai_matches_oracle(abz, n):
+    """n = 6 / 12 / 20 take the 8- / 16- / 32-lane rows of the panel kernel (gen_panel_kernel)."""
     rng = np.random.default_rng(77)
-    c, first = rand_series(rng, (3, 3), 6, hermitian=True)
-    c = c / 3
+    c, first = rand_series(rng, (3, 3), n, hermitian=True)
+    c = c / (n / 2)
     s, so = both(abz, c, first)
     bz = abz.load_bz(abz.FBZ(), np.eye(2))
     f = abz.FourierIntegrand(abz.DOSIntegrand(), s, 0.3)
