@@ -249,6 +249,7 @@ constexpr int ABZ_INNER_MAXSEG = 48;
 bool inner_adaptive_supported(int n, int integrand);
 int launch_inner_adaptive(abz_ctx* ctx, const InnerSpec& is);
 bool gen_inner_supported(int n, int M, int integrand);  // n > 4: one wavefront per 1-D integral
+bool gen_inner_panel_supported(int n, int M, int integrand);  // n > 4: one workgroup per 1-D integral, set in LDS
 int launch_gen_inner_adaptive(abz_ctx* ctx, const InnerSpec& is);
 
 // ---- generic n (5..32 bands): wave-per-node kernels (kernels_generic.hip)

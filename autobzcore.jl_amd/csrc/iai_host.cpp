@@ -542,9 +542,11 @@ int abz_iai_solve_many(abz_series* s, int lims_kind, const double* lim_a, const 
     drv.evals_per_root.assign((size_t)n_sweep, 0);
     {
         const char* e = getenv("ABZ_IAI_DEVICE_INNER");  // 0 forces the host loop at every level
-        // n > 4: the wave-per-integral kernel is correct but (16 bands) not yet faster than the host loop:
-        // opt-in with ABZ_IAI_DEVICE_INNER=2
-        const bool ok = s->n > 4 ? (gen_inner_supported(s->n, s->dims[0], integrand) && e && e[0] == '2')
+        // n > 4: the workgroup-per-integral kernel (coefficient set in LDS) runs by default where it
+        // applies; the older wave-per-integral kernel is slower than the host-driven loop at 16 bands
+        // and stays opt-in (ABZ_IAI_DEVICE_INNER=2)
+        const bool ok = s->n > 4 ? (gen_inner_panel_supported(s->n, s->dims[0], integrand) ||
+                                    (gen_inner_supported(s->n, s->dims[0], integrand) && e && e[0] == '2'))
                                  : inner_adaptive_supported(s->n, integrand);
         drv.device_inner = max_batch <= 0 && s->d >= 2 && ok && !(e && e[0] == '0');
     }

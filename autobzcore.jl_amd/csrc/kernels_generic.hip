@@ -336,108 +336,156 @@ __global__ __launch_bounds__(256) void gen_node_kernel(GenArgs a, int waves_per_
 //              g_r = -a_rc / p (g_c = 1/p - 1), a_rc <- g_r (a_cc <- 1/p).  n^3 complex FMA per node in
 //              registers instead of the 2 n^3 LDS-resident updates of the wave-per-node kernel.
 // ------------------------------------------------------------------------------------------
+__device__ __forceinline__ double rcp_nr(double x) {  // 1/x, x in the normal range: estimate + 2 Newton steps
+    double r = __builtin_amdgcn_rcp(x);
+    r = fma(fma(-x, r, 1.0), r, r);
+    r = fma(fma(-x, r, 1.0), r, r);
+    return r;
+}
+
+// Row r (lane r of the node's NP lanes) of inv((sw + i eta) I - H(x)) into ar/ai; `coef` = the staged
+// coefficient set, `myrow` = this node slot's two pivot-row buffers.
+// PAD: the set is staged as [M][NP*NP] with zeros outside the n x n block, so every loop runs to NP with
+// no condition on n (the padding block of A is the identity and stays decoupled: its columns are exact
+// zeros in the real rows).  !PAD: layout [M][n*n], loops guarded by (uniform) comparisons with n.
+template <int NP, bool PAD>
+__device__ __forceinline__ void panel_inverse_row(const double2* coef, double2* myrow, int n, int M, int first,
+                                                  double xx, double sw, double eta, int r, double (&ar)[NP],
+                                                  double (&ai)[NP]) {
+    const int ld = PAD ? NP : n;   // column stride of a staged block
+    const int nn = ld * ld;
+    const int rr = (PAD || r < n) ? r : n - 1;  // !PAD: padded rows read a valid row and are overwritten below
+    double zr, zi, pr, pi;
+    sincospi(2.0 * xx, &zi, &zr);
+    sincospi(2.0 * ((double)first * xx), &pi, &pr);
+#pragma unroll
+    for (int j = 0; j < NP; ++j) {
+        ar[j] = 0.0;
+        ai[j] = 0.0;
+    }
+    for (int m = 0; m < M; ++m) {
+        const double2* __restrict__ cm = coef + (size_t)m * nn + rr;
+#pragma unroll
+        for (int j = 0; j < NP; ++j) {
+            if (PAD || j < n) {  // uniform
+                const double2 c = cm[ld * j];
+                // A = z I - H: accumulate -H
+                ar[j] = fma(-c.x, pr, ar[j]);
+                ar[j] = fma(c.y, pi, ar[j]);
+                ai[j] = fma(-c.x, pi, ai[j]);
+                ai[j] = fma(-c.y, pr, ai[j]);
+            }
+        }
+        const double nr = pr * zr - pi * zi, ni = pr * zi + pi * zr;
+        pr = nr;
+        pi = ni;
+    }
+#pragma unroll
+    for (int j = 0; j < NP; ++j) {
+        if (!PAD && r >= n) {  // padding rows: identity, decoupled from the n x n block
+            ar[j] = 0.0;
+            ai[j] = 0.0;
+        }
+        if (j == r) {
+            ar[j] += (r < n) ? sw : 1.0;
+            ai[j] += (r < n) ? eta : 0.0;
+        }
+    }
+    // in-place inversion; pivots of the padding block are 1 and change nothing
+#pragma unroll
+    for (int c = 0; c < NP; ++c) {
+        if (PAD || c < n) {  // uniform
+            double2* buf = myrow + (c & 1) * NP;
+            if (r == c) {
+#pragma unroll
+                for (int j = 0; j < NP; ++j)
+                    if (PAD || j < n) buf[j] = make_double2(ar[j], ai[j]);
+            }
+            wave_sync();  // a node's NP lanes live in one wave
+            const double2 p = buf[c];
+            const double inv = rcp_nr(p.x * p.x + p.y * p.y);
+            const double ipr = p.x * inv, ipi = -p.y * inv;  // 1 / pivot
+            const double fr = ar[c], fi = ai[c];
+            // g = -f / p for the other rows, 1/p - 1 for the pivot row itself
+            double gr = -(fr * ipr - fi * ipi), gi = -(fr * ipi + fi * ipr);
+            if (r == c) {
+                gr = ipr - 1.0;
+                gi = ipi;
+            }
+#pragma unroll
+            for (int j = 0; j < NP; ++j) {
+                if ((PAD || j < n) && j != c) {
+                    const double2 u = buf[j];
+                    ar[j] = fma(gr, u.x, ar[j]);
+                    ar[j] = fma(-gi, u.y, ar[j]);
+                    ai[j] = fma(gr, u.y, ai[j]);
+                    ai[j] = fma(gi, u.x, ai[j]);
+                }
+            }
+            ar[c] = (r == c) ? ipr : gr;
+            ai[c] = (r == c) ? ipi : gi;
+        }
+    }
+    wave_sync();
+}
+
+// stage one coefficient set [M][n*n] into LDS, zero-padded to [M][NP*NP] when PAD
+template <int NP, bool PAD>
+__device__ __forceinline__ void panel_stage(double2* coef, const double2* __restrict__ src, int n, int M) {
+    if constexpr (PAD) {
+        for (int t = threadIdx.x; t < M * NP * NP; t += 256) {
+            const int m = t / (NP * NP), e = t - m * (NP * NP);
+            const int rr = e % NP, j = e / NP;
+            coef[t] = (rr < n && j < n) ? src[(size_t)m * n * n + rr + n * j] : make_double2(0.0, 0.0);
+        }
+    } else {
+        for (int t = threadIdx.x; t < M * n * n; t += 256) coef[t] = src[t];
+    }
+}
+
+// trace of the inverse from its rows (sum over the node's NP lanes; every lane gets it)
 template <int NP>
+__device__ __forceinline__ void panel_trace(const double (&ar)[NP], const double (&ai)[NP], int n, int r, double& tr,
+                                            double& ti) {
+    tr = 0.0;
+    ti = 0.0;
+#pragma unroll
+    for (int j = 0; j < NP; ++j) {
+        if (j == r && r < n) {
+            tr = ar[j];
+            ti = ai[j];
+        }
+    }
+#pragma unroll
+    for (int off = NP / 2; off > 0; off >>= 1) {
+        tr += __shfl_xor(tr, off, 64);
+        ti += __shfl_xor(ti, off, 64);
+    }
+}
+
+template <int NP, bool PAD>
 __global__ __launch_bounds__(256) void gen_panel_kernel(GenArgs a) {
     extern __shared__ double2 lds_p[];
     constexpr int SLOTS = 256 / NP;
     const int n = a.n, nn = n * n, M = a.M;
-    double2* coef = lds_p;                    // [M][nn]
-    double2* prow = lds_p + (size_t)M * nn;   // [SLOTS][2][NP] pivot rows (double-buffered)
+    double2* coef = lds_p;                    // [M][nn] or [M][NP*NP]
+    double2* prow = lds_p + (size_t)M * (PAD ? NP * NP : nn);   // [SLOTS][2][NP] pivot rows (double-buffered)
     const int slot = threadIdx.x / NP, r = threadIdx.x % NP;
-    const int rr = r < n ? r : n - 1;  // padded rows read a valid row and are overwritten below
     double2* myrow = prow + (size_t)slot * 2 * NP;
     const int64_t ngroups = a.nnodes / 15;
     for (int64_t g = blockIdx.x; g < ngroups; g += gridDim.x) {
         const int64_t node0 = g * 15;
         const int64_t parent = a.parents ? a.parents[node0] : 0;
         __syncthreads();  // the previous panel's readers are done with `coef`
-        {
-            const double2* __restrict__ src = a.src + parent * ((int64_t)M * nn);
-            for (int t = threadIdx.x; t < M * nn; t += 256) coef[t] = src[t];
-        }
+        panel_stage<NP, PAD>(coef, a.src + parent * ((int64_t)M * nn), n, M);
         __syncthreads();
         for (int q0 = 0; q0 < 15; q0 += SLOTS) {
             const int q = q0 + slot;
             const bool act = q < 15;
             const int64_t k = node0 + (act ? q : 0);
-            double zr, zi, pr, pi;
-            {
-                const double xx = a.x[k] * a.inv_period;
-                sincospi(2.0 * xx, &zi, &zr);
-                sincospi(2.0 * ((double)a.first * xx), &pi, &pr);
-            }
-            double ar[NP], ai[NP];
-#pragma unroll
-            for (int j = 0; j < NP; ++j) {
-                ar[j] = 0.0;
-                ai[j] = 0.0;
-            }
-            for (int m = 0; m < M; ++m) {
-                const double2* __restrict__ cm = coef + (size_t)m * nn + rr;
-#pragma unroll
-                for (int j = 0; j < NP; ++j) {
-                    if (j < n) {  // uniform
-                        const double2 c = cm[n * j];
-                        // A = z I - H: accumulate -H
-                        ar[j] = fma(-c.x, pr, ar[j]);
-                        ar[j] = fma(c.y, pi, ar[j]);
-                        ai[j] = fma(-c.x, pi, ai[j]);
-                        ai[j] = fma(-c.y, pr, ai[j]);
-                    }
-                }
-                const double nr = pr * zr - pi * zi, ni = pr * zi + pi * zr;
-                pr = nr;
-                pi = ni;
-            }
             const double sw = a.sweep_per_node ? a.sweep_per_node[k] : a.sweep0;
-#pragma unroll
-            for (int j = 0; j < NP; ++j) {
-                if (r >= n) {  // padding rows: identity, decoupled from the n x n block
-                    ar[j] = 0.0;
-                    ai[j] = 0.0;
-                }
-                if (j == r) {
-                    ar[j] += (r < n) ? sw : 1.0;
-                    ai[j] += (r < n) ? a.p[0] : 0.0;
-                }
-            }
-            // in-place inversion, pivots 0..n-1
-#pragma unroll
-            for (int c = 0; c < NP; ++c) {
-                if (c < n) {  // uniform
-                    double2* buf = myrow + (c & 1) * NP;
-                    if (r == c) {
-#pragma unroll
-                        for (int j = 0; j < NP; ++j)
-                            if (j < n) buf[j] = make_double2(ar[j], ai[j]);
-                    }
-                    wave_sync();  // a node's NP lanes live in one wave
-                    const double2 p = buf[c];
-                    const double inv = 1.0 / (p.x * p.x + p.y * p.y);
-                    const double ipr = p.x * inv, ipi = -p.y * inv;  // 1 / pivot
-                    const double fr = ar[c], fi = ai[c];
-                    // g = -f / p for the other rows, 1/p - 1 for the pivot row itself
-                    double gr = -(fr * ipr - fi * ipi), gi = -(fr * ipi + fi * ipr);
-                    if (r == c) {
-                        gr = ipr - 1.0;
-                        gi = ipi;
-                    }
-#pragma unroll
-                    for (int j = 0; j < NP; ++j) {
-                        if (j < n && j != c) {
-                            const double2 u = buf[j];
-                            ar[j] = fma(gr, u.x, ar[j]);
-                            ar[j] = fma(-gi, u.y, ar[j]);
-                            ai[j] = fma(gr, u.y, ai[j]);
-                            ai[j] = fma(gi, u.x, ai[j]);
-                        }
-                    }
-                    ar[c] = (r == c) ? ipr : gr;
-                    ai[c] = (r == c) ? ipi : gi;
-                }
-            }
-            wave_sync();
-            // row r now holds row r of inv(A)
+            double ar[NP], ai[NP];
+            panel_inverse_row<NP, PAD>(coef, myrow, n, M, a.first, a.x[k] * a.inv_period, sw, a.p[0], r, ar, ai);
             if (a.integrand == ABZ_F_GLOC) {
                 if (act && r < n) {
                     double2* out = a.values + k * a.ncomp;
@@ -446,19 +494,8 @@ __global__ __launch_bounds__(256) void gen_panel_kernel(GenArgs a) {
                         if (j < n) out[r + n * j] = make_double2(ar[j], ai[j]);
                 }
             } else {
-                double tr = 0.0, ti = 0.0;
-#pragma unroll
-                for (int j = 0; j < NP; ++j) {
-                    if (j == r && r < n) {
-                        tr = ar[j];
-                        ti = ai[j];
-                    }
-                }
-#pragma unroll
-                for (int off = NP / 2; off > 0; off >>= 1) {
-                    tr += __shfl_xor(tr, off, 64);
-                    ti += __shfl_xor(ti, off, 64);
-                }
+                double tr, ti;
+                panel_trace<NP>(ar, ai, n, r, tr, ti);
                 if (act && r == 0)
                     a.values[k * a.ncomp] = (a.integrand == ABZ_F_DOS)
                                                 ? make_double2(-ti * 0.31830988618379067153776752674503, 0.0)
@@ -468,13 +505,15 @@ __global__ __launch_bounds__(256) void gen_panel_kernel(GenArgs a) {
     }
 }
 
-static bool gen_panel_supported(const GenSpec& gs, int* np_out, size_t* lds_out) {
+static bool gen_panel_supported(const GenSpec& gs, int* np_out, size_t* lds_out, bool* pad_out) {
     if (!gs.values || !gs.panels15 || gs.grid || !gs.x || gs.deriv || gs.nnodes % 15 != 0) return false;
     if (gs.n_sweep > 1 || gs.sweep_dev) return false;
     if (!(gs.integrand == ABZ_F_DOS || gs.integrand == ABZ_F_TRGLOC || gs.integrand == ABZ_F_GLOC)) return false;
     if (gs.Hplanes.base || gs.Eplanes.base || gs.Haos || gs.Eaos) return false;
     const int np = gs.n <= 8 ? 8 : (gs.n <= 16 ? 16 : 32);
-    const size_t lds = sizeof(double2) * ((size_t)gs.M * gs.n * gs.n + (size_t)(256 / np) * 2 * np);
+    size_t lds = sizeof(double2) * ((size_t)gs.M * np * np + (size_t)(256 / np) * 2 * np);  // zero-padded set
+    *pad_out = lds <= 150 * 1024;
+    if (!*pad_out) lds = sizeof(double2) * ((size_t)gs.M * gs.n * gs.n + (size_t)(256 / np) * 2 * np);
     if (lds > 150 * 1024) return false;
     *np_out = np;
     *lds_out = lds;
@@ -530,13 +569,21 @@ int launch_gen_nodes(abz_ctx* ctx, const GenSpec& gs) {
     {
         int np = 0;
         size_t plds = 0;
+        bool pad = false;
         static const bool off = [] { const char* e = getenv("ABZ_GEN_PANEL"); return e && e[0] == '0'; }();
-        if (!off && gen_panel_supported(gs, &np, &plds)) {
+        if (!off && gen_panel_supported(gs, &np, &plds, &pad)) {
             const int64_t blocks = std::min<int64_t>(gs.nnodes / 15, 256 * 8);
             ProfScope ps(ctx, ABZ_K_EVAL);
-#define ABZ_PANEL(NPV)                                                                                                   \
-    ABZ_HIP(hipFuncSetAttribute((const void*)gen_panel_kernel<NPV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)plds)); \
-    hipLaunchKernelGGL(gen_panel_kernel<NPV>, dim3((unsigned)blocks), dim3(256), plds, ctx->stream, a);
+#define ABZ_PANEL2(NPV, PV)                                                                                                  \
+    ABZ_HIP(hipFuncSetAttribute((const void*)gen_panel_kernel<NPV, PV>, hipFuncAttributeMaxDynamicSharedMemorySize,         \
+                                (int)plds));                                                                               \
+    hipLaunchKernelGGL((gen_panel_kernel<NPV, PV>), dim3((unsigned)blocks), dim3(256), plds, ctx->stream, a);
+#define ABZ_PANEL(NPV) \
+    if (pad) {         \
+        ABZ_PANEL2(NPV, true) \
+    } else {           \
+        ABZ_PANEL2(NPV, false) \
+    }
             if (np == 8) {
                 ABZ_PANEL(8)
             } else if (np == 16) {
@@ -545,6 +592,7 @@ int launch_gen_nodes(abz_ctx* ctx, const GenSpec& gs) {
                 ABZ_PANEL(32)
             }
 #undef ABZ_PANEL
+#undef ABZ_PANEL2
             ABZ_HIP(hipGetLastError());
             return ABZ_OK;
         }
@@ -841,6 +889,92 @@ __global__ __launch_bounds__(256) void gen_inner_adaptive_kernel(GenInnerArgs a,
     }
 }
 
+// Block-per-integral version of the above for the resolvent-trace integrands: the integral's coefficient
+// set is staged in LDS once and stays there for its whole adaptive loop; each round's 15 / 30 GK nodes
+// are evaluated 256/NP at a time by NP-lane groups (panel_inverse_row), thread 0 runs adapt_step.
+template <int NP, bool PAD>
+__global__ __launch_bounds__(256) void gen_inner_panel_kernel(GenInnerArgs a) {
+    extern __shared__ double2 lds_ip[];
+    constexpr int SLOTS = 256 / NP;
+    constexpr int MS = ABZ_INNER_MAXSEG;
+    const int n = a.n, nn = n * n, M = a.M, nc = a.ncomp;  // nc = 1 (DOS, TRGLOC)
+    double2* coef = lds_ip;
+    double2* prow = coef + (size_t)M * (PAD ? NP * NP : nn);
+    double* g = reinterpret_cast<double*>(prow + (size_t)SLOTS * 2 * NP);
+    double* seg_a = g;
+    double* seg_b = seg_a + MS;
+    double* seg_E = seg_b + MS;
+    gkc* seg_I = reinterpret_cast<gkc*>(seg_E + MS);
+    gkc* vals = seg_I + (size_t)MS * nc;
+    int* heap = reinterpret_cast<int*>(vals + (size_t)30 * nc);
+    double* ctl = reinterpret_cast<double*>(heap + MS);
+    const int slot = threadIdx.x / NP, r = threadIdx.x % NP;
+    double2* myrow = prow + (size_t)slot * 2 * NP;
+    for (int64_t q = blockIdx.x; q < a.nint; q += gridDim.x) {
+        AdaptState st;
+        __syncthreads();  // the previous integral's readers are done with coef / ctl
+        panel_stage<NP, PAD>(coef, a.src + a.slot[q] * ((int64_t)M * nn), n, M);
+        if (threadIdx.x == 0) {
+            adapt_init(st, a.atol[q], a.has_rtol != 0, a.rtol_user, a.lo[q], a.hi[q], ctl);
+            ctl[5] = 0.0;  // done flag
+        }
+        const double swq = a.sweep_arr ? a.sweep_arr[q] : a.sweep;
+        while (true) {
+            __syncthreads();
+            if (ctl[5] != 0.0) break;  // uniform
+            const int nnodes = 15 * (int)ctl[0];
+            for (int t0 = 0; t0 < nnodes; t0 += SLOTS) {
+                const int t = t0 + slot;
+                const bool act = t < nnodes;
+                const int tt = act ? t : 0;
+                const int pnl = tt / 15, i = tt - 15 * pnl;
+                const double x = gk15_node(ctl[1 + 2 * pnl], ctl[2 + 2 * pnl], i);
+                double ar[NP], ai[NP];
+                panel_inverse_row<NP, PAD>(coef, myrow, n, M, a.first, x * a.inv_period, swq, a.p[0], r, ar, ai);
+                double tr, ti;
+                panel_trace<NP>(ar, ai, n, r, tr, ti);
+                if (act && r == 0) {
+                    if (a.integrand == ABZ_F_DOS) {
+                        vals[t].re = -ti * 0.31830988618379067153776752674503;
+                        vals[t].im = 0.0;
+                    } else {
+                        vals[t].re = tr;
+                        vals[t].im = ti;
+                    }
+                }
+            }
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                InnerOut out;
+                out.I = a.I_out + q * nc;
+                out.E = a.E_out + q;
+                out.nev = a.nev_out + q;
+                out.status = a.status_out + q;
+                if (adapt_step(st, nc, seg_a, seg_b, seg_E, seg_I, vals, heap, ctl, a.maxevals, out)) ctl[5] = 1.0;
+            }
+        }
+    }
+}
+
+static bool gen_inner_panel_fits(int n, int M, int integrand, int* np_out, size_t* lds_out, bool* pad_out) {
+    if (!(integrand == ABZ_F_DOS || integrand == ABZ_F_TRGLOC)) return false;
+    const int np = n <= 8 ? 8 : (n <= 16 ? 16 : 32);
+    const size_t rest = sizeof(double2) * (size_t)(256 / np) * 2 * np + sizeof(double) * (size_t)inner_group_doubles(1);
+    size_t lds = sizeof(double2) * (size_t)M * np * np + rest;  // zero-padded set
+    const bool pad = lds <= 150 * 1024;
+    if (!pad) lds = sizeof(double2) * (size_t)M * n * n + rest;
+    if (lds > 150 * 1024) return false;
+    if (np_out) *np_out = np;
+    if (lds_out) *lds_out = lds;
+    if (pad_out) *pad_out = pad;
+    return true;
+}
+
+// the block-per-integral kernel is the one worth running by default (see iai_host.cpp)
+bool gen_inner_panel_supported(int n, int M, int integrand) {
+    return n > 4 && n <= ABZ_MAX_BANDS && gen_inner_panel_fits(n, M, integrand, nullptr, nullptr, nullptr);
+}
+
 bool gen_inner_supported(int n, int M, int integrand) {
     const int nc = integrand_ncomp(integrand, n, 3);
     if (n <= 4 || n > ABZ_MAX_BANDS || nc <= 0 || nc > ADAPT_MAXC) return false;
@@ -874,6 +1008,37 @@ int launch_gen_inner_adaptive(abz_ctx* ctx, const InnerSpec& is) {
     a.E_out = is.E_out;
     a.nev_out = is.nev_out;
     a.status_out = is.status_out;
+    {
+        int np = 0;
+        size_t plds = 0;
+        bool pad = false;
+        static const bool off = [] { const char* e = getenv("ABZ_GEN_PANEL"); return e && e[0] == '0'; }();
+        if (!off && gen_inner_panel_fits(is.n, is.M, is.integrand, &np, &plds, &pad)) {
+            const int64_t blocks = std::min<int64_t>(is.nint, 256 * 8);
+            ProfScope ps(ctx, ABZ_K_EVAL);
+#define ABZ_IPANEL2(NPV, PV)                                                                                                \
+    ABZ_HIP(hipFuncSetAttribute((const void*)gen_inner_panel_kernel<NPV, PV>, hipFuncAttributeMaxDynamicSharedMemorySize,  \
+                                (int)plds));                                                                               \
+    hipLaunchKernelGGL((gen_inner_panel_kernel<NPV, PV>), dim3((unsigned)blocks), dim3(256), plds, ctx->stream, a);
+#define ABZ_IPANEL(NPV) \
+    if (pad) {          \
+        ABZ_IPANEL2(NPV, true) \
+    } else {            \
+        ABZ_IPANEL2(NPV, false) \
+    }
+            if (np == 8) {
+                ABZ_IPANEL(8)
+            } else if (np == 16) {
+                ABZ_IPANEL(16)
+            } else {
+                ABZ_IPANEL(32)
+            }
+#undef ABZ_IPANEL
+#undef ABZ_IPANEL2
+            ABZ_HIP(hipGetLastError());
+            return ABZ_OK;
+        }
+    }
     const size_t per = sizeof(double) * gen_inner_wave_doubles(is.n, is.M, a.ncomp);
     int wpb = (int)((150 * 1024) / per);
     if (wpb > 4) wpb = 4;
