@@ -246,6 +246,21 @@ function AutoBZCore.batchsolve(s::IntegralSolver{<:HIPFourierIntegrand,<:Symmetr
     return j * ns .* real.(out)
 end
 
+# ---------------------------------------------------------------- k-sharded rules (one solve on several GPUs)
+"""
+    slab_rule(hs, npt, rank, world, want)
+
+This rank's slab of the full PTR grid (outermost index in `[z0, z1)`), for a solve sharded over k: sum
+the `reduce_rule` results of all ranks (e.g. `MPI.Allreduce` / RCCL) to obtain the rule value.
+"""
+function slab_rule(hs::HIPSeries{N}, npt::Integer, rank::Integer, world::Integer, want::Integer=WANT_H) where {N}
+    z0 = (npt * rank) ÷ world; z1 = (npt * (rank + 1)) ÷ world
+    h = Ref{Ptr{Cvoid}}(C_NULL)
+    check(ccall((:abz_ptr_rule_build_slab, libabz), Cint, (Ptr{Cvoid}, Cint, Cint, Cint, Cint, Ptr{Ptr{Cvoid}}),
+        hs.h, npt, z0, z1, want, h))
+    return HIPRule(h[], (z1 - z0) * npt^(N - 1), npt, 1)
+end
+
 # ---------------------------------------------------------------- GGR
 "get_ggr_data + sum_ggr on the GPU (src/dos_ggr.jl:14-65)."
 function ggr(h::FourierSeries{S,N}, bz::SymmetricBZ, Es::Vector{Float64}; npt=50) where {S,N}
