@@ -145,3 +145,16 @@ def test_hchebinterp_driver(abz):
     assert np.abs(itp(x) - np.array([f(t) for t in x])).max() < 5e-4
     assert itp.numevals == sum(calls) and calls[0] == 16 and all(c % 16 == 0 for c in calls)
     assert abs(itp(12.2) - f(12.2)) < 5e-4 and np.ndim(itp(12.2)) == 0
+
+
+def test_synthetic_models_match_the_oracle_recipe():
+    """SURVEY 8d synthetic inputs: the product-side generators (bench / configs 2 and 5) draw the same
+    splitmix64 stream in the same order as the oracle's restatement -> identical coefficients."""
+    import itertools
+    import autobzcore.jl_amd as abz
+    g = orc.splitmix64(20240601)
+    assert np.array_equal(abz.splitmix64_uniform(20240601, 64), np.array(list(itertools.islice(g, 64))))
+    for kw in (dict(n=5, rmax=2, seed=7), dict(n=16, rmax=6, seed=20240601)):
+        a, b = orc.synthetic_wannier(**kw), abz.synthetic_wannier(**kw)
+        assert np.array_equal(a.c, b.c) and tuple(np.atleast_1d(b.first)) == tuple(np.atleast_1d(a.first))
+    assert np.array_equal(orc.tb_integer(3, 1.5).c, abz.tb_integer(3, 1.5).c)
