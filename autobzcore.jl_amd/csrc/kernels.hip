@@ -638,7 +638,19 @@ int launch_eval(abz_ctx* ctx, const EvalSpec& es) {
         if (es.nlines == 0) return ABZ_OK;
         const int64_t blocks = std::min<int64_t>(cdiv(es.nlines, 4), 256 * 8);
         const int mnn = es.M * es.n * es.n;
-        const int kpl = es.npt <= 64 ? 1 : (es.npt <= 128 ? 2 : 3);
+        // nodes per lane: minimise lane-rounds per line, ceil(npt / (64 kpl)) * kpl, weighted by the LDS
+        // operand reads that are shared by the kpl nodes of a lane (200 points: 2 x 2 rounds, not 2 x 3)
+        int kpl = 1;
+        {
+            double best = 1e30;
+            for (int k = 1; k <= 3; ++k) {
+                const double cost = (double)(cdiv(es.npt, 64 * k) * k) * (1.0 + 0.3 / k);
+                if (cost < best - 1e-12) {
+                    best = cost;
+                    kpl = k;
+                }
+            }
+        }
         // + an LDS copy of the phase table (fm * i1 < npt^2 must fit 32 bits)
         const size_t lds = sizeof(double2) * (4 * 2 * (size_t)mnn + (size_t)a.npt);
         if (mnn <= EVAL_MAX_MNN && lds <= 64 * 1024 && a.npt < 65536) {

@@ -267,6 +267,36 @@ def main():
                                                 "nodes_per_sec": sol.numevals / dt}
             except Exception as e:
                 out["iai_example"] = {"error": str(e)}
+            # configs 2 and 3 end to end (host loop + kernels + transfers; not the primary metric)
+            try:
+                cfg = {}
+                tb = abz.tb_integer(3)
+                sol2 = abz.IntegralSolver(abz.FourierIntegrand(abz.DOSIntegrand(), tb, 0.1),
+                                          abz.load_bz(abz.FBZ(), np.eye(3)), abz.PTR(npt=64))
+                sol2(0.5)
+                t0 = time.perf_counter()
+                for _ in range(10):
+                    tb.device().drop_rules()  # cold: build the 64^3 rule every time
+                    u2 = sol2(0.5)
+                cfg["config2_tb1band_64cubed_ptr"] = {"u": u2, "seconds_cold": (time.perf_counter() - t0) / 10}
+                t0 = time.perf_counter()
+                for _ in range(10):
+                    u2 = sol2(0.5)
+                cfg["config2_tb1band_64cubed_ptr"]["seconds_cached_rule"] = (time.perf_counter() - t0) / 10
+                for kind, bzk in (("FBZ", abz.FBZ()), ("CubicSymIBZ", abz.CubicSymIBZ())):
+                    sol3 = abz.IntegralSolver(abz.FourierIntegrand(abz.DOSIntegrand(), s, a.eta),
+                                              abz.load_bz(bzk, 3.85856 * np.eye(3)), abz.EvalCounter(abz.AutoPTR()), abstol=1e-3)
+                    s.device().drop_rules()
+                    t0 = time.perf_counter()
+                    r3 = sol3.solve_p(abz.MixedParameters(12.5))
+                    tc = time.perf_counter() - t0
+                    t0 = time.perf_counter()
+                    r3 = sol3.solve_p(abz.MixedParameters(12.5))
+                    cfg["config3_svo_autoptr_" + kind] = {"u": r3.u, "resid": r3.resid, "numevals": r3.numevals,
+                                                         "seconds_cold": tc, "seconds_cached_rules": time.perf_counter() - t0}
+                out["configs_end_to_end"] = cfg
+            except Exception as e:
+                out["configs_end_to_end"] = {"error": str(e)}
             # config 5: synthetic 16-band model, IAI on the full BZ (380 M adaptive nodes)
             try:
                 s16 = abz.synthetic_wannier()
