@@ -174,6 +174,41 @@ def test_rule_reduce_matches_oracle_dos(abz):
             assert abs(t[i] - np.trace(ref)) <= 1e-11 * abs(np.trace(ref))
 
 
+@pytest.mark.parametrize("n", [2, 3])
+def test_rule_reduce_non_hermitian_series(abz, n):
+    """A series that is NOT Hermitian (e.g. H + a k-dependent self-energy) takes the general paths:
+    full-matrix Fourier evaluation and the complex characteristic polynomial in the scan.  The decay of
+    the anti-Hermitian part keeps (omega + i eta) - H invertible."""
+    rng = np.random.default_rng(50 + n)
+    c, first = rand_series(rng, (3, 3, 3), n, hermitian=True)
+    extra, _ = rand_series(rng, (3, 3, 3), n, hermitian=False)
+    c = c + 0.05 * extra
+    s, so = both(abz, c, first)
+    omegas = np.array([-1.5, 0.2, 2.0])
+    eta = 0.6
+    rule = s.device().rule(9, None, want=1)
+    got = rule.reduce(abz._lib.F_DOS, [eta], omegas)[:, 0].real
+    tr = rule.reduce(abz._lib.F_TRGLOC, [eta], omegas)[:, 0]
+    g = rule.reduce(abz._lib.F_GLOC, [eta], omegas[:1])
+    for i, om in enumerate(omegas):
+        ref, _ = orc._ptr_rule_sum(so, 9, None, orc.f_gloc(eta, om))
+        assert abs(tr[i] - np.trace(ref)) <= 1e-11 * abs(np.trace(ref))
+        assert abs(got[i] + np.trace(ref).imag / np.pi) <= 1e-11 * abs(np.trace(ref))
+        if i == 0:
+            assert np.abs(g[0].reshape(n, n).T - ref).max() <= 1e-11 * np.abs(ref).max()
+    # and the same through IAI (device-side inner loops on non-Hermitian values); 2-D keeps the pure-Python
+    # oracle at a fraction of a second
+    c2, first2 = rand_series(rng, (3, 3), n, hermitian=True)
+    extra2, _ = rand_series(rng, (3, 3), n, hermitian=False)
+    s2, so2 = both(abz, (c2 + 0.05 * extra2) / 2, first2)
+    bz = abz.load_bz(abz.FBZ(), np.eye(2))
+    sol = abz.do_solve(abz.FourierIntegrand(abz.TrGlocIntegrand(), s2, eta), bz, abz.MixedParameters(0.2),
+                       abz.EvalCounter(abz.IAI()), abstol=1e-3)
+    f_tr = lambda x, h: np.trace(orc.f_gloc(eta, 0.2)(x, h), axis1=-2, axis2=-1)
+    ref = orc.solve_iai(so2, orc.load_bz("FBZ", np.eye(2)), f_tr, abstol=1e-3)
+    assert sol.numevals == ref.numevals and abs(sol.u - ref.u) <= 1e-9 * abs(ref.u)
+
+
 # ------------------------------------------------------------------ reference's own hot-path tests
 @pytest.mark.parametrize("d", [1, 2, 3])
 @pytest.mark.parametrize("kind", ["FBZ", "InversionSymIBZ"])
