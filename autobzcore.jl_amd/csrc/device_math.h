@@ -666,6 +666,71 @@ __device__ __forceinline__ void charpoly_trace_h(const CharPolyH& cp, double w, 
     tr = NEED_RE ? fma(nr, dr, ni * di) * inv : 0.0;
 }
 
+// Hermitian H, matrix-valued resolvent: G(z) = adj(w I - B) / p(w) with B = H - q I traceless,
+// w = z - q, adj(w I - B) = w^2 I + w B + C, C = adj(B) = B^2 + p1 I (Cayley-Hamilton), p as above.
+// Per node: B and C (Hermitian: 9 doubles each) once; per sweep value ~95 flops instead of a 3x3
+// complex inversion.
+struct AdjH3 {
+    double q, p1, p0;
+    double d[3];                 // diagonal of B
+    double br[3], bi[3];         // B01, B02, B12
+    double c[3];                 // diagonal of C
+    double cr[3], ci[3];         // C01, C02, C12
+};
+__device__ __forceinline__ void adj_init_h3(double h00, double h11, double h22, double b01r, double b01i, double b02r,
+                                            double b02i, double b12r, double b12i, AdjH3& s) {
+    CharPolyH cp;
+    charpoly_init_h3(h00, h11, h22, b01r, b01i, b02r, b02i, b12r, b12i, cp);
+    s.q = cp.q;
+    s.p1 = cp.p1;
+    s.p0 = cp.p0;
+    const double d0 = h00 - cp.q, d1 = h11 - cp.q, d2 = h22 - cp.q;
+    s.d[0] = d0;
+    s.d[1] = d1;
+    s.d[2] = d2;
+    s.br[0] = b01r, s.bi[0] = b01i, s.br[1] = b02r, s.bi[1] = b02i, s.br[2] = b12r, s.bi[2] = b12i;
+    const double n01 = b01r * b01r + b01i * b01i, n02 = b02r * b02r + b02i * b02i, n12 = b12r * b12r + b12i * b12i;
+    // C = B^2 + p1 I
+    s.c[0] = d0 * d0 + n01 + n02 + cp.p1;
+    s.c[1] = n01 + d1 * d1 + n12 + cp.p1;
+    s.c[2] = n02 + n12 + d2 * d2 + cp.p1;
+    // (B^2)_01 = (d0 + d1) b01 + b02 conj(b12)
+    s.cr[0] = (d0 + d1) * b01r + (b02r * b12r + b02i * b12i);
+    s.ci[0] = (d0 + d1) * b01i + (b02i * b12r - b02r * b12i);
+    // (B^2)_02 = (d0 + d2) b02 + b01 b12
+    s.cr[1] = (d0 + d2) * b02r + (b01r * b12r - b01i * b12i);
+    s.ci[1] = (d0 + d2) * b02i + (b01r * b12i + b01i * b12r);
+    // (B^2)_12 = (d1 + d2) b12 + conj(b01) b02
+    s.cr[2] = (d1 + d2) * b12r + (b01r * b02r + b01i * b02i);
+    s.ci[2] = (d1 + d2) * b12i + (b01r * b02i - b01i * b02r);
+}
+// G[a + 3 b] (column-major) at z = w + i eta
+__device__ __forceinline__ void adj_gloc_h3(const AdjH3& s, double w, double eta, double (&gr)[9], double (&gi)[9]) {
+    const double wr = w - s.q;
+    const double w2r = fma(wr, wr, -eta * eta), w2i = 2.0 * wr * eta;
+    const double ar = w2r + s.p1;
+    const double pr = fma(wr, ar, fma(-eta, w2i, s.p0)), pi = fma(wr, w2i, eta * ar);
+    const double inv = fast_rcp(fma(pr, pr, pi * pi));
+    const double ir = pr * inv, ii = -pi * inv;  // 1 / p(w)
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const double nr = fma(wr, s.d[a], w2r + s.c[a]), ni = fma(eta, s.d[a], w2i);
+        gr[a + 3 * a] = nr * ir - ni * ii;
+        gi[a + 3 * a] = nr * ii + ni * ir;
+    }
+    constexpr int RA[3] = {0, 0, 1}, RB[3] = {1, 2, 2};
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+        // upper entry (a, b): w B_ab + C_ab ; lower entry (b, a): w conj(B_ab) + conj(C_ab)
+        const double ur = fma(wr, s.br[t], fma(-eta, s.bi[t], s.cr[t])), ui = fma(wr, s.bi[t], fma(eta, s.br[t], s.ci[t]));
+        const double lr = fma(wr, s.br[t], fma(eta, s.bi[t], s.cr[t])), li = fma(-wr, s.bi[t], fma(eta, s.br[t], -s.ci[t]));
+        gr[RA[t] + 3 * RB[t]] = ur * ir - ui * ii;
+        gi[RA[t] + 3 * RB[t]] = ur * ii + ui * ir;
+        gr[RB[t] + 3 * RA[t]] = lr * ir - li * ii;
+        gi[RB[t] + 3 * RA[t]] = lr * ii + li * ir;
+    }
+}
+
 // wave64 sum via DPP-free shuffles (6 steps)
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll

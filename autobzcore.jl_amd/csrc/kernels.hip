@@ -849,6 +849,19 @@ struct NComp {
     }
 };
 
+// Cross-lane reduction of the NC components of one sweep value.  NC <= 2: wave shuffles.  NC > 2 (matrix
+// and vector valued integrands): through a wave-private LDS tile -- every lane writes its NC values,
+// then lane (c, g) sums every G-th row of column c: ~(NC + 64/G) LDS operations per lane instead of
+// 12 NC dependent shuffles.
+template <int NC>
+struct ReduceShape {
+    static constexpr bool viaLds = NC > 2;
+    static constexpr int G = viaLds ? 64 / NC : 1;        // row groups (partial sums) per wave
+    static constexpr int PW = 4 * G;                      // partial rows per sweep value and block
+    static constexpr int chunk = viaLds ? (NC > 9 ? 4 : 8) : 512 / NC;  // sweep values per LDS pass
+    static constexpr int tile = viaLds ? 64 * NC : 0;     // double2 per wave
+};
+
 struct ReduceArgs {
     PlaneView H, E;
     const double* w;
@@ -864,14 +877,14 @@ struct ReduceArgs {
 // HERM (rules of a Hermitian series, resolvent traces of n = 2, 3): real polynomial, upper triangle of
 // H only (half of the planes are never read), ~21 instructions per (node, sweep value).
 template <int N, int FID, int KT, bool HERM>
-__global__ __launch_bounds__(256, (HERM || FID == ABZ_F_DOS_EIG) ? 3 : 1) void reduce_kernel(ReduceArgs a, double2* __restrict__ partial) {
+__global__ __launch_bounds__(256, FID == ABZ_F_GLOC ? (HERM ? 2 : 1) : ((HERM || FID == ABZ_F_DOS_EIG) ? 3 : 1)) void reduce_kernel(ReduceArgs a, double2* __restrict__ partial) {
     constexpr int NC = NComp<FID>::template value<N>();
     extern __shared__ double2 lds[];  // [chunk][4 waves][NC]
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int64_t base = (int64_t)blockIdx.x * (256 * KT);
     constexpr bool polyH = HERM && (N == 2 || N == 3) && (FID == ABZ_F_DOS || FID == ABZ_F_TRGLOC);
     constexpr bool usePoly0 = !polyH && (N == 2 || N == 3) && (FID == ABZ_F_DOS || FID == ABZ_F_TRGLOC);
-    CMat<N> H[usePoly0 ? 1 : KT];  // poly mode: H is only a transient input of charpoly_init
+    CMat<N> H[(usePoly0 || (HERM && N == 3 && FID == ABZ_F_GLOC)) ? 1 : KT];  // poly / adjugate mode: H is never kept
     double e[KT][N];
     double wk[KT];
     double xk[KT][ABZ_MAX_DIM];
@@ -879,8 +892,10 @@ __global__ __launch_bounds__(256, (HERM || FID == ABZ_F_DOS_EIG) ? 3 : 1) void r
                             FID == ABZ_F_TRGLOC || FID == ABZ_F_GLOC);
     // n = 2, 3 resolvent traces: characteristic polynomial per node, ~40 flops per sweep value
     constexpr bool usePoly = usePoly0;
+    constexpr bool adjG = HERM && N == 3 && FID == ABZ_F_GLOC;  // adjugate form of the 3x3 resolvent
     CharPoly<(usePoly ? N : 2)> cp[usePoly ? KT : 1];
     CharPolyH cph[polyH ? KT : 1];
+    AdjH3 adj[adjG ? KT : 1];
     // (line, column) of this thread's first node; the following ones are 256 apart, so one 64-bit
     // division per thread and a 32-bit one per node (all views of a rule share line_len and tile)
     const int LL = a.H.line_len;
@@ -899,7 +914,12 @@ __global__ __launch_bounds__(256, (HERM || FID == ABZ_F_DOS_EIG) ? 3 : 1) void r
             vcol -= qd * (unsigned)LL;
         }
         wk[j] = ok ? (a.w ? a.w[kk] : 1.0) : 0.0;
-        if constexpr (polyH) {
+        if constexpr (adjG) {
+            const double* __restrict__ in = a.H.base + voff;
+            const int64_t pp = a.H.pitch;
+            adj_init_h3(in[0], in[8 * pp], in[16 * pp], in[6 * pp], in[7 * pp], in[12 * pp], in[13 * pp], in[14 * pp],
+                        in[15 * pp], adj[j]);
+        } else if constexpr (polyH) {
             const double* __restrict__ in = a.H.base + voff;
             const int64_t pp = a.H.pitch;
             // plane of Re H[r][c] is 2 (r + N c), Im the next one
@@ -910,7 +930,7 @@ __global__ __launch_bounds__(256, (HERM || FID == ABZ_F_DOS_EIG) ? 3 : 1) void r
                 charpoly_init_h2(in[0], in[6 * pp], in[4 * pp], in[5 * pp], cph[j]);
             }
         } else if constexpr (needH) {
-            load_planes<N>(H[usePoly0 ? 0 : j], a.H, voff);
+            load_planes<N>(H[(usePoly0 || adjG) ? 0 : j], a.H, voff);
         }
         if constexpr (usePoly) charpoly_init<N>(H[0], cp[j]);
         if constexpr (FID == ABZ_F_DOS_EIG) {
@@ -932,7 +952,10 @@ __global__ __launch_bounds__(256, (HERM || FID == ABZ_F_DOS_EIG) ? 3 : 1) void r
             }
         }
     }
-    const int chunk = 512 / NC;  // sweep values per LDS pass (<= 32 KiB)
+    using RS = ReduceShape<NC>;
+    constexpr int chunk = RS::chunk;
+    constexpr int PW = RS::PW;
+    [[maybe_unused]] double2* const T = lds + (size_t)chunk * PW * NC + (size_t)wave * RS::tile;
     for (int s0 = 0; s0 < a.n_sweep; s0 += chunk) {
         const int s1 = min(a.n_sweep, s0 + chunk);
         [[maybe_unused]] const double eta2 = a.p[0] * a.p[0], teta = 2.0 * a.p[0];
@@ -947,7 +970,15 @@ __global__ __launch_bounds__(256, (HERM || FID == ABZ_F_DOS_EIG) ? 3 : 1) void r
 #pragma unroll
             for (int j = 0; j < KT; ++j) {
                 double vr[MAXC], vi[MAXC];
-                if constexpr (polyH) {
+                if constexpr (adjG) {
+                    double gr[9], gi[9];
+                    adj_gloc_h3(adj[j], sw, a.p[0], gr, gi);
+#pragma unroll
+                    for (int c = 0; c < 9; ++c) {
+                        vr[c] = gr[c];
+                        vi[c] = gi[c];
+                    }
+                } else if constexpr (polyH) {
                     double tr, ti;
                     charpoly_trace_h<N, FID != ABZ_F_DOS>(cph[j], sw, a.p[0], eta2, teta, tr, ti);
                     vr[0] = (FID == ABZ_F_DOS) ? -ti * 0.31830988618379067153776752674503 : tr;
@@ -958,7 +989,7 @@ __global__ __launch_bounds__(256, (HERM || FID == ABZ_F_DOS_EIG) ? 3 : 1) void r
                     vr[0] = (FID == ABZ_F_DOS) ? -ti * 0.31830988618379067153776752674503 : tr;
                     vi[0] = (FID == ABZ_F_DOS) ? 0.0 : ti;
                 } else {
-                    integrand_value<N, FID>(H[usePoly0 ? 0 : j], e[j], xk[j], a.d, a.p, sw, vr, vi);
+                    integrand_value<N, FID>(H[(usePoly0 || adjG) ? 0 : j], e[j], xk[j], a.d, a.p, sw, vr, vi);
                 }
 #pragma unroll
                 for (int c = 0; c < NC; ++c) {
@@ -967,21 +998,41 @@ __global__ __launch_bounds__(256, (HERM || FID == ABZ_F_DOS_EIG) ? 3 : 1) void r
                 }
             }
             constexpr bool realValued = (FID == ABZ_F_DOS || FID == ABZ_F_DOS_EIG || FID == ABZ_F_ONE);
+            if constexpr (RS::viaLds) {
 #pragma unroll
-            for (int c = 0; c < NC; ++c) {
-                const double sr = wave_sum(ar[c]);
-                const double si = realValued ? 0.0 : wave_sum(ai[c]);
-                if (lane == 0) lds[((s - s0) * 4 + wave) * NC + c] = make_double2(sr, si);
+                for (int c = 0; c < NC; ++c) T[lane * NC + c] = make_double2(ar[c], ai[c]);
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                if (lane < RS::G * NC) {
+                    const int c = lane % NC, g = lane / NC;
+                    double2 acc = make_double2(0.0, 0.0);
+                    for (int r = g; r < 64; r += RS::G) {
+                        const double2 v = T[r * NC + c];
+                        acc.x += v.x;
+                        acc.y += v.y;
+                    }
+                    lds[((s - s0) * PW + wave * RS::G + g) * NC + c] = acc;
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            } else {
+#pragma unroll
+                for (int c = 0; c < NC; ++c) {
+                    const double sr = wave_sum(ar[c]);
+                    const double si = realValued ? 0.0 : wave_sum(ai[c]);
+                    if (lane == 0) lds[((s - s0) * PW + wave) * NC + c] = make_double2(sr, si);
+                }
             }
         }
         __syncthreads();
         const int cols = (s1 - s0) * NC;
         for (int t = threadIdx.x; t < cols; t += 256) {
             const int s = t / NC, c = t - s * NC;
-            double2 acc = lds[(s * 4 + 0) * NC + c];
-#pragma unroll
-            for (int w2 = 1; w2 < 4; ++w2) {
-                const double2 v = lds[(s * 4 + w2) * NC + c];
+            double2 acc = lds[(s * PW + 0) * NC + c];
+            for (int w2 = 1; w2 < PW; ++w2) {
+                const double2 v = lds[(s * PW + w2) * NC + c];
                 acc.x += v.x;
                 acc.y += v.y;
             }
@@ -1019,26 +1070,42 @@ __global__ __launch_bounds__(256) void final_reduce_kernel(const double2* __rest
 
 // nodes per thread: the wave reduction per sweep value is amortised over KT nodes; the cheap
 // per-node states (characteristic polynomial: 6 doubles, eigenvalues: n doubles) allow KT = 8
-template <int N, int FID>
+template <int N, int FID, bool HERM>
 constexpr int reduce_kt_of() {
+    if (HERM && N == 3 && FID == ABZ_F_GLOC) return 3;  // adjugate state: 21 doubles per node (4 would spill)
     if (FID == ABZ_F_GLOC || N >= 4) return 1;
     if (FID == ABZ_F_DOS_EIG || ((N == 2 || N == 3) && (FID == ABZ_F_DOS || FID == ABZ_F_TRGLOC))) return 8;
     return 2;
 }
 
-template <int N, int FID>
-static int launch_reduce_t(abz_ctx* ctx, const ReduceSpec& rs, const ReduceArgs& a, double2* partial,
-                           int64_t nblocks) {
-    constexpr int KT = reduce_kt_of<N, FID>();
+template <int N, int FID, bool HERM>
+static int launch_reduce_h(abz_ctx* ctx, const ReduceSpec& rs, const ReduceArgs& a) {
+    constexpr int KT = reduce_kt_of<N, FID, HERM>();
     constexpr int NC = NComp<FID>::template value<N>();
-    const int chunk = 512 / NC;
-    const size_t lds = sizeof(double2) * (size_t)std::min(chunk, rs.n_sweep) * 4 * NC;
-    constexpr bool canH = (N == 2 || N == 3) && (FID == ABZ_F_DOS || FID == ABZ_F_TRGLOC);
-    if (canH && rs.herm)
-        hipLaunchKernelGGL((reduce_kernel<N, FID, KT, canH>), dim3((unsigned)nblocks), dim3(256), lds, ctx->stream, a, partial);
-    else
-        hipLaunchKernelGGL((reduce_kernel<N, FID, KT, false>), dim3((unsigned)nblocks), dim3(256), lds, ctx->stream, a, partial);
+    const int64_t nblocks = cdiv(rs.nk, 256 * KT);
+    const int64_t ncols = (int64_t)rs.n_sweep * a.ncomp;
+    int rc = ctx->scratch[1].reserve(sizeof(double2) * (size_t)(nblocks * ncols));
+    if (rc) return rc;
+    using RS = ReduceShape<NC>;
+    const size_t lds = sizeof(double2) * ((size_t)RS::chunk * RS::PW * NC + (size_t)4 * RS::tile);
+    if (lds > 64 * 1024)
+        ABZ_HIP(hipFuncSetAttribute((const void*)reduce_kernel<N, FID, KT, HERM>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)lds));
+    hipLaunchKernelGGL((reduce_kernel<N, FID, KT, HERM>), dim3((unsigned)nblocks), dim3(256), lds, ctx->stream, a,
+                       ctx->scratch[1].as<double2>());
+    ABZ_HIP(hipGetLastError());
+    hipLaunchKernelGGL(final_reduce_kernel, dim3((unsigned)ncols), dim3(256), 0, ctx->stream, ctx->scratch[1].as<double2>(),
+                       nblocks, ncols, rs.scale, ctx->scratch[2].as<double2>());
+    ABZ_HIP(hipGetLastError());
     return ABZ_OK;
+}
+
+// Hermitian rules take the real-polynomial / adjugate paths where they exist
+template <int N, int FID>
+static int launch_reduce_t(abz_ctx* ctx, const ReduceSpec& rs, const ReduceArgs& a) {
+    constexpr bool canH = (N == 2 || N == 3) && (FID == ABZ_F_DOS || FID == ABZ_F_TRGLOC || (N == 3 && FID == ABZ_F_GLOC));
+    if (canH && rs.herm) return launch_reduce_h<N, FID, canH>(ctx, rs, a);
+    return launch_reduce_h<N, FID, false>(ctx, rs, a);
 }
 
 template <int FID>
@@ -1070,32 +1137,23 @@ int launch_reduce(abz_ctx* ctx, const ReduceSpec& rs, double* out_reim) {
     a.n_sweep = rs.n_sweep;
     a.ncomp = ncomp;
     for (int i = 0; i < 4; ++i) a.p[i] = rs.params[i];
-    int kt = 2;
-    if (rs.integrand == ABZ_F_GLOC || rs.n >= 4)
-        kt = 1;
-    else if (rs.integrand == ABZ_F_DOS_EIG || ((rs.n == 2 || rs.n == 3) && (rs.integrand == ABZ_F_DOS || rs.integrand == ABZ_F_TRGLOC)))
-        kt = 8;
-    const int64_t nblocks = cdiv(rs.nk, 256 * kt);
     const int64_t ncols = (int64_t)rs.n_sweep * ncomp;
-    int rc = ctx->scratch[1].reserve(sizeof(double2) * (size_t)(nblocks * ncols));
+    int rc = ctx->scratch[2].reserve(sizeof(double2) * (size_t)ncols);
     if (rc) return rc;
-    rc = ctx->scratch[2].reserve(sizeof(double2) * (size_t)ncols);
-    if (rc) return rc;
-    double2* partial = ctx->scratch[1].as<double2>();
     double2* outd = ctx->scratch[2].as<double2>();
     {
         ProfScope ps(ctx, ABZ_K_REDUCE);
-#define CASE(FID)                                                                   \
-    case FID:                                                                       \
-        switch (rs.n) {                                                             \
-            case 1: launch_reduce_t<1, FID>(ctx, rs, a, partial, nblocks); break;   \
-            case 2: launch_reduce_t<2, FID>(ctx, rs, a, partial, nblocks); break;   \
-            case 3: launch_reduce_t<3, FID>(ctx, rs, a, partial, nblocks); break;   \
-            case 4: launch_reduce_t<4, FID>(ctx, rs, a, partial, nblocks); break;   \
-            default:                                                                \
+#define CASE(FID)                                                          \
+    case FID:                                                              \
+        switch (rs.n) {                                                    \
+            case 1: rc = launch_reduce_t<1, FID>(ctx, rs, a); break;       \
+            case 2: rc = launch_reduce_t<2, FID>(ctx, rs, a); break;       \
+            case 3: rc = launch_reduce_t<3, FID>(ctx, rs, a); break;       \
+            case 4: rc = launch_reduce_t<4, FID>(ctx, rs, a); break;       \
+            default:                                                       \
                 set_error("n = %d bands: only n <= 4 is built in this round", rs.n); \
-                return ABZ_ERR_UNSUPPORTED;                                         \
-        }                                                                           \
+                return ABZ_ERR_UNSUPPORTED;                                \
+        }                                                                  \
         break;
         switch (rs.integrand) {
             CASE(ABZ_F_ONE)
@@ -1107,10 +1165,7 @@ int launch_reduce(abz_ctx* ctx, const ReduceSpec& rs, double* out_reim) {
             CASE(ABZ_F_DOS_EIG)
         }
 #undef CASE
-        ABZ_HIP(hipGetLastError());
-        hipLaunchKernelGGL(final_reduce_kernel, dim3((unsigned)ncols), dim3(256), 0, ctx->stream, partial, nblocks, ncols,
-                           rs.scale, outd);
-        ABZ_HIP(hipGetLastError());
+        if (rc) return rc;
     }
     ABZ_HIP(hipMemcpyAsync(out_reim, outd, sizeof(double2) * (size_t)ncols, hipMemcpyDeviceToHost, ctx->stream));
     ABZ_HIP(hipStreamSynchronize(ctx->stream));
