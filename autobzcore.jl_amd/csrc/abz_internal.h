@@ -171,8 +171,14 @@ struct EvalSpec {
     PlaneView H;
     PlaneView E;
     PlaneView U;  // eigenvector planes 2*(a + n*b) + {re, im}: component a of vector b
+    // grid mode with the last contraction fused in (src2 != nullptr, see eval_can_fuse): level-2 sets
+    // [nlines / gcnt][M2][M n n]; line = parent * gcnt + (i2 - gbeg); `src` is unused
+    const double2* src2 = nullptr;
+    int M2 = 0, first2 = 0, gbeg = 0, gcnt = 0;
+    bool deriv2 = false;
 };
 int launch_eval(abz_ctx* ctx, const EvalSpec& es);
+bool eval_can_fuse(int n, int M, int M2, int npt);
 
 int launch_eig_planes(abz_ctx* ctx, int n, PlaneView H, PlaneView E, PlaneView U, int64_t nk);
 // V[b](k) = Re sum_{a,c} conj(U[a,b]) dH[a,c] U[c,b]   (Vj: view of the n planes of one direction)

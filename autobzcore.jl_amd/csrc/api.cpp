@@ -215,12 +215,12 @@ static int plan_upload(abz_ctx* ctx, const Plan& p, PlanDev& pd) {
 // Build the level-1 coefficient sets for a plan.  deriv_dim (1-based, 0 = none) applies the
 // derivative factor to that variable's phases.  Returns pointer to level-1 sets (or coef if d == 1).
 static int build_chain(abz_series* s, const Plan& p, const PlanDev& pd, const double2* tab, int deriv_dim,
-                       const double2** level1) {
+                       const double2** level1, int last_level = 1) {
     abz_ctx* ctx = s->ctx;
     const int d = s->d;
     const double2* src = s->coef;
     int64_t src_elems = s->elems(d);
-    for (int L = d - 1; L >= 1; --L) {
+    for (int L = d - 1; L >= last_level; --L) {  // last_level = 2: stop at the level-2 sets (fused last contraction)
         // contract variable L+1 (0-based dim index L)
         const int64_t B = p.nitems[L];
         const int M = s->dims[L];
@@ -533,17 +533,59 @@ static int rule_fill(abz_rule* r) {
         es.U = Uout;
         return launch_eval(ctx, es);
     };
+    // full grids of d >= 2 variables: the last contraction (variable 2) runs inside the grid kernel
+    const bool fuse = r->full && d >= 2 && eval_can_fuse(n, s->dims[0], s->dims[1], r->npt);
+    auto run_fused = [&](const double2* level2, bool deriv1, bool deriv2, PlaneView Hout, PlaneView Eout, PlaneView Uout) -> int {
+        EvalSpec es;
+        es.n = n;
+        es.M = s->dims[0];
+        es.first = s->first[0];
+        es.period = s->period[0];
+        es.src = nullptr;
+        es.grid = true;
+        es.npt = r->npt;
+        es.nlines = plan.nitems[1];
+        es.tab = tab;
+        es.nk = r->nk;
+        es.parents = nullptr;
+        es.gi = nullptr;
+        es.x = nullptr;
+        es.deriv = deriv1;
+        es.herm = s->hermitian && !deriv2;
+        es.H = Hout;
+        es.E = Eout;
+        es.U = Uout;
+        es.src2 = level2;
+        es.M2 = s->dims[1];
+        es.first2 = s->first[1];
+        es.deriv2 = deriv2;
+        es.gbeg = (d == 2) ? plan.outer0 : 0;
+        es.gcnt = (d == 2) ? plan.outer_n : r->npt;
+        return launch_eval(ctx, es);
+    };
     const double2* level1 = nullptr;
-    int rc = build_chain(s, plan, rp->pd, tab, 0, &level1);
-    if (rc) return rc;
-    if ((rc = run_eval(level1, false, r->H, r->E, Uv))) return rc;
+    int rc;
+    if (fuse) {
+        if ((rc = build_chain(s, plan, rp->pd, tab, 0, &level1, 2))) return rc;
+        if ((rc = run_fused(level1, false, false, r->H, r->E, Uv))) return rc;
+    } else {
+        if ((rc = build_chain(s, plan, rp->pd, tab, 0, &level1))) return rc;
+        if ((rc = run_eval(level1, false, r->H, r->E, Uv))) return rc;
+    }
     if (r->want & ABZ_WANT_VEL) {
         // d/dx_1 reuses the level-1 sets; d/dx_j (j >= 2) rebuilds the chain with the derivative
         // factor on variable j (JacobianSeries, ref src/dos_ggr.jl:6-7)
         for (int j = 1; j <= d; ++j) {
-            if (j >= 2)
-                if ((rc = build_chain(s, plan, rp->pd, tab, j, &level1))) return rc;
-            if ((rc = run_eval(level1, j == 1, Dv, PlaneView(), PlaneView()))) return rc;
+            if (fuse) {
+                // variables 1 and 2 are differentiated inside the kernel; j >= 3 needs its own level-2 sets
+                if (j >= 3)
+                    if ((rc = build_chain(s, plan, rp->pd, tab, j, &level1, 2))) return rc;
+                if ((rc = run_fused(level1, j == 1, j == 2, Dv, PlaneView(), PlaneView()))) return rc;
+            } else {
+                if (j >= 2)
+                    if ((rc = build_chain(s, plan, rp->pd, tab, j, &level1))) return rc;
+                if ((rc = run_eval(level1, j == 1, Dv, PlaneView(), PlaneView()))) return rc;
+            }
             PlaneView Vj = r->V;
             Vj.base += (int64_t)(j - 1) * n * Vj.pitch;
             if ((rc = launch_velocity(ctx, n, Uv, Dv, Vj, r->nk))) return rc;

@@ -307,6 +307,9 @@ struct EvalArgs {
     int64_t nlines, nk;
     int M, first, npt, deriv, herm;
     double inv_period;
+    // fused last contraction (eval_grid_fused_kernel): level-2 sets and the contracted variable
+    const double2* src2;
+    int M2, first2, deriv2, gbeg, gcnt, nseg;
 };
 
 // planes of one node at column i1 of tile `line`; with a wave-uniform line every plane row is a scalar
@@ -356,11 +359,97 @@ __device__ __forceinline__ void eval_epilogue(const EvalArgs& a, CMat<N>& H, int
 // No block-level barrier: a wave only ever reads the LDS bytes it wrote itself.
 constexpr int EVAL_MAX_MNN = 256;  // complex coefficients per line held in LDS (M * N * N)
 
+// One unit of work of the grid kernels: pass `pass` (64 KPL nodes starting at i0) of line `line`, from the
+// line's coefficients c1 (LDS).  `mid` runs between the m-loop and the stores: the place where the next
+// unit's coefficients are handed to the other LDS buffer.
+template <int N, int KPL, bool HERM, bool VEC, class MID>
+__device__ __forceinline__ void eval_unit(const EvalArgs& a, const double2* __restrict__ c1, const double2* tab_l, int fm,
+                                          const int (&iz0)[KPL], const int (&iw0)[KPL], int npass, int i0, int lane,
+                                          int64_t line, MID&& mid) {
+    double zr[KPL], zi[KPL], pr[KPL], pi[KPL];
+    CMat<N> H[KPL];
+#pragma unroll
+    for (int j = 0; j < KPL; ++j) {
+        int ic = iz0[j], iw = iw0[j];
+        if (npass > 1) {
+            const int i1 = i0 + lane + 64 * j;
+            ic = i1 < a.npt ? i1 : 0;
+            iw = (int)(((unsigned)fm * (unsigned)ic) % (unsigned)a.npt);
+        }
+        const double2 z = tab_l[ic];
+        const double2 w = tab_l[iw];
+        zr[j] = z.x;
+        zi[j] = z.y;
+        pr[j] = w.x;
+        pi[j] = w.y;
+#pragma unroll
+        for (int aa = 0; aa < N; ++aa) {
+#pragma unroll
+            for (int bb = 0; bb < N; ++bb) {
+                H[j].re[aa][bb] = 0.0;
+                H[j].im[aa][bb] = 0.0;
+            }
+        }
+    }
+    for (int m = 0; m < a.M; ++m) {
+        const double2* __restrict__ cm = c1 + m * (N * N);
+#pragma unroll
+        for (int bb = 0; bb < N; ++bb) {
+#pragma unroll
+            for (int aa = 0; aa < N; ++aa) {
+                if (HERM && aa > bb) continue;  // upper triangle only; mirrored below
+                const double2 c = cm[aa + N * bb];
+#pragma unroll
+                for (int j = 0; j < KPL; ++j) {
+                    H[j].re[aa][bb] = fma(c.x, pr[j], H[j].re[aa][bb]);
+                    H[j].re[aa][bb] = fma(-c.y, pi[j], H[j].re[aa][bb]);
+                    if (!(HERM && aa == bb)) {
+                        H[j].im[aa][bb] = fma(c.x, pi[j], H[j].im[aa][bb]);
+                        H[j].im[aa][bb] = fma(c.y, pr[j], H[j].im[aa][bb]);
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < KPL; ++j) {
+            const double nr = pr[j] * zr[j] - pi[j] * zi[j];
+            const double ni = pr[j] * zi[j] + pi[j] * zr[j];
+            pr[j] = nr;
+            pi[j] = ni;
+        }
+    }
+    mid();
+#pragma unroll
+    for (int j = 0; j < KPL; ++j) {
+        if constexpr (HERM) {
+#pragma unroll
+            for (int bb = 0; bb < N; ++bb) {
+#pragma unroll
+                for (int aa = bb + 1; aa < N; ++aa) {
+                    H[j].re[aa][bb] = H[j].re[bb][aa];
+                    H[j].im[aa][bb] = -H[j].im[bb][aa];
+                }
+            }
+        }
+        const int i1 = i0 + lane + 64 * j;
+        // columns npt..pitch-1 are padding: written (finite filler) so every 128-B line of the
+        // tile leaves the CU whole; never read back
+        const int pitch = a.H.base ? a.H.pitch : a.E.pitch;
+        if (i1 < pitch) eval_epilogue<N, VEC>(a, H[j], line, i1);
+    }
+}
+
+__device__ __forceinline__ void wave_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 template <int N, int KPL, bool HERM, bool VEC, int OCC>
 __global__ __launch_bounds__(256, OCC) void eval_grid_kernel(EvalArgs a) {
     extern __shared__ double2 lds_c[];  // [4 waves][2 buffers][MNN]
     // the wave index is made an SGPR value: every per-line quantity (tile base, coefficient row) is
-    // then scalar arithmetic and the stores use the saddr + 32-bit lane offset form
+    // then scalar arithmetic
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int MNN = a.M * N * N;
     // derivative series: coefficient m is scaled by 2 pi i (first + m) once, on its way into LDS
@@ -416,97 +505,121 @@ __global__ __launch_bounds__(256, OCC) void eval_grid_kernel(EvalArgs a) {
                 pre[t] = src[idx < MNN ? idx : MNN - 1];  // unconditional: no select waits on the data
             }
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        const double2* __restrict__ c1 = mybuf + (size_t)cur * MNN;
-        const int i0 = pass * (64 * KPL);
-        double zr[KPL], zi[KPL], pr[KPL], pi[KPL];
-        CMat<N> H[KPL];
+        wave_lds_sync();
+        eval_unit<N, KPL, HERM, VEC>(a, mybuf + (size_t)cur * MNN, tab_l, fm, iz0, iw0, npass, pass * (64 * KPL), lane, line,
+                                     [&]() {
+            // The one wait of the loop body: the fetched registers are consumed here, unconditionally and
+            // before this unit's stores are issued (the asm pins the point; nothing is hoisted above it).
 #pragma unroll
-        for (int j = 0; j < KPL; ++j) {
-            int ic = iz0[j], iw = iw0[j];
-            if (npass > 1) {
-                const int i1 = i0 + lane + 64 * j;
-                ic = i1 < a.npt ? i1 : 0;
-                iw = (int)(((unsigned)fm * (unsigned)ic) % (unsigned)a.npt);
-            }
-            const double2 z = tab_l[ic];
-            const double2 w = tab_l[iw];
-            zr[j] = z.x;
-            zi[j] = z.y;
-            pr[j] = w.x;
-            pi[j] = w.y;
+            for (int t = 0; t < EVAL_MAX_MNN / 64; ++t) asm volatile("" : "+v"(pre[t].x), "+v"(pre[t].y));
+            if (have_next) {
+                double2* dst = mybuf + (size_t)(cur ^ 1) * MNN;
 #pragma unroll
-            for (int aa = 0; aa < N; ++aa) {
-#pragma unroll
-                for (int bb = 0; bb < N; ++bb) {
-                    H[j].re[aa][bb] = 0.0;
-                    H[j].im[aa][bb] = 0.0;
+                for (int t = 0; t < EVAL_MAX_MNN / 64; ++t) {
+                    const int idx = lane + 64 * t;
+                    if (idx < MNN) dst[idx] = stage(pre[t], idx);
                 }
             }
-        }
-
-        for (int m = 0; m < a.M; ++m) {
-            const double2* __restrict__ cm = c1 + m * (N * N);
-#pragma unroll
-            for (int bb = 0; bb < N; ++bb) {
-#pragma unroll
-                for (int aa = 0; aa < N; ++aa) {
-                    if (HERM && aa > bb) continue;  // upper triangle only; mirrored below
-                    const double2 c = cm[aa + N * bb];
-#pragma unroll
-                    for (int j = 0; j < KPL; ++j) {
-                        H[j].re[aa][bb] = fma(c.x, pr[j], H[j].re[aa][bb]);
-                        H[j].re[aa][bb] = fma(-c.y, pi[j], H[j].re[aa][bb]);
-                        if (!(HERM && aa == bb)) {
-                            H[j].im[aa][bb] = fma(c.x, pi[j], H[j].im[aa][bb]);
-                            H[j].im[aa][bb] = fma(c.y, pr[j], H[j].im[aa][bb]);
-                        }
-                    }
-                }
-            }
-#pragma unroll
-            for (int j = 0; j < KPL; ++j) {
-                const double nr = pr[j] * zr[j] - pi[j] * zi[j];
-                const double ni = pr[j] * zi[j] + pi[j] * zr[j];
-                pr[j] = nr;
-                pi[j] = ni;
-            }
-        }
-        // The one wait of the loop body: the fetched registers are consumed here, unconditionally and
-        // before this unit's stores are issued (the asm pins the point; nothing is hoisted above it).
-#pragma unroll
-        for (int t = 0; t < EVAL_MAX_MNN / 64; ++t) asm volatile("" : "+v"(pre[t].x), "+v"(pre[t].y));
-        if (have_next) {
-            double2* dst = mybuf + (size_t)(cur ^ 1) * MNN;
-#pragma unroll
-            for (int t = 0; t < EVAL_MAX_MNN / 64; ++t) {
-                const int idx = lane + 64 * t;
-                if (idx < MNN) dst[idx] = stage(pre[t], idx);
-            }
-        }
-#pragma unroll
-        for (int j = 0; j < KPL; ++j) {
-            if constexpr (HERM) {
-#pragma unroll
-                for (int bb = 0; bb < N; ++bb) {
-#pragma unroll
-                    for (int aa = bb + 1; aa < N; ++aa) {
-                        H[j].re[aa][bb] = H[j].re[bb][aa];
-                        H[j].im[aa][bb] = -H[j].im[bb][aa];
-                    }
-                }
-            }
-            const int i1 = i0 + lane + 64 * j;
-            // columns npt..pitch-1 are padding: written (finite filler) so every 128-B line of the
-            // tile leaves the CU whole; never read back
-            const int pitch = a.H.base ? a.H.pitch : a.E.pitch;
-            if (i1 < pitch) eval_epilogue<N, VEC>(a, H[j], line, i1);
-        }
+        });
         cur ^= 1;
         pass = last_pass ? 0 : pass + 1;
         line = nline;
+    }
+}
+
+// The same with the LAST CONTRACTION FUSED IN: the level-1 sets c1[i2] = sum_m2 ph2[i2][m2] c2[m2] are not
+// read from HBM but computed by the wave from its block's level-2 set c2 (M2 M n^2 complex, staged in LDS
+// once per block), so the work loop holds no global load at all.  A block owns a segment of the i2 range
+// of one parent (level-2 item); wave w takes every 4th line of it.
+template <int N, int KPL, bool HERM, bool VEC, int OCC>
+__global__ __launch_bounds__(256, OCC) void eval_grid_fused_kernel(EvalArgs a) {
+    extern __shared__ double2 lds_f[];  // [M2][MNN] level-2 set | [npt] phase table | [4 waves][2][MNN]
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int MNN = a.M * N * N;
+    double2* const c2s = lds_f;
+    double2* const tab_l = c2s + (size_t)a.M2 * MNN;
+    double2* const mybuf = tab_l + a.npt + (size_t)wave * 2 * MNN;
+    int fm = a.first % a.npt;
+    if (fm < 0) fm += a.npt;
+    int fm2 = a.first2 % a.npt;
+    if (fm2 < 0) fm2 += a.npt;
+    const int npass = (a.npt + 64 * KPL - 1) / (64 * KPL);
+    const int64_t parent = blockIdx.x / a.nseg;
+    const int seg = blockIdx.x - (int)(parent * a.nseg);
+    {
+        const double2* __restrict__ src2 = a.src2 + parent * ((int64_t)a.M2 * MNN);
+        for (int i = threadIdx.x; i < a.M2 * MNN; i += 256) c2s[i] = src2[i];
+        for (int i = threadIdx.x; i < a.npt; i += 256) tab_l[i] = a.tab[i];
+    }
+    __syncthreads();
+    const int lo = a.gbeg + (int)(((int64_t)a.gcnt * seg) / a.nseg);
+    const int hi = a.gbeg + (int)(((int64_t)a.gcnt * (seg + 1)) / a.nseg);
+    // c1 of grid index i2 into dst: lane t-th elements idx = lane + 64 t
+    auto contract_line = [&](int i2, double2* dst) {
+        unsigned ip = (unsigned)(((unsigned)fm2 * (unsigned)i2) % (unsigned)a.npt);
+        double accr[EVAL_MAX_MNN / 64], acci[EVAL_MAX_MNN / 64];
+#pragma unroll
+        for (int t = 0; t < EVAL_MAX_MNN / 64; ++t) {
+            accr[t] = 0.0;
+            acci[t] = 0.0;
+        }
+        for (int m2 = 0; m2 < a.M2; ++m2) {
+            double2 ph = tab_l[ip];
+            if (a.deriv2) {
+                const double f = 6.283185307179586476925286766559 * (double)(a.first2 + m2);
+                ph = make_double2(-f * ph.y, f * ph.x);
+            }
+            const double2* __restrict__ row = c2s + (size_t)m2 * MNN;
+#pragma unroll
+            for (int t = 0; t < EVAL_MAX_MNN / 64; ++t) {
+                if (64 * t < MNN) {  // uniform
+                    const int idx = lane + 64 * t;
+                    const double2 c = row[idx < MNN ? idx : MNN - 1];
+                    accr[t] = fma(c.x, ph.x, accr[t]);
+                    accr[t] = fma(-c.y, ph.y, accr[t]);
+                    acci[t] = fma(c.x, ph.y, acci[t]);
+                    acci[t] = fma(c.y, ph.x, acci[t]);
+                }
+            }
+            ip += (unsigned)i2;
+            if (ip >= (unsigned)a.npt) ip -= (unsigned)a.npt;
+        }
+#pragma unroll
+        for (int t = 0; t < EVAL_MAX_MNN / 64; ++t) {
+            const int idx = lane + 64 * t;
+            if (idx < MNN) {
+                double2 v = make_double2(accr[t], acci[t]);
+                if (a.deriv) {
+                    const double f = 6.283185307179586476925286766559 * (double)(a.first + idx / (N * N));
+                    v = make_double2(-f * v.y, f * v.x);
+                }
+                dst[idx] = v;
+            }
+        }
+    };
+    int i2 = lo + wave;
+    if (i2 >= hi) return;
+    contract_line(i2, mybuf);
+    int iz0[KPL], iw0[KPL];
+#pragma unroll
+    for (int j = 0; j < KPL; ++j) {
+        const int i1 = lane + 64 * j;
+        iz0[j] = i1 < a.npt ? i1 : 0;
+        iw0[j] = (int)(((unsigned)fm * (unsigned)iz0[j]) % (unsigned)a.npt);
+    }
+    int cur = 0, pass = 0;
+    while (i2 < hi) {
+        const bool last_pass = pass + 1 >= npass;
+        const int ni2 = last_pass ? i2 + 4 : i2;
+        const int64_t line = parent * a.gcnt + (i2 - a.gbeg);
+        wave_lds_sync();
+        eval_unit<N, KPL, HERM, VEC>(a, mybuf + (size_t)cur * MNN, tab_l, fm, iz0, iw0, npass, pass * (64 * KPL), lane, line,
+                                     [] {});
+        // after the stores are issued: the next line's contraction overlaps their drain
+        if (last_pass && ni2 < hi) contract_line(ni2, mybuf + (size_t)(cur ^ 1) * MNN);
+        if (last_pass) cur ^= 1;
+        pass = last_pass ? 0 : pass + 1;
+        i2 = ni2;
     }
 }
 
@@ -574,6 +687,19 @@ __global__ __launch_bounds__(256) void eval_node_kernel(EvalArgs a) {
             return ABZ_ERR_UNSUPPORTED;                             \
     }
 
+// Can the last contraction (variable 2, M2 coefficients) be fused into the grid kernel?  The level-2 set
+// must fit in LDS beside the phase table and the wave buffers (three blocks per CU).
+bool eval_can_fuse(int n, int M, int M2, int npt) {
+    // Opt-in (ABZ_FUSE2=1, read per call so that bench.py can time both variants in one process): the fused
+    // kernel saves one launch and the 36 MB round trip of the level-1 sets but carries ~7 % more work;
+    // measured 3-9 % faster per rebuild depending on the box, with a lower roofline fraction of its own.
+    const char* e = getenv("ABZ_FUSE2");
+    if (!(e && e[0] == '1') || n > 4) return false;
+    const int mnn = M * n * n;
+    const size_t lds = sizeof(double2) * ((size_t)M2 * mnn + (size_t)npt + 4 * 2 * (size_t)mnn);
+    return mnn <= EVAL_MAX_MNN && npt < 65536 && lds <= 48 * 1024;
+}
+
 static int eval_occ() {
     static int occ = [] {
         const char* e = getenv("ABZ_EVAL_OCC");
@@ -633,10 +759,17 @@ int launch_eval(abz_ctx* ctx, const EvalSpec& es) {
     a.deriv = es.deriv ? 1 : 0;
     a.herm = (es.herm && !es.deriv) ? 1 : 0;
     a.inv_period = 1.0 / es.period;
+    a.src2 = es.src2;
+    a.M2 = es.M2;
+    a.first2 = es.first2;
+    a.deriv2 = es.deriv2 ? 1 : 0;
+    a.gbeg = es.gbeg;
+    a.gcnt = es.gcnt;
+    a.nseg = 1;
     ProfScope ps(ctx, ABZ_K_EVAL);
     if (es.grid) {
         if (es.nlines == 0) return ABZ_OK;
-        const int64_t blocks = std::min<int64_t>(cdiv(es.nlines, 4), 256 * 8);
+        int64_t blocks = std::min<int64_t>(cdiv(es.nlines, 4), 256 * 8);
         const int mnn = es.M * es.n * es.n;
         // nodes per lane: minimise lane-rounds per line, ceil(npt / (64 kpl)) * kpl, weighted by the LDS
         // operand reads that are shared by the kpl nodes of a lane (200 points: 2 x 2 rounds, not 2 x 3)
@@ -652,8 +785,43 @@ int launch_eval(abz_ctx* ctx, const EvalSpec& es) {
             }
         }
         // + an LDS copy of the phase table (fm * i1 < npt^2 must fit 32 bits)
-        const size_t lds = sizeof(double2) * (4 * 2 * (size_t)mnn + (size_t)a.npt);
-        if (mnn <= EVAL_MAX_MNN && lds <= 64 * 1024 && a.npt < 65536) {
+        size_t lds = sizeof(double2) * (4 * 2 * (size_t)mnn + (size_t)a.npt);
+        if (es.src2) {  // fused last contraction: caller checked eval_can_fuse()
+            lds += sizeof(double2) * (size_t)es.M2 * mnn;
+            // segments of the i2 range per parent: enough blocks to fill the chip, >= 2 lines per wave
+            const int64_t nparents = es.nlines / std::max(es.gcnt, 1);
+            // two waves of resident blocks (3 per CU) measured best; each wave of a block gets >= 2 lines
+            static const int target = [] { const char* e = getenv("ABZ_FUSE_BLOCKS"); return e ? atoi(e) : 1536; }();
+            int64_t nseg = std::max<int64_t>(1, target / std::max<int64_t>(nparents, 1));
+            nseg = std::max<int64_t>(1, std::min<int64_t>(nseg, cdiv(es.gcnt, 8)));
+            a.nseg = (int)nseg;
+            blocks = nparents * nseg;
+#define LKF(NN, KK, OO)                                                                                                          \
+    if (a.U.base)                                                                                                                \
+        hipLaunchKernelGGL((eval_grid_fused_kernel<NN, KK, false, true, 2>), dim3((unsigned)blocks), dim3(256), lds, ctx->stream, a);  \
+    else if (a.herm)                                                                                                             \
+        hipLaunchKernelGGL((eval_grid_fused_kernel<NN, KK, true, false, OO>), dim3((unsigned)blocks), dim3(256), lds, ctx->stream, a); \
+    else                                                                                                                         \
+        hipLaunchKernelGGL((eval_grid_fused_kernel<NN, KK, false, false, 2>), dim3((unsigned)blocks), dim3(256), lds, ctx->stream, a);
+#define LK(NN, KK)                         \
+    if (NN == 3 && eval_occ() == 3) {      \
+        LKF(NN, KK, 3)                     \
+    } else if (NN == 3 && eval_occ() == 4) { \
+        LKF(NN, KK, 4)                     \
+    } else {                               \
+        LKF(NN, KK, 2)                     \
+    }
+#define FN(NN)                    \
+    switch (kpl) {                \
+        case 1: LK(NN, 1) break;  \
+        case 2: LK(NN, 2) break;  \
+        default: LK(NN, 3) break; \
+    }
+            ABZ_DISPATCH_N(es.n, FN)
+#undef FN
+#undef LK
+#undef LKF
+        } else if (mnn <= EVAL_MAX_MNN && lds <= 64 * 1024 && a.npt < 65536) {
 #define LKO(NN, KK, OO)                                                                                                        \
     if (a.U.base)                                                                                                              \
         hipLaunchKernelGGL((eval_grid_kernel<NN, KK, false, true, 2>), dim3((unsigned)blocks), dim3(256), lds, ctx->stream, a);  \

@@ -167,6 +167,30 @@ def main():
     eval_ms, eval_n = ctx.prof_read(L.K_EVAL)
     ctx.prof_enable(False)
 
+    # the same rebuild with the last contraction fused into the Fourier-eval kernel (ABZ_FUSE2=1, opt-in):
+    # one launch and 36 MB of HBM round trip less, ~7 % more work inside the kernel (not the primary number)
+    two = None
+    if world == 1:
+        os.environ["ABZ_FUSE2"] = "1"
+        for _ in range(max(a.warmup, 1)):
+            rule.rebuild()
+        ctx.sync()
+        ctx.prof_enable(True, kernels=[L.K_EVAL])
+        ctx.prof_reset()
+        t0 = time.perf_counter()
+        for _ in range(a.steps):
+            rule.rebuild()
+        ctx.sync()
+        t2 = time.perf_counter() - t0
+        ms2, n2 = ctx.prof_read(L.K_EVAL)
+        ctx.prof_enable(False)
+        del os.environ["ABZ_FUSE2"]
+        rule.rebuild()
+        ctx.sync()
+        two = {"ms_per_step": 1e3 * t2 / a.steps, "eval_kernel_avg_ms": ms2 / max(n2, 1),
+               "frac": nk * 168 / ((ms2 / max(n2, 1)) * 1e-3) / 1e9 / 8000.0 if n2 else None,
+               "note": "opt-in variant ABZ_FUSE2=1: contract x1 + eval_grid_fused_kernel (level-1 sets never leave the CU)"}
+
     # ---------------- Phase B: K fused sweeps over this rank's omegas (matrix-cached, reference-faithful)
     for _ in range(max(1, a.warmup // 2)):
         rule.reduce(L.F_DOS, [a.eta], mine)
@@ -244,6 +268,7 @@ def main():
                          "kernel": "eval_grid_kernel<3> (Fourier-eval + fused eig)",
                          "algorithmic_bytes_per_kpoint": 16 * n * n + 8 * n,
                          "avg_launch_ms": eval_ms / max(eval_n, 1), "launches": eval_n,
+                         "fused_contraction_variant": two,
                          "contract_avg_ms": con_ms / max(con_n, 1),
                          "reduce_avg_ms": red_ms / max(red_n, 1),
                          # Hermitian rule: the scan reads the upper triangle only, n^2 doubles per k-point

@@ -426,6 +426,34 @@ def test_kshard_partial_rules_sum_to_the_full_rule(abz, svo):
         assert solver(12.5) == solver(12.5)
 
 
+@pytest.mark.parametrize("d,n,npt", [(2, 2, 17), (3, 3, 10), (3, 1, 70), (3, 4, 6)])
+def test_fused_last_contraction_variant(abz, d, n, npt):
+    """ABZ_FUSE2=1 (opt-in): the level-1 sets are contracted inside the grid kernel instead of by their own
+    kernel.  Same values up to the rounding of a different summation order, incl. eigenvalues, velocities
+    (derivative factors on variables 1, 2 and 3) and slabs."""
+    rng = np.random.default_rng(900 + 10 * d + n)
+    c, first = rand_series(rng, (3, 5, 3)[:d], n, hermitian=True)
+    s, _ = both(abz, c, first)
+    dev = s.device()
+    L = abz._lib
+    want = L.WANT_H | L.WANT_EIG | L.WANT_VEL
+    ref = abz.DeviceRule(dev, npt, None, want).export(x=False, w=False, H=True, eig=True, vel=True)
+    os.environ["ABZ_FUSE2"] = "1"
+    try:
+        got = abz.DeviceRule(dev, npt, None, want).export(x=False, w=False, H=True, eig=True, vel=True)
+        dev.kshard, dev.allreduce = (1, 3), (lambda a: a)
+        slab = abz.DeviceRule(dev, npt, None, L.WANT_H).export(x=True, w=False, H=True)
+    finally:
+        del os.environ["ABZ_FUSE2"]
+        dev.kshard, dev.allreduce = None, None
+    scale = np.abs(ref["H"]).max()
+    for key, tol in (("H", 1e-13), ("eig", 1e-12), ("vel", 1e-10)):
+        assert np.abs(got[key] - ref[key]).max() <= tol * scale * (10 if key == "vel" else 1), key
+    z0, z1 = (npt * 1) // 3, (npt * 2) // 3
+    lo, hi = z0 * npt ** (d - 1), z1 * npt ** (d - 1)
+    assert np.abs(slab["H"] - ref["H"][lo:hi]).max() <= 1e-13 * scale and abs(slab["x"][0, d - 1] - z0 / npt) < 1e-15
+
+
 # ------------------------------------------------------------------ generic n (wave-per-node kernels)
 @pytest.mark.parametrize("d,n", [(1, 5), (2, 8), (3, 6), (3, 16)])
 def test_generic_n_eval_and_rules(abz, d, n):
