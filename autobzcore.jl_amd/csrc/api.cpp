@@ -665,7 +665,9 @@ static int rule_build(abz_series* s, int npt, int64_t nirr, const int32_t* irr_i
     RULE_TRY(make_phase_table(ctx, npt, rp->tab));
     const size_t bytes = sizeof(double) * (size_t)(r->ntiles * tile);
     RULE_HIP(hipMalloc((void**)&r->vals, bytes));
-    RULE_HIP(hipMemset(r->vals, 0, bytes));  // padding of irregular tiles stays finite
+    // on the context's stream: it is non-blocking, a null-stream memset would not be ordered before the
+    // fill kernels below (and could land on top of their results)
+    RULE_HIP(hipMemsetAsync(r->vals, 0, bytes, ctx->stream));  // padding of irregular tiles stays finite
     if (getenv("ABZ_DEBUG_ALLOC")) fprintf(stderr, "[abz] rule values %p (%zu bytes)\n", (void*)r->vals, bytes);
     auto mkview = [&](int plane0, bool present) {
         PlaneView v;

@@ -619,7 +619,10 @@ int abz_contract_nodes(abz_series* s, int src_level, const int64_t* parents, con
         DevBuf bigger;
         int rc = bigger.reserve(need * 2);
         if (rc) return rc;
-        ABZ_HIP(hipMemcpy(bigger.p, pool.p, sizeof(double2) * (size_t)(base * Lrow), hipMemcpyDeviceToDevice));
+        // on the context's (non-blocking) stream, and complete before the old pool is freed
+        ABZ_HIP(hipMemcpyAsync(bigger.p, pool.p, sizeof(double2) * (size_t)(base * Lrow), hipMemcpyDeviceToDevice,
+                               s->ctx->stream));
+        ABZ_HIP(hipStreamSynchronize(s->ctx->stream));
         pool.release();
         pool = bigger;
     }
