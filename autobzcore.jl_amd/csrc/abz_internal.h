@@ -148,7 +148,8 @@ int launch_contract(abz_ctx* ctx, const double2* src, int64_t src_slot_elems, co
 // full-grid contraction: out[(parent*npt + gi)][l], parents 0..nparents-1, all gi, phases from tab
 constexpr int ABZ_CONTRACT_GRID_MAXM = 16;
 int launch_contract_grid(abz_ctx* ctx, const double2* src, int64_t src_slot_elems, int64_t nparents, const double2* tab,
-                         double2* out, int64_t L, int M, int first, int npt, bool deriv, int gbeg, int gcnt);
+                         double2* out, int64_t L, int M, int first, int npt, bool deriv, int gbeg, int gcnt,
+                         const double2* phs_table = nullptr);  // phs_table [npt][M]: scalar-phase kernel (no derivative)
 
 struct EvalSpec {
     int n;              // bands

@@ -188,11 +188,13 @@ static void plan_runs(Plan& p, int d, int npt, const T* pts, int64_t nk, bool co
 
 struct PlanDev {
     DevBuf gi[ABZ_MAX_DIM + 1], xs[ABZ_MAX_DIM + 1], parent[ABZ_MAX_DIM + 1];
+    DevBuf phg[ABZ_MAX_DIM + 1];  // full grids: phase table [npt][M_{L+1}] of the contraction at level L
     void release() {
         for (int i = 0; i <= ABZ_MAX_DIM; ++i) {
             gi[i].release();
             xs[i].release();
             parent[i].release();
+            phg[i].release();
         }
     }
 };
@@ -234,7 +236,7 @@ static int build_chain(abz_series* s, const Plan& p, const PlanDev& pd, const do
         const int gcnt = (p.full && L == d - 1) ? p.outer_n : p.npt;
         if (p.full && M <= ABZ_CONTRACT_GRID_MAXM && gcnt > 0 && B / gcnt <= 65535) {
             rc = launch_contract_grid(ctx, src, src_elems, B / gcnt, tab, out, Lrow, M, s->first[L], p.npt,
-                                      deriv_dim == L + 1, gbeg, gcnt);
+                                      deriv_dim == L + 1, gbeg, gcnt, pd.phg[L].p ? pd.phg[L].as<double2>() : nullptr);
             if (rc) return rc;
         } else {
             rc = ctx->scratch[0].reserve(sizeof(double2) * (size_t)std::max<int64_t>(B * M, 1));
@@ -663,6 +665,25 @@ static int rule_build(abz_series* s, int npt, int64_t nirr, const int32_t* irr_i
     const int64_t tile = (int64_t)r->planes * pitch;
     RULE_TRY(plan_upload(ctx, plan, rp->pd));
     RULE_TRY(make_phase_table(ctx, npt, rp->tab));
+    if (r->full) {  // per-level phase tables [npt][M] for the scalar-phase contraction kernel
+        for (int L = 1; L < d; ++L) {
+            const int M = s->dims[L];
+            RULE_TRY(rp->pd.phg[L].reserve(sizeof(double2) * (size_t)npt * M));
+            PhaseSpec ps;
+            ps.B = npt;
+            ps.M = M;
+            ps.first = s->first[L];
+            ps.gi = nullptr;
+            ps.x = nullptr;
+            ps.tab = rp->tab.as<double2>();
+            ps.npt = npt;
+            ps.g0 = 0;
+            ps.gcnt = npt;
+            ps.period = s->period[L];
+            ps.deriv = false;
+            RULE_TRY(launch_phases(ctx, ps, rp->pd.phg[L].as<double2>()));
+        }
+    }
     const size_t bytes = sizeof(double) * (size_t)(r->ntiles * tile);
     RULE_HIP(hipMalloc((void**)&r->vals, bytes));
     // on the context's stream: it is non-blocking, a null-stream memset would not be ordered before the

@@ -197,18 +197,67 @@ __global__ __launch_bounds__(128) void contract_grid_kernel(const double2* __res
     }
 }
 
+// The same with the phases read as SCALARS from a per-level table phs[gi][m] (global memory, wave-uniform
+// address -> s_load through the scalar cache, SGPR operands of v_fma_f64).  The LDS-phase kernel above is
+// bound by LDS bandwidth: a broadcast ds_read_b128 still costs 64 lanes x 16 B of the LDS pipe for 4 FMAs
+// per lane (18.8 us for the 36 MB level-1 sets of the 150^3 SVO grid); here the phases cost no vector or
+// LDS cycles at all.
+template <int M>  // exact coefficient count: straight-line loads, no per-m branches
+__global__ __launch_bounds__(128) void contract_grid_s_kernel(const double2* __restrict__ src, int64_t slot_elems,
+                                                              const double2* __restrict__ phs, double2* __restrict__ out,
+                                                              int64_t L, int chunk, int gbeg, int gcnt) {
+    const int64_t l = (int64_t)blockIdx.x * 128 + threadIdx.x;
+    if (l >= L) return;
+    const int64_t parent = blockIdx.y;
+    const int g0 = gbeg + blockIdx.z * chunk;
+    const int g1 = min(gbeg + gcnt, g0 + chunk);
+    double2 c[M];
+#pragma unroll
+    for (int m = 0; m < M; ++m) c[m] = src[parent * slot_elems + (int64_t)m * L + l];
+    for (int gi = g0; gi < g1; ++gi) {
+        cptr_t p = as_const(phs + (int64_t)gi * M);
+        double ar = 0.0, ai = 0.0;
+#pragma unroll
+        for (int m = 0; m < M; ++m) {
+            const double px = p[m].x, py = p[m].y;  // scalar loads
+            ar = fma(c[m].x, px, ar);
+            ar = fma(-c[m].y, py, ar);
+            ai = fma(c[m].x, py, ai);
+            ai = fma(c[m].y, px, ai);
+        }
+        out[(parent * gcnt + (gi - gbeg)) * L + l] = make_double2(ar, ai);
+    }
+}
+
 int launch_contract_grid(abz_ctx* ctx, const double2* src, int64_t src_slot_elems, int64_t nparents, const double2* tab,
-                         double2* out, int64_t L, int M, int first, int npt, bool deriv, int gbeg, int gcnt) {
+                         double2* out, int64_t L, int M, int first, int npt, bool deriv, int gbeg, int gcnt,
+                         const double2* phs_table) {
     if (nparents == 0 || L == 0 || gcnt == 0) return ABZ_OK;
     ProfScope ps(ctx, ABZ_K_CONTRACT);
     const int64_t gx = cdiv(L, 128);
     // enough blocks to fill the chip, at least ~4 grid indices per thread to amortise the loads
-    int64_t nsplit = std::max<int64_t>(1, std::min<int64_t>(cdiv(gcnt, 4), cdiv(4096, gx * nparents)));
+    static const int target_blocks = [] { const char* e = getenv("ABZ_CONTRACT_BLOCKS"); return e ? atoi(e) : 4096; }();
+    int64_t nsplit = std::max<int64_t>(1, std::min<int64_t>(cdiv(gcnt, 4), cdiv(target_blocks, gx * nparents)));
     const int chunk = (int)cdiv(gcnt, nsplit);
     nsplit = cdiv(gcnt, chunk);
     if (nparents > 65535 || nsplit > 65535) {
         set_error("contract_grid: grid too large");
         return ABZ_ERR_UNSUPPORTED;
+    }
+    static const bool scalar_ok = [] { const char* e = getenv("ABZ_CONTRACT_SCALAR"); return !(e && e[0] == '0'); }();
+    if (phs_table && !deriv && scalar_ok) {
+#define CS(MM)                                                                                                         \
+    case MM:                                                                                                           \
+        hipLaunchKernelGGL(contract_grid_s_kernel<MM>, dim3((unsigned)gx, (unsigned)nparents, (unsigned)nsplit), dim3(128), 0, \
+                           ctx->stream, src, src_slot_elems, phs_table, out, L, chunk, gbeg, gcnt);                    \
+        break;
+        switch (M) {
+            CS(1) CS(2) CS(3) CS(4) CS(5) CS(6) CS(7) CS(8) CS(9) CS(10) CS(11) CS(12) CS(13) CS(14) CS(15) CS(16)
+            default: set_error("contract_grid: M = %d", M); return ABZ_ERR_UNSUPPORTED;
+        }
+#undef CS
+        ABZ_HIP(hipGetLastError());
+        return ABZ_OK;
     }
     hipLaunchKernelGGL(contract_grid_kernel, dim3((unsigned)gx, (unsigned)nparents, (unsigned)nsplit), dim3(128),
                        sizeof(double2) * (size_t)chunk * M, ctx->stream, src, src_slot_elems, tab, out, L, M, first, npt,
