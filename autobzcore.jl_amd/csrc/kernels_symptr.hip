@@ -11,6 +11,7 @@ namespace abz {
 
 struct SymArgs {
     int npt, d, nsyms;
+    int small;  // every |S v| < 2^31: 32-bit arithmetic (a 64-bit modulo costs ~4x more)
     int64_t N;
     int S[48 * 9];  // up to 48 symmetries of a 3-d lattice, row-major
 };
@@ -18,10 +19,19 @@ struct SymArgs {
 __device__ __forceinline__ int64_t sym_image(const SymArgs& a, const int* v, int s) {
     int64_t img = 0, mul = 1;
     for (int r = 0; r < a.d; ++r) {
-        int64_t t = 0;
-        for (int c = 0; c < a.d; ++c) t += (int64_t)a.S[(s * a.d + r) * a.d + c] * v[c];
-        t %= a.npt;
-        if (t < 0) t += a.npt;
+        int64_t t;
+        if (a.small) {
+            int t32 = 0;
+            for (int c = 0; c < a.d; ++c) t32 += a.S[(s * a.d + r) * a.d + c] * v[c];
+            t32 %= a.npt;
+            if (t32 < 0) t32 += a.npt;
+            t = t32;
+        } else {
+            t = 0;
+            for (int c = 0; c < a.d; ++c) t += (int64_t)a.S[(s * a.d + r) * a.d + c] * v[c];
+            t %= a.npt;
+            if (t < 0) t += a.npt;
+        }
         img += t * mul;
         mul *= a.npt;
     }
@@ -99,7 +109,12 @@ int symptr_device(abz_ctx* ctx, int npt, int d, const int32_t* syms, int nsyms, 
     a.nsyms = nsyms;
     a.N = 1;
     for (int j = 0; j < d; ++j) a.N *= npt;
-    for (int i = 0; i < nsyms * d * d; ++i) a.S[i] = syms[i];
+    int64_t smax = 1;
+    for (int i = 0; i < nsyms * d * d; ++i) {
+        a.S[i] = syms[i];
+        smax = std::max<int64_t>(smax, std::llabs((long long)syms[i]));
+    }
+    a.small = (smax * d * (int64_t)npt < ((int64_t)1 << 30)) ? 1 : 0;
     const int64_t nb = (a.N + 255) / 256;
     DevBuf flag, counts, offs, didx, dw;
     int rc;
