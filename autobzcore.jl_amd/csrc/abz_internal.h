@@ -244,6 +244,7 @@ struct InnerSpec {
     double params[4];
     double sweep;
     const double* sweep_arr = nullptr;  // device [nint]: per-integral sweep value (overrides `sweep`)
+    bool herm = false;  // the series is Hermitian: upper-triangle series, real characteristic polynomial
     bool has_rtol;
     double rtol_user;
     int64_t maxevals;
@@ -253,7 +254,7 @@ struct InnerSpec {
     int* status_out;         // device [nint]: 0 ok, 1 = segment store overflow (redo on the host)
 };
 constexpr int ABZ_INNER_MAXSEG = 48;
-bool inner_adaptive_supported(int n, int integrand);
+bool inner_adaptive_supported(int n, int M, int integrand);
 int launch_inner_adaptive(abz_ctx* ctx, const InnerSpec& is);
 bool gen_inner_supported(int n, int M, int integrand);  // n > 4: one wavefront per 1-D integral
 bool gen_inner_panel_supported(int n, int M, int integrand);  // n > 4: one workgroup per 1-D integral, set in LDS

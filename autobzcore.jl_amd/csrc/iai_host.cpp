@@ -287,6 +287,7 @@ int IaiDriver::solve_inner_device(std::vector<Quad1D>& kids) {
     for (int i = 0; i < 4; ++i) is.params[i] = params[i];
     is.sweep = sweep;
     is.sweep_arr = d_sw;
+    is.herm = s->hermitian;
     is.has_rtol = has_rtol;
     is.rtol_user = rtol_user;
     is.maxevals = maxevals;
@@ -547,7 +548,7 @@ int abz_iai_solve_many(abz_series* s, int lims_kind, const double* lim_a, const 
         // and stays opt-in (ABZ_IAI_DEVICE_INNER=2)
         const bool ok = s->n > 4 ? (gen_inner_panel_supported(s->n, s->dims[0], integrand) ||
                                     (gen_inner_supported(s->n, s->dims[0], integrand) && e && e[0] == '2'))
-                                 : inner_adaptive_supported(s->n, integrand);
+                                 : inner_adaptive_supported(s->n, s->dims[0], integrand);
         drv.device_inner = max_batch <= 0 && s->d >= 2 && ok && !(e && e[0] == '0');
     }
     // one top-level integral per sweep value; they advance in lock-step like any other siblings

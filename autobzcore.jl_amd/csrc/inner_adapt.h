@@ -43,6 +43,9 @@ __device__ __forceinline__ void adapt_init(AdaptState& st, double at, bool has_r
 
 // Consumes the values of the pending panels (vals: [30][nc]), updates the heap and either schedules the
 // next bisection in ctl (returns false) or writes the result (returns true).
+// REGS: scalar integrands pull the panel values into registers first (worth it where the caller has the
+// registers to spare: the n <= 4 kernel; the generic-n kernels keep their rows in registers instead).
+template <bool REGS = false>
 __device__ inline bool adapt_step(AdaptState& st, int nc, double* seg_a, double* seg_b, double* seg_E, gkc* seg_I,
                                   const gkc* vals, int* heap, double* ctl, long long maxevals, const InnerOut& out) {
     constexpr int MS = ABZ_INNER_MAXSEG;
@@ -60,12 +63,26 @@ __device__ inline bool adapt_step(AdaptState& st, int nc, double* seg_a, double*
         }
         newseg[pnl] = sl;
     }
+    // scalar integrands: pull the panel values into registers with back-to-back LDS reads first -- the rule
+    // below is executed by ONE lane, and reads interleaved with the stores of its results would each pay
+    // the full LDS latency
+    gkc rv[30];
+    const bool fast = REGS && nc == 1;
+    if (fast) {
+#pragma unroll
+        for (int i = 0; i < 30; ++i) rv[i] = vals[i < 15 * np ? i : 0];
+    }
     if (st.first) {
         st.first = false;
         const int sl = newseg[0];
         seg_a[sl] = ctl[1];
         seg_b[sl] = ctl[2];
-        seg_E[sl] = gk15_rule(vals, nc, seg_a[sl], seg_b[sl], seg_I + (size_t)sl * nc);
+        if (fast) {
+            gkc I1;
+            seg_E[sl] = gk15_rule(rv, 1, ctl[1], ctl[2], &I1);
+            seg_I[sl] = I1;
+        } else
+            seg_E[sl] = gk15_rule(vals, nc, seg_a[sl], seg_b[sl], seg_I + (size_t)sl * nc);
         for (int c = 0; c < nc; ++c) {
             st.Ir[c] = seg_I[(size_t)sl * nc + c].re;
             st.Ii[c] = seg_I[(size_t)sl * nc + c].im;
@@ -88,8 +105,18 @@ __device__ inline bool adapt_step(AdaptState& st, int nc, double* seg_a, double*
         seg_b[s1] = ctl[2];
         seg_a[s2] = ctl[3];
         seg_b[s2] = ctl[4];
-        seg_E[s1] = gk15_rule(vals, nc, seg_a[s1], seg_b[s1], seg_I + (size_t)s1 * nc);
-        seg_E[s2] = gk15_rule(vals + (size_t)15 * nc, nc, seg_a[s2], seg_b[s2], seg_I + (size_t)s2 * nc);
+        if (fast) {
+            gkc I1, I2;
+            const double E1 = gk15_rule(rv, 1, ctl[1], ctl[2], &I1);
+            const double E2 = gk15_rule(rv + 15, 1, ctl[3], ctl[4], &I2);
+            seg_I[s1] = I1;
+            seg_I[s2] = I2;
+            seg_E[s1] = E1;
+            seg_E[s2] = E2;
+        } else {
+            seg_E[s1] = gk15_rule(vals, nc, seg_a[s1], seg_b[s1], seg_I + (size_t)s1 * nc);
+            seg_E[s2] = gk15_rule(vals + (size_t)15 * nc, nc, seg_a[s2], seg_b[s2], seg_I + (size_t)s2 * nc);
+        }
         {
 #pragma clang fp contract(off)
             for (int c = 0; c < nc; ++c) {

@@ -1709,6 +1709,56 @@ int launch_node_integrand(abz_ctx* ctx, const NodeEvalSpec& ns, double2* values_
 // ------------------------------------------------------------------------------------------
 // IAI innermost level on the device: adaptive GK(7,15) per 1-D integral, one half-wave each
 // ------------------------------------------------------------------------------------------
+// H = sum_m c1[m] (w z^m) with the coefficient set in LDS (every lane of a group reads the same address);
+// HERM: upper triangle only, mirrored.
+template <int N, bool HERM>
+__device__ __forceinline__ void series_lane_lds(const double2* c1, int M, double zr, double zi, double wr, double wi,
+                                                CMat<N>& H) {
+#pragma unroll
+    for (int a = 0; a < N; ++a) {
+#pragma unroll
+        for (int b = 0; b < N; ++b) {
+            H.re[a][b] = 0.0;
+            H.im[a][b] = 0.0;
+        }
+    }
+    double pr = wr, pi = wi;
+    for (int m = 0; m < M; ++m) {
+        const double2* cm = c1 + m * (N * N);
+#pragma unroll
+        for (int b = 0; b < N; ++b) {
+#pragma unroll
+            for (int a = 0; a < N; ++a) {
+                if (HERM && a > b) continue;
+                const double2 c = cm[a + N * b];
+                H.re[a][b] = fma(c.x, pr, H.re[a][b]);
+                H.re[a][b] = fma(-c.y, pi, H.re[a][b]);
+                if (!(HERM && a == b)) {
+                    H.im[a][b] = fma(c.x, pi, H.im[a][b]);
+                    H.im[a][b] = fma(c.y, pr, H.im[a][b]);
+                }
+            }
+        }
+        const double nr = pr * zr - pi * zi;
+        const double ni = pr * zi + pi * zr;
+        pr = nr;
+        pi = ni;
+    }
+    if constexpr (HERM) {
+#pragma unroll
+        for (int b = 0; b < N; ++b) {
+#pragma unroll
+            for (int a = b + 1; a < N; ++a) {
+                H.re[a][b] = H.re[b][a];
+                H.im[a][b] = -H.im[b][a];
+            }
+        }
+    }
+}
+
+// LDS doubles of one integral of inner_adaptive_kernel: the adaptive state + its coefficient set
+__host__ __device__ inline int inner_group_stride(int ncomp, int mnn) { return inner_group_doubles(ncomp) + 2 * mnn; }
+
 struct InnerArgs {
     const double2* src;
     const int64_t* slot;
@@ -1727,13 +1777,15 @@ struct InnerArgs {
     int* status_out;
 };
 
-template <int N, int FID>
+template <int N, int FID, bool HERM>
 __global__ __launch_bounds__(256) void inner_adaptive_kernel(InnerArgs a) {
     extern __shared__ double lds_in[];
     constexpr int MS = ABZ_INNER_MAXSEG;
     const int group = threadIdx.x >> 5, l = threadIdx.x & 31;
     const int nc = a.ncomp;
-    double* g = lds_in + (size_t)group * inner_group_doubles(nc);
+    const int MNN = a.M * N * N;
+    double* g = lds_in + (size_t)group * inner_group_stride(nc, MNN);
+    double2* const cl = reinterpret_cast<double2*>(g + inner_group_doubles(nc));  // this integral's coefficients
     double* seg_a = g;
     double* seg_b = seg_a + MS;
     double* seg_E = seg_b + MS;
@@ -1748,12 +1800,13 @@ __global__ __launch_bounds__(256) void inner_adaptive_kernel(InnerArgs a) {
         // ---- lane 0 state
         AdaptState st;
         bool done = !live;
-        cptr_t c1 = as_const(a.src);
         double tailv[ABZ_MAX_DIM] = {0.0, 0.0, 0.0};
         double swq = a.sweep;
         if (live) {
             if (a.sweep_arr) swq = a.sweep_arr[q];
-            c1 = as_const(a.src + a.slot[q] * ((int64_t)a.M * N * N));
+            // the set stays in LDS for the whole adaptive loop (the nodes of every round re-read it)
+            const double2* __restrict__ src = a.src + a.slot[q] * (int64_t)MNN;
+            for (int idx = l; idx < MNN; idx += 32) cl[idx] = src[idx];
             if (FID == ABZ_F_LINEAR_X && a.tail)
                 for (int j = 0; j < a.d - 1; ++j) tailv[j] = a.tail[q * (a.d - 1) + j];
             if (l == 0) adapt_init(st, a.atol[q], a.has_rtol != 0, a.rtol_user, a.lo[q], a.hi[q], ctl);
@@ -1778,7 +1831,7 @@ __global__ __launch_bounds__(256) void inner_adaptive_kernel(InnerArgs a) {
                     sincospi(2.0 * xx, &zi, &zr);
                     sincospi(2.0 * ((double)a.first * xx), &wi, &wr);
                     CMat<N> H;
-                    series_lane<N>(c1, a.M, a.first, zr, zi, wr, wi, false, H);
+                    series_lane_lds<N, HERM>(cl, a.M, zr, zi, wr, wi, H);
                     double e[N];
                     if constexpr (FID == ABZ_F_DOS_EIG) {
                         if constexpr (N == 3) {
@@ -1790,7 +1843,21 @@ __global__ __launch_bounds__(256) void inner_adaptive_kernel(InnerArgs a) {
                     }
                     double xk[ABZ_MAX_DIM] = {x, tailv[0], tailv[1]};
                     double vr[MAXC], vi[MAXC];
-                    integrand_value<N, FID>(H, e, xk, a.d, a.p, swq, vr, vi);
+                    if constexpr (HERM && (N == 2 || N == 3) && (FID == ABZ_F_DOS || FID == ABZ_F_TRGLOC)) {
+                        // Hermitian H: resolvent trace from the real characteristic polynomial
+                        CharPolyH cp;
+                        if constexpr (N == 3)
+                            charpoly_init_h3(H.re[0][0], H.re[1][1], H.re[2][2], H.re[0][1], H.im[0][1], H.re[0][2], H.im[0][2],
+                                             H.re[1][2], H.im[1][2], cp);
+                        else
+                            charpoly_init_h2(H.re[0][0], H.re[1][1], H.re[0][1], H.im[0][1], cp);
+                        double tr, ti;
+                        charpoly_trace_h<N, true>(cp, swq, a.p[0], a.p[0] * a.p[0], 2.0 * a.p[0], tr, ti);
+                        vr[0] = (FID == ABZ_F_DOS) ? -ti * 0.31830988618379067153776752674503 : tr;
+                        vi[0] = (FID == ABZ_F_DOS) ? 0.0 : ti;
+                    } else {
+                        integrand_value<N, FID>(H, e, xk, a.d, a.p, swq, vr, vi);
+                    }
                     constexpr int NC = NComp<FID>::template value<N>();
 #pragma unroll
                     for (int c = 0; c < NC; ++c) {
@@ -1810,15 +1877,17 @@ __global__ __launch_bounds__(256) void inner_adaptive_kernel(InnerArgs a) {
                 out.E = a.E_out + q;
                 out.nev = a.nev_out + q;
                 out.status = a.status_out + q;
-                done = adapt_step(st, nc, seg_a, seg_b, seg_E, seg_I, vals, heap, ctl, a.maxevals, out);
+                done = adapt_step<true>(st, nc, seg_a, seg_b, seg_E, seg_I, vals, heap, ctl, a.maxevals, out);
             }
         }
     }
 }
 
-bool inner_adaptive_supported(int n, int integrand) {
+bool inner_adaptive_supported(int n, int M, int integrand) {
     const int nc = integrand_ncomp(integrand, n, 3);
-    return n >= 1 && n <= 4 && nc > 0 && nc <= MAXC && sizeof(double) * (size_t)inner_group_doubles(nc) * 8 <= 150 * 1024;
+    // + the coefficient set of every integral in flight
+    return n >= 1 && n <= 4 && nc > 0 && nc <= MAXC && M * n * n <= EVAL_MAX_MNN &&
+           sizeof(double) * (size_t)inner_group_stride(nc, M * n * n) * 8 <= 150 * 1024;
 }
 
 int launch_inner_adaptive(abz_ctx* ctx, const InnerSpec& is) {
@@ -1856,14 +1925,25 @@ int launch_inner_adaptive(abz_ctx* ctx, const InnerSpec& is) {
     a.nev_out = is.nev_out;
     a.status_out = is.status_out;
     ProfScope ps(ctx, ABZ_K_EVAL);
-    const size_t lds = sizeof(double) * (size_t)inner_group_doubles(ncomp) * 8;
+    const int mnn = is.M * is.n * is.n;
+    if (mnn > EVAL_MAX_MNN) {
+        set_error("inner adaptive kernel: %d coefficients per line exceed the LDS budget", mnn);
+        return ABZ_ERR_UNSUPPORTED;
+    }
+    const size_t lds = sizeof(double) * (size_t)inner_group_stride(ncomp, mnn) * 8;
     const unsigned blocks = (unsigned)std::min<int64_t>(cdiv(is.nint, 8), 256 * 16);
-#define LAUNCH_INNER(NN, FID)                                                                                         \
+#define LAUNCH_INNER2(NN, FID, HH)                                                                                    \
     {                                                                                                                 \
         if (lds > 48 * 1024)                                                                                          \
-            ABZ_HIP(hipFuncSetAttribute((const void*)inner_adaptive_kernel<NN, FID>,                                  \
+            ABZ_HIP(hipFuncSetAttribute((const void*)inner_adaptive_kernel<NN, FID, HH>,                              \
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                       \
-        hipLaunchKernelGGL((inner_adaptive_kernel<NN, FID>), dim3(blocks), dim3(256), lds, ctx->stream, a);           \
+        hipLaunchKernelGGL((inner_adaptive_kernel<NN, FID, HH>), dim3(blocks), dim3(256), lds, ctx->stream, a);       \
+    }
+#define LAUNCH_INNER(NN, FID)             \
+    if (is.herm) {                        \
+        LAUNCH_INNER2(NN, FID, true)      \
+    } else {                              \
+        LAUNCH_INNER2(NN, FID, false)     \
     }
 #define CASE(FID)                                                                                                     \
     case FID:                                                                                                         \
@@ -1886,6 +1966,7 @@ int launch_inner_adaptive(abz_ctx* ctx, const InnerSpec& is) {
     }
 #undef CASE
 #undef LAUNCH_INNER
+#undef LAUNCH_INNER2
     ABZ_HIP(hipGetLastError());
     return ABZ_OK;
 }
