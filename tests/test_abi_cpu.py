@@ -158,3 +158,30 @@ def test_synthetic_models_match_the_oracle_recipe():
         a, b = orc.synthetic_wannier(**kw), abz.synthetic_wannier(**kw)
         assert np.array_equal(a.c, b.c) and tuple(np.atleast_1d(b.first)) == tuple(np.atleast_1d(a.first))
     assert np.array_equal(orc.tb_integer(3, 1.5).c, abz.tb_integer(3, 1.5).c)
+
+
+def test_sweep_archive_layout_and_partial_flush(tmp_path):
+    """ref: ext/HDF5Ext.jl:123-158 -- data sets I, E, t, retcode, numevals, args/<j>, kwargs/<name>; the
+    archive on disk always holds every chunk finished so far."""
+    import autobzcore.jl_amd as abz
+    from autobzcore.jl_amd.solver import IntegralSolution
+    path = tmp_path / "sweep.npz"
+    seen = []
+
+    def fake_batchsolve(solver, part, callback=None):  # stands in for the fused device sweep
+        vals = []
+        for i, p in enumerate(part):
+            sol = IntegralSolution(p.args[0] ** 2 + 1j * p.kwargs["b"], 1e-4, True, 15)
+            callback(solver, (i,), i + 1, p, sol, 0.01)
+            vals.append(sol.u)
+        if path.exists():
+            seen.append(int(abz.SweepArchive.load(path)["done"].sum()))
+        return np.array(vals)
+
+    ps = [abz.MixedParameters(float(w), b=0.5 * k) for k, w in enumerate(np.linspace(0, 1, 10))]
+    out = abz.batchsolve_archive(path, None, ps, chunk=4, solve=fake_batchsolve)
+    z = abz.SweepArchive.load(path)
+    assert seen == [4, 8]  # after chunks 1 and 2, before the last one
+    assert z["done"].all() and np.array_equal(z["I"], out) and np.array_equal(z["numevals"], np.full(10, 15))
+    assert np.allclose(z["args/1"], np.linspace(0, 1, 10)) and np.allclose(z["kwargs/b"], 0.5 * np.arange(10))
+    assert np.allclose(z["E"], 1e-4) and z["retcode"].dtype == np.int32 and np.all(z["retcode"] == 1)

@@ -454,6 +454,19 @@ def test_fused_last_contraction_variant(abz, d, n, npt):
     assert np.abs(slab["H"] - ref["H"][lo:hi]).max() <= 1e-13 * scale and abs(slab["x"][0, d - 1] - z0 / npt) < 1e-15
 
 
+def test_batchsolve_archive_matches_batchsolve(abz, svo, tmp_path):
+    """ref: ext/HDF5Ext.jl:123-158 (sweep output with partial-result persistence)."""
+    s, _ = svo
+    bz = abz.load_bz(abz.CubicSymIBZ(), 3.85856 * np.eye(3))
+    solver = abz.IntegralSolver(abz.FourierIntegrand(abz.DOSIntegrand(), s, 0.1), bz, abz.EvalCounter(abz.PTR(npt=24)))
+    om = np.linspace(11.5, 13.5, 9)
+    ref = abz.batchsolve(solver, om)
+    out = abz.batchsolve_archive(tmp_path / "sweep.npz", solver, om, chunk=4)
+    z = abz.SweepArchive.load(tmp_path / "sweep.npz")
+    assert np.array_equal(out, ref) and np.array_equal(z["I"], ref) and z["done"].all()
+    assert np.allclose(z["args/1"], om) and np.all(z["numevals"] == z["numevals"][0]) and z["numevals"][0] > 0
+
+
 # ------------------------------------------------------------------ generic n (wave-per-node kernels)
 @pytest.mark.parametrize("d,n", [(1, 5), (2, 8), (3, 6), (3, 16)])
 def test_generic_n_eval_and_rules(abz, d, n):
