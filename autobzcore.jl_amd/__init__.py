@@ -22,6 +22,7 @@ from .solver import (IAI, PTR, TAI, AutoPTR, AutoSymPTRJL, AuxQuadGKJL, BatchInt
                      EvalCounter, FourierIntegrand, FourierValue, GlocIntegrand, IntegralProblem, IntegralSolution,
                      IntegralSolver, LinearIntegrand, LinearXIntegrand, MixedParameters, MonkhorstPack, NestedBatchIntegrand, NestedQuad,
                      NullParameters, ParameterIntegrand, TrGlocIntegrand, UnitIntegrand, batchparam, batchsolve,
-                     do_solve, init, paramproduct, paramzip, solve, solve_)
+                     do_solve, init, paramproduct, paramzip, solve, solve_,
+                     AbstractSymRep, TrivialRep, UnknownRep, MatrixRep, SymRep, symmetrize)
 
 __all__ = [n for n in dir() if not n.startswith("_")]

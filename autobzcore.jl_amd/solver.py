@@ -137,7 +137,15 @@ class DeviceIntegrand:
     argnames = ()
     nparams = 0      # leading args that are fixed parameters
     swept = False    # last arg is the swept parameter (omega)
-    matrix = False   # value is a matrix/vector (UnknownRep under symmetries)
+    matrix = False   # value is a matrix/vector (UnknownRep under symmetries unless `symrep` is set)
+    symrep = None    # an AbstractSymRep: how the integral maps from the IBZ to the full BZ (SymRep(f))
+
+    def with_symrep(self, rep):
+        """The same integrand with a symmetry representation attached (the reference's `SymRep(f)` trait)."""
+        import copy
+        g = copy.copy(self)
+        g.symrep = rep
+        return g
 
     def bind(self, p: MixedParameters):
         vals = list(p.args)
@@ -479,13 +487,64 @@ def _ptr_rule_values(f: FourierIntegrand, dev, npt, syms, plist):
     return out, rule.nk
 
 
-def _symmetrize(f, bz, x):
-    """TrivialRep for numbers: nsyms * x; unknown for arrays.  ref: src/brillouin.jl:96-114."""
-    return nsyms(bz) * x
+class AbstractSymRep:
+    """ref: src/brillouin.jl:48-58.  A representation maps the integral over the irreducible domain to
+    the integral over the full BZ: `symmetrize_(bz, x)`."""
+
+
+class TrivialRep(AbstractSymRep):
+    """ref: src/brillouin.jl:67-71,106."""
+
+    def symmetrize_(self, bz, x):
+        return nsyms(bz) * x
+
+
+class UnknownRep(AbstractSymRep):
+    """ref: src/brillouin.jl:60-65,107 -- the solve is repeated on the full BZ."""
+
+    def symmetrize_(self, bz, x):
+        return x
+
+
+class MatrixRep(AbstractSymRep):
+    """A user-defined representation (the reference's extension point `SymRep(f)` + `symmetrize_`,
+    src/brillouin.jl:73-108) for matrix-valued integrals whose integrand transforms as
+    f(S k) = D_S f(k) D_S^dagger: x_FBZ = sum_S D_S x_IBZ D_S^dagger, `reps[i]` belonging to `bz.syms[i]`."""
+
+    def __init__(self, reps):
+        self.reps = [np.asarray(D) for D in reps]
+
+    def symmetrize_(self, bz, x):
+        if len(self.reps) != nsyms(bz):
+            raise ValueError("MatrixRep needs one matrix per symmetry of the BZ")
+        x = np.asarray(x)
+        return sum(D @ x @ D.conj().T for D in self.reps)
+
+
+def SymRep(f):
+    """Representation of the integral of f: its `symrep` attribute, else UnknownRep.  ref: src/brillouin.jl:85."""
+    return getattr(f, "symrep", None) or UnknownRep()
 
 
 def _is_trivial(u):
     return np.ndim(u) == 0
+
+
+def symmetrize(f, bz, x):
+    """ref: src/brillouin.jl:96-114: numbers are TrivialRep, a full BZ maps x to itself."""
+    if bz.syms is None:
+        return x
+    if _is_trivial(x):
+        return nsyms(bz) * x
+    return (f if isinstance(f, AbstractSymRep) else SymRep(f)).symmetrize_(bz, x)
+
+
+_symmetrize_value = symmetrize  # (keyword arguments named `symmetrize` shadow the function below)
+
+
+def _needs_fbz(f, bz, u):
+    """An array-valued integral on a symmetric BZ without a known representation."""
+    return bz.syms is not None and not _is_trivial(u) and isinstance(SymRep(f.f.f), UnknownRep)
 
 
 def _redo_on_fbz(f, bz, p, alg, kws):
@@ -577,9 +636,9 @@ def do_solve(f, dom, p, alg, cacheval=None, abstol=None, reltol=None, maxiters=2
         if isinstance(alg, PTR):
             vals, nev = _ptr_rule_values(f, dev, alg.npt, bz.syms, [pm])
             u = vals[0]
-            if bz.syms is not None and not _is_trivial(u):
+            if _needs_fbz(f, bz, u):
                 return _redo_on_fbz(f, bz, p, EvalCounter(alg) if counter else alg, kws)
-            return IntegralSolution(j * ns * u, None, True, nev if counter else -1)
+            return IntegralSolution(j * symmetrize(fi, bz, u), None, True, nev if counter else -1)
         if isinstance(alg, AutoPTR):
             sols = _autoptr_many(f, dev, bz, [pm], alg, abstol, reltol, maxiters)
             s = sols[0]
@@ -595,9 +654,9 @@ def do_solve(f, dom, p, alg, cacheval=None, abstol=None, reltol=None, maxiters=2
             else:
                 u, err, nev = _iai_host(f, dev, bz.lims, pm, at, reltol, maxiters)
                 extra = {}
-            if bz.syms is not None and not _is_trivial(u):
+            if _needs_fbz(f, bz, u):
                 return _redo_on_fbz(f, bz, p, EvalCounter(alg) if counter else alg, kws)
-            sol = IntegralSolution(j * ns * u, j * ns * err, True, nev if counter else -1)
+            sol = IntegralSolution(j * symmetrize(fi, bz, u), j * ns * err, True, nev if counter else -1)
             sol.extra = extra
             return sol
         raise ValueError(f"unsupported BZ algorithm {type(alg).__name__}")
@@ -649,11 +708,12 @@ def _autoptr_many(f, dev, bz, plist, alg: AutoPTR, abstol, reltol, maxiters, sym
     n0, dn = alg.npt_sequence()
     npt = n0
     active = list(range(len(plist)))
+    sym = (lambda v: _symmetrize_value(f.f.f, bz, v)) if symmetrize else (lambda v: v)
     I1, nev1 = _ptr_rule_values(f, dev, npt, bz.syms, plist)
-    I1 = [ns * v for v in I1]
-    numevals = [nev1] * len(plist)
-    if bz.syms is not None and symmetrize and not _is_trivial(I1[0]):
+    if symmetrize and _needs_fbz(f, bz, I1[0]):
         return [None] * len(plist)
+    I1 = [sym(v) for v in I1]
+    numevals = [nev1] * len(plist)
     out = [None] * len(plist)
     I2 = list(I1)
     err = [math.inf] * len(plist)
@@ -665,7 +725,7 @@ def _autoptr_many(f, dev, bz, plist, alg: AutoPTR, abstol, reltol, maxiters, sym
         for v, i in zip(vals, active):
             if not first:
                 I1[i] = I2[i]
-            I2[i] = ns * v
+            I2[i] = sym(v)
             numevals[i] += nev
             err[i] = norm(np.asarray(I2[i]) - np.asarray(I1[i]))
             if err[i] <= max(atol, rtol * norm(I2[i])) or numevals[i] >= maxiters or not np.isfinite(err[i]):
@@ -762,14 +822,14 @@ def batchsolve(solver: IntegralSolver, ps, nthreads=1, callback=None):
             j = abs(np.linalg.det(bz.B))
             jn = j * nsyms(bz)
             res = _iai_device_many(f, dev, bz.lims, plist, None if abstol is None else abstol / jn, reltol, maxiters)
-            sols = [IntegralSolution(jn * u, jn * e, True, nev) for u, e, nev, _ in res]
-            if bz.syms is not None and not _is_trivial(res[0][0]):
+            sols = [IntegralSolution(j * symmetrize(f.f.f, bz, u), jn * e, True, nev) for u, e, nev, _ in res]
+            if _needs_fbz(f, bz, res[0][0]):
                 sols = None
         elif isinstance(inner, PTR):
             j = abs(np.linalg.det(bz.B))
             vals, nev = _ptr_rule_values(f, dev, inner.npt, bz.syms, plist)
-            sols = [IntegralSolution(j * nsyms(bz) * v, None, True, nev) for v in vals]
-            if bz.syms is not None and not _is_trivial(vals[0]):
+            sols = [IntegralSolution(j * symmetrize(f.f.f, bz, v), None, True, nev) for v in vals]
+            if _needs_fbz(f, bz, vals[0]):
                 sols = None
         else:
             sols = _autoptr_many(f, dev, bz, plist, inner, abstol, reltol, maxiters)

@@ -467,6 +467,34 @@ def test_batchsolve_archive_matches_batchsolve(abz, svo, tmp_path):
     assert np.allclose(z["args/1"], om) and np.all(z["numevals"] == z["numevals"][0]) and z["numevals"][0] > 0
 
 
+def test_symrep_extension_point_matrix_valued_on_the_ibz(abz):
+    """ref: src/brillouin.jl:73-108 (`SymRep(f)` + `symmetrize_`).  H(k) = diag(cos kx, cos ky) + t (cos kx + cos ky) s_x
+    obeys H(S k) = D_S H(k) D_S^T with D_S = s_x for the symmetries that swap the axes, 1 otherwise; with that
+    representation attached the Green's function integrated over the IBZ maps to the full-BZ result, for
+    PTR, AutoPTR and IAI; without it the solve is repeated on the full BZ (UnknownRep) with a warning."""
+    sx = np.array([[0.0, 1.0], [1.0, 0.0]])
+    c = np.zeros((3, 3, 2, 2), dtype=np.complex128)
+    for (i, j), M in (((0, 1), np.diag([0.5, 0.0]) + 0.15 * sx), ((2, 1), np.diag([0.5, 0.0]) + 0.15 * sx),
+                      ((1, 0), np.diag([0.0, 0.5]) + 0.15 * sx), ((1, 2), np.diag([0.0, 0.5]) + 0.15 * sx)):
+        c[i, j] = M
+    s = abz.FourierSeries(c, period=1.0, first=(-1, -1), ndim=2)
+    ibz = abz.load_bz(abz.CubicSymIBZ(), np.eye(2))
+    fbz = abz.load_bz(abz.FBZ(), np.eye(2))
+    reps = [sx if S[0, 0] == 0 else np.eye(2) for S in ibz.syms]
+    g = abz.GlocIntegrand().with_symrep(abz.MatrixRep(reps))
+    for alg, kw in ((abz.PTR(npt=24), {}), (abz.AutoPTR(), dict(abstol=1e-6)), (abz.IAI(), dict(abstol=1e-6))):
+        ref = abz.IntegralSolver(abz.FourierIntegrand(abz.GlocIntegrand(), s, 0.3), fbz, alg, **kw)(0.2)
+        got = abz.IntegralSolver(abz.FourierIntegrand(g, s, 0.3), ibz, alg, **kw)(0.2)
+        assert np.abs(got - ref).max() <= 1e-5 * np.abs(ref).max(), type(alg).__name__
+        assert abs(got[0, 1]) > 1e-3  # the off-diagonal element is not zero: the test sees the representation
+    with pytest.warns(UserWarning):
+        red = abz.IntegralSolver(abz.FourierIntegrand(abz.GlocIntegrand(), s, 0.3), ibz, abz.PTR(npt=24))(0.2)
+    ref = abz.IntegralSolver(abz.FourierIntegrand(abz.GlocIntegrand(), s, 0.3), fbz, abz.PTR(npt=24))(0.2)
+    assert np.abs(red - ref).max() <= 1e-12 * np.abs(ref).max()
+    swp = abz.batchsolve(abz.IntegralSolver(abz.FourierIntegrand(g, s, 0.3), ibz, abz.PTR(npt=24)), [0.2, 0.5])
+    assert np.abs(swp[0] - ref).max() <= 1e-12 * np.abs(ref).max()
+
+
 # ------------------------------------------------------------------ generic n (wave-per-node kernels)
 @pytest.mark.parametrize("d,n", [(1, 5), (2, 8), (3, 6), (3, 16)])
 def test_generic_n_eval_and_rules(abz, d, n):
