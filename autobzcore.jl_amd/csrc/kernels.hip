@@ -17,6 +17,7 @@
 #include "inner_adapt.h"
 
 #include <cmath>
+#include <type_traits>
 #include <cstdlib>
 
 namespace abz {
@@ -355,6 +356,7 @@ struct EvalArgs {
     PlaneView H, E, U;
     int64_t nlines, nk;
     int M, first, npt, deriv, herm;
+    int nt;  // non-temporal stores (rule values larger than the Infinity Cache)
     double inv_period;
     // fused last contraction (eval_grid_fused_kernel): level-2 sets and the contracted variable
     const double2* src2;
@@ -362,8 +364,16 @@ struct EvalArgs {
 };
 
 // planes of one node at column i1 of tile `line`; with a wave-uniform line every plane row is a scalar
-// base and the lane offset i1 is the same 32-bit register for all of them (saddr stores)
-template <int N>
+// base and the lane offset i1 is the same 32-bit register for all of them.  NT: non-temporal stores
+// (streaming: the values are not re-read by this kernel and a large rule does not fit the caches anyway).
+template <bool NT>
+__device__ __forceinline__ void store_f64(double* p, double v) {
+    if constexpr (NT)
+        __builtin_nontemporal_store(v, p);
+    else
+        *p = v;
+}
+template <int N, bool NT = false>
 __device__ __forceinline__ void store_planes_at(const CMat<N>& H, const PlaneView& v, int64_t line, int i1) {
     double* __restrict__ row = v.base + line * v.tile;
     const unsigned u = (unsigned)i1;
@@ -371,8 +381,8 @@ __device__ __forceinline__ void store_planes_at(const CMat<N>& H, const PlaneVie
     for (int b = 0; b < N; ++b) {
 #pragma unroll
         for (int a = 0; a < N; ++a) {
-            (row + (int64_t)(2 * (a + N * b)) * v.pitch)[u] = H.re[a][b];
-            (row + (int64_t)(2 * (a + N * b) + 1) * v.pitch)[u] = H.im[a][b];
+            store_f64<NT>((row + (int64_t)(2 * (a + N * b)) * v.pitch) + u, H.re[a][b]);
+            store_f64<NT>((row + (int64_t)(2 * (a + N * b) + 1) * v.pitch) + u, H.im[a][b]);
         }
     }
 }
@@ -480,11 +490,53 @@ __device__ __forceinline__ void eval_unit(const EvalArgs& a, const double2* __re
                 }
             }
         }
-        const int i1 = i0 + lane + 64 * j;
+        if constexpr (VEC) {
+            const int i1 = i0 + lane + 64 * j;
+            const int pitch = a.H.base ? a.H.pitch : a.E.pitch;
+            if (i1 < pitch) eval_epilogue<N, VEC>(a, H[j], line, i1);
+        }
+    }
+    if constexpr (!VEC) {
         // columns npt..pitch-1 are padding: written (finite filler) so every 128-B line of the
-        // tile leaves the CU whole; never read back
+        // tile leaves the CU whole; never read back.
+        // Order: ALL H(k) stores of the unit first, then the eigensolves (they overlap the drain of those
+        // stores), then the eigenvalue stores.  With non-temporal stores on rules larger than the Infinity
+        // Cache this is worth 19 % at 150^3 (neither change alone is: the interleaved order leaves the
+        // store queue empty during every eigensolve, and temporal stores make the 605 MB fight for L2/MALL).
         const int pitch = a.H.base ? a.H.pitch : a.E.pitch;
-        if (i1 < pitch) eval_epilogue<N, VEC>(a, H[j], line, i1);
+        auto epilogue = [&](auto nt) {
+            constexpr bool NT = decltype(nt)::value;
+            if (a.H.base) {
+#pragma unroll
+                for (int j = 0; j < KPL; ++j) {
+                    const int i1 = i0 + lane + 64 * j;
+                    if (i1 < pitch) store_planes_at<N, NT>(H[j], a.H, line, i1);
+                }
+            }
+            if (a.E.base) {
+#pragma unroll
+                for (int j = 0; j < KPL; ++j) {
+                    const int i1 = i0 + lane + 64 * j;
+                    if (i1 < pitch) {
+                        double e[N];
+                        if constexpr (N == 3) {
+                            herm_eig3_values(H[j], e);
+                        } else {
+                            CMat<N> V;
+                            herm_eig<N, false>(H[j], e, V);
+                        }
+                        double* __restrict__ row = a.E.base + line * a.E.tile;
+                        const unsigned u = (unsigned)i1;
+#pragma unroll
+                        for (int b = 0; b < N; ++b) store_f64<NT>((row + (int64_t)b * a.E.pitch) + u, e[b]);
+                    }
+                }
+            }
+        };
+        if (a.nt)
+            epilogue(std::true_type{});
+        else
+            epilogue(std::false_type{});
     }
 }
 
@@ -808,6 +860,14 @@ int launch_eval(abz_ctx* ctx, const EvalSpec& es) {
     a.deriv = es.deriv ? 1 : 0;
     a.herm = (es.herm && !es.deriv) ? 1 : 0;
     a.inv_period = 1.0 / es.period;
+    {
+        // streaming stores once the values written by this launch exceed the 256 MB Infinity Cache
+        // (npt = 100, 168 MB: 7 % slower with them; 150, 605 MB: 19 % faster)
+        static const int force = [] { const char* e = getenv("ABZ_NT_STORES"); return e ? atoi(e) : -1; }();
+        const PlaneView& pv = es.H.base ? es.H : es.E;
+        const double bytes = 8.0 * (double)pv.tile * (double)(es.grid ? es.nlines : (es.nk + 63) / 64);
+        a.nt = force >= 0 ? force : (bytes > 256.0 * 1024 * 1024 ? 1 : 0);
+    }
     a.src2 = es.src2;
     a.M2 = es.M2;
     a.first2 = es.first2;
