@@ -7,7 +7,7 @@ fallback: without the built library and a gfx950 device the compute calls raise.
 """
 from . import _lib
 from ._lib import AbzError, Context
-from .bz import (FBZ, IBZ, Basis, CubicLimits, CubicSymIBZ, HyperCube, InversionSymIBZ, PuncturedInterval,
+from .bz import (FBZ, IBZ, Basis, CubicLimits, CubicSymIBZ, HyperCube, InversionSymIBZ, PolygonLimits, PolyhedralLimits, PuncturedInterval,
                  SymmetricBZ, TetrahedralLimits, canonical_reciprocal_basis, load_bz, nsyms)
 from .dos import DOSProblem, DOSSolution, GGR
 from . import dos

@@ -25,12 +25,21 @@ class CubicLimits:
     def __eq__(self, o):
         return isinstance(o, CubicLimits) and np.array_equal(self.a, o.a) and np.array_equal(self.b, o.b)
 
+    # iterated-limits protocol (IteratedIntegration.segments / fixandeliminate): break points of the
+    # outermost variable, and the limits of the remaining ones once it is fixed
+    def segs(self):
+        return (float(self.a[-1]), float(self.b[-1]))
+
+    def fix(self, x):
+        return CubicLimits(self.a[:-1], self.b[:-1])
+
 
 @dataclass
 class TetrahedralLimits:
     """0 <= x_1 <= ... <= x_d <= a_d (scaled).  ref: src/brillouin.jl:304."""
 
     a: np.ndarray
+    s: float = 1.0  # scale left by the variables fixed so far
 
     def __post_init__(self):
         self.a = np.atleast_1d(np.asarray(self.a, dtype=np.float64))
@@ -40,7 +49,123 @@ class TetrahedralLimits:
         return len(self.a)
 
     def __eq__(self, o):
-        return isinstance(o, TetrahedralLimits) and np.array_equal(self.a, o.a)
+        return isinstance(o, TetrahedralLimits) and np.array_equal(self.a, o.a) and self.s == o.s
+
+    def segs(self):
+        return (0.0, float(self.a[-1]) * self.s)
+
+    def fix(self, x):
+        return TetrahedralLimits(self.a[:-1], x / float(self.a[-1]))
+
+
+def _unique_sorted(vals):
+    """Distinct coordinates (sqrt(eps) tolerances, first occurrence kept), ascending.
+    ref: get_segs, ext/SymmetryReduceBZExt.jl:15-31."""
+    tol = float(np.sqrt(np.finfo(float).eps))
+    uniq = []
+    for v in vals:
+        if not any(abs(v - u) <= max(tol, tol * max(abs(v), abs(u))) for u in uniq):
+            uniq.append(float(v))
+    return tuple(sorted(uniq))
+
+
+class PolygonLimits:
+    """Convex polygon in (x, y): verts [nv, 2] in order around the boundary (IAI over a 2-D zone, and the
+    z-slices of PolyhedralLimits).  ref: Polygon2, ext/SymmetryReduceBZExt.jl:43-59."""
+
+    def __init__(self, verts):
+        self.verts = np.ascontiguousarray(np.asarray(verts, dtype=np.float64).reshape(-1, 2))
+
+    @property
+    def ndim(self):
+        return 2
+
+    def segs(self):
+        return _unique_sorted(self.verts[:, 1])
+
+    def packed(self):
+        return self.verts.reshape(-1).copy()
+
+    def fix(self, y):
+        v, nv = self.verts, len(self.verts)
+        hits = []
+        for j in range(nv):
+            y1, y2 = v[j, 1], v[(j + 1) % nv, 1]
+            if (y1 < y and y2 > y) or (y1 > y and y2 < y) or y1 == y:
+                t = (y - y1) / (y2 - y1) if y2 != y1 else 0.0
+                hits.append(t * v[(j + 1) % nv, 0] + (1 - t) * v[j, 0])
+                if len(hits) == 2:
+                    break
+        if not hits:
+            raise ValueError("could not find intersection with polygon")
+        return CubicLimits(np.array([min(hits)]), np.array([max(hits)]))
+
+
+class PolyhedralLimits:
+    """Convex polyhedron in (x, y, z) by its faces (each [nv, 3], vertices in order around the face, shared
+    vertices bit-identical) -- the irreducible Brillouin zone of a general lattice, in the coordinates of
+    the reciprocal basis.  ref: Polyhedron3, ext/SymmetryReduceBZExt.jl:33-58, ext/ibzlims.jl:198-243."""
+
+    def __init__(self, faces):
+        self.faces = [np.ascontiguousarray(np.asarray(f, dtype=np.float64).reshape(-1, 3)) for f in faces]
+
+    @classmethod
+    def from_vertices(cls, vertices):
+        """Faces of the convex hull of `vertices` (coplanar hull triangles merged, vertices ordered around
+        each face), like get_uniquefacets of the reference's SymmetryReduceBZ extension."""
+        from scipy.spatial import ConvexHull
+        V = np.asarray(vertices, dtype=np.float64)
+        hull = ConvexHull(V)
+        groups = []  # (unit normal with offset, set of vertex indices)
+        for eq, simp in zip(hull.equations, hull.simplices):
+            for g in groups:
+                if np.allclose(g[0], eq, atol=1e-9):
+                    g[1].update(int(i) for i in simp)
+                    break
+            else:
+                groups.append((eq, set(int(i) for i in simp)))
+        faces = []
+        for eq, idx in groups:
+            idx = sorted(idx)
+            P = V[idx]
+            nrm = eq[:3]
+            c = P.mean(axis=0)
+            u = P[0] - c
+            u = u / np.linalg.norm(u)
+            w = np.cross(nrm, u)
+            ang = np.arctan2((P - c) @ w, (P - c) @ u)
+            faces.append(P[np.argsort(ang, kind="stable")])
+        return cls(faces)
+
+    @property
+    def ndim(self):
+        return 3
+
+    def segs(self):
+        return _unique_sorted(np.concatenate([f[:, 2] for f in self.faces]))
+
+    def packed(self):
+        return np.concatenate([np.concatenate([[float(len(f))], f.reshape(-1)]) for f in self.faces])
+
+    def fix(self, z):
+        pts = []
+        for face in self.faces:
+            nv = len(face)
+            for j in range(nv):
+                p1, p2 = face[j], face[(j + 1) % nv]
+                z1, z2 = p1[2], p2[2]
+                if ((z1 <= z and z2 >= z) or (z1 >= z and z2 <= z)) and z2 != z1:
+                    t = (z - z1) / (z2 - z1)
+                    q = (t * p2[0] + (1 - t) * p1[0], t * p2[1] + (1 - t) * p1[1])
+                    if q not in pts:
+                        pts.append(q)
+        P = np.array(pts)
+        c = P.mean(axis=0)
+        return PolygonLimits(P[np.argsort(np.arctan2(P[:, 1] - c[1], P[:, 0] - c[0]), kind="stable")])
+
+    def volume(self):
+        from scipy.spatial import ConvexHull
+        return float(ConvexHull(np.concatenate(self.faces)).volume)
 
 
 @dataclass
@@ -110,7 +235,10 @@ class CubicSymIBZ(AbstractBZ):
 
 
 class IBZ(AbstractBZ):
-    """ref: src/brillouin.jl:220-244 -- needs SymmetryReduceBZ (out of the hot-path scope)."""
+    """ref: src/brillouin.jl:220-244.  The reference computes the zone with SymmetryReduceBZ.jl from the
+    crystal structure (ext/SymmetryReduceBZExt.jl:85-123); that geometry package is outside this build, so
+    the irreducible zone is given explicitly: `load_bz(IBZ(), A, hull=vertices, syms=point_group)` with the
+    vertices of the convex zone and the point-group operations, both in the reciprocal-lattice basis."""
 
 
 def canonical_reciprocal_basis(A):
@@ -140,7 +268,7 @@ def cube_automorphisms(d):
     return [S @ P for P in permutation_matrices(d) for S in sign_flip_matrices(d)]
 
 
-def load_bz(bz: AbstractBZ, A=None, B=None, atol=None) -> SymmetricBZ:
+def load_bz(bz: AbstractBZ, A=None, B=None, atol=None, hull=None, syms=None) -> SymmetricBZ:
     """ref: src/brillouin.jl:179-212,264-307; `A` may be the path of a Wannier90 `seedname.wout`
     (ext/WannierIOExt.jl:12-17, default atol 1e-5 for the printed 6-digit lattice)."""
     if isinstance(A, (str, bytes)) or hasattr(A, "__fspath__"):
@@ -178,5 +306,16 @@ def load_bz(bz: AbstractBZ, A=None, B=None, atol=None) -> SymmetricBZ:
             warnings.warn("Non-orthogonal lattice vectors detected with CubicSymIBZ. Unexpected behavior may occur")
         return SymmetricBZ(A, B, TetrahedralLimits(np.full(d, 0.5)), cube_automorphisms(d))
     if isinstance(bz, IBZ):
-        raise NotImplementedError("SymmetryReduceBZ extension not loaded (IBZ is outside the hot-path scope)")
+        if hull is None or syms is None:
+            raise NotImplementedError("IBZ(): SymmetryReduceBZ is not part of this build -- pass the zone explicitly: "
+                                      "load_bz(IBZ(), A, hull=vertices, syms=point_group)")
+        V = np.asarray(hull, dtype=np.float64)
+        if V.ndim != 2 or V.shape[1] != d or d not in (2, 3):
+            raise ValueError("hull: [nv, d] vertices of the irreducible zone, d = 2 or 3")
+        if d == 3:
+            lims = PolyhedralLimits.from_vertices(V)
+        else:
+            from scipy.spatial import ConvexHull
+            lims = PolygonLimits(V[ConvexHull(V).vertices])  # counter-clockwise
+        return SymmetricBZ(A, B, lims, [np.asarray(S) for S in syms])
     raise TypeError(f"unknown BZ kind {bz!r}")

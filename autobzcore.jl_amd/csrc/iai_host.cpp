@@ -11,6 +11,7 @@
 #include <algorithm>
 #include <cmath>
 #include <complex>
+#include <memory>
 #include <cstdlib>
 #include <cstring>
 #include <vector>
@@ -36,22 +37,131 @@ struct Seg {
     int64_t ioff;  // offset of I[ncomp] in the owner's value store
 };
 
+// Break points of a polytope along one coordinate: the distinct vertex coordinates (sqrt(eps)
+// tolerances, first occurrence kept), ascending.  ref: get_segs, ext/SymmetryReduceBZExt.jl:15-31.
+static void unique_sorted(const std::vector<double>& vals, std::vector<double>& out) {
+    const double tol = 1.4901161193847656e-08;
+    out.clear();
+    for (double v : vals) {
+        bool dup = false;
+        for (double u : out)
+            if (std::fabs(v - u) <= std::max(tol, tol * std::max(std::fabs(v), std::fabs(u)))) {
+                dup = true;
+                break;
+            }
+        if (!dup) out.push_back(v);
+    }
+    std::sort(out.begin(), out.end());
+}
+
+// Iterated limits.  CUBIC / TETRAHEDRAL: closed forms.  POLYHEDRAL (3 variables): convex polyhedron by its
+// faces, packed [nv, x y z * nv] per face; fixing z gives a POLYGON (2 variables): vertices [x y] in order
+// around the boundary; fixing y gives an interval (CUBIC).  The slicing arithmetic is the oracle's, with
+// FMA contraction off, so that both sides place the same panels.
+// ref: Polyhedron3 / Polygon2, pg_vert_from_zslice, xlim_from_yslice (ext/SymmetryReduceBZExt.jl:33-58,
+// ext/ibzlims.jl:198-289).
 struct Lims {
     int kind;
     double a[ABZ_MAX_DIM], b[ABZ_MAX_DIM];
     double s;
-    void segs(int L, double& lo, double& hi) const {  // range of variable L (1-based)
+    std::shared_ptr<const std::vector<double>> poly;
+    void segs(int L, std::vector<double>& out) const {  // break points of variable L (1-based)
+        out.clear();
         if (kind == ABZ_LIMS_CUBIC) {
-            lo = a[L - 1];
-            hi = b[L - 1];
-        } else {
-            lo = 0.0;
-            hi = a[L - 1] * s;
+            out.push_back(a[L - 1]);
+            out.push_back(b[L - 1]);
+        } else if (kind == ABZ_LIMS_TETRAHEDRAL) {
+            out.push_back(0.0);
+            out.push_back(a[L - 1] * s);
+        } else if (kind == ABZ_LIMS_POLYHEDRAL) {
+            std::vector<double> zs;
+            const std::vector<double>& f = *poly;
+            for (size_t i = 0; i < f.size();) {
+                const int nv = (int)f[i++];
+                for (int j = 0; j < nv; ++j, i += 3) zs.push_back(f[i + 2]);
+            }
+            unique_sorted(zs, out);
+        } else {  // polygon
+            std::vector<double> ys;
+            const std::vector<double>& v = *poly;
+            for (size_t i = 0; i + 1 < v.size(); i += 2) ys.push_back(v[i + 1]);
+            unique_sorted(ys, out);
         }
     }
     Lims fix(int L, double x) const {  // limits of variables 1..L-1 once variable L is fixed
+#pragma clang fp contract(off)
         Lims r = *this;
-        if (kind == ABZ_LIMS_TETRAHEDRAL) r.s = x / a[L - 1];
+        if (kind == ABZ_LIMS_TETRAHEDRAL) {
+            r.s = x / a[L - 1];
+        } else if (kind == ABZ_LIMS_POLYHEDRAL) {
+            const std::vector<double>& f = *poly;
+            std::vector<double> pts;  // (x, y) pairs
+            for (size_t i = 0; i < f.size();) {
+                const int nv = (int)f[i++];
+                const double* face = &f[i];
+                for (int j = 0; j < nv; ++j) {
+                    const double* p1 = face + 3 * j;
+                    const double* p2 = face + 3 * ((j + 1) % nv);
+                    const double z1 = p1[2], z2 = p2[2];
+                    if ((z1 <= x && z2 >= x) || (z1 >= x && z2 <= x)) {
+                        if (z2 == z1) continue;
+                        const double t = (x - z1) / (z2 - z1);
+                        const double omt = 1 - t;
+                        const double qx = t * p2[0] + omt * p1[0];
+                        const double qy = t * p2[1] + omt * p1[1];
+                        bool dup = false;
+                        for (size_t k = 0; k + 1 < pts.size() && !dup; k += 2) dup = pts[k] == qx && pts[k + 1] == qy;
+                        if (!dup) {
+                            pts.push_back(qx);
+                            pts.push_back(qy);
+                        }
+                    }
+                }
+                i += (size_t)3 * nv;
+            }
+            const size_t np = pts.size() / 2;
+            double cx = 0.0, cy = 0.0;
+            for (size_t k = 0; k < np; ++k) {
+                cx = cx + pts[2 * k];
+                cy = cy + pts[2 * k + 1];
+            }
+            cx = cx / (double)np;
+            cy = cy / (double)np;
+            std::vector<std::pair<double, size_t>> ang(np);
+            for (size_t k = 0; k < np; ++k) ang[k] = {std::atan2(pts[2 * k + 1] - cy, pts[2 * k] - cx), k};
+            std::stable_sort(ang.begin(), ang.end(), [](const auto& u, const auto& v) { return u.first < v.first; });
+            auto pg = std::make_shared<std::vector<double>>(2 * np);
+            for (size_t k = 0; k < np; ++k) {
+                (*pg)[2 * k] = pts[2 * ang[k].second];
+                (*pg)[2 * k + 1] = pts[2 * ang[k].second + 1];
+            }
+            r.kind = ABZ_LIMS_POLYGON;
+            r.poly = pg;
+        } else if (kind == ABZ_LIMS_POLYGON) {
+            const std::vector<double>& v = *poly;
+            const size_t nv = v.size() / 2;
+            double lb = 0.0, ub = 0.0;
+            int k = 0;
+            for (size_t j = 0; j < nv && k < 2; ++j) {
+                const size_t jp = (j + 1) % nv;
+                const double y1 = v[2 * j + 1], y2 = v[2 * jp + 1];
+                if ((y1 < x && y2 > x) || (y1 > x && y2 < x) || y1 == x) {
+                    const double t = (y2 != y1) ? (x - y1) / (y2 - y1) : 0.0;
+                    const double omt = 1 - t;
+                    const double lim = t * v[2 * jp] + omt * v[2 * j];
+                    if (++k == 1)
+                        lb = ub = lim;
+                    else {
+                        ub = std::max(lb, lim);
+                        lb = std::min(lb, lim);
+                    }
+                }
+            }
+            r.kind = ABZ_LIMS_CUBIC;
+            r.poly.reset();
+            r.a[0] = lb;
+            r.b[0] = ub;
+        }
         return r;
     }
 };
@@ -235,7 +345,12 @@ int IaiDriver::solve_inner_device(std::vector<Quad1D>& kids) {
     for (int64_t i = 0; i < nq; ++i) {
         const Quad1D& k = kids[(size_t)i];
         slot[(size_t)i] = k.slot;
-        k.lims.segs(1, lo[(size_t)i], hi[(size_t)i]);
+        {
+            std::vector<double> sg;
+            k.lims.segs(1, sg);
+            lo[(size_t)i] = sg.front();
+            hi[(size_t)i] = sg.back();  // the innermost slice of a convex domain is one interval
+        }
         at[(size_t)i] = k.has_atol ? k.atol : -1.0;
         sw[(size_t)i] = k.sweep;
         if (need_tail)
@@ -335,9 +450,10 @@ int IaiDriver::solve_level(int L, std::vector<Quad1D>& quads) {
     std::vector<size_t> active;
     for (size_t i = 0; i < quads.size(); ++i) {
         Quad1D& q = quads[i];
-        double lo, hi;
-        q.lims.segs(L, lo, hi);
-        q.pend.assign(1, Seg{lo, hi, 0.0, 0});
+        std::vector<double> sg;
+        q.lims.segs(L, sg);
+        q.pend.clear();
+        for (size_t k = 0; k + 1 < sg.size(); ++k) q.pend.push_back(Seg{sg[k], sg[k + 1], 0.0, 0});
         q.popped.clear();
         q.started = false;
         q.done = false;
@@ -393,9 +509,9 @@ int IaiDriver::solve_level(int L, std::vector<Quad1D>& quads) {
                         k.tail[0] = x;
                         for (int j = 1; j < ABZ_MAX_DIM; ++j) k.tail[j] = q.tail[j - 1];
                         k.lims = q.lims.fix(L, x);
-                        double lo, hi;
-                        k.lims.segs(L - 1, lo, hi);
-                        const double len = hi - lo;
+                        std::vector<double> sg;
+                        k.lims.segs(L - 1, sg);
+                        const double len = sg.back() - sg.front();  // ref: len = segs[end] - segs[1]
                         k.has_atol = q.has_atol;
                         k.atol = q.has_atol ? q.atol / len : 0.0;  // ref src/fourier.jl:479-480
                     }
@@ -428,12 +544,16 @@ int IaiDriver::solve_level(int L, std::vector<Quad1D>& quads) {
                 got[p] = sg;
             }
             if (!q.started) {
+                // QuadGK's first pass: every initial segment once, I and E summed in segment order
                 q.started = true;
-                q.heap.clear();
-                q.heap.push_back(got[0]);
+                q.heap.assign(got.begin(), got.end());
                 for (int c = 0; c < ncomp; ++c) q.I[(size_t)c] = q.store[(size_t)(got[0].ioff + c)];
                 q.E = got[0].E;
-                q.numevals = 15;
+                for (size_t h = 1; h < got.size(); ++h) {
+                    for (int c = 0; c < ncomp; ++c) q.I[(size_t)c] += q.store[(size_t)(got[h].ioff + c)];
+                    q.E += got[h].E;
+                }
+                q.numevals = 15 * (int64_t)got.size();
                 if (q.E <= std::max(at, rt * vnorm(q.I)) || q.numevals >= maxevals) {
                     q.done = true;
                     q.pend.clear();
@@ -522,8 +642,26 @@ int abz_iai_solve_many(abz_series* s, int lims_kind, const double* lim_a, const 
                        double* panels, int64_t max_panels, int64_t* npanels) {
     ABZ_REQUIRE(s && s->ctx && lim_a && out_reim, "abz_iai_solve: null argument");
     ABZ_REQUIRE(n_sweep >= 1 && sweeps, "abz_iai_solve: at least one sweep value");
-    ABZ_REQUIRE(lims_kind == ABZ_LIMS_CUBIC || lims_kind == ABZ_LIMS_TETRAHEDRAL, "unknown limits kind %d", lims_kind);
-    ABZ_REQUIRE(lims_kind != ABZ_LIMS_CUBIC || lim_b, "CubicLimits need lim_b");
+    ABZ_REQUIRE(lims_kind >= ABZ_LIMS_CUBIC && lims_kind <= ABZ_LIMS_POLYGON, "unknown limits kind %d", lims_kind);
+    ABZ_REQUIRE(lims_kind == ABZ_LIMS_TETRAHEDRAL || lim_b, "these limits need lim_b");
+    ABZ_REQUIRE(lims_kind != ABZ_LIMS_POLYHEDRAL || s->d == 3, "PolyhedralLimits are for 3 variables");
+    ABZ_REQUIRE(lims_kind != ABZ_LIMS_POLYGON || s->d == 2, "PolygonLimits are for 2 variables");
+    std::shared_ptr<const std::vector<double>> poly;
+    if (lims_kind >= ABZ_LIMS_POLYHEDRAL) {
+        const int64_t len = (int64_t)lim_b[0];
+        ABZ_REQUIRE(len >= 6, "polytope description too short");
+        poly = std::make_shared<std::vector<double>>(lim_a, lim_a + len);
+        if (lims_kind == ABZ_LIMS_POLYHEDRAL) {  // [nv, xyz * nv] per face
+            int64_t i = 0;
+            while (i < len) {
+                const int64_t nv = (int64_t)lim_a[i];
+                ABZ_REQUIRE(nv >= 3 && i + 1 + 3 * nv <= len, "malformed face list");
+                i += 1 + 3 * nv;
+            }
+        } else {
+            ABZ_REQUIRE(len % 2 == 0, "polygon vertices come as (x, y) pairs");
+        }
+    }
     ABZ_REQUIRE(nparams >= 0 && nparams <= 4, "nparams = %d not in 0..4", nparams);
     ABZ_HIP(hipSetDevice(s->ctx->device));
     IaiDriver drv;
@@ -560,9 +698,10 @@ int abz_iai_solve_many(abz_series* s, int lims_kind, const double* lim_a, const 
         q.root = r;
         q.lims.kind = lims_kind;
         q.lims.s = 1.0;
+        q.lims.poly = poly;
         for (int j = 0; j < s->d; ++j) {
-            q.lims.a[j] = lim_a[j];
-            q.lims.b[j] = lim_b ? lim_b[j] : 0.0;
+            q.lims.a[j] = lims_kind < ABZ_LIMS_POLYHEDRAL ? lim_a[j] : 0.0;
+            q.lims.b[j] = (lims_kind < ABZ_LIMS_POLYHEDRAL && lim_b) ? lim_b[j] : 0.0;
         }
         q.has_atol = abstol >= 0;
         q.atol = abstol >= 0 ? abstol : 0.0;

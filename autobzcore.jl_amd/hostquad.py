@@ -87,15 +87,21 @@ def _norm(v):
     return float(np.linalg.norm(np.atleast_1d(np.asarray(v)).reshape(-1)))
 
 
-def auxquadgk(g, a, b, atol, rtol, maxevals):
-    """Scalar-mode globally adaptive GK(7,15): g maps 15/30 points to a list of values."""
+def auxquadgk(g, segs, atol, rtol, maxevals):
+    """Scalar-mode globally adaptive GK(7,15) over the break points `segs`: g maps points to a list of values."""
     atol_ = 0.0 if atol is None else atol
     rtol_ = (0.0 if atol_ > 0 else math.sqrt(np.finfo(float).eps)) if rtol is None else rtol
-    fv = g(_gk_nodes(a, b))
-    I, E = _gk_eval(fv, a, b)
-    numevals = 15
+    nseg = len(segs) - 1
+    fv = g(np.concatenate([_gk_nodes(segs[i], segs[i + 1]) for i in range(nseg)]))
     heap = _Heap()
-    heap.xs.append((a, b, I, E))
+    for i in range(nseg):
+        Ii, Ei = _gk_eval(fv[15 * i:15 * i + 15], segs[i], segs[i + 1])
+        heap.xs.append((segs[i], segs[i + 1], Ii, Ei))
+    I, E = heap.xs[0][2], heap.xs[0][3]
+    for sg in heap.xs[1:]:
+        I = I + sg[2]
+        E = E + sg[3]
+    numevals = 15 * nseg
     if not (E <= max(atol_, rtol_ * _norm(I)) or numevals >= maxevals):
         heap.heapify()
         while E > max(atol_, rtol_ * _norm(I)) and numevals < maxevals:
@@ -117,6 +123,7 @@ def auxquadgk(g, a, b, atol, rtol, maxevals):
 
 
 def nested_quad_host(f, dev, lims, p, abstol, reltol, maxiters):
+    """Any iterated limits with the protocol `segs()` / `fix(x)` (bz.py: Cubic, Tetrahedral, Polyhedral, Polygon)."""
     from .solver import FourierValue  # local import: solver imports this module lazily
     d = f.w.d
     if lims.ndim != d:
@@ -124,13 +131,7 @@ def nested_quad_host(f, dev, lims, p, abstol, reltol, maxiters):
     user = f.f.f
     count = [0]
 
-    def segs(level, scale):
-        if isinstance(lims, CubicLimits):
-            return float(lims.a[level - 1]), float(lims.b[level - 1])
-        return 0.0, float(lims.a[level - 1]) * scale
-
-    def level_solve(level, tail, scale, atol):
-        a, b = segs(level, scale)
+    def level_solve(level, lim, tail, atol):
         if level == 1:
             def g(xs):
                 pts = np.column_stack([xs] + [np.full(len(xs), t) for t in tail])
@@ -141,12 +142,12 @@ def nested_quad_host(f, dev, lims, p, abstol, reltol, maxiters):
             def g(xs):
                 out = []
                 for x in xs:
-                    sc = x / float(lims.a[level - 1]) if isinstance(lims, TetrahedralLimits) else scale
-                    ia, ib = segs(level - 1, sc)
-                    at = None if atol is None else atol / (ib - ia)  # ref: src/fourier.jl:479-480
-                    out.append(level_solve(level - 1, (x,) + tail, sc, at)[0])
+                    inner = lim.fix(x)
+                    sg = inner.segs()
+                    at = None if atol is None else atol / (sg[-1] - sg[0])  # ref: src/fourier.jl:479-480
+                    out.append(level_solve(level - 1, inner, (x,) + tail, at)[0])
                 return out
-        return auxquadgk(g, a, b, atol, reltol, maxiters)
+        return auxquadgk(g, tuple(lim.segs()), atol, reltol, maxiters)
 
-    I, E = level_solve(d, (), 1.0, abstol)
+    I, E = level_solve(d, lims, (), abstol)
     return I, E, count[0]

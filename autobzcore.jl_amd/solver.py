@@ -17,7 +17,8 @@ from typing import Any, Callable, Optional
 import numpy as np
 
 from . import _lib as L
-from .bz import (Basis, CubicLimits, HyperCube, PuncturedInterval, SymmetricBZ, TetrahedralLimits, nsyms)
+from .bz import (Basis, CubicLimits, HyperCube, PolygonLimits, PolyhedralLimits, PuncturedInterval, SymmetricBZ,
+                 TetrahedralLimits, nsyms)
 from .series import FourierSeries
 
 
@@ -565,9 +566,13 @@ def _iai_device_many(f: FourierIntegrand, dev, lims, plist, abstol, reltol, maxi
         kind, a, b = L.LIMS_CUBIC, lims.a, lims.b
     elif isinstance(lims, TetrahedralLimits):
         kind, a, b = L.LIMS_TETRAHEDRAL, lims.a, None
+    elif isinstance(lims, (PolyhedralLimits, PolygonLimits)):
+        kind = L.LIMS_POLYHEDRAL if isinstance(lims, PolyhedralLimits) else L.LIMS_POLYGON
+        a = lims.packed()
+        b = np.array([float(len(a))])
     else:
-        raise ValueError("IAI needs CubicLimits or TetrahedralLimits")
-    if len(a) != d:
+        raise ValueError("IAI needs CubicLimits, TetrahedralLimits, PolyhedralLimits or PolygonLimits")
+    if lims.ndim != d:
         raise ValueError("variables in Fourier series don't match domain")  # ref: src/fourier.jl:506
     _, pa = L.f64(a)
     pb = L.f64(b)[1] if b is not None else None
@@ -678,7 +683,7 @@ def do_solve(f, dom, p, alg, cacheval=None, abstol=None, reltol=None, maxiters=2
             s.numevals = -1
         return s
     if isinstance(alg, NestedQuad):
-        if not isinstance(dom, (CubicLimits, TetrahedralLimits)):
+        if not isinstance(dom, (CubicLimits, TetrahedralLimits, PolyhedralLimits, PolygonLimits)):
             raise ValueError("NestedQuad needs iterated limits")
         if isdev:
             u, err, nev, _ = _iai_device(f, dev, dom, pm, abstol, reltol, maxiters)
@@ -805,7 +810,8 @@ def batchsolve(solver: IntegralSolver, ps, nthreads=1, callback=None):
     inner = alg.alg if isinstance(alg, EvalCounter) else alg
     isdev = isinstance(f, FourierIntegrand) and isinstance(f.f.f, DeviceIntegrand)
     fused = isdev and isinstance(solver.dom, SymmetricBZ) and isinstance(inner, (PTR, AutoPTR, IAI))
-    fused = fused or (isdev and isinstance(inner, NestedQuad) and isinstance(solver.dom, (CubicLimits, TetrahedralLimits)))
+    fused = fused or (isdev and isinstance(inner, NestedQuad) and
+                      isinstance(solver.dom, (CubicLimits, TetrahedralLimits, PolyhedralLimits, PolygonLimits)))
     flat_idx = [i[::-1] for i in np.ndindex(*arr.shape[::-1])]
     t0 = time.time()
     if fused:

@@ -64,6 +64,13 @@ typedef struct abz_rule abz_rule;     /* device-resident cached rule values (Fou
 /* iterated limits for IAI (ref: src/brillouin.jl:2-5,267,304) */
 #define ABZ_LIMS_CUBIC 0        /* CubicLimits(a, b) */
 #define ABZ_LIMS_TETRAHEDRAL 1  /* TetrahedralLimits(a): 0 <= x_1 <= ... <= x_d <= a_d (scaled) */
+/* General convex irreducible zones (ext/SymmetryReduceBZExt.jl:33-58, ext/ibzlims.jl:198-289):
+ * lim_a = packed polytope, lim_b[0] = number of doubles in lim_a.
+ *   POLYHEDRAL (d = 3): per face [nv, x y z of its nv vertices in order around the face]; vertices shared
+ *                       between faces must be bit-identical.
+ *   POLYGON (d = 2):    vertices (x, y) in order around the boundary. */
+#define ABZ_LIMS_POLYHEDRAL 2
+#define ABZ_LIMS_POLYGON 3
 
 /* profiled kernels (abz_prof_read) */
 #define ABZ_K_CONTRACT 0   /* outer-dimension contraction (workspace_contract!)      */

@@ -335,6 +335,87 @@ class TetrahedralLimits:
     # NB: after fixing x_d = x the next variable runs over [0, a_{d-1} * x / a_d]
 
 
+def _unique_sorted(vals):
+    """Break points of a polytope along one coordinate: the distinct vertex coordinates (sqrt(eps)
+    tolerances, first occurrence kept), ascending.  ref: get_segs, ext/SymmetryReduceBZExt.jl:15-31."""
+    tol = math.sqrt(np.finfo(float).eps)
+    uniq = []
+    for v in vals:
+        if not any(abs(v - u) <= max(tol, tol * max(abs(v), abs(u))) for u in uniq):
+            uniq.append(float(v))
+    assert len(uniq) >= 2, uniq
+    return tuple(sorted(uniq))
+
+
+class PolygonLimits:
+    """Convex polygon in (x, y): verts [nv, 2] ordered around the boundary.
+    ref: Polygon2 + xlim_from_yslice, ext/SymmetryReduceBZExt.jl:43-59, ext/ibzlims.jl:245-289."""
+
+    def __init__(self, verts):
+        self.verts = np.asarray(verts, dtype=np.float64)
+
+    @property
+    def ndim(self):
+        return 2
+
+    def segs(self):
+        return _unique_sorted(self.verts[:, 1])
+
+    def fix(self, y):
+        v = self.verts
+        nv = len(v)
+        lb, k = None, 0
+        for j in range(nv):
+            y1, y2 = v[j, 1], v[(j + 1) % nv, 1]
+            if (y1 < y and y2 > y) or (y1 > y and y2 < y) or y1 == y:
+                t = (y - y1) / (y2 - y1) if y2 != y1 else 0.0
+                lim = t * v[(j + 1) % nv, 0] + (1 - t) * v[j, 0]
+                k += 1
+                if k == 1:
+                    lb = lim
+                elif k == 2:
+                    return CubicLimits(np.array([min(lb, lim)]), np.array([max(lb, lim)]))
+        assert k == 1, "could not find intersection with polygon"
+        return CubicLimits(np.array([lb]), np.array([lb]))
+
+
+class PolyhedralLimits:
+    """Convex polyhedron in (x, y, z) given by its faces (each [nv, 3], vertices in order around the
+    face; triangles of a hull triangulation qualify).  Vertices shared between faces must be bit-identical.
+    ref: Polyhedron3 + pg_vert_from_zslice, ext/SymmetryReduceBZExt.jl:33-58, ext/ibzlims.jl:198-243."""
+
+    def __init__(self, faces):
+        self.faces = [np.asarray(f, dtype=np.float64) for f in faces]
+
+    @property
+    def ndim(self):
+        return 3
+
+    def segs(self):
+        return _unique_sorted(np.concatenate([f[:, 2] for f in self.faces]))
+
+    def fix(self, z):
+        pts = []
+        for face in self.faces:
+            nv = len(face)
+            for j in range(nv):
+                p1, p2 = face[j], face[(j + 1) % nv]
+                z1, z2 = p1[2], p2[2]
+                if (z1 <= z and z2 >= z) or (z1 >= z and z2 <= z):
+                    if z2 == z1:
+                        continue  # edge in the plane: its end points come from the neighbouring edges
+                    t = (z - z1) / (z2 - z1)
+                    pts.append((t * p2[0] + (1 - t) * p1[0], t * p2[1] + (1 - t) * p1[1]))
+        uniq = []
+        for q in pts:  # exact duplicates from shared edges
+            if q not in uniq:
+                uniq.append(q)
+        P = np.array(uniq)
+        c = P.mean(axis=0)
+        order = np.argsort(np.arctan2(P[:, 1] - c[1], P[:, 0] - c[0]), kind="stable")
+        return PolygonLimits(P[order])
+
+
 @dataclass
 class SymmetricBZ:
     """ref: src/brillouin.jl:33-46."""
@@ -721,7 +802,7 @@ def nested_quad(s, lims, f, abstol=None, reltol=None, maxiters=2**62, norm=None,
     last_err = [0.0]
 
     def level(cur: FourierSeries, lims, tail: tuple, atol_l, rec=None):
-        a, b = lims.segs()
+        segs = tuple(lims.segs())  # break points of the outermost variable (2 for boxes, more for polytopes)
         if cur.d == 1:
             def g(xs):
                 ph = phases(cur, 0, xs)  # (N, M)
@@ -735,12 +816,12 @@ def nested_quad(s, lims, f, abstol=None, reltol=None, maxiters=2**62, norm=None,
                 out = []
                 for x in xs:
                     inner = lims.fix(x)
-                    ia, ib = inner.segs()
-                    ln = ib - ia
+                    isegs = inner.segs()
+                    ln = isegs[-1] - isegs[0]  # ref: len = segs[end] - segs[1], src/fourier.jl:466,480
                     at = None if atol_l is None else atol_l / ln
                     out.append(level(contract(cur, x), inner, (x,) + tail, at))
                 return out
-        I, E, _ = auxquadgk(g, (a, b), atol=atol_l, rtol=reltol, maxevals=maxiters, norm=norm,
+        I, E, _ = auxquadgk(g, segs, atol=atol_l, rtol=reltol, maxevals=maxiters, norm=norm,
                             record=rec, batch=batch)
         last_err[0] = E
         return I

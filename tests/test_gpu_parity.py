@@ -495,6 +495,52 @@ def test_symrep_extension_point_matrix_valued_on_the_ibz(abz):
     assert np.abs(swp[0] - ref).max() <= 1e-12 * np.abs(ref).max()
 
 
+def test_iai_over_general_convex_zones(abz):
+    """ref: ext/SymmetryReduceBZExt.jl:33-58, ext/ibzlims.jl:198-289.  IAI over an explicitly given irreducible
+    zone (PolyhedralLimits / PolygonLimits): same panels and numevals as the oracle's restatement, the
+    polyhedral tetrahedron agrees with CubicSymIBZ, volumes come out, and the zone + point group reproduce
+    the full-BZ integral."""
+    from scipy.spatial import ConvexHull
+    rng = np.random.default_rng(41)
+    c, first = rand_series(rng, (3, 3, 3), 2, hermitian=True)
+    s, so = both(abz, c / 3, first)
+    # (1) cubic IBZ given as a polyhedron
+    V = np.array([[0, 0, 0], [0, 0, .5], [0, .5, .5], [.5, .5, .5]], dtype=float)
+    cub = abz.load_bz(abz.CubicSymIBZ(), np.eye(3))
+    ibz = abz.load_bz(abz.IBZ(), np.eye(3), hull=V, syms=cub.syms)
+    assert isinstance(ibz.lims, abz.PolyhedralLimits) and abz.nsyms(ibz) == 48
+    so_c, _ = orc.integer_lattice(3), None
+    sc = abz.FourierSeries(so_c.c[..., 0, 0], period=1.0, first=so_c.first, ndim=3)
+    f = abz.FourierIntegrand(abz.LinearIntegrand(), sc, 1.3, 1.0)
+    a = abz.do_solve(f, cub, abz.MixedParameters(), abz.EvalCounter(abz.IAI()), abstol=1e-7)
+    b = abz.do_solve(f, ibz, abz.MixedParameters(), abz.EvalCounter(abz.IAI()), abstol=1e-7)
+    assert abs(a.u - b.u) <= 1e-12 * abs(a.u) and a.numevals == b.numevals and abs(b.u - (2 * np.pi) ** 3) < 1e-6
+    # (2) a random convex polytope: initial break points at the vertex coordinates, panels as in the oracle
+    P = rng.standard_normal((9, 3)) * 0.2 + 0.5
+    lim = abz.PolyhedralLimits.from_vertices(P)
+    fd = abz.FourierIntegrand(abz.DOSIntegrand(), s, 0.3)
+    sol = abz.do_solve(fd, lim, abz.MixedParameters(0.2), abz.EvalCounter(abz.NestedQuad(abz.AuxQuadGKJL())), abstol=1e-4)
+    ref = orc.nested_quad(so, orc.PolyhedralLimits(lim.faces), orc.f_dos(0.3, 0.2), abstol=1e-4)
+    assert sol.numevals == ref[2] and abs(sol.u - ref[0]) <= 1e-10 * abs(ref[0])
+    one = abz.do_solve(abz.FourierIntegrand(abz.UnitIntegrand(), s), lim, abz.MixedParameters(),
+                       abz.NestedQuad(abz.AuxQuadGKJL()), abstol=1e-9)
+    assert abs(one.u - ConvexHull(P).volume) <= 1e-8
+    # (3) 2-D polygon + a user closure on the host path
+    th = np.arange(6) * np.pi / 3
+    hexv = 0.3 * np.column_stack([np.cos(th), np.sin(th)]) + 0.5
+    c2, first2 = rand_series(rng, (3, 3), 2, hermitian=True)
+    s2, so2 = both(abz, c2 / 3, first2)
+    pg = abz.PolygonLimits(hexv)
+    sol2 = abz.do_solve(abz.FourierIntegrand(abz.DOSIntegrand(), s2, 0.3), pg, abz.MixedParameters(0.2),
+                        abz.EvalCounter(abz.NestedQuad(abz.AuxQuadGKJL())), abstol=1e-5)
+    ref2 = orc.nested_quad(so2, orc.PolygonLimits(hexv), orc.f_dos(0.3, 0.2), abstol=1e-5)
+    assert sol2.numevals == ref2[2] and abs(sol2.u - ref2[0]) <= 1e-10 * abs(ref2[0])
+    user = lambda v, eta, omega: -np.imag(np.trace(np.linalg.inv((omega + 1j * eta) * np.eye(2) - v.s))) / np.pi
+    sol3 = abz.do_solve(abz.FourierIntegrand(user, s2, 0.3), pg, abz.MixedParameters(0.2),
+                        abz.NestedQuad(abz.AuxQuadGKJL()), abstol=1e-5)
+    assert abs(sol3.u - ref2[0]) <= 1e-9 * abs(ref2[0])
+
+
 # ------------------------------------------------------------------ generic n (wave-per-node kernels)
 @pytest.mark.parametrize("d,n", [(1, 5), (2, 8), (3, 6), (3, 16)])
 def test_generic_n_eval_and_rules(abz, d, n):

@@ -304,3 +304,40 @@ def test_ggr_cache_linearity():
     a = orc.dos_ggr(h, bz, [0.3], npt=100)[0]
     b = orc.dos_ggr(h2, bz, [0.6], npt=100)[0]
     assert a > 0 and abs(a / 2 - b) < 1e-12
+
+
+def test_polyhedral_limits_general_irreducible_zones():
+    """ref: ext/SymmetryReduceBZExt.jl:33-58, ext/ibzlims.jl:198-289 (Polyhedron3 / Polygon2 limits).
+    (1) the tetrahedron 0 <= x <= y <= z <= 1/2 given as a polyhedron reproduces TetrahedralLimits (same
+    panels, same numevals); (2) the integral of 1 over a convex polytope is its volume, with the vertex
+    coordinates as initial break points; (3) the product-side limits slice exactly like the oracle's."""
+    from scipy.spatial import ConvexHull
+    import autobzcore.jl_amd as abz
+    so = orc.integer_lattice(3)
+    f = lambda x, h: 1.3 * np.asarray(h) + 1.0
+    V = np.array([[0, 0, 0], [0, 0, .5], [0, .5, .5], [.5, .5, .5]], dtype=float)
+    pl = abz.PolyhedralLimits.from_vertices(V)
+    a = orc.nested_quad(so, orc.TetrahedralLimits(np.full(3, 0.5)), f, abstol=1e-8)
+    b = orc.nested_quad(so, orc.PolyhedralLimits(pl.faces), f, abstol=1e-8)
+    assert a[2] == b[2] and abs(a[0] - b[0]) <= 1e-15
+    rng = np.random.default_rng(4)
+    P = rng.standard_normal((9, 3)) * 0.2 + 0.5
+    plr = abz.PolyhedralLimits.from_vertices(P)
+    assert len(plr.segs()) > 2  # interior break points: several initial panels
+    one = orc.nested_quad(so, orc.PolyhedralLimits(plr.faces), lambda x, h: np.ones(len(x)), abstol=1e-10)
+    assert abs(one[0] - ConvexHull(P).volume) <= 1e-9
+    po = orc.PolyhedralLimits(plr.faces)
+    zs = plr.segs()
+    for z in np.linspace(zs[0], zs[-1], 7)[1:-1]:
+        pa, pb = plr.fix(z), po.fix(z)
+        assert np.array_equal(pa.verts, pb.verts) and pa.segs() == pb.segs()
+        ys = pa.segs()
+        for y in np.linspace(ys[0], ys[-1], 5)[1:-1]:
+            ca, cb = pa.fix(y), pb.fix(y)
+            assert np.array_equal(ca.a, cb.a) and np.array_equal(ca.b, cb.b)
+    # 2-D: hexagon
+    th = np.arange(6) * np.pi / 3
+    hexv = 0.3 * np.column_stack([np.cos(th), np.sin(th)]) + 0.5
+    s2 = orc.integer_lattice(2)
+    area = orc.nested_quad(s2, orc.PolygonLimits(hexv), lambda x, h: np.ones(len(x)), abstol=1e-10)
+    assert abs(area[0] - 1.5 * np.sqrt(3) * 0.09) <= 1e-9
