@@ -24,7 +24,19 @@ const libabz = "libabzhip"   # autobzcore.jl_amd/libabzhip.so on the loader path
 # ---------------------------------------------------------------- constants of abzhip.h
 const WANT_H, WANT_EIG, WANT_VEL = Cint(1), Cint(2), Cint(4)
 const F_ONE, F_LINEAR, F_LINEAR_X, F_DOS, F_TRGLOC, F_GLOC, F_DOS_EIG = Cint.(0:6)
-const LIMS_CUBIC, LIMS_TETRAHEDRAL = Cint(0), Cint(1)
+const LIMS_CUBIC, LIMS_TETRAHEDRAL, LIMS_POLYHEDRAL, LIMS_POLYGON = Cint(0), Cint(1), Cint(2), Cint(3)
+
+# (kind, lim_a, lim_b) of the reference's limits types for abz_iai_solve(_many); the SymmetryReduceBZ
+# extension's Polyhedron3 travels as packed faces [nv, x y z ...] with lim_b = [length(lim_a)]
+function pack_limits(l)
+    l isa CubicLimits && return (LIMS_CUBIC, Float64[l.a...], Float64[l.b...])
+    hasproperty(l, :face_coord) || return (LIMS_TETRAHEDRAL, Float64[l.a...], Float64[])
+    a = Float64[]
+    for f in l.face_coord            # nv x 3 matrices, vertices in order around the face
+        push!(a, size(f, 1)); append!(a, vec(permutedims(f)))
+    end
+    return (LIMS_POLYHEDRAL, a, Float64[length(a)])
+end
 
 function check(rc::Cint)
     rc == 0 && return nothing
@@ -176,8 +188,7 @@ function AutoBZCore.do_solve(f::HIPFourierIntegrand, bz::SymmetricBZ, p, alg::IA
     abstol=nothing, reltol=nothing, maxiters=typemax(Int)) where {d}
     j = abs(det(bz.B)); ns = nsyms(bz)
     params, omega = bind(f.f.f, merge(f.f.p, p))
-    kind, a, b = bz.lims isa CubicLimits ? (LIMS_CUBIC, Float64[bz.lims.a...], Float64[bz.lims.b...]) :
-                 (LIMS_TETRAHEDRAL, Float64[bz.lims.a...], Float64[])
+    kind, a, b = pack_limits(bz.lims)
     out = Ref{ComplexF64}(0); err = Ref{Float64}(0); nev = Ref{Int64}(0); npan = Ref{Int64}(0)
     GC.@preserve params a b begin
         check(ccall((:abz_iai_solve, libabz), Cint,
@@ -230,8 +241,7 @@ function AutoBZCore.batchsolve(s::IntegralSolver{<:HIPFourierIntegrand,<:Symmetr
     hs = HIPSeries(f.w.series)
     j = abs(det(bz.B)); ns = nsyms(bz); m = length(omegas)
     params, _ = bind(f.f.f, merge(f.f.p, MixedParameters(first(omegas))))
-    kind, a, b = bz.lims isa CubicLimits ? (LIMS_CUBIC, Float64[bz.lims.a...], Float64[bz.lims.b...]) :
-                 (LIMS_TETRAHEDRAL, Float64[bz.lims.a...], Float64[])
+    kind, a, b = pack_limits(bz.lims)
     abstol = get(s.kwargs, :abstol, nothing); reltol = get(s.kwargs, :reltol, nothing)
     sw = Float64.(omegas); out = Vector{ComplexF64}(undef, m); err = Vector{Float64}(undef, m); nev = Vector{Int64}(undef, m)
     npan = Ref{Int64}(0)
