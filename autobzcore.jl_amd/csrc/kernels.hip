@@ -1,16 +1,23 @@
 // HIP kernels of the hot path, written for gfx950 (MI355X, wave64) only.
 //
-//   phase_kernel      e^{2 pi i f x / t} tables for a batch of nodes            (tiny)
-//   contract_kernel   outer-dimension contraction  C'[b][l] = sum_m ph[b][m] C[parent(b)][m][l]
-//                     = workspace_contract!  (ref src/fourier.jl:152,158,242,252,468,478)
-//   eval_grid_kernel  innermost 1-D series on a full PTR grid, one wavefront per line (i2,i3),
-//                     one lane per node i1, coefficients of the line read through the scalar
-//                     cache (wave-uniform), fused Hermitian eigensolve, planar coalesced stores
-//                     = workspace_evaluate! in fourier_ptr!  (ref src/fourier.jl:132-147)
-//   eval_node_kernel  same at explicit nodes (symmetric rules, IAI panels, BatchIntegrand)
-//   reduce_kernel     sum_k w_k f(H(k); omega_i) for all omega_i of a sweep in one pass over the
-//                     cached rule = quadsum (ref src/fourier.jl:204-207,289-292)
-//   ggr_kernel        GGR formula scan (ref src/dos_ggr.jl:58-104)
+//   phase_kernel            e^{2 pi i f x / t} tables for a batch of nodes                     (tiny)
+//   contract_grid_s_kernel  full-grid contraction of the outermost remaining variable, phases as scalars
+//   contract_grid_kernel    the same with LDS-staged phases (derivative builds); contract_kernel: node lists
+//                           = workspace_contract!  (ref src/fourier.jl:152,158,242,252,468,478)
+//   eval_grid_kernel        innermost 1-D series on a full PTR grid: one wavefront per pass of a line (i2,i3),
+//                           KPL nodes per lane, the line's coefficients in a wave-private double-buffered LDS
+//                           slot, one load group and one wait per unit of work (in-order vmcnt), fused
+//                           Hermitian eigensolve, tiled-planar stores (H first, non-temporal on large rules)
+//                           = workspace_evaluate! in fourier_ptr!  (ref src/fourier.jl:132-147)
+//   eval_grid_fused_kernel  opt-in: the same with the last contraction computed by the wave itself
+//   eval_node_kernel        the series at explicit nodes (symmetric rules, abz_eval_nodes)
+//   reduce_kernel           sum_k w_k f(H(k); omega_i) for all omega_i of a sweep in one pass over the cached
+//                           rule = quadsum (ref src/fourier.jl:204-207,289-292); Hermitian rules: real
+//                           characteristic polynomial / adjugate forms
+//   ggr_kernel              GGR formula scan (ref src/dos_ggr.jl:58-104)
+//   node_integrand_kernel   IAI innermost nodes (n <= 4); inner_adaptive_kernel: whole innermost adaptive
+//                           loops on the device, half a wavefront per 1-D integral
+//   (generic n: kernels_generic.hip; symmetric-rule tables: kernels_symptr.hip)
 #include "abz_internal.h"
 #include "device_math.h"
 #include "gk15.h"
