@@ -1,6 +1,7 @@
 // Host side of the C ABI (include/abzhip.h): handles, rule construction plans, exports.
 #include <algorithm>
 #include <cstdarg>
+#include <chrono>
 #include <cstring>
 #include <map>
 #include <numeric>
@@ -653,6 +654,18 @@ static int rule_build(abz_series* s, int npt, int64_t nirr, const int32_t* irr_i
         }
         plan_runs<int32_t>(plan, d, npt, irr_idx, nirr, false);
     }
+    const bool dbg = getenv("ABZ_DEBUG_TIMING") != nullptr;
+    auto tnow = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    double tdbg = tnow();
+    auto lap = [&](const char* what) {
+        if (dbg) {
+            (void)hipStreamSynchronize(ctx->stream);
+            const double t = tnow();
+            fprintf(stderr, "[abz] rule_build %-14s %8.3f ms\n", what, 1e3 * (t - tdbg));
+            tdbg = t;
+        }
+    };
+    lap("plan");
     r->nk = plan.nk;
     // tiles: a grid line (pitch = npt rounded up to 16 doubles = 128 B) or 64 nodes of an irregular list
     const int line_len = r->full ? npt : 64;
@@ -664,7 +677,9 @@ static int rule_build(abz_series* s, int npt, int64_t nirr, const int32_t* irr_i
     r->planes = pH + pE + pV;
     const int64_t tile = (int64_t)r->planes * pitch;
     RULE_TRY(plan_upload(ctx, plan, rp->pd));
+    lap("plan_upload");
     RULE_TRY(make_phase_table(ctx, npt, rp->tab));
+    lap("phase_table");
     if (r->full) {  // per-level phase tables [npt][M] for the scalar-phase contraction kernel
         for (int L = 1; L < d; ++L) {
             const int M = s->dims[L];
@@ -719,8 +734,10 @@ static int rule_build(abz_series* s, int npt, int64_t nirr, const int32_t* irr_i
         RULE_TRY(rp->tmpU.reserve(tb));
         RULE_TRY(rp->tmpD.reserve(tb));
     }
+    lap("alloc+w/idx");
     RULE_TRY(rule_fill(r));
     RULE_HIP(hipStreamSynchronize(ctx->stream));
+    lap("fill");
     if (want & ABZ_WANT_VEL) {  // keep the big temporaries only while a rebuild needs them
         rp->tmpU.release();
         rp->tmpD.release();
