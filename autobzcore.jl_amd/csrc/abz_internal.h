@@ -32,6 +32,16 @@ void set_error(const char* fmt, ...);
     } while (0)
 
 // Device buffer that grows but never shrinks (scratch); freed with its owner.
+// Host <-> device copies of arrays beyond a few hundred KB go through the context's pinned staging buffer:
+// ROCm pins pageable memory on the fly for such copies, which costs milliseconds per call (5 MB of plan
+// arrays took 15-27 ms; staged: < 2 ms).  Both calls return when the data has arrived.
+int stage_h2d(abz_ctx* ctx, void* dst_dev, const void* src_host, size_t bytes);
+int stage_d2h(abz_ctx* ctx, void* dst_host, const void* src_dev, size_t bytes);
+
+// caching device allocator (api.cpp): blocks freed with dev_free are reused by later dev_alloc calls
+int dev_alloc(void** out, size_t bytes, size_t* cap_out);
+void dev_free(void* p, size_t cap);
+
 struct DevBuf {
     void* p = nullptr;
     size_t cap = 0;
@@ -69,7 +79,8 @@ struct abz_ctx {
     abz::ProfSlot prof_slots[ABZ_K_COUNT];
     std::vector<hipEvent_t> event_pool;
     abz::DevBuf scratch[6];  // phases, partials, staging...
-    abz::DevBuf pinned_dummy;
+    void* pin = nullptr;     // pinned host staging buffer (hipHostMalloc), grown on demand
+    size_t pin_cap = 0;
 };
 
 struct abz_series {
@@ -102,6 +113,7 @@ struct abz_rule {
     bool herm = false;    // values come from a Hermitian series (set by every fill): H(k) = H(k)^dagger
     int64_t k_offset = 0;  // full grids: flat grid index of node 0 (non-zero for a slab of the outermost variable)
     double* vals = nullptr;  // [ntiles][planes][pitch]: H planes 2*(a + n*b) + {re, im}, then E (n), then V (d*n)
+    size_t vals_cap = 0, w_cap = 0, idx_cap = 0;  // block sizes as handed out by dev_alloc
     int planes = 0;
     abz::PlaneView H, E, V;  // views into vals (base == nullptr when absent)
     double* w = nullptr;   // [nk] weights (symmetric rules)

@@ -154,13 +154,16 @@ int symptr_device(abz_ctx* ctx, int npt, int d, const int32_t* syms, int nsyms, 
         e = hipMemcpyAsync(offs.p, ho.data(), sizeof(int64_t) * (size_t)nb, hipMemcpyHostToDevice, ctx->stream);
         hipLaunchKernelGGL(compact_scatter_kernel, dim3((unsigned)nb), dim3(256), 0, ctx->stream, flag.as<int>(), a.N,
                            offs.as<int64_t>(), npt, d, didx.as<int32_t>(), dw.as<int64_t>());
-        if (e == hipSuccess) e = hipMemcpyAsync(idx.data(), didx.p, sizeof(int32_t) * idx.size(), hipMemcpyDeviceToHost, ctx->stream);
-        if (e == hipSuccess) e = hipMemcpyAsync(w.data(), dw.p, sizeof(int64_t) * w.size(), hipMemcpyDeviceToHost, ctx->stream);
-        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
         if (e != hipSuccess) {
             cleanup();
             set_error("symptr_device: %s", hipGetErrorString(e));
             return ABZ_ERR_HIP;
+        }
+        // MB-sized results: through the pinned staging buffer
+        if ((rc = stage_d2h(ctx, idx.data(), didx.p, sizeof(int32_t) * idx.size())) ||
+            (rc = stage_d2h(ctx, w.data(), dw.p, sizeof(int64_t) * w.size()))) {
+            cleanup();
+            return rc;
         }
     }
     cleanup();
