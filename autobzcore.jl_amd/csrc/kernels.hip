@@ -1636,9 +1636,7 @@ int export_planes(abz_ctx* ctx, PlaneView v, int ncomp, int64_t nk, double* host
     double* stg = ctx->scratch[3].as<double>();
     hipLaunchKernelGGL(export_kernel, dim3((unsigned)cdiv(nk * ncomp, 256)), dim3(256), 0, ctx->stream, v, ncomp, nk, stg);
     ABZ_HIP(hipGetLastError());
-    ABZ_HIP(hipMemcpyAsync(host_out, stg, bytes, hipMemcpyDeviceToHost, ctx->stream));
-    ABZ_HIP(hipStreamSynchronize(ctx->stream));
-    return ABZ_OK;
+    return stage_d2h(ctx, host_out, stg, bytes);  // large: through the pinned staging buffer
 }
 
 // ------------------------------------------------------------------------------------------
