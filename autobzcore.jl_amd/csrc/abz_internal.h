@@ -298,6 +298,21 @@ struct GenSpec {
     bool panels15 = false;  // nodes come as GK(7,15) panels: every aligned run of 15 shares its parent
 };
 int launch_gen_nodes(abz_ctx* ctx, const GenSpec& gs);
+
+// store-free PTR sums (kernels.hip): rule(f, B) of a full grid / slab without materialising the rule
+struct SumSpec {
+    int n, d, M, first, npt;
+    const double2* src;   // level-1 sets, one per line
+    const double2* tab;
+    int64_t nlines, line0;
+    int integrand, n_sweep;
+    const double* sweep_host;
+    double params[4];
+    double scale;
+};
+
+bool eval_sum_supported(int n, int M, int npt, int integrand, bool herm);
+int launch_eval_sum(abz_ctx* ctx, const SumSpec& ss, double* out_reim);
 int launch_gen_reduce(abz_ctx* ctx, const ReduceSpec& rs, double* out_reim);
 
 }  // namespace abz

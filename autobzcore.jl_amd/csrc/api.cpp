@@ -1006,6 +1006,79 @@ int abz_rule_reduce(abz_rule* r, int integrand, const double* params, int nparam
     return launch_reduce(ctx, rs, out_reim);
 }
 
+int abz_ptr_sum(abz_series* s, int npt, int outer_begin, int outer_end, int integrand, const double* params, int nparams,
+                const double* sweep, int n_sweep, int nsyms, double* out_reim) {
+    int rc = check_series(s);
+    if (rc) return rc;
+    ABZ_REQUIRE(out_reim, "null out");
+    ABZ_REQUIRE(npt >= 1 && nsyms >= 1, "npt = %d, nsyms = %d", npt, nsyms);
+    ABZ_REQUIRE(nparams >= 0 && nparams <= 4, "nparams = %d not in 0..4", nparams);
+    const int d = s->d, n = s->n;
+    ABZ_REQUIRE(0 <= outer_begin && outer_begin < outer_end && outer_end <= npt, "slab [%d, %d) outside the grid of %d points",
+                outer_begin, outer_end, npt);
+    ABZ_REQUIRE(d >= 2 || (outer_begin == 0 && outer_end == npt), "a slab needs at least two variables");
+    if (!eval_sum_supported(n, s->dims[0], npt, integrand, s->hermitian)) {
+        set_error("store-free sum not available for this series / grid / integrand (use a rule)");
+        return ABZ_ERR_UNSUPPORTED;
+    }
+    const bool swept = integrand == ABZ_F_DOS || integrand == ABZ_F_TRGLOC || integrand == ABZ_F_GLOC || integrand == ABZ_F_DOS_EIG;
+    ABZ_REQUIRE(!swept || (sweep && n_sweep >= 1), "sweep values required for integrand %d", integrand);
+    const int need = (integrand == ABZ_F_LINEAR || integrand == ABZ_F_LINEAR_X) ? 2 : (swept ? 1 : 0);
+    ABZ_REQUIRE(nparams >= need && (need == 0 || params), "integrand %d needs %d parameters", integrand, need);
+    abz_ctx* ctx = s->ctx;
+    ABZ_HIP(hipSetDevice(ctx->device));
+    Plan plan;
+    plan_full(plan, d, npt, d >= 2 ? outer_begin : 0, d >= 2 ? outer_end - outer_begin : npt);
+    PlanDev pd;
+    DevBuf tab;
+    auto done = [&](int code) {
+        pd.release();
+        tab.release();
+        return code;
+    };
+    if ((rc = make_phase_table(ctx, npt, tab))) return done(rc);
+    for (int L = 1; L < d; ++L) {  // scalar-phase tables of the contraction levels
+        const int M = s->dims[L];
+        if ((rc = pd.phg[L].reserve(sizeof(double2) * (size_t)npt * M))) return done(rc);
+        PhaseSpec ps;
+        ps.B = npt;
+        ps.M = M;
+        ps.first = s->first[L];
+        ps.gi = nullptr;
+        ps.x = nullptr;
+        ps.tab = tab.as<double2>();
+        ps.npt = npt;
+        ps.g0 = 0;
+        ps.gcnt = npt;
+        ps.period = s->period[L];
+        ps.deriv = false;
+        if ((rc = launch_phases(ctx, ps, pd.phg[L].as<double2>()))) return done(rc);
+    }
+    const double2* level1 = nullptr;
+    if ((rc = build_chain(s, plan, pd, tab.as<double2>(), 0, &level1))) return done(rc);
+    SumSpec ss;
+    ss.n = n;
+    ss.d = d;
+    ss.M = s->dims[0];
+    ss.first = s->first[0];
+    ss.npt = npt;
+    ss.src = level1;
+    ss.tab = tab.as<double2>();
+    ss.nlines = d == 1 ? 1 : plan.nitems[1];
+    ss.line0 = (int64_t)(d >= 2 ? outer_begin : 0);
+    for (int j = 0; j + 2 < d; ++j) ss.line0 *= npt;  // lines per outer index: npt^(d-2)
+    ss.integrand = integrand;
+    ss.n_sweep = n_sweep;
+    ss.sweep_host = sweep;
+    for (int i = 0; i < 4; ++i) ss.params[i] = (i < nparams && params) ? params[i] : 0.0;
+    double vol = 1.0;
+    for (int j = 0; j < d; ++j) vol *= (double)npt;
+    ss.scale = 1.0 / (vol * (double)nsyms);
+    rc = launch_eval_sum(ctx, ss, out_reim);
+    (void)hipStreamSynchronize(ctx->stream);
+    return done(rc);
+}
+
 int abz_rule_ggr(abz_rule* r, const double* E, int nE, double* out) {
     ABZ_REQUIRE(r && E && out && nE >= 1, "abz_rule_ggr: bad arguments");
     ABZ_REQUIRE(r->V.base && r->E.base, "GGR needs a rule built with ABZ_WANT_VEL");

@@ -362,6 +362,7 @@ struct EvalArgs {
     const double* x;
     PlaneView H, E, U;
     int64_t nlines, nk;
+    int64_t line0;  // store-free sums on a slab: global index of line 0 (for node coordinates)
     int M, first, npt, deriv, herm;
     int nt;  // non-temporal stores (rule values larger than the Infinity Cache)
     double inv_period;
@@ -428,12 +429,11 @@ constexpr int EVAL_MAX_MNN = 256;  // complex coefficients per line held in LDS 
 // One unit of work of the grid kernels: pass `pass` (64 KPL nodes starting at i0) of line `line`, from the
 // line's coefficients c1 (LDS).  `mid` runs between the m-loop and the stores: the place where the next
 // unit's coefficients are handed to the other LDS buffer.
-template <int N, int KPL, bool HERM, bool VEC, class MID>
-__device__ __forceinline__ void eval_unit(const EvalArgs& a, const double2* __restrict__ c1, const double2* tab_l, int fm,
-                                          const int (&iz0)[KPL], const int (&iw0)[KPL], int npass, int i0, int lane,
-                                          int64_t line, MID&& mid) {
+template <int N, int KPL, bool HERM, class MID>
+__device__ __forceinline__ void eval_unit_core(const EvalArgs& a, const double2* __restrict__ c1, const double2* tab_l, int fm,
+                                               const int (&iz0)[KPL], const int (&iw0)[KPL], int npass, int i0, int lane,
+                                               MID&& mid, CMat<N> (&H)[KPL]) {
     double zr[KPL], zi[KPL], pr[KPL], pi[KPL];
-    CMat<N> H[KPL];
 #pragma unroll
     for (int j = 0; j < KPL; ++j) {
         int ic = iz0[j], iw = iw0[j];
@@ -497,7 +497,15 @@ __device__ __forceinline__ void eval_unit(const EvalArgs& a, const double2* __re
                 }
             }
         }
-        if constexpr (VEC) {
+    }
+}
+
+// The store epilogue of a unit: values of its 64 KPL nodes into the tiled-planar rule arrays.
+template <int N, int KPL, bool VEC>
+__device__ __forceinline__ void eval_unit_store(const EvalArgs& a, CMat<N> (&H)[KPL], int i0, int lane, int64_t line) {
+    if constexpr (VEC) {
+#pragma unroll
+        for (int j = 0; j < KPL; ++j) {
             const int i1 = i0 + lane + 64 * j;
             const int pitch = a.H.base ? a.H.pitch : a.E.pitch;
             if (i1 < pitch) eval_epilogue<N, VEC>(a, H[j], line, i1);
@@ -545,6 +553,15 @@ __device__ __forceinline__ void eval_unit(const EvalArgs& a, const double2* __re
         else
             epilogue(std::false_type{});
     }
+}
+
+template <int N, int KPL, bool HERM, bool VEC, class MID>
+__device__ __forceinline__ void eval_unit(const EvalArgs& a, const double2* __restrict__ c1, const double2* tab_l, int fm,
+                                          const int (&iz0)[KPL], const int (&iw0)[KPL], int npass, int i0, int lane,
+                                          int64_t line, MID&& mid) {
+    CMat<N> H[KPL];
+    eval_unit_core<N, KPL, HERM>(a, c1, tab_l, fm, iz0, iw0, npass, i0, lane, mid, H);
+    eval_unit_store<N, KPL, VEC>(a, H, i0, lane, line);
 }
 
 __device__ __forceinline__ void wave_lds_sync() {
@@ -861,6 +878,7 @@ int launch_eval(abz_ctx* ctx, const EvalSpec& es) {
     a.U = es.U;
     a.nlines = es.nlines;
     a.nk = es.nk;
+    a.line0 = 0;
     a.M = es.M;
     a.first = es.first;
     a.npt = es.npt > 0 ? es.npt : 1;
@@ -1350,6 +1368,272 @@ __global__ __launch_bounds__(256) void final_reduce_kernel(const double2* __rest
         }
         out[col] = make_double2(ar * scale, ai * scale);
     }
+}
+
+// ------------------------------------------------------------------------------------------
+// Store-free PTR: rule(f, B) without materialising the rule.  Same work loop as eval_grid_kernel, but a
+// unit's H(k) go straight into the integrand and the per-lane partial sums; nothing is written per node.
+// For grids that are used once (an AutoPTR refinement step, a single omega) or do not fit in HBM
+// (1000^3 k-points x 168 B = 168 GB): the kernel is bound by the m-loop, ~40 G k-points/s.
+// NW sweep values per launch share the H(k) of a node (their sums live in registers).
+// ------------------------------------------------------------------------------------------
+struct SumArgs {
+    int fid, nw, ncomp, d;
+    double p[4];
+    double sweep[8];
+};
+
+template <int N, int KPL, bool HERM, int FID, int NW>
+__global__ __launch_bounds__(256, 2) void eval_sum_grid_kernel(EvalArgs a, SumArgs q, double2* __restrict__ partial) {
+    extern __shared__ double2 lds_c[];  // [4 waves][2 buffers][MNN] | [npt] table
+    constexpr int NC = NComp<FID>::template value<N>();
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int MNN = a.M * N * N;
+    double2* const mybuf = lds_c + (size_t)wave * 2 * MNN;
+    int fm = a.first % a.npt;
+    if (fm < 0) fm += a.npt;
+    const int npass = (a.npt + 64 * KPL - 1) / (64 * KPL);
+    double2* const tab_l = lds_c + (size_t)4 * 2 * MNN;
+    for (int i = threadIdx.x; i < a.npt; i += 256) tab_l[i] = a.tab[i];
+    __syncthreads();
+    double accr[NW][NC], acci[NW][NC];
+#pragma unroll
+    for (int w = 0; w < NW; ++w) {
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            accr[w][c] = 0.0;
+            acci[w][c] = 0.0;
+        }
+    }
+    const int64_t lstride = (int64_t)gridDim.x * 4;
+    int64_t line = (int64_t)blockIdx.x * 4 + wave;
+    if (line < a.nlines) {
+        const double2* __restrict__ src = a.src + line * MNN;
+#pragma unroll
+        for (int t = 0; t < EVAL_MAX_MNN / 64; ++t) {
+            const int idx = lane + 64 * t;
+            if (idx < MNN) mybuf[idx] = src[idx];
+        }
+    }
+    int iz0[KPL], iw0[KPL];
+#pragma unroll
+    for (int j = 0; j < KPL; ++j) {
+        const int i1 = lane + 64 * j;
+        iz0[j] = i1 < a.npt ? i1 : 0;
+        iw0[j] = (int)(((unsigned)fm * (unsigned)iz0[j]) % (unsigned)a.npt);
+    }
+    [[maybe_unused]] const double eta2 = q.p[0] * q.p[0], teta = 2.0 * q.p[0];
+    int cur = 0, pass = 0;
+    while (line < a.nlines) {
+        const bool last_pass = pass + 1 >= npass;
+        const int64_t nline = last_pass ? line + lstride : line;
+        const bool have_next = nline < a.nlines;
+        double2 pre[EVAL_MAX_MNN / 64];
+        {
+            const double2* __restrict__ src = a.src + (have_next ? nline : line) * MNN;
+#pragma unroll
+            for (int t = 0; t < EVAL_MAX_MNN / 64; ++t) {
+                const int idx = lane + 64 * t;
+                pre[t] = src[idx < MNN ? idx : MNN - 1];
+            }
+        }
+        wave_lds_sync();
+        const int i0 = pass * (64 * KPL);
+        CMat<N> H[KPL];
+        eval_unit_core<N, KPL, HERM>(a, mybuf + (size_t)cur * MNN, tab_l, fm, iz0, iw0, npass, i0, lane, [&]() {
+            if (have_next) {
+                double2* dst = mybuf + (size_t)(cur ^ 1) * MNN;
+#pragma unroll
+                for (int t = 0; t < EVAL_MAX_MNN / 64; ++t) {
+                    const int idx = lane + 64 * t;
+                    if (idx < MNN) dst[idx] = pre[t];
+                }
+            }
+        }, H);
+        // integrand at the unit's nodes
+#pragma unroll
+        for (int j = 0; j < KPL; ++j) {
+            const int i1 = i0 + lane + 64 * j;
+            if (i1 < a.npt) {
+                double xk[ABZ_MAX_DIM] = {0.0, 0.0, 0.0};
+                if constexpr (FID == ABZ_F_LINEAR_X) {
+                    xk[0] = (double)i1 / (double)a.npt;
+                    int64_t r = line + a.line0;  // (i2, i3) of the line, slab offset included
+                    for (int t = 1; t < q.d; ++t) {
+                        xk[t] = (double)(r % a.npt) / (double)a.npt;
+                        r /= a.npt;
+                    }
+                }
+                if constexpr (HERM && (N == 2 || N == 3) && (FID == ABZ_F_DOS || FID == ABZ_F_TRGLOC)) {
+                    CharPolyH cp;
+                    if constexpr (N == 3)
+                        charpoly_init_h3(H[j].re[0][0], H[j].re[1][1], H[j].re[2][2], H[j].re[0][1], H[j].im[0][1], H[j].re[0][2],
+                                         H[j].im[0][2], H[j].re[1][2], H[j].im[1][2], cp);
+                    else
+                        charpoly_init_h2(H[j].re[0][0], H[j].re[1][1], H[j].re[0][1], H[j].im[0][1], cp);
+#pragma unroll
+                    for (int w = 0; w < NW; ++w) {
+                        if (w < q.nw) {
+                            double tr, ti;
+                            charpoly_trace_h<N, FID != ABZ_F_DOS>(cp, q.sweep[w], q.p[0], eta2, teta, tr, ti);
+                            accr[w][0] += (FID == ABZ_F_DOS) ? -ti * 0.31830988618379067153776752674503 : tr;
+                            acci[w][0] += (FID == ABZ_F_DOS) ? 0.0 : ti;
+                        }
+                    }
+                } else {
+                    double e[N];
+                    if constexpr (FID == ABZ_F_DOS_EIG) {
+                        if constexpr (N == 3) {
+                            herm_eig3_values(H[j], e);
+                        } else {
+                            CMat<N> V;
+                            herm_eig<N, false>(H[j], e, V);
+                        }
+                    }
+#pragma unroll
+                    for (int w = 0; w < NW; ++w) {
+                        if (w < q.nw) {
+                            double vr[MAXC], vi[MAXC];
+                            integrand_value<N, FID>(H[j], e, xk, q.d, q.p, q.sweep[w], vr, vi);
+#pragma unroll
+                            for (int c = 0; c < NC; ++c) {
+                                accr[w][c] += vr[c];
+                                acci[w][c] += vi[c];
+                            }
+                        }
+                    }
+                }
+            }
+        }
+        cur ^= 1;
+        pass = last_pass ? 0 : pass + 1;
+        line = nline;
+    }
+    // block partial sums: wave shuffles, then the 4 waves through LDS (after everyone is done with it)
+    __syncthreads();
+    double2* red = lds_c;  // [4][NW * NC]
+#pragma unroll
+    for (int w = 0; w < NW; ++w) {
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const double sr = wave_sum(accr[w][c]);
+            const double si = wave_sum(acci[w][c]);
+            if (lane == 0) red[wave * (NW * NC) + w * NC + c] = make_double2(sr, si);
+        }
+    }
+    __syncthreads();
+    for (int t = threadIdx.x; t < NW * NC; t += 256) {
+        const int w = t / NC, c = t - w * NC;
+        double2 acc = red[t];
+        for (int w2 = 1; w2 < 4; ++w2) {
+            acc.x += red[w2 * (NW * NC) + t].x;
+            acc.y += red[w2 * (NW * NC) + t].y;
+        }
+        if (w < q.nw && c < q.ncomp) partial[(int64_t)blockIdx.x * ((int64_t)q.nw * q.ncomp) + (int64_t)w * q.ncomp + c] = acc;
+    }
+}
+
+bool eval_sum_supported(int n, int M, int npt, int integrand, bool herm) {
+    if (!herm || n < 1 || n > 4 || npt <= 128 || npt >= 65536) return false;
+    const int mnn = M * n * n;
+    if (mnn > EVAL_MAX_MNN || sizeof(double2) * (4 * 2 * (size_t)mnn + (size_t)npt) > 64 * 1024) return false;
+    if ((integrand == ABZ_F_LINEAR || integrand == ABZ_F_LINEAR_X) && n != 1) return false;
+    return integrand >= ABZ_F_ONE && integrand <= ABZ_F_DOS_EIG;
+}
+
+// out_reim [n_sweep][ncomp][2] (host): scale * sum over the nlines * npt nodes
+int launch_eval_sum(abz_ctx* ctx, const SumSpec& ss, double* out_reim) {
+    const int ncomp = integrand_ncomp(ss.integrand, ss.n, ss.d);
+    const bool swept = ss.integrand == ABZ_F_DOS || ss.integrand == ABZ_F_TRGLOC || ss.integrand == ABZ_F_GLOC ||
+                       ss.integrand == ABZ_F_DOS_EIG;
+    const int ns = swept ? ss.n_sweep : 1;
+    if (ss.integrand == ABZ_F_ONE) {  // the sum of ones
+        out_reim[0] = ss.scale * (double)ss.nlines * (double)ss.npt;
+        out_reim[1] = 0.0;
+        return ABZ_OK;
+    }
+    EvalArgs a{};
+    a.src = ss.src;
+    a.tab = ss.tab;
+    a.nlines = ss.nlines;
+    a.nk = ss.nlines * ss.npt;
+    a.line0 = ss.line0;
+    a.M = ss.M;
+    a.first = ss.first;
+    a.npt = ss.npt;
+    a.deriv = 0;
+    a.herm = 1;
+    a.nt = 0;
+    a.inv_period = 1.0;
+    int kpl = 2;
+    {
+        double best = 1e30;
+        for (int k = 2; k <= 3; ++k) {
+            const double cost = (double)(cdiv(ss.npt, 64 * k) * k) * (1.0 + 0.3 / k);
+            if (cost < best - 1e-12) {
+                best = cost;
+                kpl = k;
+            }
+        }
+    }
+    const int mnn = ss.M * ss.n * ss.n;
+    const size_t lds = sizeof(double2) * (4 * 2 * (size_t)mnn + (size_t)ss.npt);
+    const int64_t blocks = std::min<int64_t>(cdiv(ss.nlines, 4), 256 * 8);
+    // scalar integrands: up to 8 sweep values share the H(k) of a node (must match the NW of the dispatch below)
+    const int nwmax = (ss.integrand == ABZ_F_GLOC || ss.integrand == ABZ_F_LINEAR_X) ? 1 : 8;
+    int rc = ctx->scratch[1].reserve(sizeof(double2) * (size_t)(blocks * nwmax * ncomp));
+    if (rc) return rc;
+    if ((rc = ctx->scratch[2].reserve(sizeof(double2) * (size_t)(nwmax * ncomp)))) return rc;
+    double2* partial = ctx->scratch[1].as<double2>();
+    double2* outd = ctx->scratch[2].as<double2>();
+    for (int s0 = 0; s0 < ns; s0 += nwmax) {
+        SumArgs q;
+        q.fid = ss.integrand;
+        q.nw = std::min(nwmax, ns - s0);
+        q.ncomp = ncomp;
+        q.d = ss.d;
+        for (int i = 0; i < 4; ++i) q.p[i] = ss.params[i];
+        for (int w = 0; w < 8; ++w) q.sweep[w] = (swept && w < q.nw) ? ss.sweep_host[s0 + w] : 0.0;
+        {
+            ProfScope ps(ctx, ABZ_K_EVAL);
+#define SUMK(NN, KK, FF, WW) \
+    hipLaunchKernelGGL((eval_sum_grid_kernel<NN, KK, true, FF, WW>), dim3((unsigned)blocks), dim3(256), lds, ctx->stream, a, q, partial)
+#define SUMN(NN, FF, WW)   \
+    if (kpl == 2) {        \
+        SUMK(NN, 2, FF, WW); \
+    } else {               \
+        SUMK(NN, 3, FF, WW); \
+    }
+#define SUMF(FF, WW)                               \
+    switch (ss.n) {                                \
+        case 1: SUMN(1, FF, WW) break;             \
+        case 2: SUMN(2, FF, WW) break;             \
+        case 3: SUMN(3, FF, WW) break;             \
+        default: SUMN(4, FF, WW) break;            \
+    }
+            switch (ss.integrand) {
+                case ABZ_F_LINEAR: SUMN(1, ABZ_F_LINEAR, 8) break;
+                case ABZ_F_LINEAR_X: SUMN(1, ABZ_F_LINEAR_X, 1) break;
+                case ABZ_F_DOS: SUMF(ABZ_F_DOS, 8) break;
+                case ABZ_F_TRGLOC: SUMF(ABZ_F_TRGLOC, 8) break;
+                case ABZ_F_GLOC: SUMF(ABZ_F_GLOC, 1) break;
+                case ABZ_F_DOS_EIG: SUMF(ABZ_F_DOS_EIG, 8) break;
+                default: set_error("store-free sum: integrand %d", ss.integrand); return ABZ_ERR_UNSUPPORTED;
+            }
+#undef SUMF
+#undef SUMN
+#undef SUMK
+            ABZ_HIP(hipGetLastError());
+            const int64_t ncols = (int64_t)q.nw * ncomp;
+            hipLaunchKernelGGL(final_reduce_kernel, dim3((unsigned)ncols), dim3(256), 0, ctx->stream, partial, blocks, ncols,
+                               ss.scale, outd);
+            ABZ_HIP(hipGetLastError());
+        }
+        ABZ_HIP(hipMemcpyAsync(out_reim + 2 * (size_t)s0 * ncomp, outd, sizeof(double2) * (size_t)(q.nw * ncomp),
+                               hipMemcpyDeviceToHost, ctx->stream));
+        ABZ_HIP(hipStreamSynchronize(ctx->stream));
+    }
+    return ABZ_OK;
 }
 
 // nodes per thread: the wave reduction per sweep value is amortised over KT nodes; the cheap

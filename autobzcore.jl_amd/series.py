@@ -144,6 +144,44 @@ class DeviceSeries:
             out.append(E)
         return out[0] if len(out) == 1 else tuple(out)
 
+    # ---- store-free rule values
+    stream_above_bytes = 32 << 30  # rules beyond this many bytes are summed on the fly instead of being cached
+
+    def ptr_sum_supported(self, npt, fid):
+        s = self.s
+        return (s.n <= 4 and npt > 128 and self.hermitian() and
+                not (fid in (L.F_LINEAR, L.F_LINEAR_X) and s.n != 1))
+
+    def hermitian(self):
+        """H_{-R} = H_R^dagger on the stored coefficient array (what the library detects at upload)."""
+        c = self.s.c
+        flip = c[tuple(slice(None, None, -1) for _ in range(self.s.d))]
+        sym = all(2 * f + m - 1 == 0 for f, m in zip(np.atleast_1d(self.s.first), c.shape[:self.s.d]))
+        return bool(sym and np.array_equal(c, np.conj(np.swapaxes(flip, -1, -2))))
+
+    def ptr_sum(self, npt, fid, params=(), sweep=None, nsyms=1):
+        """rule(f, B) on the full npt^d grid without materialising H(k) (abz_ptr_sum); with `kshard` set, this
+        rank's slab followed by the all-reduce.  Returns complex [n_sweep, ncomp] like DeviceRule.reduce."""
+        s = self.s
+        ncomp = {L.F_GLOC: s.n * s.n, L.F_LINEAR_X: s.d}.get(fid, 1)
+        params = np.ascontiguousarray(np.asarray(params, dtype=np.float64).reshape(-1))
+        swept = fid in (L.F_DOS, L.F_TRGLOC, L.F_GLOC, L.F_DOS_EIG)
+        if swept:
+            sw = np.ascontiguousarray(np.asarray(sweep, dtype=np.float64).reshape(-1))
+            ns, psw = len(sw), sw.ctypes.data_as(L.c_f64p)
+        else:
+            ns, psw = 1, None
+        out = np.zeros((ns, ncomp, 2))
+        z0, z1 = 0, int(npt)
+        if self.kshard and self.kshard[1] > 1:
+            z0, z1 = slab_range(int(npt), *self.kshard)
+        if z1 > z0:
+            L.check(L.lib().abz_ptr_sum(self.h, int(npt), z0, z1, fid, params.ctypes.data_as(L.c_f64p) if len(params) else None,
+                                        len(params), psw, ns, int(nsyms), out.ctypes.data_as(L.c_f64p)))
+        if self.kshard and self.kshard[1] > 1:
+            out = self.allreduce(out)
+        return out.view(np.complex128).reshape(ns, ncomp)
+
     # ---- cached PTR rules
     def rule(self, npt, syms=None, want=L.WANT_H):
         """Cached rule.  With `self.kshard = (rank, world)` set (dist.kshard) the rule holds this rank's
@@ -168,6 +206,11 @@ class DeviceSeries:
                 old.close()
         self.rules[key] = r  # most recently used last
         return r
+
+    def has_rule(self, npt, syms=None, want=L.WANT_H):
+        """Is a rule serving this request already resident?"""
+        k0, k1 = int(npt), _syms_key(syms)
+        return any(n2 == k0 and s2 == k1 and (w2 & want) == want and k2 == self.kshard for (n2, s2, w2, k2) in self.rules)
 
     def drop_rules(self):
         for r in self.rules.values():

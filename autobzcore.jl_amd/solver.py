@@ -453,18 +453,33 @@ def _ptr_rule_values(f: FourierIntegrand, dev, npt, syms, plist):
     Device integrands that share their fixed parameters are reduced in ONE fused pass."""
     fi = f.f.f
     if isinstance(fi, DeviceIntegrand):
-        rule = dev.rule(npt, syms, _want_for(fi))
         bound = [fi.bind(p) for p in plist]
         out = [None] * len(plist)
         groups = {}
         for i, (params, sw) in enumerate(bound):
             groups.setdefault(tuple(params), []).append(i)
+        # A full grid whose values would not be worth (or not fit) keeping: sum it on the fly (abz_ptr_sum)
+        want = _want_for(fi)
+        n, d = f.w.n, f.w.d
+        nk = int(npt) ** d
+        rule_bytes = nk * (16 * n * n if want & L.WANT_H else 8 * n)
+        stream = (syms is None and rule_bytes > dev.stream_above_bytes and not dev.has_rule(npt, syms, want) and
+                  dev.ptr_sum_supported(npt, fi.fid))
+        rule = None
         for params, idxs in groups.items():
             sweeps = [bound[i][1] for i in idxs] if fi.swept else None
-            vals = rule.reduce(fi.fid, params, sweeps)
+            vals = None
+            if stream:
+                try:
+                    vals = dev.ptr_sum(npt, fi.fid, params, sweeps)
+                except L.AbzError:
+                    stream = False  # the library declined (e.g. its own Hermiticity test): use a rule
+            if vals is None:
+                rule = rule or dev.rule(npt, syms, want)
+                vals = rule.reduce(fi.fid, params, sweeps)
             for j, i in enumerate(idxs):
                 out[i] = _shape_value(f, vals[j if fi.swept else 0])
-        return out, rule.nk
+        return out, (rule.nk if rule is not None else nk)
     # host path: H(k) batch back to the host, user closure per node (ref: quadsum)
     rule = dev.rule(npt, syms, L.WANT_H)
     data = rule.export(x=True, w=True, H=True)

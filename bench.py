@@ -322,6 +322,28 @@ def main():
                 out["configs_end_to_end"] = cfg
             except Exception as e:
                 out["configs_end_to_end"] = {"error": str(e)}
+            # store-free rule values (abz_ptr_sum): the 1000^3 grid (10^9 k-points, 168 GB if it were stored)
+            try:
+                dev0 = s.device()
+                dev0.ptr_sum(300, L.F_DOS, [a.eta], [12.5])
+                sf = {}
+                for nw in (1, 8):
+                    om = np.linspace(12.0, 13.0, nw)
+                    t0 = time.perf_counter()
+                    dev0.ptr_sum(1000, L.F_DOS, [a.eta], om)
+                    dt = time.perf_counter() - t0
+                    sf[f"seconds_{nw}_omega"] = dt
+                    sf[f"kpoints_per_sec_{nw}_omega"] = 1e9 / dt
+                sol_s = abz.IntegralSolver(abz.FourierIntegrand(abz.DOSIntegrand(), s, 0.01), abz.load_bz(abz.FBZ(), 3.85856 * np.eye(3)),
+                                           abz.EvalCounter(abz.AutoPTR()), abstol=1e-3)
+                t0 = time.perf_counter()
+                r_s = sol_s.solve_p(abz.MixedParameters(12.5))
+                sf["autoptr_fbz_eta0.01"] = {"u": r_s.u, "resid": r_s.resid, "numevals": r_s.numevals,
+                                             "seconds": time.perf_counter() - t0}
+                sf["note"] = "DOS on the 1000^3 full-BZ grid without materialising H(k): Fourier evaluation feeds the integrand"
+                out["store_free_1000cubed"] = sf
+            except Exception as e:
+                out["store_free_1000cubed"] = {"error": str(e)}
             # config 5: synthetic 16-band model, IAI on the full BZ (380 M adaptive nodes)
             try:
                 s16 = abz.synthetic_wannier()

@@ -155,6 +155,16 @@ int abz_rule_export(abz_rule* r, double* x, double* w, double* H, double* eig, d
 int abz_rule_reduce(abz_rule* r, int integrand, const double* params, int nparams,
                     const double* sweep, int n_sweep, int nsyms, double* out_reim);
 
+/* Store-free rule value: the same number as abz_rule_reduce on the full grid (or on the slab
+ * [outer_begin, outer_end) of its outermost variable), computed without materialising H(k): the
+ * Fourier evaluation feeds the integrand directly and only the sums leave the kernel.  For grids that are
+ * used once (an AutoPTR refinement step) or do not fit in HBM (1000^3 k-points = 168 GB of rule values).
+ * Hermitian series, n <= 4, npt > 128; ABZ_ERR_UNSUPPORTED otherwise (build a rule instead).
+ * Replaces: FourierPTR ctor + rule(f, B) back to back (src/fourier.jl:166-207). */
+int abz_ptr_sum(abz_series* s, int npt, int outer_begin, int outer_end, int integrand,
+                const double* params, int nparams, const double* sweep, int n_sweep, int nsyms,
+                double* out_reim);
+
 /* Replaces: sum_ggr / ggr_formula (src/dos_ggr.jl:58-104) for nE energies; rule must hold VEL. */
 int abz_rule_ggr(abz_rule* r, const double* E, int nE, double* out);
 

@@ -541,6 +541,56 @@ def test_iai_over_general_convex_zones(abz):
     assert abs(sol3.u - ref2[0]) <= 1e-9 * abs(ref2[0])
 
 
+@pytest.mark.parametrize("d,n,npt", [(1, 2, 300), (2, 3, 150), (2, 1, 200), (3, 3, 131), (3, 4, 129), (3, 2, 140)])
+def test_store_free_rule_value_equals_rule_reduce(abz, d, n, npt):
+    """abz_ptr_sum: rule(f, B) without materialising the rule (grids used once / beyond HBM).  Same numbers as
+    abz_rule_reduce on the cached rule for every integrand, sweeps longer than one launch, slabs, and through
+    the solver when the rule would exceed `stream_above_bytes`."""
+    rng = np.random.default_rng(700 + 10 * d + n)
+    c, first = rand_series(rng, (5, 3, 3)[:d], n, hermitian=True)
+    s, _ = both(abz, c / 2, first)
+    dev = s.device()
+    L = abz._lib
+    rule = dev.rule(npt, None, L.WANT_H | L.WANT_EIG)
+    om = np.linspace(-1.5, 1.5, 11)  # 11 > 8 sweep values: two launches
+    for fid in (L.F_DOS, L.F_TRGLOC, L.F_DOS_EIG, L.F_GLOC):
+        ref = rule.reduce(fid, [0.3], om)
+        got = dev.ptr_sum(npt, fid, [0.3], om)
+        assert np.abs(got - ref).max() <= 1e-12 * np.abs(ref).max(), fid
+    assert abs(dev.ptr_sum(npt, L.F_ONE)[0, 0] - 1.0) < 1e-14
+    if n == 1:
+        for fid in (L.F_LINEAR, L.F_LINEAR_X):
+            ref = rule.reduce(fid, [1.3, 0.25])
+            got = dev.ptr_sum(npt, fid, [1.3, 0.25])
+            assert np.abs(got - ref).max() <= 1e-12 * np.abs(ref).max(), fid
+    if d >= 2:  # slabs add up (k-sharded streaming)
+        tot = 0
+        for r in range(3):
+            dev.kshard, dev.allreduce = (r, 3), (lambda a: a)
+            try:
+                tot = tot + dev.ptr_sum(npt, L.F_DOS, [0.3], om[:3])
+                if n == 1:
+                    totx = dev.ptr_sum(npt, L.F_LINEAR_X, [1.3, 0.25]) + (totx if r else 0)
+            finally:
+                dev.kshard, dev.allreduce = None, None
+        assert np.abs(tot - rule.reduce(L.F_DOS, [0.3], om[:3])).max() <= 1e-12
+        if n == 1:
+            assert np.abs(totx - rule.reduce(L.F_LINEAR_X, [1.3, 0.25])).max() <= 1e-12
+    # through the solver: a rule "too large to keep" is summed on the fly, the value is the same
+    bz = abz.load_bz(abz.FBZ(), np.eye(d))
+    solver = abz.IntegralSolver(abz.FourierIntegrand(abz.DOSIntegrand(), s, 0.3), bz, abz.PTR(npt=npt + 1))
+    ref = solver(0.2)
+    dev.drop_rules()
+    old = dev.stream_above_bytes
+    dev.stream_above_bytes = 0
+    try:
+        got = solver(0.2)
+        assert not dev.has_rule(npt + 1, None, L.WANT_H)  # nothing was materialised
+    finally:
+        dev.stream_above_bytes = old
+    assert abs(got - ref) <= 1e-12 * abs(ref)
+
+
 # ------------------------------------------------------------------ generic n (wave-per-node kernels)
 @pytest.mark.parametrize("d,n", [(1, 5), (2, 8), (3, 6), (3, 16)])
 def test_generic_n_eval_and_rules(abz, d, n):
