@@ -256,6 +256,16 @@ function AutoBZCore.batchsolve(s::IntegralSolver{<:HIPFourierIntegrand,<:Symmetr
     return j * ns .* real.(out)
 end
 
+# ---------------------------------------------------------------- store-free rule value
+"rule(f, B) on the full npt^d grid without materialising FourierPTR (abz_ptr_sum): grids used once or beyond HBM."
+function ptr_sum(hs::HIPSeries, npt::Integer, f, params::Vector{Float64}, omegas::Vector{Float64}; z0=0, z1=npt, nsyms=1)
+    out = Vector{ComplexF64}(undef, length(omegas))
+    GC.@preserve params omegas out check(ccall((:abz_ptr_sum, libabz), Cint,
+        (Ptr{Cvoid}, Cint, Cint, Cint, Cint, Ptr{Float64}, Cint, Ptr{Float64}, Cint, Cint, Ptr{ComplexF64}),
+        hs.h, npt, z0, z1, fid(f), params, length(params), omegas, length(omegas), nsyms, out))
+    return out
+end
+
 # ---------------------------------------------------------------- k-sharded rules (one solve on several GPUs)
 """
     slab_rule(hs, npt, rank, world, want)
