@@ -1,0 +1,71 @@
+/* Plain-C client of the C ABI (include/abzhip.h): no Python, no C++ -- the way a host language binds it.
+ * Config 1 of BASELINE.json: s(x) = cos(2 pi x) (coefficients [0.5, 0, 0.5], offset -2 .. here first = -1),
+ * f = 1.3 s + 1 integrates to 1 per unit cell, through PTR (rule + reduce), the store-free sum, IAI and
+ * abz_eval_nodes.  Exit code 0 = all checks passed, 77 = no GPU (ABZ_ERR_NOGPU), anything else = failure. */
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+
+#include "abzhip.h"
+
+#define CHECK(call)                                                              \
+    do {                                                                         \
+        int rc_ = (call);                                                        \
+        if (rc_ != ABZ_OK) {                                                     \
+            fprintf(stderr, "%s -> %d: %s\n", #call, rc_, abz_last_error());     \
+            return rc_ == ABZ_ERR_NOGPU ? 77 : 1;                                \
+        }                                                                        \
+    } while (0)
+
+int main(void) {
+    abz_ctx* ctx = NULL;
+    CHECK(abz_ctx_create(0, &ctx));
+    /* 1-D scalar series: coefficients (re, im) of e^{2 pi i m x}, m = -1, 0, 1 */
+    const double coef[6] = {0.5, 0.0, 0.0, 0.0, 0.5, 0.0};
+    const int32_t dims[1] = {3}, first[1] = {-1};
+    const double period[1] = {1.0};
+    abz_series* s = NULL;
+    CHECK(abz_series_create(ctx, coef, 1, dims, first, period, 1, &s));
+
+    /* H(k) at explicit nodes */
+    const double k[3] = {0.0, 0.25, 0.5};
+    double H[3 * 2];
+    CHECK(abz_eval_nodes(s, k, 3, ABZ_WANT_H, H, NULL));
+    if (fabs(H[0] - 1.0) > 1e-14 || fabs(H[2]) > 1e-14 || fabs(H[4] + 1.0) > 1e-14) {
+        fprintf(stderr, "eval_nodes: %g %g %g\n", H[0], H[2], H[4]);
+        return 2;
+    }
+
+    /* PTR: cached rule + reduction of f = 1.3 s + 1 */
+    abz_rule* r = NULL;
+    CHECK(abz_ptr_rule_build(s, 50, 0, NULL, NULL, ABZ_WANT_H, &r));
+    const double p[2] = {1.3, 1.0};
+    double out[2];
+    CHECK(abz_rule_reduce(r, ABZ_F_LINEAR, p, 2, NULL, 0, 1, out));
+    if (fabs(out[0] - 1.0) > 1e-14 || fabs(out[1]) > 1e-14) {
+        fprintf(stderr, "rule_reduce: %.17g %.17g\n", out[0], out[1]);
+        return 3;
+    }
+    CHECK(abz_rule_destroy(r));
+
+    /* the same without materialising the rule (grids of more than 128 points) */
+    CHECK(abz_ptr_sum(s, 400, 0, 400, ABZ_F_LINEAR, p, 2, NULL, 0, 1, out));
+    if (fabs(out[0] - 1.0) > 1e-14) {
+        fprintf(stderr, "ptr_sum: %.17g\n", out[0]);
+        return 4;
+    }
+
+    /* IAI (nested Gauss-Kronrod, here one level) on [0, 1] */
+    const double a[1] = {0.0}, b[1] = {1.0};
+    double err = 0.0;
+    int64_t nev = 0, npan = 0;
+    CHECK(abz_iai_solve(s, ABZ_LIMS_CUBIC, a, b, ABZ_F_LINEAR, p, 2, 0.0, 1e-10, -1.0, 0, 0, out, &err, &nev, NULL, 0, &npan));
+    if (fabs(out[0] - 1.0) > 1e-9 || nev < 15) {
+        fprintf(stderr, "iai_solve: %.17g err %g numevals %lld\n", out[0], err, (long long)nev);
+        return 5;
+    }
+    CHECK(abz_series_destroy(s));
+    CHECK(abz_ctx_destroy(ctx));
+    printf("abi_smoke ok: numevals(IAI) = %lld, library version %d\n", (long long)nev, abz_version());
+    return 0;
+}

@@ -185,3 +185,27 @@ def test_sweep_archive_layout_and_partial_flush(tmp_path):
     assert z["done"].all() and np.array_equal(z["I"], out) and np.array_equal(z["numevals"], np.full(10, 15))
     assert np.allclose(z["args/1"], np.linspace(0, 1, 10)) and np.allclose(z["kwargs/b"], 0.5 * np.arange(10))
     assert np.allclose(z["E"], 1e-4) and z["retcode"].dtype == np.int32 and np.all(z["retcode"] == 1)
+
+
+def _build_c_client(tmp_path):
+    """gcc -std=c11 on tests/c/abi_smoke.c against include/abzhip.h and the in-tree libabzhip.so."""
+    import subprocess
+    exe = tmp_path / "abi_smoke"
+    libdir = os.path.join(ROOT, "autobzcore.jl_amd")
+    cmd = ["gcc", "-std=c11", "-Wall", "-Wextra", "-Werror", "-O1", "-I", os.path.join(ROOT, "include"),
+           os.path.join(ROOT, "tests", "c", "abi_smoke.c"), "-o", str(exe), "-L", libdir, "-labzhip", "-lm",
+           "-Wl,-rpath," + libdir]
+    out = subprocess.run(cmd, capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr
+    return exe
+
+
+def test_header_is_plain_c_and_a_c_client_links(tmp_path):
+    """The boundary is a C ABI: the header compiles as C11 with -Wall -Wextra -Werror and a plain-C program
+    links against the library.  Without a GPU it must stop at abz_ctx_create with ABZ_ERR_NOGPU (exit 77)."""
+    import subprocess
+    exe = _build_c_client(tmp_path)
+    run = subprocess.run([str(exe)], capture_output=True, text=True)
+    assert run.returncode in (0, 77), run.stdout + run.stderr
+    if run.returncode == 77:
+        assert "no CPU fallback" in run.stderr

@@ -591,6 +591,15 @@ def test_store_free_rule_value_equals_rule_reduce(abz, d, n, npt):
     assert abs(got - ref) <= 1e-12 * abs(ref)
 
 
+def test_plain_c_client_of_the_abi(tmp_path):
+    """tests/c/abi_smoke.c: config 1 (1-D cos series, f = 1.3 s + 1 -> 1) through eval_nodes, rule + reduce,
+    the store-free sum and IAI, from plain C."""
+    import subprocess
+    from test_abi_cpu import _build_c_client
+    run = subprocess.run([str(_build_c_client(tmp_path))], capture_output=True, text=True)
+    assert run.returncode == 0 and "abi_smoke ok" in run.stdout, run.stdout + run.stderr
+
+
 # ------------------------------------------------------------------ generic n (wave-per-node kernels)
 @pytest.mark.parametrize("d,n", [(1, 5), (2, 8), (3, 6), (3, 16)])
 def test_generic_n_eval_and_rules(abz, d, n):
