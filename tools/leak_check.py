@@ -1,0 +1,37 @@
+"""Device-memory leak check: many series / rules / solves created and dropped; free memory must come back
+(up to the allocator's cache, ABZ_POOL_MB)."""
+import gc, os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+import torch
+import autobzcore.jl_amd as abz
+L = abz._lib
+rng = np.random.default_rng(0)
+def free_gb():
+    torch.cuda.synchronize()
+    return torch.cuda.mem_get_info()[0] / 2**30
+svo = abz.load_w90_series(os.path.join(ROOT, "tests", "golden", "svo_hr.dat.gz"))
+svo.device().rule(16, None, L.WANT_H)  # context up
+f0 = free_gb()
+t0 = time.time()
+for it in range(120):
+    n = int(rng.integers(1, 5)); d = int(rng.integers(1, 4))
+    dims = tuple(int(rng.choice([3, 5])) for _ in range(d))
+    c = rng.standard_normal(dims + (n, n)) + 1j * rng.standard_normal(dims + (n, n))
+    flip = c[tuple(slice(None, None, -1) for _ in dims)]
+    c = 0.5 * (c + np.conj(np.swapaxes(flip, -1, -2)))
+    s = abz.FourierSeries(c, period=1.0, first=tuple(-(m // 2) for m in dims), ndim=d)
+    bz = abz.load_bz(abz.FBZ() if it % 2 else abz.InversionSymIBZ(), np.eye(d))
+    for alg in (abz.PTR(npt=int(rng.integers(8, 60))), abz.IAI()):
+        abz.IntegralSolver(abz.FourierIntegrand(abz.DOSIntegrand(), s, 0.4), bz, alg, abstol=1e-2)(0.1)
+    if it % 10 == 0:
+        r = abz.DeviceRule(svo.device(), 150, None, 3); r.rebuild(); r.close()
+    del s
+    if it % 30 == 29:
+        gc.collect()
+        print(f"iter {it+1}: free {free_gb():.2f} GiB (start {f0:.2f})", flush=True)
+gc.collect()
+f1 = free_gb()
+print(f"done in {time.time()-t0:.1f} s: free at start {f0:.2f} GiB, at end {f1:.2f} GiB, difference {f0-f1:.2f} GiB (pool cap 4 GiB)")
+assert f0 - f1 < 4.5
