@@ -10,6 +10,9 @@ pipeline and holds no golden vectors; every pin used by tests/test_oracle_pins.p
 known answer from the reference's own tests/docs:
   test/fourier.jl:40-56, test/brillouin.jl:15-44, test/interface_tests.jl:90-158,
   test/dos.jl:88-132, docs/src/examples.md:60,105, src/AutoBZCore.jl:14-17.
+The polytope limits (PolyhedralLimits / PolygonLimits) restate ext/SymmetryReduceBZExt.jl:15-58 and
+ext/ibzlims.jl:198-289, which ARE part of the reference tree; they are pinned by volumes, by the
+tetrahedral special case and by exact slices (tests/test_oracle_pins.py).
 
 The arithmetic of the path lives in un-vendored Julia packages (pins from Project.toml:36-53
 and aps_example/Manifest.toml): FourierSeriesEvaluators 1.x, AutoSymPTR 0.4.x,
