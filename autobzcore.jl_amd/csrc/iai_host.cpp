@@ -11,7 +11,7 @@
 #include <algorithm>
 #include <cmath>
 #include <complex>
-#include <memory>
+#include <deque>
 #include <cstdlib>
 #include <cstring>
 #include <vector>
@@ -64,7 +64,24 @@ struct Lims {
     int kind;
     double a[ABZ_MAX_DIM], b[ABZ_MAX_DIM];
     double s;
-    std::shared_ptr<const std::vector<double>> poly;
+    // polytope data: owned by the arena of the solve (raw pointers: a Lims is copied for every kid of every
+    // round, reference counting there cost a third of the sweep time of the reference's demo)
+    const std::vector<double>* poly = nullptr;
+    std::deque<std::vector<double>>* arena = nullptr;
+    // end points of variable L without touching the heap (every kid of every round asks for them)
+    bool range(int L, double& lo, double& hi) const {
+        if (kind == ABZ_LIMS_CUBIC) {
+            lo = a[L - 1];
+            hi = b[L - 1];
+            return true;
+        }
+        if (kind == ABZ_LIMS_TETRAHEDRAL) {
+            lo = 0.0;
+            hi = a[L - 1] * s;
+            return true;
+        }
+        return false;  // polytopes: several break points, see segs()
+    }
     void segs(int L, std::vector<double>& out) const {  // break points of variable L (1-based)
         out.clear();
         if (kind == ABZ_LIMS_CUBIC) {
@@ -89,11 +106,18 @@ struct Lims {
         }
     }
     Lims fix(int L, double x) const {  // limits of variables 1..L-1 once variable L is fixed
+        if (kind <= ABZ_LIMS_TETRAHEDRAL) {  // the hot case, inlined into the kid loops
+            Lims r = *this;
+            if (kind == ABZ_LIMS_TETRAHEDRAL) r.s = x / a[L - 1];
+            return r;
+        }
+        return fix_poly(L, x);
+    }
+    __attribute__((noinline)) Lims fix_poly(int L, double x) const {
 #pragma clang fp contract(off)
         Lims r = *this;
-        if (kind == ABZ_LIMS_TETRAHEDRAL) {
-            r.s = x / a[L - 1];
-        } else if (kind == ABZ_LIMS_POLYHEDRAL) {
+        (void)L;
+        if (kind == ABZ_LIMS_POLYHEDRAL) {
             const std::vector<double>& f = *poly;
             std::vector<double> pts;  // (x, y) pairs
             for (size_t i = 0; i < f.size();) {
@@ -130,13 +154,14 @@ struct Lims {
             std::vector<std::pair<double, size_t>> ang(np);
             for (size_t k = 0; k < np; ++k) ang[k] = {std::atan2(pts[2 * k + 1] - cy, pts[2 * k] - cx), k};
             std::stable_sort(ang.begin(), ang.end(), [](const auto& u, const auto& v) { return u.first < v.first; });
-            auto pg = std::make_shared<std::vector<double>>(2 * np);
+            arena->emplace_back(2 * np);
+            std::vector<double>& pg = arena->back();
             for (size_t k = 0; k < np; ++k) {
-                (*pg)[2 * k] = pts[2 * ang[k].second];
-                (*pg)[2 * k + 1] = pts[2 * ang[k].second + 1];
+                pg[2 * k] = pts[2 * ang[k].second];
+                pg[2 * k + 1] = pts[2 * ang[k].second + 1];
             }
             r.kind = ABZ_LIMS_POLYGON;
-            r.poly = pg;
+            r.poly = &pg;
         } else if (kind == ABZ_LIMS_POLYGON) {
             const std::vector<double>& v = *poly;
             const size_t nv = v.size() / 2;
@@ -158,7 +183,7 @@ struct Lims {
                 }
             }
             r.kind = ABZ_LIMS_CUBIC;
-            r.poly.reset();
+            r.poly = nullptr;
             r.a[0] = lb;
             r.b[0] = ub;
         }
@@ -345,7 +370,7 @@ int IaiDriver::solve_inner_device(std::vector<Quad1D>& kids) {
     for (int64_t i = 0; i < nq; ++i) {
         const Quad1D& k = kids[(size_t)i];
         slot[(size_t)i] = k.slot;
-        {
+        if (!k.lims.range(1, lo[(size_t)i], hi[(size_t)i])) {
             std::vector<double> sg;
             k.lims.segs(1, sg);
             lo[(size_t)i] = sg.front();
@@ -450,10 +475,15 @@ int IaiDriver::solve_level(int L, std::vector<Quad1D>& quads) {
     std::vector<size_t> active;
     for (size_t i = 0; i < quads.size(); ++i) {
         Quad1D& q = quads[i];
-        std::vector<double> sg;
-        q.lims.segs(L, sg);
         q.pend.clear();
-        for (size_t k = 0; k + 1 < sg.size(); ++k) q.pend.push_back(Seg{sg[k], sg[k + 1], 0.0, 0});
+        double lo1, hi1;
+        if (q.lims.range(L, lo1, hi1)) {
+            q.pend.push_back(Seg{lo1, hi1, 0.0, 0});
+        } else {
+            std::vector<double> sg;
+            q.lims.segs(L, sg);
+            for (size_t k = 0; k + 1 < sg.size(); ++k) q.pend.push_back(Seg{sg[k], sg[k + 1], 0.0, 0});
+        }
         q.popped.clear();
         q.started = false;
         q.done = false;
@@ -509,9 +539,14 @@ int IaiDriver::solve_level(int L, std::vector<Quad1D>& quads) {
                         k.tail[0] = x;
                         for (int j = 1; j < ABZ_MAX_DIM; ++j) k.tail[j] = q.tail[j - 1];
                         k.lims = q.lims.fix(L, x);
-                        std::vector<double> sg;
-                        k.lims.segs(L - 1, sg);
-                        const double len = sg.back() - sg.front();  // ref: len = segs[end] - segs[1]
+                        double lo1, hi1;
+                        if (!k.lims.range(L - 1, lo1, hi1)) {
+                            std::vector<double> sg;
+                            k.lims.segs(L - 1, sg);
+                            lo1 = sg.front();
+                            hi1 = sg.back();
+                        }
+                        const double len = hi1 - lo1;  // ref: len = segs[end] - segs[1]
                         k.has_atol = q.has_atol;
                         k.atol = q.has_atol ? q.atol / len : 0.0;  // ref src/fourier.jl:479-480
                     }
@@ -646,11 +681,13 @@ int abz_iai_solve_many(abz_series* s, int lims_kind, const double* lim_a, const 
     ABZ_REQUIRE(lims_kind == ABZ_LIMS_TETRAHEDRAL || lim_b, "these limits need lim_b");
     ABZ_REQUIRE(lims_kind != ABZ_LIMS_POLYHEDRAL || s->d == 3, "PolyhedralLimits are for 3 variables");
     ABZ_REQUIRE(lims_kind != ABZ_LIMS_POLYGON || s->d == 2, "PolygonLimits are for 2 variables");
-    std::shared_ptr<const std::vector<double>> poly;
+    std::deque<std::vector<double>> arena;  // the polytope and every polygon sliced from it during this solve
+    const std::vector<double>* poly = nullptr;
     if (lims_kind >= ABZ_LIMS_POLYHEDRAL) {
         const int64_t len = (int64_t)lim_b[0];
         ABZ_REQUIRE(len >= 6, "polytope description too short");
-        poly = std::make_shared<std::vector<double>>(lim_a, lim_a + len);
+        arena.emplace_back(lim_a, lim_a + len);
+        poly = &arena.back();
         if (lims_kind == ABZ_LIMS_POLYHEDRAL) {  // [nv, xyz * nv] per face
             int64_t i = 0;
             while (i < len) {
@@ -699,6 +736,7 @@ int abz_iai_solve_many(abz_series* s, int lims_kind, const double* lim_a, const 
         q.lims.kind = lims_kind;
         q.lims.s = 1.0;
         q.lims.poly = poly;
+        q.lims.arena = &arena;
         for (int j = 0; j < s->d; ++j) {
             q.lims.a[j] = lims_kind < ABZ_LIMS_POLYHEDRAL ? lim_a[j] : 0.0;
             q.lims.b[j] = (lims_kind < ABZ_LIMS_POLYHEDRAL && lim_b) ? lim_b[j] : 0.0;
