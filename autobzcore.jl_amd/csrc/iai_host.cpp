@@ -285,6 +285,12 @@ struct IaiDriver {
     int eval_nodes(int64_t nn);
     int solve_level(int L, std::vector<Quad1D>& quads);
     int solve_inner_device(std::vector<Quad1D>& kids);
+    int solve_inner_device_flat(int64_t nq, std::vector<cd>& vals);
+    // structure-of-arrays description of the innermost integrals of a round (no per-integral objects)
+    std::vector<int64_t> f_slot;
+    std::vector<int> f_root;
+    std::vector<double> f_lo, f_hi, f_at, f_sw, f_tl;
+    std::vector<char> f_out;
 };
 
 // upload h_parents/h_x, contract level-L sets into level-(L-1) pool slots base_slot..base_slot+nn-1
@@ -360,6 +366,105 @@ int IaiDriver::eval_nodes(int64_t nn) {
 
 // All integrals of `kids` integrate variable 1: run their whole adaptive loops on the device
 // (inner_adaptive_kernel); an integral that overflows the device segment store is redone on the host.
+// The same from structure-of-arrays input (f_slot, f_lo, ...), results straight into vals [nq][ncomp]:
+// a 432-solve sweep creates ~35 M innermost integrals, one heap-backed Quad1D each cost 4/5 of its time.
+int IaiDriver::solve_inner_device_flat(int64_t nq, std::vector<cd>& vals) {
+    vals.resize((size_t)(nq * ncomp));
+    if (nq == 0) return ABZ_OK;
+    const bool need_tail = integrand == ABZ_F_LINEAR_X && d > 1;
+    int rc;
+    const size_t in_bytes = sizeof(int64_t) * (size_t)nq + sizeof(double) * (size_t)nq * 4;
+    if ((rc = s->iai_io[0].reserve(in_bytes))) return rc;
+    char* base = static_cast<char*>(s->iai_io[0].p);
+    int64_t* d_slot = reinterpret_cast<int64_t*>(base);
+    double* d_lo = reinterpret_cast<double*>(base + sizeof(int64_t) * (size_t)nq);
+    double* d_hi = d_lo + nq;
+    double* d_at = d_hi + nq;
+    double* d_sw = d_at + nq;
+    ABZ_HIP(hipMemcpyAsync(d_sw, f_sw.data(), sizeof(double) * (size_t)nq, hipMemcpyHostToDevice, ctx->stream));
+    ABZ_HIP(hipMemcpyAsync(d_slot, f_slot.data(), sizeof(int64_t) * (size_t)nq, hipMemcpyHostToDevice, ctx->stream));
+    ABZ_HIP(hipMemcpyAsync(d_lo, f_lo.data(), sizeof(double) * (size_t)nq, hipMemcpyHostToDevice, ctx->stream));
+    ABZ_HIP(hipMemcpyAsync(d_hi, f_hi.data(), sizeof(double) * (size_t)nq, hipMemcpyHostToDevice, ctx->stream));
+    ABZ_HIP(hipMemcpyAsync(d_at, f_at.data(), sizeof(double) * (size_t)nq, hipMemcpyHostToDevice, ctx->stream));
+    double* d_tail = nullptr;
+    if (need_tail) {
+        if ((rc = s->iai_io[2].reserve(sizeof(double) * (size_t)(nq * (d - 1))))) return rc;
+        d_tail = s->iai_io[2].as<double>();
+        ABZ_HIP(hipMemcpyAsync(d_tail, f_tl.data(), sizeof(double) * (size_t)(nq * (d - 1)), hipMemcpyHostToDevice, ctx->stream));
+    }
+    const size_t out_bytes = sizeof(double2) * (size_t)(nq * ncomp) + sizeof(double) * (size_t)nq + sizeof(int64_t) * (size_t)nq +
+                             sizeof(int) * (size_t)nq;
+    if ((rc = s->iai_io[3].reserve(out_bytes))) return rc;
+    char* ob = static_cast<char*>(s->iai_io[3].p);
+    InnerSpec is;
+    is.n = n;
+    is.d = d;
+    is.M = s->dims[0];
+    is.first = s->first[0];
+    is.period = s->period[0];
+    is.src = (d == 1) ? s->coef : s->iai_pool[1].as<double2>();
+    is.nint = nq;
+    is.slot = d_slot;
+    is.lo = d_lo;
+    is.hi = d_hi;
+    is.atol = d_at;
+    is.tail = d_tail;
+    is.integrand = integrand;
+    for (int i = 0; i < 4; ++i) is.params[i] = params[i];
+    is.sweep = sweep;
+    is.sweep_arr = d_sw;
+    is.herm = s->hermitian;
+    is.has_rtol = has_rtol;
+    is.rtol_user = rtol_user;
+    is.maxevals = maxevals;
+    is.I_out = reinterpret_cast<double2*>(ob);
+    is.E_out = reinterpret_cast<double*>(ob + sizeof(double2) * (size_t)(nq * ncomp));
+    is.nev_out = reinterpret_cast<int64_t*>(is.E_out + nq);
+    is.status_out = reinterpret_cast<int*>(is.nev_out + nq);
+    if ((rc = (n > 4 ? launch_gen_inner_adaptive(ctx, is) : launch_inner_adaptive(ctx, is)))) return rc;
+    f_out.resize(out_bytes);
+    ABZ_HIP(hipMemcpyAsync(f_out.data(), ob, out_bytes, hipMemcpyDeviceToHost, ctx->stream));
+    ABZ_HIP(hipStreamSynchronize(ctx->stream));
+    const cd* hI = reinterpret_cast<const cd*>(f_out.data());
+    const double* hE = reinterpret_cast<const double*>(f_out.data() + sizeof(double2) * (size_t)(nq * ncomp));
+    const int64_t* hN = reinterpret_cast<const int64_t*>(hE + nq);
+    const int* hS = reinterpret_cast<const int*>(hN + nq);
+    std::memcpy(vals.data(), hI, sizeof(cd) * (size_t)(nq * ncomp));
+    std::vector<Quad1D> redo;
+    std::vector<int64_t> redo_idx;
+    for (int64_t i = 0; i < nq; ++i) {
+        if (hS[i] != 0) {  // segment store overflow on the device: redo this one with the host loop
+            Quad1D k;
+            k.slot = f_slot[(size_t)i];
+            k.sweep = f_sw[(size_t)i];
+            k.root = f_root[(size_t)i];
+            if (need_tail)
+                for (int j = 0; j < d - 1; ++j) k.tail[j] = f_tl[(size_t)(i * (d - 1) + j)];
+            k.lims.kind = ABZ_LIMS_CUBIC;
+            k.lims.s = 1.0;
+            k.lims.a[0] = f_lo[(size_t)i];
+            k.lims.b[0] = f_hi[(size_t)i];
+            k.has_atol = f_at[(size_t)i] >= 0.0;
+            k.atol = k.has_atol ? f_at[(size_t)i] : 0.0;
+            redo.push_back(k);
+            redo_idx.push_back(i);
+            continue;
+        }
+        total_evals += hN[i];
+        evals_per_root[(size_t)f_root[(size_t)i]] += hN[i];
+    }
+    if (!redo.empty()) {
+        const bool keep = device_inner;
+        device_inner = false;
+        rc = solve_level(1, redo);
+        device_inner = keep;
+        if (rc) return rc;
+        for (size_t j = 0; j < redo.size(); ++j)
+            for (int c = 0; c < ncomp; ++c) vals[(size_t)(redo_idx[j] * ncomp + c)] = redo[j].I[(size_t)c];
+    }
+    return ABZ_OK;
+}
+
 int IaiDriver::solve_inner_device(std::vector<Quad1D>& kids) {
     const int64_t nq = (int64_t)kids.size();
     if (nq == 0) return ABZ_OK;
@@ -525,6 +630,47 @@ int IaiDriver::solve_level(int L, std::vector<Quad1D>& quads) {
             s->iai_used[L - 1] = 0;  // sets of the previous round are dead
             int rc = contract_nodes(L, nn, 0);
             if (rc) return rc;
+            const bool flat = (L - 1 == 1) && device_inner;
+            if (flat) {
+                // innermost integrals as plain arrays (see solve_inner_device_flat)
+                const bool need_tail = integrand == ABZ_F_LINEAR_X && d > 1;
+                f_slot.resize((size_t)nn);
+                f_root.resize((size_t)nn);
+                f_lo.resize((size_t)nn);
+                f_hi.resize((size_t)nn);
+                f_at.resize((size_t)nn);
+                f_sw.resize((size_t)nn);
+                if (need_tail) f_tl.resize((size_t)(nn * (d - 1)));
+                t = 0;
+                for (size_t qi : active) {
+                    Quad1D& q = quads[qi];
+                    for (size_t p = 0; p < q.pend.size(); ++p) {
+                        for (int i = 0; i < 15; ++i, ++t) {
+                            const double x = h_x[(size_t)t];
+                            const Lims kl = q.lims.fix(L, x);
+                            double lo1, hi1;
+                            if (!kl.range(1, lo1, hi1)) {
+                                std::vector<double> sg;
+                                kl.segs(1, sg);
+                                lo1 = sg.front();
+                                hi1 = sg.back();  // the innermost slice of a convex domain is one interval
+                            }
+                            f_slot[(size_t)t] = t;
+                            f_root[(size_t)t] = q.root;
+                            f_sw[(size_t)t] = q.sweep;
+                            f_lo[(size_t)t] = lo1;
+                            f_hi[(size_t)t] = hi1;
+                            f_at[(size_t)t] = q.has_atol ? q.atol / (hi1 - lo1) : -1.0;  // ref src/fourier.jl:479-480
+                            if (need_tail) {
+                                f_tl[(size_t)(t * (d - 1))] = x;
+                                for (int j = 1; j < d - 1; ++j) f_tl[(size_t)(t * (d - 1) + j)] = q.tail[j - 1];
+                            }
+                        }
+                    }
+                }
+                rc = solve_inner_device_flat(nn, vals);
+                if (rc) return rc;
+            } else {
             kids.assign((size_t)nn, Quad1D());
             t = 0;
             for (size_t qi : active) {
@@ -558,6 +704,7 @@ int IaiDriver::solve_level(int L, std::vector<Quad1D>& quads) {
             for (int64_t i = 0; i < nn; ++i)
                 for (int c = 0; c < ncomp; ++c) vals[(size_t)(i * ncomp + c)] = kids[(size_t)i].I[(size_t)c];
         }
+            }
         // ---- deliver: GK sums, heap bookkeeping, next refinement (QuadGK adapt, scalar mode)
         std::vector<size_t> next;
         t = 0;

@@ -18,3 +18,9 @@ abz.batchsolve(solver, om[:8])
 for rep in range(2):
     t0 = time.perf_counter(); v = abz.batchsolve(solver, om); dt = time.perf_counter() - t0
     print(f"432-omega IAI sweep: {dt:.3f} s  (sum {v.sum():.6f})", flush=True)
+ctx = h.device().ctx
+ctx.prof_enable(True); ctx.prof_reset()
+t0 = time.perf_counter(); v = abz.batchsolve(solver, om); dt = time.perf_counter() - t0
+for name, kid in (("contract", L.K_CONTRACT), ("eval/inner", L.K_EVAL)):
+    ms, n = ctx.prof_read(kid); print(f"  {name}: {n} launches, {ms:.1f} ms")
+print(f"  wall {1e3*dt:.1f} ms")
