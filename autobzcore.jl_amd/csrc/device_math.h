@@ -666,6 +666,74 @@ __device__ __forceinline__ void charpoly_trace_h(const CharPolyH& cp, double w, 
     tr = NEED_RE ? fma(nr, dr, ni * di) * inv : 0.0;
 }
 
+// N = 4, Hermitian: characteristic polynomial of B = H - (tr H / 4) I by Faddeev-LeVerrier,
+// p(w) = w^4 + c2 w^2 + c3 w + c4 with REAL coefficients (c1 = -tr B = 0):
+//   M2 = B,  c2 = -tr(B M2)/2;  M3 = B M2 + c2 I,  c3 = -tr(B M3)/3;  M4 = B M3 + c3 I,  c4 = -tr(B M4)/4.
+// ~700 flops once per node; every sweep value then costs ~36 instead of a 4x4 complex inversion.
+struct CharPolyH4 {
+    double q, c2, c3, c4;
+};
+__device__ __forceinline__ void charpoly_init_h4(const CMat<4>& H, CharPolyH4& cp) {
+    const double q = 0.25 * (H.re[0][0] + H.re[1][1] + H.re[2][2] + H.re[3][3]);
+    CMat<4> B = H;
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+        B.re[a][a] -= q;
+        B.im[a][a] = 0.0;
+    }
+    // P = B * M (complex 4x4); only Re tr(B M) and the matrix itself are needed
+    auto mul = [&](const CMat<4>& M, CMat<4>& P) {
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                double pr = 0.0, pi = 0.0;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    pr = fma(B.re[a][k], M.re[k][b], pr);
+                    pr = fma(-B.im[a][k], M.im[k][b], pr);
+                    pi = fma(B.re[a][k], M.im[k][b], pi);
+                    pi = fma(B.im[a][k], M.re[k][b], pi);
+                }
+                P.re[a][b] = pr;
+                P.im[a][b] = pi;
+            }
+        }
+    };
+    CMat<4> P2, P3, P4;
+    mul(B, P2);  // B^2
+    const double c2 = -0.5 * (P2.re[0][0] + P2.re[1][1] + P2.re[2][2] + P2.re[3][3]);
+#pragma unroll
+    for (int a = 0; a < 4; ++a) P2.re[a][a] += c2;  // M3
+    mul(P2, P3);
+    const double c3 = -(1.0 / 3.0) * (P3.re[0][0] + P3.re[1][1] + P3.re[2][2] + P3.re[3][3]);
+#pragma unroll
+    for (int a = 0; a < 4; ++a) P3.re[a][a] += c3;  // M4
+    mul(P3, P4);
+    cp.q = q;
+    cp.c2 = c2;
+    cp.c3 = c3;
+    cp.c4 = -0.25 * (P4.re[0][0] + P4.re[1][1] + P4.re[2][2] + P4.re[3][3]);
+}
+// tr inv((w + i eta) I - H) = p'(z) / p(z), z = (w - q) + i eta
+template <bool NEED_RE>
+__device__ __forceinline__ void charpoly_trace_h4(const CharPolyH4& cp, double w, double eta, double eta2, double teta,
+                                                  double& tr, double& ti) {
+    const double zr = w - cp.q;
+    const double z2r = fma(zr, zr, -eta2), z2i = teta * zr;
+    // p = (z^2 + c2) z^2 + c3 z + c4
+    const double ar = z2r + cp.c2;
+    const double dr = fma(ar, z2r, fma(-z2i, z2i, fma(cp.c3, zr, cp.c4)));
+    const double di = fma(ar, z2i, fma(z2i, z2r, cp.c3 * eta));
+    // p' = z (4 z^2 + 2 c2) + c3
+    const double br = fma(4.0, z2r, 2.0 * cp.c2), bi = 4.0 * z2i;
+    const double nr = fma(zr, br, fma(-eta, bi, cp.c3));
+    const double ni = fma(zr, bi, eta * br);
+    const double inv = fast_rcp(fma(dr, dr, di * di));
+    ti = fma(ni, dr, -(nr * di)) * inv;
+    tr = NEED_RE ? fma(nr, dr, ni * di) * inv : 0.0;
+}
+
 // Hermitian H, matrix-valued resolvent: G(z) = adj(w I - B) / p(w) with B = H - q I traceless,
 // w = z - q, adj(w I - B) = w^2 I + w B + C, C = adj(B) = B^2 + p1 I (Cayley-Hamilton), p as above.
 // Per node: B and C (Hermitian: 9 doubles each) once; per sweep value ~95 flops instead of a 3x3

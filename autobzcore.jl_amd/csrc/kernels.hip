@@ -1179,14 +1179,15 @@ struct ReduceArgs {
 // HERM (rules of a Hermitian series, resolvent traces of n = 2, 3): real polynomial, upper triangle of
 // H only (half of the planes are never read), ~21 instructions per (node, sweep value).
 template <int N, int FID, int KT, bool HERM>
-__global__ __launch_bounds__(256, FID == ABZ_F_GLOC ? (HERM ? 2 : 1) : ((HERM || FID == ABZ_F_DOS_EIG) ? 3 : 1)) void reduce_kernel(ReduceArgs a, double2* __restrict__ partial) {
+__global__ __launch_bounds__(256, FID == ABZ_F_GLOC ? (HERM ? 2 : 1) : ((HERM || FID == ABZ_F_DOS_EIG) ? (N == 4 ? 2 : 3) : 1)) void reduce_kernel(ReduceArgs a, double2* __restrict__ partial) {
     constexpr int NC = NComp<FID>::template value<N>();
     extern __shared__ double2 lds[];  // [chunk][4 waves][NC]
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int64_t base = (int64_t)blockIdx.x * (256 * KT);
     constexpr bool polyH = HERM && (N == 2 || N == 3) && (FID == ABZ_F_DOS || FID == ABZ_F_TRGLOC);
     constexpr bool usePoly0 = !polyH && (N == 2 || N == 3) && (FID == ABZ_F_DOS || FID == ABZ_F_TRGLOC);
-    CMat<N> H[(usePoly0 || (HERM && N == 3 && FID == ABZ_F_GLOC)) ? 1 : KT];  // poly / adjugate mode: H is never kept
+    CMat<N> H[(usePoly0 || (HERM && N == 3 && FID == ABZ_F_GLOC) ||
+               (HERM && N == 4 && (FID == ABZ_F_DOS || FID == ABZ_F_TRGLOC))) ? 1 : KT];  // polynomial modes: H is never kept
     double e[KT][N];
     double wk[KT];
     double xk[KT][ABZ_MAX_DIM];
@@ -1195,6 +1196,8 @@ __global__ __launch_bounds__(256, FID == ABZ_F_GLOC ? (HERM ? 2 : 1) : ((HERM ||
     // n = 2, 3 resolvent traces: characteristic polynomial per node, ~40 flops per sweep value
     constexpr bool usePoly = usePoly0;
     constexpr bool adjG = HERM && N == 3 && FID == ABZ_F_GLOC;  // adjugate form of the 3x3 resolvent
+    constexpr bool poly4 = HERM && N == 4 && (FID == ABZ_F_DOS || FID == ABZ_F_TRGLOC);  // Faddeev-LeVerrier
+    CharPolyH4 cp4[poly4 ? KT : 1];
     CharPoly<(usePoly ? N : 2)> cp[usePoly ? KT : 1];
     CharPolyH cph[polyH ? KT : 1];
     AdjH3 adj[adjG ? KT : 1];
@@ -1231,6 +1234,9 @@ __global__ __launch_bounds__(256, FID == ABZ_F_GLOC ? (HERM ? 2 : 1) : ((HERM ||
             } else {
                 charpoly_init_h2(in[0], in[6 * pp], in[4 * pp], in[5 * pp], cph[j]);
             }
+        } else if constexpr (poly4) {
+            load_planes<N>(H[0], a.H, voff);
+            if constexpr (N == 4) charpoly_init_h4(H[0], cp4[j]);
         } else if constexpr (needH) {
             load_planes<N>(H[(usePoly0 || adjG) ? 0 : j], a.H, voff);
         }
@@ -1280,6 +1286,11 @@ __global__ __launch_bounds__(256, FID == ABZ_F_GLOC ? (HERM ? 2 : 1) : ((HERM ||
                         vr[c] = gr[c];
                         vi[c] = gi[c];
                     }
+                } else if constexpr (poly4) {
+                    double tr, ti;
+                    charpoly_trace_h4<FID != ABZ_F_DOS>(cp4[j], sw, a.p[0], eta2, teta, tr, ti);
+                    vr[0] = (FID == ABZ_F_DOS) ? -ti * 0.31830988618379067153776752674503 : tr;
+                    vi[0] = (FID == ABZ_F_DOS) ? 0.0 : ti;
                 } else if constexpr (polyH) {
                     double tr, ti;
                     charpoly_trace_h<N, FID != ABZ_F_DOS>(cph[j], sw, a.p[0], eta2, teta, tr, ti);
@@ -1291,7 +1302,7 @@ __global__ __launch_bounds__(256, FID == ABZ_F_GLOC ? (HERM ? 2 : 1) : ((HERM ||
                     vr[0] = (FID == ABZ_F_DOS) ? -ti * 0.31830988618379067153776752674503 : tr;
                     vi[0] = (FID == ABZ_F_DOS) ? 0.0 : ti;
                 } else {
-                    integrand_value<N, FID>(H[(usePoly0 || adjG) ? 0 : j], e[j], xk[j], a.d, a.p, sw, vr, vi);
+                    integrand_value<N, FID>(H[(usePoly0 || adjG || poly4) ? 0 : j], e[j], xk[j], a.d, a.p, sw, vr, vi);
                 }
 #pragma unroll
                 for (int c = 0; c < NC; ++c) {
@@ -1480,6 +1491,21 @@ __global__ __launch_bounds__(256, 2) void eval_sum_grid_kernel(EvalArgs a, SumAr
                             acci[w][0] += (FID == ABZ_F_DOS) ? 0.0 : ti;
                         }
                     }
+                } else if (N == 4 && HERM && (FID == ABZ_F_DOS || FID == ABZ_F_TRGLOC) && q.nw >= 3) {
+                    // 4 bands, several sweep values: Faddeev-LeVerrier polynomial once, ~36 flops per value
+                    if constexpr (N == 4) {
+                        CharPolyH4 cp;
+                        charpoly_init_h4(H[j], cp);
+#pragma unroll
+                        for (int w = 0; w < NW; ++w) {
+                            if (w < q.nw) {
+                                double tr, ti;
+                                charpoly_trace_h4<FID != ABZ_F_DOS>(cp, q.sweep[w], q.p[0], eta2, teta, tr, ti);
+                                accr[w][0] += (FID == ABZ_F_DOS) ? -ti * 0.31830988618379067153776752674503 : tr;
+                                acci[w][0] += (FID == ABZ_F_DOS) ? 0.0 : ti;
+                            }
+                        }
+                    }
                 } else {
                     double e[N];
                     if constexpr (FID == ABZ_F_DOS_EIG) {
@@ -1641,6 +1667,7 @@ int launch_eval_sum(abz_ctx* ctx, const SumSpec& ss, double* out_reim) {
 template <int N, int FID, bool HERM>
 constexpr int reduce_kt_of() {
     if (HERM && N == 3 && FID == ABZ_F_GLOC) return 3;  // adjugate state: 21 doubles per node (4 would spill)
+    if (HERM && N == 4 && (FID == ABZ_F_DOS || FID == ABZ_F_TRGLOC)) return 8;  // 4 real coefficients per node
     if (FID == ABZ_F_GLOC || N >= 4) return 1;
     if (FID == ABZ_F_DOS_EIG || ((N == 2 || N == 3) && (FID == ABZ_F_DOS || FID == ABZ_F_TRGLOC))) return 8;
     return 2;
@@ -1671,7 +1698,7 @@ static int launch_reduce_h(abz_ctx* ctx, const ReduceSpec& rs, const ReduceArgs&
 // Hermitian rules take the real-polynomial / adjugate paths where they exist
 template <int N, int FID>
 static int launch_reduce_t(abz_ctx* ctx, const ReduceSpec& rs, const ReduceArgs& a) {
-    constexpr bool canH = (N == 2 || N == 3) && (FID == ABZ_F_DOS || FID == ABZ_F_TRGLOC || (N == 3 && FID == ABZ_F_GLOC));
+    constexpr bool canH = ((N == 2 || N == 3 || N == 4) && (FID == ABZ_F_DOS || FID == ABZ_F_TRGLOC)) || (N == 3 && FID == ABZ_F_GLOC);
     if (canH && rs.herm) return launch_reduce_h<N, FID, canH>(ctx, rs, a);
     return launch_reduce_h<N, FID, false>(ctx, rs, a);
 }
