@@ -1017,7 +1017,9 @@ int abz_ptr_sum(abz_series* s, int npt, int outer_begin, int outer_end, int inte
     ABZ_REQUIRE(0 <= outer_begin && outer_begin < outer_end && outer_end <= npt, "slab [%d, %d) outside the grid of %d points",
                 outer_begin, outer_end, npt);
     ABZ_REQUIRE(d >= 2 || (outer_begin == 0 && outer_end == npt), "a slab needs at least two variables");
-    if (!eval_sum_supported(n, s->dims[0], npt, integrand, s->hermitian)) {
+    const bool generic = n > 4;
+    if (!(generic ? gen_sum_supported(n, s->dims[0], npt, integrand, s->hermitian)
+                  : eval_sum_supported(n, s->dims[0], npt, integrand, s->hermitian))) {
         set_error("store-free sum not available for this series / grid / integrand (use a rule)");
         return ABZ_ERR_UNSUPPORTED;
     }
@@ -1074,7 +1076,7 @@ int abz_ptr_sum(abz_series* s, int npt, int outer_begin, int outer_end, int inte
     double vol = 1.0;
     for (int j = 0; j < d; ++j) vol *= (double)npt;
     ss.scale = 1.0 / (vol * (double)nsyms);
-    rc = launch_eval_sum(ctx, ss, out_reim);
+    rc = generic ? launch_gen_sum(ctx, ss, out_reim) : launch_eval_sum(ctx, ss, out_reim);
     (void)hipStreamSynchronize(ctx->stream);
     return done(rc);
 }

@@ -1559,6 +1559,12 @@ __global__ __launch_bounds__(256, 2) void eval_sum_grid_kernel(EvalArgs a, SumAr
     }
 }
 
+int launch_final_reduce(abz_ctx* ctx, const double2* partial, int64_t nblocks, int64_t ncols, double scale, double2* out) {
+    hipLaunchKernelGGL(final_reduce_kernel, dim3((unsigned)ncols), dim3(256), 0, ctx->stream, partial, nblocks, ncols, scale, out);
+    ABZ_HIP(hipGetLastError());
+    return ABZ_OK;
+}
+
 bool eval_sum_supported(int n, int M, int npt, int integrand, bool herm) {
     if (!herm || n < 1 || n > 4 || npt <= 128 || npt >= 65536) return false;
     const int mnn = M * n * n;

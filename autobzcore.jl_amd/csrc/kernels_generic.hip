@@ -348,16 +348,13 @@ __device__ __forceinline__ double rcp_nr(double x) {  // 1/x, x in the normal ra
 // PAD: the set is staged as [M][NP*NP] with zeros outside the n x n block, so every loop runs to NP with
 // no condition on n (the padding block of A is the identity and stays decoupled: its columns are exact
 // zeros in the real rows).  !PAD: layout [M][n*n], loops guarded by (uniform) comparisons with n.
+// -H(x) row r from the staged set: phases w z^m from their seeds (pr, pi) and z
 template <int NP, bool PAD>
-__device__ __forceinline__ void panel_inverse_row(const double2* coef, double2* myrow, int n, int M, int first,
-                                                  double xx, double sw, double eta, int r, double (&ar)[NP],
-                                                  double (&ai)[NP]) {
+__device__ __forceinline__ void panel_series_row(const double2* coef, int n, int M, double zr, double zi, double pr,
+                                                 double pi, int r, double (&ar)[NP], double (&ai)[NP]) {
     const int ld = PAD ? NP : n;   // column stride of a staged block
     const int nn = ld * ld;
-    const int rr = (PAD || r < n) ? r : n - 1;  // !PAD: padded rows read a valid row and are overwritten below
-    double zr, zi, pr, pi;
-    sincospi(2.0 * xx, &zi, &zr);
-    sincospi(2.0 * ((double)first * xx), &pi, &pr);
+    const int rr = (PAD || r < n) ? r : n - 1;  // !PAD: padded rows read a valid row and are overwritten later
 #pragma unroll
     for (int j = 0; j < NP; ++j) {
         ar[j] = 0.0;
@@ -380,6 +377,11 @@ __device__ __forceinline__ void panel_inverse_row(const double2* coef, double2* 
         pr = nr;
         pi = ni;
     }
+}
+
+// row r of A = (sw + i eta) I - H from the row of -H; padding rows become identity rows
+template <int NP, bool PAD>
+__device__ __forceinline__ void panel_shift_row(int n, double sw, double eta, int r, double (&ar)[NP], double (&ai)[NP]) {
 #pragma unroll
     for (int j = 0; j < NP; ++j) {
         if (!PAD && r >= n) {  // padding rows: identity, decoupled from the n x n block
@@ -391,7 +393,11 @@ __device__ __forceinline__ void panel_inverse_row(const double2* coef, double2* 
             ai[j] += (r < n) ? eta : 0.0;
         }
     }
-    // in-place inversion; pivots of the padding block are 1 and change nothing
+}
+
+// in-place inversion of the matrix whose row r this lane holds; pivots of the padding block are 1 and change nothing
+template <int NP, bool PAD>
+__device__ __forceinline__ void panel_invert_rows(double2* myrow, int n, int r, double (&ar)[NP], double (&ai)[NP]) {
 #pragma unroll
     for (int c = 0; c < NP; ++c) {
         if (PAD || c < n) {  // uniform
@@ -427,6 +433,18 @@ __device__ __forceinline__ void panel_inverse_row(const double2* coef, double2* 
         }
     }
     wave_sync();
+}
+
+template <int NP, bool PAD>
+__device__ __forceinline__ void panel_inverse_row(const double2* coef, double2* myrow, int n, int M, int first,
+                                                  double xx, double sw, double eta, int r, double (&ar)[NP],
+                                                  double (&ai)[NP]) {
+    double zr, zi, pr, pi;
+    sincospi(2.0 * xx, &zi, &zr);
+    sincospi(2.0 * ((double)first * xx), &pi, &pr);
+    panel_series_row<NP, PAD>(coef, n, M, zr, zi, pr, pi, r, ar, ai);
+    panel_shift_row<NP, PAD>(n, sw, eta, r, ar, ai);
+    panel_invert_rows<NP, PAD>(myrow, n, r, ar, ai);
 }
 
 // stage one coefficient set [M][n*n] into LDS, zero-padded to [M][NP*NP] when PAD
@@ -503,6 +521,144 @@ __global__ __launch_bounds__(256) void gen_panel_kernel(GenArgs a) {
             }
         }
     }
+}
+
+// ------------------------------------------------------------------------------------------
+// Store-free PTR for n > 4: rule(f, B) of a full grid for resolvent-trace integrands.  One workgroup per
+// grid line (its coefficient set staged in LDS, as in the panel kernels), a node per NP-lane group: the row
+// of -H(k) is computed once and re-used for up to 4 sweep values (shift, invert, trace), the traces are
+// accumulated per group and reduced at the end.  Nothing is written per node.
+// ------------------------------------------------------------------------------------------
+struct GenSumArgs {
+    const double2* src;   // level-1 sets [nlines][M][n*n]
+    const double2* tab;   // phase table [npt]
+    double2* partial;     // [gridDim.x][nw]
+    int64_t nlines;
+    int n, M, first, npt, nw, is_dos;
+    double eta;
+    double sweep[4];
+};
+
+template <int NP, bool PAD>
+__global__ __launch_bounds__(256) void gen_grid_sum_kernel(GenSumArgs a) {
+    extern __shared__ double2 lds_gs[];
+    constexpr int SLOTS = 256 / NP;
+    const int n = a.n, nn = n * n, M = a.M;
+    double2* coef = lds_gs;
+    double2* prow = coef + (size_t)M * (PAD ? NP * NP : nn);
+    double2* red = prow + (size_t)SLOTS * 2 * NP;  // [SLOTS][4]
+    const int slot = threadIdx.x / NP, r = threadIdx.x % NP;
+    double2* myrow = prow + (size_t)slot * 2 * NP;
+    int fm = a.first % a.npt;
+    if (fm < 0) fm += a.npt;
+    double accr[4] = {0.0, 0.0, 0.0, 0.0}, acci[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int64_t line = blockIdx.x; line < a.nlines; line += gridDim.x) {
+        __syncthreads();
+        panel_stage<NP, PAD>(coef, a.src + line * ((int64_t)M * nn), n, M);
+        __syncthreads();
+        for (int i0 = 0; i0 < a.npt; i0 += SLOTS) {
+            const int i1 = i0 + slot;
+            const bool act = i1 < a.npt;
+            const int ic = act ? i1 : 0;
+            const double2 z = a.tab[ic];
+            const double2 w = a.tab[(int)(((unsigned)fm * (unsigned)ic) % (unsigned)a.npt)];
+            double hr[NP], hi[NP];
+            panel_series_row<NP, PAD>(coef, n, M, z.x, z.y, w.x, w.y, r, hr, hi);
+            for (int q = 0; q < a.nw; ++q) {  // uniform
+                double ar[NP], ai[NP];
+#pragma unroll
+                for (int j = 0; j < NP; ++j) {
+                    ar[j] = hr[j];
+                    ai[j] = hi[j];
+                }
+                panel_shift_row<NP, PAD>(n, a.sweep[q], a.eta, r, ar, ai);
+                panel_invert_rows<NP, PAD>(myrow, n, r, ar, ai);
+                double tr, ti;
+                panel_trace<NP>(ar, ai, n, r, tr, ti);
+                if (act) {
+                    accr[q] += a.is_dos ? -ti * 0.31830988618379067153776752674503 : tr;
+                    acci[q] += a.is_dos ? 0.0 : ti;
+                }
+            }
+        }
+    }
+    __syncthreads();
+    if (r == 0)
+        for (int q = 0; q < 4; ++q) red[slot * 4 + q] = make_double2(accr[q], acci[q]);
+    __syncthreads();
+    if (threadIdx.x < a.nw) {
+        double sr = 0.0, si = 0.0;
+        for (int sl = 0; sl < SLOTS; ++sl) {
+            sr += red[sl * 4 + threadIdx.x].x;
+            si += red[sl * 4 + threadIdx.x].y;
+        }
+        a.partial[(int64_t)blockIdx.x * a.nw + threadIdx.x] = make_double2(sr, si);
+    }
+}
+
+bool gen_sum_supported(int n, int M, int npt, int integrand, bool herm) {
+    if (n <= 4 || n > ABZ_MAX_BANDS || !herm || npt < 1 || npt >= 65536) return false;
+    if (!(integrand == ABZ_F_DOS || integrand == ABZ_F_TRGLOC)) return false;
+    const int np = n <= 8 ? 8 : (n <= 16 ? 16 : 32);
+    const size_t rest = sizeof(double2) * ((size_t)(256 / np) * 2 * np + (size_t)(256 / np) * 4);
+    return sizeof(double2) * (size_t)M * n * n + rest <= 150 * 1024;
+}
+
+int launch_gen_sum(abz_ctx* ctx, const SumSpec& ss, double* out_reim) {
+    const int n = ss.n, M = ss.M;
+    const int np = n <= 8 ? 8 : (n <= 16 ? 16 : 32);
+    const size_t rest = sizeof(double2) * ((size_t)(256 / np) * 2 * np + (size_t)(256 / np) * 4);
+    size_t lds = sizeof(double2) * (size_t)M * np * np + rest;
+    const bool pad = lds <= 150 * 1024;
+    if (!pad) lds = sizeof(double2) * (size_t)M * n * n + rest;
+    const int64_t blocks = std::min<int64_t>(ss.nlines, 256 * 2);
+    int rc = ctx->scratch[1].reserve(sizeof(double2) * (size_t)(blocks * 4));
+    if (rc) return rc;
+    if ((rc = ctx->scratch[2].reserve(sizeof(double2) * 4))) return rc;
+    GenSumArgs a;
+    a.src = ss.src;
+    a.tab = ss.tab;
+    a.partial = ctx->scratch[1].as<double2>();
+    a.nlines = ss.nlines;
+    a.n = n;
+    a.M = M;
+    a.first = ss.first;
+    a.npt = ss.npt;
+    a.is_dos = ss.integrand == ABZ_F_DOS ? 1 : 0;
+    a.eta = ss.params[0];
+    for (int s0 = 0; s0 < ss.n_sweep; s0 += 4) {
+        a.nw = std::min(4, ss.n_sweep - s0);
+        for (int q = 0; q < 4; ++q) a.sweep[q] = q < a.nw ? ss.sweep_host[s0 + q] : 0.0;
+        {
+            ProfScope ps(ctx, ABZ_K_EVAL);
+#define ABZ_GS2(NPV, PV)                                                                                              \
+    ABZ_HIP(hipFuncSetAttribute((const void*)gen_grid_sum_kernel<NPV, PV>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                (int)lds));                                                                           \
+    hipLaunchKernelGGL((gen_grid_sum_kernel<NPV, PV>), dim3((unsigned)blocks), dim3(256), lds, ctx->stream, a);
+#define ABZ_GS(NPV)   \
+    if (pad) {        \
+        ABZ_GS2(NPV, true) \
+    } else {          \
+        ABZ_GS2(NPV, false) \
+    }
+            if (np == 8) {
+                ABZ_GS(8)
+            } else if (np == 16) {
+                ABZ_GS(16)
+            } else {
+                ABZ_GS(32)
+            }
+#undef ABZ_GS
+#undef ABZ_GS2
+            ABZ_HIP(hipGetLastError());
+            rc = launch_final_reduce(ctx, a.partial, blocks, a.nw, ss.scale, ctx->scratch[2].as<double2>());
+            if (rc) return rc;
+        }
+        ABZ_HIP(hipMemcpyAsync(out_reim + 2 * (size_t)s0, ctx->scratch[2].p, sizeof(double2) * (size_t)a.nw, hipMemcpyDeviceToHost,
+                               ctx->stream));
+        ABZ_HIP(hipStreamSynchronize(ctx->stream));
+    }
+    return ABZ_OK;
 }
 
 static bool gen_panel_supported(const GenSpec& gs, int* np_out, size_t* lds_out, bool* pad_out) {

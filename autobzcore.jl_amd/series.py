@@ -149,7 +149,9 @@ class DeviceSeries:
 
     def ptr_sum_supported(self, npt, fid):
         s = self.s
-        return (s.n <= 4 and npt > 128 and self.hermitian() and
+        if s.n > 4:  # generic-n kernels: resolvent traces only
+            return fid in (L.F_DOS, L.F_TRGLOC) and self.hermitian()
+        return (npt > 128 and self.hermitian() and
                 not (fid in (L.F_LINEAR, L.F_LINEAR_X) and s.n != 1))
 
     def hermitian(self):

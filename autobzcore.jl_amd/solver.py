@@ -463,8 +463,9 @@ def _ptr_rule_values(f: FourierIntegrand, dev, npt, syms, plist):
         n, d = f.w.n, f.w.d
         nk = int(npt) ** d
         rule_bytes = nk * (16 * n * n if want & L.WANT_H else 8 * n)
-        stream = (syms is None and rule_bytes > dev.stream_above_bytes and not dev.has_rule(npt, syms, want) and
-                  dev.ptr_sum_supported(npt, fi.fid))
+        # (more than 4 bands: the store-free panel kernels beat building + scanning a rule at any size)
+        stream = (syms is None and (rule_bytes > dev.stream_above_bytes or n > 4) and
+                  not dev.has_rule(npt, syms, want) and dev.ptr_sum_supported(npt, fi.fid))
         rule = None
         for params, idxs in groups.items():
             sweeps = [bound[i][1] for i in idxs] if fi.swept else None

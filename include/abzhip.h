@@ -159,7 +159,8 @@ int abz_rule_reduce(abz_rule* r, int integrand, const double* params, int nparam
  * [outer_begin, outer_end) of its outermost variable), computed without materialising H(k): the
  * Fourier evaluation feeds the integrand directly and only the sums leave the kernel.  For grids that are
  * used once (an AutoPTR refinement step) or do not fit in HBM (1000^3 k-points = 168 GB of rule values).
- * Hermitian series, n <= 4, npt > 128; ABZ_ERR_UNSUPPORTED otherwise (build a rule instead).
+ * Hermitian series; n <= 4 with npt > 128 (any integrand), or 5..32 bands (resolvent traces DOS / TRGLOC,
+ * any npt); ABZ_ERR_UNSUPPORTED otherwise (build a rule instead).
  * Replaces: FourierPTR ctor + rule(f, B) back to back (src/fourier.jl:166-207). */
 int abz_ptr_sum(abz_series* s, int npt, int outer_begin, int outer_end, int integrand,
                 const double* params, int nparams, const double* sweep, int n_sweep, int nsyms,

@@ -600,6 +600,40 @@ def test_plain_c_client_of_the_abi(tmp_path):
     assert run.returncode == 0 and "abi_smoke ok" in run.stdout, run.stdout + run.stderr
 
 
+@pytest.mark.parametrize("d,n,npt", [(1, 6, 40), (2, 12, 21), (2, 20, 9), (3, 16, 7)])
+def test_store_free_rule_value_generic_n(abz, d, n, npt):
+    """abz_ptr_sum for 5..32 bands (gen_grid_sum_kernel): equals the reduction of the materialised rule, for
+    sweeps longer than one launch (4 values) and through the solver, which prefers it for n > 4."""
+    rng = np.random.default_rng(800 + 10 * d + n)
+    c, first = rand_series(rng, (3, 3, 3)[:d], n, hermitian=True)
+    s, _ = both(abz, c / np.sqrt(n), first)
+    dev = s.device()
+    L = abz._lib
+    rule = abz.DeviceRule(dev, npt, None, L.WANT_H)
+    om = np.linspace(-1.0, 1.0, 6)
+    for fid in (L.F_DOS, L.F_TRGLOC):
+        ref = rule.reduce(fid, [0.3], om)
+        got = dev.ptr_sum(npt, fid, [0.3], om)
+        assert np.abs(got - ref).max() <= 1e-12 * np.abs(ref).max(), fid
+    rule.close()
+    if d >= 2:
+        tot = 0
+        for r in range(2):
+            dev.kshard, dev.allreduce = (r, 2), (lambda a: a)
+            try:
+                tot = tot + dev.ptr_sum(npt, L.F_DOS, [0.3], om[:2])
+            finally:
+                dev.kshard, dev.allreduce = None, None
+        assert np.abs(tot - dev.ptr_sum(npt, L.F_DOS, [0.3], om[:2])).max() <= 1e-13
+    bz = abz.load_bz(abz.FBZ(), np.eye(d))
+    solver = abz.IntegralSolver(abz.FourierIntegrand(abz.DOSIntegrand(), s, 0.3), bz, abz.PTR(npt=npt))
+    val = solver(0.2)
+    assert not dev.has_rule(npt, None, L.WANT_H)  # summed on the fly
+    full = abz.DeviceRule(dev, npt, None, L.WANT_H)
+    ref = full.reduce(L.F_DOS, [0.3], [0.2])[0, 0].real * abs(np.linalg.det(bz.B))
+    assert abs(val - ref) <= 1e-12 * abs(ref)
+
+
 # ------------------------------------------------------------------ generic n (wave-per-node kernels)
 @pytest.mark.parametrize("d,n", [(1, 5), (2, 8), (3, 6), (3, 16)])
 def test_generic_n_eval_and_rules(abz, d, n):
