@@ -589,6 +589,15 @@ def test_store_free_rule_value_equals_rule_reduce(abz, d, n, npt):
     finally:
         dev.stream_above_bytes = old
     assert abs(got - ref) <= 1e-12 * abs(ref)
+    # a series that is not Hermitian is declined by the library (ABZ_ERR_UNSUPPORTED): rules are used instead
+    c2, first2 = rand_series(rng, (3, 3, 3)[:d], n, hermitian=False)
+    s2, _ = both(abz, c2 / 4, first2)
+    d2 = s2.device()
+    with pytest.raises(abz._lib.AbzError):
+        d2.ptr_sum(npt, L.F_TRGLOC, [2.5], [0.1])
+    d2.stream_above_bytes = 0
+    sol2 = abz.IntegralSolver(abz.FourierIntegrand(abz.TrGlocIntegrand(), s2, 2.5), bz, abz.PTR(npt=npt))(0.1)
+    assert d2.has_rule(npt, None, L.WANT_H) and np.isfinite(sol2)
 
 
 def test_plain_c_client_of_the_abi(tmp_path):
