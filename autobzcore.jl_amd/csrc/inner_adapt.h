@@ -10,13 +10,17 @@ namespace abz {
 
 constexpr int ADAPT_MAXC = 16;
 
-struct AdaptState {
+// MAXC = 1: the scalar integrands' instantiation -- every per-component array is one register and no loop
+// over components survives, so the lane that runs the step never touches scratch memory
+template <int MAXC>
+struct AdaptStateT {
     int nseg = 0, nheap = 0, popped = -1, status = 0;
     bool first = true;
     double E = 0.0, atol = 0.0, rtol = 0.0;
     long long numevals = 0;
-    double Ir[ADAPT_MAXC], Ii[ADAPT_MAXC];
+    double Ir[MAXC], Ii[MAXC];
 };
+using AdaptState = AdaptStateT<ADAPT_MAXC>;
 
 struct InnerOut {
     double2* I;
@@ -26,11 +30,12 @@ struct InnerOut {
 };
 
 // ctl: [0] number of pending panels, [1..4] their (a, b) pairs
-__device__ __forceinline__ void adapt_init(AdaptState& st, double at, bool has_rtol, double rtol_user, double lo, double hi,
-                                           double* ctl) {
-    st = AdaptState();
+template <int MAXC>
+__device__ __forceinline__ void adapt_init(AdaptStateT<MAXC>& st, double at, bool has_rtol, double rtol_user, double lo,
+                                           double hi, double* ctl) {
+    st = AdaptStateT<MAXC>();
 #pragma unroll
-    for (int c = 0; c < ADAPT_MAXC; ++c) {
+    for (int c = 0; c < MAXC; ++c) {
         st.Ir[c] = 0.0;
         st.Ii[c] = 0.0;
     }
@@ -45,10 +50,11 @@ __device__ __forceinline__ void adapt_init(AdaptState& st, double at, bool has_r
 // next bisection in ctl (returns false) or writes the result (returns true).
 // REGS: scalar integrands pull the panel values into registers first (worth it where the caller has the
 // registers to spare: the n <= 4 kernel; the generic-n kernels keep their rows in registers instead).
-template <bool REGS = false>
-__device__ inline bool adapt_step(AdaptState& st, int nc, double* seg_a, double* seg_b, double* seg_E, gkc* seg_I,
+template <bool REGS = false, int MAXC = ADAPT_MAXC>
+__device__ inline bool adapt_step(AdaptStateT<MAXC>& st, int nc_, double* seg_a, double* seg_b, double* seg_E, gkc* seg_I,
                                   const gkc* vals, int* heap, double* ctl, long long maxevals, const InnerOut& out) {
     constexpr int MS = ABZ_INNER_MAXSEG;
+    const int nc = MAXC == 1 ? 1 : nc_;
     const int np = (int)ctl[0];
     int newseg[2] = {-1, -1};
     for (int pnl = 0; pnl < np; ++pnl) {
@@ -94,7 +100,7 @@ __device__ inline bool adapt_step(AdaptState& st, int nc, double* seg_a, double*
     } else {
         // I = (I - I_parent) + I_1 + I_2, E likewise; the parent's values are read before its slot is reused
         const int sp = st.popped;
-        double pIr[ADAPT_MAXC], pIi[ADAPT_MAXC];
+        double pIr[MAXC], pIi[MAXC];
         for (int c = 0; c < nc; ++c) {
             pIr[c] = seg_I[(size_t)sp * nc + c].re;
             pIi[c] = seg_I[(size_t)sp * nc + c].im;

@@ -11,6 +11,8 @@
 // A = (omega + i eta) I - H has a positive-definite anti-Hermitian part (eta > 0) whenever H is
 // Hermitian, so elimination without pivoting is backward stable up to a growth factor <= ||A||/eta;
 // that is what the Gauss-Jordan below relies on.
+#include <utility>
+
 #include "abz_internal.h"
 #include "inner_adapt.h"
 
@@ -336,11 +338,29 @@ __global__ __launch_bounds__(256) void gen_node_kernel(GenArgs a, int waves_per_
 //              g_r = -a_rc / p (g_c = 1/p - 1), a_rc <- g_r (a_cc <- 1/p).  n^3 complex FMA per node in
 //              registers instead of the 2 n^3 LDS-resident updates of the wave-per-node kernel.
 // ------------------------------------------------------------------------------------------
+// double2 entries of one node slot's two pivot-row buffers; the NP/4 of padding puts the slots of a wave
+// (64/NP of them, all reading / writing their buffers at once) on different LDS banks
+#ifdef ABZ_PANEL_NOPAD
+__host__ __device__ constexpr int panel_rowbuf(int np) { return 2 * np; }
+#else
+__host__ __device__ constexpr int panel_rowbuf(int np) { return 2 * np + np / 4; }
+#endif
+
 __device__ __forceinline__ double rcp_nr(double x) {  // 1/x, x in the normal range: estimate + 2 Newton steps
     double r = __builtin_amdgcn_rcp(x);
     r = fma(fma(-x, r, 1.0), r, r);
     r = fma(fma(-x, r, 1.0), r, r);
     return r;
+}
+
+// Eight LDS reads in flight, then ONE wait: the empty asm needs all eight values in registers at this
+// point, so the reads are issued back to back instead of one `s_waitcnt` per read (what the scheduler
+// produces on its own under this kernel's register pressure).
+__device__ __forceinline__ void pin8(double2 (&u)[8]) {
+    asm volatile(""
+                 : "+v"(u[0].x), "+v"(u[0].y), "+v"(u[1].x), "+v"(u[1].y), "+v"(u[2].x), "+v"(u[2].y), "+v"(u[3].x),
+                   "+v"(u[3].y), "+v"(u[4].x), "+v"(u[4].y), "+v"(u[5].x), "+v"(u[5].y), "+v"(u[6].x), "+v"(u[6].y),
+                   "+v"(u[7].x), "+v"(u[7].y));
 }
 
 // Row r (lane r of the node's NP lanes) of inv((sw + i eta) I - H(x)) into ar/ai; `coef` = the staged
@@ -362,15 +382,31 @@ __device__ __forceinline__ void panel_series_row(const double2* coef, int n, int
     }
     for (int m = 0; m < M; ++m) {
         const double2* __restrict__ cm = coef + (size_t)m * nn + rr;
+        if constexpr (PAD) {
 #pragma unroll
-        for (int j = 0; j < NP; ++j) {
-            if (PAD || j < n) {  // uniform
-                const double2 c = cm[ld * j];
-                // A = z I - H: accumulate -H
-                ar[j] = fma(-c.x, pr, ar[j]);
-                ar[j] = fma(c.y, pi, ar[j]);
-                ai[j] = fma(-c.x, pi, ai[j]);
-                ai[j] = fma(-c.y, pr, ai[j]);
+            for (int j0 = 0; j0 < NP; j0 += 8) {
+                double2 c[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) c[j] = cm[ld * (j0 + j)];
+                pin8(c);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {  // A = z I - H: accumulate -H
+                    ar[j0 + j] = fma(-c[j].x, pr, ar[j0 + j]);
+                    ar[j0 + j] = fma(c[j].y, pi, ar[j0 + j]);
+                    ai[j0 + j] = fma(-c[j].x, pi, ai[j0 + j]);
+                    ai[j0 + j] = fma(-c[j].y, pr, ai[j0 + j]);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < NP; ++j) {
+                if (j < n) {  // uniform
+                    const double2 c = cm[ld * j];
+                    ar[j] = fma(-c.x, pr, ar[j]);
+                    ar[j] = fma(c.y, pi, ar[j]);
+                    ai[j] = fma(-c.x, pi, ai[j]);
+                    ai[j] = fma(-c.y, pr, ai[j]);
+                }
             }
         }
         const double nr = pr * zr - pi * zi, ni = pr * zi + pi * zr;
@@ -395,44 +431,108 @@ __device__ __forceinline__ void panel_shift_row(int n, double sw, double eta, in
     }
 }
 
-// in-place inversion of the matrix whose row r this lane holds; pivots of the padding block are 1 and change nothing
-template <int NP, bool PAD>
-__device__ __forceinline__ void panel_invert_rows(double2* myrow, int n, int r, double (&ar)[NP], double (&ai)[NP]) {
+// value of `v` in lane C of this lane's NP-lane group (`ds_swizzle_b32`, bit-mask mode: lane' = (lane & ~(NP-1)) | C
+// inside each half wave): the LDS crossbar without an LDS access, 2.2 clk per dword against 14 clk for every
+// `ds_write_b128` of a row published through memory (tools/micro/ldstest.hip)
+template <int NP, int C>
+__device__ __forceinline__ double group_bcast(double v) {
+    constexpr int pattern = ((32 - NP) & 0x1f) | (C << 5);  // and_mask | or_mask << 5, xor_mask 0
+    const int lo = __builtin_amdgcn_ds_swizzle(__double2loint(v), pattern);
+    const int hi = __builtin_amdgcn_ds_swizzle(__double2hiint(v), pattern);
+    return __hiloint2double(hi, lo);
+}
+
+// one Gauss-Jordan pivot (column C) of the zero-padded NP x NP matrix whose row r this lane holds: the pivot
+// row comes from lane C of the group, eight columns at a time (the eight that hold the pivot first)
+template <int NP, int C>
+__device__ __forceinline__ void panel_pivot(int r, double (&ar)[NP], double (&ai)[NP]) {
+    constexpr int NB = NP / 8;
+    double gr = 0.0, gi = 0.0, ipr = 0.0, ipi = 0.0;
 #pragma unroll
-    for (int c = 0; c < NP; ++c) {
-        if (PAD || c < n) {  // uniform
-            double2* buf = myrow + (c & 1) * NP;
-            if (r == c) {
+    for (int b = 0; b < NB; ++b) {
+        const int j0 = 8 * ((C / 8 + b) % NB);
+        double ur[8], ui[8];
 #pragma unroll
-                for (int j = 0; j < NP; ++j)
-                    if (PAD || j < n) buf[j] = make_double2(ar[j], ai[j]);
-            }
-            wave_sync();  // a node's NP lanes live in one wave
-            const double2 p = buf[c];
-            const double inv = rcp_nr(p.x * p.x + p.y * p.y);
-            const double ipr = p.x * inv, ipi = -p.y * inv;  // 1 / pivot
-            const double fr = ar[c], fi = ai[c];
+        for (int j = 0; j < 8; ++j) {
+            ur[j] = group_bcast<NP, C>(ar[j0 + j]);
+            ui[j] = group_bcast<NP, C>(ai[j0 + j]);
+        }
+        if (b == 0) {
+            const double pr = ur[C % 8], pi = ui[C % 8];
+            const double inv = rcp_nr(pr * pr + pi * pi);
+            ipr = pr * inv;
+            ipi = -pi * inv;  // 1 / pivot
+            const double fr = ar[C], fi = ai[C];
             // g = -f / p for the other rows, 1/p - 1 for the pivot row itself
-            double gr = -(fr * ipr - fi * ipi), gi = -(fr * ipi + fi * ipr);
-            if (r == c) {
+            gr = -(fr * ipr - fi * ipi);
+            gi = -(fr * ipi + fi * ipr);
+            if (r == C) {
                 gr = ipr - 1.0;
                 gi = ipi;
             }
+        }
 #pragma unroll
-            for (int j = 0; j < NP; ++j) {
-                if ((PAD || j < n) && j != c) {
-                    const double2 u = buf[j];
-                    ar[j] = fma(gr, u.x, ar[j]);
-                    ar[j] = fma(-gi, u.y, ar[j]);
-                    ai[j] = fma(gr, u.y, ai[j]);
-                    ai[j] = fma(gi, u.x, ai[j]);
-                }
+        for (int j = 0; j < 8; ++j) {
+            if (j0 + j != C) {
+                ar[j0 + j] = fma(gr, ur[j], ar[j0 + j]);
+                ar[j0 + j] = fma(-gi, ui[j], ar[j0 + j]);
+                ai[j0 + j] = fma(gr, ui[j], ai[j0 + j]);
+                ai[j0 + j] = fma(gi, ur[j], ai[j0 + j]);
             }
-            ar[c] = (r == c) ? ipr : gr;
-            ai[c] = (r == c) ? ipi : gi;
         }
     }
-    wave_sync();
+    ar[C] = (r == C) ? ipr : gr;
+    ai[C] = (r == C) ? ipi : gi;
+}
+
+template <int NP, int... C>
+__device__ __forceinline__ void panel_pivots(int r, double (&ar)[NP], double (&ai)[NP], std::integer_sequence<int, C...>) {
+    (panel_pivot<NP, C>(r, ar, ai), ...);
+}
+
+// in-place inversion of the matrix whose row r this lane holds; pivots of the padding block are 1 and change nothing.
+// PAD: pivot rows travel by `group_bcast`, `myrow` is not used.  !PAD: through the slot's LDS row buffers.
+template <int NP, bool PAD>
+__device__ __forceinline__ void panel_invert_rows(double2* myrow, int n, int r, double (&ar)[NP], double (&ai)[NP]) {
+    if constexpr (PAD) {
+        panel_pivots<NP>(r, ar, ai, std::make_integer_sequence<int, NP>());
+        return;
+    } else {
+#pragma unroll
+        for (int c = 0; c < NP; ++c) {
+            if (c < n) {  // uniform
+                double2* buf = myrow + (c & 1) * NP;
+                if (r == c) {
+#pragma unroll
+                    for (int j = 0; j < NP; ++j)
+                        if (j < n) buf[j] = make_double2(ar[j], ai[j]);
+                }
+                wave_sync();  // a node's NP lanes live in one wave
+                const double2 p = buf[c];
+                const double inv = rcp_nr(p.x * p.x + p.y * p.y);
+                const double ipr = p.x * inv, ipi = -p.y * inv;  // 1 / pivot
+                const double fr = ar[c], fi = ai[c];
+                double gr = -(fr * ipr - fi * ipi), gi = -(fr * ipi + fi * ipr);
+                if (r == c) {
+                    gr = ipr - 1.0;
+                    gi = ipi;
+                }
+#pragma unroll
+                for (int j = 0; j < NP; ++j) {
+                    if (j < n && j != c) {
+                        const double2 u = buf[j];
+                        ar[j] = fma(gr, u.x, ar[j]);
+                        ar[j] = fma(-gi, u.y, ar[j]);
+                        ai[j] = fma(gr, u.y, ai[j]);
+                        ai[j] = fma(gi, u.x, ai[j]);
+                    }
+                }
+                ar[c] = (r == c) ? ipr : gr;
+                ai[c] = (r == c) ? ipi : gi;
+            }
+        }
+        wave_sync();
+    }
 }
 
 template <int NP, bool PAD>
@@ -451,13 +551,13 @@ __device__ __forceinline__ void panel_inverse_row(const double2* coef, double2* 
 template <int NP, bool PAD>
 __device__ __forceinline__ void panel_stage(double2* coef, const double2* __restrict__ src, int n, int M) {
     if constexpr (PAD) {
-        for (int t = threadIdx.x; t < M * NP * NP; t += 256) {
+        for (int t = threadIdx.x; t < M * NP * NP; t += blockDim.x) {
             const int m = t / (NP * NP), e = t - m * (NP * NP);
             const int rr = e % NP, j = e / NP;
             coef[t] = (rr < n && j < n) ? src[(size_t)m * n * n + rr + n * j] : make_double2(0.0, 0.0);
         }
     } else {
-        for (int t = threadIdx.x; t < M * n * n; t += 256) coef[t] = src[t];
+        for (int t = threadIdx.x; t < M * n * n; t += blockDim.x) coef[t] = src[t];
     }
 }
 
@@ -489,7 +589,7 @@ __global__ __launch_bounds__(256) void gen_panel_kernel(GenArgs a) {
     double2* coef = lds_p;                    // [M][nn] or [M][NP*NP]
     double2* prow = lds_p + (size_t)M * (PAD ? NP * NP : nn);   // [SLOTS][2][NP] pivot rows (double-buffered)
     const int slot = threadIdx.x / NP, r = threadIdx.x % NP;
-    double2* myrow = prow + (size_t)slot * 2 * NP;
+    double2* myrow = prow + (size_t)slot * panel_rowbuf(NP);
     const int64_t ngroups = a.nnodes / 15;
     for (int64_t g = blockIdx.x; g < ngroups; g += gridDim.x) {
         const int64_t node0 = g * 15;
@@ -546,9 +646,9 @@ __global__ __launch_bounds__(256) void gen_grid_sum_kernel(GenSumArgs a) {
     const int n = a.n, nn = n * n, M = a.M;
     double2* coef = lds_gs;
     double2* prow = coef + (size_t)M * (PAD ? NP * NP : nn);
-    double2* red = prow + (size_t)SLOTS * 2 * NP;  // [SLOTS][4]
+    double2* red = prow + (size_t)SLOTS * panel_rowbuf(NP);  // [SLOTS][4]
     const int slot = threadIdx.x / NP, r = threadIdx.x % NP;
-    double2* myrow = prow + (size_t)slot * 2 * NP;
+    double2* myrow = prow + (size_t)slot * panel_rowbuf(NP);
     int fm = a.first % a.npt;
     if (fm < 0) fm += a.npt;
     double accr[4] = {0.0, 0.0, 0.0, 0.0}, acci[4] = {0.0, 0.0, 0.0, 0.0};
@@ -600,14 +700,14 @@ bool gen_sum_supported(int n, int M, int npt, int integrand, bool herm) {
     if (n <= 4 || n > ABZ_MAX_BANDS || !herm || npt < 1 || npt >= 65536) return false;
     if (!(integrand == ABZ_F_DOS || integrand == ABZ_F_TRGLOC)) return false;
     const int np = n <= 8 ? 8 : (n <= 16 ? 16 : 32);
-    const size_t rest = sizeof(double2) * ((size_t)(256 / np) * 2 * np + (size_t)(256 / np) * 4);
+    const size_t rest = sizeof(double2) * ((size_t)(256 / np) * panel_rowbuf(np) + (size_t)(256 / np) * 4);
     return sizeof(double2) * (size_t)M * n * n + rest <= 150 * 1024;
 }
 
 int launch_gen_sum(abz_ctx* ctx, const SumSpec& ss, double* out_reim) {
     const int n = ss.n, M = ss.M;
     const int np = n <= 8 ? 8 : (n <= 16 ? 16 : 32);
-    const size_t rest = sizeof(double2) * ((size_t)(256 / np) * 2 * np + (size_t)(256 / np) * 4);
+    const size_t rest = sizeof(double2) * ((size_t)(256 / np) * panel_rowbuf(np) + (size_t)(256 / np) * 4);
     size_t lds = sizeof(double2) * (size_t)M * np * np + rest;
     const bool pad = lds <= 150 * 1024;
     if (!pad) lds = sizeof(double2) * (size_t)M * n * n + rest;
@@ -667,9 +767,9 @@ static bool gen_panel_supported(const GenSpec& gs, int* np_out, size_t* lds_out,
     if (!(gs.integrand == ABZ_F_DOS || gs.integrand == ABZ_F_TRGLOC || gs.integrand == ABZ_F_GLOC)) return false;
     if (gs.Hplanes.base || gs.Eplanes.base || gs.Haos || gs.Eaos) return false;
     const int np = gs.n <= 8 ? 8 : (gs.n <= 16 ? 16 : 32);
-    size_t lds = sizeof(double2) * ((size_t)gs.M * np * np + (size_t)(256 / np) * 2 * np);  // zero-padded set
+    size_t lds = sizeof(double2) * ((size_t)gs.M * np * np + (size_t)(256 / np) * panel_rowbuf(np));  // zero-padded set
     *pad_out = lds <= 150 * 1024;
-    if (!*pad_out) lds = sizeof(double2) * ((size_t)gs.M * gs.n * gs.n + (size_t)(256 / np) * 2 * np);
+    if (!*pad_out) lds = sizeof(double2) * ((size_t)gs.M * gs.n * gs.n + (size_t)(256 / np) * panel_rowbuf(np));
     if (lds > 150 * 1024) return false;
     *np_out = np;
     *lds_out = lds;
@@ -1048,15 +1148,15 @@ __global__ __launch_bounds__(256) void gen_inner_adaptive_kernel(GenInnerArgs a,
 // Block-per-integral version of the above for the resolvent-trace integrands: the integral's coefficient
 // set is staged in LDS once and stays there for its whole adaptive loop; each round's 15 / 30 GK nodes
 // are evaluated 256/NP at a time by NP-lane groups (panel_inverse_row), thread 0 runs adapt_step.
-template <int NP, bool PAD>
-__global__ __launch_bounds__(256) void gen_inner_panel_kernel(GenInnerArgs a) {
+template <int NP, bool PAD, int NT, int WPE>
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(WPE ? WPE : 1, WPE ? WPE : 8))) void gen_inner_panel_kernel(GenInnerArgs a) {
     extern __shared__ double2 lds_ip[];
-    constexpr int SLOTS = 256 / NP;
+    constexpr int SLOTS = NT / NP;
     constexpr int MS = ABZ_INNER_MAXSEG;
     const int n = a.n, nn = n * n, M = a.M, nc = a.ncomp;  // nc = 1 (DOS, TRGLOC)
     double2* coef = lds_ip;
     double2* prow = coef + (size_t)M * (PAD ? NP * NP : nn);
-    double* g = reinterpret_cast<double*>(prow + (size_t)SLOTS * 2 * NP);
+    double* g = reinterpret_cast<double*>(prow + (size_t)SLOTS * panel_rowbuf(NP));
     double* seg_a = g;
     double* seg_b = seg_a + MS;
     double* seg_E = seg_b + MS;
@@ -1065,9 +1165,9 @@ __global__ __launch_bounds__(256) void gen_inner_panel_kernel(GenInnerArgs a) {
     int* heap = reinterpret_cast<int*>(vals + (size_t)30 * nc);
     double* ctl = reinterpret_cast<double*>(heap + MS);
     const int slot = threadIdx.x / NP, r = threadIdx.x % NP;
-    double2* myrow = prow + (size_t)slot * 2 * NP;
+    double2* myrow = prow + (size_t)slot * panel_rowbuf(NP);
     for (int64_t q = blockIdx.x; q < a.nint; q += gridDim.x) {
-        AdaptState st;
+        AdaptStateT<1> st;
         __syncthreads();  // the previous integral's readers are done with coef / ctl
         panel_stage<NP, PAD>(coef, a.src + a.slot[q] * ((int64_t)M * nn), n, M);
         if (threadIdx.x == 0) {
@@ -1081,6 +1181,7 @@ __global__ __launch_bounds__(256) void gen_inner_panel_kernel(GenInnerArgs a) {
             const int nnodes = 15 * (int)ctl[0];
             for (int t0 = 0; t0 < nnodes; t0 += SLOTS) {
                 const int t = t0 + slot;
+                if (t0 + (int)(threadIdx.x >> 6) * (64 / NP) >= nnodes) continue;  // no node for this wave in the pass
                 const bool act = t < nnodes;
                 const int tt = act ? t : 0;
                 const int pnl = tt / 15, i = tt - 15 * pnl;
@@ -1106,16 +1207,24 @@ __global__ __launch_bounds__(256) void gen_inner_panel_kernel(GenInnerArgs a) {
                 out.E = a.E_out + q;
                 out.nev = a.nev_out + q;
                 out.status = a.status_out + q;
-                if (adapt_step(st, nc, seg_a, seg_b, seg_E, seg_I, vals, heap, ctl, a.maxevals, out)) ctl[5] = 1.0;
+                if (adapt_step<false, 1>(st, nc, seg_a, seg_b, seg_E, seg_I, vals, heap, ctl, a.maxevals, out)) ctl[5] = 1.0;
             }
         }
     }
 }
 
+// threads of a gen_inner_panel_kernel workgroup: a round's 30 nodes in one pass where the lane groups allow it
+static int gen_inner_panel_threads(int np) {
+    static const int forced = [] { const char* e = getenv("ABZ_IPANEL_THREADS"); return e ? atoi(e) : 0; }();
+    if (forced == 256 || forced == 512) return forced;
+    return np >= 16 ? 512 : 256;
+}
+
 static bool gen_inner_panel_fits(int n, int M, int integrand, int* np_out, size_t* lds_out, bool* pad_out) {
     if (!(integrand == ABZ_F_DOS || integrand == ABZ_F_TRGLOC)) return false;
     const int np = n <= 8 ? 8 : (n <= 16 ? 16 : 32);
-    const size_t rest = sizeof(double2) * (size_t)(256 / np) * 2 * np + sizeof(double) * (size_t)inner_group_doubles(1);
+    const size_t rest = sizeof(double2) * (size_t)(gen_inner_panel_threads(np) / np) * panel_rowbuf(np) +
+                        sizeof(double) * (size_t)inner_group_doubles(1);
     size_t lds = sizeof(double2) * (size_t)M * np * np + rest;  // zero-padded set
     const bool pad = lds <= 150 * 1024;
     if (!pad) lds = sizeof(double2) * (size_t)M * n * n + rest;
@@ -1172,16 +1281,27 @@ int launch_gen_inner_adaptive(abz_ctx* ctx, const InnerSpec& is) {
         if (!off && gen_inner_panel_fits(is.n, is.M, is.integrand, &np, &plds, &pad)) {
             const int64_t blocks = std::min<int64_t>(is.nint, 256 * 8);
             ProfScope ps(ctx, ABZ_K_EVAL);
-#define ABZ_IPANEL2(NPV, PV)                                                                                                \
-    ABZ_HIP(hipFuncSetAttribute((const void*)gen_inner_panel_kernel<NPV, PV>, hipFuncAttributeMaxDynamicSharedMemorySize,  \
-                                (int)plds));                                                                               \
-    hipLaunchKernelGGL((gen_inner_panel_kernel<NPV, PV>), dim3((unsigned)blocks), dim3(256), plds, ctx->stream, a);
+#define ABZ_IPANEL3(NPV, PV, NTV, WV)                                                                          \
+    ABZ_HIP(hipFuncSetAttribute((const void*)gen_inner_panel_kernel<NPV, PV, NTV, WV>,                        \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)plds));                      \
+    hipLaunchKernelGGL((gen_inner_panel_kernel<NPV, PV, NTV, WV>), dim3((unsigned)blocks), dim3(NTV), plds, ctx->stream, a);
+#define ABZ_IPANEL2(NPV, PV)                    \
+    if (nt == 512 && wpe == 4) {                \
+        ABZ_IPANEL3(NPV, PV, 512, 4)            \
+    } else if (nt == 512) {                     \
+        ABZ_IPANEL3(NPV, PV, 512, 0)            \
+    } else {                                    \
+        ABZ_IPANEL3(NPV, PV, 256, 0)            \
+    }
 #define ABZ_IPANEL(NPV) \
     if (pad) {          \
         ABZ_IPANEL2(NPV, true) \
     } else {            \
         ABZ_IPANEL2(NPV, false) \
     }
+            const int nt = gen_inner_panel_threads(np);
+            static const int wpe_env = [] { const char* e = getenv("ABZ_IPANEL_WPE"); return e ? atoi(e) : 0; }();
+            const int wpe = wpe_env ? wpe_env : (nt == 512 ? 4 : 3);
             if (np == 8) {
                 ABZ_IPANEL(8)
             } else if (np == 16) {
@@ -1190,6 +1310,7 @@ int launch_gen_inner_adaptive(abz_ctx* ctx, const InnerSpec& is) {
                 ABZ_IPANEL(32)
             }
 #undef ABZ_IPANEL
+#undef ABZ_IPANEL3
 #undef ABZ_IPANEL2
             ABZ_HIP(hipGetLastError());
             return ABZ_OK;
