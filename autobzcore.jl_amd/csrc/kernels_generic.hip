@@ -640,7 +640,7 @@ struct GenSumArgs {
 };
 
 template <int NP, bool PAD>
-__global__ __launch_bounds__(256) void gen_grid_sum_kernel(GenSumArgs a) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 4))) void gen_grid_sum_kernel(GenSumArgs a) {
     extern __shared__ double2 lds_gs[];
     constexpr int SLOTS = 256 / NP;
     const int n = a.n, nn = n * n, M = a.M;
@@ -664,7 +664,8 @@ __global__ __launch_bounds__(256) void gen_grid_sum_kernel(GenSumArgs a) {
             const double2 w = a.tab[(int)(((unsigned)fm * (unsigned)ic) % (unsigned)a.npt)];
             double hr[NP], hi[NP];
             panel_series_row<NP, PAD>(coef, n, M, z.x, z.y, w.x, w.y, r, hr, hi);
-            for (int q = 0; q < a.nw; ++q) {  // uniform
+#pragma unroll 1
+            for (int q = 0; q < a.nw; ++q) {  // uniform; one copy of the inversion in the code
                 double ar[NP], ai[NP];
 #pragma unroll
                 for (int j = 0; j < NP; ++j) {
@@ -675,9 +676,12 @@ __global__ __launch_bounds__(256) void gen_grid_sum_kernel(GenSumArgs a) {
                 panel_invert_rows<NP, PAD>(myrow, n, r, ar, ai);
                 double tr, ti;
                 panel_trace<NP>(ar, ai, n, r, tr, ti);
-                if (act) {
-                    accr[q] += a.is_dos ? -ti * 0.31830988618379067153776752674503 : tr;
-                    acci[q] += a.is_dos ? 0.0 : ti;
+                const double dr = !act ? 0.0 : (a.is_dos ? -ti * 0.31830988618379067153776752674503 : tr);
+                const double di = (!act || a.is_dos) ? 0.0 : ti;
+#pragma unroll
+                for (int qq = 0; qq < 4; ++qq) {  // static indices: the accumulators stay in registers
+                    accr[qq] += (qq == q) ? dr : 0.0;
+                    acci[qq] += (qq == q) ? di : 0.0;
                 }
             }
         }
@@ -1301,7 +1305,7 @@ int launch_gen_inner_adaptive(abz_ctx* ctx, const InnerSpec& is) {
     }
             const int nt = gen_inner_panel_threads(np);
             static const int wpe_env = [] { const char* e = getenv("ABZ_IPANEL_WPE"); return e ? atoi(e) : 0; }();
-            const int wpe = wpe_env ? wpe_env : (nt == 512 ? 4 : 3);
+            const int wpe = wpe_env ? wpe_env : ((nt == 512 && np <= 16) ? 4 : 0);  // 32 rows x 2 arrays alone fill 128 VGPRs
             if (np == 8) {
                 ABZ_IPANEL(8)
             } else if (np == 16) {
