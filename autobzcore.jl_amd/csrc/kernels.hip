@@ -2163,6 +2163,7 @@ template <int N, int FID, bool HERM>
 __global__ __launch_bounds__(256) void inner_adaptive_kernel(InnerArgs a) {
     extern __shared__ double lds_in[];
     constexpr int MS = ABZ_INNER_MAXSEG;
+    constexpr int NC = NComp<FID>::template value<N>();  // >= a.ncomp; 1 for the scalar integrands
     const int group = threadIdx.x >> 5, l = threadIdx.x & 31;
     const int nc = a.ncomp;
     const int MNN = a.M * N * N;
@@ -2180,7 +2181,7 @@ __global__ __launch_bounds__(256) void inner_adaptive_kernel(InnerArgs a) {
         const int64_t q = q0 + group;
         const bool live = q < a.nint;  // the whole group shares it; both groups of a wave loop together
         // ---- lane 0 state
-        AdaptState st;
+        AdaptStateT<NC> st;
         bool done = !live;
         double tailv[ABZ_MAX_DIM] = {0.0, 0.0, 0.0};
         double swq = a.sweep;
@@ -2240,7 +2241,6 @@ __global__ __launch_bounds__(256) void inner_adaptive_kernel(InnerArgs a) {
                     } else {
                         integrand_value<N, FID>(H, e, xk, a.d, a.p, swq, vr, vi);
                     }
-                    constexpr int NC = NComp<FID>::template value<N>();
 #pragma unroll
                     for (int c = 0; c < NC; ++c) {
                         if (c < nc) {
@@ -2259,7 +2259,7 @@ __global__ __launch_bounds__(256) void inner_adaptive_kernel(InnerArgs a) {
                 out.E = a.E_out + q;
                 out.nev = a.nev_out + q;
                 out.status = a.status_out + q;
-                done = adapt_step<true>(st, nc, seg_a, seg_b, seg_E, seg_I, vals, heap, ctl, a.maxevals, out);
+                done = adapt_step<true, NC>(st, nc, seg_a, seg_b, seg_E, seg_I, vals, heap, ctl, a.maxevals, out);
             }
         }
     }
