@@ -1451,7 +1451,7 @@ __global__ __launch_bounds__(256, 2) void eval_sum_grid_kernel(EvalArgs a, SumAr
         wave_lds_sync();
         const int i0 = pass * (64 * KPL);
         CMat<N> H[KPL];
-        eval_unit_core<N, KPL, HERM>(a, mybuf + (size_t)cur * MNN, tab_l, fm, iz0, iw0, npass, i0, lane, [&]() {
+        eval_unit_core<N, KPL, HERM>(a, mybuf + (size_t)cur * MNN, tab_l, fm, iz0, iw0, npass, i0, lane, [=]() {
             if (have_next) {
                 double2* dst = mybuf + (size_t)(cur ^ 1) * MNN;
 #pragma unroll
