@@ -216,6 +216,7 @@ int integrand_ncomp(int integrand, int n, int d);
 // result: host out_reim [n_sweep][ncomp][2]
 int launch_reduce(abz_ctx* ctx, const ReduceSpec& rs, double* out_reim);
 
+int launch_gen_velocity(abz_ctx* ctx, int n, PlaneView U, PlaneView dH, PlaneView Vj, int64_t nk);
 int launch_ggr(abz_ctx* ctx, int n, int d, int npt, PlaneView E, PlaneView V, const double* w, int64_t nk,
                const double* Es_host, int nE, double* out_host);
 
@@ -286,6 +287,7 @@ struct GenSpec {
     int64_t nnodes;
     PlaneView Hplanes;
     PlaneView Eplanes;
+    PlaneView Uplanes;  // eigenvectors out (velocity builds)
     double2* Haos;
     double* Eaos;
     int integrand;

@@ -753,10 +753,6 @@ static int rule_build(abz_series* s, int npt, int64_t nirr, const int32_t* irr_i
     ABZ_REQUIRE((want & (ABZ_WANT_H | ABZ_WANT_EIG | ABZ_WANT_VEL)) != 0, "want = %d selects nothing", want);
     ABZ_REQUIRE((irr_idx == nullptr) == (wsym == nullptr), "irr_idx and wsym must be given together");
     if (want & ABZ_WANT_VEL) want |= ABZ_WANT_EIG;
-    if (s->n > 4 && (want & ABZ_WANT_VEL)) {
-        set_error("band velocities (GGR) for n = %d > 4 bands are not built in this round", s->n);
-        return ABZ_ERR_UNSUPPORTED;
-    }
     abz_ctx* ctx = s->ctx;
     ABZ_HIP(hipSetDevice(ctx->device));
     const int d = s->d, n = s->n;

@@ -836,11 +836,8 @@ static int eval_occ() {
 
 int launch_eval(abz_ctx* ctx, const EvalSpec& es) {
     if (es.n > 4) {
-        if (es.U.base) {
-            set_error("eigenvectors / velocities for n = %d > 4 bands are not built in this round", es.n);
-            return ABZ_ERR_UNSUPPORTED;
-        }
         GenSpec gs;
+        gs.Uplanes = es.U;
         gs.n = es.n;
         gs.M = es.M;
         gs.first = es.first;
@@ -1059,6 +1056,7 @@ __global__ __launch_bounds__(256) void velocity_kernel(PlaneView Uv, PlaneView D
 
 int launch_velocity(abz_ctx* ctx, int n, PlaneView U, PlaneView dH, PlaneView Vj, int64_t nk) {
     if (nk == 0) return ABZ_OK;
+    if (n > 4) return launch_gen_velocity(ctx, n, U, dH, Vj, nk);
 #define FN(NN) hipLaunchKernelGGL(velocity_kernel<NN>, dim3((unsigned)cdiv(nk, 256)), dim3(256), 0, ctx->stream, U, dH, Vj, nk)
     ABZ_DISPATCH_N(n, FN)
 #undef FN
@@ -1824,9 +1822,12 @@ struct GgrArgs {
     const double* Es;
     int64_t nk;
     int n, d, nE;
+    int vstride;  // planes between the velocity components of a band (= number of bands of the rule)
     double b;
 };
 
+// N bands per thread.  n <= 4: N = n, one block row.  n > 4: N = 1 and blockIdx.y is the band (the partial sums
+// of the bands are further rows of `partial`).
 template <int N, int D>
 __global__ __launch_bounds__(256) void ggr_kernel(GgrArgs a, double* __restrict__ partial) {
     extern __shared__ double ldsd[];  // [nE chunk][4]
@@ -1837,14 +1838,15 @@ __global__ __launch_bounds__(256) void ggr_kernel(GgrArgs a, double* __restrict_
     const double wk = ok ? (a.w ? a.w[kk] : 1.0) : 0.0;
     double e[N];
     double v[D][N];
-    const double* __restrict__ ei = a.E.base + view_off(a.E, kk);
-    const double* __restrict__ vi = a.V.base + view_off(a.V, kk);
+    const double* __restrict__ ei = a.E.base + view_off(a.E, kk) + (int64_t)blockIdx.y * a.E.pitch;
+    const double* __restrict__ vi = a.V.base + view_off(a.V, kk) + (int64_t)blockIdx.y * a.V.pitch;
 #pragma unroll
     for (int bnd = 0; bnd < N; ++bnd) {
         e[bnd] = ei[(int64_t)bnd * a.E.pitch];
 #pragma unroll
-        for (int j = 0; j < D; ++j) v[j][bnd] = vi[(int64_t)(j * N + bnd) * a.V.pitch];
+        for (int j = 0; j < D; ++j) v[j][bnd] = vi[(int64_t)(j * a.vstride + bnd) * a.V.pitch];
     }
+    const int64_t prow = (int64_t)blockIdx.y * gridDim.x + blockIdx.x;
     const int chunk = 1024;
     for (int s0 = 0; s0 < a.nE; s0 += chunk) {
         const int s1 = min(a.nE, s0 + chunk);
@@ -1867,7 +1869,7 @@ __global__ __launch_bounds__(256) void ggr_kernel(GgrArgs a, double* __restrict_
         }
         __syncthreads();
         for (int t = threadIdx.x; t < s1 - s0; t += 256)
-            partial[(int64_t)blockIdx.x * a.nE + s0 + t] = ldsd[t * 4] + ldsd[t * 4 + 1] + ldsd[t * 4 + 2] + ldsd[t * 4 + 3];
+            partial[prow * a.nE + s0 + t] = ldsd[t * 4] + ldsd[t * 4 + 1] + ldsd[t * 4 + 2] + ldsd[t * 4 + 3];
         __syncthreads();
     }
 }
@@ -1883,12 +1885,9 @@ __global__ void final_reduce_real_kernel(const double* __restrict__ partial, int
 
 int launch_ggr(abz_ctx* ctx, int n, int d, int npt, PlaneView E, PlaneView V, const double* w, int64_t nk,
                const double* Es_host, int nE, double* out_host) {
-    if (n > 4) {
-        set_error("GGR: n = %d bands: only n <= 4 is built in this round", n);
-        return ABZ_ERR_UNSUPPORTED;
-    }
     const int64_t nblocks = cdiv(nk, 256);
-    int rc = ctx->scratch[1].reserve(sizeof(double) * (size_t)(nblocks * nE));
+    const int brows = n > 4 ? n : 1;  // n > 4: one block row per band
+    int rc = ctx->scratch[1].reserve(sizeof(double) * (size_t)(nblocks * brows * nE));
     if (rc) return rc;
     rc = ctx->scratch[2].reserve(sizeof(double) * (size_t)nE * 2);
     if (rc) return rc;
@@ -1905,11 +1904,13 @@ int launch_ggr(abz_ctx* ctx, int n, int d, int npt, PlaneView E, PlaneView V, co
     a.n = n;
     a.d = d;
     a.nE = nE;
+    a.vstride = n;
     a.b = 1.0 / (2.0 * (double)npt);
     {
         ProfScope ps(ctx, ABZ_K_GGR);
         const size_t lds = sizeof(double) * 4 * (size_t)std::min(nE, 1024);
-#define GG(NN, DD) hipLaunchKernelGGL((ggr_kernel<NN, DD>), dim3((unsigned)nblocks), dim3(256), lds, ctx->stream, a, partial)
+#define GG(NN, DD) \
+    hipLaunchKernelGGL((ggr_kernel<NN, DD>), dim3((unsigned)nblocks, (unsigned)brows), dim3(256), lds, ctx->stream, a, partial)
 #define GD(NN)                     \
     switch (d) {                   \
         case 1: GG(NN, 1); break;  \
@@ -1920,13 +1921,14 @@ int launch_ggr(abz_ctx* ctx, int n, int d, int npt, PlaneView E, PlaneView V, co
             case 1: GD(1) break;
             case 2: GD(2) break;
             case 3: GD(3) break;
-            default: GD(4) break;
+            case 4: GD(4) break;
+            default: GD(1) break;  // band = blockIdx.y
         }
 #undef GD
 #undef GG
         ABZ_HIP(hipGetLastError());
         hipLaunchKernelGGL(final_reduce_real_kernel, dim3((unsigned)cdiv(nE, 256)), dim3(256), 0, ctx->stream, partial,
-                           nblocks, (int64_t)nE, outd);
+                           nblocks * brows, (int64_t)nE, outd);
         ABZ_HIP(hipGetLastError());
     }
     ABZ_HIP(hipMemcpyAsync(out_host, outd, sizeof(double) * (size_t)nE, hipMemcpyDeviceToHost, ctx->stream));

@@ -83,9 +83,14 @@ __device__ void wave_inverse(double2* A, double2* X, int n, int lane) {
 }
 
 // Cooperative cyclic Jacobi on the Hermitian matrix given by the UPPER triangle of A (column-major,
-// destroyed).  Eigenvalues ascending into e[0..n) (LDS doubles).
-__device__ void wave_eig(double2* A, double* e, int n, int lane) {
+// destroyed).  Eigenvalues ascending into e[0..n) (LDS doubles).  V (optional, n*n in LDS): the rotations
+// are accumulated, column j of V is the eigenvector of A's final diagonal entry j, and the rank of that
+// entry in the ascending order is left in A[j + n*j].y (the diagonal's imaginary part is otherwise zero).
+__device__ void wave_eig(double2* A, double* e, int n, int lane, double2* V = nullptr) {
     const int nn = n * n;
+    if (V) {
+        for (int t = lane; t < nn; t += 64) V[t] = make_double2((t % n == t / n) ? 1.0 : 0.0, 0.0);
+    }
     // hermitise from the upper triangle, real diagonal
     for (int t = lane; t < nn; t += 64) {
         const int a = t % n, b = t / n;
@@ -130,6 +135,11 @@ __device__ void wave_eig(double2* A, double* e, int n, int lane) {
                     np_[0] = make_double2(c * x.x - (sgr * y.x - sgi * y.y), c * x.y - (sgr * y.y + sgi * y.x));
                     nq_[0] = make_double2(s * x.x + (cgr * y.x - cgi * y.y), s * x.y + (cgr * y.y + cgi * y.x));
                 }
+                if (V && r < n) {  // V <- V J: the same column rotation, every row (a lane owns its row of V)
+                    const double2 x = V[r + n * p], y = V[r + n * q];
+                    V[r + n * p] = make_double2(c * x.x - (sgr * y.x - sgi * y.y), c * x.y - (sgr * y.y + sgi * y.x));
+                    V[r + n * q] = make_double2(s * x.x + (cgr * y.x - cgi * y.y), s * x.y + (cgr * y.y + cgi * y.x));
+                }
                 wave_sync();
                 if (act) {
                     A[r + n * p] = np_[0];
@@ -158,6 +168,7 @@ __device__ void wave_eig(double2* A, double* e, int n, int lane) {
             rank += (u < v || (u == v && j < lane)) ? 1 : 0;
         }
         e[rank] = v;
+        if (V) A[lane + n * lane].y = (double)rank;
     }
     wave_sync();
 }
@@ -175,6 +186,7 @@ struct GenArgs {
     // outputs
     PlaneView Hplanes;
     PlaneView Eplanes;
+    PlaneView Uplanes;  // eigenvectors, planes 2*(a + n*band) + {re, im} (null: eigenvalues only)
     double2* Haos;  // [node][n*n]
     double* Eaos;   // [node][n]
     // integrand
@@ -305,14 +317,23 @@ __global__ __launch_bounds__(256) void gen_node_kernel(GenArgs a, int waves_per_
             if (a.Haos) a.Haos[k * nn + t] = make_double2(hr, hi);
         }
         wave_sync();
-        const bool need_eig = a.Eplanes.base || a.Eaos || (a.values && a.integrand == ABZ_F_DOS_EIG);
+        const bool need_eig = a.Eplanes.base || a.Eaos || a.Uplanes.base || (a.values && a.integrand == ABZ_F_DOS_EIG);
         if (need_eig) {
             for (int t = lane; t < nn; t += 64) W[t] = H[t];
             wave_sync();
-            wave_eig(W, ev, n, lane);
+            wave_eig(W, ev, n, lane, a.Uplanes.base ? X : nullptr);
             for (int b = lane; b < n; b += 64) {
                 if (a.Eplanes.base) a.Eplanes.base[view_off(a.Eplanes, k) + (int64_t)b * a.Eplanes.pitch] = ev[b];
                 if (a.Eaos) a.Eaos[k * n + b] = ev[b];
+            }
+            if (a.Uplanes.base) {  // U[:, rank(j)] = V[:, j]
+                double* uo = a.Uplanes.base + view_off(a.Uplanes, k);
+                for (int t = lane; t < nn; t += 64) {
+                    const int ra = t % n, j = t / n;
+                    const int band = (int)W[j + n * j].y;
+                    uo[(int64_t)(2 * (ra + n * band)) * a.Uplanes.pitch] = X[t].x;
+                    uo[(int64_t)(2 * (ra + n * band) + 1) * a.Uplanes.pitch] = X[t].y;
+                }
             }
         }
         if (a.values) {
@@ -323,6 +344,35 @@ __global__ __launch_bounds__(256) void gen_node_kernel(GenArgs a, int waves_per_
         }
         wave_sync();
     }
+}
+
+// Band velocities for n > 4: v_b = Re sum_{a,c} conj(U[a][b]) D[a][c] U[c][b], one thread per (node, band),
+// nodes fastest (every plane read is coalesced across the lanes; a band's threads re-read D through L2).
+__global__ __launch_bounds__(256) void gen_velocity_kernel(PlaneView Uv, PlaneView Dv, PlaneView Vv, int64_t nk, int n) {
+    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int b = blockIdx.y;
+    if (k >= nk) return;
+    const double* __restrict__ u = Uv.base + view_off(Uv, k) + (int64_t)(2 * n * b) * Uv.pitch;  // column b of U
+    const double* __restrict__ dm = Dv.base + view_off(Dv, k);
+    double v = 0.0;
+    for (int a = 0; a < n; ++a) {
+        double tr = 0.0, ti = 0.0;  // t = sum_c D[a][c] U[c][b]
+        for (int c = 0; c < n; ++c) {
+            const double dr = dm[(int64_t)(2 * (a + n * c)) * Dv.pitch], di = dm[(int64_t)(2 * (a + n * c) + 1) * Dv.pitch];
+            const double ur = u[(int64_t)(2 * c) * Uv.pitch], ui = u[(int64_t)(2 * c + 1) * Uv.pitch];
+            tr += dr * ur - di * ui;
+            ti += dr * ui + di * ur;
+        }
+        v += u[(int64_t)(2 * a) * Uv.pitch] * tr + u[(int64_t)(2 * a + 1) * Uv.pitch] * ti;
+    }
+    Vv.base[view_off(Vv, k) + (int64_t)b * Vv.pitch] = v;
+}
+
+int launch_gen_velocity(abz_ctx* ctx, int n, PlaneView U, PlaneView dH, PlaneView Vj, int64_t nk) {
+    if (nk == 0) return ABZ_OK;
+    hipLaunchKernelGGL(gen_velocity_kernel, dim3((unsigned)cdiv2(nk, 256), (unsigned)n), dim3(256), 0, ctx->stream, U, dH, Vj, nk, n);
+    ABZ_HIP(hipGetLastError());
+    return ABZ_OK;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -769,7 +819,7 @@ static bool gen_panel_supported(const GenSpec& gs, int* np_out, size_t* lds_out,
     if (!gs.values || !gs.panels15 || gs.grid || !gs.x || gs.deriv || gs.nnodes % 15 != 0) return false;
     if (gs.n_sweep > 1 || gs.sweep_dev) return false;
     if (!(gs.integrand == ABZ_F_DOS || gs.integrand == ABZ_F_TRGLOC || gs.integrand == ABZ_F_GLOC)) return false;
-    if (gs.Hplanes.base || gs.Eplanes.base || gs.Haos || gs.Eaos) return false;
+    if (gs.Hplanes.base || gs.Eplanes.base || gs.Uplanes.base || gs.Haos || gs.Eaos) return false;
     const int np = gs.n <= 8 ? 8 : (gs.n <= 16 ? 16 : 32);
     size_t lds = sizeof(double2) * ((size_t)gs.M * np * np + (size_t)(256 / np) * panel_rowbuf(np));  // zero-padded set
     *pad_out = lds <= 150 * 1024;
@@ -812,6 +862,7 @@ int launch_gen_nodes(abz_ctx* ctx, const GenSpec& gs) {
     a.inv_period = 1.0 / gs.period;
     a.Hplanes = gs.Hplanes;
     a.Eplanes = gs.Eplanes;
+    a.Uplanes = gs.Uplanes;
     a.Haos = gs.Haos;
     a.Eaos = gs.Eaos;
     a.integrand = gs.integrand;

@@ -864,6 +864,27 @@ def test_ggr_velocities_match_oracle(abz, svo):
     assert np.abs(out["vel"].sum(axis=2) - v.sum(axis=2)).max() < 1e-8
 
 
+def test_ggr_more_than_four_bands(abz):
+    """GGR for n > 4 (ref: src/dos_ggr.jl:1-44 falls back to LAPACK's eigen there): eigenvalues, band velocities
+    and the scanned DOS of a 6-band model against the oracle."""
+    so = orc.synthetic_wannier(n=6, rmax=2, seed=7)
+    s = abz.FourierSeries(so.c, period=1.0, first=so.first, ndim=3)
+    rule = s.device().rule(6, None, want=2 | 4)
+    out = rule.export(eig=True, vel=True)
+    w, e, v = orc.get_ggr_data(so, 6, None)
+    assert np.abs(out["eig"] - e).max() < 1e-11
+    ok = np.min(np.diff(e, axis=1), axis=1) > 1e-6
+    assert ok.sum() > 100
+    assert np.abs(out["vel"][ok] - v[ok]).max() < 1e-8
+    assert np.abs(out["vel"].sum(axis=2) - v.sum(axis=2)).max() < 1e-8
+    Es = np.linspace(-2.0, 2.0, 9)
+    for kind, bzk in (("FBZ", abz.FBZ()), ("InversionSymIBZ", abz.InversionSymIBZ())):
+        u = abz.dos.solve(abz.DOSProblem(s, Es, abz.load_bz(bzk, np.eye(3))), abz.GGR(npt=10)).u
+        ref = orc.dos_ggr(so, orc.load_bz(kind, np.eye(3)), Es, npt=10)
+        assert np.abs(ref).max() > 0.1
+        assert np.abs(u - ref).max() <= 1e-9 * max(1.0, np.abs(ref).max())
+
+
 def test_ggr_cache_invalidation(abz):
     """ref: test/dos.jl:114-132."""
     h = abz.FourierSeries(np.array([0.5, 0.0, 0.5]).reshape(3, 1, 1), period=1.0, offset=-2, ndim=1)
