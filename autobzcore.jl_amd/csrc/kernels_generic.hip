@@ -535,54 +535,20 @@ __device__ __forceinline__ void panel_pivot(int r, double (&ar)[NP], double (&ai
     ai[C] = (r == C) ? ipi : gi;
 }
 
-template <int NP, int... C>
-__device__ __forceinline__ void panel_pivots(int r, double (&ar)[NP], double (&ai)[NP], std::integer_sequence<int, C...>) {
-    (panel_pivot<NP, C>(r, ar, ai), ...);
+template <int NP, bool GUARD, int... C>
+__device__ __forceinline__ void panel_pivots(int n, int r, double (&ar)[NP], double (&ai)[NP], std::integer_sequence<int, C...>) {
+    // GUARD: the rows / columns >= n are an identity block kept in registers only (unpadded LDS layout); their
+    // pivots are 1 and are skipped (uniform)
+    ((!GUARD || C < n ? panel_pivot<NP, C>(r, ar, ai) : (void)0), ...);
 }
 
-// in-place inversion of the matrix whose row r this lane holds; pivots of the padding block are 1 and change nothing.
-// PAD: pivot rows travel by `group_bcast`, `myrow` is not used.  !PAD: through the slot's LDS row buffers.
+// in-place inversion of the matrix whose row r this lane holds (rows >= n: identity rows, columns >= n of the real
+// rows: zeros -- by the zero-padded staging (PAD) or by panel_series_row / panel_shift_row (!PAD)).  The pivot rows
+// travel by `group_bcast`; `myrow` (the slot's LDS row buffers of the first version) is not used any more.
 template <int NP, bool PAD>
 __device__ __forceinline__ void panel_invert_rows(double2* myrow, int n, int r, double (&ar)[NP], double (&ai)[NP]) {
-    if constexpr (PAD) {
-        panel_pivots<NP>(r, ar, ai, std::make_integer_sequence<int, NP>());
-        return;
-    } else {
-#pragma unroll
-        for (int c = 0; c < NP; ++c) {
-            if (c < n) {  // uniform
-                double2* buf = myrow + (c & 1) * NP;
-                if (r == c) {
-#pragma unroll
-                    for (int j = 0; j < NP; ++j)
-                        if (j < n) buf[j] = make_double2(ar[j], ai[j]);
-                }
-                wave_sync();  // a node's NP lanes live in one wave
-                const double2 p = buf[c];
-                const double inv = rcp_nr(p.x * p.x + p.y * p.y);
-                const double ipr = p.x * inv, ipi = -p.y * inv;  // 1 / pivot
-                const double fr = ar[c], fi = ai[c];
-                double gr = -(fr * ipr - fi * ipi), gi = -(fr * ipi + fi * ipr);
-                if (r == c) {
-                    gr = ipr - 1.0;
-                    gi = ipi;
-                }
-#pragma unroll
-                for (int j = 0; j < NP; ++j) {
-                    if (j < n && j != c) {
-                        const double2 u = buf[j];
-                        ar[j] = fma(gr, u.x, ar[j]);
-                        ar[j] = fma(-gi, u.y, ar[j]);
-                        ai[j] = fma(gr, u.y, ai[j]);
-                        ai[j] = fma(gi, u.x, ai[j]);
-                    }
-                }
-                ar[c] = (r == c) ? ipr : gr;
-                ai[c] = (r == c) ? ipi : gi;
-            }
-        }
-        wave_sync();
-    }
+    (void)myrow;
+    panel_pivots<NP, !PAD>(n, r, ar, ai, std::make_integer_sequence<int, NP>());
 }
 
 template <int NP, bool PAD>

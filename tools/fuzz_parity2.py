@@ -54,8 +54,10 @@ for n in (5, 7, 8, 9, 12, 16, 17, 24, 32):
         print(f"gen n={n:2d} d={d} npt={npt}: H {eH:.1e} eig {eE:.1e} trgloc {eR:.1e} dos_eig {eD:.1e}{flag}", flush=True)
 
 # ---- generic n: IAI (panel kernels, device-side inner loops), 2-D so that the Python oracle stays fast
-for n in (5, 8, 11, 16, 19, 32):
-    c, first = herm_series((3, 3), n, 1.0 / np.sqrt(n))
+# (20, (11, 3)): the zero-padded coefficient set of the inner variable (11 x 32 x 32 complex) does not fit the LDS,
+# so the kernels run on the unpadded layout with register-only identity padding
+for n, dims in ((5, (3, 3)), (8, (3, 3)), (11, (3, 3)), (16, (3, 3)), (19, (3, 3)), (32, (3, 3)), (20, (11, 3))):
+    c, first = herm_series(dims, n, 1.0 / np.sqrt(n))
     s = abz.FourierSeries(c, period=1.0, first=first, ndim=2)
     so = orc.FourierSeries(c, period=1.0, first=first, ndim=2)
     bz = abz.load_bz(abz.FBZ(), np.eye(2))
