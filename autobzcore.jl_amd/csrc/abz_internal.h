@@ -288,6 +288,7 @@ struct GenSpec {
     PlaneView Hplanes;
     PlaneView Eplanes;
     PlaneView Uplanes;  // eigenvectors out (velocity builds)
+    bool herm = false;  // the series is Hermitian: H(k) = H(k)^dagger to rounding
     double2* Haos;
     double* Eaos;
     int integrand;

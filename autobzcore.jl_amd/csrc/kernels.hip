@@ -838,6 +838,7 @@ int launch_eval(abz_ctx* ctx, const EvalSpec& es) {
     if (es.n > 4) {
         GenSpec gs;
         gs.Uplanes = es.U;
+        gs.herm = es.herm && !es.deriv;
         gs.n = es.n;
         gs.M = es.M;
         gs.first = es.first;

@@ -388,6 +388,14 @@ int launch_gen_velocity(abz_ctx* ctx, int n, PlaneView U, PlaneView dH, PlaneVie
 //              g_r = -a_rc / p (g_c = 1/p - 1), a_rc <- g_r (a_cc <- 1/p).  n^3 complex FMA per node in
 //              registers instead of the 2 n^3 LDS-resident updates of the wave-per-node kernel.
 // ------------------------------------------------------------------------------------------
+__device__ __forceinline__ double rsqrt_nr(double x) {  // 1/sqrt(x), x in the normal range: estimate + 2 Newton steps
+    double y = __builtin_amdgcn_rsq(x);
+    const double hx = 0.5 * x;
+    y = fma(fma(-hx * y, y, 0.5), y, y);
+    y = fma(fma(-hx * y, y, 0.5), y, y);
+    return y;
+}
+
 // double2 entries of one node slot's two pivot-row buffers; the NP/4 of padding puts the slots of a wave
 // (64/NP of them, all reading / writing their buffers at once) on different LDS banks
 #ifdef ABZ_PANEL_NOPAD
@@ -781,6 +789,325 @@ int launch_gen_sum(abz_ctx* ctx, const SumSpec& ss, double* out_reim) {
     return ABZ_OK;
 }
 
+// ------------------------------------------------------------------------------------------
+// Rule builds with eigenvalues (and eigenvectors) on full grids for 5..16 bands: the row layout of the panel
+// kernels (lane r of a node's NP lanes owns row r) with a PARALLEL-ORDER two-sided Jacobi.  One step of the
+// round-robin tournament rotates NP/2 disjoint pairs (p, q) at once:
+//   rows     row_p' = c row_p - s conj(g) row_q,  row_q' = s row_p + c conj(g) row_q   -- partner lanes swap rows
+//            (`ds_bpermute_b32`), the p lane computes the angle and hands it to the q lane
+//   columns  x' = c x - s g y,  y' = s x + c g y  on (x, y) = (a_rp, a_rq) of every row, for every pair of the step
+//            -- local to the lane, the pairs' (c, s, g) by `group_bcast` (pair indices are compile-time: the NP-1
+//            steps are separate template instances)
+// The diagonal is carried in a scalar per lane and updated by +- t |a_pq| as in the per-lane solver (device_math.h).
+// NP/2 rotations per ~450 instructions instead of one rotation per 2 wave barriers of `wave_eig`.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ double lane_read(double v, int addr4) {
+    const int lo = __builtin_amdgcn_ds_bpermute(addr4, __double2loint(v));
+    const int hi = __builtin_amdgcn_ds_bpermute(addr4, __double2hiint(v));
+    return __hiloint2double(hi, lo);
+}
+
+// pair I (0 .. NP/2-1) of step T (0 .. NP-2) of the round-robin ordering on NP players: {0, T+1}, {(T+i)%m+1, (T-i)%m+1}
+template <int NP, int T, int I>
+struct RRPair {
+    static constexpr int m = NP - 1;
+    static constexpr int a = I == 0 ? 0 : (T + I) % m + 1;
+    static constexpr int b = I == 0 ? T + 1 : (T - I + m) % m + 1;
+    static constexpr int lo = a < b ? a : b;
+    static constexpr int hi = a < b ? b : a;
+};
+
+template <int NP, int T, int I, bool VEC>
+__device__ __forceinline__ void jacobi_columns(double c, double s, double gr, double gi, double (&ar)[NP], double (&ai)[NP],
+                                               double (&vr)[NP], double (&vi)[NP]) {
+    constexpr int P = RRPair<NP, T, I>::lo, Q = RRPair<NP, T, I>::hi;
+    const double cc = group_bcast<NP, P>(c), ss = group_bcast<NP, P>(s);
+    const double ggr = group_bcast<NP, P>(gr), ggi = group_bcast<NP, P>(gi);
+    const double sgr = ss * ggr, sgi = ss * ggi, cgr = cc * ggr, cgi = cc * ggi;
+    {
+        const double xr = ar[P], xi = ai[P], yr = ar[Q], yi = ai[Q];
+        ar[P] = cc * xr - (sgr * yr - sgi * yi);
+        ai[P] = cc * xi - (sgr * yi + sgi * yr);
+        ar[Q] = ss * xr + (cgr * yr - cgi * yi);
+        ai[Q] = ss * xi + (cgr * yi + cgi * yr);
+    }
+    if constexpr (VEC) {
+        const double xr = vr[P], xi = vi[P], yr = vr[Q], yi = vi[Q];
+        vr[P] = cc * xr - (sgr * yr - sgi * yi);
+        vi[P] = cc * xi - (sgr * yi + sgi * yr);
+        vr[Q] = ss * xr + (cgr * yr - cgi * yi);
+        vi[Q] = ss * xi + (cgr * yi + cgi * yr);
+    }
+}
+
+template <int NP, int T, bool VEC, int... I>
+__device__ __forceinline__ void jacobi_all_columns(double c, double s, double gr, double gi, double (&ar)[NP], double (&ai)[NP],
+                                                   double (&vr)[NP], double (&vi)[NP], std::integer_sequence<int, I...>) {
+    (jacobi_columns<NP, T, I, VEC>(c, s, gr, gi, ar, ai, vr, vi), ...);
+}
+
+template <int NP, int T, bool VEC>
+__device__ __forceinline__ void jacobi_step(int r, int lane, double tiny, double& dg, double (&ar)[NP], double (&ai)[NP],
+                                            double (&vr)[NP], double (&vi)[NP]) {
+    constexpr int m = NP - 1;
+    int pr;  // this lane's partner in step T
+    {
+        const int x = r - 1;
+        int y = (2 * T - x) % m;
+        if (y < 0) y += m;
+        pr = (r == 0) ? T + 1 : (x == T ? 0 : y + 1);
+    }
+    const int addr = ((lane & ~(NP - 1)) | pr) << 2;
+    const bool prole = r < pr;
+    double er = 0.0, ei = 0.0;  // a[r][pr]
+#pragma unroll
+    for (int j = 0; j < NP; ++j) {
+        if (j == pr) {
+            er = ar[j];
+            ei = ai[j];
+        }
+    }
+    const double dgp = lane_read(dg, addr);
+    // the pair's rotation from the p lane's data (alpha = a_pq, d = a_qq - a_pp)
+    const double b2 = er * er + ei * ei;
+    const bool ok = b2 > tiny;
+    const double b2s = ok ? b2 : 1.0;
+    const double rb = rsqrt_nr(b2s), b = b2s * rb;
+    double gr = er * rb, gi = -ei * rb;  // g = conj(alpha) / |alpha|
+    const double d = dgp - dg;
+    const double r2 = fma(d, d, 4.0 * b2s);
+    const double t = copysign(2.0 * b, d) * rcp_nr(fabs(d) + r2 * rsqrt_nr(r2));
+    double c = rsqrt_nr(fma(t, t, 1.0));
+    double s = t * c;
+    double tb = t * b;
+    if (!ok) {
+        c = 1.0;
+        s = 0.0;
+        tb = 0.0;
+        gr = 1.0;
+        gi = 0.0;
+    }
+    {  // the q lane works with exactly the p lane's numbers
+        const double c2 = lane_read(c, addr), s2 = lane_read(s, addr), g2r = lane_read(gr, addr), g2i = lane_read(gi, addr),
+                     tb2 = lane_read(tb, addr);
+        if (!prole) {
+            c = c2;
+            s = s2;
+            gr = g2r;
+            gi = g2i;
+            tb = tb2;
+        }
+    }
+    dg += prole ? -tb : tb;
+    // rows: new = ks * mine + kp * partner's
+    const double ksr = prole ? c : c * gr, ksi = prole ? 0.0 : -c * gi;
+    const double kpr = prole ? -s * gr : s, kpi = prole ? s * gi : 0.0;
+#pragma unroll
+    for (int j0 = 0; j0 < NP; j0 += 8) {
+        double br[8], bi[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            br[j] = lane_read(ar[j0 + j], addr);
+            bi[j] = lane_read(ai[j0 + j], addr);
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const double xr = ar[j0 + j], xi = ai[j0 + j];
+            ar[j0 + j] = (ksr * xr - ksi * xi) + (kpr * br[j] - kpi * bi[j]);
+            ai[j0 + j] = (ksr * xi + ksi * xr) + (kpr * bi[j] + kpi * br[j]);
+        }
+    }
+    jacobi_all_columns<NP, T, VEC>(c, s, gr, gi, ar, ai, vr, vi, std::make_integer_sequence<int, NP / 2>());
+}
+
+template <int NP, bool VEC, int... T>
+__device__ __forceinline__ void jacobi_sweep(int r, int lane, double tiny, double& dg, double (&ar)[NP], double (&ai)[NP],
+                                             double (&vr)[NP], double (&vi)[NP], std::integer_sequence<int, T...>) {
+    (jacobi_step<NP, T, VEC>(r, lane, tiny, dg, ar, ai, vr, vi), ...);
+}
+
+// out[j] = v of lane j of the node's lanes
+template <int NP, int... J>
+__device__ __forceinline__ void group_gather(double v, double (&out)[NP], std::integer_sequence<int, J...>) {
+    ((out[J] = group_bcast<NP, J>(v)), ...);
+}
+
+// sum over the NP lanes of a node (every lane gets it)
+template <int NP>
+__device__ __forceinline__ double group_sum(double v) {
+#pragma unroll
+    for (int off = NP / 2; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+// Eigenvalues (ascending rank of this lane's eigenvalue in `rank`, the value in `dg`) of the Hermitian matrix whose
+// row r this lane holds (rows / columns >= n: zero, they never couple); VEC: row r of the eigenvector matrix in vr/vi,
+// its column j belongs to the eigenvalue held by lane j.
+template <int NP, bool VEC>
+__device__ __forceinline__ void rows_eig(int n, int r, int lane, double (&ar)[NP], double (&ai)[NP], double (&vr)[NP],
+                                         double (&vi)[NP], double& dg, int& rank) {
+    dg = 0.0;
+    double nrm = 0.0;
+#pragma unroll
+    for (int j = 0; j < NP; ++j) {
+        if (j == r) {
+            dg = ar[j];
+            ai[j] = 0.0;
+        }
+        nrm += ar[j] * ar[j] + ai[j] * ai[j];
+        if constexpr (VEC) {
+            vr[j] = (j == r) ? 1.0 : 0.0;
+            vi[j] = 0.0;
+        }
+    }
+    const double tiny = 1e-34 * group_sum<NP>(nrm);  // |a_pq| <= 1e-17 ||A||_F counts as zero
+    for (int sweep = 0; sweep < 16; ++sweep) {
+        double off2 = 0.0;
+#pragma unroll
+        for (int j = 0; j < NP; ++j) off2 += (j == r) ? 0.0 : ar[j] * ar[j] + ai[j] * ai[j];
+        off2 = group_sum<NP>(off2);
+        if (!__any(off2 > tiny)) break;  // wave-uniform: the nodes of a wave sweep together
+        jacobi_sweep<NP, VEC>(r, lane, tiny, dg, ar, ai, vr, vi, std::make_integer_sequence<int, NP - 1>());
+    }
+    const double mine = r < n ? dg : __builtin_huge_val();  // padding rows rank last
+    double vals[NP];
+    group_gather<NP>(mine, vals, std::make_integer_sequence<int, NP>());
+    rank = 0;
+#pragma unroll
+    for (int j = 0; j < NP; ++j) rank += (vals[j] < mine || (vals[j] == mine && j < r)) ? 1 : 0;
+}
+
+struct GenEigArgs {
+    const double2* src;  // level-1 coefficient sets, one per grid line
+    const double2* tab;
+    PlaneView H, E, U;
+    int64_t nlines;
+    int n, M, first, npt;
+};
+
+template <int NP, bool PAD, bool VEC>
+__global__ __launch_bounds__(256) void gen_grid_eig_kernel(GenEigArgs a) {
+    extern __shared__ double2 lds_ge[];
+    constexpr int SLOTS = 256 / NP;
+    const int n = a.n, nn = n * n, M = a.M;
+    double2* coef = lds_ge;
+    const int slot = threadIdx.x / NP, r = threadIdx.x % NP, lane = threadIdx.x & 63;
+    int fm = a.first % a.npt;
+    if (fm < 0) fm += a.npt;
+    for (int64_t line = blockIdx.x; line < a.nlines; line += gridDim.x) {
+        __syncthreads();
+        panel_stage<NP, PAD>(coef, a.src + line * ((int64_t)M * nn), n, M);
+        __syncthreads();
+        for (int i0 = 0; i0 < a.npt; i0 += SLOTS) {
+            if (i0 + (int)(threadIdx.x >> 6) * (64 / NP) >= a.npt) continue;  // no node for this wave (only wave-level sync below)
+            const int i1 = i0 + slot;
+            const bool act = i1 < a.npt;
+            const int ic = act ? i1 : 0;
+            const double2 z = a.tab[ic];
+            const double2 w = a.tab[(int)(((unsigned)fm * (unsigned)ic) % (unsigned)a.npt)];
+            double hr[NP], hi[NP];
+            panel_series_row<NP, PAD>(coef, n, M, z.x, z.y, w.x, w.y, r, hr, hi);  // row r of -H(k)
+#pragma unroll
+            for (int j = 0; j < NP; ++j) {
+                const bool real = PAD || (r < n && j < n);
+                hr[j] = real ? -hr[j] : 0.0;
+                hi[j] = real ? -hi[j] : 0.0;
+            }
+            const int64_t k = line * a.npt + ic;
+            const bool wr = act && r < n;
+            if (a.H.base && wr) {
+                double* ho = a.H.base + view_off(a.H, k);
+#pragma unroll
+                for (int j = 0; j < NP; ++j) {
+                    if (j < n) {
+                        ho[(int64_t)(2 * (r + n * j)) * a.H.pitch] = hr[j];
+                        ho[(int64_t)(2 * (r + n * j) + 1) * a.H.pitch] = hi[j];
+                    }
+                }
+            }
+            double vr[NP], vi[NP], dg;
+            int rank;
+            rows_eig<NP, VEC>(n, r, lane, hr, hi, vr, vi, dg, rank);
+            if (wr) a.E.base[view_off(a.E, k) + (int64_t)rank * a.E.pitch] = dg;
+            if constexpr (VEC) {
+                double ranks[NP];
+                group_gather<NP>((double)rank, ranks, std::make_integer_sequence<int, NP>());
+                if (wr) {
+                    double* uo = a.U.base + view_off(a.U, k);
+#pragma unroll
+                    for (int j = 0; j < NP; ++j) {
+                        if (j < n) {
+                            const int band = (int)ranks[j];
+                            uo[(int64_t)(2 * (r + n * band)) * a.U.pitch] = vr[j];
+                            uo[(int64_t)(2 * (r + n * band) + 1) * a.U.pitch] = vi[j];
+                        }
+                    }
+                }
+            }
+        }
+    }
+}
+
+// full-grid rule values with eigenvalues for 5..16 bands of a Hermitian series
+static bool gen_grid_eig_supported(const GenSpec& gs, int* np_out, size_t* lds_out, bool* pad_out) {
+    static const bool off = [] { const char* e = getenv("ABZ_GEN_ROWEIG"); return e && e[0] == '0'; }();
+    if (off || !gs.grid || gs.deriv || gs.values || gs.Haos || gs.Eaos || !gs.Eplanes.base || !gs.herm) return false;
+    static const bool vec_on = [] { const char* e = getenv("ABZ_GEN_ROWEIG_VEC"); return e && e[0] == '1'; }();
+    if (gs.Uplanes.base && !vec_on) return false;  // eigenvectors: the instance spills (512 registers + scratch), opt-in
+    if (gs.n <= 4 || gs.n > 16 || gs.npt < 1 || gs.npt >= 65536) return false;
+    const int np = gs.n <= 8 ? 8 : 16;
+    size_t lds = sizeof(double2) * (size_t)gs.M * np * np;
+    *pad_out = lds <= 150 * 1024;
+    if (!*pad_out) lds = sizeof(double2) * (size_t)gs.M * gs.n * gs.n;
+    if (lds > 150 * 1024) return false;
+    *np_out = np;
+    *lds_out = lds;
+    return true;
+}
+
+static int launch_gen_grid_eig(abz_ctx* ctx, const GenSpec& gs, int np, size_t lds, bool pad) {
+    GenEigArgs a;
+    a.src = gs.src;
+    a.tab = gs.tab;
+    a.H = gs.Hplanes;
+    a.E = gs.Eplanes;
+    a.U = gs.Uplanes;
+    a.nlines = gs.nnodes / gs.npt;
+    a.n = gs.n;
+    a.M = gs.M;
+    a.first = gs.first;
+    a.npt = gs.npt;
+    const int64_t blocks = std::min<int64_t>(a.nlines, 256 * 4);
+    const bool vec = gs.Uplanes.base != nullptr;
+    ProfScope ps(ctx, ABZ_K_EVAL);
+#define ABZ_GE3(NPV, PV, VV)                                                                                              \
+    ABZ_HIP(hipFuncSetAttribute((const void*)gen_grid_eig_kernel<NPV, PV, VV>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                (int)lds));                                                                               \
+    hipLaunchKernelGGL((gen_grid_eig_kernel<NPV, PV, VV>), dim3((unsigned)blocks), dim3(256), lds, ctx->stream, a);
+#define ABZ_GE2(NPV, PV) \
+    if (vec) {           \
+        ABZ_GE3(NPV, PV, true) \
+    } else {             \
+        ABZ_GE3(NPV, PV, false) \
+    }
+#define ABZ_GE(NPV) \
+    if (pad) {      \
+        ABZ_GE2(NPV, true) \
+    } else {        \
+        ABZ_GE2(NPV, false) \
+    }
+    if (np == 8) {
+        ABZ_GE(8)
+    } else {
+        ABZ_GE(16)
+    }
+#undef ABZ_GE
+#undef ABZ_GE2
+#undef ABZ_GE3
+    ABZ_HIP(hipGetLastError());
+    return ABZ_OK;
+}
+
 static bool gen_panel_supported(const GenSpec& gs, int* np_out, size_t* lds_out, bool* pad_out) {
     if (!gs.values || !gs.panels15 || gs.grid || !gs.x || gs.deriv || gs.nnodes % 15 != 0) return false;
     if (gs.n_sweep > 1 || gs.sweep_dev) return false;
@@ -842,6 +1169,12 @@ int launch_gen_nodes(abz_ctx* ctx, const GenSpec& gs) {
     if (gs.values && (gs.integrand == ABZ_F_LINEAR || gs.integrand == ABZ_F_LINEAR_X)) {
         set_error("ABZ_F_LINEAR(_X) needs a scalar (n = 1) series");
         return ABZ_ERR_ARG;
+    }
+    {
+        int np = 0;
+        size_t plds = 0;
+        bool pad = false;
+        if (gen_grid_eig_supported(gs, &np, &plds, &pad)) return launch_gen_grid_eig(ctx, gs, np, plds, pad);
     }
     {
         int np = 0;
