@@ -1053,7 +1053,7 @@ static bool gen_grid_eig_supported(const GenSpec& gs, int* np_out, size_t* lds_o
     static const bool off = [] { const char* e = getenv("ABZ_GEN_ROWEIG"); return e && e[0] == '0'; }();
     if (off || !gs.grid || gs.deriv || gs.values || gs.Haos || gs.Eaos || !gs.Eplanes.base || !gs.herm) return false;
     static const bool vec_on = [] { const char* e = getenv("ABZ_GEN_ROWEIG_VEC"); return e && e[0] == '1'; }();
-    if (gs.Uplanes.base && !vec_on) return false;  // eigenvectors: the instance spills (512 registers + scratch), opt-in
+    if (gs.Uplanes.base && gs.n > 8 && !vec_on) return false;  // eigenvectors at 16 rows: the instance spills 4.6 KB, opt-in
     if (gs.n <= 4 || gs.n > 16 || gs.npt < 1 || gs.npt >= 65536) return false;
     const int np = gs.n <= 8 ? 8 : 16;
     size_t lds = sizeof(double2) * (size_t)gs.M * np * np;
