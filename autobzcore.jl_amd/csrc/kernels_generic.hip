@@ -1025,6 +1025,7 @@ __global__ __launch_bounds__(256) void gen_grid_eig_kernel(GenEigArgs a) {
                     }
                 }
             }
+            if (!a.E.base) continue;  // values only (uniform)
             double vr[NP], vi[NP], dg;
             int rank;
             rows_eig<NP, VEC>(n, r, lane, hr, hi, vr, vi, dg, rank);
@@ -1048,10 +1049,11 @@ __global__ __launch_bounds__(256) void gen_grid_eig_kernel(GenEigArgs a) {
     }
 }
 
-// full-grid rule values with eigenvalues for 5..16 bands of a Hermitian series
+// full-grid rule values (and eigenvalues, Hermitian series) for 5..16 bands
 static bool gen_grid_eig_supported(const GenSpec& gs, int* np_out, size_t* lds_out, bool* pad_out) {
     static const bool off = [] { const char* e = getenv("ABZ_GEN_ROWEIG"); return e && e[0] == '0'; }();
-    if (off || !gs.grid || gs.deriv || gs.values || gs.Haos || gs.Eaos || !gs.Eplanes.base || !gs.herm) return false;
+    if (off || !gs.grid || gs.deriv || gs.values || gs.Haos || gs.Eaos || !(gs.Eplanes.base || gs.Hplanes.base)) return false;
+    if (gs.Eplanes.base && !gs.herm) return false;  // the Jacobi works on full rows: H(k) must be Hermitian to rounding
     static const bool vec_on = [] { const char* e = getenv("ABZ_GEN_ROWEIG_VEC"); return e && e[0] == '1'; }();
     if (gs.Uplanes.base && gs.n > 8 && !vec_on) return false;  // eigenvectors at 16 rows: the instance spills 4.6 KB, opt-in
     if (gs.n <= 4 || gs.n > 16 || gs.npt < 1 || gs.npt >= 65536) return false;
@@ -1330,7 +1332,118 @@ __global__ __launch_bounds__(256) void final_reduce2_kernel(const double2* __res
         out[col] = make_double2((sh[0].x + sh[1].x + sh[2].x + sh[3].x) * scale, (sh[0].y + sh[1].y + sh[2].y + sh[3].y) * scale);
 }
 
+// Resolvent-trace scans of a cached rule for 5..16 bands (Hermitian values) on the row kernels: lane r of a node's
+// NP lanes loads row r of H(k) from the rule's planes, then per swept value shift, swizzle-pivot inversion, trace.
+// Four swept values per pass over the nodes (the rule is re-read per pass: 16 n^2 B per node against 4 inversions).
+struct GenRowsReduceArgs {
+    PlaneView H;
+    const double* w;
+    const double* sweep;  // device [n_sweep]
+    double2* partial;     // [blocks][n_sweep]
+    int64_t nk;
+    int n, n_sweep, is_dos;
+    double eta;
+};
+
+template <int NP>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 4))) void gen_rows_reduce_kernel(GenRowsReduceArgs a) {
+    constexpr int SLOTS = 256 / NP;
+    __shared__ double2 red[SLOTS * 4];
+    const int n = a.n;
+    const int slot = threadIdx.x / NP, r = threadIdx.x % NP;
+    for (int s0 = 0; s0 < a.n_sweep; s0 += 4) {
+        const int nw = min(4, a.n_sweep - s0);
+        double accr[4] = {0.0, 0.0, 0.0, 0.0}, acci[4] = {0.0, 0.0, 0.0, 0.0};
+        for (int64_t k0 = (int64_t)blockIdx.x * SLOTS; k0 < a.nk; k0 += (int64_t)gridDim.x * SLOTS) {
+            const int64_t k = k0 + slot;
+            const bool act = k < a.nk;
+            const int64_t kc = act ? k : 0;
+            const double wk = act ? (a.w ? a.w[kc] : 1.0) : 0.0;
+            const double* __restrict__ hin = a.H.base + view_off(a.H, kc);
+            const int rr = r < n ? r : 0;
+            double hr[NP], hi[NP];  // row r of -H; rows / columns >= n: zero
+#pragma unroll
+            for (int j = 0; j < NP; ++j) {
+                const bool real = r < n && j < n;
+                const int jj = j < n ? j : 0;
+                const double vr = hin[(int64_t)(2 * (rr + n * jj)) * a.H.pitch], vi = hin[(int64_t)(2 * (rr + n * jj) + 1) * a.H.pitch];
+                hr[j] = real ? -vr : 0.0;
+                hi[j] = real ? -vi : 0.0;
+            }
+#pragma unroll 1
+            for (int q = 0; q < nw; ++q) {
+                double ar[NP], ai[NP];
+#pragma unroll
+                for (int j = 0; j < NP; ++j) {
+                    ar[j] = hr[j];
+                    ai[j] = hi[j];
+                }
+                panel_shift_row<NP, false>(n, a.sweep[s0 + q], a.eta, r, ar, ai);
+                panel_invert_rows<NP, false>(nullptr, n, r, ar, ai);
+                double tr, ti;
+                panel_trace<NP>(ar, ai, n, r, tr, ti);
+                const double dr = wk * (a.is_dos ? -ti * 0.31830988618379067153776752674503 : tr);
+                const double di = a.is_dos ? 0.0 : wk * ti;
+#pragma unroll
+                for (int qq = 0; qq < 4; ++qq) {
+                    accr[qq] += (qq == q) ? dr : 0.0;
+                    acci[qq] += (qq == q) ? di : 0.0;
+                }
+            }
+        }
+        __syncthreads();
+        if (r == 0)
+            for (int q = 0; q < 4; ++q) red[slot * 4 + q] = make_double2(accr[q], acci[q]);
+        __syncthreads();
+        if ((int)threadIdx.x < nw) {
+            double sr = 0.0, si = 0.0;
+            for (int sl = 0; sl < SLOTS; ++sl) {
+                sr += red[sl * 4 + threadIdx.x].x;
+                si += red[sl * 4 + threadIdx.x].y;
+            }
+            a.partial[(int64_t)blockIdx.x * a.n_sweep + s0 + threadIdx.x] = make_double2(sr, si);
+        }
+    }
+}
+
+static bool gen_rows_reduce_supported(const ReduceSpec& rs) {
+    static const bool off = [] { const char* e = getenv("ABZ_GEN_ROWREDUCE"); return e && e[0] == '0'; }();
+    return !off && rs.herm && rs.H.base && rs.n > 4 && rs.n <= 16 && (rs.integrand == ABZ_F_DOS || rs.integrand == ABZ_F_TRGLOC);
+}
+
+static int launch_gen_rows_reduce(abz_ctx* ctx, const ReduceSpec& rs, double* out_reim) {
+    const int np = rs.n <= 8 ? 8 : 16;
+    const int64_t blocks = std::min<int64_t>(cdiv2(rs.nk, 256 / np), 256 * 2);
+    int rc = ctx->scratch[1].reserve(sizeof(double2) * (size_t)(blocks * rs.n_sweep));
+    if (rc) return rc;
+    if ((rc = ctx->scratch[2].reserve(sizeof(double2) * (size_t)rs.n_sweep))) return rc;
+    GenRowsReduceArgs a;
+    a.H = rs.H;
+    a.w = rs.w;
+    a.sweep = rs.sweep_dev;
+    a.partial = ctx->scratch[1].as<double2>();
+    a.nk = rs.nk;
+    a.n = rs.n;
+    a.n_sweep = rs.n_sweep;
+    a.is_dos = rs.integrand == ABZ_F_DOS ? 1 : 0;
+    a.eta = rs.params[0];
+    double2* outd = ctx->scratch[2].as<double2>();
+    {
+        ProfScope ps(ctx, ABZ_K_REDUCE);
+        if (np == 8)
+            hipLaunchKernelGGL(gen_rows_reduce_kernel<8>, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, a);
+        else
+            hipLaunchKernelGGL(gen_rows_reduce_kernel<16>, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, a);
+        ABZ_HIP(hipGetLastError());
+        if ((rc = launch_final_reduce(ctx, a.partial, blocks, rs.n_sweep, rs.scale, outd))) return rc;
+    }
+    ABZ_HIP(hipMemcpyAsync(out_reim, outd, sizeof(double2) * (size_t)rs.n_sweep, hipMemcpyDeviceToHost, ctx->stream));
+    ABZ_HIP(hipStreamSynchronize(ctx->stream));
+    return ABZ_OK;
+}
+
 int launch_gen_reduce(abz_ctx* ctx, const ReduceSpec& rs, double* out_reim) {
+    if (gen_rows_reduce_supported(rs)) return launch_gen_rows_reduce(ctx, rs, out_reim);
     const int ncomp = integrand_ncomp(rs.integrand, rs.n, rs.d);
     if (ncomp < 0 || rs.integrand == ABZ_F_LINEAR || rs.integrand == ABZ_F_LINEAR_X) {
         set_error("integrand %d is not available for n = %d bands", rs.integrand, rs.n);
