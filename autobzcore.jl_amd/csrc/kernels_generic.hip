@@ -396,14 +396,6 @@ __device__ __forceinline__ double rsqrt_nr(double x) {  // 1/sqrt(x), x in the n
     return y;
 }
 
-// double2 entries of one node slot's two pivot-row buffers; the NP/4 of padding puts the slots of a wave
-// (64/NP of them, all reading / writing their buffers at once) on different LDS banks
-#ifdef ABZ_PANEL_NOPAD
-__host__ __device__ constexpr int panel_rowbuf(int np) { return 2 * np; }
-#else
-__host__ __device__ constexpr int panel_rowbuf(int np) { return 2 * np + np / 4; }
-#endif
-
 __device__ __forceinline__ double rcp_nr(double x) {  // 1/x, x in the normal range: estimate + 2 Newton steps
     double r = __builtin_amdgcn_rcp(x);
     r = fma(fma(-x, r, 1.0), r, r);
@@ -422,7 +414,7 @@ __device__ __forceinline__ void pin8(double2 (&u)[8]) {
 }
 
 // Row r (lane r of the node's NP lanes) of inv((sw + i eta) I - H(x)) into ar/ai; `coef` = the staged
-// coefficient set, `myrow` = this node slot's two pivot-row buffers.
+// coefficient set.
 // PAD: the set is staged as [M][NP*NP] with zeros outside the n x n block, so every loop runs to NP with
 // no condition on n (the padding block of A is the identity and stays decoupled: its columns are exact
 // zeros in the real rows).  !PAD: layout [M][n*n], loops guarded by (uniform) comparisons with n.
@@ -552,15 +544,14 @@ __device__ __forceinline__ void panel_pivots(int n, int r, double (&ar)[NP], dou
 
 // in-place inversion of the matrix whose row r this lane holds (rows >= n: identity rows, columns >= n of the real
 // rows: zeros -- by the zero-padded staging (PAD) or by panel_series_row / panel_shift_row (!PAD)).  The pivot rows
-// travel by `group_bcast`; `myrow` (the slot's LDS row buffers of the first version) is not used any more.
+// travel by `group_bcast` (the first version published them through per-slot LDS row buffers).
 template <int NP, bool PAD>
-__device__ __forceinline__ void panel_invert_rows(double2* myrow, int n, int r, double (&ar)[NP], double (&ai)[NP]) {
-    (void)myrow;
+__device__ __forceinline__ void panel_invert_rows(int n, int r, double (&ar)[NP], double (&ai)[NP]) {
     panel_pivots<NP, !PAD>(n, r, ar, ai, std::make_integer_sequence<int, NP>());
 }
 
 template <int NP, bool PAD>
-__device__ __forceinline__ void panel_inverse_row(const double2* coef, double2* myrow, int n, int M, int first,
+__device__ __forceinline__ void panel_inverse_row(const double2* coef, int n, int M, int first,
                                                   double xx, double sw, double eta, int r, double (&ar)[NP],
                                                   double (&ai)[NP]) {
     double zr, zi, pr, pi;
@@ -568,7 +559,7 @@ __device__ __forceinline__ void panel_inverse_row(const double2* coef, double2* 
     sincospi(2.0 * ((double)first * xx), &pi, &pr);
     panel_series_row<NP, PAD>(coef, n, M, zr, zi, pr, pi, r, ar, ai);
     panel_shift_row<NP, PAD>(n, sw, eta, r, ar, ai);
-    panel_invert_rows<NP, PAD>(myrow, n, r, ar, ai);
+    panel_invert_rows<NP, PAD>(n, r, ar, ai);
 }
 
 // stage one coefficient set [M][n*n] into LDS, zero-padded to [M][NP*NP] when PAD
@@ -611,9 +602,7 @@ __global__ __launch_bounds__(256) void gen_panel_kernel(GenArgs a) {
     constexpr int SLOTS = 256 / NP;
     const int n = a.n, nn = n * n, M = a.M;
     double2* coef = lds_p;                    // [M][nn] or [M][NP*NP]
-    double2* prow = lds_p + (size_t)M * (PAD ? NP * NP : nn);   // [SLOTS][2][NP] pivot rows (double-buffered)
     const int slot = threadIdx.x / NP, r = threadIdx.x % NP;
-    double2* myrow = prow + (size_t)slot * panel_rowbuf(NP);
     const int64_t ngroups = a.nnodes / 15;
     for (int64_t g = blockIdx.x; g < ngroups; g += gridDim.x) {
         const int64_t node0 = g * 15;
@@ -627,7 +616,7 @@ __global__ __launch_bounds__(256) void gen_panel_kernel(GenArgs a) {
             const int64_t k = node0 + (act ? q : 0);
             const double sw = a.sweep_per_node ? a.sweep_per_node[k] : a.sweep0;
             double ar[NP], ai[NP];
-            panel_inverse_row<NP, PAD>(coef, myrow, n, M, a.first, a.x[k] * a.inv_period, sw, a.p[0], r, ar, ai);
+            panel_inverse_row<NP, PAD>(coef, n, M, a.first, a.x[k] * a.inv_period, sw, a.p[0], r, ar, ai);
             if (a.integrand == ABZ_F_GLOC) {
                 if (act && r < n) {
                     double2* out = a.values + k * a.ncomp;
@@ -669,10 +658,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 4))) voi
     constexpr int SLOTS = 256 / NP;
     const int n = a.n, nn = n * n, M = a.M;
     double2* coef = lds_gs;
-    double2* prow = coef + (size_t)M * (PAD ? NP * NP : nn);
-    double2* red = prow + (size_t)SLOTS * panel_rowbuf(NP);  // [SLOTS][4]
+    double2* red = coef + (size_t)M * (PAD ? NP * NP : nn);  // [SLOTS][4]
     const int slot = threadIdx.x / NP, r = threadIdx.x % NP;
-    double2* myrow = prow + (size_t)slot * panel_rowbuf(NP);
     int fm = a.first % a.npt;
     if (fm < 0) fm += a.npt;
     double accr[4] = {0.0, 0.0, 0.0, 0.0}, acci[4] = {0.0, 0.0, 0.0, 0.0};
@@ -697,7 +684,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 4))) voi
                     ai[j] = hi[j];
                 }
                 panel_shift_row<NP, PAD>(n, a.sweep[q], a.eta, r, ar, ai);
-                panel_invert_rows<NP, PAD>(myrow, n, r, ar, ai);
+                panel_invert_rows<NP, PAD>(n, r, ar, ai);
                 double tr, ti;
                 panel_trace<NP>(ar, ai, n, r, tr, ti);
                 const double dr = !act ? 0.0 : (a.is_dos ? -ti * 0.31830988618379067153776752674503 : tr);
@@ -728,14 +715,14 @@ bool gen_sum_supported(int n, int M, int npt, int integrand, bool herm) {
     if (n <= 4 || n > ABZ_MAX_BANDS || !herm || npt < 1 || npt >= 65536) return false;
     if (!(integrand == ABZ_F_DOS || integrand == ABZ_F_TRGLOC)) return false;
     const int np = n <= 8 ? 8 : (n <= 16 ? 16 : 32);
-    const size_t rest = sizeof(double2) * ((size_t)(256 / np) * panel_rowbuf(np) + (size_t)(256 / np) * 4);
+    const size_t rest = sizeof(double2) * (size_t)(256 / np) * 4;
     return sizeof(double2) * (size_t)M * n * n + rest <= 150 * 1024;
 }
 
 int launch_gen_sum(abz_ctx* ctx, const SumSpec& ss, double* out_reim) {
     const int n = ss.n, M = ss.M;
     const int np = n <= 8 ? 8 : (n <= 16 ? 16 : 32);
-    const size_t rest = sizeof(double2) * ((size_t)(256 / np) * panel_rowbuf(np) + (size_t)(256 / np) * 4);
+    const size_t rest = sizeof(double2) * (size_t)(256 / np) * 4;
     size_t lds = sizeof(double2) * (size_t)M * np * np + rest;
     const bool pad = lds <= 150 * 1024;
     if (!pad) lds = sizeof(double2) * (size_t)M * n * n + rest;
@@ -1116,9 +1103,9 @@ static bool gen_panel_supported(const GenSpec& gs, int* np_out, size_t* lds_out,
     if (!(gs.integrand == ABZ_F_DOS || gs.integrand == ABZ_F_TRGLOC || gs.integrand == ABZ_F_GLOC)) return false;
     if (gs.Hplanes.base || gs.Eplanes.base || gs.Uplanes.base || gs.Haos || gs.Eaos) return false;
     const int np = gs.n <= 8 ? 8 : (gs.n <= 16 ? 16 : 32);
-    size_t lds = sizeof(double2) * ((size_t)gs.M * np * np + (size_t)(256 / np) * panel_rowbuf(np));  // zero-padded set
+    size_t lds = sizeof(double2) * (size_t)gs.M * np * np;  // zero-padded set
     *pad_out = lds <= 150 * 1024;
-    if (!*pad_out) lds = sizeof(double2) * ((size_t)gs.M * gs.n * gs.n + (size_t)(256 / np) * panel_rowbuf(np));
+    if (!*pad_out) lds = sizeof(double2) * (size_t)gs.M * gs.n * gs.n;
     if (lds > 150 * 1024) return false;
     *np_out = np;
     *lds_out = lds;
@@ -1379,7 +1366,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 4))) voi
                     ai[j] = hi[j];
                 }
                 panel_shift_row<NP, false>(n, a.sweep[s0 + q], a.eta, r, ar, ai);
-                panel_invert_rows<NP, false>(nullptr, n, r, ar, ai);
+                panel_invert_rows<NP, false>(n, r, ar, ai);
                 double tr, ti;
                 panel_trace<NP>(ar, ai, n, r, tr, ti);
                 const double dr = wk * (a.is_dos ? -ti * 0.31830988618379067153776752674503 : tr);
@@ -1622,8 +1609,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(WPE ? WPE : 
     constexpr int MS = ABZ_INNER_MAXSEG;
     const int n = a.n, nn = n * n, M = a.M, nc = a.ncomp;  // nc = 1 (DOS, TRGLOC)
     double2* coef = lds_ip;
-    double2* prow = coef + (size_t)M * (PAD ? NP * NP : nn);
-    double* g = reinterpret_cast<double*>(prow + (size_t)SLOTS * panel_rowbuf(NP));
+    double* g = reinterpret_cast<double*>(coef + (size_t)M * (PAD ? NP * NP : nn));
     double* seg_a = g;
     double* seg_b = seg_a + MS;
     double* seg_E = seg_b + MS;
@@ -1632,7 +1618,6 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(WPE ? WPE : 
     int* heap = reinterpret_cast<int*>(vals + (size_t)30 * nc);
     double* ctl = reinterpret_cast<double*>(heap + MS);
     const int slot = threadIdx.x / NP, r = threadIdx.x % NP;
-    double2* myrow = prow + (size_t)slot * panel_rowbuf(NP);
     for (int64_t q = blockIdx.x; q < a.nint; q += gridDim.x) {
         AdaptStateT<1> st;
         __syncthreads();  // the previous integral's readers are done with coef / ctl
@@ -1654,7 +1639,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(WPE ? WPE : 
                 const int pnl = tt / 15, i = tt - 15 * pnl;
                 const double x = gk15_node(ctl[1 + 2 * pnl], ctl[2 + 2 * pnl], i);
                 double ar[NP], ai[NP];
-                panel_inverse_row<NP, PAD>(coef, myrow, n, M, a.first, x * a.inv_period, swq, a.p[0], r, ar, ai);
+                panel_inverse_row<NP, PAD>(coef, n, M, a.first, x * a.inv_period, swq, a.p[0], r, ar, ai);
                 double tr, ti;
                 panel_trace<NP>(ar, ai, n, r, tr, ti);
                 if (act && r == 0) {
@@ -1690,8 +1675,7 @@ static int gen_inner_panel_threads(int np) {
 static bool gen_inner_panel_fits(int n, int M, int integrand, int* np_out, size_t* lds_out, bool* pad_out) {
     if (!(integrand == ABZ_F_DOS || integrand == ABZ_F_TRGLOC)) return false;
     const int np = n <= 8 ? 8 : (n <= 16 ? 16 : 32);
-    const size_t rest = sizeof(double2) * (size_t)(gen_inner_panel_threads(np) / np) * panel_rowbuf(np) +
-                        sizeof(double) * (size_t)inner_group_doubles(1);
+    const size_t rest = sizeof(double) * (size_t)inner_group_doubles(1);
     size_t lds = sizeof(double2) * (size_t)M * np * np + rest;  // zero-padded set
     const bool pad = lds <= 150 * 1024;
     if (!pad) lds = sizeof(double2) * (size_t)M * n * n + rest;
