@@ -358,7 +358,7 @@ def main():
                                       "nodes_per_sec": sol.numevals / dt}
             except Exception as e:
                 out["iai_config5"] = {"error": str(e)}
-        if not a.no_cpu:
+        if not a.no_cpu and world == 1:  # the CPU leg is timed at N = 1 only
             try:
                 out["cpu_baseline"] = cpu_baseline(a.cpu_npt, 4, s)
                 cb = out["cpu_baseline"]
