@@ -679,6 +679,32 @@ def test_generic_n_eval_and_rules(abz, d, n):
         assert np.abs(g[i].reshape(n, n).T - G).max() <= 1e-10 * np.abs(G).max()
 
 
+@pytest.mark.parametrize("n3,copies", [(3, 2), (5, 3), (2, 8)])
+def test_generic_n_eigenvalues_degenerate_and_diagonal(abz, n3, copies):
+    """The row-layout Jacobi of rule builds for 5..16 bands on exactly degenerate spectra (block-diagonal copies of
+    one series: every eigenvalue `copies`-fold) and on an already diagonal H(k)."""
+    rng = np.random.default_rng(31 + n3)
+    c3, first = rand_series(rng, (3, 5), n3, hermitian=True)
+    n = n3 * copies
+    c = np.zeros(c3.shape[:2] + (n, n), dtype=complex)
+    for b in range(copies):
+        c[..., b * n3:(b + 1) * n3, b * n3:(b + 1) * n3] = c3
+    s, so = both(abz, c, first)
+    npt = 10
+    out = s.device().rule(npt, None, want=3).export(H=True, eig=True)
+    e3 = np.linalg.eigvalsh(out["H"][:, :n3, :n3], UPLO="U")
+    ref = np.sort(np.repeat(e3, copies, axis=1), axis=1)
+    assert np.abs(out["eig"] - ref).max() <= 1e-12 * np.abs(ref).max()
+    # diagonal H(k): nothing to rotate
+    cd = np.zeros_like(c)
+    for a in range(n):
+        cd[..., a, a] = c3[..., 0, 0] * (1.0 + 0.1 * a)
+    sd, sod = both(abz, cd, first)
+    outd = sd.device().rule(npt, None, want=3).export(H=True, eig=True)
+    diag = np.real(np.einsum("kaa->ka", outd["H"]))
+    assert np.abs(outd["eig"] - np.sort(diag, axis=1)).max() <= 1e-13 * np.abs(diag).max()
+
+
 @pytest.mark.parametrize("n", [6, 12, 20])
 def test_generic_n_iai_matches_oracle(abz, n):
     """n = 6 / 12 / 20 take the 8- / 16- / 32-lane rows of the panel kernel (gen_panel_kernel)."""
