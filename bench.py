@@ -358,6 +358,33 @@ def main():
                                       "nodes_per_sec": sol.numevals / dt}
             except Exception as e:
                 out["iai_config5"] = {"error": str(e)}
+            # the same 16-band model on fixed grids: store-free PTR sums, a cached rule with eigenvalues, its scan
+            try:
+                from autobzcore.jl_amd import _lib as L16
+                dev16 = s16.device()
+                om16 = np.linspace(-1.0, 1.0, 16)
+                b16 = {}
+                dev16.ptr_sum(96, L16.F_DOS, [0.05], om16)
+                t0 = time.perf_counter()
+                dev16.ptr_sum(96, L16.F_DOS, [0.05], om16)
+                dt = time.perf_counter() - t0
+                b16["store_free_96cubed_16_omega"] = {"seconds": dt, "kpoint_omega_per_sec": 96**3 * 16 / dt}
+                r16 = abz.DeviceRule(dev16, 48, None, L16.WANT_H | L16.WANT_EIG)
+                dev16.ctx.sync()
+                t0 = time.perf_counter()
+                r16.rebuild()
+                dev16.ctx.sync()
+                dt = time.perf_counter() - t0
+                b16["rule_48cubed_H_and_eig"] = {"seconds": dt, "kpoints_per_sec": 48**3 / dt}
+                r16.reduce(L16.F_DOS, [0.05], om16)
+                t0 = time.perf_counter()
+                r16.reduce(L16.F_DOS, [0.05], om16)
+                dt = time.perf_counter() - t0
+                b16["rule_scan_16_omega"] = {"seconds": dt, "kpoint_omega_per_sec": 48**3 * 16 / dt}
+                r16.close()
+                out["bands16_fixed_grids"] = b16
+            except Exception as e:
+                out["bands16_fixed_grids"] = {"error": str(e)}
         if not a.no_cpu and world == 1:  # the CPU leg is timed at N = 1 only
             try:
                 out["cpu_baseline"] = cpu_baseline(a.cpu_npt, 4, s)
