@@ -905,6 +905,15 @@ __device__ __forceinline__ void jacobi_step(int r, int lane, double tiny, double
         }
     }
     jacobi_all_columns<NP, T, VEC>(c, s, gr, gi, ar, ai, vr, vi, std::make_integer_sequence<int, NP / 2>());
+    // the rotated pair's off-diagonal entry is zero by construction: make it exact (left to rounding it stalls at
+    // ~1e-16 ||A|| and the sweeps never see convergence)
+#pragma unroll
+    for (int j = 0; j < NP; ++j) {
+        if (j == pr) {
+            ar[j] = 0.0;
+            ai[j] = 0.0;
+        }
+    }
 }
 
 template <int NP, bool VEC, int... T>
