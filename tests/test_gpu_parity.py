@@ -705,6 +705,27 @@ def test_generic_n_eigenvalues_degenerate_and_diagonal(abz, n3, copies):
     assert np.abs(outd["eig"] - np.sort(diag, axis=1)).max() <= 1e-13 * np.abs(diag).max()
 
 
+@pytest.mark.parametrize("n,kind", [(6, "CubicSymIBZ"), (11, "InversionSymIBZ"), (16, "CubicSymIBZ")])
+def test_generic_n_symmetric_ptr_sweep(abz, n, kind):
+    """PTR on the irreducible nodes with integer weights for more than four bands (symmetric rule built by the
+    wave-per-node kernel, scanned by the row kernel, 4 swept values per pass: 7 omegas = one full + one ragged
+    pass) against the oracle's symmetric rule sum; ref: src/fourier.jl:210-292, src/brillouin.jl:337-355."""
+    rng = np.random.default_rng(500 + n)
+    c, first = rand_series(rng, (3, 3, 3), n, hermitian=True)
+    c = c / np.sqrt(n)
+    s, so = both(abz, c, first)
+    kinds = {"InversionSymIBZ": abz.InversionSymIBZ(), "CubicSymIBZ": abz.CubicSymIBZ()}
+    bz = abz.load_bz(kinds[kind], np.eye(3))
+    obz = orc.load_bz(kind, np.eye(3))
+    eta, npt = 0.2, 7
+    omegas = np.linspace(-0.8, 0.9, 7)
+    solver = abz.IntegralSolver(abz.FourierIntegrand(abz.DOSIntegrand(), s, eta), bz, abz.PTR(npt=npt))
+    got = np.asarray(abz.batchsolve(solver, omegas), dtype=float)
+    for u, om in zip(got, omegas):
+        ref = orc.solve_ptr(so, obz, orc.f_dos(eta, om), npt=npt).u
+        assert abs(u - ref) <= 1e-10 * abs(ref)
+
+
 @pytest.mark.parametrize("n", [6, 12, 20])
 def test_generic_n_iai_matches_oracle(abz, n):
     """n = 6 / 12 / 20 take the 8- / 16- / 32-lane rows of the panel kernel (gen_panel_kernel)."""
