@@ -1402,12 +1402,115 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 4))) voi
     }
 }
 
+// Matrix-valued scan (G_loc = sum_k w_k inv((omega + i eta) I - H(k))) on the same rows: one swept value per pass,
+// lane r accumulates row r of the resolvent; the node slots of a wave are summed by shuffles, the waves of a block
+// through LDS.  partial: [blocks][n_sweep][n*n] complex, component r + n*c (column-major, as `integrand_value`).
+template <int NP>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 4))) void gen_rows_gloc_kernel(GenRowsReduceArgs a) {
+    __shared__ double2 red[4][NP * NP];
+    constexpr int SLOTS = 256 / NP;
+    const int n = a.n, nn = n * n;
+    const int slot = threadIdx.x / NP, r = threadIdx.x % NP, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    for (int s0 = 0; s0 < a.n_sweep; ++s0) {
+        const double sw = a.sweep[s0];
+        double gr[NP], gi[NP];
+#pragma unroll
+        for (int j = 0; j < NP; ++j) {
+            gr[j] = 0.0;
+            gi[j] = 0.0;
+        }
+        for (int64_t k0 = (int64_t)blockIdx.x * SLOTS; k0 < a.nk; k0 += (int64_t)gridDim.x * SLOTS) {
+            const int64_t k = k0 + slot;
+            const bool act = k < a.nk;
+            const int64_t kc = act ? k : 0;
+            const double wk = act ? (a.w ? a.w[kc] : 1.0) : 0.0;
+            const double* __restrict__ hin = a.H.base + view_off(a.H, kc);
+            const int rr = r < n ? r : 0;
+            double ar[NP], ai[NP];
+#pragma unroll
+            for (int j = 0; j < NP; ++j) {
+                const bool real = r < n && j < n;
+                const int jj = j < n ? j : 0;
+                const double vr = hin[(int64_t)(2 * (rr + n * jj)) * a.H.pitch], vi = hin[(int64_t)(2 * (rr + n * jj) + 1) * a.H.pitch];
+                ar[j] = real ? -vr : 0.0;
+                ai[j] = real ? -vi : 0.0;
+            }
+            panel_shift_row<NP, false>(n, sw, a.eta, r, ar, ai);
+            panel_invert_rows<NP, false>(n, r, ar, ai);
+#pragma unroll
+            for (int j = 0; j < NP; ++j) {
+                gr[j] = fma(wk, ar[j], gr[j]);
+                gi[j] = fma(wk, ai[j], gi[j]);
+            }
+        }
+        // the 64 / NP node slots of a wave
+#pragma unroll
+        for (int j = 0; j < NP; ++j) {
+#pragma unroll
+            for (int off = NP; off < 64; off <<= 1) {
+                gr[j] += __shfl_xor(gr[j], off, 64);
+                gi[j] += __shfl_xor(gi[j], off, 64);
+            }
+        }
+        __syncthreads();  // the previous swept value's readers are done with `red`
+        if (lane < NP) {
+#pragma unroll
+            for (int j = 0; j < NP; ++j) red[wave][r + NP * j] = make_double2(gr[j], gi[j]);
+        }
+        __syncthreads();
+        for (int t = threadIdx.x; t < nn; t += 256) {
+            const int rw = t % n, c = t / n;
+            const int e = rw + NP * c;
+            const double2 v0 = red[0][e], v1 = red[1][e], v2 = red[2][e], v3 = red[3][e];
+            a.partial[((int64_t)blockIdx.x * a.n_sweep + s0) * nn + t] = make_double2((v0.x + v1.x) + (v2.x + v3.x), (v0.y + v1.y) + (v2.y + v3.y));
+        }
+    }
+}
+
 static bool gen_rows_reduce_supported(const ReduceSpec& rs) {
     static const bool off = [] { const char* e = getenv("ABZ_GEN_ROWREDUCE"); return e && e[0] == '0'; }();
-    return !off && rs.herm && rs.H.base && rs.n > 4 && rs.n <= 16 && (rs.integrand == ABZ_F_DOS || rs.integrand == ABZ_F_TRGLOC);
+    return !off && rs.herm && rs.H.base && rs.n > 4 && rs.n <= 16 &&
+           (rs.integrand == ABZ_F_DOS || rs.integrand == ABZ_F_TRGLOC || rs.integrand == ABZ_F_GLOC);
+}
+
+static int launch_gen_rows_gloc(abz_ctx* ctx, const ReduceSpec& rs, double* out_reim) {
+    const int np = rs.n <= 8 ? 8 : 16, nn = rs.n * rs.n;
+    const int64_t blocks = std::min<int64_t>(cdiv2(rs.nk, 256 / np), 256);
+    // swept values per launch: partial sums of at most 64 MB
+    const int chunk = (int)std::max<int64_t>(1, std::min<int64_t>(rs.n_sweep, (64ll << 20) / (int64_t)(sizeof(double2) * blocks * nn)));
+    int rc = ctx->scratch[1].reserve(sizeof(double2) * (size_t)(blocks * chunk * nn));
+    if (rc) return rc;
+    if ((rc = ctx->scratch[2].reserve(sizeof(double2) * (size_t)chunk * nn))) return rc;
+    GenRowsReduceArgs a;
+    a.H = rs.H;
+    a.w = rs.w;
+    a.partial = ctx->scratch[1].as<double2>();
+    a.nk = rs.nk;
+    a.n = rs.n;
+    a.is_dos = 0;
+    a.eta = rs.params[0];
+    double2* outd = ctx->scratch[2].as<double2>();
+    for (int s0 = 0; s0 < rs.n_sweep; s0 += chunk) {
+        a.n_sweep = std::min(chunk, rs.n_sweep - s0);
+        a.sweep = rs.sweep_dev + s0;
+        {
+            ProfScope ps(ctx, ABZ_K_REDUCE);
+            if (np == 8)
+                hipLaunchKernelGGL(gen_rows_gloc_kernel<8>, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, a);
+            else
+                hipLaunchKernelGGL(gen_rows_gloc_kernel<16>, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, a);
+            ABZ_HIP(hipGetLastError());
+            if ((rc = launch_final_reduce(ctx, a.partial, blocks, (int64_t)a.n_sweep * nn, rs.scale, outd))) return rc;
+        }
+        ABZ_HIP(hipMemcpyAsync(out_reim + 2 * (size_t)s0 * nn, outd, sizeof(double2) * (size_t)a.n_sweep * nn, hipMemcpyDeviceToHost,
+                               ctx->stream));
+        ABZ_HIP(hipStreamSynchronize(ctx->stream));
+    }
+    return ABZ_OK;
 }
 
 static int launch_gen_rows_reduce(abz_ctx* ctx, const ReduceSpec& rs, double* out_reim) {
+    if (rs.integrand == ABZ_F_GLOC) return launch_gen_rows_gloc(ctx, rs, out_reim);
     const int np = rs.n <= 8 ? 8 : 16;
     const int64_t blocks = std::min<int64_t>(cdiv2(rs.nk, 256 / np), 256 * 2);
     int rc = ctx->scratch[1].reserve(sizeof(double2) * (size_t)(blocks * rs.n_sweep));
