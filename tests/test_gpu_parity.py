@@ -705,6 +705,27 @@ def test_generic_n_eigenvalues_degenerate_and_diagonal(abz, n3, copies):
     assert np.abs(outd["eig"] - np.sort(diag, axis=1)).max() <= 1e-13 * np.abs(diag).max()
 
 
+def test_generic_n_gloc_long_sweep(abz):
+    """Matrix-valued G_loc scan of a 16-band rule over 70 swept values (more than one launch of the row kernel: its
+    partial sums are capped at 64 MB) against numpy on the exported H(k) and, at both ends, the oracle's rule sum."""
+    rng = np.random.default_rng(909)
+    n, npt, eta = 16, 16, 0.15
+    c, first = rand_series(rng, (3, 3, 3), n, hermitian=True)
+    c = c / np.sqrt(n)
+    s, so = both(abz, c, first)
+    rule = s.device().rule(npt, None, want=1)
+    H = rule.export(H=True)["H"]
+    omegas = np.linspace(-1.0, 1.0, 70)
+    g = rule.reduce(abz._lib.F_GLOC, [eta], omegas)
+    eye = np.eye(n)
+    for i in (0, 33, 63, 64, 69):
+        ref = np.linalg.inv((omegas[i] + 1j * eta) * eye - H).mean(axis=0)
+        assert np.abs(g[i].reshape(n, n).T - ref).max() <= 1e-11 * np.abs(ref).max()
+    for i in (0, 69):
+        G, _ = orc._ptr_rule_sum(so, npt, None, orc.f_gloc(eta, omegas[i]))
+        assert np.abs(g[i].reshape(n, n).T - G).max() <= 1e-10 * np.abs(G).max()
+
+
 @pytest.mark.parametrize("n,kind", [(6, "CubicSymIBZ"), (11, "InversionSymIBZ"), (16, "CubicSymIBZ")])
 def test_generic_n_symmetric_ptr_sweep(abz, n, kind):
     """PTR on the irreducible nodes with integer weights for more than four bands (symmetric rule built by the
