@@ -291,4 +291,53 @@ function ggr(h::FourierSeries{S,N}, bz::SymmetricBZ, Es::Vector{Float64}; npt=50
     return out
 end
 
+# ---------------------------------------------------------------- the rest of abzhip.h (housekeeping)
+version() = Int(ccall((:abz_version, libabz), Cint, ()))
+function device_count()
+    n = Ref{Cint}(0)
+    check(ccall((:abz_device_count, libabz), Cint, (Ptr{Cint},), n))
+    return Int(n[])
+end
+synchronize(ctx::HIPContext=context()) = check(ccall((:abz_ctx_sync, libabz), Cint, (Ptr{Cvoid},), ctx.h))
+
+"New coefficients of the same shape (mutating `h.c`, test/dos.jl:122-129); cached rules go stale until `rebuild!`."
+function update!(hs::HIPSeries, s::FourierSeries)
+    coef = reinterpret(Float64, vec(s.c))
+    GC.@preserve coef check(ccall((:abz_series_update, libabz), Cint, (Ptr{Cvoid}, Ptr{Float64}), hs.h, coef))
+    return hs
+end
+rebuild!(r::HIPRule) = (check(ccall((:abz_rule_rebuild, libabz), Cint, (Ptr{Cvoid},), r.h)); r)
+
+function rule_info(r::HIPRule)
+    nk = Ref{Int64}(0); n = Ref{Cint}(0); d = Ref{Cint}(0); npt = Ref{Cint}(0); want = Ref{Cint}(0)
+    check(ccall((:abz_rule_info, libabz), Cint, (Ptr{Cvoid}, Ptr{Int64}, Ptr{Cint}, Ptr{Cint}, Ptr{Cint}, Ptr{Cint}),
+                r.h, nk, n, d, npt, want))
+    return (nk=nk[], n=Int(n[]), d=Int(d[]), npt=Int(npt[]), want=want[])
+end
+
+"`symptr_rule` with the orbit tables computed on the GPU (bit-identical to the host version, ~50x faster on large grids)."
+function symptr_rule_device(npt, ::Val{d}, syms; ctx::HIPContext=context()) where {d}
+    S = Cint[round(Int, M[a, b]) for M in syms for a in 1:d for b in 1:d]   # row-major per matrix
+    nirr = Ref{Int64}(0)
+    check(ccall((:abz_symptr_rule_device, libabz), Cint,
+                (Ptr{Cvoid}, Cint, Cint, Ptr{Cint}, Cint, Ptr{Int64}, Ptr{Cint}, Ptr{Int64}),
+                ctx.h, npt, d, S, length(syms), nirr, C_NULL, C_NULL))   # first call: count
+    idx = Matrix{Cint}(undef, d, nirr[]); w = Vector{Int64}(undef, nirr[])
+    check(ccall((:abz_symptr_rule_device, libabz), Cint,
+                (Ptr{Cvoid}, Cint, Cint, Ptr{Cint}, Cint, Ptr{Int64}, Ptr{Cint}, Ptr{Int64}),
+                ctx.h, npt, d, S, length(syms), nirr, idx, w))
+    return idx, w
+end
+
+"HIP-event timing of the library's own launches: `prof_enable(true)`, run, `prof_read(K_EVAL)` -> (ms, launches)."
+const K_CONTRACT, K_EVAL, K_REDUCE, K_GGR, K_EIG = Cint.(0:4)
+prof_enable(on::Bool=true; ctx::HIPContext=context()) =
+    check(ccall((:abz_prof_enable, libabz), Cint, (Ptr{Cvoid}, Cint), ctx.h, on ? 1 : 0))
+prof_reset(; ctx::HIPContext=context()) = check(ccall((:abz_prof_reset, libabz), Cint, (Ptr{Cvoid},), ctx.h))
+function prof_read(kernel::Cint; ctx::HIPContext=context())
+    ms = Ref{Float64}(0.0); n = Ref{Int64}(0)
+    check(ccall((:abz_prof_read, libabz), Cint, (Ptr{Cvoid}, Cint, Ptr{Float64}, Ptr{Int64}), ctx.h, kernel, ms, n))
+    return ms[], n[]
+end
+
 end # module
