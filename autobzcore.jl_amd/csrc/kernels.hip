@@ -354,6 +354,28 @@ __device__ __forceinline__ void load_planes(CMat<N>& H, const PlaneView& v, int6
     }
 }
 
+// Hermitian values: the upper triangle's planes only (n^2 loads instead of 2 n^2), the rest mirrored in registers
+template <int N>
+__device__ __forceinline__ void load_planes_herm(CMat<N>& H, const PlaneView& v, int64_t off) {
+    const double* __restrict__ in = v.base + off;
+#pragma unroll
+    for (int b = 0; b < N; ++b) {
+#pragma unroll
+        for (int a = 0; a <= b; ++a) {
+            H.re[a][b] = in[(int64_t)(2 * (a + N * b)) * v.pitch];
+            H.im[a][b] = (a == b) ? 0.0 : in[(int64_t)(2 * (a + N * b) + 1) * v.pitch];
+        }
+    }
+#pragma unroll
+    for (int b = 0; b < N; ++b) {
+#pragma unroll
+        for (int a = b + 1; a < N; ++a) {
+            H.re[a][b] = H.re[b][a];
+            H.im[a][b] = -H.im[b][a];
+        }
+    }
+}
+
 struct EvalArgs {
     const double2* src;
     const double2* tab;
@@ -1234,7 +1256,7 @@ __global__ __launch_bounds__(256, FID == ABZ_F_GLOC ? (HERM ? 2 : 1) : ((HERM ||
                 charpoly_init_h2(in[0], in[6 * pp], in[4 * pp], in[5 * pp], cph[j]);
             }
         } else if constexpr (poly4) {
-            load_planes<N>(H[0], a.H, voff);
+            load_planes_herm<N>(H[0], a.H, voff);
             if constexpr (N == 4) charpoly_init_h4(H[0], cp4[j]);
         } else if constexpr (needH) {
             load_planes<N>(H[(usePoly0 || adjG) ? 0 : j], a.H, voff);
