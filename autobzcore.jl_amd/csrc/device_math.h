@@ -677,10 +677,12 @@ __device__ __forceinline__ void charpoly_trace_h(const CharPolyH& cp, double w, 
     tr = NEED_RE ? fma(nr, dr, ni * di) * inv : 0.0;
 }
 
-// N = 4, Hermitian: characteristic polynomial of B = H - (tr H / 4) I by Faddeev-LeVerrier,
-// p(w) = w^4 + c2 w^2 + c3 w + c4 with REAL coefficients (c1 = -tr B = 0):
-//   M2 = B,  c2 = -tr(B M2)/2;  M3 = B M2 + c2 I,  c3 = -tr(B M3)/3;  M4 = B M3 + c3 I,  c4 = -tr(B M4)/4.
-// ~700 flops once per node; every sweep value then costs ~36 instead of a 4x4 complex inversion.
+// N = 4, Hermitian: characteristic polynomial of B = H - (tr H / 4) I,
+// p(w) = w^4 + c2 w^2 + c3 w + c4 with REAL coefficients (c1 = -tr B = 0), from the power sums s_k = tr B^k by
+// Newton's identities: c2 = -s2/2, c3 = -s3/3, c4 = (s2^2/2 - s4)/4 (the Faddeev-LeVerrier recursion with tr B = 0).
+// B is Hermitian, so only the upper triangle of B^2 is formed: s2 = tr B^2, s3 = sum (B^2)_ab B_ba, s4 = ||B^2||_F^2.
+// ~170 flops once per node (three full 4x4 complex products in the first version: ~770); every sweep value then
+// costs ~36 instead of a 4x4 complex inversion.
 struct CharPolyH4 {
     double q, c2, c3, c4;
 };
@@ -692,39 +694,35 @@ __device__ __forceinline__ void charpoly_init_h4(const CMat<4>& H, CharPolyH4& c
         B.re[a][a] -= q;
         B.im[a][a] = 0.0;
     }
-    // P = B * M (complex 4x4); only Re tr(B M) and the matrix itself are needed
-    auto mul = [&](const CMat<4>& M, CMat<4>& P) {
+    double s2 = 0.0, s3 = 0.0, s4 = 0.0;
 #pragma unroll
-        for (int a = 0; a < 4; ++a) {
+    for (int a = 0; a < 4; ++a) {
 #pragma unroll
-            for (int b = 0; b < 4; ++b) {
-                double pr = 0.0, pi = 0.0;
+        for (int b = a; b < 4; ++b) {
+            double pr = 0.0, pi = 0.0;  // (B^2)_ab
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    pr = fma(B.re[a][k], M.re[k][b], pr);
-                    pr = fma(-B.im[a][k], M.im[k][b], pr);
-                    pi = fma(B.re[a][k], M.im[k][b], pi);
-                    pi = fma(B.im[a][k], M.re[k][b], pi);
+            for (int k = 0; k < 4; ++k) {
+                pr = fma(B.re[a][k], B.re[k][b], pr);
+                pr = fma(-B.im[a][k], B.im[k][b], pr);
+                if (a != b) {
+                    pi = fma(B.re[a][k], B.im[k][b], pi);
+                    pi = fma(B.im[a][k], B.re[k][b], pi);
                 }
-                P.re[a][b] = pr;
-                P.im[a][b] = pi;
+            }
+            if (a == b) {
+                s2 += pr;
+                s3 = fma(pr, B.re[a][a], s3);
+                s4 = fma(pr, pr, s4);
+            } else {
+                s3 = fma(2.0, fma(pr, B.re[a][b], pi * B.im[a][b]), s3);  // 2 Re((B^2)_ab conj(B_ab))
+                s4 = fma(2.0, fma(pr, pr, pi * pi), s4);
             }
         }
-    };
-    CMat<4> P2, P3, P4;
-    mul(B, P2);  // B^2
-    const double c2 = -0.5 * (P2.re[0][0] + P2.re[1][1] + P2.re[2][2] + P2.re[3][3]);
-#pragma unroll
-    for (int a = 0; a < 4; ++a) P2.re[a][a] += c2;  // M3
-    mul(P2, P3);
-    const double c3 = -(1.0 / 3.0) * (P3.re[0][0] + P3.re[1][1] + P3.re[2][2] + P3.re[3][3]);
-#pragma unroll
-    for (int a = 0; a < 4; ++a) P3.re[a][a] += c3;  // M4
-    mul(P3, P4);
+    }
     cp.q = q;
-    cp.c2 = c2;
-    cp.c3 = c3;
-    cp.c4 = -0.25 * (P4.re[0][0] + P4.re[1][1] + P4.re[2][2] + P4.re[3][3]);
+    cp.c2 = -0.5 * s2;
+    cp.c3 = -(1.0 / 3.0) * s3;
+    cp.c4 = 0.25 * (0.5 * s2 * s2 - s4);
 }
 // tr inv((w + i eta) I - H) = p'(z) / p(z), z = (w - q) + i eta
 template <bool NEED_RE>
