@@ -808,6 +808,129 @@ __device__ __forceinline__ void adj_gloc_h3(const AdjH3& s, double w, double eta
     }
 }
 
+// Hermitian H, N = 4, matrix-valued resolvent by the same route: with B = H - q I traceless and the
+// Faddeev-LeVerrier matrices M2 = B, M3 = B^2 + c2 I, M4 = B M3 + c3 I (all Hermitian, they are polynomials in B),
+//   adj(w I - B) = w^3 I + w^2 B + w M3 + M4,   G(z) = adj(w I - B) / p(w),   w = z - q.
+// Per node: the three matrices once (upper triangles, 48 doubles); per sweep value ~230 flops for the 16 entries
+// instead of a 4x4 complex inversion.
+struct AdjH4 {
+    double q, c2, c3, c4;
+    double bd[4], br[6], bi[6];     // B:  diagonal, then (0,1) (0,2) (0,3) (1,2) (1,3) (2,3)
+    double m3d[4], m3r[6], m3i[6];  // M3
+    double m4d[4], m4r[6], m4i[6];  // M4
+};
+__device__ __forceinline__ void adj_init_h4(const CMat<4>& H, AdjH4& s) {
+    constexpr int RA[6] = {0, 0, 0, 1, 1, 2}, RB[6] = {1, 2, 3, 2, 3, 3};
+    const double q = 0.25 * (H.re[0][0] + H.re[1][1] + H.re[2][2] + H.re[3][3]);
+    CMat<4> B = H, M3;
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+        B.re[a][a] -= q;
+        B.im[a][a] = 0.0;
+    }
+    // B^2 (Hermitian): upper triangle, mirrored
+    double s2 = 0.0, s3 = 0.0;
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+#pragma unroll
+        for (int b = a; b < 4; ++b) {
+            double pr = 0.0, pi = 0.0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                pr = fma(B.re[a][k], B.re[k][b], pr);
+                pr = fma(-B.im[a][k], B.im[k][b], pr);
+                if (a != b) {
+                    pi = fma(B.re[a][k], B.im[k][b], pi);
+                    pi = fma(B.im[a][k], B.re[k][b], pi);
+                }
+            }
+            M3.re[a][b] = pr;
+            M3.im[a][b] = pi;
+            M3.re[b][a] = pr;
+            M3.im[b][a] = -pi;
+            if (a == b) {
+                s2 += pr;
+                s3 = fma(pr, B.re[a][a], s3);
+            } else {
+                s3 = fma(2.0, fma(pr, B.re[a][b], pi * B.im[a][b]), s3);
+            }
+        }
+    }
+    const double c2 = -0.5 * s2, c3 = -(1.0 / 3.0) * s3;
+#pragma unroll
+    for (int a = 0; a < 4; ++a) M3.re[a][a] += c2;
+    // M4 = B M3 + c3 I (upper triangle), c4 = -tr(B M4) / 4
+    double t4 = 0.0;
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+        double pr = 0.0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            pr = fma(B.re[a][k], M3.re[k][a], pr);
+            pr = fma(-B.im[a][k], M3.im[k][a], pr);
+        }
+        s.m4d[a] = pr + c3;
+        t4 = fma(B.re[a][a], s.m4d[a], t4);
+        s.bd[a] = B.re[a][a];
+        s.m3d[a] = M3.re[a][a];
+    }
+#pragma unroll
+    for (int t = 0; t < 6; ++t) {
+        const int a = RA[t], b = RB[t];
+        double pr = 0.0, pi = 0.0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            pr = fma(B.re[a][k], M3.re[k][b], pr);
+            pr = fma(-B.im[a][k], M3.im[k][b], pr);
+            pi = fma(B.re[a][k], M3.im[k][b], pi);
+            pi = fma(B.im[a][k], M3.re[k][b], pi);
+        }
+        s.m4r[t] = pr;
+        s.m4i[t] = pi;
+        s.br[t] = B.re[a][b];
+        s.bi[t] = B.im[a][b];
+        s.m3r[t] = M3.re[a][b];
+        s.m3i[t] = M3.im[a][b];
+        t4 = fma(2.0, fma(B.re[a][b], pr, B.im[a][b] * pi), t4);  // 2 Re(B_ab conj(M4_ab))
+    }
+    s.q = q;
+    s.c2 = c2;
+    s.c3 = c3;
+    s.c4 = -0.25 * t4;
+}
+// G[a + 4 b] (column-major) at z = w + i eta
+__device__ __forceinline__ void adj_gloc_h4(const AdjH4& s, double w, double eta, double (&gr)[16], double (&gi)[16]) {
+    constexpr int RA[6] = {0, 0, 0, 1, 1, 2}, RB[6] = {1, 2, 3, 2, 3, 3};
+    const double zr = w - s.q, zi = eta;
+    const double z2r = fma(zr, zr, -zi * zi), z2i = 2.0 * zr * zi;
+    const double z3r = fma(z2r, zr, -z2i * zi), z3i = fma(z2r, zi, z2i * zr);
+    // p = (z^2 + c2) z^2 + c3 z + c4
+    const double ar = z2r + s.c2;
+    const double pr = fma(ar, z2r, fma(-z2i, z2i, fma(s.c3, zr, s.c4)));
+    const double pi = fma(ar, z2i, fma(z2i, z2r, s.c3 * zi));
+    const double inv = fast_rcp(fma(pr, pr, pi * pi));
+    const double ir = pr * inv, ii = -pi * inv;  // 1 / p
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+        const double nr = fma(z2r, s.bd[a], fma(zr, s.m3d[a], z3r + s.m4d[a]));
+        const double ni = fma(z2i, s.bd[a], fma(zi, s.m3d[a], z3i));
+        gr[a + 4 * a] = nr * ir - ni * ii;
+        gi[a + 4 * a] = nr * ii + ni * ir;
+    }
+#pragma unroll
+    for (int t = 0; t < 6; ++t) {
+        // upper (a, b): z^2 B_ab + z M3_ab + M4_ab; lower (b, a): the same with the conjugate entries
+        const double ur = fma(z2r, s.br[t], fma(-z2i, s.bi[t], fma(zr, s.m3r[t], fma(-zi, s.m3i[t], s.m4r[t]))));
+        const double ui = fma(z2r, s.bi[t], fma(z2i, s.br[t], fma(zr, s.m3i[t], fma(zi, s.m3r[t], s.m4i[t]))));
+        const double lr = fma(z2r, s.br[t], fma(z2i, s.bi[t], fma(zr, s.m3r[t], fma(zi, s.m3i[t], s.m4r[t]))));
+        const double li = fma(-z2r, s.bi[t], fma(z2i, s.br[t], fma(-zr, s.m3i[t], fma(zi, s.m3r[t], -s.m4i[t]))));
+        gr[RA[t] + 4 * RB[t]] = ur * ir - ui * ii;
+        gi[RA[t] + 4 * RB[t]] = ur * ii + ui * ir;
+        gr[RB[t] + 4 * RA[t]] = lr * ir - li * ii;
+        gi[RB[t] + 4 * RA[t]] = lr * ii + li * ir;
+    }
+}
+
 // wave64 sum via DPP-free shuffles (6 steps)
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll

@@ -1207,7 +1207,7 @@ __global__ __launch_bounds__(256, FID == ABZ_F_GLOC ? (HERM ? 2 : 1) : ((HERM ||
     const int64_t base = (int64_t)blockIdx.x * (256 * KT);
     constexpr bool polyH = HERM && (N == 2 || N == 3) && (FID == ABZ_F_DOS || FID == ABZ_F_TRGLOC);
     constexpr bool usePoly0 = !polyH && (N == 2 || N == 3) && (FID == ABZ_F_DOS || FID == ABZ_F_TRGLOC);
-    CMat<N> H[(usePoly0 || (HERM && N == 3 && FID == ABZ_F_GLOC) ||
+    CMat<N> H[(usePoly0 || (HERM && (N == 3 || N == 4) && FID == ABZ_F_GLOC) ||
                (HERM && N == 4 && (FID == ABZ_F_DOS || FID == ABZ_F_TRGLOC))) ? 1 : KT];  // polynomial modes: H is never kept
     double e[KT][N];
     double wk[KT];
@@ -1222,6 +1222,8 @@ __global__ __launch_bounds__(256, FID == ABZ_F_GLOC ? (HERM ? 2 : 1) : ((HERM ||
     CharPoly<(usePoly ? N : 2)> cp[usePoly ? KT : 1];
     CharPolyH cph[polyH ? KT : 1];
     AdjH3 adj[adjG ? KT : 1];
+    constexpr bool adjG4 = HERM && N == 4 && FID == ABZ_F_GLOC;  // the same for 4 bands
+    AdjH4 adj4[adjG4 ? KT : 1];
     // (line, column) of this thread's first node; the following ones are 256 apart, so one 64-bit
     // division per thread and a 32-bit one per node (all views of a rule share line_len and tile)
     const int LL = a.H.line_len;
@@ -1255,6 +1257,9 @@ __global__ __launch_bounds__(256, FID == ABZ_F_GLOC ? (HERM ? 2 : 1) : ((HERM ||
             } else {
                 charpoly_init_h2(in[0], in[6 * pp], in[4 * pp], in[5 * pp], cph[j]);
             }
+        } else if constexpr (adjG4) {
+            load_planes_herm<N>(H[0], a.H, voff);
+            if constexpr (N == 4) adj_init_h4(H[0], adj4[j]);
         } else if constexpr (poly4) {
             load_planes_herm<N>(H[0], a.H, voff);
             if constexpr (N == 4) charpoly_init_h4(H[0], cp4[j]);
@@ -1307,6 +1312,14 @@ __global__ __launch_bounds__(256, FID == ABZ_F_GLOC ? (HERM ? 2 : 1) : ((HERM ||
                         vr[c] = gr[c];
                         vi[c] = gi[c];
                     }
+                } else if constexpr (adjG4) {
+                    double gr[16], gi[16];
+                    adj_gloc_h4(adj4[j], sw, a.p[0], gr, gi);
+#pragma unroll
+                    for (int c = 0; c < 16; ++c) {
+                        vr[c] = gr[c];
+                        vi[c] = gi[c];
+                    }
                 } else if constexpr (poly4) {
                     double tr, ti;
                     charpoly_trace_h4<FID != ABZ_F_DOS>(cp4[j], sw, a.p[0], eta2, teta, tr, ti);
@@ -1323,7 +1336,7 @@ __global__ __launch_bounds__(256, FID == ABZ_F_GLOC ? (HERM ? 2 : 1) : ((HERM ||
                     vr[0] = (FID == ABZ_F_DOS) ? -ti * 0.31830988618379067153776752674503 : tr;
                     vi[0] = (FID == ABZ_F_DOS) ? 0.0 : ti;
                 } else {
-                    integrand_value<N, FID>(H[(usePoly0 || adjG || poly4) ? 0 : j], e[j], xk[j], a.d, a.p, sw, vr, vi);
+                    integrand_value<N, FID>(H[(usePoly0 || adjG || adjG4 || poly4) ? 0 : j], e[j], xk[j], a.d, a.p, sw, vr, vi);
                 }
 #pragma unroll
                 for (int c = 0; c < NC; ++c) {
@@ -1725,7 +1738,7 @@ static int launch_reduce_h(abz_ctx* ctx, const ReduceSpec& rs, const ReduceArgs&
 // Hermitian rules take the real-polynomial / adjugate paths where they exist
 template <int N, int FID>
 static int launch_reduce_t(abz_ctx* ctx, const ReduceSpec& rs, const ReduceArgs& a) {
-    constexpr bool canH = ((N == 2 || N == 3 || N == 4) && (FID == ABZ_F_DOS || FID == ABZ_F_TRGLOC)) || (N == 3 && FID == ABZ_F_GLOC);
+    constexpr bool canH = ((N == 2 || N == 3 || N == 4) && (FID == ABZ_F_DOS || FID == ABZ_F_TRGLOC)) || ((N == 3 || N == 4) && FID == ABZ_F_GLOC);
     if (canH && rs.herm) return launch_reduce_h<N, FID, canH>(ctx, rs, a);
     return launch_reduce_h<N, FID, false>(ctx, rs, a);
 }
