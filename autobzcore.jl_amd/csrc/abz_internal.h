@@ -72,7 +72,13 @@ struct ProfSlot {
 
 }  // namespace abz
 
+// Handle lifetimes: a series keeps its context alive and a rule keeps its series alive (reference counts),
+// so the destroy calls may come in any order (finalizers of a garbage-collected host language do).  A destroy
+// call marks the handle closed -- further API calls on it fail with ABZ_ERR_ARG while dependants still hold the
+// object -- and the memory goes when the last dependant is destroyed.
 struct abz_ctx {
+    int refs = 1;
+    bool closed = false;
     int device = 0;
     hipStream_t stream = nullptr;
     unsigned prof = 0;  // bit k set: record HIP events around launches of kernel id k
@@ -84,6 +90,8 @@ struct abz_ctx {
 };
 
 struct abz_series {
+    int refs = 1;
+    bool closed = false;
     abz_ctx* ctx = nullptr;
     int d = 0, n = 0;
     int dims[ABZ_MAX_DIM] = {1, 1, 1};

@@ -400,7 +400,52 @@ static int check_series(const abz_series* s) {
         set_error("null series handle");
         return ABZ_ERR_ARG;
     }
+    if (s->closed || s->ctx->closed) {
+        set_error("series handle (or its context) was destroyed");
+        return ABZ_ERR_ARG;
+    }
     return ABZ_OK;
+}
+
+static int check_rule(const abz_rule* r) {
+    if (!r || !r->plan || !r->s) {
+        set_error("null rule handle");
+        return ABZ_ERR_ARG;
+    }
+    if (r->s->closed || r->s->ctx->closed) {
+        set_error("the rule's series (or context) was destroyed");
+        return ABZ_ERR_ARG;
+    }
+    return ABZ_OK;
+}
+
+static void ctx_release(abz_ctx* ctx) {
+    if (--ctx->refs > 0) return;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    for (auto& b : ctx->scratch) b.release();
+    if (ctx->pin) (void)hipHostFree(ctx->pin);
+    for (auto& sl : ctx->prof_slots)
+        for (auto& pr : sl.pending) {
+            (void)hipEventDestroy(pr.first);
+            (void)hipEventDestroy(pr.second);
+        }
+    for (auto e : ctx->event_pool) (void)hipEventDestroy(e);
+    (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+static void series_release(abz_series* s) {
+    if (--s->refs > 0) return;
+    abz_ctx* ctx = s->ctx;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    for (auto& b : s->pool) b.release();
+    for (auto& b : s->iai_pool) b.release();
+    for (auto& b : s->iai_io) b.release();
+    if (s->coef) (void)hipFree(s->coef);
+    delete s;
+    ctx_release(ctx);
 }
 
 }  // namespace abz
@@ -440,30 +485,25 @@ int abz_ctx_create(int device, abz_ctx** out) {
     }
     abz_ctx* ctx = new abz_ctx();
     ctx->device = device;
-    ABZ_HIP(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+    hipError_t e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) {
+        delete ctx;
+        set_error("hipStreamCreateWithFlags failed: %s", hipGetErrorString(e));
+        return ABZ_ERR_HIP;
+    }
     *out = ctx;
     return ABZ_OK;
 }
 
 int abz_ctx_destroy(abz_ctx* ctx) {
-    if (!ctx) return ABZ_OK;
-    (void)hipSetDevice(ctx->device);
-    (void)hipStreamSynchronize(ctx->stream);
-    for (auto& b : ctx->scratch) b.release();
-    if (ctx->pin) (void)hipHostFree(ctx->pin);
-    for (auto& sl : ctx->prof_slots)
-        for (auto& pr : sl.pending) {
-            (void)hipEventDestroy(pr.first);
-            (void)hipEventDestroy(pr.second);
-        }
-    for (auto e : ctx->event_pool) (void)hipEventDestroy(e);
-    (void)hipStreamDestroy(ctx->stream);
-    delete ctx;
+    if (!ctx || ctx->closed) return ABZ_OK;
+    ctx->closed = true;
+    ctx_release(ctx);  // freed once the last series created on it is gone
     return ABZ_OK;
 }
 
 int abz_ctx_sync(abz_ctx* ctx) {
-    ABZ_REQUIRE(ctx, "null ctx");
+    ABZ_REQUIRE(ctx && !ctx->closed, "null or destroyed ctx");
     ABZ_HIP(hipStreamSynchronize(ctx->stream));
     return ABZ_OK;
 }
@@ -500,6 +540,7 @@ static bool detect_hermitian(const abz_series* s, const double* coef_reim);
 int abz_series_create(abz_ctx* ctx, const double* coef_reim, int d, const int32_t* dims, const int32_t* first,
                       const double* period, int n, abz_series** out) {
     ABZ_REQUIRE(ctx && coef_reim && dims && first && period && out, "abz_series_create: null argument");
+    ABZ_REQUIRE(!ctx->closed, "abz_series_create: the context was destroyed");
     ABZ_REQUIRE(d >= 1 && d <= ABZ_MAX_DIM, "series dimension d = %d not in 1..%d", d, ABZ_MAX_DIM);
     ABZ_REQUIRE(n >= 1 && n <= ABZ_MAX_BANDS, "n = %d bands not in 1..%d", n, ABZ_MAX_BANDS);
     *out = nullptr;
@@ -533,6 +574,7 @@ int abz_series_create(abz_ctx* ctx, const double* coef_reim, int d, const int32_
         return ABZ_ERR_HIP;
     }
     s->hermitian = detect_hermitian(s, coef_reim);
+    ctx->refs += 1;
     *out = s;
     return ABZ_OK;
 }
@@ -579,13 +621,9 @@ int abz_series_update(abz_series* s, const double* coef_reim) {
 }
 
 int abz_series_destroy(abz_series* s) {
-    if (!s) return ABZ_OK;
-    (void)hipSetDevice(s->ctx->device);
-    (void)hipStreamSynchronize(s->ctx->stream);
-    for (auto& b : s->pool) b.release();
-    for (auto& b : s->iai_pool) b.release();
-    if (s->coef) (void)hipFree(s->coef);
-    delete s;
+    if (!s || s->closed) return ABZ_OK;
+    s->closed = true;
+    series_release(s);  // freed once the last rule built from it is gone
     return ABZ_OK;
 }
 
@@ -617,9 +655,11 @@ static void rule_free(abz_rule* r) {
 
 int abz_rule_destroy(abz_rule* r) {
     if (!r) return ABZ_OK;
-    (void)hipSetDevice(r->s->ctx->device);
-    (void)hipStreamSynchronize(r->s->ctx->stream);
+    abz_series* s = r->s;
+    (void)hipSetDevice(s->ctx->device);
+    (void)hipStreamSynchronize(s->ctx->stream);
     rule_free(r);
+    series_release(s);
     return ABZ_OK;
 }
 
@@ -867,6 +907,7 @@ static int rule_build(abz_series* s, int npt, int64_t nirr, const int32_t* irr_i
         rp->tmpU.release();
         rp->tmpD.release();
     }
+    s->refs += 1;
     *out = r;
     return ABZ_OK;
 }
@@ -888,7 +929,8 @@ int abz_ptr_rule_build_slab(abz_series* s, int npt, int outer_begin, int outer_e
 }
 
 int abz_rule_rebuild(abz_rule* r) {
-    ABZ_REQUIRE(r && r->plan, "null rule");
+    int rc0 = check_rule(r);
+    if (rc0) return rc0;
     abz_ctx* ctx = r->s->ctx;
     ABZ_HIP(hipSetDevice(ctx->device));
     RulePlan* rp = static_cast<RulePlan*>(r->plan);
@@ -912,7 +954,8 @@ int abz_rule_info(const abz_rule* r, int64_t* nk, int* n, int* d, int* npt, int*
 }
 
 int abz_rule_export(abz_rule* r, double* x, double* w, double* H, double* eig, double* vel) {
-    ABZ_REQUIRE(r, "null rule");
+    int rc0 = check_rule(r);
+    if (rc0) return rc0;
     abz_ctx* ctx = r->s->ctx;
     ABZ_HIP(hipSetDevice(ctx->device));
     const int d = r->s->d, n = r->s->n;
@@ -960,7 +1003,9 @@ int abz_rule_export(abz_rule* r, double* x, double* w, double* H, double* eig, d
 
 int abz_rule_reduce(abz_rule* r, int integrand, const double* params, int nparams, const double* sweep, int n_sweep,
                     int nsyms, double* out_reim) {
-    ABZ_REQUIRE(r && out_reim, "null rule / out");
+    int rc0 = check_rule(r);
+    if (rc0) return rc0;
+    ABZ_REQUIRE(out_reim, "null out");
     ABZ_REQUIRE(nparams >= 0 && nparams <= 4, "nparams = %d not in 0..4", nparams);
     ABZ_REQUIRE(nsyms >= 1, "nsyms must be >= 1");
     abz_ctx* ctx = r->s->ctx;
@@ -1078,7 +1123,9 @@ int abz_ptr_sum(abz_series* s, int npt, int outer_begin, int outer_end, int inte
 }
 
 int abz_rule_ggr(abz_rule* r, const double* E, int nE, double* out) {
-    ABZ_REQUIRE(r && E && out && nE >= 1, "abz_rule_ggr: bad arguments");
+    int rc0 = check_rule(r);
+    if (rc0) return rc0;
+    ABZ_REQUIRE(E && out && nE >= 1, "abz_rule_ggr: bad arguments");
     ABZ_REQUIRE(r->V.base && r->E.base, "GGR needs a rule built with ABZ_WANT_VEL");
     abz_ctx* ctx = r->s->ctx;
     ABZ_HIP(hipSetDevice(ctx->device));

@@ -822,7 +822,7 @@ int abz_iai_solve_many(abz_series* s, int lims_kind, const double* lim_a, const 
                        const double* params, int nparams, const double* sweeps, int n_sweep, double abstol, double reltol,
                        int64_t maxevals, int64_t max_batch, double* out_reim, double* err, int64_t* numevals,
                        double* panels, int64_t max_panels, int64_t* npanels) {
-    ABZ_REQUIRE(s && s->ctx && lim_a && out_reim, "abz_iai_solve: null argument");
+    ABZ_REQUIRE(s && s->ctx && !s->closed && !s->ctx->closed && lim_a && out_reim, "abz_iai_solve: null argument");
     ABZ_REQUIRE(n_sweep >= 1 && sweeps, "abz_iai_solve: at least one sweep value");
     ABZ_REQUIRE(lims_kind >= ABZ_LIMS_CUBIC && lims_kind <= ABZ_LIMS_POLYGON, "unknown limits kind %d", lims_kind);
     ABZ_REQUIRE(lims_kind == ABZ_LIMS_TETRAHEDRAL || lim_b, "these limits need lim_b");
@@ -925,7 +925,7 @@ int abz_iai_solve(abz_series* s, int lims_kind, const double* lim_a, const doubl
 // ---- building blocks for a host-language (Julia) adaptive loop -------------------------------
 int abz_contract_nodes(abz_series* s, int src_level, const int64_t* parents, const double* x, int64_t nnodes,
                        int64_t* slots_out) {
-    ABZ_REQUIRE(s && s->ctx && parents && x && slots_out, "abz_contract_nodes: null argument");
+    ABZ_REQUIRE(s && s->ctx && !s->closed && !s->ctx->closed && parents && x && slots_out, "abz_contract_nodes: null argument");
     ABZ_REQUIRE(src_level >= 2 && src_level <= s->d, "src_level = %d must be in 2..d", src_level);
     ABZ_HIP(hipSetDevice(s->ctx->device));
     IaiDriver drv;
@@ -961,7 +961,7 @@ int abz_contract_nodes(abz_series* s, int src_level, const int64_t* parents, con
 
 int abz_eval_line_nodes(abz_series* s, const int64_t* parents, const double* x, const double* tail, int64_t nnodes,
                         int integrand, const double* params, int nparams, double sweep, double* values_reim) {
-    ABZ_REQUIRE(s && s->ctx && parents && x && values_reim, "abz_eval_line_nodes: null argument");
+    ABZ_REQUIRE(s && s->ctx && !s->closed && !s->ctx->closed && parents && x && values_reim, "abz_eval_line_nodes: null argument");
     ABZ_REQUIRE(nparams >= 0 && nparams <= 4, "nparams = %d not in 0..4", nparams);
     ABZ_HIP(hipSetDevice(s->ctx->device));
     IaiDriver drv;

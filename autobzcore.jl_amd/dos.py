@@ -63,7 +63,7 @@ def _init_cacheval(h, domain, p, alg):
         raise ValueError("GGR supports BZ parameters from load_bz")
     if p.ndim != h.d:
         raise ValueError("GGR: BZ and series dimensions differ")
-    h.invalidate()  # coefficients may have been mutated in place (test/dos.jl:123)
+    h.invalidate()  # coefficients may have been mutated in place (test/dos.jl:123): re-upload, rules refill lazily
     return h.device().rule(alg.npt, p.syms, L.WANT_EIG | L.WANT_VEL)
 
 

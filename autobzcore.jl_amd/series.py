@@ -53,10 +53,12 @@ class FourierSeries:
         return self.c.shape[: self.d]
 
     def invalidate(self):
-        """Drop device copies after mutating `c` in place (ref: DOSCache.isfresh, test/dos.jl:123-124)."""
+        """Call after mutating `c` in place (ref: DOSCache.isfresh, test/dos.jl:123-124): every device copy
+        gets the new coefficients and its cached rules are re-evaluated before their next use.  Handles held
+        elsewhere (a solver's cacheval, a second DOSCache on the same series) stay valid."""
+        self._dev = {k: dev for k, dev in self._dev.items() if dev._h is not None}
         for dev in self._dev.values():
-            dev.close()
-        self._dev = {}
+            dev.update()
 
     def device(self, ctx=None):
         ctx = ctx or L.Context.default()
@@ -99,6 +101,7 @@ class DeviceSeries:
         self.allreduce = None  # callable summing a float64 array over the ranks of the shard group
         self.rule_bytes = 0
         self.max_rule_bytes = 96 << 30  # keep rules resident in the 288 GB of HBM, LRU beyond this
+        self.generation = 0  # bumped by update(): rules evaluated from older coefficients refill before use
         self._fin = weakref.finalize(self, DeviceSeries._destroy, h, self.rules)
 
     @staticmethod
@@ -114,9 +117,22 @@ class DeviceSeries:
 
     def close(self):
         self._fin()
+        self._h = None
+
+    @property
+    def h(self):
+        if self._h is None:
+            raise L.AbzError("DeviceSeries was closed")
+        return self._h
+
+    @h.setter
+    def h(self, v):
+        self._h = v
 
     def update(self, c=None):
-        """Upload new coefficients of the same shape (cached rules become stale: rebuild them)."""
+        """Upload new coefficients of the same shape.  Every cached rule is stale from here on and is
+        re-evaluated in place (abz_rule_rebuild, which also refreshes its Hermitian flag) before its next
+        use -- the reference rebuilds its rule from the current series on every solve."""
         if c is not None:
             c = np.asarray(c, dtype=np.complex128)
             if c.shape != self.s.c.shape:
@@ -124,6 +140,7 @@ class DeviceSeries:
             self.s.c = np.array(c)
         buf = np.ascontiguousarray(julia_coefficient_order(self.s.c, self.s.d).view(np.float64))
         L.check(L.lib().abz_series_update(self.h, buf.ctypes.data_as(L.c_f64p)))
+        self.generation += 1
 
     # ---- arbitrary nodes (BatchIntegrand body / fallback evaluator)
     def eval_nodes(self, k, want=L.WANT_H):
@@ -289,11 +306,23 @@ class DeviceRule:
             if len(w):
                 L.check(L.lib().abz_ptr_rule_build(dev.h, self.npt, len(w), idx.ctypes.data_as(L.c_i32p),
                                                    w.ctypes.data_as(L.c_i64p), want, C.byref(h)))
-        self.h = h if h.value else None
+        self._h = h if h.value else None
+        self._closed = False
+        self.generation = dev.generation
         per = (2 * n * n if want & L.WANT_H else 0) + (n if want & (L.WANT_EIG | L.WANT_VEL) else 0) + \
               (d * n if want & L.WANT_VEL else 0)
         self.nbytes = 8 * per * self.nk_local
-        self._fin = weakref.finalize(self, DeviceRule._destroy, self.h)
+        self._fin = weakref.finalize(self, DeviceRule._destroy, self._h)
+
+    @property
+    def h(self):
+        """The abz_rule handle (None for an empty k-shard); a stale rule is refilled first."""
+        if self._closed:
+            raise L.AbzError("DeviceRule was closed")
+        if self._h is not None and self.generation != self.dev.generation:
+            self.generation = self.dev.generation
+            L.check(L.lib().abz_rule_rebuild(self._h))
+        return self._h
 
     @staticmethod
     def _destroy(h):
@@ -310,14 +339,19 @@ class DeviceRule:
 
     def close(self):
         self._fin()
+        self._closed = True
+        self._h = None
 
     def __len__(self):
         return self.nk
 
     def rebuild(self):
         """Re-evaluate all cached values in place from the series' current coefficients (async)."""
-        if self.h is not None:
-            L.check(L.lib().abz_rule_rebuild(self.h))
+        if self._closed:
+            raise L.AbzError("DeviceRule was closed")
+        if self._h is not None:
+            self.generation = self.dev.generation
+            L.check(L.lib().abz_rule_rebuild(self._h))
 
     def reduce(self, fid, params=(), sweep=None, nsyms=None):
         """(sum_k w_k f(k, H(k); sweep_i)) / (npt^d nsyms) for every sweep value -> complex array

@@ -45,6 +45,8 @@ function check(rc::Cint)
 end
 
 # ---------------------------------------------------------------- handles
+# Lifetimes: the library reference-counts context <- series <- rule, so these finalizers may run in any order
+# (abz_*_destroy only marks a handle closed while dependants still use the object).
 mutable struct HIPContext
     h::Ptr{Cvoid}
     function HIPContext(device::Integer=0)
@@ -304,6 +306,7 @@ synchronize(ctx::HIPContext=context()) = check(ccall((:abz_ctx_sync, libabz), Ci
 function update!(hs::HIPSeries, s::FourierSeries)
     coef = reinterpret(Float64, vec(s.c))
     GC.@preserve coef check(ccall((:abz_series_update, libabz), Cint, (Ptr{Cvoid}, Ptr{Float64}), hs.h, coef))
+    foreach(rebuild!, values(hs.rules))   # cached rule values follow the coefficients (the reference rebuilds its rule per solve)
     return hs
 end
 rebuild!(r::HIPRule) = (check(ccall((:abz_rule_rebuild, libabz), Cint, (Ptr{Cvoid},), r.h)); r)
