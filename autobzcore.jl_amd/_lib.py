@@ -21,6 +21,7 @@ PROTOTYPES = {
     "abz_version": (C.c_int, []),
     "abz_device_count": (C.c_int, [c_ip]),
     "abz_ctx_create": (C.c_int, [C.c_int, c_vpp]),
+    "abz_ctx_create_on_stream": (C.c_int, [C.c_int, C.c_void_p, c_vpp]),
     "abz_ctx_destroy": (C.c_int, [C.c_void_p]),
     "abz_ctx_sync": (C.c_int, [C.c_void_p]),
     "abz_prof_enable": (C.c_int, [C.c_void_p, C.c_int]),
@@ -38,6 +39,8 @@ PROTOTYPES = {
     "abz_rule_info": (C.c_int, [C.c_void_p, c_i64p, c_ip, c_ip, c_ip, c_ip]),
     "abz_rule_export": (C.c_int, [C.c_void_p, c_f64p, c_f64p, c_f64p, c_f64p, c_f64p]),
     "abz_rule_reduce": (C.c_int, [C.c_void_p, C.c_int, c_f64p, C.c_int, c_f64p, C.c_int, C.c_int, c_f64p]),
+    "abz_rule_reduce_device": (C.c_int, [C.c_void_p, C.c_int, c_f64p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    "abz_rule_values_ptr": (C.c_int, [C.c_void_p, c_vpp, c_i64p]),
     "abz_rule_ggr": (C.c_int, [C.c_void_p, c_f64p, C.c_int, c_f64p]),
     "abz_symptr_rule": (C.c_int, [C.c_int, C.c_int, c_i32p, C.c_int, c_i64p, c_i32p, c_i64p]),
     "abz_symptr_rule_device": (C.c_int, [C.c_void_p, C.c_int, C.c_int, c_i32p, C.c_int, c_i64p, c_i32p, c_i64p]),
@@ -115,14 +118,19 @@ class Context:
 
     _default = None
 
-    def __init__(self, device=None):
+    def __init__(self, device=None, stream=None):
+        """`stream`: a raw hipStream_t the caller owns (e.g. `torch.cuda.Stream().cuda_stream`); the library's
+        launches are then ordered with the caller's work and with RCCL collectives on that stream."""
         if device is None:
             device = int(os.environ.get("LOCAL_RANK", "0"))
         n = C.c_int(0)
         check(lib().abz_device_count(C.byref(n)))
         self.device = device % max(n.value, 1)
         h = C.c_void_p()
-        check(lib().abz_ctx_create(self.device, C.byref(h)))
+        if stream is None:
+            check(lib().abz_ctx_create(self.device, C.byref(h)))
+        else:
+            check(lib().abz_ctx_create_on_stream(self.device, C.c_void_p(int(stream)), C.byref(h)))
         self.h = h
 
     @classmethod

@@ -81,6 +81,7 @@ struct abz_ctx {
     bool closed = false;
     int device = 0;
     hipStream_t stream = nullptr;
+    bool owns_stream = true;  // false: borrowed from the caller (abz_ctx_create_on_stream)
     unsigned prof = 0;  // bit k set: record HIP events around launches of kernel id k
     abz::ProfSlot prof_slots[ABZ_K_COUNT];
     std::vector<hipEvent_t> event_pool;
@@ -219,6 +220,7 @@ struct ReduceSpec {
     const double* sweep_dev;  // device [n_sweep]
     int n_sweep;
     double scale;
+    double* out_dev = nullptr;  // device [n_sweep][ncomp][2]: leave the result in HBM, no host synchronisation
 };
 int integrand_ncomp(int integrand, int n, int d);
 // result: host out_reim [n_sweep][ncomp][2]

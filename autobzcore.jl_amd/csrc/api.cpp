@@ -431,7 +431,7 @@ static void ctx_release(abz_ctx* ctx) {
             (void)hipEventDestroy(pr.second);
         }
     for (auto e : ctx->event_pool) (void)hipEventDestroy(e);
-    (void)hipStreamDestroy(ctx->stream);
+    if (ctx->owns_stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
 
@@ -469,7 +469,13 @@ int abz_device_count(int* n) {
     return ABZ_OK;
 }
 
-int abz_ctx_create(int device, abz_ctx** out) {
+static int ctx_create(int device, hipStream_t borrowed, bool borrow, abz_ctx** out);
+int abz_ctx_create(int device, abz_ctx** out) { return ctx_create(device, nullptr, false, out); }
+int abz_ctx_create_on_stream(int device, void* hip_stream, abz_ctx** out) {
+    return ctx_create(device, static_cast<hipStream_t>(hip_stream), true, out);
+}
+
+static int ctx_create(int device, hipStream_t borrowed, bool borrow, abz_ctx** out) {
     ABZ_REQUIRE(out != nullptr, "abz_ctx_create: null out");
     *out = nullptr;
     int n = 0;
@@ -485,11 +491,16 @@ int abz_ctx_create(int device, abz_ctx** out) {
     }
     abz_ctx* ctx = new abz_ctx();
     ctx->device = device;
-    hipError_t e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
-    if (e != hipSuccess) {
-        delete ctx;
-        set_error("hipStreamCreateWithFlags failed: %s", hipGetErrorString(e));
-        return ABZ_ERR_HIP;
+    if (borrow) {
+        ctx->stream = borrowed;
+        ctx->owns_stream = false;
+    } else {
+        hipError_t e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+        if (e != hipSuccess) {
+            delete ctx;
+            set_error("hipStreamCreateWithFlags failed: %s", hipGetErrorString(e));
+            return ABZ_ERR_HIP;
+        }
     }
     *out = ctx;
     return ABZ_OK;
@@ -1001,8 +1012,29 @@ int abz_rule_export(abz_rule* r, double* x, double* w, double* H, double* eig, d
     return ABZ_OK;
 }
 
+static int rule_reduce(abz_rule* r, int integrand, const double* params, int nparams, const double* sweep, int n_sweep,
+                       int nsyms, double* out_reim, bool device_io);
+
 int abz_rule_reduce(abz_rule* r, int integrand, const double* params, int nparams, const double* sweep, int n_sweep,
                     int nsyms, double* out_reim) {
+    return rule_reduce(r, integrand, params, nparams, sweep, n_sweep, nsyms, out_reim, false);
+}
+
+int abz_rule_reduce_device(abz_rule* r, int integrand, const double* params, int nparams, const double* sweep_dev,
+                           int n_sweep, int nsyms, double* out_dev_reim) {
+    return rule_reduce(r, integrand, params, nparams, sweep_dev, n_sweep, nsyms, out_dev_reim, true);
+}
+
+int abz_rule_values_ptr(const abz_rule* r, void** base, int64_t* nbytes) {
+    int rc0 = check_rule(r);
+    if (rc0) return rc0;
+    if (base) *base = r->vals;
+    if (nbytes) *nbytes = (int64_t)sizeof(double) * r->ntiles * r->planes * (r->H.base ? r->H.pitch : r->E.pitch);
+    return ABZ_OK;
+}
+
+static int rule_reduce(abz_rule* r, int integrand, const double* params, int nparams, const double* sweep, int n_sweep,
+                       int nsyms, double* out_reim, bool device_io) {
     int rc0 = check_rule(r);
     if (rc0) return rc0;
     ABZ_REQUIRE(out_reim, "null out");
@@ -1036,7 +1068,9 @@ int abz_rule_reduce(abz_rule* r, int integrand, const double* params, int nparam
     for (int i = 0; i < 4; ++i) rs.params[i] = (i < nparams) ? params[i] : 0.0;
     rs.n_sweep = ns;
     rs.sweep_dev = nullptr;
-    if (swept) {
+    if (swept && device_io) {
+        rs.sweep_dev = sweep;
+    } else if (swept) {
         int rc = upload(ctx, ctx->scratch[5], sweep, (size_t)ns);
         if (rc) return rc;
         rs.sweep_dev = ctx->scratch[5].as<double>();
@@ -1044,7 +1078,8 @@ int abz_rule_reduce(abz_rule* r, int integrand, const double* params, int nparam
     double vol = 1.0;
     for (int j = 0; j < rs.d; ++j) vol *= (double)r->npt;
     rs.scale = 1.0 / (vol * (double)nsyms);
-    return launch_reduce(ctx, rs, out_reim);
+    if (device_io) rs.out_dev = out_reim;
+    return launch_reduce(ctx, rs, device_io ? nullptr : out_reim);
 }
 
 int abz_ptr_sum(abz_series* s, int npt, int outer_begin, int outer_end, int integrand, const double* params, int nparams,

@@ -1802,6 +1802,10 @@ int launch_reduce(abz_ctx* ctx, const ReduceSpec& rs, double* out_reim) {
 #undef CASE
         if (rc) return rc;
     }
+    if (rs.out_dev) {  // the sums stay in HBM (they feed a collective on the same stream)
+        ABZ_HIP(hipMemcpyAsync(rs.out_dev, outd, sizeof(double2) * (size_t)ncols, hipMemcpyDeviceToDevice, ctx->stream));
+        return ABZ_OK;
+    }
     ABZ_HIP(hipMemcpyAsync(out_reim, outd, sizeof(double2) * (size_t)ncols, hipMemcpyDeviceToHost, ctx->stream));
     ABZ_HIP(hipStreamSynchronize(ctx->stream));
     return ABZ_OK;

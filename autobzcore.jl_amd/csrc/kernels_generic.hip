@@ -1502,6 +1502,11 @@ static int launch_gen_rows_gloc(abz_ctx* ctx, const ReduceSpec& rs, double* out_
             ABZ_HIP(hipGetLastError());
             if ((rc = launch_final_reduce(ctx, a.partial, blocks, (int64_t)a.n_sweep * nn, rs.scale, outd))) return rc;
         }
+        if (rs.out_dev) {  // chunk results stay in HBM; the next chunk reuses `outd` in stream order
+            ABZ_HIP(hipMemcpyAsync(rs.out_dev + 2 * (size_t)s0 * nn, outd, sizeof(double2) * (size_t)a.n_sweep * nn,
+                                   hipMemcpyDeviceToDevice, ctx->stream));
+            continue;
+        }
         ABZ_HIP(hipMemcpyAsync(out_reim + 2 * (size_t)s0 * nn, outd, sizeof(double2) * (size_t)a.n_sweep * nn, hipMemcpyDeviceToHost,
                                ctx->stream));
         ABZ_HIP(hipStreamSynchronize(ctx->stream));
@@ -1535,6 +1540,10 @@ static int launch_gen_rows_reduce(abz_ctx* ctx, const ReduceSpec& rs, double* ou
             hipLaunchKernelGGL(gen_rows_reduce_kernel<16>, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, a);
         ABZ_HIP(hipGetLastError());
         if ((rc = launch_final_reduce(ctx, a.partial, blocks, rs.n_sweep, rs.scale, outd))) return rc;
+    }
+    if (rs.out_dev) {
+        ABZ_HIP(hipMemcpyAsync(rs.out_dev, outd, sizeof(double2) * (size_t)rs.n_sweep, hipMemcpyDeviceToDevice, ctx->stream));
+        return ABZ_OK;
     }
     ABZ_HIP(hipMemcpyAsync(out_reim, outd, sizeof(double2) * (size_t)rs.n_sweep, hipMemcpyDeviceToHost, ctx->stream));
     ABZ_HIP(hipStreamSynchronize(ctx->stream));
@@ -1590,6 +1599,10 @@ int launch_gen_reduce(abz_ctx* ctx, const ReduceSpec& rs, double* out_reim) {
         hipLaunchKernelGGL(final_reduce2_kernel, dim3((unsigned)ncols), dim3(256), 0, ctx->stream, partial, blocks * wpb,
                            ncols, rs.scale, outd);
         ABZ_HIP(hipGetLastError());
+    }
+    if (rs.out_dev) {
+        ABZ_HIP(hipMemcpyAsync(rs.out_dev, outd, sizeof(double2) * (size_t)ncols, hipMemcpyDeviceToDevice, ctx->stream));
+        return ABZ_OK;
     }
     ABZ_HIP(hipMemcpyAsync(out_reim, outd, sizeof(double2) * (size_t)ncols, hipMemcpyDeviceToHost, ctx->stream));
     ABZ_HIP(hipStreamSynchronize(ctx->stream));

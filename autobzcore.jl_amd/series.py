@@ -373,6 +373,23 @@ class DeviceRule:
                                             self.nsyms if nsyms is None else nsyms, out.ctypes.data_as(L.c_f64p)))
         return self._sum_over_ranks(out).view(np.complex128).reshape(ns, ncomp)
 
+    def reduce_device(self, fid, params, sweep_ptr, n_sweep, out_ptr, nsyms=None):
+        """abz_rule_reduce_device: `sweep_ptr` / `out_ptr` are raw device addresses (e.g. tensor.data_ptr()) of
+        [n_sweep] and [n_sweep][ncomp][2] doubles; enqueues on the context's stream and returns.  The caller
+        follows with its collective on the same stream (dist.py)."""
+        params = np.ascontiguousarray(np.asarray(params, dtype=np.float64).reshape(-1))
+        pp = params.ctypes.data_as(L.c_f64p) if len(params) else None
+        if self.h is not None:
+            L.check(L.lib().abz_rule_reduce_device(self.h, fid, pp, len(params), C.c_void_p(int(sweep_ptr)), int(n_sweep),
+                                                   self.nsyms if nsyms is None else nsyms, C.c_void_p(int(out_ptr))))
+
+    def values_ptr(self):
+        """(device address, bytes) of the rule's value block."""
+        base = C.c_void_p()
+        nb = C.c_int64(0)
+        L.check(L.lib().abz_rule_values_ptr(self.h, C.byref(base), C.byref(nb)))
+        return int(base.value or 0), int(nb.value)
+
     def export(self, x=True, w=True, H=False, eig=False, vel=False):
         """Host copies in the reference's layout: x [nk,d], w [nk], H [nk,n,n], eig [nk,n], vel [nk,d,n]."""
         s = self.dev.s

@@ -1,16 +1,29 @@
 #!/usr/bin/env python3
 """Hot-path benchmark (driver contract: `python bench.py --gpus N --steps K --warmup W`).
 
+`--gpus N > 1` without a torchrun environment: this process starts N fresh rank processes
+(`python -m torch.distributed.run --nproc-per-node N bench.py ...`) BEFORE anything touches the GPU,
+relays rank 0's JSON line and exits with the children's status.  Under torchrun (WORLD_SIZE set) it
+is one rank.
+
 Workload (BASELINE.json configs[3] / its per-GPU share, named in `config.workload`): SVO 3-band
 Wannier Hamiltonian (aps_example/svo_hr.dat, 1331 R vectors), full-BZ PTR grid npt^3.
-  Phase A (primary metric, "k-point evals/sec (H(k)+eig)"): one STEP = re-evaluate H(k) and its
+  Phase A (primary metric, "k-point evals/sec (H(k)+eig)"): one PASS = re-evaluate H(k) and its
      Hermitian eigenvalues at all npt^3 nodes from the device-resident coefficients into the
-     device-resident rule (abz_rule_rebuild: contract, contract, eval+eig kernels).
+     device-resident rule (abz_rule_rebuild: contract, contract, eval+eig kernels); one STEP =
+     `--passes-per-step` back-to-back passes (a step of one pass is 0.14 ms: 20 of them are below
+     timer and placement noise), so the timed region of K steps is >= 0.3 s.
   Phase B (secondary, "DOS(omega) points/sec"): the DOS integrand scan+reduce over the cached rule
      for this rank's share of the 256-omega sweep (256/8 = 32 per GPU), fused in one pass.
-Multi-GPU: omega sweep sharded round-robin like batchparam (src/interfaces.jl:199-208), every rank
-holds a replica of the coefficients and builds its own rule (no data-path collective), one
-all_gather of the per-rank results => scaling "weak".
+Multi-GPU, primary number: every rank holds a replica of the coefficients and rebuilds its own rule
+(no data-path collective) => scaling "weak".  Beside it, at every N, the FIXED jobs the north star
+names (strong scaling, speed-up against the same job on rank 0 alone measured in the same run):
+  * the 256-omega DOS sweep on the 150^3 grid, omega-sharded (replicated build + 256/N omega per rank +
+    one all_gather, src/interfaces.jl:199-222) and k-sharded (1/N slab of the grid per rank + all 256
+    omega + one all_reduce) -- scan results stay in HBM and feed the RCCL collective on the
+    same stream (abz_rule_reduce_device);
+  * a 432-omega IAI sweep on the cubic IBZ (the size of the reference demo's sweep) through
+    batchsolve_sharded.
 Inputs are resident in HBM when the timed region starts; all timing is bracketed by a barrier and a
 device synchronize on both sides; kernel durations come from HIP events on the library's stream.
 """
@@ -18,6 +31,8 @@ import argparse
 import ctypes
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -27,105 +42,145 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 measured copy)
+F64_PEAK_TFLOPS = 78.6  # f64 vector = f64 matrix peak (AMD spec, not in the local guide)
 
 
-def pmc_traffic(npt):
-    """HBM bytes per launch of the Fourier-eval kernel from the committed rocprofv3 PMC passes
-    (profiles/r01_traffic.json, written by tools/collect_profiles.sh: WRITE_SIZE and FETCH_SIZE in
-    separate --pmc runs, FETCH_SIZE doubled per the gfx950 correction).  None if not collected for
-    this grid size: counters cannot be read from inside an un-profiled bench run."""
-    path = os.path.join(ROOT, "profiles", "r01_traffic.json")
-    try:
-        t = json.load(open(path))
-        if int(t.get("npt", -1)) == int(npt):
-            return float(t["hbm_bytes_per_launch"])
-    except Exception:
-        pass
-    return None
-
-
-def cpu_baseline(npt_sample, n_omega_sample, s):
-    """Time the C restatement of the reference's CPU path (oracle/abz_oracle.c, kind 'port') on the
-    host cores on a BOUNDED sample of the same workload: the same SVO series on a smaller PTR grid."""
-    lib_path = os.path.join(ROOT, "oracle", "_build", "liboracle.so")
-    if not os.path.exists(lib_path):
-        return None
-    lib = ctypes.CDLL(lib_path)
-    lib.orc_num_threads.restype = ctypes.c_int
-    # a 1-GPU box owns a 16-core share of the host: more OpenMP threads only get throttled
-    share = min(len(os.sched_getaffinity(0)), int(os.environ.get("ABZ_CPU_THREADS", "16")))
-    lib.orc_set_threads(share)
-    cores = lib.orc_num_threads()
-    from autobzcore.jl_amd.series import julia_coefficient_order
-    coef = np.ascontiguousarray(julia_coefficient_order(s.c, 3))
-    dims = np.array(s.dims, dtype=np.int32)
-    first = np.array(s.first, dtype=np.int32)
-    nk = npt_sample**3
-    vals = np.empty(nk * 9, dtype=np.complex128)
-    eig = np.empty(nk * 3)
-    P = ctypes.c_void_p
-    args = (coef.ctypes.data_as(P), 3, dims.ctypes.data_as(P), first.ctypes.data_as(P), 3, npt_sample,
-            vals.ctypes.data_as(P), eig.ctypes.data_as(P))
-    lib.orc_fourier_ptr(*args)  # warm-up (page faults, thread pool)
-    t0 = time.perf_counter()
-    reps = 0
-    while reps < 3 or time.perf_counter() - t0 < 6.0:
-        lib.orc_fourier_ptr(*args)
-        reps += 1
-    tA = (time.perf_counter() - t0) / reps
-    omegas = np.linspace(10, 15, n_omega_sample)
-    out = np.empty(n_omega_sample)
-    lib.orc_dos_scan.argtypes = [P, ctypes.c_int64, ctypes.c_int, ctypes.c_double, P, ctypes.c_int, P]
-    t0 = time.perf_counter()
-    lib.orc_dos_scan(vals.ctypes.data_as(P), nk, 3, 0.1, omegas.ctypes.data_as(P), n_omega_sample, out.ctypes.data_as(P))
-    tB = time.perf_counter() - t0
-    # one thread (bounded: ~2 s)
-    lib.orc_set_threads(1)
-    t0 = time.perf_counter()
-    r1 = 0
-    while r1 < 1 or time.perf_counter() - t0 < 2.0:
-        lib.orc_fourier_ptr(*args)
-        r1 += 1
-    tA1 = (time.perf_counter() - t0) / r1
-    lib.orc_set_threads(share)
-    return {"value": nk / tA, "unit": "k-point evals/s (H(k)+eig)", "cores": cores, "kind": "port",
-            "value_1_thread": nk / tA1,
-            "sample": f"SVO 3-band, PTR npt={npt_sample} FBZ ({nk} k-points), {reps} reps; "
-                      f"C restatement of the reference loops (not Julia), gcc -O3 -march=x86-64-v3 -fopenmp, "
-                      f"{cores} threads of {os.cpu_count()} logical CPUs",
-            "dos_kpoint_omega_per_sec": nk * n_omega_sample / tB,
-            "dos_sample": f"{n_omega_sample} omegas over the same {nk} cached H(k)"}
-
-
-def main():
+def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--npt", type=int, default=150)
+    ap.add_argument("--passes-per-step", type=int, default=128)
     ap.add_argument("--omegas-per-rank", type=int, default=32)
     ap.add_argument("--eta", type=float, default=0.1)
-    ap.add_argument("--cpu-npt", type=int, default=64)
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-iai", action="store_true")
-    a = ap.parse_args()
+    ap.add_argument("--no-extras", action="store_true", help="primary metric + sharded jobs only")
+    ap.add_argument("--c5-abstol", type=float, default=1e-3, help="config 5 (16-band IAI) tolerance; SURVEY 8d: 1e-3")
+    return ap.parse_args()
 
+
+def spawn_ranks(a):
+    """Start N rank processes; this parent never imports torch.cuda nor creates an abz context."""
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "1")
+    p = subprocess.run(cmd, env=env)
+    return p.returncode
+
+
+def pmc_traffic(npt):
+    """HBM bytes per launch of the Fourier-eval kernel from the committed rocprofv3 PMC passes
+    (profiles/r02_traffic.json or r01_traffic.json, written by tools/collect_profiles.sh: WRITE_SIZE and
+    FETCH_SIZE in separate --pmc runs, FETCH_SIZE doubled per the gfx950 correction).  None if not
+    collected for this grid size: counters cannot be read from inside an un-profiled bench run."""
+    for name in ("r02_traffic.json", "r01_traffic.json"):
+        try:
+            t = json.load(open(os.path.join(ROOT, "profiles", name)))
+            if int(t.get("npt", -1)) == int(npt):
+                return float(t["hbm_bytes_per_launch"])
+        except Exception:
+            pass
+    return None
+
+
+def cpu_baseline(npt, s, eta, budget_s=25.0):
+    """Time the C restatement of the reference's CPU path (oracle/abz_oracle.c, kind 'port') on the host
+    cores, on the ACTUAL grid of the GPU workload (npt^3) and a bounded omega count."""
+    lib_path = os.path.join(ROOT, "oracle", "_build", "liboracle.so")
+    if not os.path.exists(lib_path):
+        return None
+    flags = "-march=x86-64-v3 (prebuilt)"
+    try:  # a -march=native build made on the box that times it (building the checker is not using it)
+        subprocess.run(["make", "-C", os.path.join(ROOT, "oracle"), "native"], check=True, capture_output=True, timeout=120)
+        native = os.path.join(ROOT, "oracle", "_build", "liboracle_native.so")
+        if os.path.exists(native):
+            lib_path, flags = native, "-march=native (built on this box)"
+    except Exception:
+        pass
+    lib = ctypes.CDLL(lib_path)
+    lib.orc_num_threads.restype = ctypes.c_int
+    aff = len(os.sched_getaffinity(0))
+    want = int(os.environ.get("ABZ_CPU_THREADS", str(aff)))
+    lib.orc_set_threads(want)
+    cores = lib.orc_num_threads()
+    from autobzcore.jl_amd.series import julia_coefficient_order
+    coef = np.ascontiguousarray(julia_coefficient_order(s.c, 3))
+    dims = np.array(s.dims, dtype=np.int32)
+    first = np.array(s.first, dtype=np.int32)
+    nk = npt**3
+    vals = np.empty(nk * 9, dtype=np.complex128)
+    eig = np.empty(nk * 3)
+    P = ctypes.c_void_p
+    args = (coef.ctypes.data_as(P), 3, dims.ctypes.data_as(P), first.ctypes.data_as(P), 3, npt,
+            vals.ctypes.data_as(P), eig.ctypes.data_as(P))
+    fn = getattr(lib, "orc_fourier_ptr3", None) or lib.orc_fourier_ptr
+    fn(*args)  # warm-up (page faults, thread pool)
+    t0 = time.perf_counter()
+    reps = 0
+    while reps < 2 or time.perf_counter() - t0 < 0.3 * budget_s:
+        fn(*args)
+        reps += 1
+    tA = (time.perf_counter() - t0) / reps
+    scan = getattr(lib, "orc_dos_scan3", None) or lib.orc_dos_scan
+    scan.argtypes = [P, ctypes.c_int64, ctypes.c_int, ctypes.c_double, P, ctypes.c_int, P]
+    n_om = 32
+    omegas = np.linspace(10, 15, 256)[:: 256 // n_om]
+    out = np.empty(n_om)
+    t0 = time.perf_counter()
+    scan(vals.ctypes.data_as(P), nk, 3, eta, omegas.ctypes.data_as(P), n_om, out.ctypes.data_as(P))
+    tB = time.perf_counter() - t0
+    res = {"value": nk / tA, "unit": "k-point evals/s (H(k)+eig)", "cores": cores, "kind": "port",
+           "nproc": os.cpu_count(), "affinity": aff,
+           "sample": f"SVO 3-band, PTR npt={npt} FBZ ({nk} k-points, the GPU workload's grid), {reps} builds + a "
+                     f"{n_om}-omega scan of the cached H(k); C restatement of the reference loops (not Julia): closed-form "
+                     f"3x3 Hermitian eigenvalues and adjugate inverse like StaticArrays, gcc -O3 {flags} "
+                     f"-fcx-limited-range -fopenmp, {cores} threads (affinity {aff}, {os.cpu_count()} logical CPUs)",
+           "build_seconds": tA, "dos_kpoint_omega_per_sec": nk * n_om / tB, "scan_seconds_per_omega": tB / n_om,
+           "dos_sample": f"{n_om} of the 256 omegas over the same {nk} cached H(k)"}
+    for th in (16, 1):
+        if th >= cores and th != 1:
+            continue
+        lib.orc_set_threads(th)
+        t0 = time.perf_counter()
+        r1 = 0
+        while r1 < 1 or time.perf_counter() - t0 < (2.0 if th > 1 else 4.0):
+            fn(*args)
+            r1 += 1
+        res[f"value_{th}_thread" + ("s" if th > 1 else "")] = nk * r1 / (time.perf_counter() - t0)
+    lib.orc_set_threads(want)
+    return res
+
+
+def rank_main(a):
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if "WORLD_SIZE" in os.environ and a.gpus != world:
+        raise SystemExit(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={world}")
     import torch
     import torch.distributed as dist
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the product path has no CPU fallback")
     ndev = torch.cuda.device_count()
-    local = local % max(ndev, 1)  # rehearsal: several ranks may share one card (backend gloo)
+    rehearsal = ndev < world  # several ranks share one card: collectives through gloo (RCCL refuses duplicate devices)
+    local = local % max(ndev, 1)
     torch.cuda.set_device(local)
-    backend = os.environ.get("ABZ_DIST_BACKEND", "nccl")  # nccl = RCCL over xGMI
+    backend = os.environ.get("ABZ_DIST_BACKEND", "gloo" if rehearsal else "nccl")  # nccl = RCCL over xGMI
     if world > 1:
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local))
         else:
             dist.init_process_group(backend)
+    n_ranks_seen = dist.get_world_size() if world > 1 else 1
+    assert n_ranks_seen == a.gpus, (n_ranks_seen, a.gpus)
+    cdev = "cuda" if (world == 1 or backend == "nccl") else "cpu"
 
     def barrier():
         if world > 1:
@@ -134,43 +189,51 @@ def main():
 
     import autobzcore.jl_amd as abz
     from autobzcore.jl_amd import _lib as L
-    ctx = abz.Context(local)
+    # the library works on a stream owned by torch: its launches and the RCCL collectives are ordered there
+    st = torch.cuda.Stream(device=local)
+    torch.cuda.set_stream(st)
+    ctx = abz.Context(local, stream=st.cuda_stream)
     abz.Context._default = ctx
     s = abz.load_w90_series(os.path.join(ROOT, "tests", "golden", "svo_hr.dat.gz"))
     dev = s.device(ctx)
     npt = a.npt
     nk = npt**3
+    n = 3
     rule = dev.rule(npt, None, L.WANT_H | L.WANT_EIG)  # inputs + rule buffers resident before timing
-    # omega sweep: 256 points in [10, 15] eV at 8 GPUs; round-robin shard like batchparam
+    base_addr, rule_bytes = rule.values_ptr()
     n_total = a.omegas_per_rank * world
     omegas_all = np.linspace(10.0, 15.0, n_total)
     mine = omegas_all[rank::world]
+    P = max(1, a.passes_per_step)
 
-    # ---------------- Phase A: K rebuilds
-    # contraction kernels: timed in the warm-up loop (events only around them)
+    # ---------------- Phase A: K steps of P rebuilds
     ctx.prof_enable(True, kernels=[L.K_CONTRACT])
     ctx.prof_reset()
-    for _ in range(max(a.warmup, 1)):
+    for _ in range(max(a.warmup, 1) * P):
         rule.rebuild()
     ctx.sync()
     con_ms, con_n = ctx.prof_read(L.K_CONTRACT)
-    # timed region: HIP events only around the dominant (Fourier-eval) kernel
-    ctx.prof_enable(True, kernels=[L.K_EVAL])
+    ctx.prof_enable(True, kernels=[L.K_EVAL])  # timed region: HIP events only around the dominant (Fourier-eval) kernel
     ctx.prof_reset()
+    block_ms = []
     barrier()
     t0 = time.perf_counter()
     for _ in range(a.steps):
-        rule.rebuild()
+        for _ in range(P):
+            rule.rebuild()
+        if world == 1:  # per-step spread (the sync costs ~10 us per 18 ms step)
+            ctx.sync()
+            block_ms.append(time.perf_counter())
     ctx.sync()
     barrier()
     tA = time.perf_counter() - t0
     eval_ms, eval_n = ctx.prof_read(L.K_EVAL)
     ctx.prof_enable(False)
+    step_ms = np.diff([t0] + block_ms) * 1e3 if block_ms else np.array([tA * 1e3 / a.steps])
 
-    # the same rebuild with the last contraction fused into the Fourier-eval kernel (ABZ_FUSE2=1, opt-in):
-    # one launch and 36 MB of HBM round trip less, ~7 % more work inside the kernel (not the primary number)
+    # the same rebuild with the last contraction fused into the Fourier-eval kernel (ABZ_FUSE2=1, opt-in)
     two = None
-    if world == 1:
+    if world == 1 and not a.no_extras:
         os.environ["ABZ_FUSE2"] = "1"
         for _ in range(max(a.warmup, 1)):
             rule.rebuild()
@@ -178,7 +241,7 @@ def main():
         ctx.prof_enable(True, kernels=[L.K_EVAL])
         ctx.prof_reset()
         t0 = time.perf_counter()
-        for _ in range(a.steps):
+        for _ in range(a.steps * 8):
             rule.rebuild()
         ctx.sync()
         t2 = time.perf_counter() - t0
@@ -187,84 +250,189 @@ def main():
         del os.environ["ABZ_FUSE2"]
         rule.rebuild()
         ctx.sync()
-        two = {"ms_per_step": 1e3 * t2 / a.steps, "eval_kernel_avg_ms": ms2 / max(n2, 1),
+        two = {"ms_per_pass": 1e3 * t2 / (a.steps * 8), "eval_kernel_avg_ms": ms2 / max(n2, 1),
                "frac": nk * 168 / ((ms2 / max(n2, 1)) * 1e-3) / 1e9 / 8000.0 if n2 else None,
                "note": "opt-in variant ABZ_FUSE2=1: contract x1 + eval_grid_fused_kernel (level-1 sets never leave the CU)"}
 
-    # ---------------- Phase B: K fused sweeps over this rank's omegas (matrix-cached, reference-faithful)
-    for _ in range(max(1, a.warmup // 2)):
+    # ---------------- Phase B: fused sweeps over this rank's omegas (matrix-cached, reference-faithful)
+    nB = a.steps * 50
+    for _ in range(max(1, a.warmup)):
         rule.reduce(L.F_DOS, [a.eta], mine)
     ctx.prof_enable(True, kernels=[L.K_REDUCE])
     ctx.prof_reset()
     barrier()
     t0 = time.perf_counter()
-    for _ in range(a.steps):
+    for _ in range(nB):
         dos = rule.reduce(L.F_DOS, [a.eta], mine)[:, 0].real
     ctx.sync()
     barrier()
-    tB = time.perf_counter() - t0
+    tB = (time.perf_counter() - t0) / nB
     red_ms, red_n = ctx.prof_read(L.K_REDUCE)
     ctx.prof_enable(False)
-    # eigenvalue-cached variant of the same sweep (24 B per k instead of 144 B)
     barrier()
     t0 = time.perf_counter()
-    for _ in range(a.steps):
+    for _ in range(nB):  # eigenvalue-cached variant of the same sweep (24 B per k instead of 144 B)
         dos_e = rule.reduce(L.F_DOS_EIG, [a.eta], mine)[:, 0].real
     ctx.sync()
     barrier()
-    tBe = time.perf_counter() - t0
+    tBe = (time.perf_counter() - t0) / nB
+    assert np.abs(dos - dos_e).max() < 1e-9 * np.abs(dos).max()
 
-    # one GPU: the whole 256-omega sweep of the north star in one fused pass (measured, not extrapolated)
-    t256 = None
-    if world == 1:
-        om256 = np.linspace(10.0, 15.0, 256)
-        rule.reduce(L.F_DOS, [a.eta], om256)
+    # ---------------- the fixed 256-omega job, strong scaling
+    om256 = np.linspace(10.0, 15.0, 256)
+    om_dev = torch.from_numpy(om256).to(f"cuda:{local}")
+    out_dev = torch.zeros(256, 2, dtype=torch.float64, device=f"cuda:{local}")
+    REPS = 40
+
+    def job_n1():  # rank 0 alone: build + one fused 256-omega scan; the sums come back over PCIe
+        rule.rebuild()
+        rule.reduce_device(L.F_DOS, [a.eta], om_dev.data_ptr(), 256, out_dev.data_ptr())
+        return out_dev[:, 0].cpu().numpy()
+
+    def timed(fn, reps, everyone=True):
+        fn()
+        if everyone:
+            barrier()
+        else:
+            torch.cuda.synchronize()
         t0 = time.perf_counter()
-        for _ in range(5):
-            rule.reduce(L.F_DOS, [a.eta], om256)
-        ctx.sync()
-        t256 = (time.perf_counter() - t0) / 5
+        for _ in range(reps):
+            r = fn()
+        torch.cuda.synchronize()
+        if everyone:
+            barrier()
+        return (time.perf_counter() - t0) / reps, r
 
-    # gather of the sweep (C1: one tiny all_gather) and max-over-ranks timing
-    cdev = "cuda" if (world == 1 or backend == "nccl") else "cpu"
+    t_n1, ref256 = (None, None)
+    if rank == 0:
+        t_n1, ref256 = timed(job_n1, REPS, everyone=False)
+    barrier()
+    jobs = None
+    if world > 1:
+        # (1) omega-sharded: replicated build, 256/N omega per rank (round-robin like batchparam), one all_gather
+        idx = np.arange(256)[rank::world]
+        om_mine = torch.from_numpy(om256[idx]).to(f"cuda:{local}")
+        part = torch.zeros(len(idx), 2, dtype=torch.float64, device=f"cuda:{local}")
+        gathered = [torch.zeros_like(part) for _ in range(world)] if 256 % world == 0 else None
+
+        def job_omega():
+            rule.rebuild()
+            rule.reduce_device(L.F_DOS, [a.eta], om_mine.data_ptr(), len(idx), part.data_ptr())
+            if gathered is None:
+                raise SystemExit("256 omegas do not divide over this world size")
+            if cdev == "cuda":
+                dist.all_gather(gathered, part)
+                full = torch.stack(gathered, 1).reshape(-1, 2)[:, 0]  # [256/N, N] -> omega order (round-robin)
+                return full.cpu().numpy()
+            pc = part.cpu()
+            g = [torch.zeros_like(pc) for _ in range(world)]
+            dist.all_gather(g, pc)
+            return torch.stack(g, 1).reshape(-1, 2)[:, 0].numpy()
+
+        # (2) k-sharded: a slab of the outermost grid variable per rank, all 256 omega, one all_reduce(sum)
+        dev.kshard = (rank, world)
+        rule_k = abz.DeviceRule(dev, npt, None, L.WANT_H | L.WANT_EIG)
+        dev.kshard = None
+        acc = torch.zeros(256, 2, dtype=torch.float64, device=f"cuda:{local}")
+
+        def job_k():
+            rule_k.rebuild()
+            rule_k.reduce_device(L.F_DOS, [a.eta], om_dev.data_ptr(), 256, acc.data_ptr())
+            if cdev == "cuda":
+                dist.all_reduce(acc)
+                return acc[:, 0].cpu().numpy()
+            c = acc.cpu()
+            dist.all_reduce(c)
+            return c[:, 0].numpy()
+
+        t_om, r_om = timed(job_omega, REPS)
+        t_k, r_k = timed(job_k, REPS)
+        tt = torch.tensor([t_om, t_k], dtype=torch.float64, device=cdev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        t_om, t_k = (float(v) for v in tt.cpu())
+        if rank == 0:
+            err_om = float(np.abs(r_om - ref256).max() / np.abs(ref256).max())
+            err_k = float(np.abs(r_k - ref256).max() / np.abs(ref256).max())
+            assert err_om < 1e-12 and err_k < 1e-11, (err_om, err_k)
+            jobs = {"omega_sharded": {"seconds": t_om, "speedup_vs_n1": t_n1 / t_om, "max_rel_diff_vs_n1": err_om,
+                                      "collective": "all_gather of 256/N complex sums per rank"},
+                    "k_sharded": {"seconds": t_k, "speedup_vs_n1": t_n1 / t_k, "max_rel_diff_vs_n1": err_k,
+                                  "collective": "all_reduce(sum) of 256 complex partial sums",
+                                  "slab_planes": [int((npt * (r + 1)) // world - (npt * r) // world) for r in range(world)]}}
+        rule_k.close()
+
+    # ---------------- a sweep big enough to shard by omega: 432 IAI solves on the cubic IBZ
+    iai_job = None
+    if not a.no_iai:
+        fiai = abz.FourierIntegrand(abz.DOSIntegrand(), s, 0.01)
+        bzc = abz.load_bz(abz.CubicSymIBZ(), 3.85856 * np.eye(3))
+        sol_iai = abz.IntegralSolver(fiai, bzc, abz.IAI(), abstol=1e-3)
+        om432 = np.linspace(10.0, 15.0, 432)
+        t1, r1 = (None, None)
+        if rank == 0:
+            abz.batchsolve(sol_iai, om432[:8])
+            t0 = time.perf_counter()
+            r1 = abz.batchsolve(sol_iai, om432)
+            t1 = time.perf_counter() - t0
+        barrier()
+        iai_job = {"n_solves": 432, "seconds_n1": t1}
+        if world > 1:
+            abz.batchsolve_sharded(sol_iai, om432[: 2 * world], device=cdev)
+            barrier()
+            t0 = time.perf_counter()
+            rN = abz.batchsolve_sharded(sol_iai, om432, device=cdev)
+            barrier()
+            tN = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=cdev)
+            dist.all_reduce(tN, op=dist.ReduceOp.MAX)
+            if rank == 0:
+                assert np.array_equal(np.asarray(rN, dtype=float), np.asarray(r1, dtype=float)), "sharded IAI sweep differs"
+                iai_job.update({"seconds": float(tN.cpu()[0]), "speedup_vs_n1": t1 / float(tN.cpu()[0]),
+                                "bit_identical_to_n1": True})
+
+    # max-over-ranks timing of the primary legs
     times = torch.tensor([tA, tB, tBe], dtype=torch.float64, device=cdev)
-    res = torch.tensor(dos, dtype=torch.float64, device=cdev)
     if world > 1:
         dist.all_reduce(times, op=dist.ReduceOp.MAX)
-        parts = [torch.empty_like(res) for _ in range(world)]
-        dist.all_gather(parts, res)
-        full = np.empty(n_total)
-        for r, p in enumerate(parts):
-            full[r::world] = p.cpu().numpy()
-    else:
-        full = dos
     tA, tB, tBe = (float(v) for v in times.cpu())
-    assert np.all(np.isfinite(full)) and np.abs(dos - dos_e).max() < 1e-9 * np.abs(dos).max()
 
     if rank == 0:
-        n = 3
-        bytes_per_k = 16 * n * n + 8 * n + 16 * n * n * 1331 / nk  # B_A = H out + eig out + coefficients once
-        kps = world * nk * a.steps / tA
+        kps = world * nk * P * a.steps / tA
         eval_avg_s = (eval_ms / max(eval_n, 1)) * 1e-3
         achieved = nk * (16 * n * n + 8 * n) / eval_avg_s / 1e9 if eval_avg_s > 0 else 0.0
+        build_ms = 1e3 * tA / (a.steps * P)
         out = {
             "metric": "k-point evals/sec (H(k)+eig)", "value": kps, "unit": "k-points/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * tA / a.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
             "data": "synthetic PTR grid over the reference's svo_hr.dat example coefficients (device resident)",
             "config": {"workload": f"BASELINE configs[3] per-GPU share: SVO 3-band Wannier H(k)+eig on a {npt}^3 PTR grid (FBZ) "
-                                   f"+ fused DOS sweep of {a.omegas_per_rank} omega per GPU (256 at 8 GPUs), eta={a.eta}",
-                       "npt": npt, "nk_per_gpu": nk, "n_bands": 3, "n_R": 1331, "omegas_per_gpu": a.omegas_per_rank,
+                                   f"+ fused DOS sweep of {a.omegas_per_rank} omega per GPU (256 at 8 GPUs), eta={a.eta}; "
+                                   f"one step = {P} passes over the grid",
+                       "npt": npt, "nk_per_gpu": nk, "passes_per_step": P, "n_bands": 3, "n_R": 1331,
+                       "omegas_per_gpu": a.omegas_per_rank,
                        "parallelism": f"omega-sharded x{world}, coefficient+rule replicas"},
-            "dos_points_per_sec": world * len(mine) * a.steps / tB,
-            "dos_points_per_sec_eigcached": world * len(mine) * a.steps / tBe,
-            "ms_per_sweep": 1e3 * tB / a.steps,
-            "kpoint_omega_per_sec": world * len(mine) * nk * a.steps / tB,
-            "job_seconds_256_omega": (tA / a.steps + t256) if t256 is not None else None,
-            "ms_per_sweep_256_omega": 1e3 * t256 if t256 is not None else None,
+            "n_ranks_seen": n_ranks_seen, "backend": ("rccl(nccl)" if backend == "nccl" else backend) if world > 1 else None,
+            "rehearsal_ranks_share_one_gpu": bool(rehearsal),
+            "timed_region_seconds": tA, "ms_per_pass": build_ms,
+            "ms_per_step_min_median_max": [float(step_ms.min()), float(np.median(step_ms)), float(step_ms.max())],
+            "rule_buffer": {"base_address": hex(base_addr), "bytes": rule_bytes, "base_mod_2MiB": base_addr % (2 << 20),
+                            "base_mod_4KiB": base_addr % 4096},
+            "dos_points_per_sec": world * len(mine) / tB,
+            "dos_points_per_sec_eigcached": world * len(mine) / tBe,
+            "ms_per_sweep": 1e3 * tB,
+            "kpoint_omega_per_sec": world * len(mine) * nk / tB,
+            "job_seconds_256_omega": min([t_n1] + ([jobs["omega_sharded"]["seconds"], jobs["k_sharded"]["seconds"]] if jobs else [])),
+            "speedup_vs_n1": (t_n1 / min(jobs["omega_sharded"]["seconds"], jobs["k_sharded"]["seconds"])) if jobs else 1.0,
+            "job_256_omega": {"what": f"fixed job (strong scaling): rule build on the {npt}^3 grid + DOS at 256 omega + the collective + "
+                                      "results on the host; n1 = the same job on rank 0 alone in this run",
+                              "seconds_n1": t_n1, "sharded": jobs,
+                              "amdahl_note": f"omega-sharding replicates the {build_ms:.3f} ms build on every rank: speed-up <= "
+                                             f"{t_n1 / build_ms:.1f}x whatever N; k-sharding divides build and scan alike and is bounded "
+                                             "by the all_reduce latency only"},
+            "iai_sweep_432_omega": iai_job,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(npt),
-                         "traffic_note": "HBM bytes per launch from rocprofv3 PMC passes (profiles/r01_traffic.json); algorithmic bytes per launch = nk*168",
+                         "traffic_note": "HBM bytes per launch from rocprofv3 PMC passes (profiles/r0x_traffic.json); algorithmic bytes per launch = nk*168",
                          "kernel": "eval_grid_kernel<3> (Fourier-eval + fused eig)",
                          "algorithmic_bytes_per_kpoint": 16 * n * n + 8 * n,
                          "avg_launch_ms": eval_ms / max(eval_n, 1), "launches": eval_n,
@@ -274,134 +442,152 @@ def main():
                          # Hermitian rule: the scan reads the upper triangle only, n^2 doubles per k-point
                          "reduce_read_GBs": nk * (8 * n * n) / ((red_ms / max(red_n, 1)) * 1e-3) / 1e9 if red_n else None},
         }
-        if not a.no_iai and world == 1:
-            # extra (not the primary metric): one IAI solve of the reference's own example
-            # (aps_example/aps_example.jl:29-34, eta = 0.01 eV, abstol 1e-3) with host-driven outer
-            # panels and device-side innermost adaptive loops
-            try:
-                fiai = abz.FourierIntegrand(abz.DOSIntegrand(), s, 0.01)
-                out["iai_example"] = {}
-                for kind, bzk in (("CubicSymIBZ", abz.CubicSymIBZ()), ("FBZ", abz.FBZ())):
-                    bz = abz.load_bz(bzk, 3.85856 * np.eye(3))
-                    prob = abz.IntegralProblem(fiai, bz, abz.MixedParameters(12.5))
-                    abz.solve(prob, abz.IAI(), abstol=1e-3)  # warm-up (allocations)
-                    t0 = time.perf_counter()
-                    sol = abz.solve(prob, abz.EvalCounter(abz.IAI()), abstol=1e-3)
-                    dt = time.perf_counter() - t0
-                    out["iai_example"][kind] = {"u": sol.u, "resid": sol.resid, "numevals": sol.numevals, "seconds": dt,
-                                                "nodes_per_sec": sol.numevals / dt}
-            except Exception as e:
-                out["iai_example"] = {"error": str(e)}
-            # configs 2 and 3 end to end (host loop + kernels + transfers; not the primary metric)
-            try:
-                cfg = {}
-                tb = abz.tb_integer(3)
-                sol2 = abz.IntegralSolver(abz.FourierIntegrand(abz.DOSIntegrand(), tb, 0.1),
-                                          abz.load_bz(abz.FBZ(), np.eye(3)), abz.PTR(npt=64))
-                sol2(0.5)
-                t0 = time.perf_counter()
-                for _ in range(10):
-                    tb.device().drop_rules()  # cold: build the 64^3 rule every time
-                    u2 = sol2(0.5)
-                cfg["config2_tb1band_64cubed_ptr"] = {"u": u2, "seconds_cold": (time.perf_counter() - t0) / 10}
-                t0 = time.perf_counter()
-                for _ in range(10):
-                    u2 = sol2(0.5)
-                cfg["config2_tb1band_64cubed_ptr"]["seconds_cached_rule"] = (time.perf_counter() - t0) / 10
-                for kind, bzk in (("FBZ", abz.FBZ()), ("CubicSymIBZ", abz.CubicSymIBZ())):
-                    sol3 = abz.IntegralSolver(abz.FourierIntegrand(abz.DOSIntegrand(), s, a.eta),
-                                              abz.load_bz(bzk, 3.85856 * np.eye(3)), abz.EvalCounter(abz.AutoPTR()), abstol=1e-3)
-                    s.device().drop_rules()
-                    t0 = time.perf_counter()
-                    r3 = sol3.solve_p(abz.MixedParameters(12.5))
-                    tc = time.perf_counter() - t0
-                    t0 = time.perf_counter()
-                    r3 = sol3.solve_p(abz.MixedParameters(12.5))
-                    cfg["config3_svo_autoptr_" + kind] = {"u": r3.u, "resid": r3.resid, "numevals": r3.numevals,
-                                                         "seconds_cold": tc, "seconds_cached_rules": time.perf_counter() - t0}
-                out["configs_end_to_end"] = cfg
-            except Exception as e:
-                out["configs_end_to_end"] = {"error": str(e)}
-            # store-free rule values (abz_ptr_sum): the 1000^3 grid (10^9 k-points, 168 GB if it were stored)
-            try:
-                dev0 = s.device()
-                dev0.ptr_sum(300, L.F_DOS, [a.eta], [12.5])
-                sf = {}
-                for nw in (1, 8):
-                    om = np.linspace(12.0, 13.0, nw)
-                    t0 = time.perf_counter()
-                    dev0.ptr_sum(1000, L.F_DOS, [a.eta], om)
-                    dt = time.perf_counter() - t0
-                    sf[f"seconds_{nw}_omega"] = dt
-                    sf[f"kpoints_per_sec_{nw}_omega"] = 1e9 / dt
-                sol_s = abz.IntegralSolver(abz.FourierIntegrand(abz.DOSIntegrand(), s, 0.01), abz.load_bz(abz.FBZ(), 3.85856 * np.eye(3)),
-                                           abz.EvalCounter(abz.AutoPTR()), abstol=1e-3)
-                t0 = time.perf_counter()
-                r_s = sol_s.solve_p(abz.MixedParameters(12.5))
-                sf["autoptr_fbz_eta0.01"] = {"u": r_s.u, "resid": r_s.resid, "numevals": r_s.numevals,
-                                             "seconds": time.perf_counter() - t0}
-                sf["note"] = "DOS on the 1000^3 full-BZ grid without materialising H(k): Fourier evaluation feeds the integrand"
-                out["store_free_1000cubed"] = sf
-            except Exception as e:
-                out["store_free_1000cubed"] = {"error": str(e)}
-            # config 5: synthetic 16-band model, IAI on the full BZ (380 M adaptive nodes)
-            try:
-                s16 = abz.synthetic_wannier()
-                f16 = abz.FourierIntegrand(abz.DOSIntegrand(), s16, 0.05)
-                prob = abz.IntegralProblem(f16, abz.load_bz(abz.FBZ(), np.eye(3)), abz.MixedParameters(0.2))
-                abz.solve(prob, abz.IAI(), abstol=10.0, reltol=0.0)  # warm-up
-                t0 = time.perf_counter()
-                sol = abz.solve(prob, abz.EvalCounter(abz.IAI()), abstol=0.1, reltol=0.0)
-                dt = time.perf_counter() - t0
-                out["iai_config5"] = {"model": "synthetic 16-band, 2197 R (seed 20240601), DOS eta=0.05 omega=0.2, abstol 0.1",
-                                      "u": sol.u, "resid": sol.resid, "numevals": sol.numevals, "seconds": dt,
-                                      "nodes_per_sec": sol.numevals / dt}
-            except Exception as e:
-                out["iai_config5"] = {"error": str(e)}
-            # the same 16-band model on fixed grids: store-free PTR sums, a cached rule with eigenvalues, its scan
-            try:
-                from autobzcore.jl_amd import _lib as L16
-                dev16 = s16.device()
-                om16 = np.linspace(-1.0, 1.0, 16)
-                b16 = {}
-                dev16.ptr_sum(96, L16.F_DOS, [0.05], om16)
-                t0 = time.perf_counter()
-                dev16.ptr_sum(96, L16.F_DOS, [0.05], om16)
-                dt = time.perf_counter() - t0
-                b16["store_free_96cubed_16_omega"] = {"seconds": dt, "kpoint_omega_per_sec": 96**3 * 16 / dt}
-                r16 = abz.DeviceRule(dev16, 48, None, L16.WANT_H | L16.WANT_EIG)
-                dev16.ctx.sync()
-                t0 = time.perf_counter()
-                r16.rebuild()
-                dev16.ctx.sync()
-                dt = time.perf_counter() - t0
-                b16["rule_48cubed_H_and_eig"] = {"seconds": dt, "kpoints_per_sec": 48**3 / dt}
-                r16.reduce(L16.F_DOS, [0.05], om16)
-                t0 = time.perf_counter()
-                r16.reduce(L16.F_DOS, [0.05], om16)
-                dt = time.perf_counter() - t0
-                b16["rule_scan_16_omega"] = {"seconds": dt, "kpoint_omega_per_sec": 48**3 * 16 / dt}
-                r16.close()
-                out["bands16_fixed_grids"] = b16
-            except Exception as e:
-                out["bands16_fixed_grids"] = {"error": str(e)}
+        if world == 1 and not a.no_extras:
+            extras(a, abz, L, s, ctx, out, nk)
         if not a.no_cpu and world == 1:  # the CPU leg is timed at N = 1 only
             try:
-                out["cpu_baseline"] = cpu_baseline(a.cpu_npt, 4, s)
-                cb = out["cpu_baseline"]
-                # the north star's comparison: a 256-omega DOS sweep (build the cached rule once, scan it
-                # per omega) on this GPU vs the CPU port's rates on the same grid
-                gpu_job = out.get("job_seconds_256_omega")
-                if gpu_job:
-                    cpu_job = nk / cb["value"] + nk * 256 / cb["dos_kpoint_omega_per_sec"]
-                    out["dos_sweep_256_omega"] = {"gpu_seconds": gpu_job, "cpu_port_seconds_est": cpu_job,
-                                                  "speedup": cpu_job / gpu_job,
-                                                  "note": "rule build + one fused 256-omega scan of the same 150^3 grid (measured) vs the CPU port's build + scan rates (bounded sample, extrapolated)"}
+                cb = cpu_baseline(npt, s, a.eta)
+                out["cpu_baseline"] = cb
+                if cb:
+                    cpu_job = cb["build_seconds"] + 256 * cb["scan_seconds_per_omega"]
+                    out["dos_sweep_256_omega"] = {"gpu_seconds": t_n1, "cpu_port_seconds": cpu_job, "speedup": cpu_job / t_n1,
+                                                  "note": f"rule build + 256-omega scan of the same {npt}^3 grid: GPU measured end to end; CPU port "
+                                                          f"build measured on this grid, its scan measured for 32 of the 256 omegas (per-omega cost is constant) x 8"}
             except Exception as e:  # the baseline never blocks the GPU number
                 out["cpu_baseline"] = {"error": str(e)}
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
     if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
+
+
+def extras(a, abz, L, s, ctx, out, nk):
+    """N = 1 only, outside every timed region of the primary metric: end-to-end times of the other configs."""
+    if not a.no_iai:
+        # one IAI solve of the reference's own example (aps_example/aps_example.jl:29-34, eta = 0.01 eV, abstol 1e-3)
+        try:
+            fiai = abz.FourierIntegrand(abz.DOSIntegrand(), s, 0.01)
+            out["iai_example"] = {}
+            for kind, bzk in (("CubicSymIBZ", abz.CubicSymIBZ()), ("FBZ", abz.FBZ())):
+                bz = abz.load_bz(bzk, 3.85856 * np.eye(3))
+                prob = abz.IntegralProblem(fiai, bz, abz.MixedParameters(12.5))
+                abz.solve(prob, abz.IAI(), abstol=1e-3)  # warm-up (allocations)
+                t0 = time.perf_counter()
+                sol = abz.solve(prob, abz.EvalCounter(abz.IAI()), abstol=1e-3)
+                dt = time.perf_counter() - t0
+                out["iai_example"][kind] = {"u": sol.u, "resid": sol.resid, "numevals": sol.numevals, "seconds": dt,
+                                            "nodes_per_sec": sol.numevals / dt}
+        except Exception as e:
+            out["iai_example"] = {"error": str(e)}
+    # configs 2 and 3 end to end (host loop + kernels + transfers; not the primary metric)
+    try:
+        cfg = {}
+        tb = abz.tb_integer(3)
+        sol2 = abz.IntegralSolver(abz.FourierIntegrand(abz.DOSIntegrand(), tb, 0.1),
+                                  abz.load_bz(abz.FBZ(), np.eye(3)), abz.PTR(npt=64))
+        sol2(0.5)
+        t0 = time.perf_counter()
+        for _ in range(10):
+            tb.device().drop_rules()  # cold: build the 64^3 rule every time
+            u2 = sol2(0.5)
+        cfg["config2_tb1band_64cubed_ptr"] = {"u": u2, "seconds_cold": (time.perf_counter() - t0) / 10}
+        t0 = time.perf_counter()
+        for _ in range(10):
+            u2 = sol2(0.5)
+        cfg["config2_tb1band_64cubed_ptr"]["seconds_cached_rule"] = (time.perf_counter() - t0) / 10
+        for kind, bzk in (("FBZ", abz.FBZ()), ("CubicSymIBZ", abz.CubicSymIBZ())):
+            sol3 = abz.IntegralSolver(abz.FourierIntegrand(abz.DOSIntegrand(), s, a.eta),
+                                      abz.load_bz(bzk, 3.85856 * np.eye(3)), abz.EvalCounter(abz.AutoPTR()), abstol=1e-3)
+            s.device().drop_rules()
+            t0 = time.perf_counter()
+            r3 = sol3.solve_p(abz.MixedParameters(12.5))
+            tc = time.perf_counter() - t0
+            t0 = time.perf_counter()
+            r3 = sol3.solve_p(abz.MixedParameters(12.5))
+            cfg["config3_svo_autoptr_" + kind] = {"u": r3.u, "resid": r3.resid, "numevals": r3.numevals,
+                                                 "seconds_cold": tc, "seconds_cached_rules": time.perf_counter() - t0}
+        out["configs_end_to_end"] = cfg
+    except Exception as e:
+        out["configs_end_to_end"] = {"error": str(e)}
+    # store-free rule values (abz_ptr_sum): the 1000^3 grid (10^9 k-points, 168 GB if it were stored)
+    try:
+        dev0 = s.device()
+        dev0.ptr_sum(300, L.F_DOS, [a.eta], [12.5])
+        sf = {}
+        for nw in (1, 8):
+            om = np.linspace(12.0, 13.0, nw)
+            t0 = time.perf_counter()
+            dev0.ptr_sum(1000, L.F_DOS, [a.eta], om)
+            dt = time.perf_counter() - t0
+            sf[f"seconds_{nw}_omega"] = dt
+            sf[f"kpoints_per_sec_{nw}_omega"] = 1e9 / dt
+        sol_s = abz.IntegralSolver(abz.FourierIntegrand(abz.DOSIntegrand(), s, 0.01), abz.load_bz(abz.FBZ(), 3.85856 * np.eye(3)),
+                                   abz.EvalCounter(abz.AutoPTR()), abstol=1e-3)
+        t0 = time.perf_counter()
+        r_s = sol_s.solve_p(abz.MixedParameters(12.5))
+        sf["autoptr_fbz_eta0.01"] = {"u": r_s.u, "resid": r_s.resid, "numevals": r_s.numevals,
+                                     "seconds": time.perf_counter() - t0}
+        sf["note"] = "DOS on the 1000^3 full-BZ grid without materialising H(k): Fourier evaluation feeds the integrand"
+        out["store_free_1000cubed"] = sf
+    except Exception as e:
+        out["store_free_1000cubed"] = {"error": str(e)}
+    s16 = abz.synthetic_wannier()
+    if not a.no_iai:
+        # config 5: synthetic 16-band model, IAI on the full BZ
+        try:
+            f16 = abz.FourierIntegrand(abz.DOSIntegrand(), s16, 0.05)
+            prob = abz.IntegralProblem(f16, abz.load_bz(abz.FBZ(), np.eye(3)), abz.MixedParameters(0.2))
+            abz.solve(prob, abz.IAI(), abstol=10.0, reltol=0.0)  # warm-up
+            t0 = time.perf_counter()
+            sol = abz.solve(prob, abz.EvalCounter(abz.IAI()), abstol=a.c5_abstol, reltol=0.0)
+            dt = time.perf_counter() - t0
+            # flops per inner node (SURVEY 8d): series 8 n^2 M + Gauss-Jordan 8 n^3
+            fl = 8 * 16 * 16 * 13 + 8 * 16**3
+            out["iai_config5"] = {"model": f"synthetic 16-band, 2197 R (seed 20240601), DOS eta=0.05 omega=0.2, IAI on the FBZ",
+                                  "abstol": a.c5_abstol, "abstol_stated_by_SURVEY_8d": 1e-3,
+                                  "u": sol.u, "resid": sol.resid, "numevals": sol.numevals, "seconds": dt,
+                                  "nodes_per_sec": sol.numevals / dt,
+                                  "f64_tflops": sol.numevals * fl / dt / 1e12,
+                                  "frac_of_f64_peak": sol.numevals * fl / dt / 1e12 / F64_PEAK_TFLOPS}
+        except Exception as e:
+            out["iai_config5"] = {"error": str(e)}
+    # the same 16-band model on fixed grids: store-free PTR sums, a cached rule with eigenvalues, its scan
+    try:
+        dev16 = s16.device()
+        om16 = np.linspace(-1.0, 1.0, 16)
+        b16 = {}
+        dev16.ptr_sum(96, L.F_DOS, [0.05], om16)
+        t0 = time.perf_counter()
+        dev16.ptr_sum(96, L.F_DOS, [0.05], om16)
+        dt = time.perf_counter() - t0
+        fl = 8 * 16 * 16 * 13 / 16 + 8 * 16**3  # per (k, omega): the series row is shared by the swept values
+        b16["store_free_96cubed_16_omega"] = {"seconds": dt, "kpoint_omega_per_sec": 96**3 * 16 / dt,
+                                              "f64_tflops": 96**3 * 16 * fl / dt / 1e12,
+                                              "frac_of_f64_peak": 96**3 * 16 * fl / dt / 1e12 / F64_PEAK_TFLOPS}
+        r16 = abz.DeviceRule(dev16, 48, None, L.WANT_H | L.WANT_EIG)
+        dev16.ctx.sync()
+        t0 = time.perf_counter()
+        for _ in range(5):
+            r16.rebuild()
+        dev16.ctx.sync()
+        dt = (time.perf_counter() - t0) / 5
+        b16["rule_48cubed_H_and_eig"] = {"seconds": dt, "kpoints_per_sec": 48**3 / dt}
+        r16.reduce(L.F_DOS, [0.05], om16)
+        t0 = time.perf_counter()
+        r16.reduce(L.F_DOS, [0.05], om16)
+        dt = time.perf_counter() - t0
+        b16["rule_scan_16_omega"] = {"seconds": dt, "kpoint_omega_per_sec": 48**3 * 16 / dt}
+        r16.close()
+        out["bands16_fixed_grids"] = b16
+    except Exception as e:
+        out["bands16_fixed_grids"] = {"error": str(e)}
+
+
+def main():
+    a = parse_args()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(a))
+    rank_main(a)
 
 
 if __name__ == "__main__":

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define ABZ_VERSION 100
+#define ABZ_VERSION 200
 
 /* status codes */
 #define ABZ_OK 0
@@ -87,6 +87,12 @@ int abz_version(void);
 int abz_device_count(int* n);
 /* One context per host thread / rank: binds `device`, creates its stream. */
 int abz_ctx_create(int device, abz_ctx** out);
+/* The same on a stream the caller owns (a `hipStream_t`, e.g. the current stream of the PyTorch harness):
+ * the library's launches are then ordered with the caller's own work and with RCCL collectives enqueued on
+ * that stream -- the sharded sweep needs no host synchronisation between its scan and its gather.  The
+ * stream is borrowed: abz_ctx_destroy does not destroy it.  Replaces: nothing in the reference (it has no
+ * device queue); the per-thread workspace rule of src/fourier.jl:60-86 still applies, one context per thread. */
+int abz_ctx_create_on_stream(int device, void* hip_stream, abz_ctx** out);
 int abz_ctx_destroy(abz_ctx* ctx);
 int abz_ctx_sync(abz_ctx* ctx);
 /* HIP-event timing of the library's own launches on the context's stream.  on = 0: off; 1: every
@@ -154,6 +160,16 @@ int abz_rule_export(abz_rule* r, double* x, double* w, double* H, double* eig, d
  * -- the caller applies |det B| and symmetrisation like do_solve_autobz (src/brillouin.jl:337-355). */
 int abz_rule_reduce(abz_rule* r, int integrand, const double* params, int nparams,
                     const double* sweep, int n_sweep, int nsyms, double* out_reim);
+
+/* abz_rule_reduce without the host round trip: `sweep_dev` [n_sweep] and `out_dev_reim`
+ * [n_sweep][ncomp][2] are DEVICE pointers, the call only enqueues work on the context's stream and returns.
+ * This is the per-rank leg of a sharded sweep / of a k-sharded solve: the partial sums stay in HBM and go
+ * straight into the RCCL all_gather / all_reduce (src/interfaces.jl:210-222's fan-in). */
+int abz_rule_reduce_device(abz_rule* r, int integrand, const double* params, int nparams,
+                           const double* sweep_dev, int n_sweep, int nsyms, double* out_dev_reim);
+/* Device address and size in bytes of the rule's value block (tiled planar layout):
+ * zero-copy views for a device-side harness, and the placement log of bench.py. */
+int abz_rule_values_ptr(const abz_rule* r, void** base, int64_t* nbytes);
 
 /* Store-free rule value: the same number as abz_rule_reduce on the full grid (or on the slab
  * [outer_begin, outer_end) of its outermost variable), computed without materialising H(k): the

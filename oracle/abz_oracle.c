@@ -12,6 +12,13 @@
  *   orc_dos_scan      per-omega weighted sum over cached H(k) of -Im tr inv((w+i eta)I - H)/pi
  *                                                         ref: quadsum at src/fourier.jl:204-207 with
  *                                                         the integrand of aps_example/aps_example.jl:30
+ *   orc_fourier_ptr3 / orc_dos_scan3   the same two loops for n = 3 bands at fixed size, doing what the
+ *                     reference does for SMatrix{3,3}: series terms as unrolled 3x3 complex multiply-adds,
+ *                     eigenvalues by StaticArrays' closed form for 3x3 Hermitian matrices (trigonometric
+ *                     roots of the characteristic cubic, ref: src/dos_ggr.jl:19), inverse by the adjugate
+ *                     (StaticArrays inv of a 3x3, ref: aps_example/aps_example.jl:30).  Built with
+ *                     -fcx-limited-range: Julia's complex multiply has no Annex-G NaN recovery branch.
+ *                     These are the cpu_baseline of bench.py.
  * Parity status: pinned through tests/test_oracle_c.py against the numpy oracle (itself pinned
  * analytically, oracle/abz_oracle.py).
  */
@@ -213,6 +220,132 @@ void orc_dos_scan(const cd* vals, int64_t nk, int n, double eta, const double* o
             for (int i = 0; i < nn; ++i) A[i] = -h[i];
             for (int i = 0; i < n; ++i) A[i + n * i] += z;
             acc += -cimag(trace_inverse(A, n)) / M_PI;
+        }
+        out[w] = acc / (double)nk;
+    }
+}
+
+/* ---------------------------------------------------------------------------------------------
+ * n = 3 at fixed size (the SVO workload): what the reference's SMatrix{3,3} code paths do.
+ * ------------------------------------------------------------------------------------------- */
+/* eigvals(Hermitian(h)) for 3x3, upper triangle, column-major: closed form (trigonometric solution of the
+ * characteristic cubic), ascending.  StaticArrays uses this form for 3x3 Hermitian matrices. */
+static inline void eig3_closed(const cd* h, double* e) {
+    const double a00 = creal(h[0]), a11 = creal(h[4]), a22 = creal(h[8]);
+    const cd a01 = h[3], a02 = h[6], a12 = h[7];
+    const double n01 = creal(a01) * creal(a01) + cimag(a01) * cimag(a01);
+    const double n02 = creal(a02) * creal(a02) + cimag(a02) * cimag(a02);
+    const double n12 = creal(a12) * creal(a12) + cimag(a12) * cimag(a12);
+    const double p1 = n01 + n02 + n12;
+    const double q = (a00 + a11 + a22) / 3.0;
+    const double b00 = a00 - q, b11 = a11 - q, b22 = a22 - q;
+    const double p2 = b00 * b00 + b11 * b11 + b22 * b22 + 2.0 * p1;
+    if (!(p2 > 0.0)) {
+        e[0] = e[1] = e[2] = q;
+        return;
+    }
+    const double p = sqrt(p2 / 6.0);
+    /* det(B), B = A - qI Hermitian: b00 b11 b22 + 2 Re(a01 a12 conj(a02)) - b00|a12|^2 - b11|a02|^2 - b22|a01|^2 */
+    const cd t = a01 * a12 * conj(a02);
+    const double detB = b00 * b11 * b22 + 2.0 * creal(t) - b00 * n12 - b11 * n02 - b22 * n01;
+    double r = detB / (2.0 * p * p * p);
+    r = r < -1.0 ? -1.0 : (r > 1.0 ? 1.0 : r);
+    const double phi = acos(r) / 3.0;
+    const double e3 = q + 2.0 * p * cos(phi);
+    const double e1 = q + 2.0 * p * cos(phi + 2.0 * M_PI / 3.0);
+    e[0] = e1;
+    e[1] = 3.0 * q - e1 - e3;
+    e[2] = e3;
+}
+
+void orc_eig3_closed(const cd* h, double* e) { eig3_closed(h, e); }
+
+/* tr inv(A), A general complex 3x3 column-major, by the adjugate (only the diagonal cofactors survive the trace) */
+static inline cd trace_inverse3(const cd* A) {
+    const cd c00 = A[4] * A[8] - A[7] * A[5];
+    const cd c11 = A[0] * A[8] - A[6] * A[2];
+    const cd c22 = A[0] * A[4] - A[3] * A[1];
+    const cd c01 = A[7] * A[2] - A[1] * A[8]; /* cofactors of the first column for the determinant */
+    const cd c02 = A[1] * A[5] - A[4] * A[2];
+    const cd det = A[0] * c00 + A[3] * c01 + A[6] * c02;
+    return (c00 + c11 + c22) / det;
+}
+
+void orc_fourier_ptr3(const cd* coef, int d, const int* dims, const int* first, int n, int npt, cd* vals, double* eig) {
+    if (n != 3 || d != 3) {
+        orc_fourier_ptr(coef, d, dims, first, n, npt, vals, eig);
+        return;
+    }
+    enum { NN = 9 };
+    const int M0 = dims[0], M1 = dims[1], M2 = dims[2];
+    cd* ph[3];
+    for (int j = 0; j < 3; ++j) {
+        ph[j] = (cd*)malloc(sizeof(cd) * (size_t)npt * dims[j]);
+        for (int i = 0; i < npt; ++i)
+            for (int m = 0; m < dims[j]; ++m) {
+                const double ang = 2.0 * M_PI * (double)(first[j] + m) * ((double)i / (double)npt);
+                ph[j][i * dims[j] + m] = cos(ang) + I * sin(ang);
+            }
+    }
+    const int64_t L2 = (int64_t)M1 * M0 * NN, L1 = (int64_t)M0 * NN;
+#pragma omp parallel
+    {
+        cd* c2 = (cd*)malloc(sizeof(cd) * (size_t)L2);
+        cd* c1 = (cd*)malloc(sizeof(cd) * (size_t)L1);
+#pragma omp for schedule(static)
+        for (int i3 = 0; i3 < npt; ++i3) {
+            for (int64_t l = 0; l < L2; ++l) c2[l] = 0.0;
+            for (int m = 0; m < M2; ++m) {
+                const cd p = ph[2][i3 * M2 + m];
+                const cd* src = coef + (int64_t)m * L2;
+                for (int64_t l = 0; l < L2; ++l) c2[l] += src[l] * p;
+            }
+            for (int i2 = 0; i2 < npt; ++i2) {
+                for (int64_t l = 0; l < L1; ++l) c1[l] = 0.0;
+                for (int m = 0; m < M1; ++m) {
+                    const cd p = ph[1][i2 * M1 + m];
+                    const cd* src = c2 + (int64_t)m * L1;
+                    for (int64_t l = 0; l < L1; ++l) c1[l] += src[l] * p;
+                }
+                for (int i1 = 0; i1 < npt; ++i1) {
+                    const int64_t k = ((int64_t)i3 * npt + i2) * npt + i1;
+                    cd acc[NN];
+                    for (int a = 0; a < NN; ++a) acc[a] = 0.0;
+                    const cd* pp = ph[0] + (int64_t)i1 * M0;
+                    for (int m = 0; m < M0; ++m) {
+                        const cd p = pp[m];
+                        const cd* src = c1 + (int64_t)m * NN;
+                        for (int a = 0; a < NN; ++a) acc[a] += src[a] * p;
+                    }
+                    cd* out = vals + k * NN;
+                    for (int a = 0; a < NN; ++a) out[a] = acc[a];
+                    if (eig) eig3_closed(acc, eig + k * 3);
+                }
+            }
+        }
+        free(c2);
+        free(c1);
+    }
+    for (int j = 0; j < 3; ++j) free(ph[j]);
+}
+
+void orc_dos_scan3(const cd* vals, int64_t nk, int n, double eta, const double* omegas, int nw, double* out) {
+    if (n != 3) {
+        orc_dos_scan(vals, nk, n, eta, omegas, nw, out);
+        return;
+    }
+    for (int w = 0; w < nw; ++w) {
+        const cd z = omegas[w] + I * eta;
+        double acc = 0.0;
+#pragma omp parallel for reduction(+ : acc) schedule(static)
+        for (int64_t k = 0; k < nk; ++k) {
+            cd A[9];
+            const cd* h = vals + k * 9;
+            for (int i = 0; i < 9; ++i) A[i] = -h[i];
+            A[0] += z;
+            A[4] += z;
+            A[8] += z;
+            acc += -cimag(trace_inverse3(A)) / M_PI;
         }
         out[w] = acc / (double)nk;
     }
