@@ -107,9 +107,6 @@ def cpu_baseline(npt, s, eta, budget_s=25.0):
     lib = ctypes.CDLL(lib_path)
     lib.orc_num_threads.restype = ctypes.c_int
     aff = len(os.sched_getaffinity(0))
-    want = int(os.environ.get("ABZ_CPU_THREADS", str(aff)))
-    lib.orc_set_threads(want)
-    cores = lib.orc_num_threads()
     from autobzcore.jl_amd.series import julia_coefficient_order
     coef = np.ascontiguousarray(julia_coefficient_order(s.c, 3))
     dims = np.array(s.dims, dtype=np.int32)
@@ -121,7 +118,21 @@ def cpu_baseline(npt, s, eta, budget_s=25.0):
     args = (coef.ctypes.data_as(P), 3, dims.ctypes.data_as(P), first.ctypes.data_as(P), 3, npt,
             vals.ctypes.data_as(P), eig.ctypes.data_as(P))
     fn = getattr(lib, "orc_fourier_ptr3", None) or lib.orc_fourier_ptr
-    fn(*args)  # warm-up (page faults, thread pool)
+    # thread count: every core the process may use, unless fewer threads are faster (a 1-GPU box is a CPU-quota
+    # share of a 256-thread host: 256 OpenMP threads get throttled there and run 8x slower than 16)
+    tried = {}
+    cands = [int(os.environ["ABZ_CPU_THREADS"])] if "ABZ_CPU_THREADS" in os.environ else \
+        sorted({t for t in (aff, 128, 64, 32, 16, 8) if t <= aff}, reverse=True)
+    for th in cands:
+        lib.orc_set_threads(th)
+        fn(*args)  # warm-up (page faults, thread pool)
+        t0 = time.perf_counter()
+        fn(*args)
+        tried[th] = nk / (time.perf_counter() - t0)
+    want = max(tried, key=tried.get)
+    lib.orc_set_threads(want)
+    cores = lib.orc_num_threads()
+    fn(*args)
     t0 = time.perf_counter()
     reps = 0
     while reps < 2 or time.perf_counter() - t0 < 0.3 * budget_s:
@@ -137,23 +148,20 @@ def cpu_baseline(npt, s, eta, budget_s=25.0):
     scan(vals.ctypes.data_as(P), nk, 3, eta, omegas.ctypes.data_as(P), n_om, out.ctypes.data_as(P))
     tB = time.perf_counter() - t0
     res = {"value": nk / tA, "unit": "k-point evals/s (H(k)+eig)", "cores": cores, "kind": "port",
-           "nproc": os.cpu_count(), "affinity": aff,
+           "nproc": os.cpu_count(), "affinity": aff, "kpoints_per_sec_by_thread_count": tried,
            "sample": f"SVO 3-band, PTR npt={npt} FBZ ({nk} k-points, the GPU workload's grid), {reps} builds + a "
                      f"{n_om}-omega scan of the cached H(k); C restatement of the reference loops (not Julia): closed-form "
                      f"3x3 Hermitian eigenvalues and adjugate inverse like StaticArrays, gcc -O3 {flags} "
-                     f"-fcx-limited-range -fopenmp, {cores} threads (affinity {aff}, {os.cpu_count()} logical CPUs)",
+                     f"-fcx-limited-range -fopenmp, {cores} threads = the fastest of {sorted(tried)} (affinity {aff}, {os.cpu_count()} logical CPUs)",
            "build_seconds": tA, "dos_kpoint_omega_per_sec": nk * n_om / tB, "scan_seconds_per_omega": tB / n_om,
            "dos_sample": f"{n_om} of the 256 omegas over the same {nk} cached H(k)"}
-    for th in (16, 1):
-        if th >= cores and th != 1:
-            continue
-        lib.orc_set_threads(th)
-        t0 = time.perf_counter()
-        r1 = 0
-        while r1 < 1 or time.perf_counter() - t0 < (2.0 if th > 1 else 4.0):
-            fn(*args)
-            r1 += 1
-        res[f"value_{th}_thread" + ("s" if th > 1 else "")] = nk * r1 / (time.perf_counter() - t0)
+    lib.orc_set_threads(1)
+    t0 = time.perf_counter()
+    r1 = 0
+    while r1 < 1 or time.perf_counter() - t0 < 3.0:
+        fn(*args)
+        r1 += 1
+    res["value_1_thread"] = nk * r1 / (time.perf_counter() - t0)
     lib.orc_set_threads(want)
     return res
 
