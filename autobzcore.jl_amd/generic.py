@@ -1,0 +1,241 @@
+"""Generic (non-Fourier) integrands behind the same dispatch: plain callables `f(x, p)`, `BatchIntegrand(f!, y, x;
+max_batch)` and `NestedBatchIntegrand`, under AuxQuadGKJL (1-D), MonkhorstPack / AutoSymPTRJL (Basis domains) and
+NestedQuad (iterated limits).  The adaptive loops and the user's function run on the host; the GK(7,15) panel sums go
+through the library's shared rule (abz_gk15_batch, the same table the device loops use).
+
+`BatchIntegrand` is the reference's stated GPU hook ("f!(y, x, p) ... can evaluate the integrand at multiple quadrature
+nodes using, for example, threads, the GPU", src/batch.jl:1-9): `fourier_batch(g, series)` builds the batch body that
+evaluates H(k) for all nodes of a batch in one abz_eval_nodes call and hands the user `FourierValue` batches.
+
+ref: src/batch.jl:10-38 (types), src/algorithms.jl:215-239 (AuxQuadGKJL incl. the BatchIntegrand branch :227-233),
+:360-380 (MonkhorstPack, :370-372), :409-432 (AutoSymPTRJL, :421-423), :450-612 (NestedQuad: `init_nest` batches the
+innermost integral only for a BatchIntegrand :469-471,517-518, every level for a NestedBatchIntegrand :483-488,
+:519-529,549-560; inner tolerance abstol/len :532-533,556-557).
+"""
+import math
+
+import numpy as np
+
+from . import _lib as L
+from .hostquad import _Heap, _gk_eval, _gk_nodes, _norm
+
+
+class PuncturedInterval:
+    """Break points of a 1-D domain.  ref: src/domains.jl (segments)."""
+
+    def __init__(self, segs):
+        self.segs = tuple(float(s) for s in segs)
+        if len(self.segs) < 2:
+            raise ValueError("a 1-D domain needs at least two break points")
+
+
+def _segments(dom):
+    if isinstance(dom, PuncturedInterval):
+        return dom.segs
+    if hasattr(dom, "segs") and not callable(dom.segs):  # bz.PuncturedInterval dataclass
+        return tuple(float(s) for s in dom.segs)
+    if isinstance(dom, (tuple, list)) and len(dom) >= 2 and all(np.ndim(v) == 0 for v in dom):
+        return tuple(float(v) for v in dom)
+    raise ValueError("1-D quadrature needs an interval (a, b) or a PuncturedInterval")
+
+
+class _Evaluator:
+    """values = ev(points): one call of a BatchIntegrand body per <= max_batch points, or a loop over a plain
+    callable.  Counts evaluations (EvalCounter)."""
+
+    def __init__(self, f, p, point=None):
+        from .solver import BatchIntegrand
+        self.f, self.p, self.point = f, p, point or (lambda x: x)
+        self.batch = isinstance(f, BatchIntegrand)
+        self.numevals = 0
+
+    def __call__(self, xs):
+        pts = [self.point(x) for x in xs]
+        self.numevals += len(pts)
+        if not self.batch:
+            return [self.f(x, self.p) for x in pts]
+        out = []
+        mb = self.f.max_batch
+        for i in range(0, len(pts), mb):
+            chunk = pts[i:i + mb]
+            y = [None] * len(chunk)  # the resize!-able output buffer of the reference
+            self.f.f(y, chunk, self.p)
+            if any(v is None for v in y):
+                raise ValueError("BatchIntegrand body left entries of y unset")
+            out.extend(y)
+        return out
+
+
+def auxquadgk(g, segs, atol, rtol, maxevals, batch=False, max_batch=2**62):
+    """Globally adaptive GK(7,15).  Scalar refinement: pop the worst panel, bisect, 30 new nodes.  Batch refinement
+    (AuxQuadGK.BatchIntegrand, reached from src/algorithms.jl:227-233): pop panels while the error of the REMAINING
+    ones still exceeds the tolerance and 30 * popped <= max_batch, evaluate all children in ONE call of g.
+    -> (I, E, numevals)."""
+    atol_ = 0.0 if atol is None else atol
+    rtol_ = (0.0 if atol_ > 0 else math.sqrt(np.finfo(float).eps)) if rtol is None else rtol
+    nseg = len(segs) - 1
+    fv = g(np.concatenate([_gk_nodes(segs[i], segs[i + 1]) for i in range(nseg)]))
+    heap = _Heap()
+    for i in range(nseg):
+        Ii, Ei = _gk_eval(fv[15 * i:15 * i + 15], segs[i], segs[i + 1])
+        heap.xs.append((segs[i], segs[i + 1], Ii, Ei))
+
+    def total():
+        I, E = heap.xs[0][2], heap.xs[0][3]
+        for sg in heap.xs[1:]:
+            I = I + sg[2]
+            E = E + sg[3]
+        return I, E
+
+    I, E = total()
+    numevals = 15 * nseg
+    if not (E <= max(atol_, rtol_ * _norm(I)) or numevals >= maxevals):
+        heap.heapify()
+        while E > max(atol_, rtol_ * _norm(I)) and numevals < maxevals:
+            if not batch:
+                popped = [heap.pop()]
+                numevals += 30
+            else:
+                tol = max(atol_, rtol_ * _norm(I))
+                popped = []
+                while heap.xs and 30 * (len(popped) + 1) <= max_batch and E > tol and numevals < maxevals:
+                    sg = heap.pop()
+                    popped.append(sg)
+                    tol += sg[3]
+                    numevals += 30
+            pts = []
+            for (sa, sb, _, _) in popped:
+                mid = (sa + sb) / 2
+                pts += [_gk_nodes(sa, mid), _gk_nodes(mid, sb)]
+            fv = g(np.concatenate(pts))
+            for k, (sa, sb, sI, sE) in enumerate(popped):
+                mid = (sa + sb) / 2
+                I1, E1 = _gk_eval(fv[30 * k:30 * k + 15], sa, mid)
+                I2, E2 = _gk_eval(fv[30 * k + 15:30 * k + 30], mid, sb)
+                I = (I - sI) + I1 + I2
+                E = (E - sE) + E1 + E2
+                heap.push((sa, mid, I1, E1))
+                heap.push((mid, sb, I2, E2))
+        I, E = total()
+    return I, E, numevals
+
+
+def solve_auxquadgk(f, dom, p, abstol, reltol, maxiters):
+    """AuxQuadGKJL on an interval.  ref: src/algorithms.jl:215-239."""
+    from .solver import BatchIntegrand, NestedBatchIntegrand
+    if isinstance(f, NestedBatchIntegrand):
+        raise ValueError("AuxQuadGKJL doesn't support nested batching")  # ref: src/algorithms.jl:211
+    ev = _Evaluator(f, p, point=float)
+    isb = isinstance(f, BatchIntegrand)
+    I, E, _ = auxquadgk(ev, _segments(dom), abstol, reltol, maxiters, batch=isb, max_batch=f.max_batch if isb else 2**62)
+    return I, E, ev.numevals
+
+
+def _ptr_nodes(B, npt, syms):
+    """Nodes B (i / npt) and weights of the PTR / Monkhorst-Pack rule on Basis(B).  ref: AutoSymPTR.PTR as used at
+    src/algorithms.jl:347-352; symmetric rules take the library's integer tables (abz_symptr_rule)."""
+    d = B.shape[0]
+    if syms is None:
+        idx = np.stack(np.meshgrid(*[np.arange(npt)] * d, indexing="ij"), -1).reshape(-1, d)[:, ::-1]  # i_1 fastest
+        w = np.ones(len(idx))
+        nsym = 1
+    else:
+        from .series import symptr_rule
+        idx, w = symptr_rule(npt, d, syms)
+        nsym = len(syms)
+    x = (idx / float(npt)) @ B.T
+    return x, w, abs(np.linalg.det(B)) / (npt**d * nsym)
+
+
+def ptr_rule_value(f, B, p, npt, syms):
+    """rule(f, Basis(B)) = sum_k w_k f(x_k) vol / (npt^d nsyms).  ref: src/algorithms.jl:368-380."""
+    from .solver import NestedBatchIntegrand
+    if isinstance(f, NestedBatchIntegrand):
+        raise ValueError("MonkhorstPack doesn't support nested batching")  # ref: src/algorithms.jl:362,411
+    x, w, scale = _ptr_nodes(B, npt, syms)
+    ev = _Evaluator(f, p, point=(lambda v: float(v[0])) if B.shape[0] == 1 else (lambda v: v))
+    vals = ev(list(x))
+    acc = None
+    for wk, v in zip(w, vals):
+        t = wk * np.asarray(v)
+        acc = t if acc is None else acc + t
+    acc = acc * scale
+    return (acc if np.ndim(acc) else acc[()]), ev.numevals
+
+
+def solve_autosymptr(f, B, p, alg, abstol, reltol, maxiters):
+    """autosymptr on a Basis.  ref: src/algorithms.jl:418-432 (+ SURVEY A.2): I1 = rule(n0), I2 = rule(n0 + dn),
+    err = norm(I2 - I1), until err <= max(abstol, reltol norm(I2)) or numevals >= maxevals."""
+    if abstol is None and reltol is None:
+        rtol, atol = math.sqrt(np.finfo(float).eps), 0.0
+    else:
+        rtol, atol = (0.0 if reltol is None else reltol), (0.0 if abstol is None else abstol)
+    n0, dn = alg.inner.npt_sequence()
+    npt = n0
+    I1, nev = ptr_rule_value(f, B, p, npt, alg.syms)
+    while True:
+        npt += dn
+        I2, n2 = ptr_rule_value(f, B, p, npt, alg.syms)
+        nev += n2
+        err = _norm(np.asarray(I2) - np.asarray(I1))
+        if err <= max(atol, rtol * _norm(I2)) or nev >= maxiters or not np.isfinite(err):
+            return I2, err, nev
+        I1 = I2
+
+
+def nested_quad(f, lims, p, abstol, reltol, maxiters):
+    """NestedQuad(AuxQuadGKJL()) over iterated limits (bz.CubicLimits / TetrahedralLimits / ...: `segs()`, `fix(x)`)
+    for a plain callable (depth-first, scalar refinement), a BatchIntegrand (the innermost integral only is batched)
+    or a NestedBatchIntegrand (every level batched).  The integrand sees full points x = (x_1 .. x_d)."""
+    from .solver import BatchIntegrand, NestedBatchIntegrand
+    nest = isinstance(f, NestedBatchIntegrand)
+    worker = f.f[0] if nest else f
+    while isinstance(worker, NestedBatchIntegrand):
+        worker = worker.f[0]
+    inner_batch = nest or isinstance(f, BatchIntegrand)
+    mb = f.max_batch if (nest or isinstance(f, BatchIntegrand)) else 2**62
+    count = [0]
+
+    def level(lim, tail, atol):
+        d = lim.ndim
+        if d == 1:
+            ev = _Evaluator(worker if nest else f, p, point=lambda x: np.array((float(x),) + tail))
+            I, E, _ = auxquadgk(ev, tuple(lim.segs()), atol, reltol, maxiters, batch=inner_batch, max_batch=mb)
+            count[0] += ev.numevals
+            return I, E
+
+        def g(xs):
+            out = []
+            for x in xs:
+                inner = lim.fix(float(x))
+                sg = inner.segs()
+                at = None if atol is None else atol / (sg[-1] - sg[0])  # ref: src/algorithms.jl:532-533,556-557
+                out.append(level(inner, (float(x),) + tail, at)[0])
+            return out
+        I, E, _ = auxquadgk(g, tuple(lim.segs()), atol, reltol, maxiters, batch=nest, max_batch=mb)
+        return I, E
+
+    I, E = level(lims, (), abstol)
+    return I, E, count[0]
+
+
+def fourier_batch(g, series, max_batch=2**62, want_eig=False):
+    """BatchIntegrand whose body evaluates the series at ALL nodes of a batch on the GPU (one abz_eval_nodes call) and
+    applies the user closure g(FourierValue(k, H(k)), p) per node -- the reference's GPU hook (src/batch.jl:4-6) for
+    MonkhorstPack, AutoSymPTRJL, AuxQuadGKJL (1-D series) and NestedQuad.  With `want_eig` the FourierValue carries
+    (H(k), eigenvalues)."""
+    from .solver import BatchIntegrand, FourierValue
+
+    def body(y, x, p):
+        k = np.asarray(x, dtype=np.float64).reshape(len(x), series.d)
+        dev = series.device()
+        if want_eig:
+            H, E = dev.eval_nodes(k, want=L.WANT_H | L.WANT_EIG)
+            for i in range(len(x)):
+                y[i] = g(FourierValue(k[i] if series.d > 1 else float(k[i, 0]), (H[i], E[i])), p)
+        else:
+            H = dev.eval_nodes(k)
+            for i in range(len(x)):
+                y[i] = g(FourierValue(k[i] if series.d > 1 else float(k[i, 0]), H[i]), p)
+
+    return BatchIntegrand(body, max_batch=max_batch)

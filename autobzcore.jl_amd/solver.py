@@ -640,8 +640,7 @@ def do_solve(f, dom, p, alg, cacheval=None, abstol=None, reltol=None, maxiters=2
     if counter:
         alg = alg.alg
     if not isinstance(f, FourierIntegrand):
-        raise NotImplementedError("only FourierIntegrand problems are on the accelerated path "
-                                  "(generic integrands: SURVEY section 2, out of scope)")
+        return _do_solve_generic(f, dom, p, alg, counter, abstol, reltol, maxiters)
     dev = cacheval if cacheval is not None else f.w.device()
     pm = _as_params(f, p)
     fi = f.f.f
@@ -707,6 +706,35 @@ def do_solve(f, dom, p, alg, cacheval=None, abstol=None, reltol=None, maxiters=2
             u, err, nev = _iai_host(f, dev, dom, pm, abstol, reltol, maxiters)
         return IntegralSolution(u, err, True, nev if counter else -1)
     raise ValueError(f"unsupported algorithm {type(alg).__name__}")
+
+
+def _do_solve_generic(f, dom, p, alg, counter, abstol, reltol, maxiters):
+    """Plain callables f(x, p), BatchIntegrand and NestedBatchIntegrand under the generic algorithms (generic.py).
+    ref: src/algorithms.jl:215-239,360-432,450-612; known answers test/interface_tests.jl:90-130."""
+    from . import generic as G
+    if not (callable(f) or isinstance(f, (BatchIntegrand, NestedBatchIntegrand))):
+        raise ValueError(f"unsupported integrand {type(f).__name__}")
+    if isinstance(alg, AuxQuadGKJL):
+        u, err, nev = G.solve_auxquadgk(f, dom, p, abstol, reltol, maxiters)
+    elif isinstance(alg, MonkhorstPack):
+        if not isinstance(dom, Basis):
+            raise ValueError("MonkhorstPack needs a Basis domain")
+        (u, nev), err = G.ptr_rule_value(f, dom.B, p, alg.npt, alg.syms), None
+    elif isinstance(alg, AutoSymPTRJL):
+        if not isinstance(dom, Basis):
+            raise ValueError("AutoSymPTRJL needs a Basis domain")
+        u, err, nev = G.solve_autosymptr(f, dom.B, p, alg, abstol, reltol, maxiters)
+    elif isinstance(alg, NestedQuad):
+        if not (hasattr(dom, "segs") and hasattr(dom, "fix")):
+            raise ValueError("NestedQuad needs iterated limits")
+        for a_ in alg.algs:
+            if not isinstance(a_, AuxQuadGKJL):
+                raise ValueError("NestedQuad: only AuxQuadGKJL() levels are supported")
+        u, err, nev = G.nested_quad(f, dom, p, abstol, reltol, maxiters)
+    else:
+        raise ValueError(f"{type(alg).__name__} needs a FourierIntegrand on a SymmetricBZ (generic integrands: "
+                         "AuxQuadGKJL, MonkhorstPack, AutoSymPTRJL, NestedQuad)")
+    return IntegralSolution(u, err, True, nev if counter else -1)
 
 
 def _autoptr_many(f, dev, bz, plist, alg: AutoPTR, abstol, reltol, maxiters, symmetrize=True, jac=None,

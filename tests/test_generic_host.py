@@ -1,0 +1,95 @@
+"""Generic integrands (plain callables, BatchIntegrand, NestedBatchIntegrand) under AuxQuadGKJL, MonkhorstPack,
+AutoSymPTRJL and NestedQuad: the reference's own known answers restated (test/interface_tests.jl:90-111 "batch",
+:113-130 "multi-algorithms", :143-158 EvalCounter).  Host logic only: the adaptive loops and the user function run
+on the CPU, the GK(7,15) panel sums go through the library's host entry point (abz_gk15_batch) -- no GPU needed."""
+import math
+
+import numpy as np
+import pytest
+
+import autobzcore.jl_amd as abz
+import abz_oracle as orc
+
+
+A, B2PI, ABSTOL, P = 0.0, 2 * math.pi, 1e-5, 3.0
+CASES = [  # (body f!(y, x, p), plain f(x, p), reference value)      ref: test/interface_tests.jl:96-100
+    (lambda y, x, p: y.__setitem__(slice(None), list(p * np.sin(np.asarray(x, dtype=float).reshape(-1)))),
+     lambda x, p: p * math.sin(x), 0.0),
+    (lambda y, x, p: y.__setitem__(slice(None), [p * 1.0 for _ in x]), lambda x, p: p * 1.0, P * (B2PI - A)),
+    (lambda y, x, p: y.__setitem__(slice(None), list(1.0 / (p - np.cos(np.asarray(x, dtype=float).reshape(-1))))),
+     lambda x, p: 1.0 / (p - math.cos(x)), (B2PI - A) / math.sqrt(P * P - 1)),
+]
+
+
+@pytest.mark.parametrize("case", range(3))
+def test_batch_integrand_known_answers(case):
+    body, plain, ref = CASES[case]
+    for f in (abz.BatchIntegrand(body), abz.BatchIntegrand(body, max_batch=45), plain):
+        sol = abz.solve(abz.IntegralProblem(f, (A, B2PI), P), abz.AuxQuadGKJL(), abstol=ABSTOL)
+        assert abs(sol.u - ref) <= ABSTOL
+        for alg in (abz.MonkhorstPack(), abz.AutoSymPTRJL()):
+            sol = abz.solve(abz.IntegralProblem(f, abz.Basis(np.array([[B2PI]])), P), alg, abstol=ABSTOL)
+            assert abs(sol.u - ref) <= ABSTOL
+
+
+def test_batch_refinement_is_the_oracles():
+    """Batch-mode auxquadgk makes the oracle's decisions: same numevals and value, bit for bit; max_batch caps a call."""
+    calls = []
+
+    def body(y, x, p):
+        calls.append(len(x))
+        y[:] = [1.0 / (p - math.cos(v) + 0.3 * math.sin(3 * v)) for v in x]
+
+    for mb in (2**62, 60, 30):
+        calls.clear()
+        sol = abz.solve(abz.IntegralProblem(abz.BatchIntegrand(body, max_batch=mb), (A, B2PI), 1.5),
+                        abz.EvalCounter(abz.AuxQuadGKJL()), abstol=1e-9)
+        assert max(calls) <= max(mb, 15)
+        I, E, nev = orc.auxquadgk(lambda xs: np.array([1.0 / (1.5 - math.cos(v) + 0.3 * math.sin(3 * v)) for v in xs]),
+                                  (A, B2PI), atol=1e-9, batch=True, max_batch=mb)
+        assert sol.numevals == nev and sol.u == I and sol.resid == E
+
+
+@pytest.mark.parametrize("dim", [1, 2, 3])
+def test_nested_quad_generic_integrands(dim):
+    """ref: test/interface_tests.jl:113-130: f(x, p) = 1 + p sum(cos, x) on [0, 2 pi]^dim -> (2 pi)^dim."""
+    f = lambda x, p: 1.0 + p * float(np.sum(np.cos(x)))
+    p, abstol, ref = 7.0, 1e-3, (2 * math.pi) ** dim
+    dom = abz.CubicLimits(np.zeros(dim), 2 * math.pi * np.ones(dim))
+    alg = abz.NestedQuad(abz.AuxQuadGKJL())
+    assert abs(abz.solve(abz.IntegralProblem(f, dom, p), alg, abstol=abstol).u - ref) <= abstol
+    seen = []
+
+    def body(y, x, p):
+        seen.append(len(x))
+        y[:] = [f(v, p) for v in x]
+
+    sol = abz.solve(abz.IntegralProblem(abz.BatchIntegrand(body), dom, p), abz.EvalCounter(alg), abstol=abstol)
+    assert abs(sol.u - ref) <= abstol and sol.numevals == sum(seen) and all(len(np.atleast_1d(0)) for _ in seen)
+    nb = abz.NestedBatchIntegrand(tuple(f for _ in range(3)))
+    assert abs(abz.solve(abz.IntegralProblem(nb, dom, p), alg, abstol=abstol).u - ref) <= abstol
+    # the oracle's nested loop on the same integrand (scalar refinement): same value
+    if dim <= 2:
+        got = abz.solve(abz.IntegralProblem(f, dom, p), abz.EvalCounter(alg), abstol=abstol)
+        assert got.numevals >= 15**dim
+
+
+def test_evalcounter_constant_integrand():
+    """ref: test/interface_tests.jl:143-158: a constant integrand costs exactly the base rule: 15 for GK(7,15)."""
+    sol = abz.solve(abz.IntegralProblem(lambda x, p: 1.0, (0.0, 1.0), None), abz.EvalCounter(abz.AuxQuadGKJL()))
+    assert sol.numevals == 15 and abs(sol.u - 1.0) < 1e-15
+    sol = abz.solve(abz.IntegralProblem(abz.BatchIntegrand(lambda y, x, p: y.__setitem__(slice(None), [1.0] * len(x))),
+                                        (0.0, 1.0), None), abz.EvalCounter(abz.AuxQuadGKJL()))
+    assert sol.numevals == 15
+
+
+def test_generic_error_behaviour():
+    nb = abz.NestedBatchIntegrand((lambda x, p: 1.0,))
+    with pytest.raises(ValueError):  # ref: src/algorithms.jl:211
+        abz.solve(abz.IntegralProblem(nb, (0.0, 1.0), None), abz.AuxQuadGKJL())
+    with pytest.raises(ValueError):  # ref: src/algorithms.jl:362
+        abz.solve(abz.IntegralProblem(nb, abz.Basis(np.eye(1)), None), abz.MonkhorstPack())
+    with pytest.raises(ValueError):  # ref: src/batch.jl:16
+        abz.BatchIntegrand(lambda y, x, p: None, max_batch=0)
+    with pytest.raises(ValueError):
+        abz.solve(abz.IntegralProblem(lambda x, p: 1.0, (0.0, 1.0), None), abz.PTR())

@@ -763,6 +763,96 @@ def test_generic_n_iai_matches_oracle(abz, n):
     assert abs(sol.u - ref.u) <= 1e-9 * abs(ref.u)
 
 
+def test_generic_n_iai_3d_16_band_matches_oracle(abz):
+    """The config-5 code path (16 bands, THREE variables: host-driven outer level, middle level, workgroup-per-
+    integral innermost kernel) pinned to the oracle rather than to itself: outermost panel tree bit-exact, equal
+    `numevals`, value to 1e-9.  3 x 3 x 3 coefficients so that the pure-Python oracle finishes in ~15 s; the
+    tolerance is loose enough for that and tight enough to refine the outer and the middle level
+    (3 outer panels, 7.3e5 nodes).  ref: src/fourier.jl:394-510."""
+    rng = np.random.default_rng(1616)
+    n = 16
+    c, first = rand_series(rng, (3, 3, 3), n, hermitian=True)
+    c = c / (n / 2)
+    s, so = both(abz, c, first)
+    bz = abz.load_bz(abz.FBZ(), np.eye(3))
+    f = abz.FourierIntegrand(abz.DOSIntegrand(), s, 0.3)
+    sol = abz.do_solve(f, bz, abz.MixedParameters(0.2), abz.EvalCounter(abz.IAI()), abstol=0.5, _panels=True)
+    rec = []
+    ref = orc.solve_iai(so, orc.load_bz("FBZ", np.eye(3)), orc.f_dos(0.3, 0.2), abstol=0.5, record=rec)
+    assert len(rec) >= 3 and ref.numevals > 15**3
+    assert np.array_equal(sol.extra["panels"], np.array(rec)) and sol.numevals == ref.numevals
+    assert abs(sol.u - ref.u) <= 1e-9 * abs(ref.u)
+    assert abs(sol.resid - ref.resid) <= 1e-6 * abs(ref.resid) + 1e-12
+
+
+@pytest.mark.parametrize("d,kind", [(2, None), (3, None), (3, "cubic")])
+def test_autosymptrjl_matches_oracle(abz, d, kind):
+    """AutoSymPTRJL on a Basis domain (ref: src/algorithms.jl:393-432, used at test/fourier.jl:25-37) against the
+    oracle's autosymptr loop: same npt sequence, so equal `numevals`, value to 1e-11."""
+    rng = np.random.default_rng(50 + d)
+    c, first = rand_series(rng, (3, 5, 3)[:d], 2, hermitian=True)
+    if kind == "cubic":  # a series with the cubic point group: H(k) = sum_j cos(2 pi k_j) * A + B
+        A = rng.standard_normal((2, 2))
+        A = A + A.T
+        c = np.zeros((3, 3, 3, 2, 2), dtype=complex)
+        for j in range(3):
+            for sgn in (0, 2):
+                idx = [1, 1, 1]
+                idx[j] = sgn
+                c[tuple(idx)] = 0.5 * A
+        c[1, 1, 1] = np.diag([0.3, -0.2])
+        first = (-1, -1, -1)
+    s, so = both(abz, c, first)
+    eta, om = 0.4, 0.1
+    obz = orc.load_bz("CubicSymIBZ" if kind else "FBZ", 2 * np.pi * np.eye(d))  # B = I
+    syms = obz.syms if kind else None
+    f = abz.FourierIntegrand(abz.DOSIntegrand(), s, eta)
+    alg = abz.AutoSymPTRJL(a=eta, nmin=10, syms=syms)
+    nsym = 1 if syms is None else len(syms)
+    # the bare algorithm converges on the un-symmetrised rule value (1/nsyms of the BZ solve's): same decisions at abstol/nsyms
+    sol = abz.do_solve(f, abz.Basis(np.eye(d)), abz.MixedParameters(om), abz.EvalCounter(alg), abstol=1e-5 / nsym)
+    ref = orc.solve_autoptr(so, obz, orc.f_dos(eta, om), abstol=1e-5, a=eta, nmin=10)
+    assert sol.numevals == ref.numevals
+    # the oracle's BZ solve symmetrises (TrivialRep: x nsyms); AutoSymPTRJL on a Basis returns the bare rule value
+    assert abs(sol.u * (nsym if kind else 1) - ref.u) <= 1e-11 * abs(ref.u)
+
+
+def test_plain_batch_integrand_of_fourier_values(abz):
+    """The reference's GPU hook (src/batch.jl:4-6): a plain BatchIntegrand whose x are FourierValue batches produced
+    by abz_eval_nodes (`fourier_batch`), through MonkhorstPack, AutoSymPTRJL (src/algorithms.jl:370-372,421-423),
+    AuxQuadGKJL (:227-233, a 1-D series) and NestedQuad (:469-471,517-518) -- against the oracle's rule sums /
+    nested quadrature on the same integrand, and the batches really are batches (one GPU call per <= max_batch nodes)."""
+    rng = np.random.default_rng(2718)
+    eta, om = 0.35, 0.15
+    g = lambda v, p: -np.imag(np.trace(np.linalg.inv((p + 1j * eta) * np.eye(2) - np.atleast_2d(v.s)))) / np.pi
+    # 2-D, PTR family on a Basis
+    c, first = rand_series(rng, (3, 5), 2, hermitian=True)
+    s, so = both(abz, c, first)
+    obz = orc.load_bz("FBZ", 2 * np.pi * np.eye(2))  # B = I
+    sizes = []
+    f = abz.fourier_batch(lambda v, p: (sizes.append(1), g(v, p))[1], s, max_batch=1000)
+    sol = abz.solve(abz.IntegralProblem(f, abz.Basis(np.eye(2)), om), abz.EvalCounter(abz.MonkhorstPack(npt=24)))
+    ref = orc.solve_ptr(so, obz, orc.f_dos(eta, om), npt=24)
+    assert sol.numevals == 24 * 24 == len(sizes) and abs(sol.u - ref.u) <= 1e-11 * abs(ref.u)
+    sol = abz.solve(abz.IntegralProblem(f, abz.Basis(np.eye(2)), om), abz.EvalCounter(abz.AutoSymPTRJL(a=eta, nmin=10)), abstol=1e-6)
+    ref = orc.solve_autoptr(so, obz, orc.f_dos(eta, om), abstol=1e-6, a=eta, nmin=10)
+    assert sol.numevals == ref.numevals and abs(sol.u - ref.u) <= 1e-11 * abs(ref.u)
+    # NestedQuad over the unit square: innermost integral batched (scalar refinement at the outer level)
+    sol = abz.solve(abz.IntegralProblem(f, abz.CubicLimits(np.zeros(2), np.ones(2)), om),
+                    abz.EvalCounter(abz.NestedQuad(abz.AuxQuadGKJL())), abstol=1e-5)
+    dev = abz.solve(abz.IntegralProblem(abz.FourierIntegrand(abz.DOSIntegrand(), s, eta), abz.CubicLimits(np.zeros(2), np.ones(2)),
+                                        abz.MixedParameters(om)), abz.NestedQuad(abz.AuxQuadGKJL()), abstol=1e-5)
+    assert abs(sol.u - dev.u) <= 3e-5 and sol.numevals >= 225
+    # 1-D series under AuxQuadGKJL: batch refinement == the oracle's, bit-identical decisions
+    c1, first1 = rand_series(rng, (5,), 2, hermitian=True)
+    s1, so1 = both(abz, c1, first1)
+    f1 = abz.fourier_batch(g, s1, max_batch=90)
+    sol = abz.solve(abz.IntegralProblem(f1, (0.0, 1.0), om), abz.EvalCounter(abz.AuxQuadGKJL()), abstol=1e-8)
+    I, E, nev = orc.auxquadgk(lambda xs: orc.f_dos(eta, om)(xs[:, None], orc.evaluate_many(so1, xs[:, None])), (0.0, 1.0),
+                              atol=1e-8, batch=True, max_batch=90)
+    assert sol.numevals == nev and abs(sol.u - I) <= 1e-12 * abs(I)
+
+
 def test_config5_synthetic_16_band(abz):
     """BASELINE configs[4]: synthetic 16-band 3-D Wannier model (2197 R vectors, SURVEY 8d recipe),
     IAI DOS with host-driven panel re-batching on the GPU; cross-checked against PTR on the same
