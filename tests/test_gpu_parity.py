@@ -1060,6 +1060,76 @@ def test_ggr_cache_invalidation(abz):
     assert abs(sol2 / 2 - sol3) < 1e-12
 
 
+def test_coefficient_update_refreshes_cached_rules_and_handles_stay_safe(abz):
+    """A cached PTR rule follows `update()` / `invalidate()` (the reference rebuilds its rule from the current series on
+    every solve, src/interfaces.jl:174-179): PTR, AutoPTR and GGR values after the update equal the oracle's on the new
+    coefficients.  Handles retained across an invalidation stay valid (two DOS caches on one series, a user-held rule),
+    closed handles raise instead of passing freed pointers, and the C destroy calls may come in any order."""
+    rng = np.random.default_rng(99)
+    c, first = rand_series(rng, (3, 3, 3), 3, hermitian=True)
+    s, so = both(abz, c, first)
+    bz, obz = abz.load_bz(abz.CubicSymIBZ(), np.eye(3)), orc.load_bz("CubicSymIBZ", np.eye(3))
+    eta, om = 0.3, 0.2
+    solver = abz.IntegralSolver(abz.FourierIntegrand(abz.DOSIntegrand(), s, eta), bz, abz.PTR(npt=12))
+    u0 = solver(om)
+    assert abs(u0 - orc.solve_ptr(so, obz, orc.f_dos(eta, om), npt=12).u) <= 1e-10 * abs(u0)
+    held = s.device().rule(12, bz.syms, abz._lib.WANT_H)  # a user-held handle to the cached rule
+    c2 = 0.5 * c
+    c2[1, 1, 1] += np.diag([0.4, -0.1, 0.2])
+    s.device().update(c2)
+    so2 = orc.FourierSeries(c2, period=1.0, first=first, ndim=3)
+    u1 = solver(om)
+    ref1 = orc.solve_ptr(so2, obz, orc.f_dos(eta, om), npt=12).u
+    assert abs(u1 - ref1) <= 1e-10 * abs(ref1) and abs(u1 - u0) > 1e-3 * abs(u0)
+    assert abs(held.reduce(abz._lib.F_DOS, [eta], [om], nsyms=48)[0, 0].real * 48 * abs(np.linalg.det(bz.B)) - ref1) <= 1e-10 * abs(ref1)
+    # a non-Hermitian update flips the rule's Hermitian flag with the refill
+    c3 = c2.copy()
+    c3[0, 0, 0, 0, 1] += 0.3
+    s.device().update(c3)
+    so3 = orc.FourierSeries(c3, period=1.0, first=first, ndim=3)
+    fbz, ofbz = abz.load_bz(abz.FBZ(), np.eye(3)), orc.load_bz("FBZ", np.eye(3))
+    sol = abz.IntegralSolver(abz.FourierIntegrand(abz.TrGlocIntegrand(), s, eta), fbz, abz.PTR(npt=8))
+    refg = orc.solve_ptr(so3, ofbz, orc.f_trgloc(eta, om) if hasattr(orc, "f_trgloc") else (lambda x, v: np.trace(
+        np.linalg.inv((om + 1j * eta) * np.eye(3) - v), axis1=1, axis2=2)), npt=8).u
+    assert abs(sol(om) - refg) <= 1e-10 * abs(refg)
+    # two DOS caches on the same series: re-initialising one must not free what the other holds
+    h = abz.FourierSeries(c, period=1.0, first=first, ndim=3)
+    ca = abz.dos.init(abz.DOSProblem(h, 0.1, fbz), abz.GGR(npt=10))
+    cb = abz.dos.init(abz.DOSProblem(h, 0.1, fbz), abz.GGR(npt=10))
+    ua = abz.dos.solve_(ca).u
+    h.c *= 2
+    cb.isfresh = True
+    cb.domain = 0.2
+    ub = abz.dos.solve_(cb).u
+    ca.domain = 0.2
+    assert abs(abz.dos.solve_(ca).u - ub) <= 1e-12 * abs(ub) and abs(ub - ua / 2) <= 1e-9 * abs(ua)
+    # closed handles raise
+    r = abz.DeviceRule(h.device(), 6, None, 1)
+    r.close()
+    with pytest.raises(abz.AbzError):
+        r.reduce(abz._lib.F_DOS, [eta], [om])
+    # C ABI: destroy in "finalizer order" (context first, then series, then rule); the rule still works in between
+    import ctypes as C
+    L = abz._lib
+    lib = L.lib()
+    ctx, ser, rule = C.c_void_p(), C.c_void_p(), C.c_void_p()
+    L.check(lib.abz_ctx_create(0, C.byref(ctx)))
+    coef = np.ascontiguousarray(abz.series.julia_coefficient_order(c, 3).view(np.float64))
+    dims, frst, per = np.array([3, 3, 3], dtype=np.int32), np.array(first, dtype=np.int32), np.ones(3)
+    L.check(lib.abz_series_create(ctx, coef.ctypes.data_as(L.c_f64p), 3, dims.ctypes.data_as(L.c_i32p),
+                                  frst.ctypes.data_as(L.c_i32p), per.ctypes.data_as(L.c_f64p), 3, C.byref(ser)))
+    L.check(lib.abz_ptr_rule_build(ser, 6, 0, None, None, 1, C.byref(rule)))
+    out = np.zeros((1, 1, 2))
+    sw = np.array([om])
+    par = np.array([eta])
+    L.check(lib.abz_rule_reduce(rule, L.F_DOS, par.ctypes.data_as(L.c_f64p), 1, sw.ctypes.data_as(L.c_f64p), 1, 1, out.ctypes.data_as(L.c_f64p)))
+    v0 = out[0, 0, 0]
+    assert lib.abz_ctx_destroy(ctx) == 0 and lib.abz_series_destroy(ser) == 0
+    assert lib.abz_rule_reduce(rule, L.F_DOS, par.ctypes.data_as(L.c_f64p), 1, sw.ctypes.data_as(L.c_f64p), 1, 1,
+                               out.ctypes.data_as(L.c_f64p)) == L.ERR_ARG  # closed owner: an error, not a fault
+    assert lib.abz_rule_destroy(rule) == 0 and v0 > 0
+
+
 # ------------------------------------------------------------------ errors
 def test_error_behaviour(abz):
     s = abz.FourierSeries(np.zeros((3, 3)), first=-1, ndim=2)
