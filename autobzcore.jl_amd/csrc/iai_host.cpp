@@ -34,7 +34,13 @@ void gk15_evalrule(const cd* fv, int ncomp, double a, double b, cd* I, double* E
 
 struct Seg {
     double a, b, E;
-    int64_t ioff;  // offset of I[ncomp] in the owner's value store
+    int64_t ioff;     // offset of I[ncomp] in the owner's value store
+    int64_t nev = 0;  // integrand evaluations beneath this panel (counted when the panel enters the integral)
+    // The two halves of the panel, evaluated AHEAD of the pop that consumes them (see solve_level):
+    // 0 = not requested, 1 = in flight, 2 = ready.
+    int state = 0;
+    double E1 = 0.0, E2 = 0.0;
+    int64_t ioff1 = 0, ioff2 = 0, nev1 = 0, nev2 = 0;
 };
 
 // Break points of a polytope along one coordinate: the distinct vertex coordinates (sqrt(eps)
@@ -204,10 +210,14 @@ struct Quad1D {
     std::vector<cd> store;  // segment integrals, ncomp each
     std::vector<cd> I;
     double E = 0.0;
-    int64_t numevals = 0;
+    int64_t numevals = 0;  // nodes of THIS integral (what QuadGK's maxevals counts)
+    int64_t fevals = 0;    // integrand evaluations of the whole subtree (EvalCounter)
     bool done = false, started = false;
-    // pending work of the current round: panels to evaluate, and the parents they replace
+    // pending work of the current round: panels to evaluate, and the parents they belong to --
+    // heap positions of panels whose halves were requested ahead of their pop (scalar refinement), or the
+    // panels popped together by the BatchIntegrand refinement rule
     std::vector<Seg> pend;
+    std::vector<uint32_t> req;
     std::vector<Seg> popped;
 };
 
@@ -266,9 +276,10 @@ struct IaiDriver {
     double rtol_user;
     int64_t maxevals;
     int64_t max_batch = 0;  // 0: scalar refinement; > 0: BatchIntegrand refinement with this soft cap
-    int64_t total_evals = 0;
     bool panels15 = true;  // eval_nodes is fed whole GK panels (solve_level); the node-list ABI entry clears it
-    std::vector<int64_t> evals_per_root;
+    bool speculate = true;  // request the halves of every panel that is certain to be popped (solve_level)
+    int64_t pool_cap_bytes = (int64_t)4 << 30;  // contracted sets alive at once per level (ABZ_IAI_POOL_MB)
+    int64_t launches = 0;   // innermost launches of this solve (diagnostics)
     std::vector<int64_t> h_parents;
     std::vector<double> h_x, h_tail, h_sweep;
     std::vector<cd> h_values;
@@ -281,11 +292,11 @@ struct IaiDriver {
 
     bool device_inner = false;  // innermost adaptive loops on the GPU (scalar refinement, n <= 4)
 
-    int contract_nodes(int L, int64_t nn, int64_t base_slot);
+    int contract_nodes(int L, int64_t nn, int64_t base_slot, int64_t off = 0);
     int eval_nodes(int64_t nn);
     int solve_level(int L, std::vector<Quad1D>& quads);
-    int solve_inner_device(std::vector<Quad1D>& kids);
-    int solve_inner_device_flat(int64_t nq, std::vector<cd>& vals);
+    int solve_inner_device_flat(int64_t nq, cd* vals, int64_t* nev);
+    std::vector<uint32_t> node_q;  // owner (index into the level's integrals) of every node of a round
     // structure-of-arrays description of the innermost integrals of a round (no per-integral objects)
     std::vector<int64_t> f_slot;
     std::vector<int> f_root;
@@ -294,7 +305,7 @@ struct IaiDriver {
 };
 
 // upload h_parents/h_x, contract level-L sets into level-(L-1) pool slots base_slot..base_slot+nn-1
-int IaiDriver::contract_nodes(int L, int64_t nn, int64_t base_slot) {
+int IaiDriver::contract_nodes(int L, int64_t nn, int64_t base_slot, int64_t off) {
     const int M = s->dims[L - 1];
     const int64_t Lrow = s->elems(L - 1);
     int rc;
@@ -302,9 +313,9 @@ int IaiDriver::contract_nodes(int L, int64_t nn, int64_t base_slot) {
     if ((rc = s->iai_io[1].reserve(sizeof(double) * (size_t)nn))) return rc;
     if ((rc = s->iai_io[4].reserve(sizeof(double2) * (size_t)(nn * M)))) return rc;
     if ((rc = s->iai_pool[L - 1].reserve(sizeof(double2) * (size_t)((base_slot + nn) * Lrow)))) return rc;
-    ABZ_HIP(hipMemcpyAsync(s->iai_io[0].p, h_parents.data(), sizeof(int64_t) * (size_t)nn, hipMemcpyHostToDevice,
+    ABZ_HIP(hipMemcpyAsync(s->iai_io[0].p, h_parents.data() + off, sizeof(int64_t) * (size_t)nn, hipMemcpyHostToDevice,
                            ctx->stream));
-    ABZ_HIP(hipMemcpyAsync(s->iai_io[1].p, h_x.data(), sizeof(double) * (size_t)nn, hipMemcpyHostToDevice, ctx->stream));
+    ABZ_HIP(hipMemcpyAsync(s->iai_io[1].p, h_x.data() + off, sizeof(double) * (size_t)nn, hipMemcpyHostToDevice, ctx->stream));
     PhaseSpec ps;
     ps.B = nn;
     ps.M = M;
@@ -360,7 +371,7 @@ int IaiDriver::eval_nodes(int64_t nn) {
     ABZ_HIP(hipMemcpyAsync(h_values.data(), s->iai_io[3].p, sizeof(double2) * (size_t)(nn * ncomp),
                            hipMemcpyDeviceToHost, ctx->stream));
     ABZ_HIP(hipStreamSynchronize(ctx->stream));
-    total_evals += nn;
+    launches += 1;
     return ABZ_OK;
 }
 
@@ -368,9 +379,9 @@ int IaiDriver::eval_nodes(int64_t nn) {
 // (inner_adaptive_kernel); an integral that overflows the device segment store is redone on the host.
 // The same from structure-of-arrays input (f_slot, f_lo, ...), results straight into vals [nq][ncomp]:
 // a 432-solve sweep creates ~35 M innermost integrals, one heap-backed Quad1D each cost 4/5 of its time.
-int IaiDriver::solve_inner_device_flat(int64_t nq, std::vector<cd>& vals) {
-    vals.resize((size_t)(nq * ncomp));
+int IaiDriver::solve_inner_device_flat(int64_t nq, cd* vals, int64_t* nev) {
     if (nq == 0) return ABZ_OK;
+    launches += 1;
     const bool need_tail = integrand == ABZ_F_LINEAR_X && d > 1;
     int rc;
     const size_t in_bytes = sizeof(int64_t) * (size_t)nq + sizeof(double) * (size_t)nq * 4;
@@ -429,7 +440,7 @@ int IaiDriver::solve_inner_device_flat(int64_t nq, std::vector<cd>& vals) {
     const double* hE = reinterpret_cast<const double*>(f_out.data() + sizeof(double2) * (size_t)(nq * ncomp));
     const int64_t* hN = reinterpret_cast<const int64_t*>(hE + nq);
     const int* hS = reinterpret_cast<const int*>(hN + nq);
-    std::memcpy(vals.data(), hI, sizeof(cd) * (size_t)(nq * ncomp));
+    std::memcpy(vals, hI, sizeof(cd) * (size_t)(nq * ncomp));
     std::vector<Quad1D> redo;
     std::vector<int64_t> redo_idx;
     for (int64_t i = 0; i < nq; ++i) {
@@ -450,132 +461,41 @@ int IaiDriver::solve_inner_device_flat(int64_t nq, std::vector<cd>& vals) {
             redo_idx.push_back(i);
             continue;
         }
-        total_evals += hN[i];
-        evals_per_root[(size_t)f_root[(size_t)i]] += hN[i];
+        nev[i] = hN[i];
     }
     if (!redo.empty()) {
         const bool keep = device_inner;
         device_inner = false;
+        // the host loop below reuses the round's staging vectors: keep this chunk's description
+        std::vector<int64_t> keep_par = h_parents;
+        std::vector<double> keep_x = h_x;
         rc = solve_level(1, redo);
+        h_parents.swap(keep_par);
+        h_x.swap(keep_x);
         device_inner = keep;
         if (rc) return rc;
-        for (size_t j = 0; j < redo.size(); ++j)
+        for (size_t j = 0; j < redo.size(); ++j) {
             for (int c = 0; c < ncomp; ++c) vals[(size_t)(redo_idx[j] * ncomp + c)] = redo[j].I[(size_t)c];
-    }
-    return ABZ_OK;
-}
-
-int IaiDriver::solve_inner_device(std::vector<Quad1D>& kids) {
-    const int64_t nq = (int64_t)kids.size();
-    if (nq == 0) return ABZ_OK;
-    std::vector<int64_t> slot((size_t)nq);
-    std::vector<double> lo((size_t)nq), hi((size_t)nq), at((size_t)nq), sw((size_t)nq), tl;
-    const bool need_tail = integrand == ABZ_F_LINEAR_X && d > 1;
-    if (need_tail) tl.resize((size_t)(nq * (d - 1)));
-    for (int64_t i = 0; i < nq; ++i) {
-        const Quad1D& k = kids[(size_t)i];
-        slot[(size_t)i] = k.slot;
-        if (!k.lims.range(1, lo[(size_t)i], hi[(size_t)i])) {
-            std::vector<double> sg;
-            k.lims.segs(1, sg);
-            lo[(size_t)i] = sg.front();
-            hi[(size_t)i] = sg.back();  // the innermost slice of a convex domain is one interval
+            nev[redo_idx[j]] = redo[j].fevals;
         }
-        at[(size_t)i] = k.has_atol ? k.atol : -1.0;
-        sw[(size_t)i] = k.sweep;
-        if (need_tail)
-            for (int j = 0; j < d - 1; ++j) tl[(size_t)(i * (d - 1) + j)] = k.tail[j];
-    }
-    // device staging: [slot | lo | hi | atol | tail] in iai_io[0..2], outputs in iai_io[3], iai_io[5]
-    int rc;
-    const size_t in_bytes = sizeof(int64_t) * (size_t)nq + sizeof(double) * (size_t)nq * 4;
-    if ((rc = s->iai_io[0].reserve(in_bytes))) return rc;
-    char* base = static_cast<char*>(s->iai_io[0].p);
-    int64_t* d_slot = reinterpret_cast<int64_t*>(base);
-    double* d_lo = reinterpret_cast<double*>(base + sizeof(int64_t) * (size_t)nq);
-    double* d_hi = d_lo + nq;
-    double* d_at = d_hi + nq;
-    double* d_sw = d_at + nq;
-    ABZ_HIP(hipMemcpyAsync(d_sw, sw.data(), sizeof(double) * (size_t)nq, hipMemcpyHostToDevice, ctx->stream));
-    ABZ_HIP(hipMemcpyAsync(d_slot, slot.data(), sizeof(int64_t) * (size_t)nq, hipMemcpyHostToDevice, ctx->stream));
-    ABZ_HIP(hipMemcpyAsync(d_lo, lo.data(), sizeof(double) * (size_t)nq, hipMemcpyHostToDevice, ctx->stream));
-    ABZ_HIP(hipMemcpyAsync(d_hi, hi.data(), sizeof(double) * (size_t)nq, hipMemcpyHostToDevice, ctx->stream));
-    ABZ_HIP(hipMemcpyAsync(d_at, at.data(), sizeof(double) * (size_t)nq, hipMemcpyHostToDevice, ctx->stream));
-    double* d_tail = nullptr;
-    if (need_tail) {
-        if ((rc = s->iai_io[2].reserve(sizeof(double) * tl.size()))) return rc;
-        d_tail = s->iai_io[2].as<double>();
-        ABZ_HIP(hipMemcpyAsync(d_tail, tl.data(), sizeof(double) * tl.size(), hipMemcpyHostToDevice, ctx->stream));
-    }
-    const size_t out_bytes = sizeof(double2) * (size_t)(nq * ncomp) + sizeof(double) * (size_t)nq + sizeof(int64_t) * (size_t)nq +
-                             sizeof(int) * (size_t)nq;
-    if ((rc = s->iai_io[3].reserve(out_bytes))) return rc;
-    char* ob = static_cast<char*>(s->iai_io[3].p);
-    double2* d_I = reinterpret_cast<double2*>(ob);
-    double* d_E = reinterpret_cast<double*>(ob + sizeof(double2) * (size_t)(nq * ncomp));
-    int64_t* d_nev = reinterpret_cast<int64_t*>(d_E + nq);
-    int* d_st = reinterpret_cast<int*>(d_nev + nq);
-    InnerSpec is;
-    is.n = n;
-    is.d = d;
-    is.M = s->dims[0];
-    is.first = s->first[0];
-    is.period = s->period[0];
-    is.src = (d == 1) ? s->coef : s->iai_pool[1].as<double2>();
-    is.nint = nq;
-    is.slot = d_slot;
-    is.lo = d_lo;
-    is.hi = d_hi;
-    is.atol = d_at;
-    is.tail = d_tail;
-    is.integrand = integrand;
-    for (int i = 0; i < 4; ++i) is.params[i] = params[i];
-    is.sweep = sweep;
-    is.sweep_arr = d_sw;
-    is.herm = s->hermitian;
-    is.has_rtol = has_rtol;
-    is.rtol_user = rtol_user;
-    is.maxevals = maxevals;
-    is.I_out = d_I;
-    is.E_out = d_E;
-    is.nev_out = d_nev;
-    is.status_out = d_st;
-    if ((rc = (n > 4 ? launch_gen_inner_adaptive(ctx, is) : launch_inner_adaptive(ctx, is)))) return rc;
-    std::vector<char> hb(out_bytes);
-    ABZ_HIP(hipMemcpyAsync(hb.data(), ob, out_bytes, hipMemcpyDeviceToHost, ctx->stream));
-    ABZ_HIP(hipStreamSynchronize(ctx->stream));
-    const cd* hI = reinterpret_cast<const cd*>(hb.data());
-    const double* hE = reinterpret_cast<const double*>(hb.data() + sizeof(double2) * (size_t)(nq * ncomp));
-    const int64_t* hN = reinterpret_cast<const int64_t*>(hE + nq);
-    const int* hS = reinterpret_cast<const int*>(hN + nq);
-    std::vector<Quad1D> redo;
-    std::vector<int64_t> redo_idx;
-    for (int64_t i = 0; i < nq; ++i) {
-        Quad1D& k = kids[(size_t)i];
-        if (hS[i] != 0) {
-            redo.push_back(k);
-            redo_idx.push_back(i);
-            continue;
-        }
-        k.I.assign(hI + (size_t)i * ncomp, hI + (size_t)(i + 1) * ncomp);
-        k.E = hE[i];
-        k.numevals = hN[i];
-        k.done = true;
-        total_evals += hN[i];
-        evals_per_root[(size_t)k.root] += hN[i];
-    }
-    if (!redo.empty()) {
-        const bool keep = device_inner;
-        device_inner = false;
-        rc = solve_level(1, redo);
-        device_inner = keep;
-        if (rc) return rc;
-        for (size_t j = 0; j < redo.size(); ++j) kids[(size_t)redo_idx[j]] = redo[j];
     }
     return ABZ_OK;
 }
 
 // Run every integral of `quads` (all integrate variable L) to completion.
+//
+// Refinement is QuadGK's scalar rule -- pop the panel with the largest error, bisect it, replace it by its halves --
+// and every integral applies its pops strictly in that order, so values, errors, panel trees and evaluation counts are
+// those of the depth-first reference.  What is NOT serialised is the evaluation of the halves: with a fixed tolerance
+// (reltol = 0) a panel k is certain to be popped before the loop can stop as soon as the errors of the panels that
+// will still be in the heap when k reaches its top -- k itself and every panel with a smaller error -- add up to more
+// than the tolerance (error estimates are non-negative, so E_tot >= that sum > tol at that moment).  Every round
+// therefore requests the halves of ALL such panels at once, for all sibling integrals, and replays the pops as their
+// halves arrive.  A sweep of rounds is then as deep as the panel tree (tens) instead of as long as the pop sequence
+// (10^5 for config 5 at abstol 1e-3, each with a host round trip), and a round carries 10^4..10^6 innermost integrals
+// instead of ~100.  Contracted coefficient sets of a round are produced and consumed in chunks of `pool_cap_bytes`.
+// With a relative tolerance in play, or a finite maxevals, only the top panel is requested (the round-1 behaviour);
+// the BatchIntegrand refinement rule (max_batch > 0) pops its panels together as before.
 int IaiDriver::solve_level(int L, std::vector<Quad1D>& quads) {
     std::vector<size_t> active;
     for (size_t i = 0; i < quads.size(); ++i) {
@@ -590,13 +510,22 @@ int IaiDriver::solve_level(int L, std::vector<Quad1D>& quads) {
             for (size_t k = 0; k + 1 < sg.size(); ++k) q.pend.push_back(Seg{sg[k], sg[k + 1], 0.0, 0});
         }
         q.popped.clear();
+        q.req.clear();
+        q.heap.clear();
+        q.store.clear();
         q.started = false;
         q.done = false;
+        q.numevals = 0;
+        q.fevals = 0;
         q.I.assign((size_t)ncomp, cd(0, 0));
         active.push_back(i);
     }
-    std::vector<cd> vals;      // [node][ncomp] of this round
-    std::vector<Quad1D> kids;  // inner integrals of this round (L > 1)
+    const bool unlimited = maxevals >= ((int64_t)1 << 62);
+    std::vector<cd> vals;        // [node][ncomp] of this round
+    std::vector<int64_t> nev;    // [node]: integrand evaluations beneath the node
+    std::vector<Quad1D> kids;    // inner integrals of a chunk (L - 1 > 1, or host-side innermost loops)
+    std::vector<uint32_t> order;
+    std::vector<double> suffix;
     double xs15[15];
     while (!active.empty()) {
         // ---- gather the nodes of all pending panels
@@ -604,6 +533,7 @@ int IaiDriver::solve_level(int L, std::vector<Quad1D>& quads) {
         for (size_t qi : active) nn += 15 * (int64_t)quads[qi].pend.size();
         h_parents.resize((size_t)nn);
         h_x.resize((size_t)nn);
+        node_q.resize((size_t)nn);
         if (L == 1) h_sweep.resize((size_t)nn);
         if (d > 1) h_tail.resize((size_t)(nn * (d - 1)));
         int64_t t = 0;
@@ -614,72 +544,73 @@ int IaiDriver::solve_level(int L, std::vector<Quad1D>& quads) {
                 for (int i = 0; i < 15; ++i, ++t) {
                     h_parents[(size_t)t] = q.slot;
                     h_x[(size_t)t] = xs15[i];
+                    node_q[(size_t)t] = (uint32_t)qi;
                     if (L == 1) h_sweep[(size_t)t] = q.sweep;
                     if (d > 1 && L == 1)
                         for (int j = 0; j < d - 1; ++j) h_tail[(size_t)(t * (d - 1) + j)] = q.tail[j];
                 }
-                if (L == 1) evals_per_root[(size_t)q.root] += 15;
             }
         }
+        vals.resize((size_t)(nn * ncomp));
+        nev.resize((size_t)nn);
         // ---- evaluate them
         if (L == 1) {
             int rc = eval_nodes(nn);
             if (rc) return rc;
-            vals.assign(h_values.begin(), h_values.end());
+            std::copy(h_values.begin(), h_values.begin() + (size_t)(nn * ncomp), vals.begin());
+            std::fill(nev.begin(), nev.end(), (int64_t)1);
         } else {
-            s->iai_used[L - 1] = 0;  // sets of the previous round are dead
-            int rc = contract_nodes(L, nn, 0);
-            if (rc) return rc;
+            // chunks: the level-(L-1) sets of a chunk are contracted, integrated over and then overwritten
+            const int64_t set_bytes = (int64_t)sizeof(double2) * s->elems(L - 1);
+            int64_t chunk = std::max<int64_t>(15, (pool_cap_bytes / std::max<int64_t>(set_bytes, 1)) / 15 * 15);
             const bool flat = (L - 1 == 1) && device_inner;
-            if (flat) {
-                // innermost integrals as plain arrays (see solve_inner_device_flat)
-                const bool need_tail = integrand == ABZ_F_LINEAR_X && d > 1;
-                f_slot.resize((size_t)nn);
-                f_root.resize((size_t)nn);
-                f_lo.resize((size_t)nn);
-                f_hi.resize((size_t)nn);
-                f_at.resize((size_t)nn);
-                f_sw.resize((size_t)nn);
-                if (need_tail) f_tl.resize((size_t)(nn * (d - 1)));
-                t = 0;
-                for (size_t qi : active) {
-                    Quad1D& q = quads[qi];
-                    for (size_t p = 0; p < q.pend.size(); ++p) {
-                        for (int i = 0; i < 15; ++i, ++t) {
-                            const double x = h_x[(size_t)t];
-                            const Lims kl = q.lims.fix(L, x);
-                            double lo1, hi1;
-                            if (!kl.range(1, lo1, hi1)) {
-                                std::vector<double> sg;
-                                kl.segs(1, sg);
-                                lo1 = sg.front();
-                                hi1 = sg.back();  // the innermost slice of a convex domain is one interval
-                            }
-                            f_slot[(size_t)t] = t;
-                            f_root[(size_t)t] = q.root;
-                            f_sw[(size_t)t] = q.sweep;
-                            f_lo[(size_t)t] = lo1;
-                            f_hi[(size_t)t] = hi1;
-                            f_at[(size_t)t] = q.has_atol ? q.atol / (hi1 - lo1) : -1.0;  // ref src/fourier.jl:479-480
-                            if (need_tail) {
-                                f_tl[(size_t)(t * (d - 1))] = x;
-                                for (int j = 1; j < d - 1; ++j) f_tl[(size_t)(t * (d - 1) + j)] = q.tail[j - 1];
-                            }
+            const bool need_tail = integrand == ABZ_F_LINEAR_X && d > 1;
+            for (int64_t c0 = 0; c0 < nn; c0 += chunk) {
+                const int64_t cn = std::min(chunk, nn - c0);
+                s->iai_used[L - 1] = 0;  // sets of the previous chunk are dead
+                // parents index THIS level's sets, which stay put for the whole round; the new sets are chunk-local
+                int rc = contract_nodes(L, cn, 0, c0);
+                if (rc) return rc;
+                if (flat) {
+                    // innermost integrals as plain arrays (see solve_inner_device_flat)
+                    f_slot.resize((size_t)cn);
+                    f_root.resize((size_t)cn);
+                    f_lo.resize((size_t)cn);
+                    f_hi.resize((size_t)cn);
+                    f_at.resize((size_t)cn);
+                    f_sw.resize((size_t)cn);
+                    if (need_tail) f_tl.resize((size_t)(cn * (d - 1)));
+                    for (int64_t u = 0; u < cn; ++u) {
+                        const Quad1D& q = quads[node_q[(size_t)(c0 + u)]];
+                        const double x = h_x[(size_t)(c0 + u)];
+                        const Lims kl = q.lims.fix(L, x);
+                        double lo1, hi1;
+                        if (!kl.range(1, lo1, hi1)) {
+                            std::vector<double> sg;
+                            kl.segs(1, sg);
+                            lo1 = sg.front();
+                            hi1 = sg.back();  // the innermost slice of a convex domain is one interval
+                        }
+                        f_slot[(size_t)u] = u;
+                        f_root[(size_t)u] = q.root;
+                        f_sw[(size_t)u] = q.sweep;
+                        f_lo[(size_t)u] = lo1;
+                        f_hi[(size_t)u] = hi1;
+                        f_at[(size_t)u] = q.has_atol ? q.atol / (hi1 - lo1) : -1.0;  // ref src/fourier.jl:479-480
+                        if (need_tail) {
+                            f_tl[(size_t)(u * (d - 1))] = x;
+                            for (int j = 1; j < d - 1; ++j) f_tl[(size_t)(u * (d - 1) + j)] = q.tail[j - 1];
                         }
                     }
-                }
-                rc = solve_inner_device_flat(nn, vals);
-                if (rc) return rc;
-            } else {
-            kids.assign((size_t)nn, Quad1D());
-            t = 0;
-            for (size_t qi : active) {
-                Quad1D& q = quads[qi];
-                for (size_t p = 0; p < q.pend.size(); ++p) {
-                    for (int i = 0; i < 15; ++i, ++t) {
-                        Quad1D& k = kids[(size_t)t];
-                        const double x = h_x[(size_t)t];
-                        k.slot = t;
+                    rc = solve_inner_device_flat(cn, &vals[(size_t)(c0 * ncomp)], &nev[(size_t)c0]);
+                    if (rc) return rc;
+                } else {
+                    kids.assign((size_t)cn, Quad1D());
+                    for (int64_t u = 0; u < cn; ++u) {
+                        const Quad1D& q = quads[node_q[(size_t)(c0 + u)]];
+                        Quad1D& k = kids[(size_t)u];
+                        const double x = h_x[(size_t)(c0 + u)];
+                        k.slot = u;
                         k.sweep = q.sweep;
                         k.root = q.root;
                         k.tail[0] = x;
@@ -696,24 +627,35 @@ int IaiDriver::solve_level(int L, std::vector<Quad1D>& quads) {
                         k.has_atol = q.has_atol;
                         k.atol = q.has_atol ? q.atol / len : 0.0;  // ref src/fourier.jl:479-480
                     }
+                    // the recursion reuses the staging vectors of this round
+                    std::vector<int64_t> keep_par;
+                    std::vector<double> keep_x;
+                    std::vector<uint32_t> keep_q;
+                    keep_par.swap(h_parents);
+                    keep_x.swap(h_x);
+                    keep_q.swap(node_q);
+                    rc = solve_level(L - 1, kids);
+                    h_parents.swap(keep_par);
+                    h_x.swap(keep_x);
+                    node_q.swap(keep_q);
+                    if (rc) return rc;
+                    for (int64_t u = 0; u < cn; ++u) {
+                        for (int c = 0; c < ncomp; ++c) vals[(size_t)((c0 + u) * ncomp + c)] = kids[(size_t)u].I[(size_t)c];
+                        nev[(size_t)(c0 + u)] = kids[(size_t)u].fevals;
+                    }
                 }
             }
-            rc = (L - 1 == 1 && device_inner) ? solve_inner_device(kids) : solve_level(L - 1, kids);
-            if (rc) return rc;
-            vals.resize((size_t)(nn * ncomp));
-            for (int64_t i = 0; i < nn; ++i)
-                for (int c = 0; c < ncomp; ++c) vals[(size_t)(i * ncomp + c)] = kids[(size_t)i].I[(size_t)c];
         }
-            }
-        // ---- deliver: GK sums, heap bookkeeping, next refinement (QuadGK adapt, scalar mode)
+        // ---- deliver: GK sums, then replay the pops whose halves are there, then the next requests
         std::vector<size_t> next;
         t = 0;
         std::vector<cd> Iseg((size_t)ncomp);
+        std::vector<Seg> got;
         for (size_t qi : active) {
             Quad1D& q = quads[qi];
             const double rt = tol_r(q);
             const double at = q.has_atol ? q.atol : 0.0;
-            std::vector<Seg> got(q.pend.size());
+            got.resize(q.pend.size());
             for (size_t p = 0; p < q.pend.size(); ++p, t += 15) {
                 Seg sg = q.pend[p];
                 gk15_evalrule(&vals[(size_t)(t * ncomp)], ncomp, sg.a, sg.b, Iseg.data(), &sg.E);
@@ -722,6 +664,8 @@ int IaiDriver::solve_level(int L, std::vector<Quad1D>& quads) {
                     return ABZ_ERR_ARG;
                 }
                 sg.ioff = (int64_t)q.store.size();
+                sg.nev = 0;
+                for (int i = 0; i < 15; ++i) sg.nev += nev[(size_t)(t + i)];
                 q.store.insert(q.store.end(), Iseg.begin(), Iseg.end());
                 got[p] = sg;
             }
@@ -731,9 +675,11 @@ int IaiDriver::solve_level(int L, std::vector<Quad1D>& quads) {
                 q.heap.assign(got.begin(), got.end());
                 for (int c = 0; c < ncomp; ++c) q.I[(size_t)c] = q.store[(size_t)(got[0].ioff + c)];
                 q.E = got[0].E;
+                q.fevals = got[0].nev;
                 for (size_t h = 1; h < got.size(); ++h) {
                     for (int c = 0; c < ncomp; ++c) q.I[(size_t)c] += q.store[(size_t)(got[h].ioff + c)];
                     q.E += got[h].E;
+                    q.fevals += got[h].nev;
                 }
                 q.numevals = 15 * (int64_t)got.size();
                 if (q.E <= std::max(at, rt * vnorm(q.I)) || q.numevals >= maxevals) {
@@ -742,8 +688,8 @@ int IaiDriver::solve_level(int L, std::vector<Quad1D>& quads) {
                     continue;
                 }
                 heapify(q.heap);
-            } else {
-                // children arrive in the order their parents were popped: (left, right) per parent
+            } else if (max_batch > 0) {
+                // BatchIntegrand refinement: children arrive in the order their parents were popped
                 for (size_t k = 0; k < q.popped.size(); ++k) {
                     const Seg& par = q.popped[k];
                     const Seg& s1 = got[2 * k];
@@ -752,18 +698,84 @@ int IaiDriver::solve_level(int L, std::vector<Quad1D>& quads) {
                         q.I[(size_t)c] = (q.I[(size_t)c] - q.store[(size_t)(par.ioff + c)]) +
                                          q.store[(size_t)(s1.ioff + c)] + q.store[(size_t)(s2.ioff + c)];
                     q.E = (q.E - par.E) + s1.E + s2.E;
+                    q.fevals += s1.nev + s2.nev;
                     heap_push(q.heap, s1);
                     heap_push(q.heap, s2);
+                }
+            } else {
+                // halves requested ahead: attach them to their parents (heap positions are stable between the
+                // request and this point)
+                for (size_t k = 0; k < q.req.size(); ++k) {
+                    Seg& par = q.heap[q.req[k]];
+                    par.state = 2;
+                    par.E1 = got[2 * k].E;
+                    par.ioff1 = got[2 * k].ioff;
+                    par.nev1 = got[2 * k].nev;
+                    par.E2 = got[2 * k + 1].E;
+                    par.ioff2 = got[2 * k + 1].ioff;
+                    par.nev2 = got[2 * k + 1].nev;
                 }
             }
             q.pend.clear();
             q.popped.clear();
+            q.req.clear();
+            bool finished = false;
             double tol = std::max(at, rt * vnorm(q.I));
-            if (q.E > tol && q.numevals < maxevals) {
-                if (max_batch <= 0) {
-                    // scalar mode (QuadGK adapt): pop the worst panel, bisect
-                    q.popped.push_back(heap_pop(q.heap));
+            if (max_batch <= 0) {
+                // replay QuadGK's adapt loop for as long as the halves of the top panel are known
+                while (true) {
+                    tol = std::max(at, rt * vnorm(q.I));
+                    if (!(q.E > tol && q.numevals < maxevals)) {
+                        finished = true;
+                        break;
+                    }
+                    if (q.heap[0].state != 2) break;
+                    const Seg par = heap_pop(q.heap);
                     q.numevals += 30;
+                    const double mid = (par.a + par.b) / 2;
+                    Seg s1{par.a, mid, par.E1, par.ioff1};
+                    Seg s2{mid, par.b, par.E2, par.ioff2};
+                    s1.nev = par.nev1;
+                    s2.nev = par.nev2;
+                    for (int c = 0; c < ncomp; ++c)
+                        q.I[(size_t)c] = (q.I[(size_t)c] - q.store[(size_t)(par.ioff + c)]) +
+                                         q.store[(size_t)(s1.ioff + c)] + q.store[(size_t)(s2.ioff + c)];
+                    q.E = (q.E - par.E) + s1.E + s2.E;
+                    q.fevals += s1.nev + s2.nev;
+                    heap_push(q.heap, s1);
+                    heap_push(q.heap, s2);
+                }
+            } else {
+                finished = !(q.E > tol && q.numevals < maxevals);
+            }
+            if (!finished) {
+                if (max_batch <= 0) {
+                    // the top panel is needed now; with a fixed tolerance so is every panel whose own error plus the
+                    // errors of all smaller panels exceeds it (they are certain to be popped: see the header comment)
+                    const size_t hn = q.heap.size();
+                    if (speculate && rt == 0.0 && unlimited && hn > 1) {
+                        order.resize(hn);
+                        for (size_t h = 0; h < hn; ++h) order[h] = (uint32_t)h;
+                        std::stable_sort(order.begin(), order.end(),
+                                         [&](uint32_t u, uint32_t v) { return q.heap[u].E > q.heap[v].E; });
+                        suffix.resize(hn);
+                        double acc = 0.0;
+                        for (size_t h = hn; h-- > 0;) {  // small errors first: S_k = sum_{j >= k} E_j
+                            acc += q.heap[order[h]].E;
+                            suffix[h] = acc;
+                        }
+                        const double need = tol * (1.0 + 1e-9);
+                        for (size_t h = 0; h < hn && suffix[h] > need; ++h)
+                            if (q.heap[order[h]].state == 0) q.req.push_back(order[h]);
+                    }
+                    if (q.heap[0].state == 0 && std::find(q.req.begin(), q.req.end(), 0u) == q.req.end()) q.req.push_back(0u);
+                    for (uint32_t h : q.req) {
+                        Seg& par = q.heap[h];
+                        par.state = 1;
+                        const double mid = (par.a + par.b) / 2;
+                        q.pend.push_back(Seg{par.a, mid, 0.0, 0});
+                        q.pend.push_back(Seg{mid, par.b, 0.0, 0});
+                    }
                 } else {
                     // BatchIntegrand refine: pop panels while the error of the REMAINING ones still
                     // exceeds the tolerance (auxquadgk batch mode, src/algorithms.jl:227-233)
@@ -774,11 +786,11 @@ int IaiDriver::solve_level(int L, std::vector<Quad1D>& quads) {
                         q.numevals += 30;
                         q.popped.push_back(sg);
                     }
-                }
-                for (const Seg& par : q.popped) {
-                    const double mid = (par.a + par.b) / 2;
-                    q.pend.push_back(Seg{par.a, mid, 0.0, 0});
-                    q.pend.push_back(Seg{mid, par.b, 0.0, 0});
+                    for (const Seg& par : q.popped) {
+                        const double mid = (par.a + par.b) / 2;
+                        q.pend.push_back(Seg{par.a, mid, 0.0, 0});
+                        q.pend.push_back(Seg{mid, par.b, 0.0, 0});
+                    }
                 }
                 next.push_back(qi);
             } else {
@@ -862,7 +874,12 @@ int abz_iai_solve_many(abz_series* s, int lims_kind, const double* lim_a, const 
     drv.rtol_user = reltol;
     drv.maxevals = maxevals > 0 ? maxevals : (int64_t)1 << 62;
     drv.max_batch = max_batch;
-    drv.evals_per_root.assign((size_t)n_sweep, 0);
+    {
+        const char* e = getenv("ABZ_IAI_SPECULATE");  // 0: one panel per integral per round (the round-1 driver)
+        drv.speculate = !(e && e[0] == '0');
+        const char* m = getenv("ABZ_IAI_POOL_MB");
+        if (m && atoll(m) > 0) drv.pool_cap_bytes = (int64_t)atoll(m) << 20;
+    }
     {
         const char* e = getenv("ABZ_IAI_DEVICE_INNER");  // 0 forces the host loop at every level
         // n > 4: the workgroup-per-integral kernel (coefficient set in LDS) runs by default where it
@@ -899,7 +916,7 @@ int abz_iai_solve_many(abz_series* s, int lims_kind, const double* lim_a, const 
             out_reim[2 * ((size_t)r * drv.ncomp + c) + 1] = top[(size_t)r].I[(size_t)c].imag();
         }
         if (err) err[r] = top[(size_t)r].E;
-        if (numevals) numevals[r] = drv.evals_per_root[(size_t)r];
+        if (numevals) numevals[r] = top[(size_t)r].fevals;
     }
     if (npanels) *npanels = (int64_t)top[0].heap.size();
     if (panels) {  // panels of the first solve
