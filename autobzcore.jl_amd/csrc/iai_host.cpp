@@ -469,9 +469,11 @@ int IaiDriver::solve_inner_device_flat(int64_t nq, cd* vals, int64_t* nev) {
         // the host loop below reuses the round's staging vectors: keep this chunk's description
         std::vector<int64_t> keep_par = h_parents;
         std::vector<double> keep_x = h_x;
+        std::vector<uint32_t> keep_q = node_q;
         rc = solve_level(1, redo);
         h_parents.swap(keep_par);
         h_x.swap(keep_x);
+        node_q.swap(keep_q);
         device_inner = keep;
         if (rc) return rc;
         for (size_t j = 0; j < redo.size(); ++j) {
