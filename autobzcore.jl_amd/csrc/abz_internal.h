@@ -277,6 +277,10 @@ struct InnerSpec {
     int* status_out;         // device [nint]: 0 ok, 1 = segment store overflow (redo on the host)
 };
 constexpr int ABZ_INNER_MAXSEG = 48;
+// workgroup-per-integral kernel (5..32 bands): the store is 44 B per segment beside a 53 KB coefficient set, so it
+// can be deep -- at config 5's abstol = 1e-3 thousands of innermost integrals need more than 48 panels, and each
+// of them fell back to the host-driven loop (30 of the solve's 40 s)
+constexpr int ABZ_PANEL_MAXSEG = 384;
 bool inner_adaptive_supported(int n, int M, int integrand);
 int launch_inner_adaptive(abz_ctx* ctx, const InnerSpec& is);
 bool gen_inner_supported(int n, int M, int integrand);  // n > 4: one wavefront per 1-D integral

@@ -9,6 +9,7 @@
 // contraction / evaluation launch.  A 1-D integral's decisions depend only on its own node values,
 // so its panel tree is the one the depth-first traversal builds.
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <complex>
 #include <deque>
@@ -280,6 +281,11 @@ struct IaiDriver {
     bool speculate = true;  // request the halves of every panel that is certain to be popped (solve_level)
     int64_t pool_cap_bytes = (int64_t)4 << 30;  // contracted sets alive at once per level (ABZ_IAI_POOL_MB)
     int64_t launches = 0;   // innermost launches of this solve (diagnostics)
+    // ABZ_IAI_STATS=1: innermost launches by size (log2 buckets): count, integrals, seconds
+    bool stats = false;
+    int64_t st_cnt[40] = {0}, st_int[40] = {0};
+    double st_sec[40] = {0};
+    int64_t st_rounds[ABZ_MAX_DIM + 1] = {0, 0, 0, 0};
     std::vector<int64_t> h_parents;
     std::vector<double> h_x, h_tail, h_sweep;
     std::vector<cd> h_values;
@@ -432,10 +438,18 @@ int IaiDriver::solve_inner_device_flat(int64_t nq, cd* vals, int64_t* nev) {
     is.E_out = reinterpret_cast<double*>(ob + sizeof(double2) * (size_t)(nq * ncomp));
     is.nev_out = reinterpret_cast<int64_t*>(is.E_out + nq);
     is.status_out = reinterpret_cast<int*>(is.nev_out + nq);
+    const auto st_t0 = std::chrono::steady_clock::now();
     if ((rc = (n > 4 ? launch_gen_inner_adaptive(ctx, is) : launch_inner_adaptive(ctx, is)))) return rc;
     f_out.resize(out_bytes);
     ABZ_HIP(hipMemcpyAsync(f_out.data(), ob, out_bytes, hipMemcpyDeviceToHost, ctx->stream));
     ABZ_HIP(hipStreamSynchronize(ctx->stream));
+    if (stats) {
+        int b = 0;
+        while (((int64_t)1 << (b + 1)) <= nq) ++b;
+        st_cnt[b] += 1;
+        st_int[b] += nq;
+        st_sec[b] += std::chrono::duration<double>(std::chrono::steady_clock::now() - st_t0).count();
+    }
     const cd* hI = reinterpret_cast<const cd*>(f_out.data());
     const double* hE = reinterpret_cast<const double*>(f_out.data() + sizeof(double2) * (size_t)(nq * ncomp));
     const int64_t* hN = reinterpret_cast<const int64_t*>(hE + nq);
@@ -530,6 +544,7 @@ int IaiDriver::solve_level(int L, std::vector<Quad1D>& quads) {
     std::vector<double> suffix;
     double xs15[15];
     while (!active.empty()) {
+        st_rounds[L] += 1;
         // ---- gather the nodes of all pending panels
         int64_t nn = 0;
         for (size_t qi : active) nn += 15 * (int64_t)quads[qi].pend.size();
@@ -879,6 +894,8 @@ int abz_iai_solve_many(abz_series* s, int lims_kind, const double* lim_a, const 
     {
         const char* e = getenv("ABZ_IAI_SPECULATE");  // 0: one panel per integral per round (the round-1 driver)
         drv.speculate = !(e && e[0] == '0');
+        const char* st = getenv("ABZ_IAI_STATS");
+        drv.stats = st && st[0] == '1';
         const char* m = getenv("ABZ_IAI_POOL_MB");
         if (m && atoll(m) > 0) drv.pool_cap_bytes = (int64_t)atoll(m) << 20;
     }
@@ -912,6 +929,15 @@ int abz_iai_solve_many(abz_series* s, int lims_kind, const double* lim_a, const 
     }
     int rc = drv.solve_level(s->d, top);
     if (rc) return rc;
+    if (drv.stats) {
+        fprintf(stderr, "[abz iai] rounds per level:");
+        for (int L = 1; L <= s->d; ++L) fprintf(stderr, " L%d=%lld", L, (long long)drv.st_rounds[L]);
+        fprintf(stderr, "\n[abz iai] innermost launches by size: 2^b integrals | launches | integrals | seconds\n");
+        for (int b = 0; b < 40; ++b)
+            if (drv.st_cnt[b])
+                fprintf(stderr, "[abz iai]   2^%-2d %9lld %12lld %9.3f\n", b, (long long)drv.st_cnt[b], (long long)drv.st_int[b],
+                        drv.st_sec[b]);
+    }
     for (int r = 0; r < n_sweep; ++r) {
         for (int c = 0; c < drv.ncomp; ++c) {
             out_reim[2 * ((size_t)r * drv.ncomp + c)] = top[(size_t)r].I[(size_t)c].real();

@@ -50,10 +50,10 @@ __device__ __forceinline__ void adapt_init(AdaptStateT<MAXC>& st, double at, boo
 // next bisection in ctl (returns false) or writes the result (returns true).
 // REGS: scalar integrands pull the panel values into registers first (worth it where the caller has the
 // registers to spare: the n <= 4 kernel; the generic-n kernels keep their rows in registers instead).
-template <bool REGS = false, int MAXC = ADAPT_MAXC>
+// MS: capacity of the segment store (an integral that needs more reports status 1 and is redone by the host loop).
+template <bool REGS = false, int MAXC = ADAPT_MAXC, int MS = ABZ_INNER_MAXSEG>
 __device__ inline bool adapt_step(AdaptStateT<MAXC>& st, int nc_, double* seg_a, double* seg_b, double* seg_E, gkc* seg_I,
                                   const gkc* vals, int* heap, double* ctl, long long maxevals, const InnerOut& out) {
-    constexpr int MS = ABZ_INNER_MAXSEG;
     const int nc = MAXC == 1 ? 1 : nc_;
     const int np = (int)ctl[0];
     int newseg[2] = {-1, -1};
@@ -205,8 +205,8 @@ __device__ inline bool adapt_step(AdaptStateT<MAXC>& st, int nc_, double* seg_a,
 }
 
 // LDS doubles of one integral in flight: seg_a, seg_b, seg_E | seg_I | vals[30] | heap | ctl
-__host__ __device__ inline int inner_group_doubles(int ncomp) {
-    return 3 * ABZ_INNER_MAXSEG + 2 * ncomp * ABZ_INNER_MAXSEG + 2 * ncomp * 30 + ABZ_INNER_MAXSEG / 2 + 8;
+__host__ __device__ inline int inner_group_doubles(int ncomp, int ms = ABZ_INNER_MAXSEG) {
+    return 3 * ms + 2 * ncomp * ms + 2 * ncomp * 30 + ms / 2 + 8;
 }
 
 }  // namespace abz

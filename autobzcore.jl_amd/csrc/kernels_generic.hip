@@ -1731,7 +1731,7 @@ template <int NP, bool PAD, int NT, int WPE>
 __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(WPE ? WPE : 1, WPE ? WPE : 8))) void gen_inner_panel_kernel(GenInnerArgs a) {
     extern __shared__ double2 lds_ip[];
     constexpr int SLOTS = NT / NP;
-    constexpr int MS = ABZ_INNER_MAXSEG;
+    constexpr int MS = ABZ_PANEL_MAXSEG;
     const int n = a.n, nn = n * n, M = a.M, nc = a.ncomp;  // nc = 1 (DOS, TRGLOC)
     double2* coef = lds_ip;
     double* g = reinterpret_cast<double*>(coef + (size_t)M * (PAD ? NP * NP : nn));
@@ -1784,7 +1784,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(WPE ? WPE : 
                 out.E = a.E_out + q;
                 out.nev = a.nev_out + q;
                 out.status = a.status_out + q;
-                if (adapt_step<false, 1>(st, nc, seg_a, seg_b, seg_E, seg_I, vals, heap, ctl, a.maxevals, out)) ctl[5] = 1.0;
+                if (adapt_step<false, 1, MS>(st, nc, seg_a, seg_b, seg_E, seg_I, vals, heap, ctl, a.maxevals, out)) ctl[5] = 1.0;
             }
         }
     }
@@ -1800,7 +1800,7 @@ static int gen_inner_panel_threads(int np) {
 static bool gen_inner_panel_fits(int n, int M, int integrand, int* np_out, size_t* lds_out, bool* pad_out) {
     if (!(integrand == ABZ_F_DOS || integrand == ABZ_F_TRGLOC)) return false;
     const int np = n <= 8 ? 8 : (n <= 16 ? 16 : 32);
-    const size_t rest = sizeof(double) * (size_t)inner_group_doubles(1);
+    const size_t rest = sizeof(double) * (size_t)inner_group_doubles(1, ABZ_PANEL_MAXSEG);
     size_t lds = sizeof(double2) * (size_t)M * np * np + rest;  // zero-padded set
     const bool pad = lds <= 150 * 1024;
     if (!pad) lds = sizeof(double2) * (size_t)M * n * n + rest;

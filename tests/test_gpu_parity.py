@@ -785,6 +785,32 @@ def test_generic_n_iai_3d_16_band_matches_oracle(abz):
     assert abs(sol.resid - ref.resid) <= 1e-6 * abs(ref.resid) + 1e-12
 
 
+@pytest.mark.parametrize("n,dims,eta,abstol", [(3, (3, 3, 3), 0.2, 0.3), (16, (3, 3, 3), 0.3, 0.5), (2, (7, 5), 0.05, 1e-3)])
+def test_iai_speculative_requests_change_nothing(abz, monkeypatch, n, dims, eta, abstol):
+    """The driver requests the halves of every panel that is certain to be popped in one round; pops are replayed in
+    QuadGK's order.  Value bits, error, numevals and panels equal those of the one-panel-per-round driver
+    (ABZ_IAI_SPECULATE=0 = the round-1 behaviour), also with the set pools cut into many chunks."""
+    rng = np.random.default_rng(4242 + n)
+    c, first = rand_series(rng, dims, n, hermitian=True)
+    c = c / max(1.0, n / 2)
+    s = abz.FourierSeries(c, period=1.0, first=first, ndim=len(dims))
+    d = len(dims)
+    bz = abz.load_bz(abz.FBZ(), np.eye(d))
+    f = abz.FourierIntegrand(abz.DOSIntegrand(), s, eta)
+    runs = {}
+    for tag, env in (("spec", {}), ("serial", {"ABZ_IAI_SPECULATE": "0"}), ("chunks", {"ABZ_IAI_POOL_MB": "1"})):
+        for k in ("ABZ_IAI_SPECULATE", "ABZ_IAI_POOL_MB"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        sol = abz.do_solve(f, bz, abz.MixedParameters(0.1), abz.EvalCounter(abz.IAI()), abstol=abstol, reltol=0.0, _panels=True)
+        runs[tag] = (sol.u, sol.resid, sol.numevals, sol.extra["panels"])
+    for tag in ("serial", "chunks"):
+        assert runs[tag][0] == runs["spec"][0] and runs[tag][1] == runs["spec"][1] and runs[tag][2] == runs["spec"][2]
+        assert np.array_equal(runs[tag][3], runs["spec"][3])
+    assert runs["spec"][2] > 15**d and len(runs["spec"][3]) >= 2
+
+
 @pytest.mark.parametrize("d,kind", [(2, None), (3, None), (3, "cubic")])
 def test_autosymptrjl_matches_oracle(abz, d, kind):
     """AutoSymPTRJL on a Basis domain (ref: src/algorithms.jl:393-432, used at test/fourier.jl:25-37) against the
