@@ -443,6 +443,8 @@ static void series_release(abz_series* s) {
     for (auto& b : s->pool) b.release();
     for (auto& b : s->iai_pool) b.release();
     for (auto& b : s->iai_io) b.release();
+    for (auto& q : s->iai_pin)
+        if (q) (void)hipHostFree(q);
     if (s->coef) (void)hipFree(s->coef);
     delete s;
     ctx_release(ctx);

@@ -284,7 +284,6 @@ struct IaiDriver {
     // ABZ_IAI_STATS=1: innermost launches by size (log2 buckets): count, integrals, seconds
     bool stats = false;
     int64_t st_cnt[40] = {0}, st_int[40] = {0};
-    double st_sec[40] = {0};
     int64_t st_rounds[ABZ_MAX_DIM + 1] = {0, 0, 0, 0};
     std::vector<int64_t> h_parents;
     std::vector<double> h_x, h_tail, h_sweep;
@@ -298,20 +297,66 @@ struct IaiDriver {
 
     bool device_inner = false;  // innermost adaptive loops on the GPU (scalar refinement, n <= 4)
 
-    int contract_nodes(int L, int64_t nn, int64_t base_slot, int64_t off = 0);
+    int contract_nodes(int L, int64_t nn, int64_t base_slot, int64_t off = 0, const int64_t* par = nullptr, const double* x = nullptr);
     int eval_nodes(int64_t nn);
     int solve_level(int L, std::vector<Quad1D>& quads);
-    int solve_inner_device_flat(int64_t nq, cd* vals, int64_t* nev);
+    int flat_enqueue(int64_t nq, int buf);
+    int flat_collect(int64_t nq, int buf, cd* vals, int64_t* nev, std::vector<int64_t>& redo);
+    size_t flat_out_bytes(int64_t nq) const {
+        return sizeof(double2) * (size_t)(nq * ncomp) + sizeof(double) * (size_t)nq + sizeof(int64_t) * (size_t)nq + sizeof(int) * (size_t)nq;
+    }
+    hipEvent_t ev[2] = {nullptr, nullptr};
+    double st_wait = 0.0;
+    ~IaiDriver() {
+        for (auto e : ev)
+            if (e) (void)hipEventDestroy(e);
+    }
     std::vector<uint32_t> node_q;  // owner (index into the level's integrals) of every node of a round
     // structure-of-arrays description of the innermost integrals of a round (no per-integral objects)
-    std::vector<int64_t> f_slot;
-    std::vector<int> f_root;
-    std::vector<double> f_lo, f_hi, f_at, f_sw, f_tl;
-    std::vector<char> f_out;
+    // (they live in a pinned host block laid out like the device staging buffer: one async copy per chunk; pageable
+    // vectors of this size made the runtime pin and unpin them on every copy)
+    int64_t* f_par = nullptr;   // [cn] parents of the chunk's contraction
+    double* f_x = nullptr;      // [cn] its coordinates
+    int64_t* f_slot = nullptr;
+    double *f_lo = nullptr, *f_hi = nullptr, *f_at = nullptr, *f_sw = nullptr, *f_tl = nullptr;
+    int pin_reserve(int which, size_t bytes);
+    int flat_layout(int64_t cn, bool need_tail, int buf);
 };
 
+int IaiDriver::pin_reserve(int which, size_t bytes) {
+    if (bytes <= s->iai_pin_cap[which]) return ABZ_OK;
+    if (s->iai_pin[which]) (void)hipHostFree(s->iai_pin[which]);
+    s->iai_pin[which] = nullptr;
+    s->iai_pin_cap[which] = 0;
+    const size_t want = bytes + (bytes >> 2) + 4096;
+    hipError_t e = hipHostMalloc(&s->iai_pin[which], want, hipHostMallocDefault);
+    if (e != hipSuccess) {
+        set_error("hipHostMalloc(%zu) failed: %s", want, hipGetErrorString(e));
+        return ABZ_ERR_NOMEM;
+    }
+    s->iai_pin_cap[which] = want;
+    return ABZ_OK;
+}
+
+// pinned input block of a chunk of cn innermost integrals: [par | x | slot | lo | hi | at | sw | tail]
+int IaiDriver::flat_layout(int64_t cn, bool need_tail, int buf) {
+    const size_t words = (size_t)cn * (7 + (need_tail ? (size_t)(d - 1) : 0));
+    int rc = pin_reserve(buf, sizeof(double) * words);
+    if (rc) return rc;
+    char* b = static_cast<char*>(s->iai_pin[buf]);
+    f_par = reinterpret_cast<int64_t*>(b);
+    f_x = reinterpret_cast<double*>(b + sizeof(int64_t) * (size_t)cn);
+    f_slot = reinterpret_cast<int64_t*>(f_x + cn);
+    f_lo = reinterpret_cast<double*>(f_slot + cn);
+    f_hi = f_lo + cn;
+    f_at = f_hi + cn;
+    f_sw = f_at + cn;
+    f_tl = need_tail ? f_sw + cn : nullptr;
+    return ABZ_OK;
+}
+
 // upload h_parents/h_x, contract level-L sets into level-(L-1) pool slots base_slot..base_slot+nn-1
-int IaiDriver::contract_nodes(int L, int64_t nn, int64_t base_slot, int64_t off) {
+int IaiDriver::contract_nodes(int L, int64_t nn, int64_t base_slot, int64_t off, const int64_t* par, const double* x) {
     const int M = s->dims[L - 1];
     const int64_t Lrow = s->elems(L - 1);
     int rc;
@@ -319,9 +364,9 @@ int IaiDriver::contract_nodes(int L, int64_t nn, int64_t base_slot, int64_t off)
     if ((rc = s->iai_io[1].reserve(sizeof(double) * (size_t)nn))) return rc;
     if ((rc = s->iai_io[4].reserve(sizeof(double2) * (size_t)(nn * M)))) return rc;
     if ((rc = s->iai_pool[L - 1].reserve(sizeof(double2) * (size_t)((base_slot + nn) * Lrow)))) return rc;
-    ABZ_HIP(hipMemcpyAsync(s->iai_io[0].p, h_parents.data() + off, sizeof(int64_t) * (size_t)nn, hipMemcpyHostToDevice,
+    ABZ_HIP(hipMemcpyAsync(s->iai_io[0].p, par ? par : h_parents.data() + off, sizeof(int64_t) * (size_t)nn, hipMemcpyHostToDevice,
                            ctx->stream));
-    ABZ_HIP(hipMemcpyAsync(s->iai_io[1].p, h_x.data() + off, sizeof(double) * (size_t)nn, hipMemcpyHostToDevice, ctx->stream));
+    ABZ_HIP(hipMemcpyAsync(s->iai_io[1].p, x ? x : h_x.data() + off, sizeof(double) * (size_t)nn, hipMemcpyHostToDevice, ctx->stream));
     PhaseSpec ps;
     ps.B = nn;
     ps.M = M;
@@ -385,8 +430,9 @@ int IaiDriver::eval_nodes(int64_t nn) {
 // (inner_adaptive_kernel); an integral that overflows the device segment store is redone on the host.
 // The same from structure-of-arrays input (f_slot, f_lo, ...), results straight into vals [nq][ncomp]:
 // a 432-solve sweep creates ~35 M innermost integrals, one heap-backed Quad1D each cost 4/5 of its time.
-int IaiDriver::solve_inner_device_flat(int64_t nq, cd* vals, int64_t* nev) {
-    if (nq == 0) return ABZ_OK;
+// Enqueue the innermost adaptive loops of the chunk described in pinned input block `buf` (flat_layout): input copy,
+// kernel, output copy into pinned output block `buf`, event.  Nothing is waited for.
+int IaiDriver::flat_enqueue(int64_t nq, int buf) {
     launches += 1;
     const bool need_tail = integrand == ABZ_F_LINEAR_X && d > 1;
     int rc;
@@ -398,19 +444,15 @@ int IaiDriver::solve_inner_device_flat(int64_t nq, cd* vals, int64_t* nev) {
     double* d_hi = d_lo + nq;
     double* d_at = d_hi + nq;
     double* d_sw = d_at + nq;
-    ABZ_HIP(hipMemcpyAsync(d_sw, f_sw.data(), sizeof(double) * (size_t)nq, hipMemcpyHostToDevice, ctx->stream));
-    ABZ_HIP(hipMemcpyAsync(d_slot, f_slot.data(), sizeof(int64_t) * (size_t)nq, hipMemcpyHostToDevice, ctx->stream));
-    ABZ_HIP(hipMemcpyAsync(d_lo, f_lo.data(), sizeof(double) * (size_t)nq, hipMemcpyHostToDevice, ctx->stream));
-    ABZ_HIP(hipMemcpyAsync(d_hi, f_hi.data(), sizeof(double) * (size_t)nq, hipMemcpyHostToDevice, ctx->stream));
-    ABZ_HIP(hipMemcpyAsync(d_at, f_at.data(), sizeof(double) * (size_t)nq, hipMemcpyHostToDevice, ctx->stream));
+    // [slot | lo | hi | at | sw] is contiguous in the pinned block, in the device block's order
+    ABZ_HIP(hipMemcpyAsync(d_slot, f_slot, in_bytes, hipMemcpyHostToDevice, ctx->stream));
     double* d_tail = nullptr;
     if (need_tail) {
         if ((rc = s->iai_io[2].reserve(sizeof(double) * (size_t)(nq * (d - 1))))) return rc;
         d_tail = s->iai_io[2].as<double>();
-        ABZ_HIP(hipMemcpyAsync(d_tail, f_tl.data(), sizeof(double) * (size_t)(nq * (d - 1)), hipMemcpyHostToDevice, ctx->stream));
+        ABZ_HIP(hipMemcpyAsync(d_tail, f_tl, sizeof(double) * (size_t)(nq * (d - 1)), hipMemcpyHostToDevice, ctx->stream));
     }
-    const size_t out_bytes = sizeof(double2) * (size_t)(nq * ncomp) + sizeof(double) * (size_t)nq + sizeof(int64_t) * (size_t)nq +
-                             sizeof(int) * (size_t)nq;
+    const size_t out_bytes = flat_out_bytes(nq);
     if ((rc = s->iai_io[3].reserve(out_bytes))) return rc;
     char* ob = static_cast<char*>(s->iai_io[3].p);
     InnerSpec is;
@@ -438,63 +480,35 @@ int IaiDriver::solve_inner_device_flat(int64_t nq, cd* vals, int64_t* nev) {
     is.E_out = reinterpret_cast<double*>(ob + sizeof(double2) * (size_t)(nq * ncomp));
     is.nev_out = reinterpret_cast<int64_t*>(is.E_out + nq);
     is.status_out = reinterpret_cast<int*>(is.nev_out + nq);
-    const auto st_t0 = std::chrono::steady_clock::now();
     if ((rc = (n > 4 ? launch_gen_inner_adaptive(ctx, is) : launch_inner_adaptive(ctx, is)))) return rc;
-    f_out.resize(out_bytes);
-    ABZ_HIP(hipMemcpyAsync(f_out.data(), ob, out_bytes, hipMemcpyDeviceToHost, ctx->stream));
-    ABZ_HIP(hipStreamSynchronize(ctx->stream));
+    if ((rc = pin_reserve(2 + buf, out_bytes))) return rc;
+    ABZ_HIP(hipMemcpyAsync(s->iai_pin[2 + buf], ob, out_bytes, hipMemcpyDeviceToHost, ctx->stream));
+    if (!ev[buf]) ABZ_HIP(hipEventCreateWithFlags(&ev[buf], hipEventDisableTiming));
+    ABZ_HIP(hipEventRecord(ev[buf], ctx->stream));
     if (stats) {
         int b = 0;
         while (((int64_t)1 << (b + 1)) <= nq) ++b;
         st_cnt[b] += 1;
         st_int[b] += nq;
-        st_sec[b] += std::chrono::duration<double>(std::chrono::steady_clock::now() - st_t0).count();
     }
-    const cd* hI = reinterpret_cast<const cd*>(f_out.data());
-    const double* hE = reinterpret_cast<const double*>(f_out.data() + sizeof(double2) * (size_t)(nq * ncomp));
+    return ABZ_OK;
+}
+
+// Wait for chunk `buf` and take its results; integrals that overflowed the device segment store are listed in `redo`
+// (chunk-local indices) for the host loop.
+int IaiDriver::flat_collect(int64_t nq, int buf, cd* vals, int64_t* nev, std::vector<int64_t>& redo) {
+    const auto t0 = std::chrono::steady_clock::now();
+    ABZ_HIP(hipEventSynchronize(ev[buf]));
+    if (stats) st_wait += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    const char* f_out = static_cast<const char*>(s->iai_pin[2 + buf]);
+    const cd* hI = reinterpret_cast<const cd*>(f_out);
+    const double* hE = reinterpret_cast<const double*>(f_out + sizeof(double2) * (size_t)(nq * ncomp));
     const int64_t* hN = reinterpret_cast<const int64_t*>(hE + nq);
     const int* hS = reinterpret_cast<const int*>(hN + nq);
     std::memcpy(vals, hI, sizeof(cd) * (size_t)(nq * ncomp));
-    std::vector<Quad1D> redo;
-    std::vector<int64_t> redo_idx;
-    for (int64_t i = 0; i < nq; ++i) {
-        if (hS[i] != 0) {  // segment store overflow on the device: redo this one with the host loop
-            Quad1D k;
-            k.slot = f_slot[(size_t)i];
-            k.sweep = f_sw[(size_t)i];
-            k.root = f_root[(size_t)i];
-            if (need_tail)
-                for (int j = 0; j < d - 1; ++j) k.tail[j] = f_tl[(size_t)(i * (d - 1) + j)];
-            k.lims.kind = ABZ_LIMS_CUBIC;
-            k.lims.s = 1.0;
-            k.lims.a[0] = f_lo[(size_t)i];
-            k.lims.b[0] = f_hi[(size_t)i];
-            k.has_atol = f_at[(size_t)i] >= 0.0;
-            k.atol = k.has_atol ? f_at[(size_t)i] : 0.0;
-            redo.push_back(k);
-            redo_idx.push_back(i);
-            continue;
-        }
-        nev[i] = hN[i];
-    }
-    if (!redo.empty()) {
-        const bool keep = device_inner;
-        device_inner = false;
-        // the host loop below reuses the round's staging vectors: keep this chunk's description
-        std::vector<int64_t> keep_par = h_parents;
-        std::vector<double> keep_x = h_x;
-        std::vector<uint32_t> keep_q = node_q;
-        rc = solve_level(1, redo);
-        h_parents.swap(keep_par);
-        h_x.swap(keep_x);
-        node_q.swap(keep_q);
-        device_inner = keep;
-        if (rc) return rc;
-        for (size_t j = 0; j < redo.size(); ++j) {
-            for (int c = 0; c < ncomp; ++c) vals[(size_t)(redo_idx[j] * ncomp + c)] = redo[j].I[(size_t)c];
-            nev[redo_idx[j]] = redo[j].fevals;
-        }
-    }
+    std::memcpy(nev, hN, sizeof(int64_t) * (size_t)nq);
+    for (int64_t i = 0; i < nq; ++i)
+        if (hS[i] != 0) redo.push_back(i);
     return ABZ_OK;
 }
 
@@ -540,7 +554,7 @@ int IaiDriver::solve_level(int L, std::vector<Quad1D>& quads) {
     std::vector<cd> vals;        // [node][ncomp] of this round
     std::vector<int64_t> nev;    // [node]: integrand evaluations beneath the node
     std::vector<Quad1D> kids;    // inner integrals of a chunk (L - 1 > 1, or host-side innermost loops)
-    std::vector<uint32_t> order;
+    std::vector<std::pair<double, uint32_t>> order;
     std::vector<double> suffix;
     double xs15[15];
     while (!active.empty()) {
@@ -579,24 +593,22 @@ int IaiDriver::solve_level(int L, std::vector<Quad1D>& quads) {
         } else {
             // chunks: the level-(L-1) sets of a chunk are contracted, integrated over and then overwritten
             const int64_t set_bytes = (int64_t)sizeof(double2) * s->elems(L - 1);
-            int64_t chunk = std::max<int64_t>(15, (pool_cap_bytes / std::max<int64_t>(set_bytes, 1)) / 15 * 15);
+            // (and of at most ~2.6e5 nodes: the per-chunk host arrays stay in cache, a launch still fills the chip)
+            int64_t chunk = std::max<int64_t>(15, std::min<int64_t>(pool_cap_bytes / std::max<int64_t>(set_bytes, 1), 262140) / 15 * 15);
             const bool flat = (L - 1 == 1) && device_inner;
             const bool need_tail = integrand == ABZ_F_LINEAR_X && d > 1;
-            for (int64_t c0 = 0; c0 < nn; c0 += chunk) {
-                const int64_t cn = std::min(chunk, nn - c0);
-                s->iai_used[L - 1] = 0;  // sets of the previous chunk are dead
-                // parents index THIS level's sets, which stay put for the whole round; the new sets are chunk-local
-                int rc = contract_nodes(L, cn, 0, c0);
-                if (rc) return rc;
-                if (flat) {
-                    // innermost integrals as plain arrays (see solve_inner_device_flat)
-                    f_slot.resize((size_t)cn);
-                    f_root.resize((size_t)cn);
-                    f_lo.resize((size_t)cn);
-                    f_hi.resize((size_t)cn);
-                    f_at.resize((size_t)cn);
-                    f_sw.resize((size_t)cn);
-                    if (need_tail) f_tl.resize((size_t)(cn * (d - 1)));
+            if (flat) {
+                // Two chunks in flight: while the GPU integrates chunk c the host describes chunk c + 1 (limits,
+                // tolerances, slots) in the other pinned block.  Everything is ordered on one stream, so the device
+                // buffers and the set pool need no second copy.
+                std::vector<int64_t> redo_local, redo_nodes;
+                auto describe_and_enqueue = [&](int64_t c0, int64_t cn, int buf) -> int {
+                    int rc;
+                    if ((rc = flat_layout(cn, need_tail, buf))) return rc;
+                    std::memcpy(f_par, h_parents.data() + c0, sizeof(int64_t) * (size_t)cn);
+                    std::memcpy(f_x, h_x.data() + c0, sizeof(double) * (size_t)cn);
+                    s->iai_used[L - 1] = 0;  // sets of the previous chunk are dead (stream order)
+                    if ((rc = contract_nodes(L, cn, 0, 0, f_par, f_x))) return rc;
                     for (int64_t u = 0; u < cn; ++u) {
                         const Quad1D& q = quads[node_q[(size_t)(c0 + u)]];
                         const double x = h_x[(size_t)(c0 + u)];
@@ -609,7 +621,6 @@ int IaiDriver::solve_level(int L, std::vector<Quad1D>& quads) {
                             hi1 = sg.back();  // the innermost slice of a convex domain is one interval
                         }
                         f_slot[(size_t)u] = u;
-                        f_root[(size_t)u] = q.root;
                         f_sw[(size_t)u] = q.sweep;
                         f_lo[(size_t)u] = lo1;
                         f_hi[(size_t)u] = hi1;
@@ -619,9 +630,83 @@ int IaiDriver::solve_level(int L, std::vector<Quad1D>& quads) {
                             for (int j = 1; j < d - 1; ++j) f_tl[(size_t)(u * (d - 1) + j)] = q.tail[j - 1];
                         }
                     }
-                    rc = solve_inner_device_flat(cn, &vals[(size_t)(c0 * ncomp)], &nev[(size_t)c0]);
+                    return flat_enqueue(cn, buf);
+                };
+                const int64_t nchunks = (nn + chunk - 1) / chunk;
+                for (int64_t ci = 0; ci <= nchunks; ++ci) {
+                    if (ci < nchunks) {
+                        const int64_t c0 = ci * chunk;
+                        int rc = describe_and_enqueue(c0, std::min(chunk, nn - c0), (int)(ci & 1));
+                        if (rc) return rc;
+                    }
+                    if (ci > 0) {
+                        const int64_t c0 = (ci - 1) * chunk, cn = std::min(chunk, nn - c0);
+                        redo_local.clear();
+                        int rc = flat_collect(cn, (int)((ci - 1) & 1), &vals[(size_t)(c0 * ncomp)], &nev[(size_t)c0], redo_local);
+                        if (rc) return rc;
+                        for (int64_t u : redo_local) redo_nodes.push_back(c0 + u);
+                    }
+                }
+                // integrals that overflowed the device segment store: their sets are contracted again (the pool has
+                // moved on) and the host loop integrates them
+                for (size_t r0 = 0; r0 < redo_nodes.size(); r0 += (size_t)chunk) {
+                    const int64_t rn = (int64_t)std::min<size_t>((size_t)chunk, redo_nodes.size() - r0);
+                    std::vector<int64_t> rp((size_t)rn);
+                    std::vector<double> rx((size_t)rn);
+                    kids.assign((size_t)rn, Quad1D());
+                    for (int64_t u = 0; u < rn; ++u) {
+                        const int64_t tn = redo_nodes[r0 + (size_t)u];
+                        const Quad1D& q = quads[node_q[(size_t)tn]];
+                        Quad1D& k = kids[(size_t)u];
+                        const double x = h_x[(size_t)tn];
+                        rp[(size_t)u] = h_parents[(size_t)tn];
+                        rx[(size_t)u] = x;
+                        k.slot = u;
+                        k.sweep = q.sweep;
+                        k.root = q.root;
+                        k.tail[0] = x;
+                        for (int j = 1; j < ABZ_MAX_DIM; ++j) k.tail[j] = q.tail[j - 1];
+                        k.lims = q.lims.fix(L, x);
+                        double lo1, hi1;
+                        if (!k.lims.range(1, lo1, hi1)) {
+                            std::vector<double> sg;
+                            k.lims.segs(1, sg);
+                            lo1 = sg.front();
+                            hi1 = sg.back();
+                        }
+                        k.has_atol = q.has_atol;
+                        k.atol = q.has_atol ? q.atol / (hi1 - lo1) : 0.0;
+                    }
+                    s->iai_used[L - 1] = 0;
+                    int rc = contract_nodes(L, rn, 0, 0, rp.data(), rx.data());
                     if (rc) return rc;
-                } else {
+                    std::vector<int64_t> keep_par;
+                    std::vector<double> keep_x;
+                    std::vector<uint32_t> keep_q;
+                    keep_par.swap(h_parents);
+                    keep_x.swap(h_x);
+                    keep_q.swap(node_q);
+                    const bool keep = device_inner;
+                    device_inner = false;
+                    rc = solve_level(1, kids);
+                    device_inner = keep;
+                    h_parents.swap(keep_par);
+                    h_x.swap(keep_x);
+                    node_q.swap(keep_q);
+                    if (rc) return rc;
+                    for (int64_t u = 0; u < rn; ++u) {
+                        const int64_t tn = redo_nodes[r0 + (size_t)u];
+                        for (int c = 0; c < ncomp; ++c) vals[(size_t)(tn * ncomp + c)] = kids[(size_t)u].I[(size_t)c];
+                        nev[(size_t)tn] = kids[(size_t)u].fevals;
+                    }
+                }
+            } else
+            for (int64_t c0 = 0; c0 < nn; c0 += chunk) {
+                const int64_t cn = std::min(chunk, nn - c0);
+                s->iai_used[L - 1] = 0;  // sets of the previous chunk are dead
+                int rc;
+                {
+                    if ((rc = contract_nodes(L, cn, 0, c0))) return rc;
                     kids.assign((size_t)cn, Quad1D());
                     for (int64_t u = 0; u < cn; ++u) {
                         const Quad1D& q = quads[node_q[(size_t)(c0 + u)]];
@@ -770,20 +855,22 @@ int IaiDriver::solve_level(int L, std::vector<Quad1D>& quads) {
                     // the top panel is needed now; with a fixed tolerance so is every panel whose own error plus the
                     // errors of all smaller panels exceeds it (they are certain to be popped: see the header comment)
                     const size_t hn = q.heap.size();
-                    if (speculate && rt == 0.0 && unlimited && hn > 1) {
+                    const double need = tol * (1.0 + 1e-9);
+                    // (cheap exit first: near convergence the panels below the top no longer add up to the tolerance)
+                    if (speculate && rt == 0.0 && unlimited && hn > 1 && q.E - q.heap[0].E > need) {
                         order.resize(hn);
-                        for (size_t h = 0; h < hn; ++h) order[h] = (uint32_t)h;
-                        std::stable_sort(order.begin(), order.end(),
-                                         [&](uint32_t u, uint32_t v) { return q.heap[u].E > q.heap[v].E; });
+                        for (size_t h = 0; h < hn; ++h) order[h] = {q.heap[h].E, (uint32_t)h};
+                        std::sort(order.begin(), order.end(), [](const std::pair<double, uint32_t>& u, const std::pair<double, uint32_t>& v) {
+                            return u.first > v.first || (u.first == v.first && u.second < v.second);
+                        });
                         suffix.resize(hn);
                         double acc = 0.0;
                         for (size_t h = hn; h-- > 0;) {  // small errors first: S_k = sum_{j >= k} E_j
-                            acc += q.heap[order[h]].E;
+                            acc += order[h].first;
                             suffix[h] = acc;
                         }
-                        const double need = tol * (1.0 + 1e-9);
                         for (size_t h = 0; h < hn && suffix[h] > need; ++h)
-                            if (q.heap[order[h]].state == 0) q.req.push_back(order[h]);
+                            if (q.heap[order[h].second].state == 0) q.req.push_back(order[h].second);
                     }
                     if (q.heap[0].state == 0 && std::find(q.req.begin(), q.req.end(), 0u) == q.req.end()) q.req.push_back(0u);
                     for (uint32_t h : q.req) {
@@ -932,11 +1019,11 @@ int abz_iai_solve_many(abz_series* s, int lims_kind, const double* lim_a, const 
     if (drv.stats) {
         fprintf(stderr, "[abz iai] rounds per level:");
         for (int L = 1; L <= s->d; ++L) fprintf(stderr, " L%d=%lld", L, (long long)drv.st_rounds[L]);
-        fprintf(stderr, "\n[abz iai] innermost launches by size: 2^b integrals | launches | integrals | seconds\n");
+        fprintf(stderr, "\n[abz iai] host waited %.3f s for the GPU; innermost launches by size: 2^b integrals | launches | integrals\n",
+                drv.st_wait);
         for (int b = 0; b < 40; ++b)
             if (drv.st_cnt[b])
-                fprintf(stderr, "[abz iai]   2^%-2d %9lld %12lld %9.3f\n", b, (long long)drv.st_cnt[b], (long long)drv.st_int[b],
-                        drv.st_sec[b]);
+                fprintf(stderr, "[abz iai]   2^%-2d %9lld %12lld\n", b, (long long)drv.st_cnt[b], (long long)drv.st_int[b]);
     }
     for (int r = 0; r < n_sweep; ++r) {
         for (int c = 0; c < drv.ncomp; ++c) {
