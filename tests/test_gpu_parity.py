@@ -894,12 +894,17 @@ def test_config5_synthetic_16_band(abz):
     ptr = abz.solve(abz.IntegralProblem(f, bz, abz.MixedParameters(0.2)), abz.PTR(npt=12)).u
     ref = orc.solve_ptr(so, orc.load_bz("FBZ", np.eye(3)), orc.f_dos(0.05, 0.2), npt=12).u
     assert abs(ptr - ref) <= 1e-9 * abs(ref)
-    # IAI at abstol = 0.1 (2e-4 of the value ~ 481 = DOS * |det B|; ~4e8 inner nodes) vs a converged PTR
-    # grid.  Nested GK accumulates the inner integrals' errors, so the bar is 5x the requested abstol
-    # (a loose abstol = 1 is fooled by the eta = 0.05 peaks exactly like the reference's algorithm).
-    sol = abz.solve(abz.IntegralProblem(f, bz, abz.MixedParameters(0.2)), abz.EvalCounter(abz.IAI()), abstol=0.1, reltol=0.0)
-    big = abz.solve(abz.IntegralProblem(f, bz, abz.MixedParameters(0.2)), abz.PTR(npt=120)).u
-    assert abs(sol.u - big) < 0.5 and sol.numevals >= 15**3 and sol.resid <= 0.1
+    # IAI at SURVEY 8d's / BASELINE's abstol = 1e-3 (2e-6 of the value ~ 481 = DOS * |det B|; 5.5e9 inner nodes in
+    # ~12 s) against store-free PTR sums on grids where the eta = 0.05 peaks are resolved (npt = 240 and 300 agree to
+    # 8e-4).  Nested GK accumulates the inner integrals' errors, so the bar is 3x the requested abstol.
+    sol = abz.solve(abz.IntegralProblem(f, bz, abz.MixedParameters(0.2)), abz.EvalCounter(abz.IAI()), abstol=1e-3, reltol=0.0)
+    dev = s.device()
+    big = dev.ptr_sum(300, abz._lib.F_DOS, [0.05], [0.2])[0, 0].real * abs(np.linalg.det(bz.B))
+    mid = dev.ptr_sum(240, abz._lib.F_DOS, [0.05], [0.2])[0, 0].real * abs(np.linalg.det(bz.B))
+    assert abs(big - mid) < 2e-3
+    assert abs(sol.u - big) < 3e-3 and sol.resid <= 1e-3
+    # the round-1 driver (one panel per round, 46.7 s) counted 5 499 590 985 at this tolerance: same decisions
+    assert abs(sol.numevals - 5499590985) <= 5499590985 // 1000
 
 
 # ------------------------------------------------------------------ SVO (configs 3 / 4)
