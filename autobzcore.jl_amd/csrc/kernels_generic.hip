@@ -562,6 +562,172 @@ __device__ __forceinline__ void panel_inverse_row(const double2* coef, int n, in
     panel_invert_rows<NP, PAD>(n, r, ar, ai);
 }
 
+
+// ------------------------------------------------------------------------------------------
+// "Duo" layout of the panel kernels: a node is owned by LPN = NP/2 lanes, lane q holding rows q and q + LPN of the
+// zero-padded NP x NP matrix.  The Gauss-Jordan pivot row is broadcast ONCE per pivot for the two rows it updates in
+// every lane, so the cross-lane traffic per node halves: with one row per lane the kernels sat at ~57 % VALU and ~57 %
+// LDS-crossbar occupancy at the same time (profiles/r02a_bands16_pmc_summary.json: 0.48 LDS instructions -- mostly
+// ds_swizzle -- per VALU instruction), i.e. bounded by the sum of the two; f64 MFMA does not help here: it issues on
+// the same f64 units as v_fma_f64 (tools/micro/valutest.hip: 16 MFMA 16x16x4 + 64 FMA take the SUM of their times).
+// Registers: 4 x NP doubles for the rows + the travelling pivot row chunk: 2 waves/SIMD at NP = 16.
+// ------------------------------------------------------------------------------------------
+template <int NP>
+__device__ __forceinline__ void duo_series_rows(const double2* coef, int M, double zr, double zi, double pr, double pi, int q,
+                                                double (&a0r)[NP], double (&a0i)[NP], double (&a1r)[NP], double (&a1i)[NP]) {
+    constexpr int LPN = NP / 2;
+#pragma unroll
+    for (int j = 0; j < NP; ++j) {
+        a0r[j] = 0.0;
+        a0i[j] = 0.0;
+        a1r[j] = 0.0;
+        a1i[j] = 0.0;
+    }
+    for (int m = 0; m < M; ++m) {
+        const double2* __restrict__ cm = coef + (size_t)m * (NP * NP) + q;
+#pragma unroll
+        for (int j0 = 0; j0 < NP; j0 += 4) {
+            double2 c[8];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                c[2 * j] = cm[NP * (j0 + j)];
+                c[2 * j + 1] = cm[NP * (j0 + j) + LPN];
+            }
+            pin8(c);  // eight reads in flight, one wait
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {  // A = z I - H: accumulate -H
+                a0r[j0 + j] = fma(-c[2 * j].x, pr, a0r[j0 + j]);
+                a0r[j0 + j] = fma(c[2 * j].y, pi, a0r[j0 + j]);
+                a0i[j0 + j] = fma(-c[2 * j].x, pi, a0i[j0 + j]);
+                a0i[j0 + j] = fma(-c[2 * j].y, pr, a0i[j0 + j]);
+                a1r[j0 + j] = fma(-c[2 * j + 1].x, pr, a1r[j0 + j]);
+                a1r[j0 + j] = fma(c[2 * j + 1].y, pi, a1r[j0 + j]);
+                a1i[j0 + j] = fma(-c[2 * j + 1].x, pi, a1i[j0 + j]);
+                a1i[j0 + j] = fma(-c[2 * j + 1].y, pr, a1i[j0 + j]);
+            }
+        }
+        const double nr = pr * zr - pi * zi, ni = pr * zi + pi * zr;
+        pr = nr;
+        pi = ni;
+    }
+}
+
+// rows q and q + LPN of A = (sw + i eta) I - H from the rows of -H; padding rows (>= n) are identity rows
+template <int NP>
+__device__ __forceinline__ void duo_shift_rows(int n, double sw, double eta, int q, double (&a0r)[NP], double (&a0i)[NP],
+                                               double (&a1r)[NP], double (&a1i)[NP]) {
+    constexpr int LPN = NP / 2;
+    const double d0r = (q < n) ? sw : 1.0, d0i = (q < n) ? eta : 0.0;
+    const double d1r = (q + LPN < n) ? sw : 1.0, d1i = (q + LPN < n) ? eta : 0.0;
+#pragma unroll
+    for (int j = 0; j < LPN; ++j) {
+        a0r[j] += (j == q) ? d0r : 0.0;
+        a0i[j] += (j == q) ? d0i : 0.0;
+        a1r[j + LPN] += (j == q) ? d1r : 0.0;
+        a1i[j + LPN] += (j == q) ? d1i : 0.0;
+    }
+}
+
+// one Gauss-Jordan pivot (column C): the pivot row is row C / LPN of lane C % LPN; it travels CH columns at a time
+// (the chunk that holds the pivot first)
+template <int NP, int C>
+__device__ __forceinline__ void duo_pivot(int q, double (&a0r)[NP], double (&a0i)[NP], double (&a1r)[NP], double (&a1i)[NP]) {
+    constexpr int LPN = NP / 2, OWN = C % LPN, WHICH = C / LPN;
+    constexpr int CH = NP >= 16 ? 4 : 8;
+    constexpr int NB = NP / CH;
+    double g0r = 0.0, g0i = 0.0, g1r = 0.0, g1i = 0.0, ipr = 0.0, ipi = 0.0;
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+        const int j0 = CH * ((C / CH + b) % NB);
+        double ur[CH], ui[CH];
+#pragma unroll
+        for (int j = 0; j < CH; ++j) {
+            ur[j] = group_bcast<LPN, OWN>(WHICH ? a1r[j0 + j] : a0r[j0 + j]);
+            ui[j] = group_bcast<LPN, OWN>(WHICH ? a1i[j0 + j] : a0i[j0 + j]);
+        }
+        if (b == 0) {
+            const double pr = ur[C % CH], pi = ui[C % CH];
+            const double inv = rcp_nr(pr * pr + pi * pi);
+            ipr = pr * inv;
+            ipi = -pi * inv;  // 1 / pivot
+            // g = -f / p for the other rows, 1/p - 1 for the pivot row itself
+            g0r = -(a0r[C] * ipr - a0i[C] * ipi);
+            g0i = -(a0r[C] * ipi + a0i[C] * ipr);
+            g1r = -(a1r[C] * ipr - a1i[C] * ipi);
+            g1i = -(a1r[C] * ipi + a1i[C] * ipr);
+            const bool mine = q == OWN;
+            if (WHICH == 0) {
+                g0r = mine ? ipr - 1.0 : g0r;
+                g0i = mine ? ipi : g0i;
+            } else {
+                g1r = mine ? ipr - 1.0 : g1r;
+                g1i = mine ? ipi : g1i;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < CH; ++j) {
+            if (j0 + j != C) {
+                a0r[j0 + j] = fma(g0r, ur[j], a0r[j0 + j]);
+                a0r[j0 + j] = fma(-g0i, ui[j], a0r[j0 + j]);
+                a0i[j0 + j] = fma(g0r, ui[j], a0i[j0 + j]);
+                a0i[j0 + j] = fma(g0i, ur[j], a0i[j0 + j]);
+                a1r[j0 + j] = fma(g1r, ur[j], a1r[j0 + j]);
+                a1r[j0 + j] = fma(-g1i, ui[j], a1r[j0 + j]);
+                a1i[j0 + j] = fma(g1r, ui[j], a1i[j0 + j]);
+                a1i[j0 + j] = fma(g1i, ur[j], a1i[j0 + j]);
+            }
+        }
+    }
+    const bool mine = q == OWN;
+    a0r[C] = (mine && WHICH == 0) ? ipr : g0r;
+    a0i[C] = (mine && WHICH == 0) ? ipi : g0i;
+    a1r[C] = (mine && WHICH == 1) ? ipr : g1r;
+    a1i[C] = (mine && WHICH == 1) ? ipi : g1i;
+}
+
+template <int NP, int... C>
+__device__ __forceinline__ void duo_pivots(int q, double (&a0r)[NP], double (&a0i)[NP], double (&a1r)[NP], double (&a1i)[NP],
+                                           std::integer_sequence<int, C...>) {
+    (duo_pivot<NP, C>(q, a0r, a0i, a1r, a1i), ...);
+}
+
+// trace of the inverse over the real n x n block (sum over the node's LPN lanes; every lane gets it)
+template <int NP>
+__device__ __forceinline__ void duo_trace(const double (&a0r)[NP], const double (&a0i)[NP], const double (&a1r)[NP],
+                                          const double (&a1i)[NP], int n, int q, double& tr, double& ti) {
+    constexpr int LPN = NP / 2;
+    tr = 0.0;
+    ti = 0.0;
+    // (plain selects: nested branches on the lane-dependent row index here cost the kernel 60 registers)
+    const double m0 = q < n ? 1.0 : 0.0, m1 = q + LPN < n ? 1.0 : 0.0;
+#pragma unroll
+    for (int j = 0; j < LPN; ++j) {
+        tr += (j == q) ? m0 * a0r[j] + m1 * a1r[j + LPN] : 0.0;
+        ti += (j == q) ? m0 * a0i[j] + m1 * a1i[j + LPN] : 0.0;
+    }
+#pragma unroll
+    for (int off = LPN / 2; off > 0; off >>= 1) {
+        tr += __shfl_xor(tr, off, 64);
+        ti += __shfl_xor(ti, off, 64);
+    }
+}
+
+// tr inv((sw + i eta) I - H(x)) for the node owned by this lane's LPN-lane group (zero-padded staged set).
+// Not inlined: as part of the adaptive kernel's body the register allocator spilled ~260 VGPRs at the 256-register
+// budget of 2 waves/SIMD, on its own the function needs ~200.
+template <int NP>
+__device__ __attribute__((noinline)) void duo_inverse_trace(const double2* coef, int n, int M, int first, double xx, double sw,
+                                                            double eta, int q, double& tr, double& ti) {
+    double zr, zi, pr, pi;
+    sincospi(2.0 * xx, &zi, &zr);
+    sincospi(2.0 * ((double)first * xx), &pi, &pr);
+    double a0r[NP], a0i[NP], a1r[NP], a1i[NP];
+    duo_series_rows<NP>(coef, M, zr, zi, pr, pi, q, a0r, a0i, a1r, a1i);
+    duo_shift_rows<NP>(n, sw, eta, q, a0r, a0i, a1r, a1i);
+    duo_pivots<NP>(q, a0r, a0i, a1r, a1i, std::make_integer_sequence<int, NP>());
+    duo_trace<NP>(a0r, a0i, a1r, a1i, n, q, tr, ti);
+}
+
 // stage one coefficient set [M][n*n] into LDS, zero-padded to [M][NP*NP] when PAD
 template <int NP, bool PAD>
 __device__ __forceinline__ void panel_stage(double2* coef, const double2* __restrict__ src, int n, int M) {
@@ -1727,10 +1893,11 @@ __global__ __launch_bounds__(256) void gen_inner_adaptive_kernel(GenInnerArgs a,
 // Block-per-integral version of the above for the resolvent-trace integrands: the integral's coefficient
 // set is staged in LDS once and stays there for its whole adaptive loop; each round's 15 / 30 GK nodes
 // are evaluated 256/NP at a time by NP-lane groups (panel_inverse_row), thread 0 runs adapt_step.
-template <int NP, bool PAD, int NT, int WPE>
+template <int NP, bool PAD, int NT, int WPE, int RPL = 1>
 __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(WPE ? WPE : 1, WPE ? WPE : 8))) void gen_inner_panel_kernel(GenInnerArgs a) {
     extern __shared__ double2 lds_ip[];
-    constexpr int SLOTS = NT / NP;
+    constexpr int LPN = NP / RPL;  // lanes per node (RPL = 2: the duo layout, PAD only)
+    constexpr int SLOTS = NT / LPN;
     constexpr int MS = ABZ_PANEL_MAXSEG;
     const int n = a.n, nn = n * n, M = a.M, nc = a.ncomp;  // nc = 1 (DOS, TRGLOC)
     double2* coef = lds_ip;
@@ -1742,7 +1909,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(WPE ? WPE : 
     gkc* vals = seg_I + (size_t)MS * nc;
     int* heap = reinterpret_cast<int*>(vals + (size_t)30 * nc);
     double* ctl = reinterpret_cast<double*>(heap + MS);
-    const int slot = threadIdx.x / NP, r = threadIdx.x % NP;
+    const int slot = threadIdx.x / LPN, r = threadIdx.x % LPN;
     for (int64_t q = blockIdx.x; q < a.nint; q += gridDim.x) {
         AdaptStateT<1> st;
         __syncthreads();  // the previous integral's readers are done with coef / ctl
@@ -1758,15 +1925,19 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(WPE ? WPE : 
             const int nnodes = 15 * (int)ctl[0];
             for (int t0 = 0; t0 < nnodes; t0 += SLOTS) {
                 const int t = t0 + slot;
-                if (t0 + (int)(threadIdx.x >> 6) * (64 / NP) >= nnodes) continue;  // no node for this wave in the pass
+                if (t0 + (int)(threadIdx.x >> 6) * (64 / LPN) >= nnodes) continue;  // no node for this wave in the pass
                 const bool act = t < nnodes;
                 const int tt = act ? t : 0;
                 const int pnl = tt / 15, i = tt - 15 * pnl;
                 const double x = gk15_node(ctl[1 + 2 * pnl], ctl[2 + 2 * pnl], i);
-                double ar[NP], ai[NP];
-                panel_inverse_row<NP, PAD>(coef, n, M, a.first, x * a.inv_period, swq, a.p[0], r, ar, ai);
                 double tr, ti;
-                panel_trace<NP>(ar, ai, n, r, tr, ti);
+                if constexpr (RPL == 2) {
+                    duo_inverse_trace<NP>(coef, n, M, a.first, x * a.inv_period, swq, a.p[0], r, tr, ti);
+                } else {
+                    double ar[NP], ai[NP];
+                    panel_inverse_row<NP, PAD>(coef, n, M, a.first, x * a.inv_period, swq, a.p[0], r, ar, ai);
+                    panel_trace<NP>(ar, ai, n, r, tr, ti);
+                }
                 if (act && r == 0) {
                     if (a.integrand == ABZ_F_DOS) {
                         vals[t].re = -ti * 0.31830988618379067153776752674503;
@@ -1875,6 +2046,20 @@ int launch_gen_inner_adaptive(abz_ctx* ctx, const InnerSpec& is) {
     } else {            \
         ABZ_IPANEL2(NPV, false) \
     }
+            static const bool duo_off = [] { const char* e = getenv("ABZ_GEN_DUO"); return e && e[0] == '0'; }();
+            if (pad && np <= 16 && !duo_off) {
+                // duo layout: 2 rows per lane, np / 2 lanes per node, 256 threads = a round's 30 nodes in one pass at np = 16
+                const int64_t dblocks = std::min<int64_t>(is.nint, 256 * 8);
+                if (np == 8) {
+                    ABZ_HIP(hipFuncSetAttribute((const void*)gen_inner_panel_kernel<8, true, 128, 0, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)plds));
+                    hipLaunchKernelGGL((gen_inner_panel_kernel<8, true, 128, 0, 2>), dim3((unsigned)dblocks), dim3(128), plds, ctx->stream, a);
+                } else {
+                    ABZ_HIP(hipFuncSetAttribute((const void*)gen_inner_panel_kernel<16, true, 256, 2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)plds));
+                    hipLaunchKernelGGL((gen_inner_panel_kernel<16, true, 256, 2, 2>), dim3((unsigned)dblocks), dim3(256), plds, ctx->stream, a);
+                }
+                ABZ_HIP(hipGetLastError());
+                return ABZ_OK;
+            }
             const int nt = gen_inner_panel_threads(np);
             static const int wpe_env = [] { const char* e = getenv("ABZ_IPANEL_WPE"); return e ? atoi(e) : 0; }();
             const int wpe = wpe_env ? wpe_env : ((nt == 512 && np <= 16) ? 4 : 0);  // 32 rows x 2 arrays alone fill 128 VGPRs
