@@ -492,9 +492,20 @@ __device__ __forceinline__ double group_bcast(double v) {
     return __hiloint2double(hi, lo);
 }
 
+// The same broadcast on the VALU: `v_mov_b32 ... row_newbcast:C` (DPP, gfx90a+) copies lane C of every 16-lane row to the
+// whole row.  2 clk per dword next to f64 FMAs at 4 waves/SIMD (tools/micro/valutest.hip), no LDS crossbar.  At 16
+// lanes per node the pivot row costs one dword moved per FMA, so moving ALL of it to the VALU only trades an LDS bound
+// for a VALU bound: the imaginary parts travel by DPP, the real parts by swizzle, and both pipes carry half.
+template <int C>
+__device__ __forceinline__ double row16_bcast_dpp(double v) {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x150 + C, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x150 + C, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+
 // one Gauss-Jordan pivot (column C) of the zero-padded NP x NP matrix whose row r this lane holds: the pivot
 // row comes from lane C of the group, eight columns at a time (the eight that hold the pivot first)
-template <int NP, int C>
+template <int NP, int C, bool DPPI = true>
 __device__ __forceinline__ void panel_pivot(int r, double (&ar)[NP], double (&ai)[NP]) {
     constexpr int NB = NP / 8;
     double gr = 0.0, gi = 0.0, ipr = 0.0, ipi = 0.0;
@@ -505,7 +516,10 @@ __device__ __forceinline__ void panel_pivot(int r, double (&ar)[NP], double (&ai
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             ur[j] = group_bcast<NP, C>(ar[j0 + j]);
-            ui[j] = group_bcast<NP, C>(ai[j0 + j]);
+            if constexpr (NP == 16 && DPPI)
+                ui[j] = row16_bcast_dpp<C>(ai[j0 + j]);
+            else
+                ui[j] = group_bcast<NP, C>(ai[j0 + j]);
         }
         if (b == 0) {
             const double pr = ur[C % 8], pi = ui[C % 8];
@@ -2046,8 +2060,10 @@ int launch_gen_inner_adaptive(abz_ctx* ctx, const InnerSpec& is) {
     } else {            \
         ABZ_IPANEL2(NPV, false) \
     }
-            static const bool duo_off = [] { const char* e = getenv("ABZ_GEN_DUO"); return e && e[0] == '0'; }();
-            if (pad && np <= 16 && !duo_off) {
+            // opt-in (ABZ_GEN_DUO=1): measured SLOWER than one row per lane (config 5: 255 vs 420 M nodes/s) -- 2 waves/SIMD do
+            // not hide the swizzle -> FMA latency of the pivot chain and the body spills; kept as the recorded experiment
+            static const bool duo_on = [] { const char* e = getenv("ABZ_GEN_DUO"); return e && e[0] == '1'; }();
+            if (pad && np <= 16 && duo_on) {
                 // duo layout: 2 rows per lane, np / 2 lanes per node, 256 threads = a round's 30 nodes in one pass at np = 16
                 const int64_t dblocks = std::min<int64_t>(is.nint, 256 * 8);
                 if (np == 8) {
