@@ -387,6 +387,7 @@ struct EvalArgs {
     int64_t line0;  // store-free sums on a slab: global index of line 0 (for node coordinates)
     int M, first, npt, deriv, herm;
     int nt;  // non-temporal stores (rule values larger than the Infinity Cache)
+    int padw;  // write the padding columns npt..pitch-1 too (whole 128-B lines); 0: experiment ABZ_PAD_WRITE=0
     double inv_period;
     // fused last contraction (eval_grid_fused_kernel): level-2 sets and the contracted variable
     const double2* src2;
@@ -540,7 +541,7 @@ __device__ __forceinline__ void eval_unit_store(const EvalArgs& a, CMat<N> (&H)[
         // stores), then the eigenvalue stores.  With non-temporal stores on rules larger than the Infinity
         // Cache this is worth 19 % at 150^3 (neither change alone is: the interleaved order leaves the
         // store queue empty during every eigensolve, and temporal stores make the 605 MB fight for L2/MALL).
-        const int pitch = a.H.base ? a.H.pitch : a.E.pitch;
+        const int pitch = a.padw ? (a.H.base ? a.H.pitch : a.E.pitch) : a.npt;
         auto epilogue = [&](auto nt) {
             constexpr bool NT = decltype(nt)::value;
             if (a.H.base) {
@@ -912,6 +913,8 @@ int launch_eval(abz_ctx* ctx, const EvalSpec& es) {
         const PlaneView& pv = es.H.base ? es.H : es.E;
         const double bytes = 8.0 * (double)pv.tile * (double)(es.grid ? es.nlines : (es.nk + 63) / 64);
         a.nt = force >= 0 ? force : (bytes > 256.0 * 1024 * 1024 ? 1 : 0);
+        static const int padw = [] { const char* e = getenv("ABZ_PAD_WRITE"); return e ? atoi(e) : 1; }();
+        a.padw = padw;
     }
     a.src2 = es.src2;
     a.M2 = es.M2;
@@ -1630,6 +1633,7 @@ int launch_eval_sum(abz_ctx* ctx, const SumSpec& ss, double* out_reim) {
     a.deriv = 0;
     a.herm = 1;
     a.nt = 0;
+    a.padw = 1;
     a.inv_period = 1.0;
     int kpl = 2;
     {
