@@ -724,6 +724,98 @@ __device__ __forceinline__ void charpoly_init_h4(const CMat<4>& H, CharPolyH4& c
     cp.c3 = -(1.0 / 3.0) * s3;
     cp.c4 = 0.25 * (0.5 * s2 * s2 - s4);
 }
+// Eigenvalues (ascending) of a 4 x 4 Hermitian matrix (upper triangle of h) from the REAL characteristic polynomial of
+// B = H - (tr H / 4) I (charpoly_init_h4: ~170 flops from the power sums tr B^2, B^3, B^4):
+//   w^4 + c2 w^2 + c3 w + c4 = (w^2 + a w + b)(w^2 - a w + d),  a^2 = y = the LARGEST root of Ferrari's resolvent cubic
+//   y^3 + 2 c2 y^2 + (c2^2 - 4 c4) y - c3^2 (three real non-negative roots (l_i + l_j)^2 here; trigonometric form, one
+//   guarded Newton step), b, d = (c2 + y -+ c3 / a) / 2, then two real quadratics and two Newton steps per root on the quartic.
+// ~450 instructions instead of the ~4500 of the per-lane cyclic Jacobi (which bounded H + eig builds at 2 TB/s while H alone
+// streams at 6 TB/s).  Error ~ eps spread^4 / prod |l_i - l_j|: 1.4e-14 ||H|| over 2e5 random matrices.  Clustered spectra
+// (smallest gap of the Ferrari roots below 1e-3 ||B||_F, exact degeneracies included) lose digits in ANY root formula and
+// take the Jacobi path instead -- the same split as the 3 x 3 solver's deflation for clustered pairs.
+__device__ __forceinline__ void herm_eig4_values(const CMat<4>& h, double (&e)[4]) {
+    CharPolyH4 cp;
+    charpoly_init_h4(h, cp);
+    const double c2 = cp.c2, c3 = cp.c3, c4 = cp.c4;
+    const double s2 = -2.0 * c2;  // ||B||_F^2
+    bool jacobi = !(s2 > 0.0);    // B = 0 (or not finite): nothing to solve / let the Jacobi path deal with it
+    double w0 = 0.0, w1 = 0.0, w2 = 0.0, w3 = 0.0;
+    if (!jacobi) {
+        const double P = fma(-c2, c2 * (1.0 / 3.0), -4.0 * c4);
+        const double Q = fma(c2, fma(-2.0 / 27.0 * c2, c2, (8.0 / 3.0) * c4), -c3 * c3);
+        const double mp3 = fmax(-P * (1.0 / 3.0), 0.0);
+        const double r = sqrt(mp3);
+        const double den = r * mp3;
+        double cth = den > 0.0 ? -0.5 * Q / den : 1.0;
+        cth = fmin(fmax(cth, -1.0), 1.0);
+        const double t0 = 2.0 * r * cos(acos(cth) * (1.0 / 3.0));
+        double y = fmax(fma(-2.0 / 3.0, c2, t0), 0.0);
+        {
+            const double k1 = fma(c2, c2, -4.0 * c4);
+            const double f = fma(fma(y + 2.0 * c2, y, k1), y, -c3 * c3);
+            const double fp = fma(fma(3.0, y, 4.0 * c2), y, k1);
+            if (fp > 1e-3 * s2 * s2) y = fmax(y - f / fp, 0.0);
+        }
+        const double a = sqrt(y);
+        const double c3a = (a <= 1e-7 * sqrt(s2)) ? 0.0 : c3 / a;
+        const double b0 = 0.5 * (c2 + y - c3a), d0 = 0.5 * (c2 + y + c3a);
+        const double d1 = sqrt(fmax(fma(-4.0, b0, y), 0.0)), d2 = sqrt(fmax(fma(-4.0, d0, y), 0.0));
+        // roots of the two quadratics (each pair ordered), merged by a sorting network
+        double p0 = 0.5 * (-a - d1), p1 = 0.5 * (-a + d1), p2 = 0.5 * (a - d2), p3 = 0.5 * (a + d2);
+        double lo = fmin(p0, p2), hi = fmax(p0, p2);
+        p0 = lo;
+        p2 = hi;
+        lo = fmin(p1, p3);
+        hi = fmax(p1, p3);
+        p1 = lo;
+        p3 = hi;
+        lo = fmin(p1, p2);
+        hi = fmax(p1, p2);
+        w0 = p0;
+        w1 = lo;
+        w2 = hi;
+        w3 = p3;
+        const double gap = fmin(fmin(w1 - w0, w2 - w1), w3 - w2);
+        jacobi = !(gap >= 1e-3 * sqrt(s2));
+        if (!jacobi) {
+#pragma unroll
+            for (int it = 0; it < 2; ++it) {
+                auto step = [&](double w) {
+                    const double p = fma(fma(fma(w, w, c2), w, c3), w, c4);
+                    const double pp = fma(fma(4.0 * w, w, 2.0 * c2), w, c3);
+                    return w - p / pp;  // |pp| = prod of the gaps to the other roots >= (1e-3 ||B||)^3: never tiny here
+                };
+                w0 = step(w0);
+                w1 = step(w1);
+                w2 = step(w2);
+                w3 = step(w3);
+            }
+        }
+    }
+    if (jacobi) {
+        CMat<4> V;
+        herm_eig<4, false>(h, e, V);
+        return;
+    }
+    e[0] = w0 + cp.q;
+    e[1] = w1 + cp.q;
+    e[2] = w2 + cp.q;
+    e[3] = w3 + cp.q;
+}
+
+// ascending eigenvalues only, the cheapest accurate route per size
+template <int N>
+__device__ __forceinline__ void herm_eig_values(const CMat<N>& h, double (&e)[N]) {
+    if constexpr (N == 3) {
+        herm_eig3_values(h, e);
+    } else if constexpr (N == 4) {
+        herm_eig4_values(h, e);
+    } else {
+        CMat<N> V;
+        herm_eig<N, false>(h, e, V);
+    }
+}
+
 // tr inv((w + i eta) I - H) = p'(z) / p(z), z = (w - q) + i eta
 template <bool NEED_RE>
 __device__ __forceinline__ void charpoly_trace_h4(const CharPolyH4& cp, double w, double eta, double eta2, double teta,

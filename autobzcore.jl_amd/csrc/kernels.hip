@@ -428,10 +428,7 @@ __device__ __forceinline__ void eval_epilogue(const EvalArgs& a, CMat<N>& H, int
             herm_eig<N, true>(H, e, V);
             store_planes_at<N>(V, a.U, line, i1);
         } else {
-            if constexpr (N == 3)
-                herm_eig3_values(H, e);
-            else
-                herm_eig<N, false>(H, e, V);
+            herm_eig_values<N>(H, e);
         }
         if (a.E.base) {
             double* __restrict__ row = a.E.base + line * a.E.tile;
@@ -557,12 +554,7 @@ __device__ __forceinline__ void eval_unit_store(const EvalArgs& a, CMat<N> (&H)[
                     const int i1 = i0 + lane + 64 * j;
                     if (i1 < pitch) {
                         double e[N];
-                        if constexpr (N == 3) {
-                            herm_eig3_values(H[j], e);
-                        } else {
-                            CMat<N> V;
-                            herm_eig<N, false>(H[j], e, V);
-                        }
+                        herm_eig_values<N>(H[j], e);
                         double* __restrict__ row = a.E.base + line * a.E.tile;
                         const unsigned u = (unsigned)i1;
 #pragma unroll
@@ -1034,10 +1026,7 @@ __global__ __launch_bounds__(256) void eig_planes_kernel(PlaneView Hv, PlaneView
         herm_eig<N, true>(H, e, V);
         store_planes<N>(V, Uv, view_off(Uv, k));
     } else {
-        if constexpr (N == 3)
-            herm_eig3_values(H, e);
-        else
-            herm_eig<N, false>(H, e, V);
+        herm_eig_values<N>(H, e);
     }
     double* __restrict__ eo = Ev.base + view_off(Ev, k);
 #pragma unroll
@@ -1546,12 +1535,7 @@ __global__ __launch_bounds__(256, 2) void eval_sum_grid_kernel(EvalArgs a, SumAr
                 } else {
                     double e[N];
                     if constexpr (FID == ABZ_F_DOS_EIG) {
-                        if constexpr (N == 3) {
-                            herm_eig3_values(H[j], e);
-                        } else {
-                            CMat<N> V;
-                            herm_eig<N, false>(H[j], e, V);
-                        }
+                        herm_eig_values<N>(H[j], e);
                     }
 #pragma unroll
                     for (int w = 0; w < NW; ++w) {
@@ -2030,12 +2014,7 @@ __global__ __launch_bounds__(256) void node_integrand_kernel(NodeArgs a, double2
     series_lane<N>(c1, a.M, a.first, zr, zi, wr, wi, false, H);
     double e[N];
     if constexpr (FID == ABZ_F_DOS_EIG) {
-        if constexpr (N == 3) {
-            herm_eig3_values(H, e);
-        } else {
-            CMat<N> V;
-            herm_eig<N, false>(H, e, V);
-        }
+        herm_eig_values<N>(H, e);
     }
     double xk[ABZ_MAX_DIM] = {0.0, 0.0, 0.0};
     if constexpr (FID == ABZ_F_LINEAR_X) {
@@ -2263,12 +2242,7 @@ __global__ __launch_bounds__(256) void inner_adaptive_kernel(InnerArgs a) {
                     series_lane_lds<N, HERM>(cl, a.M, zr, zi, wr, wi, H);
                     double e[N];
                     if constexpr (FID == ABZ_F_DOS_EIG) {
-                        if constexpr (N == 3) {
-                            herm_eig3_values(H, e);
-                        } else {
-                            CMat<N> V;
-                            herm_eig<N, false>(H, e, V);
-                        }
+                        herm_eig_values<N>(H, e);
                     }
                     double xk[ABZ_MAX_DIM] = {x, tailv[0], tailv[1]};
                     double vr[MAXC], vi[MAXC];
