@@ -731,9 +731,20 @@ __device__ __forceinline__ void charpoly_init_h4(const CMat<4>& H, CharPolyH4& c
 //   guarded Newton step), b, d = (c2 + y -+ c3 / a) / 2, then two real quadratics and two Newton steps per root on the quartic.
 // ~450 instructions instead of the ~4500 of the per-lane cyclic Jacobi (which bounded H + eig builds at 2 TB/s while H alone
 // streams at 6 TB/s).  Error ~ eps spread^4 / prod |l_i - l_j|: 1.4e-14 ||H|| over 2e5 random matrices.  Clustered spectra
-// (smallest gap of the Ferrari roots below 1e-3 ||B||_F, exact degeneracies included) lose digits in ANY root formula and
-// take the Jacobi path instead -- the same split as the 3 x 3 solver's deflation for clustered pairs.
-__device__ __forceinline__ void herm_eig4_values(const CMat<4>& h, double (&e)[4]) {
+// (min_i |p'(w_i)| = min_i prod_j |l_i - l_j| below 2e-3 ||B||_F^3, exact degeneracies included) lose digits in ANY root
+// formula and take the Jacobi path instead -- the same split as the 3 x 3 solver's deflation for clustered pairs.
+__device__ __forceinline__ void herm_eig4_values(const CMat<4>& hin, double (&e)[4]) {
+    CMat<4> h;  // Hermitian(h): the upper triangle decides (src/dos_ggr.jl:19); register renames for Hermitian input
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+#pragma unroll
+        for (int b = a; b < 4; ++b) {
+            h.re[a][b] = hin.re[a][b];
+            h.im[a][b] = (a == b) ? 0.0 : hin.im[a][b];
+            h.re[b][a] = hin.re[a][b];
+            h.im[b][a] = (a == b) ? 0.0 : -hin.im[a][b];
+        }
+    }
     CharPolyH4 cp;
     charpoly_init_h4(h, cp);
     const double c2 = cp.c2, c3 = cp.c3, c4 = cp.c4;
@@ -775,15 +786,18 @@ __device__ __forceinline__ void herm_eig4_values(const CMat<4>& h, double (&e)[4
         w1 = lo;
         w2 = hi;
         w3 = p3;
-        const double gap = fmin(fmin(w1 - w0, w2 - w1), w3 - w2);
-        jacobi = !(gap >= 1e-3 * sqrt(s2));
+        // conditioning of root i = eps ||B||^4 / |p'(w_i)|, |p'(w_i)| = the product of its gaps to the other three: a
+        // pair 1e-3 ||B|| apart is fine, three roots at that spacing are not (1.3e-11 measured) -- bound the product
+        auto dp = [&](double w) { return fabs(fma(fma(4.0 * w, w, 2.0 * c2), w, c3)); };
+        const double ppmin = fmin(fmin(dp(w0), dp(w1)), fmin(dp(w2), dp(w3)));
+        jacobi = !(ppmin >= 2e-3 * s2 * sqrt(s2));
         if (!jacobi) {
 #pragma unroll
             for (int it = 0; it < 2; ++it) {
                 auto step = [&](double w) {
                     const double p = fma(fma(fma(w, w, c2), w, c3), w, c4);
                     const double pp = fma(fma(4.0 * w, w, 2.0 * c2), w, c3);
-                    return w - p / pp;  // |pp| = prod of the gaps to the other roots >= (1e-3 ||B||)^3: never tiny here
+                    return w - p / pp;  // |pp| = product of the gaps to the other roots >= 2e-3 ||B||^3 here
                 };
                 w0 = step(w0);
                 w1 = step(w1);
