@@ -279,6 +279,7 @@ struct IaiDriver {
     int64_t max_batch = 0;  // 0: scalar refinement; > 0: BatchIntegrand refinement with this soft cap
     bool panels15 = true;  // eval_nodes is fed whole GK panels (solve_level); the node-list ABI entry clears it
     bool speculate = true;  // request the halves of every panel that is certain to be popped (solve_level)
+    int64_t spec_cap_nodes = 131072;  // ... in rounds smaller than this
     int64_t pool_cap_bytes = (int64_t)4 << 30;  // contracted sets alive at once per level (ABZ_IAI_POOL_MB)
     int64_t launches = 0;   // innermost launches of this solve (diagnostics)
     // ABZ_IAI_STATS=1: innermost launches by size (log2 buckets): count, integrals, seconds
@@ -584,6 +585,9 @@ int IaiDriver::solve_level(int L, std::vector<Quad1D>& quads) {
         }
         vals.resize((size_t)(nn * ncomp));
         nev.resize((size_t)nn);
+        // requests ahead of the pops pay when a round is small (a single solve's stragglers); a round that fills the
+        // chip anyway (a 432-omega sweep: 4e5 nodes per round) only pays their bookkeeping (+20 % host time measured)
+        const bool spec_round = speculate && nn < spec_cap_nodes;
         // ---- evaluate them
         if (L == 1) {
             int rc = eval_nodes(nn);
@@ -857,7 +861,7 @@ int IaiDriver::solve_level(int L, std::vector<Quad1D>& quads) {
                     const size_t hn = q.heap.size();
                     const double need = tol * (1.0 + 1e-9);
                     // (cheap exit first: near convergence the panels below the top no longer add up to the tolerance)
-                    if (speculate && rt == 0.0 && unlimited && hn > 1 && q.E - q.heap[0].E > need) {
+                    if (spec_round && rt == 0.0 && unlimited && hn > 1 && q.E - q.heap[0].E > need) {
                         order.resize(hn);
                         for (size_t h = 0; h < hn; ++h) order[h] = {q.heap[h].E, (uint32_t)h};
                         std::sort(order.begin(), order.end(), [](const std::pair<double, uint32_t>& u, const std::pair<double, uint32_t>& v) {

@@ -12,6 +12,21 @@ dst = os.path.join(os.path.dirname(out), f"profiles_{tag}_summary")
 os.makedirs(dst, exist_ok=True)
 for f in glob.glob(os.path.join(out, "stats", "*", "*_kernel_stats.csv")):
     shutil.copy(f, os.path.join(dst, f"{tag}_kernel_stats.csv"))
+# the same statistics WITHOUT each kernel's first (cold: code object load, first-touch) launch of the process
+for f in glob.glob(os.path.join(out, "stats", "*", "*_kernel_trace.csv")):
+    per = collections.OrderedDict()
+    for r in csv.DictReader(open(f)):
+        per.setdefault(r["Kernel_Name"], []).append(float(r["End_Timestamp"]) - float(r["Start_Timestamp"]))
+    rows = []
+    for k, xs in per.items():
+        warm = xs[1:] if len(xs) > 1 else xs
+        rows.append((k, len(xs), sum(xs), sum(warm) / len(warm), min(warm), max(warm), xs[0]))
+    tot = sum(r[2] for r in rows) or 1.0
+    with open(os.path.join(dst, f"{tag}_kernel_stats_warm.csv"), "w", newline="") as fh:
+        w = csv.writer(fh)
+        w.writerow(["Name", "Calls", "TotalDurationNs", "WarmAverageNs", "WarmMinNs", "WarmMaxNs", "FirstLaunchNs", "Percentage"])
+        for r in sorted(rows, key=lambda r: -r[2]):
+            w.writerow([r[0], r[1], int(r[2]), round(r[3], 1), int(r[4]), int(r[5]), int(r[6]), round(100.0 * r[2] / tot, 3)])
 summary = {}
 for name in ("pmc_sq", "pmc_write", "pmc_fetch"):
     for f in glob.glob(os.path.join(out, name, "*", "*_counter_collection.csv")):
@@ -39,5 +54,5 @@ for k, ent in summary.items():
         json.dump({"kernel": k, "npt": 150, "tag": tag, "hbm_bytes_per_launch": ent["hbm_bytes_per_launch"],
                    "WRITE_SIZE_KB": ent["WRITE_SIZE"], "FETCH_SIZE_KB": ent["FETCH_SIZE"], "note": ent["hbm_bytes_note"],
                    "algorithmic_bytes_per_launch": 150**3 * 168},
-                  open(os.path.join(dst, "r01_traffic.json"), "w"), indent=1)
+                  open(os.path.join(dst, f"{tag[:3]}_traffic.json"), "w"), indent=1)
 print(json.dumps({k: v for k, v in summary.items() if "eval_grid" in k}, indent=1))
