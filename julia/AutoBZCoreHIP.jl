@@ -49,6 +49,7 @@ end
 # (abz_*_destroy only marks a handle closed while dependants still use the object).
 mutable struct HIPContext
     h::Ptr{Cvoid}
+    HIPContext(h::Ptr{Cvoid}, ::Val{:adopt}) = new(h)
     function HIPContext(device::Integer=0)
         ref = Ref{Ptr{Cvoid}}(C_NULL)
         check(ccall((:abz_ctx_create, libabz), Cint, (Cint, Ptr{Ptr{Cvoid}}), device, ref))
@@ -308,6 +309,26 @@ function update!(hs::HIPSeries, s::FourierSeries)
     GC.@preserve coef check(ccall((:abz_series_update, libabz), Cint, (Ptr{Cvoid}, Ptr{Float64}), hs.h, coef))
     foreach(rebuild!, values(hs.rules))   # cached rule values follow the coefficients (the reference rebuilds its rule per solve)
     return hs
+end
+"Context on a stream the caller owns (e.g. AMDGPU.jl's task-local HIP stream): launches are ordered with the caller's work."
+function HIPContext(device::Integer, stream::Ptr{Cvoid})
+    ref = Ref{Ptr{Cvoid}}(C_NULL)
+    check(ccall((:abz_ctx_create_on_stream, libabz), Cint, (Cint, Ptr{Cvoid}, Ptr{Ptr{Cvoid}}), device, stream, ref))
+    ctx = HIPContext(ref[], Val(:adopt))
+    finalizer(c -> ccall((:abz_ctx_destroy, libabz), Cint, (Ptr{Cvoid},), c.h), ctx)
+end
+"abz_rule_reduce with device-resident sweep values and sums (both `Ptr{Cvoid}` device addresses): no host round trip."
+function reduce_rule_device!(out_dev::Ptr{Cvoid}, r::HIPRule, f::HIPIntegrand, params::Vector{Float64}, sweep_dev::Ptr{Cvoid}, nsweep::Integer, nsyms::Integer=r.nsyms)
+    GC.@preserve params check(ccall((:abz_rule_reduce_device, libabz), Cint,
+        (Ptr{Cvoid}, Cint, Ptr{Float64}, Cint, Ptr{Cvoid}, Cint, Cint, Ptr{Cvoid}),
+        r.h, fid(f), params, length(params), sweep_dev, nsweep, nsyms, out_dev))
+    return out_dev
+end
+"Device address and size of the rule's value block (tiled planar layout, DESIGN.md section 3)."
+function values_ptr(r::HIPRule)
+    base = Ref{Ptr{Cvoid}}(C_NULL); nb = Ref{Int64}(0)
+    check(ccall((:abz_rule_values_ptr, libabz), Cint, (Ptr{Cvoid}, Ptr{Ptr{Cvoid}}, Ptr{Int64}), r.h, base, nb))
+    return base[], nb[]
 end
 rebuild!(r::HIPRule) = (check(ccall((:abz_rule_rebuild, libabz), Cint, (Ptr{Cvoid},), r.h)); r)
 

@@ -7,6 +7,7 @@ import sys
 import textwrap
 
 import numpy as np
+import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -105,3 +106,23 @@ def test_shard_indices_match_batchparam():
     groups = abz.batchparam(list(range(11)), 4)
     for r in range(4):
         assert [i[0] for i, _ in groups[r]] == shard_indices(11, 4, r)
+
+
+def test_bench_gpus_flag_starts_that_many_ranks():
+    """`python bench.py --gpus 2` (no torchrun environment) must start 2 rank processes itself -- before anything touches a
+    GPU -- and exit non-zero when they fail.  On this CPU-only box every rank stops with the product's 'needs an MI355X'
+    message: two of them prove that N ranks were started, the exit status that failures are not swallowed."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("CPU-only check (on a GPU box the same entry is exercised for real)")
+    env = dict(os.environ)
+    env.pop("WORLD_SIZE", None)
+    env.pop("RANK", None)
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1"],
+                       capture_output=True, text=True, timeout=600, env=env)
+    assert p.returncode != 0
+    assert (p.stdout + p.stderr).count("bench.py needs an MI355X") >= 2

