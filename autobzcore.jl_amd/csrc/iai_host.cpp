@@ -9,10 +9,16 @@
 // contraction / evaluation launch.  A 1-D integral's decisions depend only on its own node values,
 // so its panel tree is the one the depth-first traversal builds.
 #include <algorithm>
+#include <atomic>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
+#include <thread>
 #include <chrono>
 #include <cmath>
 #include <complex>
 #include <deque>
+#include <memory>
 #include <cstdlib>
 #include <cstring>
 #include <vector>
@@ -23,6 +29,72 @@
 namespace abz {
 
 typedef std::complex<double> cd;
+
+// A small persistent pool for the host side of the driver: the per-integral bookkeeping of a round (GK sums, heaps,
+// limits of the new integrals) is independent per integral, and in a parameter sweep it -- not the GPU -- bounds the
+// solve (432-omega sweep of the reference's demo: 0.06 s of host work beside 0.05 s of kernels).  Static partition,
+// deterministic results (every integral is handled by exactly one thread and sees only its own state).
+class HostPool {
+public:
+    explicit HostPool(int nthreads) : n_(std::max(1, nthreads)) {
+        for (int t = 1; t < n_; ++t) workers_.emplace_back([this, t] { loop(t); });
+    }
+    ~HostPool() {
+        {
+            std::lock_guard<std::mutex> lk(m_);
+            stop_ = true;
+            ++gen_;
+        }
+        cv_.notify_all();
+        for (auto& w : workers_) w.join();
+    }
+    int size() const { return n_; }
+    // fn(begin, end, tid) over [0, count) in n contiguous shares
+    void run(int64_t count, const std::function<void(int64_t, int64_t, int)>& fn) {
+        if (n_ == 1 || count < 2) {
+            fn(0, count, 0);
+            return;
+        }
+        {
+            std::lock_guard<std::mutex> lk(m_);
+            fn_ = &fn;
+            count_ = count;
+            pending_.store(n_ - 1, std::memory_order_relaxed);
+            ++gen_;
+        }
+        cv_.notify_all();
+        share(0);
+        while (pending_.load(std::memory_order_acquire) != 0) std::this_thread::yield();
+    }
+
+private:
+    void share(int t) {
+        const int64_t b = count_ * t / n_, e = count_ * (t + 1) / n_;
+        if (e > b) (*fn_)(b, e, t);
+    }
+    void loop(int t) {
+        uint64_t seen = 0;
+        while (true) {
+            {
+                std::unique_lock<std::mutex> lk(m_);
+                cv_.wait(lk, [&] { return gen_ != seen; });
+                seen = gen_;
+                if (stop_) return;
+            }
+            share(t);
+            pending_.fetch_sub(1, std::memory_order_release);
+        }
+    }
+    int n_;
+    std::vector<std::thread> workers_;
+    std::mutex m_;
+    std::condition_variable cv_;
+    uint64_t gen_ = 0;
+    bool stop_ = false;
+    const std::function<void(int64_t, int64_t, int)>* fn_ = nullptr;
+    int64_t count_ = 0;
+    std::atomic<int> pending_{0};
+};
 
 void gk15_nodes(double a, double b, double* x) {
     for (int i = 0; i < 15; ++i) x[i] = gk15_node(a, b, i);
@@ -306,8 +378,17 @@ struct IaiDriver {
     size_t flat_out_bytes(int64_t nq) const {
         return sizeof(double2) * (size_t)(nq * ncomp) + sizeof(double) * (size_t)nq + sizeof(int64_t) * (size_t)nq + sizeof(int) * (size_t)nq;
     }
+    std::unique_ptr<HostPool> pool;  // ABZ_HOST_THREADS (default 8, capped by the hardware); nullptr: serial
+    // run fn over [0, count): on the pool when the work is worth a wake-up and nothing shared is touched (polytope
+    // limits allocate from the solve's arena)
+    void par(int64_t count, bool safe, const std::function<void(int64_t, int64_t, int)>& fn) {
+        if (pool && safe && count >= 2048)
+            pool->run(count, fn);
+        else
+            fn(0, count, 0);
+    }
     hipEvent_t ev[2] = {nullptr, nullptr};
-    double st_wait = 0.0;
+    double st_wait = 0.0, st_gather = 0.0, st_describe = 0.0, st_deliver = 0.0, st_kids = 0.0, st_total = 0.0;
     ~IaiDriver() {
         for (auto e : ev)
             if (e) (void)hipEventDestroy(e);
@@ -555,36 +636,46 @@ int IaiDriver::solve_level(int L, std::vector<Quad1D>& quads) {
     std::vector<cd> vals;        // [node][ncomp] of this round
     std::vector<int64_t> nev;    // [node]: integrand evaluations beneath the node
     std::vector<Quad1D> kids;    // inner integrals of a chunk (L - 1 > 1, or host-side innermost loops)
-    std::vector<std::pair<double, uint32_t>> order;
-    std::vector<double> suffix;
-    double xs15[15];
+    std::vector<int64_t> act_off;  // first node of every active integral in this round's node list
     while (!active.empty()) {
         st_rounds[L] += 1;
         // ---- gather the nodes of all pending panels
+        const auto tg0 = std::chrono::steady_clock::now();
         int64_t nn = 0;
-        for (size_t qi : active) nn += 15 * (int64_t)quads[qi].pend.size();
+        act_off.resize(active.size());
+        for (size_t ai = 0; ai < active.size(); ++ai) {
+            act_off[ai] = nn;
+            nn += 15 * (int64_t)quads[active[ai]].pend.size();
+        }
         h_parents.resize((size_t)nn);
         h_x.resize((size_t)nn);
         node_q.resize((size_t)nn);
         if (L == 1) h_sweep.resize((size_t)nn);
         if (d > 1) h_tail.resize((size_t)(nn * (d - 1)));
         int64_t t = 0;
-        for (size_t qi : active) {
-            Quad1D& q = quads[qi];
-            for (size_t p = 0; p < q.pend.size(); ++p) {
-                gk15_nodes(q.pend[p].a, q.pend[p].b, xs15);
-                for (int i = 0; i < 15; ++i, ++t) {
-                    h_parents[(size_t)t] = q.slot;
-                    h_x[(size_t)t] = xs15[i];
-                    node_q[(size_t)t] = (uint32_t)qi;
-                    if (L == 1) h_sweep[(size_t)t] = q.sweep;
-                    if (d > 1 && L == 1)
-                        for (int j = 0; j < d - 1; ++j) h_tail[(size_t)(t * (d - 1) + j)] = q.tail[j];
+        const bool plain_lims = quads[active[0]].lims.kind <= ABZ_LIMS_TETRAHEDRAL;
+        par((int64_t)active.size(), true, [&](int64_t b, int64_t e, int) {
+            double x15[15];
+            for (int64_t ai = b; ai < e; ++ai) {
+                const size_t qi = active[(size_t)ai];
+                Quad1D& q = quads[qi];
+                int64_t tt = act_off[(size_t)ai];
+                for (size_t p = 0; p < q.pend.size(); ++p) {
+                    gk15_nodes(q.pend[p].a, q.pend[p].b, x15);
+                    for (int i = 0; i < 15; ++i, ++tt) {
+                        h_parents[(size_t)tt] = q.slot;
+                        h_x[(size_t)tt] = x15[i];
+                        node_q[(size_t)tt] = (uint32_t)qi;
+                        if (L == 1) h_sweep[(size_t)tt] = q.sweep;
+                        if (d > 1 && L == 1)
+                            for (int j = 0; j < d - 1; ++j) h_tail[(size_t)(tt * (d - 1) + j)] = q.tail[j];
+                    }
                 }
             }
-        }
+        });
         vals.resize((size_t)(nn * ncomp));
         nev.resize((size_t)nn);
+        if (stats) st_gather += std::chrono::duration<double>(std::chrono::steady_clock::now() - tg0).count();
         // requests ahead of the pops pay when a round is small (a single solve's stragglers); a round that fills the
         // chip anyway (a 432-omega sweep: 4e5 nodes per round) only pays their bookkeeping (+20 % host time measured)
         const bool spec_round = speculate && nn < spec_cap_nodes;
@@ -607,33 +698,37 @@ int IaiDriver::solve_level(int L, std::vector<Quad1D>& quads) {
                 // buffers and the set pool need no second copy.
                 std::vector<int64_t> redo_local, redo_nodes;
                 auto describe_and_enqueue = [&](int64_t c0, int64_t cn, int buf) -> int {
+                    const auto td0 = std::chrono::steady_clock::now();
+                    struct Acc { double& a; std::chrono::steady_clock::time_point t0; bool on; ~Acc() { if (on) a += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); } } acc_{st_describe, td0, stats};
                     int rc;
                     if ((rc = flat_layout(cn, need_tail, buf))) return rc;
                     std::memcpy(f_par, h_parents.data() + c0, sizeof(int64_t) * (size_t)cn);
                     std::memcpy(f_x, h_x.data() + c0, sizeof(double) * (size_t)cn);
                     s->iai_used[L - 1] = 0;  // sets of the previous chunk are dead (stream order)
                     if ((rc = contract_nodes(L, cn, 0, 0, f_par, f_x))) return rc;
-                    for (int64_t u = 0; u < cn; ++u) {
-                        const Quad1D& q = quads[node_q[(size_t)(c0 + u)]];
-                        const double x = h_x[(size_t)(c0 + u)];
-                        const Lims kl = q.lims.fix(L, x);
-                        double lo1, hi1;
-                        if (!kl.range(1, lo1, hi1)) {
-                            std::vector<double> sg;
-                            kl.segs(1, sg);
-                            lo1 = sg.front();
-                            hi1 = sg.back();  // the innermost slice of a convex domain is one interval
+                    par(cn, plain_lims, [&](int64_t ub, int64_t ue, int) {
+                        for (int64_t u = ub; u < ue; ++u) {
+                            const Quad1D& q = quads[node_q[(size_t)(c0 + u)]];
+                            const double x = h_x[(size_t)(c0 + u)];
+                            const Lims kl = q.lims.fix(L, x);
+                            double lo1, hi1;
+                            if (!kl.range(1, lo1, hi1)) {
+                                std::vector<double> sg;
+                                kl.segs(1, sg);
+                                lo1 = sg.front();
+                                hi1 = sg.back();  // the innermost slice of a convex domain is one interval
+                            }
+                            f_slot[(size_t)u] = u;
+                            f_sw[(size_t)u] = q.sweep;
+                            f_lo[(size_t)u] = lo1;
+                            f_hi[(size_t)u] = hi1;
+                            f_at[(size_t)u] = q.has_atol ? q.atol / (hi1 - lo1) : -1.0;  // ref src/fourier.jl:479-480
+                            if (need_tail) {
+                                f_tl[(size_t)(u * (d - 1))] = x;
+                                for (int j = 1; j < d - 1; ++j) f_tl[(size_t)(u * (d - 1) + j)] = q.tail[j - 1];
+                            }
                         }
-                        f_slot[(size_t)u] = u;
-                        f_sw[(size_t)u] = q.sweep;
-                        f_lo[(size_t)u] = lo1;
-                        f_hi[(size_t)u] = hi1;
-                        f_at[(size_t)u] = q.has_atol ? q.atol / (hi1 - lo1) : -1.0;  // ref src/fourier.jl:479-480
-                        if (need_tail) {
-                            f_tl[(size_t)(u * (d - 1))] = x;
-                            for (int j = 1; j < d - 1; ++j) f_tl[(size_t)(u * (d - 1) + j)] = q.tail[j - 1];
-                        }
-                    }
+                    });
                     return flat_enqueue(cn, buf);
                 };
                 const int64_t nchunks = (nn + chunk - 1) / chunk;
@@ -657,7 +752,7 @@ int IaiDriver::solve_level(int L, std::vector<Quad1D>& quads) {
                     const int64_t rn = (int64_t)std::min<size_t>((size_t)chunk, redo_nodes.size() - r0);
                     std::vector<int64_t> rp((size_t)rn);
                     std::vector<double> rx((size_t)rn);
-                    kids.assign((size_t)rn, Quad1D());
+                    kids.resize((size_t)rn);
                     for (int64_t u = 0; u < rn; ++u) {
                         const int64_t tn = redo_nodes[r0 + (size_t)u];
                         const Quad1D& q = quads[node_q[(size_t)tn]];
@@ -710,8 +805,9 @@ int IaiDriver::solve_level(int L, std::vector<Quad1D>& quads) {
                 s->iai_used[L - 1] = 0;  // sets of the previous chunk are dead
                 int rc;
                 {
+                    const auto tk0 = std::chrono::steady_clock::now();
                     if ((rc = contract_nodes(L, cn, 0, c0))) return rc;
-                    kids.assign((size_t)cn, Quad1D());
+                    kids.resize((size_t)cn);  // elements keep their vectors' capacity from earlier rounds (a fresh Quad1D costs six allocations)
                     for (int64_t u = 0; u < cn; ++u) {
                         const Quad1D& q = quads[node_q[(size_t)(c0 + u)]];
                         Quad1D& k = kids[(size_t)u];
@@ -740,6 +836,7 @@ int IaiDriver::solve_level(int L, std::vector<Quad1D>& quads) {
                     keep_par.swap(h_parents);
                     keep_x.swap(h_x);
                     keep_q.swap(node_q);
+                    if (stats) st_kids += std::chrono::duration<double>(std::chrono::steady_clock::now() - tk0).count();
                     rc = solve_level(L - 1, kids);
                     h_parents.swap(keep_par);
                     h_x.swap(keep_x);
@@ -753,11 +850,13 @@ int IaiDriver::solve_level(int L, std::vector<Quad1D>& quads) {
             }
         }
         // ---- deliver: GK sums, then replay the pops whose halves are there, then the next requests
+        const auto tv0 = std::chrono::steady_clock::now();
         std::vector<size_t> next;
-        t = 0;
-        std::vector<cd> Iseg((size_t)ncomp);
-        std::vector<Seg> got;
-        for (size_t qi : active) {
+        std::atomic<int> bad{0};
+        double bad_a = 0.0, bad_b = 0.0;
+        std::mutex bad_m;
+        auto deliver = [&](size_t qi, int64_t t, std::vector<cd>& Iseg, std::vector<Seg>& got,
+                           std::vector<std::pair<double, uint32_t>>& order, std::vector<double>& suffix) {
             Quad1D& q = quads[qi];
             const double rt = tol_r(q);
             const double at = q.has_atol ? q.atol : 0.0;
@@ -766,8 +865,12 @@ int IaiDriver::solve_level(int L, std::vector<Quad1D>& quads) {
                 Seg sg = q.pend[p];
                 gk15_evalrule(&vals[(size_t)(t * ncomp)], ncomp, sg.a, sg.b, Iseg.data(), &sg.E);
                 if (!std::isfinite(sg.E)) {
-                    set_error("IAI: integrand produced a non-finite value in (%g, %g) at level %d", sg.a, sg.b, L);
-                    return ABZ_ERR_ARG;
+                    std::lock_guard<std::mutex> lk(bad_m);
+                    if (!bad.exchange(1)) {
+                        bad_a = sg.a;
+                        bad_b = sg.b;
+                    }
+                    return;
                 }
                 sg.ioff = (int64_t)q.store.size();
                 sg.nev = 0;
@@ -791,7 +894,7 @@ int IaiDriver::solve_level(int L, std::vector<Quad1D>& quads) {
                 if (q.E <= std::max(at, rt * vnorm(q.I)) || q.numevals >= maxevals) {
                     q.done = true;
                     q.pend.clear();
-                    continue;
+                    return;
                 }
                 heapify(q.heap);
             } else if (max_batch > 0) {
@@ -900,7 +1003,6 @@ int IaiDriver::solve_level(int L, std::vector<Quad1D>& quads) {
                         q.pend.push_back(Seg{mid, par.b, 0.0, 0});
                     }
                 }
-                next.push_back(qi);
             } else {
                 // re-sum over the heap in storage order (QuadGK does this after adapt)
                 for (int c = 0; c < ncomp; ++c) q.I[(size_t)c] = q.store[(size_t)(q.heap[0].ioff + c)];
@@ -911,7 +1013,21 @@ int IaiDriver::solve_level(int L, std::vector<Quad1D>& quads) {
                 }
                 q.done = true;
             }
+        };
+        par((int64_t)active.size(), true, [&](int64_t b, int64_t e, int) {
+            std::vector<cd> Iseg((size_t)ncomp);
+            std::vector<Seg> got;
+            std::vector<std::pair<double, uint32_t>> order;
+            std::vector<double> suffix;
+            for (int64_t ai = b; ai < e; ++ai) deliver(active[(size_t)ai], act_off[(size_t)ai], Iseg, got, order, suffix);
+        });
+        if (bad.load()) {
+            set_error("IAI: integrand produced a non-finite value in (%g, %g) at level %d", bad_a, bad_b, L);
+            return ABZ_ERR_ARG;
         }
+        for (size_t qi : active)
+            if (!quads[qi].done) next.push_back(qi);
+        if (stats) st_deliver += std::chrono::duration<double>(std::chrono::steady_clock::now() - tv0).count();
         active.swap(next);
     }
     return ABZ_OK;
@@ -985,6 +1101,11 @@ int abz_iai_solve_many(abz_series* s, int lims_kind, const double* lim_a, const 
     {
         const char* e = getenv("ABZ_IAI_SPECULATE");  // 0: one panel per integral per round (the round-1 driver)
         drv.speculate = !(e && e[0] == '0');
+        const char* ht = getenv("ABZ_HOST_THREADS");
+        const int hw = (int)std::thread::hardware_concurrency();
+        int nth = ht ? atoi(ht) : 8;
+        if (hw > 0) nth = std::min(nth, std::max(1, hw / 2));
+        if (nth > 1 && n_sweep >= 8) drv.pool.reset(new HostPool(nth));  // single solves stay serial: their rounds are small
         const char* st = getenv("ABZ_IAI_STATS");
         drv.stats = st && st[0] == '1';
         const char* m = getenv("ABZ_IAI_POOL_MB");
@@ -1018,9 +1139,13 @@ int abz_iai_solve_many(abz_series* s, int lims_kind, const double* lim_a, const 
         q.has_atol = abstol >= 0;
         q.atol = abstol >= 0 ? abstol : 0.0;
     }
+    const auto tt0 = std::chrono::steady_clock::now();
     int rc = drv.solve_level(s->d, top);
     if (rc) return rc;
     if (drv.stats) {
+        fprintf(stderr, "[abz iai] host seconds: total %.3f | gather %.3f | describe+enqueue %.3f | deliver %.3f | kid setup %.3f | GPU wait %.3f\n",
+                std::chrono::duration<double>(std::chrono::steady_clock::now() - tt0).count(), drv.st_gather, drv.st_describe, drv.st_deliver,
+                drv.st_kids, drv.st_wait);
         fprintf(stderr, "[abz iai] rounds per level:");
         for (int L = 1; L <= s->d; ++L) fprintf(stderr, " L%d=%lld", L, (long long)drv.st_rounds[L]);
         fprintf(stderr, "\n[abz iai] host waited %.3f s for the GPU; innermost launches by size: 2^b integrals | launches | integrals\n",
