@@ -57,6 +57,9 @@ def parse_args():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-iai", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="primary metric + sharded jobs only")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="rehearsal: initialise the process group and run the sharded jobs even at world size 1 "
+                         "(under `python -m torch.distributed.run --nproc-per-node 1`): the RCCL calls on one GPU")
     ap.add_argument("--c5-abstol", type=float, default=1e-3, help="config 5 (16-band IAI) tolerance; SURVEY 8d: 1e-3")
     return ap.parse_args()
 
@@ -184,17 +187,18 @@ def rank_main(a):
     local = local % max(ndev, 1)
     torch.cuda.set_device(local)
     backend = os.environ.get("ABZ_DIST_BACKEND", "gloo" if rehearsal else "nccl")  # nccl = RCCL over xGMI
-    if world > 1:
+    distributed = world > 1 or a.force_dist
+    if distributed:
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local))
         else:
             dist.init_process_group(backend)
-    n_ranks_seen = dist.get_world_size() if world > 1 else 1
+    n_ranks_seen = dist.get_world_size() if distributed else 1
     assert n_ranks_seen == a.gpus, (n_ranks_seen, a.gpus)
     cdev = "cuda" if (world == 1 or backend == "nccl") else "cpu"
 
     def barrier():
-        if world > 1:
+        if distributed:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -244,7 +248,7 @@ def rank_main(a):
 
     # the same rebuild with the last contraction fused into the Fourier-eval kernel (ABZ_FUSE2=1, opt-in)
     two = None
-    if world == 1 and not a.no_extras:
+    if world == 1 and not a.no_extras and not a.force_dist:
         os.environ["ABZ_FUSE2"] = "1"
         for _ in range(max(a.warmup, 1)):
             rule.rebuild()
@@ -319,7 +323,7 @@ def rank_main(a):
         t_n1, ref256 = timed(job_n1, REPS, everyone=False)
     barrier()
     jobs = None
-    if world > 1:
+    if distributed:
         # (1) omega-sharded: replicated build, 256/N omega per rank (round-robin like batchparam), one all_gather
         idx = np.arange(256)[rank::world]
         om_mine = torch.from_numpy(om256[idx]).to(f"cuda:{local}")
@@ -387,7 +391,7 @@ def rank_main(a):
             t1 = time.perf_counter() - t0
         barrier()
         iai_job = {"n_solves": 432, "seconds_n1": t1}
-        if world > 1:
+        if distributed:
             abz.batchsolve_sharded(sol_iai, om432, device=cdev)  # warm-up at full size
             barrier()
             t0 = time.perf_counter()
@@ -402,7 +406,7 @@ def rank_main(a):
 
     # max-over-ranks timing of the primary legs
     times = torch.tensor([tA, tB, tBe], dtype=torch.float64, device=cdev)
-    if world > 1:
+    if distributed:
         dist.all_reduce(times, op=dist.ReduceOp.MAX)
     tA, tB, tBe = (float(v) for v in times.cpu())
 
@@ -422,7 +426,7 @@ def rank_main(a):
                        "npt": npt, "nk_per_gpu": nk, "passes_per_step": P, "n_bands": 3, "n_R": 1331,
                        "omegas_per_gpu": a.omegas_per_rank,
                        "parallelism": f"omega-sharded x{world}, coefficient+rule replicas"},
-            "n_ranks_seen": n_ranks_seen, "backend": ("rccl(nccl)" if backend == "nccl" else backend) if world > 1 else None,
+            "n_ranks_seen": n_ranks_seen, "backend": ("rccl(nccl)" if backend == "nccl" else backend) if distributed else None,
             "rehearsal_ranks_share_one_gpu": bool(rehearsal),
             "timed_region_seconds": tA, "ms_per_pass": build_ms,
             "ms_per_step_min_median_max": [float(step_ms.min()), float(np.median(step_ms)), float(step_ms.max())],
@@ -453,9 +457,9 @@ def rank_main(a):
                          # Hermitian rule: the scan reads the upper triangle only, n^2 doubles per k-point
                          "reduce_read_GBs": nk * (8 * n * n) / ((red_ms / max(red_n, 1)) * 1e-3) / 1e9 if red_n else None},
         }
-        if world == 1 and not a.no_extras:
+        if world == 1 and not a.no_extras and not a.force_dist:
             extras(a, abz, L, s, ctx, out, nk)
-        if not a.no_cpu and world == 1:  # the CPU leg is timed at N = 1 only
+        if not a.no_cpu and world == 1 and not a.force_dist:  # the CPU leg is timed at N = 1 only
             try:
                 cb = cpu_baseline(npt, s, a.eta)
                 out["cpu_baseline"] = cb
@@ -467,7 +471,7 @@ def rank_main(a):
             except Exception as e:  # the baseline never blocks the GPU number
                 out["cpu_baseline"] = {"error": str(e)}
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if distributed:
         dist.barrier()
         dist.destroy_process_group()
 
