@@ -1184,6 +1184,7 @@ struct ReduceArgs {
     const double* sweep;
     int64_t nk, k_offset;
     int d, npt, n_sweep, ncomp;
+    int sweep_per_row = 1 << 30;  // swept values per blockIdx.y row; default: all in row 0
     double p[4];
 };
 
@@ -1282,8 +1283,10 @@ __global__ __launch_bounds__(256, FID == ABZ_F_GLOC ? (HERM ? 2 : 1) : ((HERM ||
     constexpr int chunk = RS::chunk;
     constexpr int PW = RS::PW;
     [[maybe_unused]] double2* const T = lds + (size_t)chunk * PW * NC + (size_t)wave * RS::tile;
-    for (int s0 = 0; s0 < a.n_sweep; s0 += chunk) {
-        const int s1 = min(a.n_sweep, s0 + chunk);
+    const int sw_lo = (int)blockIdx.y * a.sweep_per_row;  // this block row's share of the sweep
+    const int sw_hi = min(a.n_sweep, sw_lo + a.sweep_per_row);
+    for (int s0 = sw_lo; s0 < sw_hi; s0 += chunk) {
+        const int s1 = min(sw_hi, s0 + chunk);
         [[maybe_unused]] const double eta2 = a.p[0] * a.p[0], teta = 2.0 * a.p[0];
         for (int s = s0; s < s1; ++s) {
             const double sw = a.sweep ? a.sweep[s] : 0.0;
@@ -1701,20 +1704,37 @@ constexpr int reduce_kt_of() {
     return 2;
 }
 
+// A block owns 256 KT nodes for the whole sweep, so a small rule leaves the chip under-filled: one rank's slab of a
+// k-sharded 150^3 grid (4.3e5 nodes at 8 GPUs) is 209 blocks on 256 CUs and its 256-omega scan took 0.20 ms, a quarter of
+// the full grid's 0.83 ms for an eighth of the work.  Rules with fewer than ~4 blocks per CU split the SWEEP over
+// blockIdx.y as well (the per-node polynomial is set up once per row: ~60 flops against
+// 27 per swept value).  KT = 2 instead of 8 was measured too: 4x the blocks but 0.227 ms -- the per-value wave reduction
+// is then amortised over 2 nodes instead of 8.
 template <int N, int FID, bool HERM>
-static int launch_reduce_h(abz_ctx* ctx, const ReduceSpec& rs, const ReduceArgs& a) {
+static int launch_reduce_h(abz_ctx* ctx, const ReduceSpec& rs, const ReduceArgs& a0) {
     constexpr int KT = reduce_kt_of<N, FID, HERM>();
     constexpr int NC = NComp<FID>::template value<N>();
     const int64_t nblocks = cdiv(rs.nk, 256 * KT);
+    ReduceArgs a = a0;
     const int64_t ncols = (int64_t)rs.n_sweep * a.ncomp;
     int rc = ctx->scratch[1].reserve(sizeof(double2) * (size_t)(nblocks * ncols));
     if (rc) return rc;
     using RS = ReduceShape<NC>;
+    int rows = 1;
+    {
+        static const int force = [] { const char* e = getenv("ABZ_REDUCE_ROWS"); return e ? atoi(e) : 0; }();
+        const int max_rows = (int)cdiv(rs.n_sweep, 16);  // at least 16 swept values per row: the node set-up stays < 15 %
+        const int want = force > 0 ? force : (int)cdiv(1024, nblocks);
+        rows = std::max(1, std::min(want, max_rows));
+        const int per = (int)cdiv(rs.n_sweep, rows);
+        a.sweep_per_row = per;
+        rows = (int)cdiv(rs.n_sweep, per);
+    }
     const size_t lds = sizeof(double2) * ((size_t)RS::chunk * RS::PW * NC + (size_t)4 * RS::tile);
     if (lds > 64 * 1024)
         ABZ_HIP(hipFuncSetAttribute((const void*)reduce_kernel<N, FID, KT, HERM>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                     (int)lds));
-    hipLaunchKernelGGL((reduce_kernel<N, FID, KT, HERM>), dim3((unsigned)nblocks), dim3(256), lds, ctx->stream, a,
+    hipLaunchKernelGGL((reduce_kernel<N, FID, KT, HERM>), dim3((unsigned)nblocks, (unsigned)rows), dim3(256), lds, ctx->stream, a,
                        ctx->scratch[1].as<double2>());
     ABZ_HIP(hipGetLastError());
     hipLaunchKernelGGL(final_reduce_kernel, dim3((unsigned)ncols), dim3(256), 0, ctx->stream, ctx->scratch[1].as<double2>(),

@@ -60,6 +60,8 @@ def parse_args():
     ap.add_argument("--force-dist", action="store_true",
                     help="rehearsal: initialise the process group and run the sharded jobs even at world size 1 "
                          "(under `python -m torch.distributed.run --nproc-per-node 1`): the RCCL calls on one GPU")
+    ap.add_argument("--big-npt", type=int, default=400, help="grid of the fine-grid 256-omega job (eta = 0.01)")
+    ap.add_argument("--no-big-job", action="store_true")
     ap.add_argument("--c5-abstol", type=float, default=1e-3, help="config 5 (16-band IAI) tolerance; SURVEY 8d: 1e-3")
     return ap.parse_args()
 
@@ -376,6 +378,14 @@ def rank_main(a):
                                   "slab_planes": [int((npt * (r + 1)) // world - (npt * r) // world) for r in range(world)]}}
         rule_k.close()
 
+    # ---------------- the same sweep at the reference example's eta = 0.01 eV on a grid that resolves it (k-sharded)
+    big_job = None
+    if not a.no_big_job:
+        try:
+            big_job = big_dos_job(a, abz, L, torch, dist, dev, rank, world, local, distributed, cdev, barrier, timed)
+        except Exception as e:
+            big_job = {"error": str(e)}
+
     # ---------------- a sweep big enough to shard by omega: 432 IAI solves on the cubic IBZ
     iai_job = None
     if not a.no_iai:
@@ -444,6 +454,8 @@ def rank_main(a):
                               "amdahl_note": f"omega-sharding replicates the {build_ms:.3f} ms build on every rank: speed-up <= "
                                              f"{1e3 * t_n1 / build_ms:.1f}x whatever N; k-sharding divides build and scan alike and is bounded "
                                              "by the all_reduce latency only"},
+            "job_256_omega_fine_grid": big_job,
+            "speedup_vs_n1_fine_grid": (big_job or {}).get("k_sharded", {}).get("speedup_vs_n1") if isinstance(big_job, dict) else None,
             "iai_sweep_432_omega": iai_job,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(npt),
@@ -474,6 +486,59 @@ def rank_main(a):
     if distributed:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def big_dos_job(a, abz, L, torch, dist, dev, rank, world, local, distributed, cdev, barrier, timed):
+    """Fixed job with enough work to divide by 8: the 256-omega DOS sweep at eta = 0.01 eV (the value of
+    aps_example/aps_example.jl:29) on the --big-npt^3 full-BZ grid (400^3 = 6.4e7 k-points, 10.8 GB of rule values:
+    a PTR grid that resolves eta = 0.01), k-sharded: 1/N slab per rank, all 256 omega, one all_reduce(sum).
+    N = 1 reference: rank 0 builds and scans the whole grid alone in the same run."""
+    npt, eta = a.big_npt, 0.01
+    om256 = np.linspace(10.0, 15.0, 256)
+    om_dev = torch.from_numpy(om256).to(f"cuda:{local}")
+    reps = 5
+    res = {"what": f"rule build on the {npt}^3 grid + DOS at 256 omega, eta = {eta} + collective + results on the host",
+           "npt": npt, "nk": npt**3, "eta": eta, "rule_bytes_n1": npt**3 * 168}
+    ref = None
+    if rank == 0:
+        full = abz.DeviceRule(dev, npt, None, L.WANT_H | L.WANT_EIG)
+        out = torch.zeros(256, 2, dtype=torch.float64, device=f"cuda:{local}")
+
+        def job1():
+            full.rebuild()
+            full.reduce_device(L.F_DOS, [eta], om_dev.data_ptr(), 256, out.data_ptr())
+            return out[:, 0].cpu().numpy()
+        t1, ref = timed(job1, reps, everyone=False)
+        full.close()
+        res["seconds_n1"] = t1
+        res["kpoint_omega_per_sec_n1"] = npt**3 * 256 / t1
+    barrier()
+    if distributed:
+        dev.kshard = (rank, world)
+        rk = abz.DeviceRule(dev, npt, None, L.WANT_H | L.WANT_EIG)
+        dev.kshard = None
+        acc = torch.zeros(256, 2, dtype=torch.float64, device=f"cuda:{local}")
+
+        def jobk():
+            rk.rebuild()
+            rk.reduce_device(L.F_DOS, [eta], om_dev.data_ptr(), 256, acc.data_ptr())
+            if cdev == "cuda":
+                dist.all_reduce(acc)
+                return acc[:, 0].cpu().numpy()
+            c = acc.cpu()
+            dist.all_reduce(c)
+            return c[:, 0].numpy()
+        tk, rkv = timed(jobk, reps)
+        tt = torch.tensor([tk], dtype=torch.float64, device=cdev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        rk.close()
+        if rank == 0:
+            tk = float(tt.cpu()[0])
+            err = float(np.abs(rkv - ref).max() / np.abs(ref).max())
+            assert err < 1e-11, err
+            res["k_sharded"] = {"seconds": tk, "speedup_vs_n1": res["seconds_n1"] / tk, "max_rel_diff_vs_n1": err,
+                                "kpoint_omega_per_sec": npt**3 * 256 / tk}
+    return res if rank == 0 else None
 
 
 def extras(a, abz, L, s, ctx, out, nk):
