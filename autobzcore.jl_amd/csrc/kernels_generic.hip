@@ -1159,7 +1159,142 @@ struct GenEigArgs {
     PlaneView H, E, U;
     int64_t nlines;
     int n, M, first, npt;
+    int tridiag = 1;  // eigenvalues only: Householder + Sturm bisection (0: the Jacobi, ABZ_GEN_EIG_JACOBI=1)
 };
+
+
+// ------------------------------------------------------------------------------------------
+// Eigenvalues only, 5..16 bands, row layout: Householder tridiagonalisation + Sturm bisection.
+// The parallel-order Jacobi above costs ~65 k instructions per four 16 x 16 matrices (~9 sweeps x 15 steps x ~480) and
+// bounded rule builds with eigenvalues at 25 M eigensolves/s; eigenvalues alone need ~1/15 of its flops:
+//   (1) n - 2 Householder reflections H = I - beta v v^H, A <- H A H by the rank-2 form A - v q^H - q v^H with
+//       p = beta A v, q = p - (beta/2)(v^H p) v.  Lane r owns row r: the column below the diagonal is one element per
+//       lane, its norm and v^H p are 16-lane sums, v and q travel by `group_bcast`.  Rows <= k are dead after step k and
+//       are not protected.  Only the diagonal d_k and |e_k|^2 = the column norms survive;
+//   (2) lane r finds the r-th smallest eigenvalue of the real symmetric tridiagonal (d, |e|) by bisection on the Sturm
+//       count (ratio form q_i = d_i - x - |e_{i-1}|^2 / q_{i-1} with the usual pivot guard), 48 halvings of the
+//       Gershgorin interval: all 64 lanes busy, no cross-lane traffic, backward stable (eps ||A|| like LAPACK's
+//       stebz), degenerate spectra included.
+// ~13 k instructions per four matrices.  Eigenvector builds (GGR) keep the Jacobi.
+// ------------------------------------------------------------------------------------------
+// column j of the two j-loops of a Householder step (j is a template parameter: `group_bcast` patterns are immediates)
+template <int NP, int J>
+__device__ __forceinline__ void hh_col_p(const double (&ar)[NP], const double (&ai)[NP], double vr, double vi, double (&vjr)[NP],
+                                         double (&vji)[NP], double& pr, double& pi) {
+    vjr[J] = group_bcast<NP, J>(vr);
+    vji[J] = group_bcast<NP, J>(vi);
+    pr = fma(ar[J], vjr[J], pr);
+    pr = fma(-ai[J], vji[J], pr);
+    pi = fma(ar[J], vji[J], pi);
+    pi = fma(ai[J], vjr[J], pi);
+}
+template <int NP, int J>
+__device__ __forceinline__ void hh_col_upd(double (&ar)[NP], double (&ai)[NP], double vr, double vi, double qr, double qi,
+                                           const double (&vjr)[NP], const double (&vji)[NP]) {
+    const double qjr = group_bcast<NP, J>(qr), qji = group_bcast<NP, J>(qi);
+    ar[J] -= (vr * qjr + vi * qji) + (qr * vjr[J] + qi * vji[J]);
+    ai[J] -= (vi * qjr - vr * qji) + (qi * vjr[J] - qr * vji[J]);
+}
+template <int NP, int K, int... JJ>
+__device__ __forceinline__ void hh_cols_p(const double (&ar)[NP], const double (&ai)[NP], double vr, double vi, double (&vjr)[NP],
+                                          double (&vji)[NP], double& pr, double& pi, std::integer_sequence<int, JJ...>) {
+    (hh_col_p<NP, K + 1 + JJ>(ar, ai, vr, vi, vjr, vji, pr, pi), ...);
+}
+template <int NP, int K, int... JJ>
+__device__ __forceinline__ void hh_cols_upd(double (&ar)[NP], double (&ai)[NP], double vr, double vi, double qr, double qi,
+                                            const double (&vjr)[NP], const double (&vji)[NP], std::integer_sequence<int, JJ...>) {
+    (hh_col_upd<NP, K + 1 + JJ>(ar, ai, vr, vi, qr, qi, vjr, vji), ...);
+}
+
+template <int NP, int K>
+__device__ __forceinline__ void hh_step(int n, int r, double (&ar)[NP], double (&ai)[NP], double (&e2)[NP]) {
+    e2[K] = 0.0;
+    if constexpr (K + 1 < NP) {
+        if (K + 1 >= n) return;  // uniform
+        const bool below = r > K && r < n;
+        const double xr = below ? ar[K] : 0.0, xi = below ? ai[K] : 0.0;  // column K below the diagonal, one element per lane
+        const double sigma = group_sum<NP>(xr * xr + xi * xi);
+        e2[K] = sigma;
+        if constexpr (K + 2 < NP) {
+            if (K + 2 >= n) return;  // the last off-diagonal: nothing left to eliminate (uniform)
+            const double x1r = group_bcast<NP, K + 1>(xr), x1i = group_bcast<NP, K + 1>(xi);
+            const double a1 = sqrt(x1r * x1r + x1i * x1i), nrm = sqrt(sigma);
+            const double ia1 = a1 > 0.0 ? 1.0 / a1 : 0.0;
+            const double phr = a1 > 0.0 ? x1r * ia1 : 1.0, phi = a1 > 0.0 ? x1i * ia1 : 0.0;
+            // v = x + phase ||x|| e_1 (no cancellation), beta = 2 / ||v||^2 = 1 / (||x|| (||x|| + |x_1|)); sigma = 0: beta = 0, a no-op
+            const double vr = (r == K + 1) ? phr * (a1 + nrm) : xr, vi = (r == K + 1) ? phi * (a1 + nrm) : xi;
+            const double den = nrm * (nrm + a1);
+            const double beta = den > 0.0 ? 1.0 / den : 0.0;
+            double vjr[NP], vji[NP];
+            double pr = 0.0, pi = 0.0;  // p_r = beta sum_{j > K} A[r][j] v_j
+            hh_cols_p<NP, K>(ar, ai, vr, vi, vjr, vji, pr, pi, std::make_integer_sequence<int, NP - K - 1>());
+            pr *= beta;
+            pi *= beta;
+            // kappa = (beta / 2) v^H p (real for Hermitian A up to rounding; the imaginary part is kept for the non-ideal case)
+            const double kr = 0.5 * beta * group_sum<NP>(vr * pr + vi * pi);
+            const double ki = 0.5 * beta * group_sum<NP>(vr * pi - vi * pr);
+            const double qr = pr - (kr * vr - ki * vi), qi = pi - (kr * vi + ki * vr);
+            // A[r][j] -= v_r conj(q_j) + q_r conj(v_j), j > K
+            hh_cols_upd<NP, K>(ar, ai, vr, vi, qr, qi, vjr, vji, std::make_integer_sequence<int, NP - K - 1>());
+        }
+    }
+}
+
+template <int NP, int... K>
+__device__ __forceinline__ void hh_steps(int n, int r, double (&ar)[NP], double (&ai)[NP], double (&e2)[NP],
+                                         std::integer_sequence<int, K...>) {
+    (hh_step<NP, K>(n, r, ar, ai, e2), ...);
+}
+
+template <int NP, int... J>
+__device__ __forceinline__ void diag_gather(const double (&ar)[NP], double (&d)[NP], std::integer_sequence<int, J...>) {
+    ((d[J] = group_bcast<NP, J>(ar[J])), ...);  // A[J][J] lives in lane J and is final after step J - 1
+}
+
+// lane r (r < n) returns the r-th smallest eigenvalue of the Hermitian matrix whose row r it holds (rows / columns >= n: padding)
+template <int NP>
+__device__ __forceinline__ double rows_eigvals_tridiag(int n, int r, double (&ar)[NP], double (&ai)[NP]) {
+    double e2[NP], d[NP];
+    hh_steps<NP>(n, r, ar, ai, e2, std::make_integer_sequence<int, NP>());
+    diag_gather<NP>(ar, d, std::make_integer_sequence<int, NP>());
+    // Gershgorin interval of the leading n x n tridiagonal block and the pivot guard
+    double lo = d[0], hi = d[0], emax = 0.0, eprev = 0.0;
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+        if (i < n) {
+            const double en = (i + 1 < n) ? sqrt(e2[i]) : 0.0;
+            lo = fmin(lo, d[i] - eprev - en);
+            hi = fmax(hi, d[i] + eprev + en);
+            emax = fmax(emax, e2[i]);
+            eprev = en;
+        }
+    }
+    const double span = fmax(fabs(lo), fabs(hi));
+    const double pivmin = fmax(2.2250738585072014e-308 * fmax(1.0, emax), 4.9e-324);
+    lo -= 2.3e-16 * span + pivmin;
+    hi += 2.3e-16 * span + pivmin;
+    const int want = r < n ? r : n - 1;
+    for (int it = 0; it < 48; ++it) {
+        const double x = 0.5 * (lo + hi);
+        int cnt = 0;
+        double q = d[0] - x;
+        q = fabs(q) < pivmin ? -pivmin : q;
+        cnt += q < 0.0 ? 1 : 0;
+#pragma unroll
+        for (int i = 1; i < NP; ++i) {
+            if (i < n) {  // uniform
+                q = fma(-e2[i - 1], rcp_nr(q), d[i] - x);
+                q = fabs(q) < pivmin ? -pivmin : q;
+                cnt += q < 0.0 ? 1 : 0;
+            }
+        }
+        if (cnt > want)
+            hi = x;
+        else
+            lo = x;
+    }
+    return 0.5 * (lo + hi);
+}
 
 template <int NP, bool PAD, bool VEC>
 __global__ __launch_bounds__(256) void gen_grid_eig_kernel(GenEigArgs a) {
@@ -1204,7 +1339,16 @@ __global__ __launch_bounds__(256) void gen_grid_eig_kernel(GenEigArgs a) {
             if (!a.E.base) continue;  // values only (uniform)
             double vr[NP], vi[NP], dg;
             int rank;
-            rows_eig<NP, VEC>(n, r, lane, hr, hi, vr, vi, dg, rank);
+            if constexpr (!VEC) {
+                if (a.tridiag) {  // eigenvalues only: Householder + Sturm bisection, lane r gets eigenvalue r
+                    dg = rows_eigvals_tridiag<NP>(n, r, hr, hi);
+                    rank = r;
+                } else {
+                    rows_eig<NP, VEC>(n, r, lane, hr, hi, vr, vi, dg, rank);
+                }
+            } else {
+                rows_eig<NP, VEC>(n, r, lane, hr, hi, vr, vi, dg, rank);
+            }
             if (wr) a.E.base[view_off(a.E, k) + (int64_t)rank * a.E.pitch] = dg;
             if constexpr (VEC) {
                 double ranks[NP];
@@ -1255,6 +1399,10 @@ static int launch_gen_grid_eig(abz_ctx* ctx, const GenSpec& gs, int np, size_t l
     a.M = gs.M;
     a.first = gs.first;
     a.npt = gs.npt;
+    {
+        static const bool jac = [] { const char* e = getenv("ABZ_GEN_EIG_JACOBI"); return e && e[0] == '1'; }();
+        a.tridiag = jac ? 0 : 1;
+    }
     const int64_t blocks = std::min<int64_t>(a.nlines, 256 * 4);
     const bool vec = gs.Uplanes.base != nullptr;
     ProfScope ps(ctx, ABZ_K_EVAL);
