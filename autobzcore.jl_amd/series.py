@@ -102,20 +102,24 @@ class DeviceSeries:
         self.rule_bytes = 0
         self.max_rule_bytes = 96 << 30  # keep rules resident in the 288 GB of HBM, LRU beyond this
         self.generation = 0  # bumped by update(): rules evaluated from older coefficients refill before use
-        self._fin = weakref.finalize(self, DeviceSeries._destroy, h, self.rules)
+        # the finalizer holds the raw handle only: passing `self.rules` kept every dropped series alive for ever
+        # (registry -> rules -> rule.dev -> this object); the library reference-counts series <- rule, so the rules'
+        # own finalizers may run before or after this one
+        self._fin = weakref.finalize(self, DeviceSeries._destroy, h)
 
     @staticmethod
-    def _destroy(h, rules):
+    def _destroy(h):
         try:
-            for r in list(rules.values()):
-                r.close()
-            rules.clear()
             if h:
                 L.lib().abz_series_destroy(h)
         except Exception:
             pass
 
     def close(self):
+        for r in list(self.rules.values()):
+            r.close()
+        self.rules.clear()
+        self.rule_bytes = 0
         self._fin()
         self._h = None
 
