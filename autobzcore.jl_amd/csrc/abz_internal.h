@@ -186,6 +186,8 @@ struct EvalSpec {
     const double2* tab;
     // node mode: explicit parents (slot per node), and either grid index gi or coordinate x
     int64_t nk;
+    const int64_t* run_start = nullptr;  // device [nruns + 1]: nodes of level-1 set i are [run_start[i], run_start[i + 1]) (grid-index lists)
+    int64_t nruns = 0;
     const int64_t* parents;
     const int32_t* gi;
     const double* x;
@@ -296,6 +298,8 @@ struct GenSpec {
     const double2* src;
     bool grid;               // node k = (line = k / npt, i1 = k % npt), slot = line
     const int64_t* parents;  // node mode
+    const int64_t* run_start = nullptr;  // node mode with grid indices: runs of nodes per coefficient set (see EvalSpec)
+    int64_t nruns = 0;
     const int32_t* gi;
     const double* x;
     const double2* tab;

@@ -248,6 +248,7 @@ struct Plan {
     std::vector<int32_t> gi[ABZ_MAX_DIM + 1];   // level L: grid index of variable L+1; [0]: nodes' i_1
     std::vector<double> xs[ABZ_MAX_DIM + 1];    // same with coordinates
     std::vector<int64_t> parent[ABZ_MAX_DIM + 1];  // level L item -> item at level L+1; [0]: node -> level-1 item
+    std::vector<int64_t> run_start;  // irregular lists, d >= 2: first node of every level-1 item (+ nk at the end)
 };
 
 static void plan_full(Plan& p, int d, int npt, int outer0, int outer_n) {
@@ -312,12 +313,20 @@ static void plan_runs(Plan& p, int d, int npt, const T* pts, int64_t nk, bool co
         p.parent[0].push_back(par0);
     }
     for (int L = 1; L < d; ++L) p.nitems[L] = (int64_t)(coords ? p.xs[L].size() : p.gi[L].size());
+    p.run_start.clear();
+    if (d >= 2) {  // nodes of a level-1 item are consecutive: item i owns [run_start[i], run_start[i + 1])
+        for (int64_t k = 0; k < nk; ++k)
+            if (k == 0 || p.parent[0][(size_t)k] != p.parent[0][(size_t)k - 1]) p.run_start.push_back(k);
+        p.run_start.push_back(nk);
+    }
 }
 
 struct PlanDev {
     DevBuf gi[ABZ_MAX_DIM + 1], xs[ABZ_MAX_DIM + 1], parent[ABZ_MAX_DIM + 1];
     DevBuf phg[ABZ_MAX_DIM + 1];  // full grids: phase table [npt][M_{L+1}] of the contraction at level L
+    DevBuf runs;                  // irregular lists: run_start
     void release() {
+        runs.release();
         for (int i = 0; i <= ABZ_MAX_DIM; ++i) {
             gi[i].release();
             xs[i].release();
@@ -337,6 +346,10 @@ static int plan_upload(abz_ctx* ctx, const Plan& p, PlanDev& pd) {
             rc = upload(ctx, pd.gi[L], p.gi[L].data(), p.gi[L].size());
         if (rc) return rc;
         rc = upload(ctx, pd.parent[L], p.parent[L].data(), p.parent[L].size());
+        if (rc) return rc;
+    }
+    if (!p.run_start.empty()) {
+        int rc = upload(ctx, pd.runs, p.run_start.data(), p.run_start.size());
         if (rc) return rc;
     }
     return ABZ_OK;
@@ -709,6 +722,10 @@ static int rule_fill(abz_rule* r) {
         es.nk = r->nk;
         es.parents = r->full ? nullptr : rp->pd.parent[0].as<int64_t>();
         es.gi = r->full ? nullptr : rp->pd.gi[0].as<int32_t>();
+        if (!r->full && !plan.run_start.empty() && !plan.coords) {  // runs of nodes per level-1 set (row kernels, n > 4)
+            es.run_start = rp->pd.runs.as<int64_t>();
+            es.nruns = (int64_t)plan.run_start.size() - 1;
+        }
         es.x = nullptr;
         es.deriv = deriv;
         es.herm = s->hermitian;

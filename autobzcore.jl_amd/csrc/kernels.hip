@@ -863,6 +863,8 @@ int launch_eval(abz_ctx* ctx, const EvalSpec& es) {
         gs.src = es.src;
         gs.grid = es.grid;
         gs.parents = es.parents;
+        gs.run_start = es.run_start;
+        gs.nruns = es.nruns;
         gs.gi = es.gi;
         gs.x = es.x;
         gs.tab = es.tab;

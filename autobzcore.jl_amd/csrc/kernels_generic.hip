@@ -1158,6 +1158,8 @@ struct GenEigArgs {
     const double2* tab;
     PlaneView H, E, U;
     int64_t nlines;
+    const int64_t* run_start = nullptr;  // irregular lists: line l owns nodes [run_start[l], run_start[l + 1]) with grid indices gi
+    const int32_t* gi = nullptr;
     int n, M, first, npt;
     int tridiag = 1;  // eigenvalues only: Householder + Sturm bisection (0: the Jacobi, ABZ_GEN_EIG_JACOBI=1)
 };
@@ -1309,11 +1311,15 @@ __global__ __launch_bounds__(256) void gen_grid_eig_kernel(GenEigArgs a) {
         __syncthreads();
         panel_stage<NP, PAD>(coef, a.src + line * ((int64_t)M * nn), n, M);
         __syncthreads();
-        for (int i0 = 0; i0 < a.npt; i0 += SLOTS) {
-            if (i0 + (int)(threadIdx.x >> 6) * (64 / NP) >= a.npt) continue;  // no node for this wave (only wave-level sync below)
+        // nodes of this coefficient set: the whole grid line, or its run of an irregular (symmetric-rule) list
+        const int64_t kbase = a.run_start ? a.run_start[line] : line * a.npt;
+        const int count = a.run_start ? (int)(a.run_start[line + 1] - kbase) : a.npt;
+        for (int i0 = 0; i0 < count; i0 += SLOTS) {
+            if (i0 + (int)(threadIdx.x >> 6) * (64 / NP) >= count) continue;  // no node for this wave (only wave-level sync below)
             const int i1 = i0 + slot;
-            const bool act = i1 < a.npt;
-            const int ic = act ? i1 : 0;
+            const bool act = i1 < count;
+            const int ii = act ? i1 : 0;
+            const int ic = a.gi ? a.gi[kbase + ii] : ii;
             const double2 z = a.tab[ic];
             const double2 w = a.tab[(int)(((unsigned)fm * (unsigned)ic) % (unsigned)a.npt)];
             double hr[NP], hi[NP];
@@ -1324,7 +1330,7 @@ __global__ __launch_bounds__(256) void gen_grid_eig_kernel(GenEigArgs a) {
                 hr[j] = real ? -hr[j] : 0.0;
                 hi[j] = real ? -hi[j] : 0.0;
             }
-            const int64_t k = line * a.npt + ic;
+            const int64_t k = kbase + ii;
             const bool wr = act && r < n;
             if (a.H.base && wr) {
                 double* ho = a.H.base + view_off(a.H, k);
@@ -1372,7 +1378,8 @@ __global__ __launch_bounds__(256) void gen_grid_eig_kernel(GenEigArgs a) {
 // full-grid rule values (and eigenvalues, Hermitian series) for 5..16 bands
 static bool gen_grid_eig_supported(const GenSpec& gs, int* np_out, size_t* lds_out, bool* pad_out) {
     static const bool off = [] { const char* e = getenv("ABZ_GEN_ROWEIG"); return e && e[0] == '0'; }();
-    if (off || !gs.grid || gs.deriv || gs.values || gs.Haos || gs.Eaos || !(gs.Eplanes.base || gs.Hplanes.base)) return false;
+    const bool runs = !gs.grid && gs.run_start && gs.gi && !gs.x && gs.nruns > 0;  // symmetric rules: runs of grid-index nodes
+    if (off || !(gs.grid || runs) || gs.deriv || gs.values || gs.Haos || gs.Eaos || !(gs.Eplanes.base || gs.Hplanes.base)) return false;
     if (gs.Eplanes.base && !gs.herm) return false;  // the Jacobi works on full rows: H(k) must be Hermitian to rounding
     static const bool vec_on = [] { const char* e = getenv("ABZ_GEN_ROWEIG_VEC"); return e && e[0] == '1'; }();
     if (gs.Uplanes.base && gs.n > 8 && !vec_on) return false;  // eigenvectors at 16 rows: the instance spills 4.6 KB, opt-in
@@ -1394,7 +1401,9 @@ static int launch_gen_grid_eig(abz_ctx* ctx, const GenSpec& gs, int np, size_t l
     a.H = gs.Hplanes;
     a.E = gs.Eplanes;
     a.U = gs.Uplanes;
-    a.nlines = gs.nnodes / gs.npt;
+    a.nlines = gs.grid ? gs.nnodes / gs.npt : gs.nruns;
+    a.run_start = gs.grid ? nullptr : gs.run_start;
+    a.gi = gs.grid ? nullptr : gs.gi;
     a.n = gs.n;
     a.M = gs.M;
     a.first = gs.first;
