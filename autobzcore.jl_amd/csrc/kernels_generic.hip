@@ -899,7 +899,14 @@ bool gen_sum_supported(int n, int M, int npt, int integrand, bool herm) {
     return sizeof(double2) * (size_t)M * n * n + rest <= 150 * 1024;
 }
 
+static bool gen_sum_tri_wanted(const SumSpec& ss);
+static int launch_gen_sum_tri(abz_ctx* ctx, const SumSpec& ss, double* out_reim);
+
 int launch_gen_sum(abz_ctx* ctx, const SumSpec& ss, double* out_reim) {
+    if (gen_sum_tri_wanted(ss)) {
+        const int rc = launch_gen_sum_tri(ctx, ss, out_reim);
+        if (rc != ABZ_ERR_UNSUPPORTED) return rc;
+    }
     const int n = ss.n, M = ss.M;
     const int np = n <= 8 ? 8 : (n <= 16 ? 16 : 32);
     const size_t rest = sizeof(double2) * (size_t)(256 / np) * 4;
@@ -1296,6 +1303,183 @@ __device__ __forceinline__ double rows_eigvals_tridiag(int n, int r, double (&ar
             lo = x;
     }
     return 0.5 * (lo + hi);
+}
+
+
+// ------------------------------------------------------------------------------------------
+// Store-free PTR sums of resolvent traces for MANY swept values (5..16 bands, Hermitian series): one Householder
+// tridiagonalisation per node, then tr inv(z I - H) = p'(z) / p(z) from the three-term recurrence of the real
+// symmetric tridiagonal (d, |e|^2) -- O(n) per swept value instead of an O(n^3) Gauss-Jordan inversion each:
+//   p_k = (z + b_k) p_{k-1} - |e_{k-1}|^2 p_{k-2},   p'_k = p_{k-1} + (z + b_k) p'_{k-1} - |e_{k-1}|^2 p'_{k-2}
+// (b = the diagonal of tridiag(-H), the row kernels carry -H).  Lane r of a node's NP lanes takes swept value r: up
+// to NP values per pass, every lane busy, no cross-lane traffic after the reduction.  Im z = eta > 0 keeps p away from
+// zero; the matrix is scaled to unit Gershgorin radius so that p stays far inside the double range for any spectrum.
+// 16 bands, 16 swept values: ~3.6 k instructions per four nodes against 16 x 1.3 k for the inversions.
+// ------------------------------------------------------------------------------------------
+struct GenSumTriArgs {
+    const double2* src;
+    const double2* tab;
+    double2* partial;  // [gridDim.x][nw]
+    int64_t nlines;
+    int n, M, first, npt, nw, is_dos;
+    double eta;
+    double sweep[16];
+};
+
+template <int NP, bool PAD>
+__global__ __launch_bounds__(256) void gen_grid_sum_tri_kernel(GenSumTriArgs a) {
+    extern __shared__ double2 lds_gt[];
+    constexpr int SLOTS = 256 / NP;
+    const int n = a.n, nn = n * n, M = a.M;
+    double2* coef = lds_gt;
+    double2* red = coef + (size_t)M * (PAD ? NP * NP : nn);  // [SLOTS][NP]
+    const int slot = threadIdx.x / NP, r = threadIdx.x % NP;
+    int fm = a.first % a.npt;
+    if (fm < 0) fm += a.npt;
+    double mysw = 0.0;  // this lane's swept value (lane r of the node takes value r)
+#pragma unroll
+    for (int q = 0; q < 16; ++q) mysw = (q == r) ? a.sweep[q] : mysw;
+    const bool lane_act = r < a.nw;
+    double accr = 0.0, acci = 0.0;
+    for (int64_t line = blockIdx.x; line < a.nlines; line += gridDim.x) {
+        __syncthreads();
+        panel_stage<NP, PAD>(coef, a.src + line * ((int64_t)M * nn), n, M);
+        __syncthreads();
+        for (int i0 = 0; i0 < a.npt; i0 += SLOTS) {
+            if (i0 + (int)(threadIdx.x >> 6) * (64 / NP) >= a.npt) continue;  // no node for this wave (wave-level sync only below)
+            const int i1 = i0 + slot;
+            const bool act = i1 < a.npt;
+            const int ic = act ? i1 : 0;
+            const double2 z = a.tab[ic];
+            const double2 w = a.tab[(int)(((unsigned)fm * (unsigned)ic) % (unsigned)a.npt)];
+            double hr[NP], hi[NP];
+            panel_series_row<NP, PAD>(coef, n, M, z.x, z.y, w.x, w.y, r, hr, hi);  // row r of B = -H(k)
+            if (!PAD) {
+#pragma unroll
+                for (int j = 0; j < NP; ++j) {
+                    const bool real = r < n && j < n;
+                    hr[j] = real ? hr[j] : 0.0;
+                    hi[j] = real ? hi[j] : 0.0;
+                }
+            }
+            double e2[NP], b[NP];
+            hh_steps<NP>(n, r, hr, hi, e2, std::make_integer_sequence<int, NP>());
+            diag_gather<NP>(hr, b, std::make_integer_sequence<int, NP>());
+            // scale: s = 1 / (Gershgorin radius of T + |z|): the recurrence runs on T / s-free numbers of size <= 1
+            double rad = 0.0, eprev = 0.0;
+#pragma unroll
+            for (int i = 0; i < NP; ++i) {
+                if (i < n) {
+                    const double en = (i + 1 < n) ? sqrt(e2[i]) : 0.0;
+                    rad = fmax(rad, fabs(b[i]) + eprev + en);
+                    eprev = en;
+                }
+            }
+            const double sc = rcp_nr(rad + fabs(mysw) + a.eta);
+            const double zr = mysw * sc, zi = a.eta * sc;
+            // p(z) = det(z I + T) and p'(z) by the three-term recurrence (everything scaled by sc)
+            double p0r = 1.0, p0i = 0.0, p1r = fma(b[0], sc, zr), p1i = zi;  // p_0, p_1
+            double q0r = 0.0, q0i = 0.0, q1r = 1.0, q1i = 0.0;              // p'_0, p'_1 (per unit of the scaled variable)
+#pragma unroll
+            for (int i = 1; i < NP; ++i) {
+                if (i < n) {  // uniform
+                    const double ar = fma(b[i], sc, zr), ai = zi;
+                    const double ee = e2[i - 1] * sc * sc;
+                    const double npr = fma(ar, p1r, fma(-ai, p1i, -ee * p0r));
+                    const double npi = fma(ar, p1i, fma(ai, p1r, -ee * p0i));
+                    const double nqr = p1r + fma(ar, q1r, fma(-ai, q1i, -ee * q0r));
+                    const double nqi = p1i + fma(ar, q1i, fma(ai, q1r, -ee * q0i));
+                    p0r = p1r;
+                    p0i = p1i;
+                    p1r = npr;
+                    p1i = npi;
+                    q0r = q1r;
+                    q0i = q1i;
+                    q1r = nqr;
+                    q1i = nqi;
+                }
+            }
+            // tr inv(z I - H) = p'(z) / p(z); the scaled variable gives sc * (q / p)
+            const double ip = rcp_nr(p1r * p1r + p1i * p1i) * sc;
+            const double tr = (q1r * p1r + q1i * p1i) * ip, ti = (q1i * p1r - q1r * p1i) * ip;
+            const bool use = act && lane_act;
+            accr += !use ? 0.0 : (a.is_dos ? -ti * 0.31830988618379067153776752674503 : tr);
+            acci += (!use || a.is_dos) ? 0.0 : ti;
+        }
+    }
+    __syncthreads();
+    red[slot * NP + r] = make_double2(accr, acci);
+    __syncthreads();
+    if (threadIdx.x < a.nw) {
+        double sr = 0.0, si = 0.0;
+        for (int sl = 0; sl < SLOTS; ++sl) {
+            sr += red[sl * NP + threadIdx.x].x;
+            si += red[sl * NP + threadIdx.x].y;
+        }
+        a.partial[(int64_t)blockIdx.x * a.nw + threadIdx.x] = make_double2(sr, si);
+    }
+}
+
+// sweeps of at least 3 values on 5..16 bands take the tridiagonal route
+static bool gen_sum_tri_wanted(const SumSpec& ss) {
+    static const bool off = [] { const char* e = getenv("ABZ_GEN_SUM_TRI"); return e && e[0] == '0'; }();
+    return !off && ss.n > 4 && ss.n <= 16 && ss.n_sweep >= 3;
+}
+
+static int launch_gen_sum_tri(abz_ctx* ctx, const SumSpec& ss, double* out_reim) {
+    const int n = ss.n, M = ss.M;
+    const int np = n <= 8 ? 8 : 16;
+    const size_t rest = sizeof(double2) * (size_t)256;  // [SLOTS][NP] partial sums
+    size_t lds = sizeof(double2) * (size_t)M * np * np + rest;
+    const bool pad = lds <= 150 * 1024;
+    if (!pad) lds = sizeof(double2) * (size_t)M * n * n + rest;
+    if (lds > 150 * 1024) return ABZ_ERR_UNSUPPORTED;
+    const int64_t blocks = std::min<int64_t>(ss.nlines, 256 * 4);
+    int rc = ctx->scratch[1].reserve(sizeof(double2) * (size_t)(blocks * 16));
+    if (rc) return rc;
+    if ((rc = ctx->scratch[2].reserve(sizeof(double2) * 16))) return rc;
+    GenSumTriArgs a;
+    a.src = ss.src;
+    a.tab = ss.tab;
+    a.partial = ctx->scratch[1].as<double2>();
+    a.nlines = ss.nlines;
+    a.n = n;
+    a.M = M;
+    a.first = ss.first;
+    a.npt = ss.npt;
+    a.is_dos = ss.integrand == ABZ_F_DOS ? 1 : 0;
+    a.eta = ss.params[0];
+    for (int s0 = 0; s0 < ss.n_sweep; s0 += np) {
+        a.nw = std::min(np, ss.n_sweep - s0);
+        for (int q = 0; q < 16; ++q) a.sweep[q] = q < a.nw ? ss.sweep_host[s0 + q] : 0.0;
+        {
+            ProfScope ps(ctx, ABZ_K_EVAL);
+            if (np == 8) {
+                if (pad) {
+                    ABZ_HIP(hipFuncSetAttribute((const void*)gen_grid_sum_tri_kernel<8, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                    hipLaunchKernelGGL((gen_grid_sum_tri_kernel<8, true>), dim3((unsigned)blocks), dim3(256), lds, ctx->stream, a);
+                } else {
+                    ABZ_HIP(hipFuncSetAttribute((const void*)gen_grid_sum_tri_kernel<8, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                    hipLaunchKernelGGL((gen_grid_sum_tri_kernel<8, false>), dim3((unsigned)blocks), dim3(256), lds, ctx->stream, a);
+                }
+            } else {
+                if (pad) {
+                    ABZ_HIP(hipFuncSetAttribute((const void*)gen_grid_sum_tri_kernel<16, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                    hipLaunchKernelGGL((gen_grid_sum_tri_kernel<16, true>), dim3((unsigned)blocks), dim3(256), lds, ctx->stream, a);
+                } else {
+                    ABZ_HIP(hipFuncSetAttribute((const void*)gen_grid_sum_tri_kernel<16, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                    hipLaunchKernelGGL((gen_grid_sum_tri_kernel<16, false>), dim3((unsigned)blocks), dim3(256), lds, ctx->stream, a);
+                }
+            }
+            ABZ_HIP(hipGetLastError());
+            rc = launch_final_reduce(ctx, a.partial, blocks, a.nw, ss.scale, ctx->scratch[2].as<double2>());
+            if (rc) return rc;
+        }
+        ABZ_HIP(hipMemcpyAsync(out_reim + 2 * (size_t)s0, ctx->scratch[2].p, sizeof(double2) * (size_t)a.nw, hipMemcpyDeviceToHost,
+                               ctx->stream));
+        ABZ_HIP(hipStreamSynchronize(ctx->stream));
+    }
+    return ABZ_OK;
 }
 
 template <int NP, bool PAD, bool VEC>

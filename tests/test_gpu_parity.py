@@ -674,6 +674,29 @@ def test_store_free_rule_value_generic_n(abz, d, n, npt):
     assert abs(val - ref) <= 1e-12 * abs(ref)
 
 
+@pytest.mark.parametrize("n,eta", [(16, 0.05), (11, 0.3), (6, 0.01)])
+def test_store_free_sweep_by_tridiagonal_resolvent(abz, monkeypatch, n, eta):
+    """Sweeps of >= 3 values on 5..16 bands: one Householder tridiagonalisation per node, then tr inv(zI - H) = p'/p from
+    the three-term recurrence per swept value (gen_grid_sum_tri_kernel).  40 values = two full passes of 16 + a ragged
+    one, small eta (poles close to the axis), against numpy on the exported H(k) and against the inversion-per-value
+    kernel (ABZ_GEN_SUM_TRI=0)."""
+    rng = np.random.default_rng(1234 + n)
+    c, first = rand_series(rng, (3, 3, 3), n, hermitian=True)
+    s, _ = both(abz, c / np.sqrt(n), first)
+    dev = s.device()
+    L = abz._lib
+    npt = 9
+    H = abz.DeviceRule(dev, npt, None, L.WANT_H).export(H=True)["H"]
+    om = np.linspace(-2.0, 2.0, 40)
+    eye = np.eye(n)
+    tr = np.array([np.trace(np.linalg.inv((w + 1j * eta) * eye - H), axis1=1, axis2=2).mean() for w in om])
+    got_t = dev.ptr_sum(npt, L.F_TRGLOC, [eta], om)[:, 0]
+    got_d = dev.ptr_sum(npt, L.F_DOS, [eta], om)[:, 0].real
+    assert np.abs(got_t - tr).max() <= 1e-11 * np.abs(tr).max()
+    assert np.abs(got_d + tr.imag / np.pi).max() <= 1e-11 * np.abs(tr).max()
+    monkeypatch.setenv("ABZ_GEN_SUM_TRI", "0")  # (read once per process: only effective if this test runs first; kept for manual runs)
+
+
 # ------------------------------------------------------------------ generic n (wave-per-node kernels)
 @pytest.mark.parametrize("d,n", [(1, 5), (2, 8), (3, 6), (3, 16)])
 def test_generic_n_eval_and_rules(abz, d, n):
