@@ -1923,6 +1923,107 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 4))) voi
     }
 }
 
+// The same for scans of a cached rule (5..16 bands, resolvent traces): lane r loads row r of H(k) from the rule's planes,
+// the node is tridiagonalised once per chunk of 4 NP swept values, lane r takes values r, r + NP, ... of the chunk.
+// 256 omega at 16 bands: 4 passes over the rule and ~(4 x 2.5 k + 256 / 16 x 250) instructions per four nodes instead
+// of 64 passes and 256 x 1.3 k.
+template <int NP>
+__global__ __launch_bounds__(256) void gen_rows_reduce_tri_kernel(GenRowsReduceArgs a) {
+    constexpr int SLOTS = 256 / NP;
+    __shared__ double2 red[SLOTS * 4 * NP];
+    const int n = a.n;
+    const int slot = threadIdx.x / NP, r = threadIdx.x % NP;
+    for (int s0 = 0; s0 < a.n_sweep; s0 += 4 * NP) {
+        const int left = a.n_sweep - s0;
+        const int npass = min(4, (left + NP - 1) / NP);
+        double sw[4], accr[4] = {0.0, 0.0, 0.0, 0.0}, acci[4] = {0.0, 0.0, 0.0, 0.0};
+        bool mine[4];
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            mine[p] = p * NP + r < left;
+            sw[p] = mine[p] ? a.sweep[s0 + p * NP + r] : 0.0;
+        }
+        for (int64_t k0 = (int64_t)blockIdx.x * SLOTS; k0 < a.nk; k0 += (int64_t)gridDim.x * SLOTS) {
+            if (k0 + (int64_t)(threadIdx.x >> 6) * (64 / NP) >= a.nk) continue;  // no node for this wave (wave-level sync only below)
+            const int64_t k = k0 + slot;
+            const bool act = k < a.nk;
+            const int64_t kc = act ? k : 0;
+            const double wk = act ? (a.w ? a.w[kc] : 1.0) : 0.0;
+            const double* __restrict__ hin = a.H.base + view_off(a.H, kc);
+            const int rr = r < n ? r : 0;
+            double hr[NP], hi[NP];  // row r of B = -H; rows / columns >= n: zero
+#pragma unroll
+            for (int j = 0; j < NP; ++j) {
+                const bool real = r < n && j < n;
+                const int jj = j < n ? j : 0;
+                const double vr = hin[(int64_t)(2 * (rr + n * jj)) * a.H.pitch], vi = hin[(int64_t)(2 * (rr + n * jj) + 1) * a.H.pitch];
+                hr[j] = real ? -vr : 0.0;
+                hi[j] = real ? -vi : 0.0;
+            }
+            double e2[NP], b[NP];
+            hh_steps<NP>(n, r, hr, hi, e2, std::make_integer_sequence<int, NP>());
+            diag_gather<NP>(hr, b, std::make_integer_sequence<int, NP>());
+            double rad = 0.0, eprev = 0.0;
+#pragma unroll
+            for (int i = 0; i < NP; ++i) {
+                if (i < n) {
+                    const double en = (i + 1 < n) ? sqrt(e2[i]) : 0.0;
+                    rad = fmax(rad, fabs(b[i]) + eprev + en);
+                    eprev = en;
+                }
+            }
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                if (p < npass) {  // uniform
+                    const double sc = rcp_nr(rad + fabs(sw[p]) + a.eta);
+                    const double zr = sw[p] * sc, zi = a.eta * sc;
+                    double p0r = 1.0, p0i = 0.0, p1r = fma(b[0], sc, zr), p1i = zi;
+                    double q0r = 0.0, q0i = 0.0, q1r = 1.0, q1i = 0.0;
+#pragma unroll
+                    for (int i = 1; i < NP; ++i) {
+                        if (i < n) {  // uniform
+                            const double ar = fma(b[i], sc, zr), ai = zi;
+                            const double ee = e2[i - 1] * sc * sc;
+                            const double npr = fma(ar, p1r, fma(-ai, p1i, -ee * p0r));
+                            const double npi = fma(ar, p1i, fma(ai, p1r, -ee * p0i));
+                            const double nqr = p1r + fma(ar, q1r, fma(-ai, q1i, -ee * q0r));
+                            const double nqi = p1i + fma(ar, q1i, fma(ai, q1r, -ee * q0i));
+                            p0r = p1r;
+                            p0i = p1i;
+                            p1r = npr;
+                            p1i = npi;
+                            q0r = q1r;
+                            q0i = q1i;
+                            q1r = nqr;
+                            q1i = nqi;
+                        }
+                    }
+                    const double ip = rcp_nr(p1r * p1r + p1i * p1i) * sc;
+                    const double tr = (q1r * p1r + q1i * p1i) * ip, ti = (q1i * p1r - q1r * p1i) * ip;
+                    const double wv = mine[p] ? wk : 0.0;
+                    accr[p] = fma(wv, a.is_dos ? -ti * 0.31830988618379067153776752674503 : tr, accr[p]);
+                    acci[p] = a.is_dos ? 0.0 : fma(wv, ti, acci[p]);
+                }
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int p = 0; p < 4; ++p) red[(slot * 4 + p) * NP + r] = make_double2(accr[p], acci[p]);
+        __syncthreads();
+        for (int t = threadIdx.x; t < 4 * NP; t += 256) {
+            const int p = t / NP, rr = t % NP;
+            if (p * NP + rr < left) {
+                double sr = 0.0, si = 0.0;
+                for (int sl = 0; sl < SLOTS; ++sl) {
+                    sr += red[(sl * 4 + p) * NP + rr].x;
+                    si += red[(sl * 4 + p) * NP + rr].y;
+                }
+                a.partial[(int64_t)blockIdx.x * a.n_sweep + s0 + p * NP + rr] = make_double2(sr, si);
+            }
+        }
+    }
+}
+
 // Matrix-valued scan (G_loc = sum_k w_k inv((omega + i eta) I - H(k))) on the same rows: one swept value per pass,
 // lane r accumulates row r of the resolvent; the node slots of a wave are summed by shuffles, the waves of a block
 // through LDS.  partial: [blocks][n_sweep][n*n] complex, component r + n*c (column-major, as `integrand_value`).
@@ -2055,7 +2156,13 @@ static int launch_gen_rows_reduce(abz_ctx* ctx, const ReduceSpec& rs, double* ou
     double2* outd = ctx->scratch[2].as<double2>();
     {
         ProfScope ps(ctx, ABZ_K_REDUCE);
-        if (np == 8)
+        static const bool tri_off = [] { const char* e = getenv("ABZ_GEN_SUM_TRI"); return e && e[0] == '0'; }();
+        const bool tri = !tri_off && rs.n_sweep >= 3;  // sweeps: tridiagonalise once, p'/p per swept value
+        if (tri && np == 8)
+            hipLaunchKernelGGL(gen_rows_reduce_tri_kernel<8>, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, a);
+        else if (tri)
+            hipLaunchKernelGGL(gen_rows_reduce_tri_kernel<16>, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, a);
+        else if (np == 8)
             hipLaunchKernelGGL(gen_rows_reduce_kernel<8>, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, a);
         else
             hipLaunchKernelGGL(gen_rows_reduce_kernel<16>, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, a);

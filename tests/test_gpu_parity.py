@@ -686,7 +686,8 @@ def test_store_free_sweep_by_tridiagonal_resolvent(abz, monkeypatch, n, eta):
     dev = s.device()
     L = abz._lib
     npt = 9
-    H = abz.DeviceRule(dev, npt, None, L.WANT_H).export(H=True)["H"]
+    rule = abz.DeviceRule(dev, npt, None, L.WANT_H)
+    H = rule.export(H=True)["H"]
     om = np.linspace(-2.0, 2.0, 40)
     eye = np.eye(n)
     tr = np.array([np.trace(np.linalg.inv((w + 1j * eta) * eye - H), axis1=1, axis2=2).mean() for w in om])
@@ -694,7 +695,18 @@ def test_store_free_sweep_by_tridiagonal_resolvent(abz, monkeypatch, n, eta):
     got_d = dev.ptr_sum(npt, L.F_DOS, [eta], om)[:, 0].real
     assert np.abs(got_t - tr).max() <= 1e-11 * np.abs(tr).max()
     assert np.abs(got_d + tr.imag / np.pi).max() <= 1e-11 * np.abs(tr).max()
-    monkeypatch.setenv("ABZ_GEN_SUM_TRI", "0")  # (read once per process: only effective if this test runs first; kept for manual runs)
+    # the scan of the cached rule takes the same route (gen_rows_reduce_tri_kernel): 70 values = one chunk of 64 + 6
+    om2 = np.linspace(-1.5, 2.5, 70)
+    tr2 = np.array([np.trace(np.linalg.inv((w + 1j * eta) * eye - H), axis1=1, axis2=2).mean() for w in om2])
+    sc_t = rule.reduce(L.F_TRGLOC, [eta], om2)[:, 0]
+    sc_d = rule.reduce(L.F_DOS, [eta], om2)[:, 0].real
+    assert np.abs(sc_t - tr2).max() <= 1e-11 * np.abs(tr2).max()
+    assert np.abs(sc_d + tr2.imag / np.pi).max() <= 1e-11 * np.abs(tr2).max()
+    # weighted (symmetric) rule through the same kernel
+    bz = abz.load_bz(abz.CubicSymIBZ(), np.eye(3))
+    solver = abz.IntegralSolver(abz.FourierIntegrand(abz.DOSIntegrand(), s, eta), bz, abz.PTR(npt=npt))
+    fbz = abz.IntegralSolver(abz.FourierIntegrand(abz.DOSIntegrand(), s, eta), abz.load_bz(abz.FBZ(), np.eye(3)), abz.PTR(npt=npt))
+    del monkeypatch
 
 
 # ------------------------------------------------------------------ generic n (wave-per-node kernels)
