@@ -97,7 +97,7 @@ int dev_alloc(void** out, size_t bytes, size_t* cap_out) {
 void dev_free(void* p, size_t cap) {
     if (!p) return;
     int device = 0;
-    (void)hipGetDevice(&device);
+    (void)hipGetDevice(&device);  // = the owner's device: every destroy / release path selects it first (hipSetDevice)
     if (cap > 0 && cap <= pool_limit() / 4) {
         (void)hipDeviceSynchronize();  // nothing in flight may still touch the block when it is reused
         std::lock_guard<std::mutex> lk(g_pool_mutex);
