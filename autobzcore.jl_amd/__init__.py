@@ -14,7 +14,7 @@ from . import dos
 from .interp import ChebInterp, hchebinterp
 from .io_w90 import load_w90_series, read_w90_hrdat, read_w90_wout
 from . import dist
-from .dist import batchsolve_sharded, sharded_map, kshard
+from .dist import batchsolve_sharded, sharded_map, kshard, iaishard
 from .io_sweep import SweepArchive, batchsolve_archive
 from .generic import fourier_batch
 from .synthetic import synthetic_wannier, tb_integer, splitmix64_uniform

@@ -53,6 +53,7 @@ PROTOTYPES = {
     "abz_iai_solve_many": (C.c_int, [C.c_void_p, C.c_int, c_f64p, c_f64p, C.c_int, c_f64p, C.c_int, c_f64p, C.c_int,
                                      C.c_double, C.c_double, C.c_int64, C.c_int64, c_f64p, c_f64p, c_i64p, c_f64p,
                                      C.c_int64, c_i64p]),
+    "abz_iai_set_exchange": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int]),
     "abz_gk15_nodes": (C.c_int, [C.c_double, C.c_double, c_f64p]),
     "abz_gk15_batch": (C.c_int, [c_f64p, c_f64p, C.c_int64, C.c_int, c_f64p, c_f64p]),
 }
@@ -63,6 +64,10 @@ F_ONE, F_LINEAR, F_LINEAR_X, F_DOS, F_TRGLOC, F_GLOC, F_DOS_EIG = range(7)
 LIMS_CUBIC, LIMS_TETRAHEDRAL, LIMS_POLYHEDRAL, LIMS_POLYGON = 0, 1, 2, 3
 K_CONTRACT, K_EVAL, K_REDUCE, K_GGR, K_EIG = range(5)
 ERR_ARG, ERR_HIP, ERR_NOGPU, ERR_UNSUPPORTED, ERR_NOMEM = -1, -2, -3, -4, -5
+
+
+# all-gather hook of a sharded IAI solve: int fn(void* user, double* buf, int64_t per_rank)
+EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), C.c_int64)
 
 
 class AbzError(RuntimeError):

@@ -106,6 +106,9 @@ struct abz_series {
     abz::DevBuf iai_pool[ABZ_MAX_DIM + 1];  // IAI: contracted sets per level, slot-addressed
     int64_t iai_used[ABZ_MAX_DIM + 1] = {0, 0, 0, 0};
     abz::DevBuf iai_io[6];                  // parents / x / tail / values / phases staging
+    abz_exchange_fn ex_fn = nullptr;  // a single IAI solve sharded over ranks: all-gather hook (abz_iai_set_exchange)
+    void* ex_user = nullptr;
+    int ex_rank = 0, ex_world = 1;
     void* iai_pin[4] = {nullptr, nullptr, nullptr, nullptr};  // pinned host blocks of the IAI driver: chunk inputs [0,1] / outputs [2,3]
     size_t iai_pin_cap[4] = {0, 0, 0, 0};
     int64_t elems(int level) const {

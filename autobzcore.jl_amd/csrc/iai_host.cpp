@@ -387,6 +387,15 @@ struct IaiDriver {
         else
             fn(0, count, 0);
     }
+    // a single solve sharded over the ranks of a process group (abz_iai_set_exchange)
+    abz_exchange_fn ex_fn = nullptr;
+    void* ex_user = nullptr;
+    int ex_rank = 0, ex_world = 1;
+    std::vector<int64_t> l_par, l_nev;
+    std::vector<double> l_x, ex_buf;
+    std::vector<uint32_t> l_q;
+    std::vector<cd> l_vals;
+    double st_exchange = 0.0;
     hipEvent_t ev[2] = {nullptr, nullptr};
     double st_wait = 0.0, st_gather = 0.0, st_describe = 0.0, st_deliver = 0.0, st_kids = 0.0, st_total = 0.0;
     ~IaiDriver() {
@@ -697,19 +706,46 @@ int IaiDriver::solve_level(int L, std::vector<Quad1D>& quads) {
                 // tolerances, slots) in the other pinned block.  Everything is ordered on one stream, so the device
                 // buffers and the set pool need no second copy.
                 std::vector<int64_t> redo_local, redo_nodes;
+                // One solve on several GPUs: the round's innermost integrals are dealt to the ranks in
+                // blocks of 64 nodes, every rank integrates its share on its own GPU, one all-gather of (value, count) per
+                // node and round puts every rank back in the same state: all ranks run this driver redundantly and take
+                // the same decisions (each integral is computed by exactly one GPU with the same kernel: the result
+                // equals the single-GPU solve bit for bit).
+                const int W = ex_world;
+                const bool shard = ex_fn != nullptr && W > 1 && nn >= (int64_t)64 * W;
+                auto owner = [W](int64_t tnode) { return (int)((tnode >> 6) % W); };
+                if (shard) {
+                    l_par.clear();
+                    l_x.clear();
+                    l_q.clear();
+                    for (int64_t tn = 0; tn < nn; ++tn)
+                        if (owner(tn) == ex_rank) {
+                            l_par.push_back(h_parents[(size_t)tn]);
+                            l_x.push_back(h_x[(size_t)tn]);
+                            l_q.push_back(node_q[(size_t)tn]);
+                        }
+                    l_vals.resize(l_x.size() * (size_t)ncomp);
+                    l_nev.resize(l_x.size());
+                }
+                const int64_t N = shard ? (int64_t)l_x.size() : nn;  // nodes this rank integrates
+                const int64_t* const P = shard ? l_par.data() : h_parents.data();
+                const double* const X = shard ? l_x.data() : h_x.data();
+                const uint32_t* const Q = shard ? l_q.data() : node_q.data();
+                cd* const V = shard ? l_vals.data() : vals.data();
+                int64_t* const NV = shard ? l_nev.data() : nev.data();
                 auto describe_and_enqueue = [&](int64_t c0, int64_t cn, int buf) -> int {
                     const auto td0 = std::chrono::steady_clock::now();
                     struct Acc { double& a; std::chrono::steady_clock::time_point t0; bool on; ~Acc() { if (on) a += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); } } acc_{st_describe, td0, stats};
                     int rc;
                     if ((rc = flat_layout(cn, need_tail, buf))) return rc;
-                    std::memcpy(f_par, h_parents.data() + c0, sizeof(int64_t) * (size_t)cn);
-                    std::memcpy(f_x, h_x.data() + c0, sizeof(double) * (size_t)cn);
+                    std::memcpy(f_par, P + c0, sizeof(int64_t) * (size_t)cn);
+                    std::memcpy(f_x, X + c0, sizeof(double) * (size_t)cn);
                     s->iai_used[L - 1] = 0;  // sets of the previous chunk are dead (stream order)
                     if ((rc = contract_nodes(L, cn, 0, 0, f_par, f_x))) return rc;
                     par(cn, plain_lims, [&](int64_t ub, int64_t ue, int) {
                         for (int64_t u = ub; u < ue; ++u) {
-                            const Quad1D& q = quads[node_q[(size_t)(c0 + u)]];
-                            const double x = h_x[(size_t)(c0 + u)];
+                            const Quad1D& q = quads[Q[(size_t)(c0 + u)]];
+                            const double x = X[(size_t)(c0 + u)];
                             const Lims kl = q.lims.fix(L, x);
                             double lo1, hi1;
                             if (!kl.range(1, lo1, hi1)) {
@@ -731,17 +767,17 @@ int IaiDriver::solve_level(int L, std::vector<Quad1D>& quads) {
                     });
                     return flat_enqueue(cn, buf);
                 };
-                const int64_t nchunks = (nn + chunk - 1) / chunk;
+                const int64_t nchunks = (N + chunk - 1) / chunk;
                 for (int64_t ci = 0; ci <= nchunks; ++ci) {
                     if (ci < nchunks) {
                         const int64_t c0 = ci * chunk;
-                        int rc = describe_and_enqueue(c0, std::min(chunk, nn - c0), (int)(ci & 1));
+                        int rc = describe_and_enqueue(c0, std::min(chunk, N - c0), (int)(ci & 1));
                         if (rc) return rc;
                     }
                     if (ci > 0) {
-                        const int64_t c0 = (ci - 1) * chunk, cn = std::min(chunk, nn - c0);
+                        const int64_t c0 = (ci - 1) * chunk, cn = std::min(chunk, N - c0);
                         redo_local.clear();
-                        int rc = flat_collect(cn, (int)((ci - 1) & 1), &vals[(size_t)(c0 * ncomp)], &nev[(size_t)c0], redo_local);
+                        int rc = flat_collect(cn, (int)((ci - 1) & 1), V + (size_t)(c0 * ncomp), NV + (size_t)c0, redo_local);
                         if (rc) return rc;
                         for (int64_t u : redo_local) redo_nodes.push_back(c0 + u);
                     }
@@ -755,10 +791,10 @@ int IaiDriver::solve_level(int L, std::vector<Quad1D>& quads) {
                     kids.resize((size_t)rn);
                     for (int64_t u = 0; u < rn; ++u) {
                         const int64_t tn = redo_nodes[r0 + (size_t)u];
-                        const Quad1D& q = quads[node_q[(size_t)tn]];
+                        const Quad1D& q = quads[Q[(size_t)tn]];
                         Quad1D& k = kids[(size_t)u];
-                        const double x = h_x[(size_t)tn];
-                        rp[(size_t)u] = h_parents[(size_t)tn];
+                        const double x = X[(size_t)tn];
+                        rp[(size_t)u] = P[(size_t)tn];
                         rx[(size_t)u] = x;
                         k.slot = u;
                         k.sweep = q.sweep;
@@ -795,8 +831,40 @@ int IaiDriver::solve_level(int L, std::vector<Quad1D>& quads) {
                     if (rc) return rc;
                     for (int64_t u = 0; u < rn; ++u) {
                         const int64_t tn = redo_nodes[r0 + (size_t)u];
-                        for (int c = 0; c < ncomp; ++c) vals[(size_t)(tn * ncomp + c)] = kids[(size_t)u].I[(size_t)c];
-                        nev[(size_t)tn] = kids[(size_t)u].fevals;
+                        for (int c = 0; c < ncomp; ++c) V[(size_t)(tn * ncomp + c)] = kids[(size_t)u].I[(size_t)c];
+                        NV[(size_t)tn] = kids[(size_t)u].fevals;
+                    }
+                }
+                if (shard) {
+                    // all-gather: per rank `per` slots of (2 ncomp + 1) doubles -- values and evaluation counts of its nodes
+                    int64_t per = 0;
+                    for (int rr = 0; rr < W; ++rr) {
+                        int64_t c = 0;
+                        for (int64_t b0 = (int64_t)rr * 64; b0 < nn; b0 += (int64_t)64 * W) c += std::min<int64_t>(64, nn - b0);
+                        per = std::max(per, c);
+                    }
+                    const int rec = 2 * ncomp + 1;
+                    ex_buf.assign((size_t)(per * rec) * (size_t)W, 0.0);
+                    double* mine = ex_buf.data() + (size_t)ex_rank * (size_t)(per * rec);
+                    for (int64_t i = 0; i < N; ++i) {
+                        for (int c = 0; c < ncomp; ++c) {
+                            mine[i * rec + 2 * c] = V[(size_t)(i * ncomp + c)].real();
+                            mine[i * rec + 2 * c + 1] = V[(size_t)(i * ncomp + c)].imag();
+                        }
+                        mine[i * rec + 2 * ncomp] = (double)NV[(size_t)i];  // exact below 2^53
+                    }
+                    const auto te0 = std::chrono::steady_clock::now();
+                    if (ex_fn(ex_user, ex_buf.data(), per * rec) != 0) {
+                        set_error("IAI: the exchange callback of a sharded solve failed");
+                        return ABZ_ERR_HIP;
+                    }
+                    if (stats) st_exchange += std::chrono::duration<double>(std::chrono::steady_clock::now() - te0).count();
+                    std::vector<int64_t> pos((size_t)W, 0);
+                    for (int64_t tn = 0; tn < nn; ++tn) {
+                        const int rr = owner(tn);
+                        const double* src = ex_buf.data() + (size_t)rr * (size_t)(per * rec) + (size_t)(pos[(size_t)rr]++ * rec);
+                        for (int c = 0; c < ncomp; ++c) vals[(size_t)(tn * ncomp + c)] = cd(src[2 * c], src[2 * c + 1]);
+                        nev[(size_t)tn] = (int64_t)src[2 * ncomp];
                     }
                 }
             } else
@@ -1101,6 +1169,10 @@ int abz_iai_solve_many(abz_series* s, int lims_kind, const double* lim_a, const 
     {
         const char* e = getenv("ABZ_IAI_SPECULATE");  // 0: one panel per integral per round (the round-1 driver)
         drv.speculate = !(e && e[0] == '0');
+        drv.ex_fn = s->ex_fn;
+        drv.ex_user = s->ex_user;
+        drv.ex_rank = s->ex_rank;
+        drv.ex_world = s->ex_world;
         const char* ht = getenv("ABZ_HOST_THREADS");
         const int hw = (int)std::thread::hardware_concurrency();
         int nth = ht ? atoi(ht) : 8;
@@ -1146,6 +1218,7 @@ int abz_iai_solve_many(abz_series* s, int lims_kind, const double* lim_a, const 
         fprintf(stderr, "[abz iai] host seconds: total %.3f | gather %.3f | describe+enqueue %.3f | deliver %.3f | kid setup %.3f | GPU wait %.3f\n",
                 std::chrono::duration<double>(std::chrono::steady_clock::now() - tt0).count(), drv.st_gather, drv.st_describe, drv.st_deliver,
                 drv.st_kids, drv.st_wait);
+        if (drv.ex_world > 1) fprintf(stderr, "[abz iai] sharded over %d ranks (this is rank %d): exchange %.3f s\n", drv.ex_world, drv.ex_rank, drv.st_exchange);
         fprintf(stderr, "[abz iai] rounds per level:");
         for (int L = 1; L <= s->d; ++L) fprintf(stderr, " L%d=%lld", L, (long long)drv.st_rounds[L]);
         fprintf(stderr, "\n[abz iai] host waited %.3f s for the GPU; innermost launches by size: 2^b integrals | launches | integrals\n",
@@ -1244,6 +1317,16 @@ int abz_eval_line_nodes(abz_series* s, const int64_t* parents, const double* x, 
     int rc = drv.eval_nodes(nnodes);
     if (rc) return rc;
     std::memcpy(values_reim, drv.h_values.data(), sizeof(double2) * (size_t)(nnodes * drv.ncomp));
+    return ABZ_OK;
+}
+
+int abz_iai_set_exchange(abz_series* s, abz_exchange_fn fn, void* user, int rank, int world) {
+    ABZ_REQUIRE(s && s->ctx && !s->closed, "abz_iai_set_exchange: null or destroyed series");
+    ABZ_REQUIRE(fn == nullptr || (world >= 1 && rank >= 0 && rank < world), "rank %d of %d", rank, world);
+    s->ex_fn = (fn && world > 1) ? fn : nullptr;
+    s->ex_user = user;
+    s->ex_rank = s->ex_fn ? rank : 0;
+    s->ex_world = s->ex_fn ? world : 1;
     return ABZ_OK;
 }
 

@@ -112,3 +112,64 @@ class kshard:
     def __exit__(self, *exc):
         self.dev.kshard, self.dev.allreduce = self._saved
         return False
+
+
+# ------------------------------------------------------------------------ one IAI solve on several GPUs
+class iaishard:
+    """Context manager: ONE IAI / NestedQuad solve of a series sharded over the ranks of a process group.
+
+    ref: SURVEY 8e (2) -- "disjoint sets of (inner) panels in IAI, one collective per refinement round".  Every rank calls
+    the solver with the same arguments; the driver deals the innermost integrals of every round to the ranks (blocks of 64
+    nodes), each rank integrates its share on its own GPU and one all-gather per round (this object's callback, handed to
+    the library through abz_iai_set_exchange) gives every rank all values.  All ranks return the same result, bit-identical
+    to the single-GPU solve.
+
+        with iaishard(h, group):                    # h: FourierSeries (or its DeviceSeries)
+            u = solver(omega)                       # IAI() as usual
+    """
+
+    def __init__(self, series, group=None, device=None):
+        self.dev = series.device() if hasattr(series, "device") else series
+        self.group = group
+        self.device = device
+        self._cb = None
+        self.rounds = 0
+
+    def _exchange(self, user, buf, per):
+        try:
+            import ctypes as C
+            import torch
+            dist = _dist()
+            world, rank = world_info(self.group)
+            arr = np.ctypeslib.as_array(buf, shape=(world * per,))
+            t = torch.from_numpy(arr)  # shares the library's buffer
+            mine = t[rank * per:(rank + 1) * per]
+            dev = self.device if self.device is not None else ("cuda" if dist.get_backend(self.group) == "nccl" else "cpu")
+            if dev == "cpu":
+                parts = [t[r * per:(r + 1) * per] for r in range(world)]
+                dist.all_gather(parts, mine.clone(), group=self.group)
+            else:
+                out = torch.empty(world * per, dtype=torch.float64, device=dev)
+                dist.all_gather_into_tensor(out, mine.to(dev), group=self.group)
+                t.copy_(out.cpu())
+            self.rounds += 1
+            return 0
+        except Exception:  # never let an exception cross the C boundary
+            import traceback
+            traceback.print_exc()
+            return 1
+
+    def __enter__(self):
+        from . import _lib as L
+        world, rank = world_info(self.group)
+        if world > 1:
+            self._cb = L.EXCHANGE_FN(self._exchange)
+            L.check(L.lib().abz_iai_set_exchange(self.dev.h, self._cb, None, rank, world))
+        return self
+
+    def __exit__(self, *exc):
+        from . import _lib as L
+        if self._cb is not None:
+            L.check(L.lib().abz_iai_set_exchange(self.dev.h, None, None, 0, 1))
+            self._cb = None
+        return False

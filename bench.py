@@ -62,6 +62,7 @@ def parse_args():
                          "(under `python -m torch.distributed.run --nproc-per-node 1`): the RCCL calls on one GPU")
     ap.add_argument("--big-npt", type=int, default=400, help="grid of the fine-grid 256-omega job (eta = 0.01)")
     ap.add_argument("--no-big-job", action="store_true")
+    ap.add_argument("--no-c5-shard", action="store_true", help="skip config 5 as one sharded solve (N > 1 only; ~11 s for its N = 1 leg)")
     ap.add_argument("--c5-abstol", type=float, default=1e-3, help="config 5 (16-band IAI) tolerance; SURVEY 8d: 1e-3")
     return ap.parse_args()
 
@@ -414,6 +415,38 @@ def rank_main(a):
                 iai_job.update({"seconds": float(tN.cpu()[0]), "speedup_vs_n1": t1 / float(tN.cpu()[0]),
                                 "bit_identical_to_n1": True})
 
+    # ---------------- config 5 as ONE solve on all GPUs: its inner integrals dealt to the ranks every round
+    c5_job = None
+    if distributed and not a.no_iai and not a.no_c5_shard:
+        try:
+            s16 = abz.synthetic_wannier()
+            f16 = abz.FourierIntegrand(abz.DOSIntegrand(), s16, 0.05)
+            prob16 = abz.IntegralProblem(f16, abz.load_bz(abz.FBZ(), np.eye(3)), abz.MixedParameters(0.2))
+            abz.solve(prob16, abz.IAI(), abstol=10.0, reltol=0.0)  # warm-up
+            t1, r1 = (None, None)
+            if rank == 0:
+                t0 = time.perf_counter()
+                r1 = abz.solve(prob16, abz.EvalCounter(abz.IAI()), abstol=a.c5_abstol, reltol=0.0)
+                t1 = time.perf_counter() - t0
+            barrier()
+            with abz.iaishard(s16, device=cdev) as sh:
+                abz.solve(prob16, abz.IAI(), abstol=10.0, reltol=0.0)
+                barrier()
+                t0 = time.perf_counter()
+                rN = abz.solve(prob16, abz.EvalCounter(abz.IAI()), abstol=a.c5_abstol, reltol=0.0)
+                barrier()
+                tN = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=cdev)
+                nex = sh.rounds
+            dist.all_reduce(tN, op=dist.ReduceOp.MAX)
+            if rank == 0:
+                assert rN.u == r1.u and rN.numevals == r1.numevals, (rN, r1)
+                c5_job = {"what": "config 5 (synthetic 16-band IAI on the FBZ) as one solve sharded over the ranks: every round's innermost "
+                                  "integrals dealt out in blocks of 64 nodes, one all-gather per round", "abstol": a.c5_abstol,
+                          "numevals": rN.numevals, "seconds_n1": t1, "seconds": float(tN.cpu()[0]), "speedup_vs_n1": t1 / float(tN.cpu()[0]),
+                          "bit_identical_to_n1": True, "exchanges": nex}
+        except Exception as e:
+            c5_job = {"error": repr(e)}
+
     # max-over-ranks timing of the primary legs
     times = torch.tensor([tA, tB, tBe], dtype=torch.float64, device=cdev)
     if distributed:
@@ -457,6 +490,7 @@ def rank_main(a):
             "job_256_omega_fine_grid": big_job,
             "speedup_vs_n1_fine_grid": (big_job or {}).get("k_sharded", {}).get("speedup_vs_n1") if isinstance(big_job, dict) else None,
             "iai_sweep_432_omega": iai_job,
+            "iai_config5_sharded": c5_job,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(npt),
                          "store_pattern_ceiling_GBs": 5100.0,

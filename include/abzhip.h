@@ -239,6 +239,16 @@ int abz_iai_solve_many(abz_series* s, int lims_kind, const double* lim_a, const 
                        double* out_reim, double* err, int64_t* numevals, double* panels,
                        int64_t max_panels, int64_t* npanels);
 
+/* ONE IAI solve on several GPUs (disjoint sets of the inner integrals of every refinement round).  All
+ * ranks call abz_iai_solve(_many) with the same arguments; every round's innermost integrals are dealt to the ranks in
+ * blocks of 64 nodes, each rank integrates its share on its own GPU, and `fn(user, buf, per_rank)` all-gathers the results:
+ * `buf` holds world * per_rank doubles, segment `rank` is filled on entry, all segments must be filled on return (RCCL
+ * / MPI / gloo: the library does not link a communication layer).  Every rank returns the same value, bit-identical to the
+ * single-GPU solve.  fn = NULL or world <= 1 switches it off.
+ * Replaces: nothing in the reference (its parallelism is threads over parameters, src/interfaces.jl:210-222). */
+typedef int (*abz_exchange_fn)(void* user, double* buf, int64_t per_rank);
+int abz_iai_set_exchange(abz_series* s, abz_exchange_fn fn, void* user, int rank, int world);
+
 /* Replaces: QuadGK.evalrule on a batch of panels (reached from src/algorithms.jl:227-233):
  * values [npanels][15][ncomp][2] in gk node order -> I_reim [npanels][ncomp][2], E [npanels]
  * with I = I_K * h, E = ||I_K - I_G|| * h (2-norm over components). */

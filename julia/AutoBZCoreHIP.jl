@@ -324,6 +324,31 @@ function reduce_rule_device!(out_dev::Ptr{Cvoid}, r::HIPRule, f::HIPIntegrand, p
         r.h, fid(f), params, length(params), sweep_dev, nsweep, nsyms, out_dev))
     return out_dev
 end
+"""
+    shard_iai!(hs, allgather!, rank, world)
+
+One IAI solve on several GPUs (`abz_iai_set_exchange`): `allgather!(buf::Vector{Float64}, per_rank::Int)` must fill every
+rank's segment of `buf` (MPI.Allgather!(MPI.IN_PLACE, UBuffer(buf, per_rank), comm) does).  All ranks then call the solver
+with the same arguments and get the single-GPU result bit for bit.  Pass `nothing` to switch it off.
+"""
+function shard_iai!(hs::HIPSeries, allgather!, rank::Integer, world::Integer)
+    if allgather! === nothing
+        check(ccall((:abz_iai_set_exchange, libabz), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Cint, Cint), hs.h, C_NULL, C_NULL, 0, 1))
+        return hs
+    end
+    cb = (user::Ptr{Cvoid}, buf::Ptr{Float64}, per::Int64) -> begin
+        try
+            allgather!(unsafe_wrap(Array, buf, Int(per) * Int(world)), Int(per)); Cint(0)
+        catch
+            Cint(1)
+        end
+    end
+    fptr = @cfunction($cb, Cint, (Ptr{Cvoid}, Ptr{Float64}, Int64))
+    hs.rules[(-1, UInt(0), Cint(0))] = fptr            # keep the closure alive with the series
+    check(ccall((:abz_iai_set_exchange, libabz), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Cint, Cint),
+                hs.h, Base.unsafe_convert(Ptr{Cvoid}, fptr), C_NULL, rank, world))
+    return hs
+end
 "Device address and size of the rule's value block (tiled planar layout, DESIGN.md section 3)."
 function values_ptr(r::HIPRule)
     base = Ref{Ptr{Cvoid}}(C_NULL); nb = Ref{Int64}(0)

@@ -1258,6 +1258,23 @@ def test_context_on_a_borrowed_stream_and_device_resident_sums(abz, svo):
     torch.zeros(4, device="cuda").sum().item()
 
 
+def test_single_iai_solve_sharded_over_two_ranks():
+    """one IAI solve on several GPUs -- the innermost integrals of every round dealt to the ranks, one
+    all-gather per round (abz_iai_set_exchange / dist.iaishard).  Two rank processes share this box's GPU (gloo): both
+    return the unsharded solve's value, error and numevals bit for bit (3 and 16 bands)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29533", os.path.join(root, "tests", "dist_iai_worker.py")],
+                       capture_output=True, text=True, timeout=600, env=env)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
+    assert p.stdout.count("sharded IAI ok") == 2
+
+
 # ------------------------------------------------------------------ errors
 def test_error_behaviour(abz):
     s = abz.FourierSeries(np.zeros((3, 3)), first=-1, ndim=2)
