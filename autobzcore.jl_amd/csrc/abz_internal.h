@@ -109,8 +109,8 @@ struct abz_series {
     abz_exchange_fn ex_fn = nullptr;  // a single IAI solve sharded over ranks: all-gather hook (abz_iai_set_exchange)
     void* ex_user = nullptr;
     int ex_rank = 0, ex_world = 1;
-    void* iai_pin[4] = {nullptr, nullptr, nullptr, nullptr};  // pinned host blocks of the IAI driver: chunk inputs [0,1] / outputs [2,3]
-    size_t iai_pin_cap[4] = {0, 0, 0, 0};
+    void* iai_pin[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};  // pinned host blocks of the IAI driver: chunk inputs [0,1] / outputs [2,3] / exchange [4]
+    size_t iai_pin_cap[5] = {0, 0, 0, 0, 0};
     int64_t elems(int level) const {
         int64_t e = (int64_t)n * n;
         for (int j = 0; j < level; ++j) e *= dims[j];

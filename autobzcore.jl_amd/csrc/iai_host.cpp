@@ -392,7 +392,7 @@ struct IaiDriver {
     void* ex_user = nullptr;
     int ex_rank = 0, ex_world = 1;
     std::vector<int64_t> l_par, l_nev;
-    std::vector<double> l_x, ex_buf;
+    std::vector<double> l_x;
     std::vector<uint32_t> l_q;
     std::vector<cd> l_vals;
     double st_exchange = 0.0;
@@ -844,8 +844,13 @@ int IaiDriver::solve_level(int L, std::vector<Quad1D>& quads) {
                         per = std::max(per, c);
                     }
                     const int rec = 2 * ncomp + 1;
-                    ex_buf.assign((size_t)(per * rec) * (size_t)W, 0.0);
-                    double* mine = ex_buf.data() + (size_t)ex_rank * (size_t)(per * rec);
+                    {   // pinned, so that a device-side all-gather (RCCL) stages it at PCIe rate
+                        int prc = pin_reserve(4, sizeof(double) * (size_t)(per * rec) * (size_t)W);
+                        if (prc) return prc;
+                    }
+                    double* const ex_buf = static_cast<double*>(s->iai_pin[4]);
+                    double* mine = ex_buf + (size_t)ex_rank * (size_t)(per * rec);
+                    for (int64_t i = N * rec; i < per * rec; ++i) mine[i] = 0.0;
                     for (int64_t i = 0; i < N; ++i) {
                         for (int c = 0; c < ncomp; ++c) {
                             mine[i * rec + 2 * c] = V[(size_t)(i * ncomp + c)].real();
@@ -854,7 +859,7 @@ int IaiDriver::solve_level(int L, std::vector<Quad1D>& quads) {
                         mine[i * rec + 2 * ncomp] = (double)NV[(size_t)i];  // exact below 2^53
                     }
                     const auto te0 = std::chrono::steady_clock::now();
-                    if (ex_fn(ex_user, ex_buf.data(), per * rec) != 0) {
+                    if (ex_fn(ex_user, ex_buf, per * rec) != 0) {
                         set_error("IAI: the exchange callback of a sharded solve failed");
                         return ABZ_ERR_HIP;
                     }
@@ -862,7 +867,7 @@ int IaiDriver::solve_level(int L, std::vector<Quad1D>& quads) {
                     std::vector<int64_t> pos((size_t)W, 0);
                     for (int64_t tn = 0; tn < nn; ++tn) {
                         const int rr = owner(tn);
-                        const double* src = ex_buf.data() + (size_t)rr * (size_t)(per * rec) + (size_t)(pos[(size_t)rr]++ * rec);
+                        const double* src = ex_buf + (size_t)rr * (size_t)(per * rec) + (size_t)(pos[(size_t)rr]++ * rec);
                         for (int c = 0; c < ncomp; ++c) vals[(size_t)(tn * ncomp + c)] = cd(src[2 * c], src[2 * c + 1]);
                         nev[(size_t)tn] = (int64_t)src[2 * ncomp];
                     }

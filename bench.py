@@ -77,6 +77,7 @@ def spawn_ranks(a):
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     env.setdefault("OMP_NUM_THREADS", "1")
+    print(f"bench.py: starting {a.gpus} ranks: {' '.join(cmd[1:6])} ...", file=sys.stderr, flush=True)
     p = subprocess.run(cmd, env=env)
     return p.returncode
 

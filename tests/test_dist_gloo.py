@@ -111,7 +111,8 @@ def test_shard_indices_match_batchparam():
 def test_bench_gpus_flag_starts_that_many_ranks():
     """`python bench.py --gpus 2` (no torchrun environment) must start 2 rank processes itself -- before anything touches a
     GPU -- and exit non-zero when they fail.  On this CPU-only box every rank stops with the product's 'needs an MI355X'
-    message: two of them prove that N ranks were started, the exit status that failures are not swallowed."""
+    message (the launcher may end the second rank before it gets that far, so one is enough), the launch line names the
+    rank count, and the exit status shows that failures are not swallowed."""
     import os
     import subprocess
     import sys
@@ -125,4 +126,6 @@ def test_bench_gpus_flag_starts_that_many_ranks():
     p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1"],
                        capture_output=True, text=True, timeout=600, env=env)
     assert p.returncode != 0
-    assert (p.stdout + p.stderr).count("bench.py needs an MI355X") >= 2
+    out = p.stdout + p.stderr
+    assert "bench.py: starting 2 ranks" in out and "--nproc-per-node=2" in out
+    assert out.count("bench.py needs an MI355X") >= 1
