@@ -16,6 +16,7 @@ from .io_w90 import load_w90_series, read_w90_hrdat, read_w90_wout
 from . import dist
 from .dist import batchsolve_sharded, sharded_map, kshard, iaishard
 from .io_sweep import SweepArchive, batchsolve_archive
+from .h5lite import read_h5_to_nt, write_nt_to_h5
 from .generic import fourier_batch
 from .synthetic import synthetic_wannier, tb_integer, splitmix64_uniform
 from .series import DeviceRule, DeviceSeries, FourierSeries, symptr_rule
