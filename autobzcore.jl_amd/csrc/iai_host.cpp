@@ -712,7 +712,7 @@ int IaiDriver::solve_level(int L, std::vector<Quad1D>& quads) {
                 // the same decisions (each integral is computed by exactly one GPU with the same kernel: the result
                 // equals the single-GPU solve bit for bit).
                 const int W = ex_world;
-                const bool shard = ex_fn != nullptr && W > 1 && nn >= (int64_t)64 * W;
+                const bool shard = ex_fn != nullptr && nn >= (int64_t)64 * W;
                 auto owner = [W](int64_t tnode) { return (int)((tnode >> 6) % W); };
                 if (shard) {
                     l_par.clear();
@@ -1328,7 +1328,7 @@ int abz_eval_line_nodes(abz_series* s, const int64_t* parents, const double* x, 
 int abz_iai_set_exchange(abz_series* s, abz_exchange_fn fn, void* user, int rank, int world) {
     ABZ_REQUIRE(s && s->ctx && !s->closed, "abz_iai_set_exchange: null or destroyed series");
     ABZ_REQUIRE(fn == nullptr || (world >= 1 && rank >= 0 && rank < world), "rank %d of %d", rank, world);
-    s->ex_fn = (fn && world > 1) ? fn : nullptr;
+    s->ex_fn = fn;  // world == 1 keeps the hook: a one-rank rehearsal of the exchange (the collective is then the identity)
     s->ex_user = user;
     s->ex_rank = s->ex_fn ? rank : 0;
     s->ex_world = s->ex_fn ? world : 1;

@@ -87,10 +87,11 @@ class kshard:
             u = solver(omega)                       # PTR / AutoPTR / GGR as usual, same value on all ranks
     """
 
-    def __init__(self, series, group=None, device=None):
+    def __init__(self, series, group=None, device=None, force=False):
         self.dev = series.device() if hasattr(series, "device") else series
         self.group = group
         self.device = device
+        self.force = force  # install the hook at world size 1 too (rehearsal of the transport on one GPU)
 
     def _allreduce(self, a):
         import torch
@@ -128,10 +129,11 @@ class iaishard:
             u = solver(omega)                       # IAI() as usual
     """
 
-    def __init__(self, series, group=None, device=None):
+    def __init__(self, series, group=None, device=None, force=False):
         self.dev = series.device() if hasattr(series, "device") else series
         self.group = group
         self.device = device
+        self.force = force  # install the hook at world size 1 too (rehearsal of the transport on one GPU)
         self._cb = None
         self.rounds = 0
 
@@ -162,7 +164,7 @@ class iaishard:
     def __enter__(self):
         from . import _lib as L
         world, rank = world_info(self.group)
-        if world > 1:
+        if world > 1 or (self.force and _dist().is_initialized()):
             self._cb = L.EXCHANGE_FN(self._exchange)
             L.check(L.lib().abz_iai_set_exchange(self.dev.h, self._cb, None, rank, world))
         return self

@@ -430,7 +430,7 @@ def rank_main(a):
                 r1 = abz.solve(prob16, abz.EvalCounter(abz.IAI()), abstol=a.c5_abstol, reltol=0.0)
                 t1 = time.perf_counter() - t0
             barrier()
-            with abz.iaishard(s16, device=cdev) as sh:
+            with abz.iaishard(s16, device=cdev, force=a.force_dist) as sh:
                 abz.solve(prob16, abz.IAI(), abstol=10.0, reltol=0.0)
                 barrier()
                 t0 = time.perf_counter()

@@ -244,7 +244,7 @@ int abz_iai_solve_many(abz_series* s, int lims_kind, const double* lim_a, const 
  * blocks of 64 nodes, each rank integrates its share on its own GPU, and `fn(user, buf, per_rank)` all-gathers the results:
  * `buf` holds world * per_rank doubles, segment `rank` is filled on entry, all segments must be filled on return (RCCL
  * / MPI / gloo: the library does not link a communication layer).  Every rank returns the same value, bit-identical to the
- * single-GPU solve.  fn = NULL or world <= 1 switches it off.
+ * single-GPU solve.  fn = NULL switches it off (world = 1 with a hook is allowed: a one-rank rehearsal of the transport).
  * Replaces: nothing in the reference (its parallelism is threads over parameters, src/interfaces.jl:210-222). */
 typedef int (*abz_exchange_fn)(void* user, double* buf, int64_t per_rank);
 int abz_iai_set_exchange(abz_series* s, abz_exchange_fn fn, void* user, int rank, int world);
