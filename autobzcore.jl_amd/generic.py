@@ -71,10 +71,14 @@ def auxquadgk(g, segs, atol, rtol, maxevals, batch=False, max_batch=2**62):
     (AuxQuadGK.BatchIntegrand, reached from src/algorithms.jl:227-233): pop panels while the error of the REMAINING
     ones still exceeds the tolerance and 30 * popped <= max_batch, evaluate all children in ONE call of g.
     -> (I, E, numevals)."""
+    from .solver import AuxValue
     atol_ = 0.0 if atol is None else atol
-    rtol_ = (0.0 if atol_ > 0 else math.sqrt(np.finfo(float).eps)) if rtol is None else rtol
+    anyatol = (atol_.val > 0 or atol_.aux > 0) if isinstance(atol_, AuxValue) else atol_ > 0
+    rtol_ = (0.0 if anyatol else math.sqrt(np.finfo(float).eps)) if rtol is None else rtol
     nseg = len(segs) - 1
     fv = g(np.concatenate([_gk_nodes(segs[i], segs[i + 1]) for i in range(nseg)]))
+    if len(fv) and isinstance(fv[0], AuxValue):
+        return _auxquadgk_auxvalue(g, segs, fv, atol_, rtol_, maxevals, batch, max_batch)
     heap = _Heap()
     for i in range(nseg):
         Ii, Ei = _gk_eval(fv[15 * i:15 * i + 15], segs[i], segs[i + 1])
@@ -118,6 +122,90 @@ def auxquadgk(g, segs, atol, rtol, maxevals, batch=False, max_batch=2**62):
                 heap.push((mid, sb, I2, E2))
         I, E = total()
     return I, E, numevals
+
+
+class _KeyHeap(_Heap):
+    """The same heap ordered by one component of an (E_val, E_aux) error pair."""
+
+    def __init__(self, key):
+        super().__init__()
+        self.key = key
+
+    def lt(self, a, b):
+        return b[3][self.key] < a[3][self.key]
+
+
+def _auxquadgk_auxvalue(g, segs, fv, atol, rtol, maxevals, batch, max_batch):
+    """AuxValue integrands: the quadrature sums `val` and `aux` side by side with separate error estimates; refinement
+    runs once per component in order -- first a heap ordered by the `val` errors until `val` meets its tolerance, then
+    the surviving panels are re-heapified by their `aux` errors and refined until `aux` meets it too (a tolerance given
+    as one number applies to both, an AuxValue tolerance to each).  ref: IteratedIntegration.AuxQuadGK (auxquadgk's
+    `eachorder` loop), reached from src/algorithms.jl:215-239."""
+    from .solver import AuxValue
+
+    def pair(t):
+        return (t.val, t.aux) if isinstance(t, AuxValue) else (t, t)
+
+    def gk(vals, a, b):
+        Iv, Ev = _gk_eval([v.val for v in vals], a, b)
+        Ia, Ea = _gk_eval([v.aux for v in vals], a, b)
+        return (Iv, Ia), (Ev, Ea)
+
+    nseg = len(segs) - 1
+    xs = []
+    for i in range(nseg):
+        Ii, Ei = gk(fv[15 * i:15 * i + 15], segs[i], segs[i + 1])
+        xs.append((segs[i], segs[i + 1], Ii, Ei))
+
+    def total(lst):
+        I = [lst[0][2][0], lst[0][2][1]]
+        E = [lst[0][3][0], lst[0][3][1]]
+        for sg in lst[1:]:
+            for c in (0, 1):
+                I[c] = I[c] + sg[2][c]
+                E[c] = E[c] + sg[3][c]
+        return I, E
+
+    I, E = total(xs)
+    numevals = 15 * nseg
+    at = pair(atol)
+    for key in (0, 1):
+        def tol():
+            return max(at[key], rtol * _norm(I[key]))
+        if E[key] <= tol() or numevals >= maxevals:
+            continue
+        heap = _KeyHeap(key)
+        heap.xs = xs
+        heap.heapify()
+        while E[key] > tol() and numevals < maxevals:
+            popped = []
+            if not batch:
+                popped.append(heap.pop())
+                numevals += 30
+            else:
+                t = tol()
+                while heap.xs and 30 * (len(popped) + 1) <= max_batch and E[key] > t and numevals < maxevals:
+                    sg = heap.pop()
+                    popped.append(sg)
+                    t += sg[3][key]
+                    numevals += 30
+            pts = []
+            for (sa, sb, _, _) in popped:
+                mid = (sa + sb) / 2
+                pts += [_gk_nodes(sa, mid), _gk_nodes(mid, sb)]
+            fv = g(np.concatenate(pts))
+            for k, (sa, sb, sI, sE) in enumerate(popped):
+                mid = (sa + sb) / 2
+                I1, E1 = gk(fv[30 * k:30 * k + 15], sa, mid)
+                I2, E2 = gk(fv[30 * k + 15:30 * k + 30], mid, sb)
+                for c in (0, 1):
+                    I[c] = (I[c] - sI[c]) + I1[c] + I2[c]
+                    E[c] = (E[c] - sE[c]) + E1[c] + E2[c]
+                heap.push((sa, mid, I1, E1))
+                heap.push((mid, sb, I2, E2))
+        xs = heap.xs
+        I, E = total(xs)
+    return AuxValue(I[0], I[1]), AuxValue(E[0], E[1]), numevals
 
 
 def solve_auxquadgk(f, dom, p, abstol, reltol, maxiters):

@@ -265,16 +265,17 @@ class Dataset:
 
 
 class Group:
-    def __init__(self, hid, name="/", is_file=False):
+    def __init__(self, hid, name="/", is_file=False, parent=None):
         self.id = hid
         self.name = name
+        self.parent = parent  # the group it was opened from (flush walks up to the file)
         self._is_file = is_file
         self._open = []
 
     # ---- creation
     def create_group(self, name):
         g = Group(_ck(lib().H5Gcreate2(self.id, name.encode(), H5P_DEFAULT, H5P_DEFAULT, H5P_DEFAULT), f"create_group({name!r})"),
-                  self.name.rstrip("/") + "/" + name)
+                  self.name.rstrip("/") + "/" + name, parent=self)
         self._open.append(g)
         return g
 
@@ -322,7 +323,7 @@ class Group:
         kind = lib().H5Iget_type(o)
         lib().H5Oclose(o)
         if kind == H5I_GROUP:
-            g = Group(_ck(lib().H5Gopen2(self.id, name.encode(), H5P_DEFAULT), "H5Gopen2"), self.name.rstrip("/") + "/" + name)
+            g = Group(_ck(lib().H5Gopen2(self.id, name.encode(), H5P_DEFAULT), "H5Gopen2"), self.name.rstrip("/") + "/" + name, parent=self)
             self._open.append(g)
             return g
         if kind == H5I_DATASET:

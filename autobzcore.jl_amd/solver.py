@@ -64,7 +64,11 @@ class MixedParameters:
 
 
 def paramzip(*args, **kwargs):
-    """ref: src/parameters.jl:52-60."""
+    """ref: src/parameters.jl:52-60.  Scalars zip to a 0-d array (Julia numbers iterate as 0-d containers)."""
+    if (args or kwargs) and all(np.ndim(a) == 0 for a in list(args) + list(kwargs.values())):
+        out = np.empty((), dtype=object)
+        out[()] = MixedParameters(*args, **kwargs)
+        return out
     n = len(args[0]) if args else len(next(iter(kwargs.values())))
     return [MixedParameters(*(a[i] for a in args), **{k: v[i] for k, v in kwargs.items()}) for i in range(n)]
 
@@ -81,6 +85,42 @@ def paramproduct(*args, **kwargs):
     arr = np.empty(len(out), dtype=object)
     arr[:] = out
     return arr.reshape([len(s) for s in seqs], order="F")
+
+
+class AuxValue:
+    """A value that carries an auxiliary quantity integrated along with it: both are summed by the quadrature, the adaptive
+    loop converges `val` first and `aux` after it (each with its own error estimate).
+    ref: IteratedIntegration.AuxQuadGK.AuxValue, used at src/algorithms.jl:198, src/brillouin.jl:113, ext/HDF5Ext.jl:48-64."""
+    __array_ufunc__ = None  # numpy scalars defer to __rmul__ / __radd__
+
+    def __init__(self, val, aux):
+        self.val, self.aux = val, aux
+
+    def __add__(self, o):
+        return AuxValue(self.val + o.val, self.aux + o.aux)
+
+    def __sub__(self, o):
+        return AuxValue(self.val - o.val, self.aux - o.aux)
+
+    def __neg__(self):
+        return AuxValue(-self.val, -self.aux)
+
+    def __mul__(self, c):
+        return AuxValue(self.val * c, self.aux * c)
+
+    __rmul__ = __mul__
+
+    def __truediv__(self, c):
+        return AuxValue(self.val / c, self.aux / c)
+
+    def __eq__(self, o):
+        return isinstance(o, AuxValue) and np.array_equal(self.val, o.val) and np.array_equal(self.aux, o.aux)
+
+    def __iter__(self):
+        return iter((self.val, self.aux))
+
+    def __repr__(self):
+        return f"AuxValue({self.val!r}, {self.aux!r})"
 
 
 class ParameterIntegrand:
@@ -288,6 +328,11 @@ class AuxQuadGKJL(IntegralAlgorithm):
             raise ValueError("AuxQuadGKJL: only order = 7 is supported")
         self.order = order
         self.norm = norm
+
+
+class QuadGKJL(AuxQuadGKJL):
+    """ref: src/algorithms.jl:9-20,67-96 (the duplicate of Integrals.jl's QuadGKJL): the same globally adaptive GK(7,15)
+    as AuxQuadGKJL without the AuxValue ordering -- which only differs for AuxValue integrands."""
 
 
 class IAI(AutoBZAlgorithm):
@@ -551,6 +596,8 @@ def symmetrize(f, bz, x):
     """ref: src/brillouin.jl:96-114: numbers are TrivialRep, a full BZ maps x to itself."""
     if bz.syms is None:
         return x
+    if isinstance(x, AuxValue):  # ref: src/brillouin.jl:113
+        return AuxValue(symmetrize(f, bz, x.val), symmetrize(f, bz, x.aux))
     if _is_trivial(x):
         return nsyms(bz) * x
     return (f if isinstance(f, AbstractSymRep) else SymRep(f)).symmetrize_(bz, x)

@@ -495,13 +495,13 @@ def test_batchsolve_archive_matches_batchsolve(abz, svo, tmp_path):
     out = abz.batchsolve_archive(tmp_path / "sweep.npz", solver, om, chunk=4)
     z = abz.SweepArchive.load(tmp_path / "sweep.npz")
     assert np.array_equal(out, ref) and np.array_equal(z["I"], ref) and z["done"].all()
-    assert np.allclose(z["args/1"], om) and np.all(z["numevals"] == z["numevals"][0]) and z["numevals"][0] > 0
+    assert np.allclose(z["p"], om) and np.all(z["numevals"] == z["numevals"][0]) and z["numevals"][0] > 0  # plain parameters: `p`
     from autobzcore.jl_amd import h5lite
     if h5lite.available():  # the same sweep into a real HDF5 file (the reference's container)
         out5 = abz.batchsolve_archive(tmp_path / "sweep.h5", solver, om, chunk=4)
         z5 = abz.read_h5_to_nt(tmp_path / "sweep.h5")
         assert np.array_equal(out5, ref) and np.array_equal(z5["I"], ref) and np.array_equal(z5["numevals"], z["numevals"])
-        assert np.array_equal(z5["args"]["1"], om) and z5["retcode"].dtype == np.int32 and np.all(z5["retcode"] == 1)
+        assert np.array_equal(z5["p"], om) and z5["retcode"].dtype == np.int32 and np.all(z5["retcode"] == 1)
 
 
 def test_symrep_extension_point_matrix_valued_on_the_ibz(abz):

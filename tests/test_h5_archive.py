@@ -121,3 +121,82 @@ def test_missing_library_is_an_error_not_a_change_of_format(tmp_path, monkeypatc
     with pytest.raises(h5lite.H5Error):
         abz.SweepArchive(tmp_path / "x.h5", (3,))
     assert not (tmp_path / "x.h5").exists() and not (tmp_path / "x.h5.npz").exists()
+
+
+def test_reference_hdf5ext_cases_number_sarray_auxvalue_0d_3d(tmp_path):
+    """The cases of the reference's own test of this extension (test/hdf5ext.jl:7-55), solved by the host algorithms and
+    written into groups of ONE file: Number (`p` data set), array-valued results flattened into trailing axes, AuxValue
+    split into `I/val` + `I/aux`, 0-d parameter arrays (scalar data sets) and a 3-d `paramproduct`."""
+    path = tmp_path / "ext.h5"
+    with h5lite.File(path, "w") as io:
+        # Number (test/hdf5ext.jl:9-16)
+        g1 = io.create_group("Number")
+        solver = abz.IntegralSolver(abz.IntegralProblem(lambda x, p: p, (0.0, 1.0)), abz.QuadGKJL())
+        params = np.arange(1.0, 11.0)
+        values = abz.batchsolve_archive(g1, solver, params)
+        assert np.allclose(values, params, rtol=1e-14)
+        # SArray (test/hdf5ext.jl:17-26): SHermitianCompact{2}([s, c, -s]) = [s c; c -s]
+        g2 = io.create_group("SArray")
+
+        def fm(x, p):
+            s, c = np.sin(p * x), np.cos(p * x)
+            return np.array([[s, c], [c, -s]])
+        solver2 = abz.IntegralSolver(abz.IntegralProblem(fm, (0.0, np.pi)), abz.QuadGKJL())
+        values2 = abz.batchsolve_archive(g2, solver2, [0.8, 0.9, 1.0])
+        # AuxValue (test/hdf5ext.jl:27-36)
+        g3 = io.create_group("AuxValue")
+
+        def fa(x, p):
+            z = 1.0 / complex(np.cos(x), p)
+            return abz.AuxValue(z.real, z.imag)
+        solver3 = abz.IntegralSolver(abz.IntegralProblem(fa, (0.0, 2 * np.pi)), abz.QuadGKJL(), abstol=1e-3)
+        pa = [2.0, 1.0, 0.5]
+        values3 = abz.batchsolve_archive(g3, solver3, pa)
+        # parameter dimensions (test/hdf5ext.jl:37-54)
+        solver4 = abz.IntegralSolver(abz.IntegralProblem(lambda x, p: p[0] + p[1] + p[2], (0.0, 1.0)), abz.QuadGKJL())
+        g4 = io.create_group("0d")
+        values4 = abz.batchsolve_archive(g4, solver4, abz.paramzip(0, 1, 2))
+        g5 = io.create_group("3d")
+        values5 = abz.batchsolve_archive(g5, solver4, abz.paramproduct([1, 2], [1, 2], [1, 2]))
+    nt = abz.read_h5_to_nt(path)
+    assert set(nt) == {"Number", "SArray", "AuxValue", "0d", "3d"}
+    n = nt["Number"]
+    assert np.array_equal(n["I"], values) and np.array_equal(n["p"], params) and n["retcode"].dtype == np.int32
+    assert np.all(n["numevals"] == -1) and np.all(n["E"] < 1e-12) and n["done"].all()  # no EvalCounter: -1 like the reference
+    sa = nt["SArray"]
+    assert sa["I"].shape == (3, 2, 2) and np.array_equal(sa["I"], values2)
+    for k, pk in enumerate([0.8, 0.9, 1.0]):  # closed forms of the integrals of sin / cos
+        s_, c_ = (1 - np.cos(pk * np.pi)) / pk, np.sin(pk * np.pi) / pk
+        assert np.allclose(sa["I"][k], [[s_, c_], [c_, -s_]], atol=1e-9)
+    av = nt["AuxValue"]
+    assert set(av["I"]) == {"val", "aux"} and av["I"]["val"].shape == (3,)
+    assert np.array_equal(av["I"]["val"], [v.val for v in values3]) and np.array_equal(av["I"]["aux"], [v.aux for v in values3])
+    assert np.allclose(av["I"]["val"], 0.0, atol=1e-3) and np.allclose(av["I"]["aux"], [-2 * np.pi / np.sqrt(1 + q * q) for q in pa], atol=1e-3)
+    assert np.all(np.isfinite(av["E"])) and np.all(av["E"] <= 1e-3)  # E holds the `val` error (ext/HDF5Ext.jl:140)
+    z0 = nt["0d"]
+    assert z0["I"].shape == () and float(z0["I"]) == pytest.approx(3.0) and float(values4) == pytest.approx(3.0)
+    assert [int(z0["args"][str(j)]) for j in (1, 2, 3)] == [0, 1, 2]
+    z3 = nt["3d"]
+    assert z3["I"].shape == (2, 2, 2) and z3["I"][0, 0, 0] == pytest.approx(3.0) and z3["I"][1, 1, 1] == pytest.approx(6.0)
+    assert values5.shape == (2, 2, 2) and np.array_equal(z3["I"], values5)
+    assert np.array_equal(z3["args"]["1"][:, 0, 0], [1, 2]) and np.array_equal(z3["args"]["3"][0, 0, :], [1, 2])
+
+
+def test_auxvalue_refines_the_auxiliary_quantity_after_the_value():
+    """AuxQuadGK's ordering: `val` converges first, then the same panels are refined on the `aux` error.  An integrand
+    whose value is smooth and whose auxiliary part is sharply peaked must spend its evaluations on the peak, and a plain
+    integrand of the auxiliary part alone must give the same number."""
+    eta = 1e-2
+
+    def f(x, p):
+        return abz.AuxValue(np.cos(x), eta / ((x - 0.3) ** 2 + eta * eta))
+    prob = abz.IntegralProblem(f, (-1.0, 1.0))
+    sol = abz.solve(prob, abz.EvalCounter(abz.AuxQuadGKJL()), abstol=1e-8)
+    exact = np.arctan((1 - 0.3) / eta) + np.arctan((1 + 0.3) / eta)
+    assert abs(sol.u.val - 2 * np.sin(1.0)) < 1e-12 and abs(sol.u.aux - exact) < 1e-8
+    assert sol.resid.val <= 1e-8 and sol.resid.aux <= 1e-8 and sol.numevals > 15 * 10
+    only_val = abz.solve(abz.IntegralProblem(lambda x, p: np.cos(x), (-1.0, 1.0)), abz.EvalCounter(abz.AuxQuadGKJL()), abstol=1e-8)
+    assert only_val.numevals == 15  # the value alone never needs a second panel
+    # separate tolerances: a loose one on aux stops the second stage early
+    loose = abz.solve(prob, abz.EvalCounter(abz.AuxQuadGKJL()), abstol=abz.AuxValue(1e-8, 1e-2))
+    assert loose.numevals < sol.numevals and abs(loose.u.aux - exact) < 1e-2
