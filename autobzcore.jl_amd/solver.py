@@ -399,6 +399,15 @@ class NestedQuad(IntegralAlgorithm):
         self.algs = algs or (AuxQuadGKJL(),)
 
 
+class AbsoluteEstimate(IntegralAlgorithm):
+    """AbsoluteEstimate(est_alg, abs_alg; norm, kws...): a rough solve with `est_alg` (given `kws`) sizes the integral, then
+    `abs_alg` runs with abstol = max(abstol, reltol * norm(I_est)) and reltol = 0.  ref: src/algorithms.jl:614-653."""
+
+    def __init__(self, est_alg, abs_alg, norm=None, **kws):
+        checkkwargs(kws)
+        self.est_alg, self.abs_alg, self.norm, self.kws = est_alg, abs_alg, norm, kws
+
+
 class EvalCounter(IntegralAlgorithm):
     """Counts integrand evaluations into sol.numevals.  ref: src/algorithms.jl:656-691, src/fourier.jl:512-530."""
 
@@ -686,6 +695,16 @@ def do_solve(f, dom, p, alg, cacheval=None, abstol=None, reltol=None, maxiters=2
     counter = isinstance(alg, EvalCounter)
     if counter:
         alg = alg.alg
+    if isinstance(alg, AbsoluteEstimate):  # ref: src/algorithms.jl:644-653
+        wrap = (lambda a_: EvalCounter(a_)) if counter else (lambda a_: a_)
+        est = do_solve(f, dom, p, wrap(alg.est_alg), cacheval, **alg.kws)
+        val = (alg.norm or _norm)(est.u)
+        rtol = math.sqrt(np.finfo(float).eps) if reltol is None else reltol
+        atol = max(0.0 if abstol is None else abstol, rtol * val)
+        sol = do_solve(f, dom, p, wrap(alg.abs_alg), cacheval, abstol=atol, reltol=0.0, maxiters=maxiters)
+        if counter:  # the reference's counter wraps the integrand, so it sees the evaluations of both stages
+            sol.numevals += est.numevals
+        return sol
     if not isinstance(f, FourierIntegrand):
         return _do_solve_generic(f, dom, p, alg, counter, abstol, reltol, maxiters)
     dev = cacheval if cacheval is not None else f.w.device()

@@ -93,3 +93,23 @@ def test_generic_error_behaviour():
         abz.BatchIntegrand(lambda y, x, p: None, max_batch=0)
     with pytest.raises(ValueError):
         abz.solve(abz.IntegralProblem(lambda x, p: 1.0, (0.0, 1.0), None), abz.PTR())
+
+
+def test_absolute_estimate_sizes_the_tolerance_from_a_rough_solve():
+    """ref: src/algorithms.jl:614-653, test/interface_tests.jl:132-140 -- f(x) = 1 / (z - cos x), z = 0.5 + 1e-3 i: the
+    estimate stage fixes abstol = reltol * |I_est| for the second stage, whose result then equals a direct solve with that
+    absolute tolerance; the closed form is 2 pi / (sqrt(z - 1) sqrt(z + 1))."""
+    import cmath
+    z = complex(0.5, 1e-3)
+    prob = abz.IntegralProblem(lambda x, p: 1.0 / (complex(*p) - np.cos(x)), (0.0, 2 * np.pi), (0.5, 1e-3))
+    alg = abz.AbsoluteEstimate(abz.AuxQuadGKJL(), abz.QuadGKJL(), abstol=1.0)  # the estimate only needs the magnitude
+    reltol = 1e-5
+    sol = abz.solve(prob, abz.EvalCounter(alg), reltol=reltol)
+    exact = 2 * np.pi / (cmath.sqrt(z - 1) * cmath.sqrt(z + 1))
+    assert abs(sol.u - exact) <= 10 * reltol * abs(exact)
+    est = abz.solve(prob, abz.EvalCounter(abz.AuxQuadGKJL()), abstol=1.0)
+    direct = abz.solve(prob, abz.EvalCounter(abz.QuadGKJL()), abstol=reltol * abs(est.u), reltol=0.0)
+    assert sol.u == direct.u and sol.resid == direct.resid and sol.numevals == est.numevals + direct.numevals
+    assert sol.resid <= reltol * abs(est.u)
+    with pytest.raises(ValueError):
+        abz.AbsoluteEstimate(abz.AuxQuadGKJL(), abz.QuadGKJL(), tolerance=1.0)  # checkkwargs

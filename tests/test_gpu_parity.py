@@ -504,6 +504,20 @@ def test_batchsolve_archive_matches_batchsolve(abz, svo, tmp_path):
         assert np.array_equal(z5["p"], om) and z5["retcode"].dtype == np.int32 and np.all(z5["retcode"] == 1)
 
 
+def test_absolute_estimate_ptr_then_iai_on_the_device(abz, svo):
+    """ref: src/algorithms.jl:614-653 -- the usual AutoBZ pattern: a coarse PTR rule sizes the DOS, IAI then runs with
+    abstol = reltol * |estimate|.  The second stage must be exactly the direct IAI solve at that tolerance, and the
+    counter adds both stages."""
+    s, _ = svo
+    bz = abz.load_bz(abz.CubicSymIBZ(), 3.85856 * np.eye(3))
+    prob = abz.IntegralProblem(abz.FourierIntegrand(abz.DOSIntegrand(), s, 0.1), bz, abz.MixedParameters(12.5))
+    est = abz.solve(prob, abz.EvalCounter(abz.PTR(npt=16)))
+    sol = abz.solve(prob, abz.EvalCounter(abz.AbsoluteEstimate(abz.PTR(npt=16), abz.IAI())), reltol=1e-3)
+    direct = abz.solve(prob, abz.EvalCounter(abz.IAI()), abstol=1e-3 * abs(est.u), reltol=0.0)
+    assert sol.u == direct.u and sol.resid == direct.resid and sol.numevals == est.numevals + direct.numevals
+    assert sol.resid <= 1e-3 * abs(est.u) and abs(sol.u - est.u) < 0.05 * abs(est.u)
+
+
 def test_symrep_extension_point_matrix_valued_on_the_ibz(abz):
     """ref: src/brillouin.jl:73-108 (`SymRep(f)` + `symmetrize_`).  H(k) = diag(cos kx, cos ky) + t (cos kx + cos ky) s_x
     obeys H(S k) = D_S H(k) D_S^T with D_S = s_x for the symmetries that swap the axes, 1 otherwise; with that
