@@ -66,7 +66,61 @@ class _Evaluator:
         return out
 
 
-def auxquadgk(g, segs, atol, rtol, maxevals, batch=False, max_batch=2**62):
+class _GKRule:
+    """Gauss-Kronrod (n, 2n+1) on an interval: nodes(a, b) and eval(values, a, b) -> (I, E = |I_K - I_G|).  Order 7 is
+    the library's table (the one the device kernels use, bit for bit); any other order -- `QuadGKJL(order = 9)` in
+    test/interface_tests.jl:151-156 -- is computed once on the host: the Kronrod points are the zeros of the Stieltjes
+    polynomial E_{n+1}, orthogonal on [-1, 1] to all lower degrees with weight P_n, the weights follow from exactness."""
+
+    def __init__(self, order):
+        self.order, self.npts = int(order), 2 * int(order) + 1
+        if self.order == 7:
+            return
+        from numpy.polynomial import legendre as Lg
+        n = self.order
+        xq, wq = Lg.leggauss(2 * n + 4)  # exact for every product below
+        Pn = Lg.legval(xq, [0] * n + [1])
+        basis = [Lg.legval(xq, [0] * k + [1]) for k in range(n + 2)]
+        # E = P_{n+1} + sum_{k<=n} c_k P_k with  int P_n E P_j = 0  for j = 0..n
+        A = np.array([[np.sum(wq * Pn * basis[k] * basis[j]) for k in range(n + 1)] for j in range(n + 1)])
+        rhs = -np.array([np.sum(wq * Pn * basis[n + 1] * basis[j]) for j in range(n + 1)])
+        c = np.linalg.lstsq(A, rhs, rcond=None)[0]
+        kron = np.real(Lg.legroots(np.concatenate([c, [1.0]])))
+        gauss, gw = Lg.leggauss(n)
+        x = np.sort(np.concatenate([kron, gauss]))
+        x = 0.5 * (x - x[::-1])  # symmetrise
+        V = np.array([Lg.legval(x, [0] * k + [1]) for k in range(2 * n + 1)])
+        mom = np.zeros(2 * n + 1)
+        mom[0] = 2.0
+        self.x, self.w = x, np.linalg.solve(V, mom)
+        self.gidx = np.array([int(np.argmin(np.abs(x - g))) for g in gauss])
+        self.gw = gw
+
+    def nodes(self, a, b):
+        if self.order == 7:
+            return _gk_nodes(a, b)
+        return 0.5 * (a + b) + 0.5 * (b - a) * self.x
+
+    def eval(self, vals, a, b):
+        if self.order == 7:
+            return _gk_eval(vals, a, b)
+        arr = np.asarray(vals)
+        h = 0.5 * (b - a)
+        Ik = h * np.tensordot(self.w, arr, axes=(0, 0))
+        Ig = h * np.tensordot(self.gw, arr[self.gidx], axes=(0, 0))
+        return (Ik if np.ndim(Ik) else Ik[()]), _norm(Ik - Ig)
+
+
+_RULES = {}
+
+
+def gk_rule(order):
+    if order not in _RULES:
+        _RULES[order] = _GKRule(order)
+    return _RULES[order]
+
+
+def auxquadgk(g, segs, atol, rtol, maxevals, batch=False, max_batch=2**62, order=7):
     """Globally adaptive GK(7,15).  Scalar refinement: pop the worst panel, bisect, 30 new nodes.  Batch refinement
     (AuxQuadGK.BatchIntegrand, reached from src/algorithms.jl:227-233): pop panels while the error of the REMAINING
     ones still exceeds the tolerance and 30 * popped <= max_batch, evaluate all children in ONE call of g.
@@ -76,12 +130,14 @@ def auxquadgk(g, segs, atol, rtol, maxevals, batch=False, max_batch=2**62):
     anyatol = (atol_.val > 0 or atol_.aux > 0) if isinstance(atol_, AuxValue) else atol_ > 0
     rtol_ = (0.0 if anyatol else math.sqrt(np.finfo(float).eps)) if rtol is None else rtol
     nseg = len(segs) - 1
+    rule = gk_rule(order)
+    _gk_nodes, _gk_eval, npt = rule.nodes, rule.eval, rule.npts
     fv = g(np.concatenate([_gk_nodes(segs[i], segs[i + 1]) for i in range(nseg)]))
     if len(fv) and isinstance(fv[0], AuxValue):
-        return _auxquadgk_auxvalue(g, segs, fv, atol_, rtol_, maxevals, batch, max_batch)
+        return _auxquadgk_auxvalue(g, segs, fv, atol_, rtol_, maxevals, batch, max_batch, rule)
     heap = _Heap()
     for i in range(nseg):
-        Ii, Ei = _gk_eval(fv[15 * i:15 * i + 15], segs[i], segs[i + 1])
+        Ii, Ei = _gk_eval(fv[npt * i:npt * (i + 1)], segs[i], segs[i + 1])
         heap.xs.append((segs[i], segs[i + 1], Ii, Ei))
 
     def total():
@@ -92,21 +148,21 @@ def auxquadgk(g, segs, atol, rtol, maxevals, batch=False, max_batch=2**62):
         return I, E
 
     I, E = total()
-    numevals = 15 * nseg
+    numevals = npt * nseg
     if not (E <= max(atol_, rtol_ * _norm(I)) or numevals >= maxevals):
         heap.heapify()
         while E > max(atol_, rtol_ * _norm(I)) and numevals < maxevals:
             if not batch:
                 popped = [heap.pop()]
-                numevals += 30
+                numevals += 2 * npt
             else:
                 tol = max(atol_, rtol_ * _norm(I))
                 popped = []
-                while heap.xs and 30 * (len(popped) + 1) <= max_batch and E > tol and numevals < maxevals:
+                while heap.xs and 2 * npt * (len(popped) + 1) <= max_batch and E > tol and numevals < maxevals:
                     sg = heap.pop()
                     popped.append(sg)
                     tol += sg[3]
-                    numevals += 30
+                    numevals += 2 * npt
             pts = []
             for (sa, sb, _, _) in popped:
                 mid = (sa + sb) / 2
@@ -114,8 +170,8 @@ def auxquadgk(g, segs, atol, rtol, maxevals, batch=False, max_batch=2**62):
             fv = g(np.concatenate(pts))
             for k, (sa, sb, sI, sE) in enumerate(popped):
                 mid = (sa + sb) / 2
-                I1, E1 = _gk_eval(fv[30 * k:30 * k + 15], sa, mid)
-                I2, E2 = _gk_eval(fv[30 * k + 15:30 * k + 30], mid, sb)
+                I1, E1 = _gk_eval(fv[2 * npt * k:2 * npt * k + npt], sa, mid)
+                I2, E2 = _gk_eval(fv[2 * npt * k + npt:2 * npt * (k + 1)], mid, sb)
                 I = (I - sI) + I1 + I2
                 E = (E - sE) + E1 + E2
                 heap.push((sa, mid, I1, E1))
@@ -135,13 +191,14 @@ class _KeyHeap(_Heap):
         return b[3][self.key] < a[3][self.key]
 
 
-def _auxquadgk_auxvalue(g, segs, fv, atol, rtol, maxevals, batch, max_batch):
+def _auxquadgk_auxvalue(g, segs, fv, atol, rtol, maxevals, batch, max_batch, rule):
     """AuxValue integrands: the quadrature sums `val` and `aux` side by side with separate error estimates; refinement
     runs once per component in order -- first a heap ordered by the `val` errors until `val` meets its tolerance, then
     the surviving panels are re-heapified by their `aux` errors and refined until `aux` meets it too (a tolerance given
     as one number applies to both, an AuxValue tolerance to each).  ref: IteratedIntegration.AuxQuadGK (auxquadgk's
     `eachorder` loop), reached from src/algorithms.jl:215-239."""
     from .solver import AuxValue
+    _gk_nodes, _gk_eval, npt = rule.nodes, rule.eval, rule.npts
 
     def pair(t):
         return (t.val, t.aux) if isinstance(t, AuxValue) else (t, t)
@@ -154,7 +211,7 @@ def _auxquadgk_auxvalue(g, segs, fv, atol, rtol, maxevals, batch, max_batch):
     nseg = len(segs) - 1
     xs = []
     for i in range(nseg):
-        Ii, Ei = gk(fv[15 * i:15 * i + 15], segs[i], segs[i + 1])
+        Ii, Ei = gk(fv[npt * i:npt * (i + 1)], segs[i], segs[i + 1])
         xs.append((segs[i], segs[i + 1], Ii, Ei))
 
     def total(lst):
@@ -167,7 +224,7 @@ def _auxquadgk_auxvalue(g, segs, fv, atol, rtol, maxevals, batch, max_batch):
         return I, E
 
     I, E = total(xs)
-    numevals = 15 * nseg
+    numevals = npt * nseg
     at = pair(atol)
     for key in (0, 1):
         def tol():
@@ -181,14 +238,14 @@ def _auxquadgk_auxvalue(g, segs, fv, atol, rtol, maxevals, batch, max_batch):
             popped = []
             if not batch:
                 popped.append(heap.pop())
-                numevals += 30
+                numevals += 2 * npt
             else:
                 t = tol()
-                while heap.xs and 30 * (len(popped) + 1) <= max_batch and E[key] > t and numevals < maxevals:
+                while heap.xs and 2 * npt * (len(popped) + 1) <= max_batch and E[key] > t and numevals < maxevals:
                     sg = heap.pop()
                     popped.append(sg)
                     t += sg[3][key]
-                    numevals += 30
+                    numevals += 2 * npt
             pts = []
             for (sa, sb, _, _) in popped:
                 mid = (sa + sb) / 2
@@ -196,8 +253,8 @@ def _auxquadgk_auxvalue(g, segs, fv, atol, rtol, maxevals, batch, max_batch):
             fv = g(np.concatenate(pts))
             for k, (sa, sb, sI, sE) in enumerate(popped):
                 mid = (sa + sb) / 2
-                I1, E1 = gk(fv[30 * k:30 * k + 15], sa, mid)
-                I2, E2 = gk(fv[30 * k + 15:30 * k + 30], mid, sb)
+                I1, E1 = gk(fv[2 * npt * k:2 * npt * k + npt], sa, mid)
+                I2, E2 = gk(fv[2 * npt * k + npt:2 * npt * (k + 1)], mid, sb)
                 for c in (0, 1):
                     I[c] = (I[c] - sI[c]) + I1[c] + I2[c]
                     E[c] = (E[c] - sE[c]) + E1[c] + E2[c]
@@ -208,14 +265,14 @@ def _auxquadgk_auxvalue(g, segs, fv, atol, rtol, maxevals, batch, max_batch):
     return AuxValue(I[0], I[1]), AuxValue(E[0], E[1]), numevals
 
 
-def solve_auxquadgk(f, dom, p, abstol, reltol, maxiters):
+def solve_auxquadgk(f, dom, p, abstol, reltol, maxiters, order=7):
     """AuxQuadGKJL on an interval.  ref: src/algorithms.jl:215-239."""
     from .solver import BatchIntegrand, NestedBatchIntegrand
     if isinstance(f, NestedBatchIntegrand):
         raise ValueError("AuxQuadGKJL doesn't support nested batching")  # ref: src/algorithms.jl:211
     ev = _Evaluator(f, p, point=float)
     isb = isinstance(f, BatchIntegrand)
-    I, E, _ = auxquadgk(ev, _segments(dom), abstol, reltol, maxiters, batch=isb, max_batch=f.max_batch if isb else 2**62)
+    I, E, _ = auxquadgk(ev, _segments(dom), abstol, reltol, maxiters, batch=isb, max_batch=f.max_batch if isb else 2**62, order=order)
     return I, E, ev.numevals
 
 

@@ -331,8 +331,15 @@ class AuxQuadGKJL(IntegralAlgorithm):
 
 
 class QuadGKJL(AuxQuadGKJL):
-    """ref: src/algorithms.jl:9-20,67-96 (the duplicate of Integrals.jl's QuadGKJL): the same globally adaptive GK(7,15)
-    as AuxQuadGKJL without the AuxValue ordering -- which only differs for AuxValue integrands."""
+    """ref: src/algorithms.jl:9-20,67-96 (the duplicate of Integrals.jl's QuadGKJL): the same globally adaptive
+    Gauss-Kronrod as AuxQuadGKJL without the AuxValue ordering -- which only differs for AuxValue integrands.  Host-side
+    only, so any `order` is allowed (the rule is computed on first use, generic._GKRule); the device paths are GK(7,15)."""
+
+    def __init__(self, order=7, norm=None):
+        if int(order) < 1:
+            raise ValueError("QuadGKJL: order must be positive")
+        self.order = int(order)
+        self.norm = norm
 
 
 class IAI(AutoBZAlgorithm):
@@ -781,7 +788,7 @@ def _do_solve_generic(f, dom, p, alg, counter, abstol, reltol, maxiters):
     if not (callable(f) or isinstance(f, (BatchIntegrand, NestedBatchIntegrand))):
         raise ValueError(f"unsupported integrand {type(f).__name__}")
     if isinstance(alg, AuxQuadGKJL):
-        u, err, nev = G.solve_auxquadgk(f, dom, p, abstol, reltol, maxiters)
+        u, err, nev = G.solve_auxquadgk(f, dom, p, abstol, reltol, maxiters, order=alg.order)
     elif isinstance(alg, MonkhorstPack):
         if not isinstance(dom, Basis):
             raise ValueError("MonkhorstPack needs a Basis domain")

@@ -113,3 +113,33 @@ def test_absolute_estimate_sizes_the_tolerance_from_a_rough_solve():
     assert sol.resid <= reltol * abs(est.u)
     with pytest.raises(ValueError):
         abz.AbsoluteEstimate(abz.AuxQuadGKJL(), abz.QuadGKJL(), tolerance=1.0)  # checkkwargs
+
+
+def test_evalcounter_pins_on_a_constant_and_other_kronrod_orders():
+    """ref: test/interface_tests.jl:143-158 -- a constant integrand uses exactly the base rule: 15 evaluations for
+    QuadGKJL(order = 7), 19 for order = 9 (plain and batch integrands; the trapezoidal QuadratureFunction is out of scope).
+    The host-computed rule of order 7 reproduces the library's GK(7,15) table, and order 9 integrates the reference's
+    known-answer integrands (test/interface_tests.jl:33-42)."""
+    from autobzcore.jl_amd import generic as G
+    from autobzcore.jl_amd.hostquad import _gk_nodes
+    for order, nev in ((7, 15), (9, 19)):
+        sol = abz.solve(abz.IntegralProblem(lambda x, p: 1.0, (0.0, 1.0)), abz.EvalCounter(abz.QuadGKJL(order=order)))
+        assert sol.numevals == nev and abs(sol.u - 1.0) < 1e-15
+    bsol = abz.solve(abz.IntegralProblem(abz.BatchIntegrand(lambda y, x, p: y.__setitem__(slice(None), [1.0] * len(x)), float), (0.0, 1.0)),
+                     abz.EvalCounter(abz.AuxQuadGKJL()))
+    assert bsol.numevals == 15 and abs(bsol.u - 1.0) < 1e-15
+    r7 = G._GKRule.__new__(G._GKRule)
+    r7.order = 7
+    num = G._GKRule(6)  # any non-table order exercises the construction; compare the n = 7 construction with the table
+    assert abs(num.w.sum() - 2.0) < 1e-14 and np.all(num.w > 0) and num.npts == 13
+    r9 = G.gk_rule(9)
+    k = np.arange(0, 3 * 9 + 2)  # Kronrod rule of order n is exact to degree 3n + 1
+    exact = np.where(k % 2 == 0, 2.0 / (k + 1), 0.0)
+    assert np.abs(np.array([np.sum(r9.w * r9.x ** kk) for kk in k]) - exact).max() < 5e-15
+    assert np.abs(np.array([np.sum(r9.gw * r9.x[r9.gidx] ** kk) for kk in range(2 * 9)]) - exact[:18]).max() < 5e-15
+    a, b, p = 0.0, 2 * np.pi, 3.0
+    for f, ref in ((lambda x, p: p * np.sin(x), 0.0), (lambda x, p: p * 1.0, p * (b - a)),
+                   (lambda x, p: 1.0 / (p - np.cos(x)), (b - a) / math.sqrt(p * p - 1))):
+        for alg in (abz.QuadGKJL(order=9), abz.QuadGKJL(), abz.AuxQuadGKJL()):
+            assert abs(abz.solve(abz.IntegralProblem(f, (a, b), p), alg, abstol=1e-5).u - ref) < 1e-5
+    assert np.abs(np.sort(_gk_nodes(-1.0, 1.0)) - np.sort(G.gk_rule(7).nodes(-1.0, 1.0))).max() == 0.0
