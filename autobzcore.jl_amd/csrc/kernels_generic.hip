@@ -1422,7 +1422,7 @@ __global__ __launch_bounds__(256) void gen_grid_sum_tri_kernel(GenSumTriArgs a) 
 
 // sweeps of at least 3 values on 5..16 bands take the tridiagonal route
 static bool gen_sum_tri_wanted(const SumSpec& ss) {
-    static const bool off = [] { const char* e = getenv("ABZ_GEN_SUM_TRI"); return e && e[0] == '0'; }();
+    const bool off = [] { const char* e = getenv("ABZ_GEN_SUM_TRI"); return e && e[0] == '0'; }();  // per call: tests switch it
     return !off && ss.n > 4 && ss.n <= 16 && ss.n_sweep >= 3;
 }
 
@@ -2156,7 +2156,7 @@ static int launch_gen_rows_reduce(abz_ctx* ctx, const ReduceSpec& rs, double* ou
     double2* outd = ctx->scratch[2].as<double2>();
     {
         ProfScope ps(ctx, ABZ_K_REDUCE);
-        static const bool tri_off = [] { const char* e = getenv("ABZ_GEN_SUM_TRI"); return e && e[0] == '0'; }();
+        const bool tri_off = [] { const char* e = getenv("ABZ_GEN_SUM_TRI"); return e && e[0] == '0'; }();
         const bool tri = !tri_off && rs.n_sweep >= 3;  // sweeps: tridiagonalise once, p'/p per swept value
         if (tri && np == 8)
             hipLaunchKernelGGL(gen_rows_reduce_tri_kernel<8>, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, a);
