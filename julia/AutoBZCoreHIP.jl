@@ -65,6 +65,7 @@ mutable struct HIPSeries{N}
     h::Ptr{Cvoid}
     n::Int
     rules::Dict{Tuple{Int,UInt,Cint},Any}
+    exchange::Any                             # the @cfunction of shard_iai! (kept alive with the series)
 end
 function HIPSeries(s::FourierSeries{S,N}) where {S,N}
     c = s.c                                   # Array{SMatrix{n,n,ComplexF64}} or Array{<:Number}
@@ -79,7 +80,7 @@ function HIPSeries(s::FourierSeries{S,N}) where {S,N}
             (Ptr{Cvoid}, Ptr{Float64}, Cint, Ptr{Cint}, Ptr{Cint}, Ptr{Float64}, Cint, Ptr{Ptr{Cvoid}}),
             context().h, coef, N, dims, first, per, n, ref))
     end
-    hs = HIPSeries{N}(ref[], n, Dict())
+    hs = HIPSeries{N}(ref[], n, Dict(), nothing)
     finalizer(x -> ccall((:abz_series_destroy, libabz), Cint, (Ptr{Cvoid},), x.h), hs)
 end
 
@@ -344,7 +345,7 @@ function shard_iai!(hs::HIPSeries, allgather!, rank::Integer, world::Integer)
         end
     end
     fptr = @cfunction($cb, Cint, (Ptr{Cvoid}, Ptr{Float64}, Int64))
-    hs.rules[(-1, UInt(0), Cint(0))] = fptr            # keep the closure alive with the series
+    hs.exchange = fptr                                   # keep the closure alive with the series
     check(ccall((:abz_iai_set_exchange, libabz), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Cint, Cint),
                 hs.h, Base.unsafe_convert(Ptr{Cvoid}, fptr), C_NULL, rank, world))
     return hs
