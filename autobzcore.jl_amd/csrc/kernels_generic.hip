@@ -481,31 +481,35 @@ __device__ __forceinline__ void panel_shift_row(int n, double sw, double eta, in
     }
 }
 
-// value of `v` in lane C of this lane's NP-lane group (`ds_swizzle_b32`, bit-mask mode: lane' = (lane & ~(NP-1)) | C
-// inside each half wave): the LDS crossbar without an LDS access, 2.2 clk per dword against 14 clk for every
-// `ds_write_b128` of a row published through memory (tools/micro/ldstest.hip)
+// Broadcast of lane C of every 16-lane row on the VALU: ONE `v_mov_b64_dpp ... row_newbcast:C` per double (DPP on 64-bit
+// operands exists for row_newbcast only, gfx90a+; the destination's previous value is undefined, so nothing initialises
+// it -- the first version, `update_dpp(0, ...)` on the two halves, cost four instructions per double).
+template <int C>
+__device__ __forceinline__ double row16_bcast_dpp(double v) {
+#if defined(__HIP_DEVICE_COMPILE__)  // the host pass of hipcc only knows the 32-bit signature of the builtin
+    const long long x = __builtin_bit_cast(long long, v);
+    return __builtin_bit_cast(double, (long long)__builtin_amdgcn_mov_dpp(x, 0x150 + C, 0xf, 0xf, false));
+#else
+    return v;
+#endif
+}
+
+// value of `v` in lane C of this lane's NP-lane group.  NP = 16: the DPP row broadcast above (config 5: 11.2 -> 10.5 s
+// against carrying the pivot rows half by swizzle, half by two 32-bit DPP moves).  Other group sizes: `ds_swizzle_b32`,
+// bit-mask mode: lane' = (lane & ~(NP-1)) | C inside each half wave -- the LDS crossbar without an LDS access, 2.2 clk
+// per dword against 14 clk for every `ds_write_b128` of a row published through memory (tools/micro/ldstest.hip)
 template <int NP, int C>
 __device__ __forceinline__ double group_bcast(double v) {
+    if constexpr (NP == 16) return row16_bcast_dpp<C>(v);
     constexpr int pattern = ((32 - NP) & 0x1f) | (C << 5);  // and_mask | or_mask << 5, xor_mask 0
     const int lo = __builtin_amdgcn_ds_swizzle(__double2loint(v), pattern);
     const int hi = __builtin_amdgcn_ds_swizzle(__double2hiint(v), pattern);
     return __hiloint2double(hi, lo);
 }
 
-// The same broadcast on the VALU: `v_mov_b32 ... row_newbcast:C` (DPP, gfx90a+) copies lane C of every 16-lane row to the
-// whole row.  2 clk per dword next to f64 FMAs at 4 waves/SIMD (tools/micro/valutest.hip), no LDS crossbar.  At 16
-// lanes per node the pivot row costs one dword moved per FMA, so moving ALL of it to the VALU only trades an LDS bound
-// for a VALU bound: the imaginary parts travel by DPP, the real parts by swizzle, and both pipes carry half.
-template <int C>
-__device__ __forceinline__ double row16_bcast_dpp(double v) {
-    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x150 + C, 0xf, 0xf, false);
-    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x150 + C, 0xf, 0xf, false);
-    return __hiloint2double(hi, lo);
-}
-
 // one Gauss-Jordan pivot (column C) of the zero-padded NP x NP matrix whose row r this lane holds: the pivot
 // row comes from lane C of the group, eight columns at a time (the eight that hold the pivot first)
-template <int NP, int C, bool DPPI = true>
+template <int NP, int C>
 __device__ __forceinline__ void panel_pivot(int r, double (&ar)[NP], double (&ai)[NP]) {
     constexpr int NB = NP / 8;
     double gr = 0.0, gi = 0.0, ipr = 0.0, ipi = 0.0;
@@ -516,10 +520,7 @@ __device__ __forceinline__ void panel_pivot(int r, double (&ar)[NP], double (&ai
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             ur[j] = group_bcast<NP, C>(ar[j0 + j]);
-            if constexpr (NP == 16 && DPPI)
-                ui[j] = row16_bcast_dpp<C>(ai[j0 + j]);
-            else
-                ui[j] = group_bcast<NP, C>(ai[j0 + j]);
+            ui[j] = group_bcast<NP, C>(ai[j0 + j]);
         }
         if (b == 0) {
             const double pr = ur[C % 8], pi = ui[C % 8];
