@@ -1501,8 +1501,10 @@ static int launch_gen_sum_tri(abz_ctx* ctx, const SumSpec& ss, double* out_reim)
     return ABZ_OK;
 }
 
-template <int NP, bool PAD, bool VEC>
-__global__ __launch_bounds__(256) void gen_grid_eig_kernel(GenEigArgs a) {
+// TRI: eigenvalues only by Householder + Sturm bisection (its own instance: the Jacobi path of the same kernel costs
+// it 90 more registers and the second wave per SIMD)
+template <int NP, bool PAD, bool VEC, bool TRI>
+__global__ __launch_bounds__(256, TRI ? 2 : 1) void gen_grid_eig_kernel(GenEigArgs a) {
     extern __shared__ double2 lds_ge[];
     constexpr int SLOTS = 256 / NP;
     const int n = a.n, nn = n * n, M = a.M;
@@ -1548,13 +1550,9 @@ __global__ __launch_bounds__(256) void gen_grid_eig_kernel(GenEigArgs a) {
             if (!a.E.base) continue;  // values only (uniform)
             double vr[NP], vi[NP], dg;
             int rank;
-            if constexpr (!VEC) {
-                if (a.tridiag) {  // eigenvalues only: Householder + Sturm bisection, lane r gets eigenvalue r
-                    dg = rows_eigvals_tridiag<NP>(n, r, hr, hi);
-                    rank = r;
-                } else {
-                    rows_eig<NP, VEC>(n, r, lane, hr, hi, vr, vi, dg, rank);
-                }
+            if constexpr (TRI) {  // eigenvalues only: Householder + Sturm bisection, lane r gets eigenvalue r
+                dg = rows_eigvals_tridiag<NP>(n, r, hr, hi);
+                rank = r;
             } else {
                 rows_eig<NP, VEC>(n, r, lane, hr, hi, vr, vi, dg, rank);
             }
@@ -1618,15 +1616,17 @@ static int launch_gen_grid_eig(abz_ctx* ctx, const GenSpec& gs, int np, size_t l
     const int64_t blocks = std::min<int64_t>(a.nlines, 256 * 4);
     const bool vec = gs.Uplanes.base != nullptr;
     ProfScope ps(ctx, ABZ_K_EVAL);
-#define ABZ_GE3(NPV, PV, VV)                                                                                              \
-    ABZ_HIP(hipFuncSetAttribute((const void*)gen_grid_eig_kernel<NPV, PV, VV>, hipFuncAttributeMaxDynamicSharedMemorySize, \
-                                (int)lds));                                                                               \
-    hipLaunchKernelGGL((gen_grid_eig_kernel<NPV, PV, VV>), dim3((unsigned)blocks), dim3(256), lds, ctx->stream, a);
+#define ABZ_GE3(NPV, PV, VV, TV)                                                                                              \
+    ABZ_HIP(hipFuncSetAttribute((const void*)gen_grid_eig_kernel<NPV, PV, VV, TV>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                (int)lds));                                                                                   \
+    hipLaunchKernelGGL((gen_grid_eig_kernel<NPV, PV, VV, TV>), dim3((unsigned)blocks), dim3(256), lds, ctx->stream, a);
 #define ABZ_GE2(NPV, PV) \
     if (vec) {           \
-        ABZ_GE3(NPV, PV, true) \
+        ABZ_GE3(NPV, PV, true, false) \
+    } else if (a.tridiag) { \
+        ABZ_GE3(NPV, PV, false, true) \
     } else {             \
-        ABZ_GE3(NPV, PV, false) \
+        ABZ_GE3(NPV, PV, false, false) \
     }
 #define ABZ_GE(NPV) \
     if (pad) {      \
@@ -1947,7 +1947,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 4))) voi
 // 256 omega at 16 bands: 4 passes over the rule and ~(4 x 2.5 k + 256 / 16 x 250) instructions per four nodes instead
 // of 64 passes and 256 x 1.3 k.
 template <int NP>
-__global__ __launch_bounds__(256) void gen_rows_reduce_tri_kernel(GenRowsReduceArgs a) {
+__global__ __launch_bounds__(256, 2) void gen_rows_reduce_tri_kernel(GenRowsReduceArgs a) {
     constexpr int SLOTS = 256 / NP;
     __shared__ double2 red[SLOTS * 4 * NP];
     const int n = a.n;
