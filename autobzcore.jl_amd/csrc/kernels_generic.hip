@@ -2197,8 +2197,98 @@ static int launch_gen_rows_reduce(abz_ctx* ctx, const ReduceSpec& rs, double* ou
     return ABZ_OK;
 }
 
+// DOS from CACHED EIGENVALUES for more than four bands: sum_k w_k sum_b (eta / pi) / ((omega - e_b(k))^2 + eta^2).
+// One thread per node (the eigenvalue planes are read coalesced), eight swept values per pass in registers, one
+// reciprocal (estimate + 2 Newton steps) per (k, band, omega); wave sums by shuffles, four waves through LDS, the block
+// partials summed by final_reduce_kernel in a fixed order.  Replaces the wave-per-node loop of gen_reduce_kernel for this
+// integrand (16 bands, 48^3, 16 omega: 0.94 ms there).
+struct GenEigDosArgs {
+    PlaneView E;
+    const double* w;
+    const double* sweep;
+    double2* partial;  // [gridDim.x][n_sweep]
+    int64_t nk;
+    int n, n_sweep;
+    double eta;
+};
+
+__global__ __launch_bounds__(256) void gen_eig_dos_kernel(GenEigDosArgs a) {
+    constexpr int SW = 8;
+    __shared__ double red[4][SW];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const double eta2 = a.eta * a.eta;
+    for (int s0 = 0; s0 < a.n_sweep; s0 += SW) {
+        double sw[SW], acc[SW];
+#pragma unroll
+        for (int j = 0; j < SW; ++j) {
+            sw[j] = a.sweep[min(s0 + j, a.n_sweep - 1)];
+            acc[j] = 0.0;
+        }
+        for (int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x; k < a.nk; k += (int64_t)gridDim.x * 256) {
+            const double* __restrict__ e = a.E.base + view_off(a.E, k);
+            double part[SW];
+#pragma unroll
+            for (int j = 0; j < SW; ++j) part[j] = 0.0;
+            for (int b = 0; b < a.n; ++b) {
+                const double eb = e[(int64_t)b * a.E.pitch];
+#pragma unroll
+                for (int j = 0; j < SW; ++j) {
+                    const double de = sw[j] - eb;
+                    part[j] += rcp_nr(fma(de, de, eta2));
+                }
+            }
+            const double wk = a.w ? a.w[k] : 1.0;
+#pragma unroll
+            for (int j = 0; j < SW; ++j) acc[j] = fma(wk, part[j], acc[j]);
+        }
+        __syncthreads();  // the previous pass's readers are done with `red`
+#pragma unroll
+        for (int j = 0; j < SW; ++j) {
+            const double v = wsum(acc[j]);
+            if (lane == 0) red[wave][j] = v;
+        }
+        __syncthreads();
+        if (threadIdx.x < SW && s0 + (int)threadIdx.x < a.n_sweep) {
+            const int j = threadIdx.x;
+            const double v = (red[0][j] + red[1][j]) + (red[2][j] + red[3][j]);
+            a.partial[(int64_t)blockIdx.x * a.n_sweep + s0 + j] = make_double2(v * a.eta * 0.31830988618379067153776752674503, 0.0);
+        }
+    }
+}
+
+static int launch_gen_eig_dos(abz_ctx* ctx, const ReduceSpec& rs, double* out_reim) {
+    const int64_t blocks = std::max<int64_t>(1, std::min<int64_t>(cdiv2(rs.nk, 256), 256 * 4));
+    int rc = ctx->scratch[1].reserve(sizeof(double2) * (size_t)(blocks * rs.n_sweep));
+    if (rc) return rc;
+    if ((rc = ctx->scratch[2].reserve(sizeof(double2) * (size_t)rs.n_sweep))) return rc;
+    GenEigDosArgs a;
+    a.E = rs.E;
+    a.w = rs.w;
+    a.sweep = rs.sweep_dev;
+    a.partial = ctx->scratch[1].as<double2>();
+    a.nk = rs.nk;
+    a.n = rs.n;
+    a.n_sweep = rs.n_sweep;
+    a.eta = rs.params[0];
+    double2* outd = ctx->scratch[2].as<double2>();
+    {
+        ProfScope ps(ctx, ABZ_K_REDUCE);
+        hipLaunchKernelGGL(gen_eig_dos_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, a);
+        ABZ_HIP(hipGetLastError());
+        if ((rc = launch_final_reduce(ctx, a.partial, blocks, rs.n_sweep, rs.scale, outd))) return rc;
+    }
+    if (rs.out_dev) {
+        ABZ_HIP(hipMemcpyAsync(rs.out_dev, outd, sizeof(double2) * (size_t)rs.n_sweep, hipMemcpyDeviceToDevice, ctx->stream));
+        return ABZ_OK;
+    }
+    ABZ_HIP(hipMemcpyAsync(out_reim, outd, sizeof(double2) * (size_t)rs.n_sweep, hipMemcpyDeviceToHost, ctx->stream));
+    ABZ_HIP(hipStreamSynchronize(ctx->stream));
+    return ABZ_OK;
+}
+
 int launch_gen_reduce(abz_ctx* ctx, const ReduceSpec& rs, double* out_reim) {
     if (gen_rows_reduce_supported(rs)) return launch_gen_rows_reduce(ctx, rs, out_reim);
+    if (rs.integrand == ABZ_F_DOS_EIG && rs.E.base && rs.sweep_dev && rs.n_sweep >= 1) return launch_gen_eig_dos(ctx, rs, out_reim);
     const int ncomp = integrand_ncomp(rs.integrand, rs.n, rs.d);
     if (ncomp < 0 || rs.integrand == ABZ_F_LINEAR || rs.integrand == ABZ_F_LINEAR_X) {
         set_error("integrand %d is not available for n = %d bands", rs.integrand, rs.n);
