@@ -167,11 +167,13 @@ class iaishard:
         if world > 1 or (self.force and _dist().is_initialized()):
             self._cb = L.EXCHANGE_FN(self._exchange)
             L.check(L.lib().abz_iai_set_exchange(self.dev.h, self._cb, None, rank, world))
+            self.dev.iai_exchange = True  # sweeps on this series stay on one lane (the hook lives on this handle)
         return self
 
     def __exit__(self, *exc):
         from . import _lib as L
         if self._cb is not None:
             L.check(L.lib().abz_iai_set_exchange(self.dev.h, None, None, 0, 1))
+            self.dev.iai_exchange = False
             self._cb = None
         return False

@@ -393,6 +393,47 @@ def test_iai_batchsolve_lockstep_is_bit_identical(abz):
         assert np.array_equal(np.asarray(many[k]), np.asarray(solver(b=b)))
 
 
+def test_iai_sweep_lanes_change_nothing(abz, svo, monkeypatch):
+    """Sweeps of >= 64 independent IAI solves run on two lanes (two host threads, two device contexts with their own
+    copies of the series): values, error estimates and evaluation counts must be those of the one-lane sweep, bit for bit,
+    for the 3-band SVO model on the cubic IBZ and a 6-band generic-n series; a coefficient update reaches both lanes."""
+    s, _ = svo
+    om = np.linspace(11.0, 14.0, 96)
+    bz = abz.load_bz(abz.CubicSymIBZ(), 3.85856 * np.eye(3))
+    solver = abz.IntegralSolver(abz.FourierIntegrand(abz.DOSIntegrand(), s, 0.1), bz, abz.EvalCounter(abz.IAI()), abstol=1e-2)
+
+    def sweep(sv, ps):
+        meta = []
+        vals = abz.batchsolve(sv, ps, callback=lambda s_, i, k, p, sol, t: meta.append((i, sol.resid, sol.numevals)))
+        return np.asarray(vals), sorted(meta)
+    monkeypatch.setenv("ABZ_IAI_LANES", "1")
+    v1, m1 = sweep(solver, om)
+    monkeypatch.setenv("ABZ_IAI_LANES", "2")
+    v2, m2 = sweep(solver, om)
+    monkeypatch.setenv("ABZ_IAI_LANES", "3")
+    v3, m3 = sweep(solver, om)
+    assert np.array_equal(v1, v2) and m1 == m2 and np.array_equal(v1, v3) and m1 == m3
+    assert len(s._dev) >= 3  # the lanes' copies of the device series exist
+    rng = np.random.default_rng(77)
+    c, first = rand_series(rng, (3, 3), 6, hermitian=True)
+    s6, _ = both(abz, c / np.sqrt(6), first)
+    sol6 = abz.IntegralSolver(abz.FourierIntegrand(abz.TrGlocIntegrand(), s6, 0.2), abz.load_bz(abz.FBZ(), np.eye(2)),
+                              abz.EvalCounter(abz.IAI()), abstol=1e-2)
+    om6 = np.linspace(-1.0, 1.0, 70)
+    monkeypatch.setenv("ABZ_IAI_LANES", "1")
+    a1, n1 = sweep(sol6, om6)
+    monkeypatch.setenv("ABZ_IAI_LANES", "2")
+    a2, n2 = sweep(sol6, om6)
+    assert np.array_equal(a1, a2) and n1 == n2
+    # new coefficients must reach the second lane's copy as well
+    s6.c[...] = s6.c * 0.5
+    s6.invalidate()
+    b2, _ = sweep(sol6, om6)
+    monkeypatch.setenv("ABZ_IAI_LANES", "1")
+    b1, _ = sweep(sol6, om6)
+    assert np.array_equal(b1, b2) and not np.array_equal(a1, b1)
+
+
 def test_kshard_partial_rules_sum_to_the_full_rule(abz, svo):
     """a solve sharded over k.  The W ranks' rules (slabs of the outermost variable of a
     full grid / blocks of the irreducible nodes) are built one after another on this GPU; their partial
