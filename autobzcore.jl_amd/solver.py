@@ -638,16 +638,17 @@ _LANE_CTX = {}  # device id -> extra contexts (own streams) of the sweep lanes
 
 
 def _iai_lanes(dev, nsolves, want_panels):
-    """How many lanes a sweep of `nsolves` independent IAI solves is split into (ABZ_IAI_LANES, default up to 4, one per 32 solves, from 64
-    solves on; 1 = off).  A lane = a host thread driving its own device context (stream) and its own copy of the
-    device-resident series, so one lane's host rounds (gather, heaps, delivery) overlap the other lanes' kernels: the
+    """How many lanes a sweep of `nsolves` independent IAI solves is split into (ABZ_IAI_LANES, default up to 4 with
+    at least ABZ_IAI_LANE_MIN = 16 solves each; 1 = off; tools/time_iai_lanes.py).  A lane = a host thread driving its
+    own device context (stream) and its own copy of the device-resident series, so one lane's host rounds (gather, heaps, delivery) overlap the other lanes' kernels: the
     432-solve sweep of the reference's example was 0.11 s with 0.055 s of it waiting on the GPU.  Every solve makes the
     decisions it would make alone, so the split changes no result."""
     import os
     if want_panels or getattr(dev, "iai_exchange", False) or dev.kshard is not None:
         return 1
     want = int(os.environ.get("ABZ_IAI_LANES", "4"))
-    return max(1, min(want, nsolves // 32)) if nsolves >= 64 else 1
+    per = max(1, int(os.environ.get("ABZ_IAI_LANE_MIN", "16")))  # at least this many solves per lane
+    return max(1, min(want, nsolves // per))
 
 
 def _iai_device_many(f: FourierIntegrand, dev, lims, plist, abstol, reltol, maxiters, want_panels=False):
