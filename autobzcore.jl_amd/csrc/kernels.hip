@@ -903,7 +903,7 @@ int launch_eval(abz_ctx* ctx, const EvalSpec& es) {
     {
         // streaming stores once the values written by this launch exceed the 256 MB Infinity Cache
         // (npt = 100, 168 MB: 7 % slower with them; 150, 605 MB: 19 % faster)
-        static const int force = [] { const char* e = getenv("ABZ_NT_STORES"); return e ? atoi(e) : -1; }();
+        const int force = [] { const char* e = getenv("ABZ_NT_STORES"); return e ? atoi(e) : -1; }();  // per launch (tools sweep it)
         const PlaneView& pv = es.H.base ? es.H : es.E;
         const double bytes = 8.0 * (double)pv.tile * (double)(es.grid ? es.nlines : (es.nk + 63) / 64);
         a.nt = force >= 0 ? force : (bytes > 256.0 * 1024 * 1024 ? 1 : 0);
@@ -920,7 +920,12 @@ int launch_eval(abz_ctx* ctx, const EvalSpec& es) {
     ProfScope ps(ctx, ABZ_K_EVAL);
     if (es.grid) {
         if (es.nlines == 0) return ABZ_OK;
-        int64_t blocks = std::min<int64_t>(cdiv(es.nlines, 4), 256 * 8);
+        // Workgroups: 8 per CU up to ~140^3, 16 per CU beyond (tools/time_eval_blocks.py, 3 bands: npt 150 0.1133 -> 0.1101 ms
+        // on a fast box, 0.1234 -> 0.1175 on a slow one; 200 -6 %, 250 -15 %, 300 -3 %, 500 -6 %; 110 / 128 are 3-5 %
+        // better with 8 per CU, 180 and 400 lose 2-3 % with 16).  ABZ_EVAL_BLOCKS overrides.
+        const int eval_blocks = [] { const char* e = getenv("ABZ_EVAL_BLOCKS"); return e ? atoi(e) : 0; }();  // per launch: the timing tool sweeps it
+        const int64_t quads = cdiv(es.nlines, 4);
+        int64_t blocks = std::min<int64_t>(quads, eval_blocks > 0 ? eval_blocks : (quads < 5000 ? 256 * 8 : 256 * 16));
         const int mnn = es.M * es.n * es.n;
         // nodes per lane: minimise lane-rounds per line, ceil(npt / (64 kpl)) * kpl, weighted by the LDS
         // operand reads that are shared by the kpl nodes of a lane (200 points: 2 x 2 rounds, not 2 x 3)

@@ -494,10 +494,11 @@ def rank_main(a):
             "iai_config5_sharded": c5_job,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(npt),
-                         "store_pattern_ceiling_GBs": 5100.0,
-                         "frac_of_store_pattern_ceiling": achieved / 5100.0,
+                         "store_pattern_ceiling_GBs": 5830.0,
+                         "frac_of_store_pattern_ceiling": achieved / 5830.0,
                          "store_pattern_note": "bare store pattern of this kernel's tiled planar layout without any compute "
-                                               "(tools/micro/wtest.hip, profiles/r02_store_pattern_microbench.txt): 5.1 TB/s of useful bytes",
+                                               "(tools/micro/placement.hip, profiles/r02_placement_microbench.txt): 6.2 TB/s = 5.83 TB/s of useful bytes with temporal stores, "
+                                               "5.2-5.6 TB/s with the non-temporal stores the kernel needs (allocation-dependent); a linear memset 8.2 TB/s",
                          "traffic_note": "HBM bytes per launch from rocprofv3 PMC passes (profiles/r0x_traffic.json); algorithmic bytes per launch = nk*168",
                          "kernel": "eval_grid_kernel<3> (Fourier-eval + fused eig)",
                          "algorithmic_bytes_per_kpoint": 16 * n * n + 8 * n,

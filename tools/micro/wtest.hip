@@ -76,7 +76,7 @@ int main() {
     const char* names[10] = {"A planar 8B", "B tiled [line][plane][160]", "C AoS", "D planar 16B", "E 8-line tiles no pad", "F 8-line tiles no pad NT",
                             "G tiled [line][plane][160] NT", "H 2-line tiles pitch 304 NT",
                             "I tiled [160] 16-B stores", "J tiled [160] 16-B stores NT"};
-    for (int blocks : {2048, 1024, 512}) {
+    for (int blocks : {8192, 4096, 2048, 1024, 512}) {
         for (int mode = 0; mode < 10; ++mode) {
             float best = 1e9;
             for (int rep = 0; rep < 6; ++rep) {
