@@ -57,11 +57,16 @@ struct DevBuf {
 // plane p) = base[(k / line_len) * tile + p * pitch + k % line_len].  One wave writes one tile: a
 // single contiguous ~27 KB HBM region instead of 21 streams 27 MB apart (1.7x the write bandwidth,
 // tools/micro/wtest.hip).
+// The same formula carries the PADDED PLANAR layout of full-grid rules (ABZ_RULE_PLANAR): tile = row (the stride from one
+// grid line to the next inside a plane), pitch = nlines * row (the stride from one plane to the next), so every plane is one
+// dense array of padded rows and all resident waves write it as one front (tools/micro/placement.hip).  `row` is the padded
+// row length either way (columns line_len .. row-1 of a row are padding).
 struct PlaneView {
     double* base = nullptr;  // first plane of this array inside tile 0
-    int64_t tile = 0;        // doubles per tile (all arrays of the tile)
-    int pitch = 0;
+    int64_t tile = 0;        // doubles from one line (tile) to the next
+    int pitch = 0;           // doubles from one plane to the next
     int line_len = 1;
+    int row = 0;             // padded row length (multiple of 16 doubles = 128 B)
 };
 
 struct ProfSlot {

@@ -702,7 +702,8 @@ static int rule_fill(abz_rule* r) {
     PlaneView Uv, Dv;
     if (r->want & ABZ_WANT_VEL) {
         Uv.base = rp->tmpU.as<double>();
-        Uv.pitch = r->H.pitch ? r->H.pitch : r->E.pitch;
+        Uv.pitch = r->H.row ? r->H.row : r->E.row;  // temporaries are tiled whatever the rule's layout
+        Uv.row = Uv.pitch;
         Uv.line_len = r->E.line_len;
         Uv.tile = (int64_t)2 * n * n * Uv.pitch;
         Dv = Uv;
@@ -870,7 +871,11 @@ static int rule_build(abz_series* s, int npt, int64_t nirr, const int32_t* irr_i
     const int pE = (want & ABZ_WANT_EIG) ? n : 0;
     const int pV = (want & ABZ_WANT_VEL) ? d * n : 0;
     r->planes = pH + pE + pV;
-    const int64_t tile = (int64_t)r->planes * pitch;
+    // layout of the value planes: tiles [line][plane][row] or, for full grids on request, padded planar [plane][line][row]
+    static const bool planar_on = [] { const char* e = getenv("ABZ_RULE_PLANAR"); return e && e[0] == '1'; }();
+    const bool planar = planar_on && r->full && (int64_t)r->ntiles * pitch < ((int64_t)1 << 31);
+    const int64_t tile = planar ? (int64_t)pitch : (int64_t)r->planes * pitch;
+    const int pstride = planar ? (int)(r->ntiles * pitch) : pitch;  // plane to plane
     RULE_TRY(plan_upload(ctx, plan, rp->pd));
     lap("plan_upload");
     RULE_TRY(make_phase_table(ctx, npt, rp->tab));
@@ -894,7 +899,7 @@ static int rule_build(abz_series* s, int npt, int64_t nirr, const int32_t* irr_i
             RULE_TRY(launch_phases(ctx, ps, rp->pd.phg[L].as<double2>()));
         }
     }
-    const size_t bytes = sizeof(double) * (size_t)(r->ntiles * tile);
+    const size_t bytes = sizeof(double) * (size_t)(r->ntiles * (int64_t)r->planes * pitch);
     RULE_TRY(dev_alloc((void**)&r->vals, bytes, &r->vals_cap));
     // on the context's stream: it is non-blocking, a null-stream memset would not be ordered before the
     // fill kernels below (and could land on top of their results)
@@ -903,10 +908,11 @@ static int rule_build(abz_series* s, int npt, int64_t nirr, const int32_t* irr_i
     auto mkview = [&](int plane0, bool present) {
         PlaneView v;
         if (present) {
-            v.base = r->vals + (int64_t)plane0 * pitch;
+            v.base = r->vals + (int64_t)plane0 * pstride;
             v.tile = tile;
-            v.pitch = pitch;
+            v.pitch = pstride;
             v.line_len = line_len;
+            v.row = pitch;
         }
         return v;
     };
@@ -925,7 +931,7 @@ static int rule_build(abz_series* s, int npt, int64_t nirr, const int32_t* irr_i
         RULE_TRY(stage_h2d(ctx, r->idx, it.data(), sizeof(int32_t) * (size_t)(nirr * d)));
     }
     if (want & ABZ_WANT_VEL) {
-        const size_t tb = sizeof(double) * (size_t)(r->ntiles * 2 * n * n * pitch);
+        const size_t tb = sizeof(double) * (size_t)(r->ntiles * 2 * n * n * pitch);  // tiled temporaries
         RULE_TRY(rp->tmpU.reserve(tb));
         RULE_TRY(rp->tmpD.reserve(tb));
     }
@@ -965,7 +971,7 @@ int abz_rule_rebuild(abz_rule* r) {
     ABZ_HIP(hipSetDevice(ctx->device));
     RulePlan* rp = static_cast<RulePlan*>(r->plan);
     if (r->want & ABZ_WANT_VEL) {
-        const size_t tb = sizeof(double) * (size_t)(r->ntiles * 2 * r->s->n * r->s->n * r->E.pitch);
+        const size_t tb = sizeof(double) * (size_t)(r->ntiles * 2 * r->s->n * r->s->n * r->E.row);
         int rc = rp->tmpU.reserve(tb);
         if (rc) return rc;
         if ((rc = rp->tmpD.reserve(tb))) return rc;
@@ -1048,7 +1054,7 @@ int abz_rule_values_ptr(const abz_rule* r, void** base, int64_t* nbytes) {
     int rc0 = check_rule(r);
     if (rc0) return rc0;
     if (base) *base = r->vals;
-    if (nbytes) *nbytes = (int64_t)sizeof(double) * r->ntiles * r->planes * (r->H.base ? r->H.pitch : r->E.pitch);
+    if (nbytes) *nbytes = (int64_t)sizeof(double) * r->ntiles * r->planes * (r->H.base ? r->H.row : r->E.row);
     return ABZ_OK;
 }
 
@@ -1218,6 +1224,7 @@ int abz_eval_nodes(abz_series* s, const double* k, int64_t nk, int want, double*
             if ((status = Hd.reserve(sizeof(double) * (size_t)ntl * 64 * 2 * n * n))) break;
             Hv.base = Hd.as<double>();
             Hv.pitch = 64;
+            Hv.row = 64;
             Hv.line_len = 64;
             Hv.tile = (int64_t)2 * n * n * 64;
         }
@@ -1225,6 +1232,7 @@ int abz_eval_nodes(abz_series* s, const double* k, int64_t nk, int want, double*
             if ((status = Ed.reserve(sizeof(double) * (size_t)ntl * 64 * n))) break;
             Ev.base = Ed.as<double>();
             Ev.pitch = 64;
+            Ev.row = 64;
             Ev.line_len = 64;
             Ev.tile = (int64_t)n * 64;
         }

@@ -527,7 +527,7 @@ __device__ __forceinline__ void eval_unit_store(const EvalArgs& a, CMat<N> (&H)[
 #pragma unroll
         for (int j = 0; j < KPL; ++j) {
             const int i1 = i0 + lane + 64 * j;
-            const int pitch = a.H.base ? a.H.pitch : a.E.pitch;
+            const int pitch = a.H.base ? a.H.row : a.E.row;
             if (i1 < pitch) eval_epilogue<N, VEC>(a, H[j], line, i1);
         }
     }
@@ -538,7 +538,7 @@ __device__ __forceinline__ void eval_unit_store(const EvalArgs& a, CMat<N> (&H)[
         // stores), then the eigenvalue stores.  With non-temporal stores on rules larger than the Infinity
         // Cache this is worth 19 % at 150^3 (neither change alone is: the interleaved order leaves the
         // store queue empty during every eigensolve, and temporal stores make the 605 MB fight for L2/MALL).
-        const int pitch = a.padw ? (a.H.base ? a.H.pitch : a.E.pitch) : a.npt;
+        const int pitch = a.padw ? (a.H.base ? a.H.row : a.E.row) : a.npt;
         auto epilogue = [&](auto nt) {
             constexpr bool NT = decltype(nt)::value;
             if (a.H.base) {
@@ -905,7 +905,8 @@ int launch_eval(abz_ctx* ctx, const EvalSpec& es) {
         // (npt = 100, 168 MB: 7 % slower with them; 150, 605 MB: 19 % faster)
         const int force = [] { const char* e = getenv("ABZ_NT_STORES"); return e ? atoi(e) : -1; }();  // per launch (tools sweep it)
         const PlaneView& pv = es.H.base ? es.H : es.E;
-        const double bytes = 8.0 * (double)pv.tile * (double)(es.grid ? es.nlines : (es.nk + 63) / 64);
+        const double planes_out = (es.H.base ? 2.0 * es.n * es.n : 0.0) + (es.E.base ? (double)es.n : 0.0) + (es.U.base ? 2.0 * es.n * es.n : 0.0);
+        const double bytes = 8.0 * planes_out * (double)pv.row * (double)(es.grid ? es.nlines : (es.nk + 63) / 64);
         a.nt = force >= 0 ? force : (bytes > 256.0 * 1024 * 1024 ? 1 : 0);
         static const int padw = [] { const char* e = getenv("ABZ_PAD_WRITE"); return e ? atoi(e) : 1; }();
         a.padw = padw;
