@@ -840,13 +840,10 @@ bool eval_can_fuse(int n, int M, int M2, int npt) {
     return mnn <= EVAL_MAX_MNN && npt < 65536 && lds <= 48 * 1024;
 }
 
-static int eval_occ() {
-    static int occ = [] {
-        const char* e = getenv("ABZ_EVAL_OCC");
-        const int v = e ? atoi(e) : 3;
-        return (v == 2 || v == 3 || v == 4) ? v : 3;
-    }();
-    return occ;
+static int eval_occ() {  // read per launch: tools/time_eval_blocks.py sweeps it on one buffer
+    const char* e = getenv("ABZ_EVAL_OCC");
+    const int v = e ? atoi(e) : 3;
+    return (v == 2 || v == 3 || v == 4) ? v : 3;
 }
 
 int launch_eval(abz_ctx* ctx, const EvalSpec& es) {

@@ -21,6 +21,9 @@ for npt in [int(v) for v in sys.argv[1:]]:
         for b in cands + cands[:1]:
             os.environ["ABZ_EVAL_BLOCKS"] = str(abs(b))
             os.environ["ABZ_NT_STORES"] = "0" if b < 0 else "1"  # negative candidate: temporal stores
+            if os.environ.get("OCCS"):  # candidates are then "occ * 100000 + blocks"
+                os.environ["ABZ_EVAL_OCC"] = str(abs(b) // 100000)
+                os.environ["ABZ_EVAL_BLOCKS"] = str(abs(b) % 100000)
             for _ in range(10): rule.rebuild()
             ctx.sync()
             ctx.prof_enable(True, kernels=[L.K_EVAL]); ctx.prof_reset()
