@@ -1345,6 +1345,21 @@ def test_single_iai_solve_sharded_over_two_ranks():
 
 
 # ------------------------------------------------------------------ errors
+def test_padded_planar_rule_layout_option():
+    """ABZ_RULE_PLANAR=1 lays full-grid rules out as [plane][line][row] instead of tiles [line][plane][row] (the same
+    PlaneView formula with tile = row stride, pitch = plane stride; read once per process, hence the child process): rule
+    values, exports, scans, slabs and sweeps must not notice."""
+    import subprocess
+    import sys
+    env = dict(os.environ, ABZ_RULE_PLANAR="1")
+    p = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-p", "no:cacheprovider", "-k",
+                        "full_grid_rule_matches_oracle or rule_reduce_matches_oracle_dos or kshard_partial_rules or "
+                        "svo_dos_sweep or ggr_matches_oracle or store_free_rule_value_equals"],
+                       capture_output=True, text=True, timeout=900, env=env)
+    assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-2000:]
+    assert " passed" in p.stdout and "failed" not in p.stdout
+
+
 def test_error_behaviour(abz):
     s = abz.FourierSeries(np.zeros((3, 3)), first=-1, ndim=2)
     bz3 = abz.load_bz(abz.FBZ(), np.eye(3))
