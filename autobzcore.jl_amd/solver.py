@@ -377,11 +377,21 @@ class AutoPTR(AutoBZAlgorithm):
         return n0, dn
 
 
-class TAI(AutoBZAlgorithm):
-    """ref: src/brillouin.jl:453-463 -- HCubature is outside the hot-path scope."""
+class HCubatureJL(IntegralAlgorithm):
+    """ref: src/algorithms.jl:94-124 (h-adaptive cubature: Genz-Malik boxes, GK(7,15) in one dimension).  Host-side: the
+    tree lives in generic.hcubature; a FourierIntegrand's series values at every box's points come from ONE
+    abz_eval_nodes call (the fallback evaluator, src/fourier.jl:120-122)."""
 
-    def __init__(self, *a, **k):
-        raise NotImplementedError("TAI/HCubatureJL is outside the hot-path scope (SURVEY section 2)")
+    def __init__(self, norm=None, initdiv=1):
+        self.norm, self.initdiv = norm, int(initdiv)
+
+
+class TAI(AutoBZAlgorithm):
+    """Tree-adaptive integration over the (cubic) limits of the zone: HCubatureJL on HyperCube(lims.a, lims.b); zones whose
+    limits are not cubic are integrated over the full BZ without symmetries.  ref: src/brillouin.jl:446-463."""
+
+    def __init__(self, norm=None, initdiv=1):
+        self.norm, self.initdiv = norm, int(initdiv)
 
 
 class MonkhorstPack(IntegralAlgorithm):
@@ -740,6 +750,31 @@ def _iai_host(f: FourierIntegrand, dev, lims, p: MixedParameters, abstol, reltol
     return nested_quad_host(f, dev, lims, p, abstol, reltol, maxiters)
 
 
+def _hcubature_fourier(f: FourierIntegrand, dev, cube, pm: MixedParameters, alg, abstol, reltol, maxiters):
+    """HCubatureJL for a FourierIntegrand: the tree on the host, H(k) at each box's Genz-Malik points in one device batch,
+    the integrand (a DeviceIntegrand's host form or the user's closure) per point.  ref: src/fourier.jl:120-122."""
+    from . import generic as G
+    if f.w.d != len(np.atleast_1d(cube.a)):
+        raise ValueError("variables in Fourier series don't match domain")
+    fi = f.f.f
+    nev = [0]
+    if isinstance(fi, DeviceIntegrand):
+        fixed, sw = fi.bind(pm)
+        hargs = tuple(fixed) + ((sw,) if fi.swept else ())
+
+    def batch(pts):
+        pts = np.asarray(pts, dtype=np.float64).reshape(len(pts), -1)
+        nev[0] += len(pts)
+        H = dev.eval_nodes(pts, L.WANT_H)  # [m, n, n], or [m] for a scalar series
+        out = []
+        for x, h in zip(pts, H):
+            v = FourierValue(x if f.w.d > 1 else float(x[0]), h)
+            out.append(fi.host(v, *hargs) if isinstance(fi, DeviceIntegrand) else _call_user(fi, v, pm))
+        return out
+    I, E, _ = G.hcubature(batch, cube.a, cube.b, 0.0 if abstol is None else abstol, 0.0 if reltol is None else reltol, maxiters, alg.initdiv)
+    return I, E, nev[0]
+
+
 def do_solve(f, dom, p, alg, cacheval=None, abstol=None, reltol=None, maxiters=2**62, _panels=False):
     """do_solve(f, dom, p, alg, cacheval; abstol, reltol, maxiters) -> IntegralSolution.
     ref: src/interfaces.jl:116-125 and the methods at src/fourier.jl:381-389,493-510,
@@ -798,6 +833,15 @@ def do_solve(f, dom, p, alg, cacheval=None, abstol=None, reltol=None, maxiters=2
             sol = IntegralSolution(j * symmetrize(fi, bz, u), j * ns * err, True, nev if counter else -1)
             sol.extra = extra
             return sol
+        if isinstance(alg, TAI):  # ref: src/brillouin.jl:458-462 + do_solve_autobz :337-355
+            bz_ = bz if isinstance(bz.lims, CubicLimits) else SymmetricBZ(bz.A, bz.B, CubicLimits(np.zeros(bz.ndim), np.ones(bz.ndim)), None)
+            ns_ = nsyms(bz_)
+            at = None if abstol is None else abstol / (j * ns_)
+            u, err, nev = _hcubature_fourier(f, dev, HyperCube(np.asarray(bz_.lims.a, dtype=np.float64), np.asarray(bz_.lims.b, dtype=np.float64)),
+                                             pm, HCubatureJL(alg.norm, alg.initdiv), at, reltol, maxiters)
+            if _needs_fbz(f, bz_, u):
+                return _redo_on_fbz(f, bz_, p, EvalCounter(alg) if counter else alg, kws)
+            return IntegralSolution(j * symmetrize(fi, bz_, u), j * ns_ * err, True, nev if counter else -1)
         raise ValueError(f"unsupported BZ algorithm {type(alg).__name__}")
 
     # ---- generic algorithms on unit domains (ref: test/fourier.jl:25-37)
@@ -816,6 +860,11 @@ def do_solve(f, dom, p, alg, cacheval=None, abstol=None, reltol=None, maxiters=2
         if not counter:
             s.numevals = -1
         return s
+    if isinstance(alg, HCubatureJL):
+        if not isinstance(dom, HyperCube):
+            raise ValueError("HCubatureJL needs a HyperCube domain")
+        u, err, nev = _hcubature_fourier(f, dev, dom, pm, alg, abstol, reltol, maxiters)
+        return IntegralSolution(u, err, True, nev if counter else -1)
     if isinstance(alg, NestedQuad):
         if not isinstance(dom, (CubicLimits, TetrahedralLimits, PolyhedralLimits, PolygonLimits)):
             raise ValueError("NestedQuad needs iterated limits")
@@ -843,6 +892,8 @@ def _do_solve_generic(f, dom, p, alg, counter, abstol, reltol, maxiters):
         if not isinstance(dom, Basis):
             raise ValueError("AutoSymPTRJL needs a Basis domain")
         u, err, nev = G.solve_autosymptr(f, dom.B, p, alg, abstol, reltol, maxiters)
+    elif isinstance(alg, HCubatureJL):
+        u, err, nev = G.solve_hcubature(f, dom, p, alg, abstol, reltol, maxiters)
     elif isinstance(alg, NestedQuad):
         if not (hasattr(dom, "segs") and hasattr(dom, "fix")):
             raise ValueError("NestedQuad needs iterated limits")

@@ -143,3 +143,34 @@ def test_evalcounter_pins_on_a_constant_and_other_kronrod_orders():
         for alg in (abz.QuadGKJL(order=9), abz.QuadGKJL(), abz.AuxQuadGKJL()):
             assert abs(abz.solve(abz.IntegralProblem(f, (a, b), p), alg, abstol=1e-5).u - ref) < 1e-5
     assert np.abs(np.sort(_gk_nodes(-1.0, 1.0)) - np.sort(G.gk_rule(7).nodes(-1.0, 1.0))).max() == 0.0
+
+
+def test_hcubature_known_answers_and_rule_exactness():
+    """ref: test/interface_tests.jl:45-59 (HCubatureJL, dims 1..3: p sum sin, p, prod 1/(p - cos)) and the degree of the
+    Genz-Malik rule (exact for every monomial of total degree <= 7, the embedded rule for degree <= 5)."""
+    from autobzcore.jl_amd import generic as G
+    a, b, p, abstol = 0.0, 2 * np.pi, 3.0, 1e-5
+    for dim in (1, 2, 3):
+        for f, ref in ((lambda x, p: p * np.sum(np.sin(x)), 0.0), (lambda x, p: p * 1.0, p * (b - a) ** dim),
+                       (lambda x, p: np.prod(1.0 / (p - np.cos(x))), ((b - a) / math.sqrt(p * p - 1)) ** dim)):
+            dom = abz.HyperCube(np.full(dim, a), np.full(dim, b)) if dim > 1 else (a, b)
+            sol = abz.solve(abz.IntegralProblem(f, dom, p), abz.EvalCounter(abz.HCubatureJL()), abstol=abstol)
+            assert abs(sol.u - ref) <= abstol and sol.resid <= abstol and sol.numevals > 0
+    for d in (2, 3, 4):
+        pts, w7, w5 = G._genz_malik(d)
+        assert len(pts) == 2 ** d + 2 * d * d + 2 * d + 1 and abs(w7.sum() - 1) < 1e-14 and abs(w5.sum() - 1) < 1e-14
+        import itertools
+        for deg in itertools.product(range(0, 8), repeat=d):
+            if sum(deg) > 7:
+                continue
+            exact = np.prod([0.0 if k % 2 else 1.0 / (k + 1) for k in deg])  # mean of x^k over [-1, 1]
+            mono = np.prod(pts ** np.array(deg), axis=1)
+            assert abs(np.dot(w7, mono) - exact) < 1e-14, (d, deg)
+            if sum(deg) <= 5:
+                assert abs(np.dot(w5, mono) - exact) < 1e-14, (d, deg)
+    # a constant costs exactly one rule (2^d + 2 d^2 + 2 d + 1 points; 15 in one dimension)
+    for dim, nev in ((1, 15), (2, 17), (3, 33)):
+        dom = abz.HyperCube(np.zeros(dim), np.ones(dim)) if dim > 1 else (0.0, 1.0)
+        assert abz.solve(abz.IntegralProblem(lambda x, p: 1.0, dom), abz.EvalCounter(abz.HCubatureJL())).numevals == nev
+    with pytest.raises(ValueError):
+        abz.solve(abz.IntegralProblem(abz.BatchIntegrand(lambda y, x, p: None, float), (0.0, 1.0)), abz.HCubatureJL())

@@ -286,6 +286,41 @@ def test_parameter_passing_equivalence(abz):
         assert np.abs(m - ref).max() < 1e-12
 
 
+def test_tai_and_hcubature_of_fourier_integrands(abz, svo):
+    """The rest of the reference's own hot-path tests: TAI beside IAI / PTR / AutoPTR (test/fourier.jl:40-56: f = 1.3 s + 1
+    integrates to (2 pi)^d on the FBZ and the inversion IBZ, with and without EvalCounter) and the three ways of passing
+    parameters under HCubatureJL (test/fourier.jl:9-22; the analytic value of a s x + b is b per component).  The tree is
+    on the host, every box's series values come from one abz_eval_nodes call (the fallback evaluator, src/fourier.jl:120-122);
+    a device integrand and the same Python closure give the same number, and TAI agrees with IAI on the SVO DOS."""
+    for d in (1, 2, 3):
+        so = orc.integer_lattice(d)
+        s = abz.FourierSeries(so.c[..., 0, 0], period=1.0, first=so.first, ndim=d)
+        vol = (2 * np.pi) ** d
+        for bzk in (abz.FBZ(), abz.InversionSymIBZ()):
+            bz = abz.load_bz(bzk, np.eye(d))
+            prob = abz.IntegralProblem(abz.FourierIntegrand(abz.LinearIntegrand(), s, 1.3, b=1.0), bz)
+            for counter in (False, True):
+                alg = abz.EvalCounter(abz.TAI()) if counter else abz.TAI()
+                sol = abz.solve(prob, alg, reltol=0, abstol=1e-6)
+                assert abs(sol.u - vol) < 1e-6 and sol.resid <= 1e-6
+                assert (sol.numevals > 0) if counter else (sol.numevals == -1)
+            closure = abz.IntegralProblem(abz.FourierIntegrand(lambda x, a, b: a * x.s + b, s, 1.3, b=1.0), bz)
+            assert abs(abz.solve(closure, abz.TAI(), reltol=0, abstol=1e-6).u - vol) < 1e-6
+        cube = abz.HyperCube(np.zeros(d), np.ones(d))
+        f = abz.LinearXIntegrand()
+        alg = abz.HCubatureJL()
+        u = abz.IntegralSolver(abz.IntegralProblem(abz.FourierIntegrand(f, s, 1.3, b=4.2), cube), alg)()
+        v = abz.IntegralSolver(abz.FourierIntegrand(f, s), cube, alg)(1.3, b=4.2)
+        w = abz.IntegralSolver(abz.FourierIntegrand(f, s, b=4.2), cube, alg)(1.3)
+        assert np.array_equal(u, v) and np.array_equal(v, w) and np.allclose(u, 4.2, atol=1e-7)
+    s3, _ = svo
+    bz = abz.load_bz(abz.InversionSymIBZ(), 3.85856 * np.eye(3))
+    prob = abz.IntegralProblem(abz.FourierIntegrand(abz.DOSIntegrand(), s3, 0.5), bz, abz.MixedParameters(12.5))
+    tai = abz.solve(prob, abz.EvalCounter(abz.TAI()), abstol=1e-3)
+    iai = abz.solve(prob, abz.IAI(), abstol=1e-4)
+    assert abs(tai.u - iai.u) < 2e-3 and tai.resid <= 1e-3 and tai.numevals % 33 == 0
+
+
 def test_user_closure_matches_device_integrand(abz):
     """A Python closure (host path, H(k) exported) and the fused device integrand agree."""
     rng = np.random.default_rng(3)
