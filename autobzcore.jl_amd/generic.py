@@ -328,8 +328,34 @@ def solve_autosymptr(f, B, p, alg, abstol, reltol, maxiters):
         I1 = I2
 
 
-def nested_quad(f, lims, p, abstol, reltol, maxiters):
-    """NestedQuad(AuxQuadGKJL()) over iterated limits (bz.CubicLimits / TetrahedralLimits / ...: `segs()`, `fix(x)`)
+def _fixed_rule(alg, g, segs):
+    """QuadratureFunction on the segments of a 1-D domain: sum_seg s sum_j w_j g(a + s (1 + x_j)).  -> (I, None, numevals)"""
+    x, w = alg.fun(alg.npt)
+    x, w = np.asarray(x, dtype=np.float64), np.asarray(w, dtype=np.float64)
+    pts = np.concatenate([segs[i] + 0.5 * (segs[i + 1] - segs[i]) * (1.0 + x) for i in range(len(segs) - 1)])
+    vals = g(pts)
+    I = None
+    for i in range(len(segs) - 1):
+        sc = 0.5 * (segs[i + 1] - segs[i])
+        for j in range(len(x)):
+            t = vals[i * len(x) + j] * (w[j] * sc)
+            I = t if I is None else I + t
+    return I, None, len(pts)
+
+
+def solve_quadrature_function(f, dom, p, alg):
+    """ref: src/algorithms.jl:167-191."""
+    from .solver import NestedBatchIntegrand
+    if isinstance(f, NestedBatchIntegrand):
+        raise ValueError("QuadratureFunction doesn't support nested batching")
+    ev = _Evaluator(f, p, point=float)
+    I, E, _ = _fixed_rule(alg, ev, _segments(dom))
+    return I, E, ev.numevals
+
+
+def nested_quad(f, lims, p, abstol, reltol, maxiters, algs=None):
+    """NestedQuad(algs...) -- AuxQuadGKJL / QuadGKJL (adaptive) or QuadratureFunction (fixed rule) per level, the last
+    one repeated inwards like the reference's single-algorithm form -- over iterated limits (bz.CubicLimits / TetrahedralLimits / ...: `segs()`, `fix(x)`)
     for a plain callable (depth-first, scalar refinement), a BatchIntegrand (the innermost integral only is batched)
     or a NestedBatchIntegrand (every level batched).  The integrand sees full points x = (x_1 .. x_d)."""
     from .solver import BatchIntegrand, NestedBatchIntegrand
@@ -340,12 +366,27 @@ def nested_quad(f, lims, p, abstol, reltol, maxiters):
     inner_batch = nest or isinstance(f, BatchIntegrand)
     mb = f.max_batch if (nest or isinstance(f, BatchIntegrand)) else 2**62
     count = [0]
+    from .solver import QuadratureFunction
+    algs = tuple(algs) if algs else ()
+    ntot = lims.ndim
+
+    def alg_of(d):  # level d = number of variables still free; algs[0] is the OUTERMOST level's algorithm
+        if not algs:
+            return None
+        return algs[min(ntot - d, len(algs) - 1)]
+
+    def integrate(alg, g, segs, atol, batch):
+        if isinstance(alg, QuadratureFunction):
+            I, E, _ = _fixed_rule(alg, g, segs)
+            return I, (0.0 if E is None else E)
+        I, E, _ = auxquadgk(g, segs, atol, reltol, maxiters, batch=batch, max_batch=mb, order=getattr(alg, "order", 7))
+        return I, E
 
     def level(lim, tail, atol):
         d = lim.ndim
         if d == 1:
             ev = _Evaluator(worker if nest else f, p, point=lambda x: np.array((float(x),) + tail))
-            I, E, _ = auxquadgk(ev, tuple(lim.segs()), atol, reltol, maxiters, batch=inner_batch, max_batch=mb)
+            I, E = integrate(alg_of(1), ev, tuple(lim.segs()), atol, inner_batch)
             count[0] += ev.numevals
             return I, E
 
@@ -357,8 +398,7 @@ def nested_quad(f, lims, p, abstol, reltol, maxiters):
                 at = None if atol is None else atol / (sg[-1] - sg[0])  # ref: src/algorithms.jl:532-533,556-557
                 out.append(level(inner, (float(x),) + tail, at)[0])
             return out
-        I, E, _ = auxquadgk(g, tuple(lim.segs()), atol, reltol, maxiters, batch=nest, max_batch=mb)
-        return I, E
+        return integrate(alg_of(d), g, tuple(lim.segs()), atol, nest)
 
     I, E = level(lims, (), abstol)
     return I, E, count[0]

@@ -156,6 +156,20 @@ class BatchIntegrand:
         self.max_batch = int(max_batch)
 
 
+class InplaceIntegrand:
+    """InplaceIntegrand(f!, result): f!(y, x, p) writes the (array) value at one point into y; `result` gives the shape and
+    type.  ref: src/inplace.jl:1-15.  Host-side: every evaluation gets a fresh y, the solution is an array like `result`."""
+
+    def __init__(self, f, I):
+        self.f = f
+        self.I = np.asarray(I)
+
+    def __call__(self, x, p):
+        y = np.zeros_like(self.I)
+        self.f(y, x, p)
+        return y
+
+
 class NestedBatchIntegrand:
     """Tuple of worker integrands + resizable buffers for (thread-)parallel nested quadrature.
     ref: src/batch.jl:41-77.  On the GPU path the workers are not needed (every batch is one kernel
@@ -328,6 +342,25 @@ class AuxQuadGKJL(IntegralAlgorithm):
             raise ValueError("AuxQuadGKJL: only order = 7 is supported")
         self.order = order
         self.norm = norm
+
+
+def trapz(n):
+    """Nodes and weights of the trapezoidal rule on [-1, 1].  ref: src/algorithms.jl:132-140."""
+    if n <= 1:
+        raise ValueError("trapz needs at least two points")
+    x = np.linspace(-1.0, 1.0, n)
+    h = x[1] - x[0]
+    w = np.full(n, h)
+    w[0] = w[-1] = h / 2
+    return x, w
+
+
+class QuadratureFunction(IntegralAlgorithm):
+    """A fixed rule `x, w = fun(npt)` for [-1, 1] applied to every segment of the domain (default: trapz, 50 points); no
+    error estimate.  ref: src/algorithms.jl:142-191."""
+
+    def __init__(self, fun=trapz, npt=50, nthreads=1):
+        self.fun, self.npt, self.nthreads = fun, int(npt), nthreads
 
 
 class QuadGKJL(AuxQuadGKJL):
@@ -884,6 +917,8 @@ def _do_solve_generic(f, dom, p, alg, counter, abstol, reltol, maxiters):
         raise ValueError(f"unsupported integrand {type(f).__name__}")
     if isinstance(alg, AuxQuadGKJL):
         u, err, nev = G.solve_auxquadgk(f, dom, p, abstol, reltol, maxiters, order=alg.order)
+    elif isinstance(alg, QuadratureFunction):
+        u, err, nev = G.solve_quadrature_function(f, dom, p, alg)
     elif isinstance(alg, MonkhorstPack):
         if not isinstance(dom, Basis):
             raise ValueError("MonkhorstPack needs a Basis domain")
@@ -898,9 +933,9 @@ def _do_solve_generic(f, dom, p, alg, counter, abstol, reltol, maxiters):
         if not (hasattr(dom, "segs") and hasattr(dom, "fix")):
             raise ValueError("NestedQuad needs iterated limits")
         for a_ in alg.algs:
-            if not isinstance(a_, AuxQuadGKJL):
-                raise ValueError("NestedQuad: only AuxQuadGKJL() levels are supported")
-        u, err, nev = G.nested_quad(f, dom, p, abstol, reltol, maxiters)
+            if not isinstance(a_, (AuxQuadGKJL, QuadratureFunction)):
+                raise ValueError("NestedQuad: AuxQuadGKJL / QuadGKJL / QuadratureFunction levels are supported")
+        u, err, nev = G.nested_quad(f, dom, p, abstol, reltol, maxiters, algs=alg.algs)
     else:
         raise ValueError(f"{type(alg).__name__} needs a FourierIntegrand on a SymmetricBZ (generic integrands: "
                          "AuxQuadGKJL, MonkhorstPack, AutoSymPTRJL, NestedQuad)")

@@ -174,3 +174,42 @@ def test_hcubature_known_answers_and_rule_exactness():
         assert abz.solve(abz.IntegralProblem(lambda x, p: 1.0, dom), abz.EvalCounter(abz.HCubatureJL())).numevals == nev
     with pytest.raises(ValueError):
         abz.solve(abz.IntegralProblem(abz.BatchIntegrand(lambda y, x, p: None, float), (0.0, 1.0)), abz.HCubatureJL())
+
+
+def test_inplace_integrands_quadrature_function_and_nested_fixed_rules():
+    """ref: test/interface_tests.jl:27-43 (QuadratureFunction beside the adaptive rules), :67-88 (InplaceIntegrand under
+    QuadratureFunction / QuadGKJL / AuxQuadGKJL / HCubatureJL / MonkhorstPack / AutoSymPTRJL), :113-130 (NestedQuad of a
+    fixed rule, plain and in-place), :143-158 (a constant costs exactly npt = 10 evaluations of trapz(10))."""
+    a, b, p, abstol = 0.0, 2 * np.pi, 3.0, 1e-5
+    cases = ((lambda x: p * np.sin(x), 0.0), (lambda x: p * 1.0, p * (b - a)), (lambda x: 1.0 / (p - np.cos(x)), (b - a) / math.sqrt(p * p - 1)))
+    for g, ref in cases:
+        plain = abz.IntegralProblem(lambda x, q, g=g: g(x), (a, b), p)
+        assert abs(abz.solve(plain, abz.QuadratureFunction(), abstol=abstol).u - ref) < abstol
+
+        def body(y, x, q, g=g):
+            y[...] = g(np.ravel(x)[0])
+        integrand = abz.InplaceIntegrand(body, np.array([0.0]))
+        for alg in (abz.QuadratureFunction(), abz.QuadGKJL(), abz.AuxQuadGKJL(), abz.HCubatureJL()):
+            u = abz.solve(abz.IntegralProblem(integrand, (a, b), p), alg, abstol=abstol).u
+            assert np.shape(u) == (1,) and abs(u[0] - ref) < abstol, type(alg).__name__
+        for alg in (abz.MonkhorstPack(), abz.AutoSymPTRJL()):
+            u = abz.solve(abz.IntegralProblem(integrand, abz.Basis(np.array([[b]])), p), alg, abstol=abstol).u
+            assert np.shape(u) == (1,) and abs(u[0] - ref) < abstol, type(alg).__name__
+    x, w = abz.trapz(5)
+    assert np.allclose(x, [-1, -0.5, 0, 0.5, 1]) and np.allclose(w, [0.25, 0.5, 0.5, 0.5, 0.25])
+    f = lambda x, q: 1.0 + q * np.sum(np.cos(x))
+    for dim in (1, 2, 3):
+        dom = abz.CubicLimits(np.zeros(dim), 2 * np.pi * np.ones(dim))
+        ref = (2 * np.pi) ** dim
+        nd = abz.NestedQuad(abz.QuadratureFunction())
+        assert abs(abz.solve(abz.IntegralProblem(f, dom, 7.0), nd, abstol=1e-3).u - ref) < 1e-3
+        inpl = abz.InplaceIntegrand(lambda y, x, q: y.__setitem__(Ellipsis, f(x, q)), np.array([0.0]))
+        assert abs(abz.solve(abz.IntegralProblem(inpl, dom, 7.0), nd, abstol=1e-3).u[0] - ref) < 1e-3
+        sol = abz.solve(abz.IntegralProblem(f, dom, 7.0), abz.EvalCounter(nd))
+        assert sol.numevals == 50 ** dim
+        mixed = abz.NestedQuad(abz.AuxQuadGKJL(), abz.QuadratureFunction(npt=40))  # adaptive outside, fixed rule inside
+        assert abs(abz.solve(abz.IntegralProblem(f, dom, 7.0), mixed, abstol=1e-3).u - ref) < 1e-3
+    for prob in (abz.IntegralProblem(lambda x, q: 1.0, (0.0, 1.0)),
+                 abz.IntegralProblem(abz.InplaceIntegrand(lambda y, x, q: y.__setitem__(Ellipsis, 1.0), np.zeros(())), (0.0, 1.0)),
+                 abz.IntegralProblem(abz.BatchIntegrand(lambda y, x, q: y.__setitem__(slice(None), [1.0] * len(x)), float), (0.0, 1.0))):
+        assert abz.solve(prob, abz.EvalCounter(abz.QuadratureFunction(npt=10))).numevals == 10
