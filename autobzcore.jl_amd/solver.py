@@ -458,6 +458,16 @@ class AbsoluteEstimate(IntegralAlgorithm):
         self.est_alg, self.abs_alg, self.norm, self.kws = est_alg, abs_alg, norm, kws
 
 
+def PTR_IAI(ptr=None, iai=None, **kws):
+    """IAI with abstol = reltol * |PTR estimate|.  ref: src/brillouin.jl:464-474."""
+    return AbsoluteEstimate(ptr or PTR(), iai or IAI(), **kws)
+
+
+def AutoPTR_IAI(reltol=1.0, ptr=None, iai=None, **kws):
+    """IAI with abstol = rtol * |AutoPTR estimate computed to `reltol`|.  ref: src/brillouin.jl:477-488."""
+    return AbsoluteEstimate(ptr or AutoPTR(), iai or IAI(), reltol=reltol, **kws)
+
+
 class EvalCounter(IntegralAlgorithm):
     """Counts integrand evaluations into sol.numevals.  ref: src/algorithms.jl:656-691, src/fourier.jl:512-530."""
 

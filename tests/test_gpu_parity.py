@@ -592,6 +592,11 @@ def test_absolute_estimate_ptr_then_iai_on_the_device(abz, svo):
     direct = abz.solve(prob, abz.EvalCounter(abz.IAI()), abstol=1e-3 * abs(est.u), reltol=0.0)
     assert sol.u == direct.u and sol.resid == direct.resid and sol.numevals == est.numevals + direct.numevals
     assert sol.resid <= 1e-3 * abs(est.u) and abs(sol.u - est.u) < 0.05 * abs(est.u)
+    # the reference's named combinations (src/brillouin.jl:464-488)
+    both_ = abz.solve(prob, abz.EvalCounter(abz.PTR_IAI(ptr=abz.PTR(npt=16))), reltol=1e-3)
+    assert both_.u == sol.u and both_.numevals == sol.numevals
+    auto = abz.solve(prob, abz.AutoPTR_IAI(reltol=1.0), reltol=1e-3)
+    assert abs(auto.u - sol.u) <= 2e-3 * abs(sol.u)
 
 
 def test_symrep_extension_point_matrix_valued_on_the_ibz(abz):
