@@ -20,7 +20,7 @@ from .h5lite import read_h5_to_nt, write_nt_to_h5
 from .generic import fourier_batch
 from .synthetic import synthetic_wannier, tb_integer, splitmix64_uniform
 from .series import DeviceRule, DeviceSeries, FourierSeries, symptr_rule
-from .solver import (IAI, PTR, TAI, PTR_IAI, AutoPTR_IAI, HCubatureJL, InplaceIntegrand, QuadratureFunction, trapz, AbsoluteEstimate, AutoPTR, AutoSymPTRJL, AuxQuadGKJL, AuxValue, QuadGKJL, BatchIntegrand, DOSIntegrand, DeviceIntegrand,
+from .solver import (IAI, PTR, TAI, PTR_IAI, AutoPTR_IAI, HCubatureJL, ContQuadGKJL, MeroQuadGKJL, InplaceIntegrand, QuadratureFunction, trapz, AbsoluteEstimate, AutoPTR, AutoSymPTRJL, AuxQuadGKJL, AuxValue, QuadGKJL, BatchIntegrand, DOSIntegrand, DeviceIntegrand,
                      EvalCounter, FourierIntegrand, FourierValue, GlocIntegrand, IntegralProblem, IntegralSolution,
                      IntegralSolver, LinearIntegrand, LinearXIntegrand, MixedParameters, MonkhorstPack, NestedBatchIntegrand, NestedQuad,
                      NullParameters, ParameterIntegrand, TrGlocIntegrand, UnitIntegrand, batchparam, batchsolve,

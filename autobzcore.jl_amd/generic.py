@@ -551,3 +551,139 @@ def solve_hcubature(f, dom, p, alg, abstol, reltol, maxiters):
     ev = _Evaluator(f, p, point=(lambda x: float(x[0])) if scalar else (lambda x: np.asarray(x, dtype=np.float64)))
     I, E, _ = hcubature(ev, a, b, 0.0 if abstol is None else abstol, 0.0 if reltol is None else reltol, maxiters, alg.initdiv)
     return I, E, ev.numevals
+
+
+# ---------------------------------------------------------------------------- ContQuadGKJL / MeroQuadGKJL
+def _near_poles(ts, fvals, rho):
+    """Zeros of the degree-14 interpolant of 1/f through the 15 Kronrod points (standard coordinate t in [-1, 1]) that lie
+    inside the Bernstein ellipse with semi-axes cosh(rho), sinh(rho): [(t0, d(1/f)/dt at t0)].  The reference finds them by
+    Newton deflation on the same kind of interpolant (IteratedIntegration.ContQuadGK / MeroQuadGK, `rootmeth`); here the
+    companion matrix of the Chebyshev series gives all of them at once."""
+    from numpy.polynomial import chebyshev as Ch
+    f = np.asarray(fvals, dtype=np.complex128)
+    if not np.all(np.isfinite(f)) or np.any(f == 0):
+        return []
+    g = 1.0 / f
+    scale = np.abs(g).max()
+    if not scale > 0:
+        return []
+    V = Ch.chebvander(np.asarray(ts, dtype=np.float64), len(ts) - 1)
+    try:
+        c = np.linalg.solve(V.astype(np.complex128), g / scale)
+    except np.linalg.LinAlgError:
+        return []
+    while len(c) > 1 and abs(c[-1]) < 1e-14 * np.abs(c).max():
+        c = c[:-1]
+    if len(c) < 2:
+        return []
+    roots = Ch.chebroots(c)
+    dc = Ch.chebder(c)
+    out = []
+    for z in roots:
+        w = z + np.sqrt(z * z - 1 + 0j)
+        if abs(w) < 1:
+            w = 1 / w
+        if abs(w) < math.exp(rho):
+            out.append((complex(z), complex(Ch.chebval(z, dc)) * scale))
+    return out
+
+
+def _cquad(f, p, dom, alg, abstol, reltol, maxiters, mode):
+    """The shared adaptive loop of ContQuadGKJL (mode "cont") and MeroQuadGKJL (mode "mero"): globally adaptive GK(7,15)
+    over segments with real or complex end points; a REAL segment whose integrand has poles within the Bernstein ellipse of
+    parameter rho is treated specially.  ref: src/algorithms.jl:242-328 (behaviour as documented there: plain quadgk unless a
+    root of 1/f is found nearby)."""
+    from .solver import BatchIntegrand, InplaceIntegrand, NestedBatchIntegrand
+    name = "ContQuadGK" if mode == "cont" else "MeroQuadGK"
+    if isinstance(f, NestedBatchIntegrand):
+        raise ValueError(f"{name} doesn't support nested batching")
+    if isinstance(f, BatchIntegrand):
+        raise ValueError(f"{name} doesn't support batching")
+    if isinstance(f, InplaceIntegrand):
+        raise ValueError(f"{name} doesn't support inplace integrands")
+    rule = gk_rule(alg.order)
+    tk = np.asarray(rule.nodes(-1.0, 1.0), dtype=np.float64)
+    atol = 0.0 if abstol is None else abstol
+    rtol = (0.0 if atol > 0 else math.sqrt(np.finfo(float).eps)) if reltol is None else reltol
+    nev = [0]
+
+    def call(x):
+        nev[0] += 1
+        return complex(f(x, p))
+
+    def plain(a, b):
+        """GK on the straight segment a -> b (complex end points allowed): (I, E)."""
+        c, h = 0.5 * (a + b), 0.5 * (b - a)
+        xs = [c + h * t for t in tk]
+        if isinstance(a, float) and isinstance(b, float):
+            vals = [call(float(x)) for x in xs]
+        else:
+            vals = [call(complex(x)) for x in xs]
+        Ik, Ek = rule.eval(vals, -1.0, 1.0)  # on the standard interval; the (complex) half length h scales it
+        return Ik * h, Ek * abs(h), vals
+
+    def segment(a, b):
+        """-> list of heap entries (a, b, I, E) for the piece a -> b of the path"""
+        I, E, vals = plain(a, b)
+        if not (isinstance(a, float) and isinstance(b, float)):
+            return [(a, b, I, E)]
+        poles = _near_poles(tk, vals, alg.rho)
+        poles = [(t0, dg) for t0, dg in poles if abs(t0.imag) > 1e-14 and dg != 0]
+        if not poles:
+            return [(a, b, I, E)]
+        c, h = 0.5 * (a + b), 0.5 * (b - a)
+        if mode == "mero":
+            # subtract r / (x - x0) for every nearby simple pole, add r log((b - x0) / (a - x0)) back
+            xs = [c + h * t for t in tk]
+            sub = np.array(vals, dtype=np.complex128)
+            extra = 0.0j
+            for t0, dg in poles:
+                x0 = c + h * t0
+                r = h / dg  # residue of f = 1 / (d(1/f)/dx) = h / (d(1/f)/dt)
+                sub = sub - r / (np.array(xs) - x0)
+                extra += r * (np.log(b - x0) - np.log(a - x0))
+            Ik, Ek = rule.eval(list(sub), -1.0, 1.0)
+            if Ek * abs(h) < E:  # keep the subtraction only where it helps
+                return [(a, b, Ik * h + extra, Ek * abs(h))]
+            return [(a, b, I, E)]
+        ups = [t0 for t0, _ in poles if t0.imag > 0]
+        downs = [t0 for t0, _ in poles if t0.imag < 0]
+        if ups and downs:
+            return [(a, b, I, E)]  # poles on both sides: no dent helps, refine on the real axis
+        side = -1.0 if ups else 1.0  # go away from the poles
+        m = complex(c, side * abs(h) * math.sinh(alg.rho))
+        out = []
+        for (u, v) in ((a, m), (m, b)):
+            I2, E2, _ = plain(u, v)
+            out.append((u, v, I2, E2))
+        return out
+
+    segs = _segments(dom)
+    heap = _KeyHeap(0)
+    heap.lt = lambda x, y: y[3] < x[3]
+    for i in range(len(segs) - 1):
+        heap.xs.extend(segment(float(segs[i]), float(segs[i + 1])))
+    heap.heapify()
+    I = sum(sg[2] for sg in heap.xs)
+    E = sum(sg[3] for sg in heap.xs)
+    while E > max(atol, rtol * abs(I)) and nev[0] < maxiters:
+        a, b, sI, sE = heap.pop()
+        mid = 0.5 * (a + b)
+        if isinstance(a, float) and isinstance(b, float):
+            mid = float(mid)
+        new = segment(a, mid) + segment(mid, b)
+        I = I - sI + sum(sg[2] for sg in new)
+        E = E - sE + sum(sg[3] for sg in new)
+        for sg in new:
+            heap.push(sg)
+    I = sum(sg[2] for sg in heap.xs)
+    E = sum(sg[3] for sg in heap.xs)
+    return I, E, nev[0]
+
+
+def solve_contquadgk(f, dom, p, alg, abstol, reltol, maxiters):
+    return _cquad(f, p, dom, alg, abstol, reltol, maxiters, "cont")
+
+
+def solve_meroquadgk(f, dom, p, alg, abstol, reltol, maxiters):
+    return _cquad(f, p, dom, alg, abstol, reltol, maxiters, "mero")

@@ -344,6 +344,23 @@ class AuxQuadGKJL(IntegralAlgorithm):
         self.norm = norm
 
 
+class ContQuadGKJL(IntegralAlgorithm):
+    """1-D contour deformation for scalar complex integrands: quadgk on the real axis unless 1/f has a root within the
+    Bernstein ellipse (semi-axes cosh rho, sinh rho) of a segment on one side of the axis -- the segment is then dented
+    away from it (the integrand must accept complex arguments).  ref: src/algorithms.jl:242-290; host-side, generic.py."""
+
+    def __init__(self, order=7, norm=None, rho=1.0, rootmeth=None):
+        self.order, self.norm, self.rho, self.rootmeth = int(order), norm, float(rho), rootmeth
+
+
+class MeroQuadGKJL(IntegralAlgorithm):
+    """1-D pole subtraction for meromorphic scalar integrands: quadgk on the real axis, with the simple poles found
+    within the Bernstein ellipse of a segment subtracted and integrated analytically.  ref: src/algorithms.jl:292-328."""
+
+    def __init__(self, order=7, norm=None, rho=1.0, rootmeth=None):
+        self.order, self.norm, self.rho, self.rootmeth = int(order), norm, float(rho), rootmeth
+
+
 def trapz(n):
     """Nodes and weights of the trapezoidal rule on [-1, 1].  ref: src/algorithms.jl:132-140."""
     if n <= 1:
@@ -929,6 +946,10 @@ def _do_solve_generic(f, dom, p, alg, counter, abstol, reltol, maxiters):
         u, err, nev = G.solve_auxquadgk(f, dom, p, abstol, reltol, maxiters, order=alg.order)
     elif isinstance(alg, QuadratureFunction):
         u, err, nev = G.solve_quadrature_function(f, dom, p, alg)
+    elif isinstance(alg, ContQuadGKJL):
+        u, err, nev = G.solve_contquadgk(f, dom, p, alg, abstol, reltol, maxiters)
+    elif isinstance(alg, MeroQuadGKJL):
+        u, err, nev = G.solve_meroquadgk(f, dom, p, alg, abstol, reltol, maxiters)
     elif isinstance(alg, MonkhorstPack):
         if not isinstance(dom, Basis):
             raise ValueError("MonkhorstPack needs a Basis domain")

@@ -213,3 +213,36 @@ def test_inplace_integrands_quadrature_function_and_nested_fixed_rules():
                  abz.IntegralProblem(abz.InplaceIntegrand(lambda y, x, q: y.__setitem__(Ellipsis, 1.0), np.zeros(())), (0.0, 1.0)),
                  abz.IntegralProblem(abz.BatchIntegrand(lambda y, x, q: y.__setitem__(slice(None), [1.0] * len(x)), float), (0.0, 1.0))):
         assert abz.solve(prob, abz.EvalCounter(abz.QuadratureFunction(npt=10))).numevals == 10
+
+
+def test_contour_deformation_and_pole_subtraction_quadratures():
+    """ref: test/interface_tests.jl:27-43 (ContQuadGKJL and MeroQuadGKJL integrate the three known-answer integrands like the
+    other 1-D rules) and :132-140 (f = 1 / (z - cos x), z = 0.5 + 1e-3 i, with MeroQuadGKJL as the reference there).  Near
+    a pole both need far fewer evaluations than plain quadgk and still give the closed forms."""
+    import cmath
+    a, b, p, abstol = 0.0, 2 * np.pi, 3.0, 1e-5
+    for f, ref in ((lambda x, q: q * np.sin(x), 0.0), (lambda x, q: q * (1.0 + 0 * x), p * (b - a)),
+                   (lambda x, q: 1.0 / (q - np.cos(x)), (b - a) / math.sqrt(p * p - 1))):
+        for alg in (abz.ContQuadGKJL(), abz.MeroQuadGKJL()):
+            assert abs(abz.solve(abz.IntegralProblem(f, (a, b), p), alg, abstol=abstol).u - ref) < abstol, type(alg).__name__
+    z = complex(0.5, 1e-3)
+    prob = abz.IntegralProblem(lambda x, q: 1.0 / (complex(*q) - np.cos(x)), (0.0, 2 * np.pi), (0.5, 1e-3))
+    exact = 2 * np.pi / (cmath.sqrt(z - 1) * cmath.sqrt(z + 1))
+    plain = abz.solve(prob, abz.EvalCounter(abz.QuadGKJL()), abstol=1e-8)
+    for alg in (abz.MeroQuadGKJL(), abz.ContQuadGKJL()):
+        sol = abz.solve(prob, abz.EvalCounter(alg), abstol=1e-8)
+        assert abs(sol.u - exact) < 1e-7 and sol.resid <= 1e-8, type(alg).__name__
+        assert sol.numevals < plain.numevals, (type(alg).__name__, sol.numevals, plain.numevals)
+    # a single simple pole 1e-4 above the axis: the exact answer is a logarithm
+    z0 = complex(0.3, 1e-4)
+    pole = abz.IntegralProblem(lambda x, q: 1.0 / (x - z0), (-1.0, 1.0))
+    exact = cmath.log(1 - z0) - cmath.log(-1 - z0)
+    ref = abz.solve(pole, abz.EvalCounter(abz.QuadGKJL()), abstol=1e-9)
+    for alg in (abz.MeroQuadGKJL(), abz.ContQuadGKJL()):
+        sol = abz.solve(pole, abz.EvalCounter(alg), abstol=1e-9)
+        assert abs(sol.u - exact) < 1e-8 and sol.numevals <= ref.numevals // 4, (type(alg).__name__, sol.numevals, ref.numevals)
+    for alg in (abz.ContQuadGKJL(), abz.MeroQuadGKJL()):
+        with pytest.raises(ValueError):
+            abz.solve(abz.IntegralProblem(abz.BatchIntegrand(lambda y, x, q: None, float), (0.0, 1.0)), alg)
+        with pytest.raises(ValueError):
+            abz.solve(abz.IntegralProblem(abz.InplaceIntegrand(lambda y, x, q: None, np.zeros(1)), (0.0, 1.0)), alg)
