@@ -62,7 +62,7 @@ PROTOTYPES = {
 WANT_H, WANT_EIG, WANT_VEL = 1, 2, 4
 F_ONE, F_LINEAR, F_LINEAR_X, F_DOS, F_TRGLOC, F_GLOC, F_DOS_EIG = range(7)
 LIMS_CUBIC, LIMS_TETRAHEDRAL, LIMS_POLYHEDRAL, LIMS_POLYGON = 0, 1, 2, 3
-K_CONTRACT, K_EVAL, K_REDUCE, K_GGR, K_EIG = range(5)
+K_CONTRACT, K_EVAL, K_REDUCE, K_GGR, K_EIG, K_GGRBUILD = range(6)
 ERR_ARG, ERR_HIP, ERR_NOGPU, ERR_UNSUPPORTED, ERR_NOMEM = -1, -2, -3, -4, -5
 
 

@@ -239,6 +239,30 @@ int integrand_ncomp(int integrand, int n, int d);
 int launch_reduce(abz_ctx* ctx, const ReduceSpec& rs, double* out_reim);
 
 int launch_gen_velocity(abz_ctx* ctx, int n, PlaneView U, PlaneView dH, PlaneView Vj, int64_t nk);
+
+// Fused GGR build (kernels_ggr.hip): eigenvalues + band velocities of every node in one kernel, Hermitian series,
+// n <= 4.  ref: src/dos_ggr.jl:14-44.
+struct GgrBuildSpec {
+    int n, d;
+    int M, first;   // variable 1
+    int npt;
+    const double2* tab;
+    PlaneView E, V;  // V: d*n planes, plane j*n + b = velocity of band b along variable j+1
+    // grid mode
+    bool grid = true;
+    int64_t nlines = 0;
+    bool fuse = false;  // the wave contracts variable 2 itself from the level-2 sets src2 (ggr_build_can_fuse)
+    const double2* src[3] = {nullptr, nullptr, nullptr};  // !fuse / node lists: level-1 families: plain, derivative on variable 2, on variable 3
+    const double2* src2[2] = {nullptr, nullptr};          // fuse: level-2 sets: plain, derivative on variable 3
+    int M2 = 0, first2 = 0, gbeg = 0, gcnt = 0;
+    // node lists (symmetric rules)
+    int64_t nk = 0;
+    const int64_t* parents = nullptr;
+    const int32_t* gi = nullptr;
+};
+bool ggr_build_supported(int n, int d, int M, int npt, bool herm);
+bool ggr_build_can_fuse(int n, int d, int M, int M2, int npt);
+int launch_ggr_build(abz_ctx* ctx, const GgrBuildSpec& gs);
 int launch_ggr(abz_ctx* ctx, int n, int d, int npt, PlaneView E, PlaneView V, const double* w, int64_t nk,
                const double* Es_host, int nE, double* out_host);
 

@@ -358,7 +358,7 @@ static int plan_upload(abz_ctx* ctx, const Plan& p, PlanDev& pd) {
 // Build the level-1 coefficient sets for a plan.  deriv_dim (1-based, 0 = none) applies the
 // derivative factor to that variable's phases.  Returns pointer to level-1 sets (or coef if d == 1).
 static int build_chain(abz_series* s, const Plan& p, const PlanDev& pd, const double2* tab, int deriv_dim,
-                       const double2** level1, int last_level = 1) {
+                       const double2** level1, int last_level = 1, DevBuf* last_out = nullptr) {
     abz_ctx* ctx = s->ctx;
     const int d = s->d;
     const double2* src = s->coef;
@@ -368,9 +368,11 @@ static int build_chain(abz_series* s, const Plan& p, const PlanDev& pd, const do
         const int64_t B = p.nitems[L];
         const int M = s->dims[L];
         const int64_t Lrow = s->elems(L);
-        int rc = s->pool[L].reserve(sizeof(double2) * (size_t)std::max<int64_t>(B * Lrow, 1));
+        // the sets of the last level go to `last_out` when given (several families alive at once: fused GGR build)
+        DevBuf& ob = (L == last_level && last_out) ? *last_out : s->pool[L];
+        int rc = ob.reserve(sizeof(double2) * (size_t)std::max<int64_t>(B * Lrow, 1));
         if (rc) return rc;
-        double2* out = s->pool[L].as<double2>();
+        double2* out = ob.as<double2>();
         // full grids: items of level L are (gi, parent) with gi fastest; gi runs over the slab for the
         // outermost variable and over the whole grid below it
         const int gbeg = (p.full && L == d - 1) ? p.outer0 : 0;
@@ -659,7 +661,8 @@ struct RulePlan {
     Plan plan;
     PlanDev pd;
     DevBuf tab;
-    DevBuf tmpU, tmpD;  // eigenvector / derivative planes while velocities are built
+    DevBuf tmpU, tmpD;  // eigenvector / derivative planes while velocities are built (unfused build)
+    DevBuf fam[2];      // fused GGR build: coefficient sets with the derivative factor on variable 2 / 3
 };
 }  // namespace abz
 
@@ -674,6 +677,8 @@ static void rule_free(abz_rule* r) {
         rp->tab.release();
         rp->tmpU.release();
         rp->tmpD.release();
+        rp->fam[0].release();
+        rp->fam[1].release();
         delete rp;
     }
     delete r;
@@ -689,6 +694,14 @@ int abz_rule_destroy(abz_rule* r) {
     return ABZ_OK;
 }
 
+// eigenvalues + velocities only, Hermitian series, n <= 4: the fused GGR build applies
+static bool rule_ggr_fused(const abz_rule* r) {
+    const abz_series* s = r->s;
+    static const bool planar_on = [] { const char* e = getenv("ABZ_RULE_PLANAR"); return e && e[0] == '1'; }();
+    return (r->want & ABZ_WANT_VEL) && !(r->want & ABZ_WANT_H) && !planar_on &&
+           ggr_build_supported(s->n, s->d, s->dims[0], r->npt, s->hermitian);
+}
+
 // launches only: contraction chain(s) + innermost evaluation (+ velocities)
 static int rule_fill(abz_rule* r) {
     abz_series* s = r->s;
@@ -698,6 +711,45 @@ static int rule_fill(abz_rule* r) {
     const int d = s->d, n = s->n;
     const double2* tab = rp->tab.as<double2>();
     r->herm = s->hermitian;
+    if (rule_ggr_fused(r)) {
+        // Fused GGR build (kernels_ggr.hip): H, every dH/dk_j, the eigensolve and the velocities in one kernel; only
+        // (e, v) reach HBM.  ref: src/dos_ggr.jl:14-44
+        GgrBuildSpec gs;
+        gs.n = n;
+        gs.d = d;
+        gs.M = s->dims[0];
+        gs.first = s->first[0];
+        gs.npt = r->npt;
+        gs.tab = tab;
+        gs.E = r->E;
+        gs.V = r->V;
+        gs.grid = r->full;
+        int rc;
+        if (r->full) {
+            gs.nlines = d == 1 ? 1 : plan.nitems[1];
+            gs.fuse = d >= 2 && ggr_build_can_fuse(n, d, s->dims[0], s->dims[1], r->npt);
+            if (gs.fuse) {
+                gs.M2 = s->dims[1];
+                gs.first2 = s->first[1];
+                gs.gbeg = (d == 2) ? plan.outer0 : 0;
+                gs.gcnt = (d == 2) ? plan.outer_n : r->npt;
+                if ((rc = build_chain(s, plan, rp->pd, tab, 0, &gs.src2[0], 2))) return rc;
+                if (d == 3 && (rc = build_chain(s, plan, rp->pd, tab, 3, &gs.src2[1], 2, &rp->fam[1]))) return rc;
+            } else {
+                if ((rc = build_chain(s, plan, rp->pd, tab, 0, &gs.src[0]))) return rc;
+                for (int j = 2; j <= d; ++j)
+                    if ((rc = build_chain(s, plan, rp->pd, tab, j, &gs.src[j - 1], 1, &rp->fam[j - 2]))) return rc;
+            }
+        } else {
+            gs.nk = r->nk;
+            gs.parents = d == 1 ? nullptr : rp->pd.parent[0].as<int64_t>();
+            gs.gi = rp->pd.gi[0].as<int32_t>();
+            if ((rc = build_chain(s, plan, rp->pd, tab, 0, &gs.src[0]))) return rc;
+            for (int j = 2; j <= d; ++j)
+                if ((rc = build_chain(s, plan, rp->pd, tab, j, &gs.src[j - 1], 1, &rp->fam[j - 2]))) return rc;
+        }
+        return launch_ggr_build(ctx, gs);
+    }
     // temporaries of a velocity build: eigenvectors and one derivative matrix, tiled like H alone
     PlaneView Uv, Dv;
     if (r->want & ABZ_WANT_VEL) {
@@ -930,7 +982,7 @@ static int rule_build(abz_series* s, int npt, int64_t nirr, const int32_t* irr_i
         RULE_TRY(dev_alloc((void**)&r->idx, sizeof(int32_t) * it.size(), &r->idx_cap));
         RULE_TRY(stage_h2d(ctx, r->idx, it.data(), sizeof(int32_t) * (size_t)(nirr * d)));
     }
-    if (want & ABZ_WANT_VEL) {
+    if ((want & ABZ_WANT_VEL) && !rule_ggr_fused(r)) {
         const size_t tb = sizeof(double) * (size_t)(r->ntiles * 2 * n * n * pitch);  // tiled temporaries
         RULE_TRY(rp->tmpU.reserve(tb));
         RULE_TRY(rp->tmpD.reserve(tb));
@@ -970,7 +1022,7 @@ int abz_rule_rebuild(abz_rule* r) {
     abz_ctx* ctx = r->s->ctx;
     ABZ_HIP(hipSetDevice(ctx->device));
     RulePlan* rp = static_cast<RulePlan*>(r->plan);
-    if (r->want & ABZ_WANT_VEL) {
+    if ((r->want & ABZ_WANT_VEL) && !rule_ggr_fused(r)) {
         const size_t tb = sizeof(double) * (size_t)(r->ntiles * 2 * r->s->n * r->s->n * r->E.row);
         int rc = rp->tmpU.reserve(tb);
         if (rc) return rc;

@@ -78,6 +78,7 @@ typedef struct abz_rule abz_rule;     /* device-resident cached rule values (Fou
 #define ABZ_K_REDUCE 2     /* integrand scan + reduce over a cached rule (quadsum)   */
 #define ABZ_K_GGR 3        /* GGR formula scan (sum_ggr)                             */
 #define ABZ_K_EIG 4        /* stand-alone Hermitian eigensolve                        */
+#define ABZ_K_GGRBUILD 5   /* fused GGR build: H, dH/dk, eig, velocities per node (get_ggr_data, ref src/dos_ggr.jl:14-44) */
 #define ABZ_K_COUNT 8
 
 /* ---------------------------------------------------------------- library / context */
