@@ -1825,171 +1825,6 @@ int launch_reduce(abz_ctx* ctx, const ReduceSpec& rs, double* out_reim) {
 }
 
 // ------------------------------------------------------------------------------------------
-// GGR
-// ------------------------------------------------------------------------------------------
-// ref: src/dos_ggr.jl:75-104 (same branch order)
-__device__ __forceinline__ double ggr1(double b, double E, double e, double v1) {
-    v1 = fabs(v1);
-    const double dw = fabs(E - e);
-    return (dw <= b * v1) ? 1.0 / v1 : 0.0;
-}
-__device__ __forceinline__ double ggr2(double b, double E, double e, double va, double vb) {
-    va = fabs(va);
-    vb = fabs(vb);
-    const double v1 = fmax(va, vb), v2 = fmin(va, vb);
-    const double dw = fabs(E - e);
-    const double w1 = b * fabs(v1 - v2), w3 = b * (v1 + v2);
-    if (dw <= w1) return 2.0 * b / v1;
-    if (dw <= w3) return (b * (v1 + v2) - dw) / (v1 * v2);
-    return 0.0;
-}
-__device__ __forceinline__ double ggr3(double b, double E, double e, double va, double vb, double vc) {
-    va = fabs(va);
-    vb = fabs(vb);
-    vc = fabs(vc);
-    const double v1 = fmax(va, fmax(vb, vc));
-    const double v3 = fmin(va, fmin(vb, vc));
-    const double v2 = (va + vb + vc) - v1 - v3;
-    const double dw = fabs(E - e);
-    const double w1 = b * fabs(v1 - v2 - v3);
-    const double w2 = b * (v1 - v2 + v3);
-    const double w3 = b * (v1 + v2 - v3);
-    const double w4 = b * (v1 + v2 + v3);
-    const double vn2 = v1 * v1 + v2 * v2 + v3 * v3;
-    const double p = v1 * v2 * v3;
-    if (v1 >= v2 + v3 && dw <= w1) return 4.0 * b * b / v1;
-    if (v1 <= v2 + v3 && dw <= w1) return (2.0 * b * b * (v1 * v2 + v2 * v3 + v3 * v1) - (dw * dw + vn2 * b * b)) / p;
-    if (w1 <= dw && dw <= w2)
-        return (b * b * (v1 * v2 + 3.0 * v2 * v3 + v3 * v1) - b * dw * (-v1 + v2 + v3) - (dw * dw + vn2 * b * b) * 0.5) / p;
-    if (w2 <= dw && dw <= w3) return 2.0 * b * (b * (v1 + v2) - dw) / (v1 * v2);
-    if (w3 <= dw && dw <= w4) {
-        const double t = b * (v1 + v2 + v3) - dw;
-        return t * t / (2.0 * p);
-    }
-    return 0.0;
-}
-
-struct GgrArgs {
-    PlaneView E, V;
-    const double* w;
-    const double* Es;
-    int64_t nk;
-    int n, d, nE;
-    int vstride;  // planes between the velocity components of a band (= number of bands of the rule)
-    double b;
-};
-
-// N bands per thread.  n <= 4: N = n, one block row.  n > 4: N = 1 and blockIdx.y is the band (the partial sums
-// of the bands are further rows of `partial`).
-template <int N, int D>
-__global__ __launch_bounds__(256) void ggr_kernel(GgrArgs a, double* __restrict__ partial) {
-    extern __shared__ double ldsd[];  // [nE chunk][4]
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    const bool ok = k < a.nk;
-    const int64_t kk = ok ? k : 0;
-    const double wk = ok ? (a.w ? a.w[kk] : 1.0) : 0.0;
-    double e[N];
-    double v[D][N];
-    const double* __restrict__ ei = a.E.base + view_off(a.E, kk) + (int64_t)blockIdx.y * a.E.pitch;
-    const double* __restrict__ vi = a.V.base + view_off(a.V, kk) + (int64_t)blockIdx.y * a.V.pitch;
-#pragma unroll
-    for (int bnd = 0; bnd < N; ++bnd) {
-        e[bnd] = ei[(int64_t)bnd * a.E.pitch];
-#pragma unroll
-        for (int j = 0; j < D; ++j) v[j][bnd] = vi[(int64_t)(j * a.vstride + bnd) * a.V.pitch];
-    }
-    const int64_t prow = (int64_t)blockIdx.y * gridDim.x + blockIdx.x;
-    const int chunk = 1024;
-    for (int s0 = 0; s0 < a.nE; s0 += chunk) {
-        const int s1 = min(a.nE, s0 + chunk);
-        for (int s = s0; s < s1; ++s) {
-            const double En = a.Es[s];
-            double acc = 0.0;
-#pragma unroll
-            for (int bnd = 0; bnd < N; ++bnd) {
-                double f;
-                if constexpr (D == 1)
-                    f = ggr1(a.b, En, e[bnd], v[0][bnd]);
-                else if constexpr (D == 2)
-                    f = ggr2(a.b, En, e[bnd], v[0][bnd], v[1][bnd]);
-                else
-                    f = ggr3(a.b, En, e[bnd], v[0][bnd], v[1][bnd], v[2][bnd]);
-                acc += f;
-            }
-            acc = wave_sum(wk * acc);
-            if (lane == 0) ldsd[(s - s0) * 4 + wave] = acc;
-        }
-        __syncthreads();
-        for (int t = threadIdx.x; t < s1 - s0; t += 256)
-            partial[prow * a.nE + s0 + t] = ldsd[t * 4] + ldsd[t * 4 + 1] + ldsd[t * 4 + 2] + ldsd[t * 4 + 3];
-        __syncthreads();
-    }
-}
-
-__global__ void final_reduce_real_kernel(const double* __restrict__ partial, int64_t nblocks, int64_t ncols,
-                                         double* __restrict__ out) {
-    const int64_t col = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (col >= ncols) return;
-    double s = 0.0;
-    for (int64_t b = 0; b < nblocks; ++b) s += partial[b * ncols + col];
-    out[col] = s;
-}
-
-int launch_ggr(abz_ctx* ctx, int n, int d, int npt, PlaneView E, PlaneView V, const double* w, int64_t nk,
-               const double* Es_host, int nE, double* out_host) {
-    const int64_t nblocks = cdiv(nk, 256);
-    const int brows = n > 4 ? n : 1;  // n > 4: one block row per band
-    int rc = ctx->scratch[1].reserve(sizeof(double) * (size_t)(nblocks * brows * nE));
-    if (rc) return rc;
-    rc = ctx->scratch[2].reserve(sizeof(double) * (size_t)nE * 2);
-    if (rc) return rc;
-    double* partial = ctx->scratch[1].as<double>();
-    double* Es_dev = ctx->scratch[2].as<double>();
-    double* outd = Es_dev + nE;
-    ABZ_HIP(hipMemcpyAsync(Es_dev, Es_host, sizeof(double) * (size_t)nE, hipMemcpyHostToDevice, ctx->stream));
-    GgrArgs a;
-    a.E = E;
-    a.V = V;
-    a.w = w;
-    a.Es = Es_dev;
-    a.nk = nk;
-    a.n = n;
-    a.d = d;
-    a.nE = nE;
-    a.vstride = n;
-    a.b = 1.0 / (2.0 * (double)npt);
-    {
-        ProfScope ps(ctx, ABZ_K_GGR);
-        const size_t lds = sizeof(double) * 4 * (size_t)std::min(nE, 1024);
-#define GG(NN, DD) \
-    hipLaunchKernelGGL((ggr_kernel<NN, DD>), dim3((unsigned)nblocks, (unsigned)brows), dim3(256), lds, ctx->stream, a, partial)
-#define GD(NN)                     \
-    switch (d) {                   \
-        case 1: GG(NN, 1); break;  \
-        case 2: GG(NN, 2); break;  \
-        default: GG(NN, 3); break; \
-    }
-        switch (n) {
-            case 1: GD(1) break;
-            case 2: GD(2) break;
-            case 3: GD(3) break;
-            case 4: GD(4) break;
-            default: GD(1) break;  // band = blockIdx.y
-        }
-#undef GD
-#undef GG
-        ABZ_HIP(hipGetLastError());
-        hipLaunchKernelGGL(final_reduce_real_kernel, dim3((unsigned)cdiv(nE, 256)), dim3(256), 0, ctx->stream, partial,
-                           nblocks * brows, (int64_t)nE, outd);
-        ABZ_HIP(hipGetLastError());
-    }
-    ABZ_HIP(hipMemcpyAsync(out_host, outd, sizeof(double) * (size_t)nE, hipMemcpyDeviceToHost, ctx->stream));
-    ABZ_HIP(hipStreamSynchronize(ctx->stream));
-    return ABZ_OK;
-}
-
-// ------------------------------------------------------------------------------------------
 // export planar -> AoS
 // ------------------------------------------------------------------------------------------
 __global__ void export_kernel(PlaneView v, int ncomp, int64_t nk, double* __restrict__ out) {
