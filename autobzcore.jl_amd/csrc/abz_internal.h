@@ -254,6 +254,7 @@ struct GgrBuildSpec {
     bool fuse = false;  // the wave contracts variable 2 itself from the level-2 sets src2 (ggr_build_can_fuse)
     const double2* src[3] = {nullptr, nullptr, nullptr};  // !fuse / node lists: level-1 families: plain, derivative on variable 2, on variable 3
     const double2* src2[2] = {nullptr, nullptr};          // fuse: level-2 sets: plain, derivative on variable 3
+    double2* pack2 = nullptr;  // fuse: room for ggr_build_pack2_elems() complex numbers (the packed level-2 sets)
     int M2 = 0, first2 = 0, gbeg = 0, gcnt = 0;
     // node lists (symmetric rules)
     int64_t nk = 0;
@@ -262,6 +263,7 @@ struct GgrBuildSpec {
 };
 bool ggr_build_supported(int n, int d, int M, int npt, bool herm);
 bool ggr_build_can_fuse(int n, int d, int M, int M2, int npt);
+size_t ggr_build_pack2_elems(int n, int d, int M, int M2, int64_t nparents);
 int launch_ggr_build(abz_ctx* ctx, const GgrBuildSpec& gs);
 int launch_ggr(abz_ctx* ctx, int n, int d, int npt, PlaneView E, PlaneView V, const double* w, int64_t nk,
                const double* Es_host, int nE, double* out_host);

@@ -735,6 +735,9 @@ static int rule_fill(abz_rule* r) {
                 gs.gcnt = (d == 2) ? plan.outer_n : r->npt;
                 if ((rc = build_chain(s, plan, rp->pd, tab, 0, &gs.src2[0], 2))) return rc;
                 if (d == 3 && (rc = build_chain(s, plan, rp->pd, tab, 3, &gs.src2[1], 2, &rp->fam[1]))) return rc;
+                const int64_t nparents = gs.nlines / std::max(gs.gcnt, 1);
+                if ((rc = rp->fam[0].reserve(sizeof(double2) * ggr_build_pack2_elems(n, d, gs.M, gs.M2, nparents)))) return rc;
+                gs.pack2 = rp->fam[0].as<double2>();
             } else {
                 if ((rc = build_chain(s, plan, rp->pd, tab, 0, &gs.src[0]))) return rc;
                 for (int j = 2; j <= d; ++j)

@@ -3,25 +3,33 @@
 // ref: src/dos_ggr.jl:14-44 (get_ggr_data): per node  h, V = x.s ; e, U = eigen(Hermitian(h)) ;
 //      v_j = real(diag(U' V_j U)) * t_j.
 //
-// The unfused build (api.cpp::rule_fill, round 1/2) ran 1 + 3 x (series launch + velocity_kernel) and moved the
+// The unfused build (api.cpp::rule_fill, rounds 1-2) ran 1 + 3 x (series launch + velocity_kernel) and moved the
 // eigenvectors and every dH/dk_j through HBM: ~1.5 KB per node against the 8 n (1 + d) bytes the rule keeps.
 // Here a wave evaluates H and the d derivative matrices of its nodes from the same staged coefficients, solves
 // the eigenproblem in registers and stores only (e, v): 96 B per node for 3 bands in 3 dimensions.
 //
-//  * Hermitian series only (c(-R) = c(R)^dagger): H and dH/dk_j are Hermitian, upper triangles are accumulated.
-//  * dH/dk_1 shares the level-1 coefficients with H (phase times 2 pi i (first + m)); dH/dk_j, j >= 2, need level-1
-//    sets contracted with the derivative factor on variable j.  FUSE: the wave contracts the level-1 sets of its
-//    lines itself from the level-2 sets of its block (LDS), so the level-1 sets never exist in HBM and the work
-//    loop holds no global load.  !FUSE (d = 1, or sets too large for LDS): the d level-1 families are read.
+//  * Hermitian series only (c(-R) = c(R)^dagger, symmetric frequency range): H and every dH/dk_j are Hermitian, and
+//    the level-1 coefficients of a grid line obey c1[-f] = c1[f]^dagger.  So only frequencies f >= 0 are kept, as the
+//    PACKED set of a line (pk_* below): c1[0] (upper triangle), and per f > 0 the combinations
+//        dd_a = 2 c1[f]_aa,   s_ab = c1[f]_ab + c1[f]_ba,   t_ab = c1[f]_ab - c1[f]_ba   (a < b)
+//    with which  H_ab += (s.x pr - s.y pi) + i (t.x pi + t.y pr),  H_aa += dd.x pr - dd.y pi,  p = z^f:
+//    one FMA group serves +f and -f, half the Fourier work (and half the LDS) of the plain sum over 2F + 1 terms.
+//  * dH/dk_1 shares the coefficients of H (phase q = 2 pi i f p); dH/dk_j, j >= 2, need sets contracted with the
+//    derivative factor on variable j.  FUSE: the wave contracts the packed sets of its lines itself from the packed
+//    level-2 sets of its block (LDS), so level-1 sets never exist in HBM and the work loop holds no global load.
+//    !FUSE (d = 1, or sets too large for LDS): the d level-1 families are read from HBM and packed on the way in.
 //  * Lane mapping: a wave works on TWO grid lines at a time, one per half-wave (32 lanes); a pass covers 32 KPL
-//    nodes of each line, KPL = 2 for the body (two nodes share every broadcast ds_read_b128 of a coefficient:
-//    18 reads per 144 FMAs) and KPL = 1 for a tail of <= 32 nodes.  npt = 150: 2 + 2 + 1 half-passes = 160
-//    lane-slots per line (94 %), where whole-wave passes would need 192 (one line per wave, 78 %).
+//    nodes of each line, KPL = 2 for the body (two nodes share every broadcast ds_read_b128 of a coefficient) and
+//    KPL = 1 for a tail of <= 32 nodes.  npt = 150: 2 + 2 + 1 half-passes = 160 lane-slots per line (94 %), where
+//    whole-wave passes would need 192 (78 %).
 //  * Velocities without eigenvectors (n <= 3): v_b = tr(P_b D) with the spectral projector
 //    P_b = prod_{c != b} (B - w_c) / p'(w_b), B = H - (tr H / n) I, so for n = 3
 //        v_b = [tr(B^2 D) + w_b tr(B D) + (c2 + w_b^2) tr D] / (3 w_b^2 + c2),   c2 = -tr(B^2) / 2.
-//    Conditioning eps ||B||^2 ||D|| / |p'(w_b)|: nodes with min_b |p'(w_b)| < 1e-6 ||B||_F^2 (degenerate or nearly
-//    degenerate bands: high-symmetry points and lines) take the Jacobi eigenvectors instead, as do 4 bands.
+//    Conditioning eps ||B||^2 ||D|| / |p'(w_b)|: nodes whose closest pair of bands is nearer than ~2e-3 of the
+//    spectrum's scale (high-symmetry points and lines) take Jacobi eigenvectors instead, as do 4 bands.
+//  * No scratch: a scratch reload is a vector-memory operation and its s_waitcnt vmcnt drains every store the wave
+//    has in flight (measured: the whole store time became serial).  Row bases are scalar, the lane offset is one
+//    32-bit register.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -40,6 +48,44 @@ constexpr double TWO_PI = 6.283185307179586476925286766559;
 
 inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
+// ---- packed Hermitian coefficient sets: element index of ...
+template <int N>
+struct Pk {
+    static constexpr int NT0 = N * (N + 1) / 2;                                   // elements of the f = 0 block
+    __host__ __device__ static constexpr int tri(int a, int b) { return b * (b + 1) / 2 + a; }  // c1[0]_ab, a <= b
+    __host__ __device__ static constexpr int blk(int f) { return NT0 + (f - 1) * N * N; }        // first element of block f >= 1
+    __host__ __device__ static constexpr int dd(int f, int a) { return blk(f) + a; }
+    __host__ __device__ static constexpr int pair(int a, int b) { return b * (b - 1) / 2 + a; }  // a < b
+    __host__ __device__ static constexpr int ss(int f, int a, int b) { return blk(f) + N + 2 * pair(a, b); }
+    __host__ __device__ static constexpr int tt(int f, int a, int b) { return ss(f, a, b) + 1; }
+    __host__ __device__ static constexpr int size(int F) { return NT0 + F * N * N; }
+};
+
+// packed element e of the set whose full coefficients are c[m][a + N b] (m = 0 .. 2F, frequency m - F)
+template <int N>
+__device__ __forceinline__ double2 pk_from_full(const double2* __restrict__ c, int F, int e) {
+    constexpr int NN = N * N;
+    if (e < Pk<N>::NT0) {
+        int b = 0;
+        while ((b + 1) * (b + 2) / 2 <= e) ++b;
+        const int a = e - b * (b + 1) / 2;
+        return c[F * NN + a + N * b];
+    }
+    const int r = e - Pk<N>::NT0;
+    const int f = r / NN + 1, q = r - (f - 1) * NN;
+    const double2* __restrict__ cf = c + (F + f) * NN;
+    if (q < N) {
+        const double2 v = cf[q + N * q];
+        return make_double2(2.0 * v.x, 2.0 * v.y);
+    }
+    const int pi = (q - N) >> 1;
+    int b = 1;
+    while ((b + 1) * b / 2 <= pi) ++b;
+    const int a = pi - b * (b - 1) / 2;
+    const double2 u = cf[a + N * b], v = cf[b + N * a];
+    return ((q - N) & 1) ? make_double2(u.x - v.x, u.y - v.y) : make_double2(u.x + v.x, u.y + v.y);
+}
+
 struct GgrBuildArgs {
     const double2* src[3];   // !FUSE: level-1 sets, slot stride M n n: [0] plain, [j-1] derivative on variable j
     const double2* src2[2];  // FUSE: level-2 sets, slot stride M2 M n n: [0] plain, [1] derivative on variable 3
@@ -49,8 +95,12 @@ struct GgrBuildArgs {
     int M, first, npt;
     int M2, first2, gbeg, gcnt, nseg;
     int nt;     // non-temporal stores
-    int dbg;    // experiments (ABZ_GGR_DEBUG): bit 0 skip the node solve, bit 1 one m-iteration only, bit 2 skip the contraction
+    int dbg;    // experiments (ABZ_GGR_DEBUG): bit 0 skip the node solve, bit 1 one frequency only, bit 2 skip the contraction, bit 3 skip the stores
     int pitch;  // padded row length: columns npt..pitch-1 are written too (whole 128-B lines)
+    // Constants of the 3-band solve that are no inline operands: as kernel arguments they sit in scalar registers.  As
+    // literals the compiler kept them in VGPR pairs hoisted to the kernel's entry, across the accumulation loops, and
+    // spilled them (a scratch reload in the solve drains the wave's stores).
+    double cq[8];
     // node lists (ggr_build_nodes_kernel)
     const int64_t* parents;
     const int32_t* gi;
@@ -106,164 +156,228 @@ __device__ __forceinline__ void ggr_node_jacobi(const CMat<N> (&A)[D + 1], doubl
      2.0 * ((x01r * Dm.re[0][1] + x01i * Dm.im[0][1]) + (x02r * Dm.re[0][2] + x02i * Dm.im[0][2]) +                   \
             (x12r * Dm.re[1][2] + x12i * Dm.im[1][2])))
 
+// Eigenvalues (ascending) and band velocities of one node from H = A[0] and dH/dk_j = A[j] (upper triangles), in
+// straight-line code.  Returns true when the node has to be redone by the eigenvector route (ggr_node_jacobi):
+// (nearly) degenerate bands; then e and v hold no result.
 template <int N, int D>
-__device__ __forceinline__ void ggr_node(const CMat<N> (&A)[D + 1], double (&e)[N], double (&v)[D][N]) {
+__device__ __forceinline__ bool ggr_node_fast(const GgrBuildArgs& a, const CMat<N> (&A)[D + 1], double (&e)[N], double (&v)[D][N]) {
     if constexpr (N == 1) {
         e[0] = A[0].re[0][0];
 #pragma unroll
         for (int j = 0; j < D; ++j) v[j][0] = A[j + 1].re[0][0];
+        return false;
     } else if constexpr (N == 2) {
         const CMat<2>& H = A[0];
         const double q = 0.5 * (H.re[0][0] + H.re[1][1]);
         const double d0 = 0.5 * (H.re[0][0] - H.re[1][1]);
         const double br = H.re[0][1], bi = H.im[0][1];
         const double r2 = d0 * d0 + br * br + bi * bi;
-        const double r = sqrt(r2);
-        if (r > 1e-13 * (fabs(H.re[0][0]) + fabs(H.re[1][1]) + r)) {
-            e[0] = q - r;
-            e[1] = q + r;
-            const double hr = 0.5 / r;
+        const double s = fabs(H.re[0][0]) + fabs(H.re[1][1]);
+        const bool fast = r2 > 1e-26 * s * s && r2 > 1e-290;
+        const double ir = fast_rsqrt(fast ? r2 : 1.0);
+        const double r = r2 * ir;
+        e[0] = q - r;
+        e[1] = q + r;
+        const double hr = 0.5 * ir;
 #pragma unroll
-            for (int j = 0; j < D; ++j) {
-                const CMat<2>& Dm = A[j + 1];
-                const double t0 = Dm.re[0][0] + Dm.re[1][1];
-                const double t1 = d0 * (Dm.re[0][0] - Dm.re[1][1]) + 2.0 * (br * Dm.re[0][1] + bi * Dm.im[0][1]);
-                // P_b = (B + w_b) / (2 w_b), w_b = -+ r
-                v[j][0] = 0.5 * t0 - t1 * hr;
-                v[j][1] = 0.5 * t0 + t1 * hr;
-            }
-        } else {
-            ggr_node_jacobi<2, D>(A, e, v);
+        for (int j = 0; j < D; ++j) {
+            const CMat<2>& Dm = A[j + 1];
+            const double t0 = Dm.re[0][0] + Dm.re[1][1];
+            const double t1 = d0 * (Dm.re[0][0] - Dm.re[1][1]) + 2.0 * (br * Dm.re[0][1] + bi * Dm.im[0][1]);
+            // P_b = (B + w_b) / (2 w_b), w_b = -+ r
+            v[j][0] = 0.5 * t0 - t1 * hr;
+            v[j][1] = 0.5 * t0 + t1 * hr;
         }
+        return !fast;
     } else if constexpr (N == 3) {
+        // Roots of w^3 + c2 w + c3 (B = H - q I, c2 = -tr B^2 / 2, c3 = -det B) in the trigonometric form of
+        // herm_eig3_values (device_math.h): x = 2 cos(acos(|r|) / 3) by a quartic seed + 2 Newton steps gives the
+        // isolated root, the other two follow from the quadratic factor; each root is then polished by one Newton
+        // step of the cubic itself, whose 1 / p'(w) the velocities need anyway.  Reciprocals and square roots are
+        // hardware estimates + Newton (operands are O(1) after scaling).  A close pair (disc <= 1e-6, i.e. a gap below
+        // ~2e-3 of the scale p) or a zero matrix B is computed like any other node and flagged for the redo.
         const CMat<3>& H = A[0];
-        herm_eig3_values(H, e);
-        const double q = (H.re[0][0] + H.re[1][1] + H.re[2][2]) * (1.0 / 3.0);
+        const double q = (H.re[0][0] + H.re[1][1] + H.re[2][2]) * a.cq[5];
         const double d0 = H.re[0][0] - q, d1 = H.re[1][1] - q, d2 = H.re[2][2] - q;
         const double br = H.re[0][1], bi = H.im[0][1];  // B01
         const double cr = H.re[0][2], ci = H.im[0][2];  // B02
         const double dr = H.re[1][2], di = H.im[1][2];  // B12
         const double nb = br * br + bi * bi, nc = cr * cr + ci * ci, nd = dr * dr + di * di;
         const double p2 = d0 * d0 + d1 * d1 + d2 * d2 + 2.0 * (nb + nc + nd);
+        const double p26 = fmax(p2 * a.cq[6], 1e-290);
+        const double ip = fast_rsqrt(p26);
+        const double p = p26 * ip;
+        // det B = d0 d1 d2 + 2 Re(b d conj(c)) - d0 |d|^2 - d1 |c|^2 - d2 |b|^2
+        const double bdr = br * dr - bi * di, bdi = br * di + bi * dr;
+        const double det = d0 * d1 * d2 + 2.0 * (bdr * cr + bdi * ci) - d0 * nd - d1 * nc - d2 * nb;
+        const double r = 0.5 * det * ip * ip * ip;
+        const double t = fmin(1.0, fabs(r));
+        double x = fma(fma(fma(fma(a.cq[0], t, a.cq[1]), t, a.cq[2]), t, a.cq[3]), t, a.cq[4]);  // quartic seed, device_math.h
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const double x2 = x * x;
+            const double f = fma(x2 - 3.0, x, -2.0 * t);
+            x = fma(-f, fast_rcp(fma(3.0, x2, -3.0)), x);
+        }
+        const double disc = fma(-0.75 * x, x, 3.0);
+        const bool fast = disc > a.cq[7] && p2 > 1e-290;
+        const double dsafe = fmax(disc, a.cq[7]);
+        const double sq = dsafe * fast_rsqrt(dsafe);
+        const bool pos = r >= 0.0;
+        const double wi = pos ? p * x : -(p * x);  // isolated root: largest for r >= 0, smallest otherwise
+        const double wm = -0.5 * wi;               // the pair: wm -+ p sq
+        const double wl = wm - p * sq, wh = wm + p * sq;
+        double w[3];
+        w[0] = pos ? wl : wi;
+        w[1] = pos ? wh : wl;
+        w[2] = pos ? wi : wh;
         const double c2 = -0.5 * p2;
-        double w[3], rp[3];
-        bool ok = true;
+        const double c3 = -det;
+        double rp[3];
 #pragma unroll
         for (int b = 0; b < 3; ++b) {
-            w[b] = e[b] - q;
-            const double pp = fma(3.0 * w[b], w[b], c2);
-            ok = ok && (fabs(pp) > 1e-6 * p2);
-            rp[b] = 1.0 / pp;
+            double pp = fma(3.0 * w[b], w[b], c2);
+            pp = fast ? pp : 1.0;
+            const double ri = fast_rcp(pp);
+            w[b] = fma(-fma(fma(w[b], w[b], c2), w[b], c3), ri, w[b]);  // Newton on the cubic
+            pp = fma(3.0 * w[b], w[b], c2);
+            rp[b] = fma(fma(-pp, ri, 1.0), ri, ri);
+            e[b] = q + w[b];
         }
-        if (ok) {
-            // B^2, upper triangle
-            const double s00 = d0 * d0 + nb + nc, s11 = nb + d1 * d1 + nd, s22 = nc + nd + d2 * d2;
-            const double s01r = br * (d0 + d1) + (cr * dr + ci * di), s01i = bi * (d0 + d1) + (ci * dr - cr * di);  // b (d0+d1) + c conj(d)
-            const double s02r = cr * (d0 + d2) + (br * dr - bi * di), s02i = ci * (d0 + d2) + (br * di + bi * dr);  // c (d0+d2) + b d
-            const double s12r = dr * (d1 + d2) + (br * cr + bi * ci), s12i = di * (d1 + d2) + (br * ci - bi * cr);  // d (d1+d2) + conj(b) c
+        // B^2, upper triangle
+        const double s00 = d0 * d0 + nb + nc, s11 = nb + d1 * d1 + nd, s22 = nc + nd + d2 * d2;
+        const double s01r = br * (d0 + d1) + (cr * dr + ci * di), s01i = bi * (d0 + d1) + (ci * dr - cr * di);  // b (d0+d1) + c conj(d)
+        const double s02r = cr * (d0 + d2) + (br * dr - bi * di), s02i = ci * (d0 + d2) + (br * di + bi * dr);  // c (d0+d2) + b d
+        const double s12r = dr * (d1 + d2) + (br * cr + bi * ci), s12i = di * (d1 + d2) + (br * ci - bi * cr);  // d (d1+d2) + conj(b) c
 #pragma unroll
-            for (int j = 0; j < D; ++j) {
-                const CMat<3>& Dm = A[j + 1];
-                const double t0 = Dm.re[0][0] + Dm.re[1][1] + Dm.re[2][2];
-                const double t1 = ABZ_TRHD3(d0, d1, d2, br, bi, cr, ci, dr, di, Dm);
-                const double t2 = ABZ_TRHD3(s00, s11, s22, s01r, s01i, s02r, s02i, s12r, s12i, Dm);
+        for (int j = 0; j < D; ++j) {
+            const CMat<3>& Dm = A[j + 1];
+            const double t0 = Dm.re[0][0] + Dm.re[1][1] + Dm.re[2][2];
+            const double t1 = ABZ_TRHD3(d0, d1, d2, br, bi, cr, ci, dr, di, Dm);
+            const double t2 = ABZ_TRHD3(s00, s11, s22, s01r, s01i, s02r, s02i, s12r, s12i, Dm);
 #pragma unroll
-                for (int b = 0; b < 3; ++b) v[j][b] = fma(fma(w[b], w[b], c2), t0, fma(w[b], t1, t2)) * rp[b];
-            }
-        } else {
-            ggr_node_jacobi<3, D>(A, e, v);
+            for (int b = 0; b < 3; ++b) v[j][b] = fma(fma(w[b], w[b], c2), t0, fma(w[b], t1, t2)) * rp[b];
         }
+        return !fast;
     } else {
-        ggr_node_jacobi<N, D>(A, e, v);
+        return true;  // 4 bands: eigenvectors always
     }
 }
 #undef ABZ_TRHD3
 
-// Accumulators of one node: H and D derivative matrices, upper triangles.  cset: the lane's line, D sets of MNN
-// complex coefficients in LDS ([set][m][a + N b]).
-template <int N, int D, int KPL, bool NT>
-__device__ __forceinline__ void ggr_unit(const GgrBuildArgs& a, const double2* __restrict__ cset, int MNN, const double2* tab_l,
-                                         int fm, int i0, int sub, int64_t lineA, int half, bool active) {
-    CMat<N> A[KPL][D + 1];
+// H and dH/dk_j (upper triangles) of KPL nodes per lane, i1 = i0 + sub + 32 j, from the line's D packed sets in LDS
+// (cset[set * P + e]).
+template <int N, int D, int KPL>
+__device__ __forceinline__ void ggr_accumulate(const GgrBuildArgs& a, const double2* __restrict__ cset, int F, int P, const double2* tab_l,
+                                               int i0, int sub, CMat<N> (&A)[KPL][D + 1]) {
     double zr[KPL], zi[KPL], pr[KPL], pi[KPL];
 #pragma unroll
     for (int j = 0; j < KPL; ++j) {
         const int i1 = i0 + sub + 32 * j;
-        const int ic = i1 < a.npt ? i1 : 0;
-        const int iw = (int)(((unsigned)fm * (unsigned)ic) % (unsigned)a.npt);
-        const double2 z = tab_l[ic];
-        const double2 w = tab_l[iw];
+        const double2 z = tab_l[i1 < a.npt ? i1 : 0];
         zr[j] = z.x;
         zi[j] = z.y;
-        pr[j] = w.x;
-        pi[j] = w.y;
+        pr[j] = 1.0;
+        pi[j] = 0.0;
+    }
+    // frequency 0: the accumulators start from c1[0]
 #pragma unroll
-        for (int s = 0; s <= D; ++s) {
+    for (int bb = 0; bb < N; ++bb) {
 #pragma unroll
-            for (int bb = 0; bb < N; ++bb) {
+        for (int aa = 0; aa <= bb; ++aa) {
 #pragma unroll
-                for (int aa = 0; aa <= bb; ++aa) {
-                    A[j][s].re[aa][bb] = 0.0;
-                    A[j][s].im[aa][bb] = 0.0;
+            for (int s = 0; s < D; ++s) {
+                const double2 c = cset[s * P + Pk<N>::tri(aa, bb)];
+                const int mat = s == 0 ? 0 : s + 1;
+#pragma unroll
+                for (int j = 0; j < KPL; ++j) {
+                    A[j][mat].re[aa][bb] = c.x;
+                    A[j][mat].im[aa][bb] = c.y;
                 }
+            }
+#pragma unroll
+            for (int j = 0; j < KPL; ++j) {
+                A[j][1].re[aa][bb] = 0.0;
+                A[j][1].im[aa][bb] = 0.0;
             }
         }
     }
-    const int Mrun = (a.dbg & 2) ? 1 : a.M;
-    for (int m = 0; m < Mrun; ++m) {
-        const double f = TWO_PI * (double)(a.first + m);
-        double qr[KPL], qi[KPL];  // i f p: phase of d/dx_1
-#pragma unroll
-        for (int j = 0; j < KPL; ++j) {
-            qr[j] = -f * pi[j];
-            qi[j] = f * pr[j];
-        }
-        const double2* __restrict__ cm = cset + m * (N * N);
-#pragma unroll
-        for (int bb = 0; bb < N; ++bb) {
-#pragma unroll
-            for (int aa = 0; aa <= bb; ++aa) {
-                const double2 c = cm[aa + N * bb];
-#pragma unroll
-                for (int j = 0; j < KPL; ++j) {
-                    A[j][0].re[aa][bb] = fma(c.x, pr[j], A[j][0].re[aa][bb]);
-                    A[j][0].re[aa][bb] = fma(-c.y, pi[j], A[j][0].re[aa][bb]);
-                    A[j][1].re[aa][bb] = fma(c.x, qr[j], A[j][1].re[aa][bb]);
-                    A[j][1].re[aa][bb] = fma(-c.y, qi[j], A[j][1].re[aa][bb]);
-                    if (aa != bb) {
-                        A[j][0].im[aa][bb] = fma(c.x, pi[j], A[j][0].im[aa][bb]);
-                        A[j][0].im[aa][bb] = fma(c.y, pr[j], A[j][0].im[aa][bb]);
-                        A[j][1].im[aa][bb] = fma(c.x, qi[j], A[j][1].im[aa][bb]);
-                        A[j][1].im[aa][bb] = fma(c.y, qr[j], A[j][1].im[aa][bb]);
-                    }
-                }
-#pragma unroll
-                for (int s = 1; s < D; ++s) {
-                    const double2 cs = cm[s * MNN + aa + N * bb];
-#pragma unroll
-                    for (int j = 0; j < KPL; ++j) {
-                        A[j][s + 1].re[aa][bb] = fma(cs.x, pr[j], A[j][s + 1].re[aa][bb]);
-                        A[j][s + 1].re[aa][bb] = fma(-cs.y, pi[j], A[j][s + 1].re[aa][bb]);
-                        if (aa != bb) {
-                            A[j][s + 1].im[aa][bb] = fma(cs.x, pi[j], A[j][s + 1].im[aa][bb]);
-                            A[j][s + 1].im[aa][bb] = fma(cs.y, pr[j], A[j][s + 1].im[aa][bb]);
-                        }
-                    }
-                }
-            }
-        }
+    const int Frun = (a.dbg & 2) ? (F > 0 ? 1 : 0) : F;
+    for (int f = 1; f <= Frun; ++f) {
+        const double tf = TWO_PI * (double)f;
+        double qr[KPL], qi[KPL];  // 2 pi i f p: phase of d/dx_1
 #pragma unroll
         for (int j = 0; j < KPL; ++j) {
             const double nr = pr[j] * zr[j] - pi[j] * zi[j];
             const double ni = pr[j] * zi[j] + pi[j] * zr[j];
             pr[j] = nr;
             pi[j] = ni;
+            qr[j] = -tf * ni;
+            qi[j] = tf * nr;
+        }
+        const double2* __restrict__ cf = cset + Pk<N>::blk(1) + (f - 1) * (N * N);  // block f; element offsets below are those of block 1
+#pragma unroll
+        for (int s = 0; s < D; ++s) {
+            const int mat = s == 0 ? 0 : s + 1;
+#pragma unroll
+            for (int aa = 0; aa < N; ++aa) {
+                const double2 dd = cf[s * P + aa];
+#pragma unroll
+                for (int j = 0; j < KPL; ++j) {
+                    A[j][mat].re[aa][aa] = fma(dd.x, pr[j], A[j][mat].re[aa][aa]);
+                    A[j][mat].re[aa][aa] = fma(-dd.y, pi[j], A[j][mat].re[aa][aa]);
+                    if (s == 0) {
+                        A[j][1].re[aa][aa] = fma(dd.x, qr[j], A[j][1].re[aa][aa]);
+                        A[j][1].re[aa][aa] = fma(-dd.y, qi[j], A[j][1].re[aa][aa]);
+                    }
+                }
+            }
+#pragma unroll
+            for (int bb = 1; bb < N; ++bb) {
+#pragma unroll
+                for (int aa = 0; aa < bb; ++aa) {
+                    const double2 sv = cf[s * P + N + 2 * Pk<N>::pair(aa, bb)];
+                    const double2 tv = cf[s * P + N + 2 * Pk<N>::pair(aa, bb) + 1];
+#pragma unroll
+                    for (int j = 0; j < KPL; ++j) {
+                        A[j][mat].re[aa][bb] = fma(sv.x, pr[j], A[j][mat].re[aa][bb]);
+                        A[j][mat].re[aa][bb] = fma(-sv.y, pi[j], A[j][mat].re[aa][bb]);
+                        A[j][mat].im[aa][bb] = fma(tv.x, pi[j], A[j][mat].im[aa][bb]);
+                        A[j][mat].im[aa][bb] = fma(tv.y, pr[j], A[j][mat].im[aa][bb]);
+                        if (s == 0) {
+                            A[j][1].re[aa][bb] = fma(sv.x, qr[j], A[j][1].re[aa][bb]);
+                            A[j][1].re[aa][bb] = fma(-sv.y, qi[j], A[j][1].re[aa][bb]);
+                            A[j][1].im[aa][bb] = fma(tv.x, qi[j], A[j][1].im[aa][bb]);
+                            A[j][1].im[aa][bb] = fma(tv.y, qr[j], A[j][1].im[aa][bb]);
+                        }
+                    }
+                }
+            }
         }
     }
+}
+
+template <int N, int D, bool NT>
+__device__ __forceinline__ void ggr_store(const GgrBuildArgs& a, double* __restrict__ erow, double* __restrict__ vrow, unsigned u,
+                                          const double (&e)[N], const double (&v)[D][N]) {
+#pragma unroll
+    for (int b = 0; b < N; ++b) st_f64<NT>((erow + (int64_t)b * a.E.pitch) + u, e[b]);
+#pragma unroll
+    for (int jj = 0; jj < D; ++jj) {
+#pragma unroll
+        for (int b = 0; b < N; ++b) st_f64<NT>((vrow + (int64_t)(jj * N + b) * a.V.pitch) + u, v[jj][b]);
+    }
+}
+
+// One unit of work: KPL nodes per lane -- accumulate, then node after node: the straight-line solve, the Jacobi redo of
+// flagged nodes (grid nodes on high-symmetry lines), stores.
+template <int N, int D, int KPL, bool NT>
+__device__ __forceinline__ void ggr_unit(const GgrBuildArgs& a, const double2* __restrict__ cset, int F, int P, const double2* tab_l,
+                                         int i0, int sub, int64_t lineA, int half, bool active) {
+    CMat<N> A[KPL][D + 1];
+    ggr_accumulate<N, D, KPL>(a, cset, F, P, tab_l, i0, sub, A);
     // wave-uniform row bases (scalar registers) + one 32-bit lane offset: the half-wave's own line is half * tile
-    // further on.  64-bit per-lane addresses here spilled to scratch, and a scratch reload is a vector-memory
-    // operation: its s_waitcnt vmcnt drains every store the wave has in flight (measured: the whole store time
-    // became serial, 0.075 ms of 0.28 at 150^3).
+    // further on.  64-bit per-lane addresses here were hoisted out of the loops and spilled.
     double* __restrict__ erow = a.E.base + lineA * a.E.tile;
     double* __restrict__ vrow = a.V.base + lineA * a.V.tile;
     const unsigned lane_off = (unsigned)sub + (half ? (unsigned)a.E.tile : 0u);  // E and V are views of one tile: same stride
@@ -281,86 +395,79 @@ __device__ __forceinline__ void ggr_unit(const GgrBuildArgs& a, const double2* _
                     for (int jj = 0; jj < D; ++jj) v[jj][b] = A[j][jj + 1].re[b][b] + A[j][jj + 1].im[0][N - 1] + A[j][jj + 1].re[0][N - 1];
                 }
             } else {
-                ggr_node<N, D>(A[j], e, v);
+                if (ggr_node_fast<N, D>(a, A[j], e, v)) ggr_node_jacobi<N, D>(A[j], e, v);
             }
-            // the lane offset stays ONE 32-bit register next to scalar row bases: nothing per-lane to hoist (and spill)
             unsigned u = lane_off;
             asm volatile("" : "+v"(u));
             u += (unsigned)(i0 + 32 * j);
-#pragma unroll
-            for (int b = 0; b < N; ++b) st_f64<NT>((erow + (int64_t)b * a.E.pitch) + u, e[b]);
-#pragma unroll
-            for (int jj = 0; jj < D; ++jj) {
-#pragma unroll
-                for (int b = 0; b < N; ++b) st_f64<NT>((vrow + (int64_t)(jj * N + b) * a.V.pitch) + u, v[jj][b]);
-            }
+            if ((a.dbg & 8) && e[0] != 1.2345e300) continue;  // experiment: no stores
+            ggr_store<N, D, NT>(a, erow, vrow, u, e, v);
         }
     }
 }
 
-// all passes of a pair of lines whose sets are staged in the wave's LDS buffer
+// all passes of a pair of lines whose packed sets are staged in the wave's LDS buffer
 template <int N, int D, bool NT, int KB>
-__device__ __forceinline__ void ggr_line_pair(const GgrBuildArgs& a, const double2* wbuf, int MNN, const double2* tab_l, int fm,
+__device__ __forceinline__ void ggr_line_pair(const GgrBuildArgs& a, const double2* wbuf, int F, int P, const double2* tab_l,
                                               int lane, int64_t lineA, bool haveB) {
+    // per-lane values are re-derived from `lane` for every pair of lines (a handful of integer operations): as loop
+    // invariants the compiler kept one set of LDS addresses and offsets per unit variant alive across the whole
+    // kernel and spilled them
+    asm volatile("" : "+v"(lane));
     const int half = lane >> 5, sub = lane & 31;
-    const double2* cset = wbuf + (size_t)half * D * MNN;
+    const double2* cset = wbuf + (size_t)half * D * P;
     const bool active = half == 0 || haveB;
     if constexpr (N <= 3 && KB == 2) {
         const int nfull = a.pitch / 64;
         const int rem = a.pitch - 64 * nfull;  // pitch is a multiple of 16: rem in {0, 16, 32, 48}
-        for (int p = 0; p < nfull; ++p) ggr_unit<N, D, 2, NT>(a, cset, MNN, tab_l, fm, 64 * p, sub, lineA, half, active);
+        for (int p = 0; p < nfull; ++p) ggr_unit<N, D, 2, NT>(a, cset, F, P, tab_l, 64 * p, sub, lineA, half, active);
         if (rem > 32)
-            ggr_unit<N, D, 2, NT>(a, cset, MNN, tab_l, fm, 64 * nfull, sub, lineA, half, active);
+            ggr_unit<N, D, 2, NT>(a, cset, F, P, tab_l, 64 * nfull, sub, lineA, half, active);
         else if (rem > 0)
-            ggr_unit<N, D, 1, NT>(a, cset, MNN, tab_l, fm, 64 * nfull, sub, lineA, half, active);
+            ggr_unit<N, D, 1, NT>(a, cset, F, P, tab_l, 64 * nfull, sub, lineA, half, active);
     } else {  // 4 bands: 64 accumulator doubles per node, one node per lane
-        for (int i0 = 0; i0 < a.pitch; i0 += 32) ggr_unit<N, D, 1, NT>(a, cset, MNN, tab_l, fm, i0, sub, lineA, half, active);
+        for (int i0 = 0; i0 < a.pitch; i0 += 32) ggr_unit<N, D, 1, NT>(a, cset, F, P, tab_l, i0, sub, lineA, half, active);
     }
 }
 
-constexpr int GGR_MAX_T = 4;  // coefficient elements per lane and set: M n n <= 256
+constexpr int GGR_MAX_P = 256;  // packed elements per set
 
-// ---- FUSE: block = (parent, segment of the i2 range); level-2 sets of the parent in LDS
+// ---- FUSE: block = (parent, segment of the i2 range); packed level-2 sets of the parent in LDS
 template <int N, int D, bool NT, int KB>
-__global__ __launch_bounds__(256, 2) void ggr_build_fused_kernel(GgrBuildArgs a) {
+__global__ __launch_bounds__(256, (KB == 1 && N <= 3) ? 3 : 2) void ggr_build_fused_kernel(GgrBuildArgs a) {
     static_assert(D >= 2, "the fused build contracts variable 2 in the kernel");
-    extern __shared__ double2 lds_g[];  // [D-1][M2][MNN] level-2 sets | [npt] phase table | [4 waves][2 lines][D][MNN]
+    extern __shared__ double2 lds_g[];  // [D-1][M2][P] packed level-2 sets | [npt] phase table | [4 waves][2 lines][D][P]
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-    const int MNN = a.M * N * N;
-    const int L2 = a.M2 * MNN;
+    const int F = (a.M - 1) / 2;
+    const int P = Pk<N>::size(F);
+    const int L2 = a.M2 * P;
     double2* const c2s = lds_g;
     double2* const tab_l = c2s + (size_t)(D - 1) * L2;
-    double2* const wbuf = tab_l + a.npt + (size_t)wave * 2 * D * MNN;
-    int fm = a.first % a.npt;
-    if (fm < 0) fm += a.npt;
+    double2* const wbuf = tab_l + a.npt + (size_t)wave * 2 * D * P;
     int fm2 = a.first2 % a.npt;
     if (fm2 < 0) fm2 += a.npt;
-    const int64_t parent = blockIdx.x / a.nseg;
-    const int seg = blockIdx.x - (int)(parent * a.nseg);
-    {
-        const double2* __restrict__ s0 = a.src2[0] + parent * (int64_t)L2;
-        for (int i = threadIdx.x; i < L2; i += 256) c2s[i] = s0[i];
-        if constexpr (D == 3) {
-            const double2* __restrict__ s1 = a.src2[1] + parent * (int64_t)L2;
-            for (int i = threadIdx.x; i < L2; i += 256) c2s[L2 + i] = s1[i];
-        }
-        for (int i = threadIdx.x; i < a.npt; i += 256) tab_l[i] = a.tab[i];
+    for (int i = threadIdx.x; i < a.npt; i += 256) tab_l[i] = a.tab[i];
+    // This block's share of the global list of line pairs (parent-major), contiguous and of equal length for every
+    // block: one round of resident blocks, no tail (segments of a parent dealt to 3 rounds of blocks left the SIMDs
+    // with 1.5 of their 2 waves on average).  A share spans one or two parents; the waves take its pairs round-robin.
+    const int ppp = (a.gcnt + 1) / 2;  // pairs per parent
+    const int64_t npairs_all = (a.nlines / a.gcnt) * ppp;
+    int64_t g0 = (npairs_all * blockIdx.x) / gridDim.x, g1 = (npairs_all * (blockIdx.x + 1)) / gridDim.x;
+    if (a.nseg > 0) {  // block = (parent, segment of its pairs): many more blocks than resident slots, dealt by the dispatcher
+        const int64_t par = blockIdx.x / a.nseg;
+        const int seg = blockIdx.x - (int)(par * a.nseg);
+        g0 = par * ppp + ((int64_t)ppp * seg) / a.nseg;
+        g1 = par * ppp + ((int64_t)ppp * (seg + 1)) / a.nseg;
     }
-    __syncthreads();
-    // pairs of lines of this block's segment
-    const int npairs_all = (a.gcnt + 1) / 2;
-    const int plo = (int)(((int64_t)npairs_all * seg) / a.nseg);
-    const int phi = (int)(((int64_t)npairs_all * (seg + 1)) / a.nseg);
-    const int nT = (MNN + 63) / 64;
-    // level-1 sets of grid index i2 into dst[set][idx]: set 0 plain, set 1 derivative on variable 2, set 2 from c2s'
-    // level-1 sets of grid indices i2 (line A) and i2 + dB (line B) into dst[line][set][idx]: set 0 plain, set 1 derivative
-    // on variable 2, set 2 from c2s'.  Both lines share every coefficient read; 4 D independent accumulation chains.
+    const int nT = (P + 63) / 64;
+    // packed level-1 sets of grid indices i2 (line A) and i2 + dB (line B) into dst[line][set][e]: set 0 plain, set 1
+    // derivative on variable 2, set 2 from c2s'.  Both lines share every coefficient read.
     auto contract_pair = [&](int i2, int dB, double2* dst) {
         const unsigned ipA0 = (unsigned)(((unsigned)fm2 * (unsigned)i2) % (unsigned)a.npt);
         const unsigned ipB0 = (unsigned)(((unsigned)fm2 * (unsigned)(i2 + dB)) % (unsigned)a.npt);
         for (int t = 0; t < nT; ++t) {
             const int idx = lane + 64 * t;
-            const int ii = idx < MNN ? idx : MNN - 1;
+            const int ii = idx < P ? idx : P - 1;
             double acr[2][D], aci[2][D];
 #pragma unroll
             for (int l = 0; l < 2; ++l) {
@@ -375,9 +482,9 @@ __global__ __launch_bounds__(256, 2) void ggr_build_fused_kernel(GgrBuildArgs a)
             const double2* __restrict__ row = c2s + ii;
             for (int m2 = 0; m2 < a.M2; ++m2) {
                 const double f = TWO_PI * (double)(a.first2 + m2);
-                const double2 c = row[(size_t)m2 * MNN];
+                const double2 c = row[(size_t)m2 * P];
                 double2 c3 = c;
-                if constexpr (D == 3) c3 = row[(size_t)L2 + (size_t)m2 * MNN];
+                if constexpr (D == 3) c3 = row[(size_t)L2 + (size_t)m2 * P];
 #pragma unroll
                 for (int l = 0; l < 2; ++l) {
                     const double2 ph = tab_l[ip[l]];
@@ -400,36 +507,67 @@ __global__ __launch_bounds__(256, 2) void ggr_build_fused_kernel(GgrBuildArgs a)
                     if (ip[l] >= (unsigned)a.npt) ip[l] -= (unsigned)a.npt;
                 }
             }
-            if (idx < MNN) {
+            if (idx < P) {
 #pragma unroll
                 for (int l = 0; l < 2; ++l) {
 #pragma unroll
-                    for (int s = 0; s < D; ++s) dst[(l * D + s) * MNN + idx] = make_double2(acr[l][s], aci[l][s]);
+                    for (int s = 0; s < D; ++s) dst[(l * D + s) * P + idx] = make_double2(acr[l][s], aci[l][s]);
                 }
             }
         }
     };
-    for (int p = plo + wave; p < phi; p += 4) {
-        const int i2 = a.gbeg + 2 * p;
-        const bool haveB = 2 * p + 1 < a.gcnt;
-        wave_lds_fence();  // the previous pair's reads of wbuf are done
-        if (!(a.dbg & 4)) contract_pair(i2, haveB ? 1 : 0, wbuf);
-        wave_lds_fence();
-        const int64_t lineA = parent * a.gcnt + 2 * p;
-        ggr_line_pair<N, D, NT, KB>(a, wbuf, MNN, tab_l, fm, lane, lineA, haveB);
+    int64_t g = g0;
+    while (g < g1) {
+        const int64_t parent = g / ppp;
+        const int64_t gend = g1 < (parent + 1) * ppp ? g1 : (parent + 1) * ppp;
+        __syncthreads();  // every wave is done with the previous parent's sets (and the phase table is in place)
+        {
+            const double2* __restrict__ src = a.src2[0] + parent * (int64_t)(D - 1) * L2;  // packed by ggr_pack2_kernel
+            for (int i = threadIdx.x; i < (D - 1) * L2; i += 256) c2s[i] = src[i];
+        }
+        __syncthreads();
+        for (int64_t gg = g + ((wave - (int)(g - g0)) & 3); gg < gend; gg += 4) {  // pair j of the share goes to wave j mod 4
+            const int p = (int)(gg - parent * ppp);
+            const int i2 = a.gbeg + 2 * p;
+            const bool haveB = 2 * p + 1 < a.gcnt;
+            wave_lds_fence();  // the previous pair's reads of wbuf are done
+            if (!(a.dbg & 4)) contract_pair(i2, haveB ? 1 : 0, wbuf);
+            wave_lds_fence();
+            const int64_t lineA = parent * a.gcnt + 2 * p;
+            ggr_line_pair<N, D, NT, KB>(a, wbuf, F, P, tab_l, lane, lineA, haveB);
+        }
+        g = gend;
     }
 }
 
-// ---- !FUSE: level-1 families from HBM; pairs of consecutive lines, grid-strided
+// packed level-2 sets for the fused kernel: out[parent][s][m2][e], s < nsrc = D - 1 (plain, derivative on variable 3)
+template <int N>
+__global__ __launch_bounds__(256) void ggr_pack2_kernel(const double2* __restrict__ src0, const double2* __restrict__ src1, int nsrc,
+                                                        int M, int M2, double2* __restrict__ out) {
+    const int F = (M - 1) / 2;
+    const int P = Pk<N>::size(F);
+    const int L2 = M2 * P;
+    const int64_t parent = blockIdx.x;
+    const int64_t full2 = (int64_t)M2 * M * (N * N);
+    for (int s = 0; s < nsrc; ++s) {
+        const double2* __restrict__ g = (s == 0 ? src0 : src1) + parent * full2;
+        for (int i = threadIdx.x; i < L2; i += 256) {
+            const int m2 = i / P, e = i - m2 * P;
+            out[(parent * nsrc + s) * L2 + i] = pk_from_full<N>(g + (int64_t)m2 * M * (N * N), F, e);
+        }
+    }
+}
+
+// ---- !FUSE: level-1 families from HBM, packed on their way into LDS; pairs of consecutive lines, grid-strided
 template <int N, int D, bool NT, int KB>
-__global__ __launch_bounds__(256, KB == 1 ? 3 : 2) void ggr_build_lines_kernel(GgrBuildArgs a) {
-    extern __shared__ double2 lds_g[];  // [npt] phase table | [4 waves][2 lines][D][MNN]
+__global__ __launch_bounds__(256, 2) void ggr_build_lines_kernel(GgrBuildArgs a) {
+    extern __shared__ double2 lds_g[];  // [npt] phase table | [4 waves][2 lines][D][P]
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int F = (a.M - 1) / 2;
+    const int P = Pk<N>::size(F);
     const int MNN = a.M * N * N;
     double2* const tab_l = lds_g;
-    double2* const wbuf = tab_l + a.npt + (size_t)wave * 2 * D * MNN;
-    int fm = a.first % a.npt;
-    if (fm < 0) fm += a.npt;
+    double2* const wbuf = tab_l + a.npt + (size_t)wave * 2 * D * P;
     for (int i = threadIdx.x; i < a.npt; i += 256) tab_l[i] = a.tab[i];
     __syncthreads();
     const int64_t npairs = (a.nlines + 1) / 2;
@@ -443,17 +581,17 @@ __global__ __launch_bounds__(256, KB == 1 ? 3 : 2) void ggr_build_lines_kernel(G
 #pragma unroll
             for (int s = 0; s < D; ++s) {
                 const double2* __restrict__ src = a.src[s] + line * MNN;
-                double2* dst = wbuf + (size_t)(hb * D + s) * MNN;
-                for (int idx = lane; idx < MNN; idx += 64) dst[idx] = src[idx];
+                double2* dst = wbuf + (size_t)(hb * D + s) * P;
+                for (int e = lane; e < P; e += 64) dst[e] = pk_from_full<N>(src, F, e);
             }
         }
         wave_lds_fence();
-        ggr_line_pair<N, D, NT, KB>(a, wbuf, MNN, tab_l, fm, lane, lineA, haveB);
+        ggr_line_pair<N, D, NT, KB>(a, wbuf, F, P, tab_l, lane, lineA, haveB);
     }
 }
 
 // ---- irregular node lists (symmetric rules): one lane per node, level-1 sets through the constant address space
-// (scalar loads wherever a wave's nodes share their set).
+// (scalar loads wherever a wave's nodes share their set); +f and -f folded as above.
 struct cpod {
     double x, y;
 };
@@ -466,75 +604,71 @@ template <int N, int D>
 __global__ __launch_bounds__(256) void ggr_build_nodes_kernel(GgrBuildArgs a) {
     const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (k >= a.nk) return;
-    const int MNN = a.M * N * N;
+    constexpr int NN = N * N;
+    const int MNN = a.M * NN;
+    const int F = (a.M - 1) / 2;
     const int64_t slot = a.parents ? a.parents[k] : 0;
-    int fm = a.first % a.npt;
-    if (fm < 0) fm += a.npt;
-    const int i1 = a.gi[k];
-    const double2 z = a.tab[i1];
-    const double2 w0 = a.tab[(int)(((int64_t)fm * i1) % a.npt)];
+    const double2 z = a.tab[a.gi[k]];
+    cp4_t cs[3] = {as_c4(a.src[0] + slot * MNN), as_c4(a.src[D >= 2 ? 1 : 0] + slot * MNN), as_c4(a.src[D >= 3 ? 2 : 0] + slot * MNN)};
     CMat<N> A[D + 1];
 #pragma unroll
-    for (int s = 0; s <= D; ++s) {
+    for (int bb = 0; bb < N; ++bb) {
 #pragma unroll
-        for (int bb = 0; bb < N; ++bb) {
+        for (int aa = 0; aa <= bb; ++aa) {
 #pragma unroll
-            for (int aa = 0; aa <= bb; ++aa) {
-                A[s].re[aa][bb] = 0.0;
-                A[s].im[aa][bb] = 0.0;
+            for (int s = 0; s < D; ++s) {
+                const int mat = s == 0 ? 0 : s + 1;
+                A[mat].re[aa][bb] = cs[s][F * NN + aa + N * bb].x;
+                A[mat].im[aa][bb] = cs[s][F * NN + aa + N * bb].y;
             }
+            A[1].re[aa][bb] = 0.0;
+            A[1].im[aa][bb] = 0.0;
         }
     }
-    double pr = w0.x, pi = w0.y;
-    cp4_t c0 = as_c4(a.src[0] + slot * MNN);
-    cp4_t c1 = as_c4(a.src[D >= 2 ? 1 : 0] + slot * MNN);
-    cp4_t c2 = as_c4(a.src[D >= 3 ? 2 : 0] + slot * MNN);
-    for (int m = 0; m < a.M; ++m) {
-        const double f = TWO_PI * (double)(a.first + m);
-        const double qr = -f * pi, qi = f * pr;
-#pragma unroll
-        for (int bb = 0; bb < N; ++bb) {
-#pragma unroll
-            for (int aa = 0; aa <= bb; ++aa) {
-                const int o = m * (N * N) + aa + N * bb;
-                const double cx = c0[o].x, cy = c0[o].y;
-                A[0].re[aa][bb] = fma(cx, pr, A[0].re[aa][bb]);
-                A[0].re[aa][bb] = fma(-cy, pi, A[0].re[aa][bb]);
-                A[1].re[aa][bb] = fma(cx, qr, A[1].re[aa][bb]);
-                A[1].re[aa][bb] = fma(-cy, qi, A[1].re[aa][bb]);
-                if (aa != bb) {
-                    A[0].im[aa][bb] = fma(cx, pi, A[0].im[aa][bb]);
-                    A[0].im[aa][bb] = fma(cy, pr, A[0].im[aa][bb]);
-                    A[1].im[aa][bb] = fma(cx, qi, A[1].im[aa][bb]);
-                    A[1].im[aa][bb] = fma(cy, qr, A[1].im[aa][bb]);
-                }
-                if constexpr (D >= 2) {
-                    const double sx = c1[o].x, sy = c1[o].y;
-                    A[2].re[aa][bb] = fma(sx, pr, A[2].re[aa][bb]);
-                    A[2].re[aa][bb] = fma(-sy, pi, A[2].re[aa][bb]);
-                    if (aa != bb) {
-                        A[2].im[aa][bb] = fma(sx, pi, A[2].im[aa][bb]);
-                        A[2].im[aa][bb] = fma(sy, pr, A[2].im[aa][bb]);
-                    }
-                }
-                if constexpr (D >= 3) {
-                    const double sx = c2[o].x, sy = c2[o].y;
-                    A[3].re[aa][bb] = fma(sx, pr, A[3].re[aa][bb]);
-                    A[3].re[aa][bb] = fma(-sy, pi, A[3].re[aa][bb]);
-                    if (aa != bb) {
-                        A[3].im[aa][bb] = fma(sx, pi, A[3].im[aa][bb]);
-                        A[3].im[aa][bb] = fma(sy, pr, A[3].im[aa][bb]);
-                    }
-                }
-            }
-        }
-        const double nr = pr * z.x - pi * z.y;
-        const double ni = pr * z.y + pi * z.x;
+    double pr = 1.0, pi = 0.0;
+    for (int f = 1; f <= F; ++f) {
+        const double nr = pr * z.x - pi * z.y, ni = pr * z.y + pi * z.x;
         pr = nr;
         pi = ni;
+        const double tf = TWO_PI * (double)f;
+        const double qr = -tf * pi, qi = tf * pr;
+#pragma unroll
+        for (int s = 0; s < D; ++s) {
+            const int mat = s == 0 ? 0 : s + 1;
+            cp4_t cf = cs[s] + (F + f) * NN;
+#pragma unroll
+            for (int aa = 0; aa < N; ++aa) {
+                const double dx = 2.0 * cf[aa + N * aa].x, dy = 2.0 * cf[aa + N * aa].y;
+                A[mat].re[aa][aa] = fma(dx, pr, A[mat].re[aa][aa]);
+                A[mat].re[aa][aa] = fma(-dy, pi, A[mat].re[aa][aa]);
+                if (s == 0) {
+                    A[1].re[aa][aa] = fma(dx, qr, A[1].re[aa][aa]);
+                    A[1].re[aa][aa] = fma(-dy, qi, A[1].re[aa][aa]);
+                }
+            }
+#pragma unroll
+            for (int bb = 1; bb < N; ++bb) {
+#pragma unroll
+                for (int aa = 0; aa < bb; ++aa) {
+                    const double ux = cf[aa + N * bb].x, uy = cf[aa + N * bb].y;
+                    const double vx = cf[bb + N * aa].x, vy = cf[bb + N * aa].y;
+                    const double sx = ux + vx, sy = uy + vy, tx = ux - vx, ty = uy - vy;
+                    A[mat].re[aa][bb] = fma(sx, pr, A[mat].re[aa][bb]);
+                    A[mat].re[aa][bb] = fma(-sy, pi, A[mat].re[aa][bb]);
+                    A[mat].im[aa][bb] = fma(tx, pi, A[mat].im[aa][bb]);
+                    A[mat].im[aa][bb] = fma(ty, pr, A[mat].im[aa][bb]);
+                    if (s == 0) {
+                        A[1].re[aa][bb] = fma(sx, qr, A[1].re[aa][bb]);
+                        A[1].re[aa][bb] = fma(-sy, qi, A[1].re[aa][bb]);
+                        A[1].im[aa][bb] = fma(tx, qi, A[1].im[aa][bb]);
+                        A[1].im[aa][bb] = fma(ty, qr, A[1].im[aa][bb]);
+                    }
+                }
+            }
+        }
     }
     double e[N], v[D][N];
-    ggr_node<N, D>(A, e, v);
+    if (ggr_node_fast<N, D>(a, A, e, v)) ggr_node_jacobi<N, D>(A, e, v);
     const int ll = a.E.line_len;
     const int64_t line = k / ll;
     const unsigned u = (unsigned)(k - line * ll);
@@ -551,24 +685,29 @@ __global__ __launch_bounds__(256) void ggr_build_nodes_kernel(GgrBuildArgs a) {
 
 }  // namespace
 
-// LDS bytes of the fused kernel; 0 when the case is not supported (then the line kernel or the unfused build runs)
+// LDS bytes of the kernels
+static size_t ggr_packed(int n, int M) { return (size_t)(n * (n + 1) / 2 + ((M - 1) / 2) * n * n); }
 static size_t ggr_fused_lds(int n, int d, int M, int M2, int npt) {
-    const size_t mnn = (size_t)M * n * n;
-    return sizeof(double2) * ((size_t)(d - 1) * M2 * mnn + (size_t)npt + 4 * 2 * (size_t)d * mnn);
+    const size_t P = ggr_packed(n, M);
+    return sizeof(double2) * ((size_t)(d - 1) * M2 * P + (size_t)npt + 4 * 2 * (size_t)d * P);
 }
 static size_t ggr_lines_lds(int n, int d, int M, int npt) {
-    const size_t mnn = (size_t)M * n * n;
-    return sizeof(double2) * ((size_t)npt + 4 * 2 * (size_t)d * mnn);
+    return sizeof(double2) * ((size_t)npt + 4 * 2 * (size_t)d * ggr_packed(n, M));
 }
 
 bool ggr_build_supported(int n, int d, int M, int npt, bool herm) {
-    static const bool off = [] { const char* e = getenv("ABZ_GGR_FUSED"); return e && e[0] == '0'; }();
-    if (off || !herm || n < 1 || n > 4 || d < 1 || d > 3 || npt >= 65536) return false;
-    return M * n * n <= 64 * GGR_MAX_T && ggr_lines_lds(n, d, M, npt) <= 64 * 1024;
+    const bool off = [] { const char* e = getenv("ABZ_GGR_FUSED"); return e && e[0] == '0'; }();  // per call: tests compare both builds
+    // Hermitian series have an odd number of symmetric frequencies per variable (detect_hermitian, api.cpp)
+    if (off || !herm || (M & 1) == 0 || n < 1 || n > 4 || d < 1 || d > 3 || npt >= 65536) return false;
+    return ggr_packed(n, M) <= (size_t)GGR_MAX_P && ggr_lines_lds(n, d, M, npt) <= 64 * 1024;
+}
+
+size_t ggr_build_pack2_elems(int n, int d, int M, int M2, int64_t nparents) {
+    return (size_t)nparents * (size_t)(d - 1) * (size_t)M2 * ggr_packed(n, M);
 }
 
 bool ggr_build_can_fuse(int n, int d, int M, int M2, int npt) {
-    static const bool off = [] { const char* e = getenv("ABZ_GGR_FUSE2"); return e && e[0] == '0'; }();
+    const bool off = [] { const char* e = getenv("ABZ_GGR_FUSE2"); return e && e[0] == '0'; }();  // per call
     // two blocks per CU must fit the 160 KB of LDS
     return !off && d >= 2 && ggr_fused_lds(n, d, M, M2, npt) <= 78 * 1024;
 }
@@ -596,6 +735,11 @@ int launch_ggr_build(abz_ctx* ctx, const GgrBuildSpec& gs) {
     a.nk = gs.nk;
     const int n = gs.n, d = gs.d;
     a.dbg = [] { const char* e = getenv("ABZ_GGR_DEBUG"); return e ? atoi(e) : 0; }();
+    {
+        const double cq[8] = {-0.008198810912827986, 0.03528472977563877, -0.09201052271579181, 0.33285803676124615,
+                              1.732059706718476, 1.0 / 3.0, 1.0 / 6.0, 1e-6};
+        for (int i = 0; i < 8; ++i) a.cq[i] = cq[i];
+    }
     const int kb = [] { const char* e = getenv("ABZ_GGR_KB"); return e ? atoi(e) : 2; }();  // nodes per lane in body passes
     ProfScope ps(ctx, ABZ_K_GGRBUILD);
     if (!gs.grid) {
@@ -628,13 +772,32 @@ int launch_ggr_build(abz_ctx* ctx, const GgrBuildSpec& gs) {
     if (gs.fuse) {
         const size_t lds = ggr_fused_lds(n, d, gs.M, gs.M2, gs.npt);
         const int64_t nparents = gs.nlines / std::max(gs.gcnt, 1);
-        // segments of a parent's line pairs: ~2 pairs per wave and block, at least enough blocks for two rounds of the chip
-        const int npairs = (gs.gcnt + 1) / 2;
-        static const int ppb = [] { const char* e = getenv("ABZ_GGR_PAIRS_PER_BLOCK"); return e ? atoi(e) : 8; }();
-        int64_t nseg = std::max<int64_t>(1, cdiv64(npairs, std::max(ppb, 1)));
-        nseg = std::min<int64_t>(nseg, npairs);
-        a.nseg = (int)nseg;
-        const unsigned blocks = (unsigned)(nparents * nseg);
+        // the level-2 sets, packed once per parent (the blocks then copy them into LDS as they are)
+        {
+            const unsigned pb = (unsigned)nparents;
+            switch (n) {
+                case 1: hipLaunchKernelGGL(ggr_pack2_kernel<1>, dim3(pb), dim3(256), 0, ctx->stream, gs.src2[0], gs.src2[1], d - 1, gs.M, gs.M2, gs.pack2); break;
+                case 2: hipLaunchKernelGGL(ggr_pack2_kernel<2>, dim3(pb), dim3(256), 0, ctx->stream, gs.src2[0], gs.src2[1], d - 1, gs.M, gs.M2, gs.pack2); break;
+                case 3: hipLaunchKernelGGL(ggr_pack2_kernel<3>, dim3(pb), dim3(256), 0, ctx->stream, gs.src2[0], gs.src2[1], d - 1, gs.M, gs.M2, gs.pack2); break;
+                default: hipLaunchKernelGGL(ggr_pack2_kernel<4>, dim3(pb), dim3(256), 0, ctx->stream, gs.src2[0], gs.src2[1], d - 1, gs.M, gs.M2, gs.pack2); break;
+            }
+            ABZ_HIP(hipGetLastError());
+            a.src2[0] = gs.pack2;
+            a.src2[1] = nullptr;
+        }
+        // one round of resident blocks, each with an equal contiguous share of the line pairs
+        const int64_t npairs_all = nparents * ((gs.gcnt + 1) / 2);
+        const int occ = (kb == 1 && n <= 3) ? 3 : 2;
+        const int per_cu = (int)std::max<size_t>(1, std::min<size_t>((size_t)occ, (160 * 1024) / lds));
+        const int bmul = [] { const char* e = getenv("ABZ_GGR_ROUNDS"); return e ? atoi(e) : 1; }();
+        unsigned blocks = (unsigned)std::max<int64_t>(1, std::min<int64_t>(npairs_all, (int64_t)256 * per_cu * std::max(bmul, 1)));
+        a.nseg = 0;
+        const int ppb = [] { const char* e = getenv("ABZ_GGR_PAIRS_PER_BLOCK"); return e ? atoi(e) : 8; }();  // 0: one round of equal shares
+        if (ppb > 0) {
+            const int ppp = (gs.gcnt + 1) / 2;
+            a.nseg = (int)std::max<int64_t>(1, std::min<int64_t>(cdiv64(ppp, ppb), ppp));
+            blocks = (unsigned)(nparents * a.nseg);
+        }
 #define GF(NN, DD)                                                                                                        \
     if (kb == 1 && a.nt)                                                                                                  \
         hipLaunchKernelGGL((ggr_build_fused_kernel<NN, DD, true, 1>), dim3(blocks), dim3(256), lds, ctx->stream, a);     \
@@ -906,7 +1069,7 @@ __global__ void final_reduce_real_kernel(const double* __restrict__ partial, int
 
 int launch_ggr(abz_ctx* ctx, int n, int d, int npt, PlaneView E, PlaneView V, const double* w, int64_t nk,
                const double* Es_host, int nE, double* out_host) {
-    static const bool windowed = [] { const char* e = getenv("ABZ_GGR_SCAN"); return !(e && e[0] == '0'); }();
+    const bool windowed = [] { const char* e = getenv("ABZ_GGR_SCAN"); return !(e && e[0] == '0'); }();  // per call
     const int brows = n > 4 ? n : 1;  // n > 4: one block row per band
     GgrArgs a;
     a.E = E;

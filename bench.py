@@ -599,6 +599,59 @@ def extras(a, abz, L, s, ctx, out, nk):
                                             "nodes_per_sec": sol.numevals / dt}
         except Exception as e:
             out["iai_example"] = {"error": str(e)}
+    # GGR (north star: "dos_ggr.jl's eigenvalue sweep"; ref src/dos_ggr.jl:14-65): the fused eigenvalue + velocity build on the
+    # bench grid and the scan of 256 energies over it, each with its own HIP-event kernel time and roofline fraction
+    try:
+        dev0 = s.device()
+        n, d = s.n, s.d
+        rg = abz.DeviceRule(dev0, a.npt, None, L.WANT_EIG | L.WANT_VEL)
+        for _ in range(5):
+            rg.rebuild()
+        ctx.sync()
+        ids = [L.K_CONTRACT, L.K_EVAL, L.K_EIG, L.K_GGRBUILD]
+        ctx.prof_enable(True, kernels=ids)
+        ctx.prof_reset()
+        reps = 50
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            rg.rebuild()
+        ctx.sync()
+        dt = (time.perf_counter() - t0) / reps
+        parts = {k: ctx.prof_read(k) for k in ids}
+        ctx.prof_enable(False)
+        kb_ms = parts[L.K_GGRBUILD][0] / max(parts[L.K_GGRBUILD][1], 1)
+        bytes_k = 8 * n * (1 + d)  # e and v out per k-point; + 8 (weight) only on symmetric rules
+        g = {"npt": a.npt, "kpoints": nk, "build_seconds": dt, "build_kpoints_per_sec": nk / dt,
+             "build_kernel_ms": kb_ms, "build_launches_per_rebuild": {int(k): parts[k][1] // reps for k in ids if parts[k][1]},
+             "build_contract_ms": parts[L.K_CONTRACT][0] / reps,
+             "build_algorithmic_bytes_per_kpoint": bytes_k,
+             "build_roofline": {"bound": "hbm (write) / f64 VALU", "achieved_GBs": nk * bytes_k / (kb_ms * 1e-3) / 1e9, "peak_GBs": HBM_PEAK_GBS,
+                                "frac": nk * bytes_k / (kb_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                "note": "VALU-bound in practice (profiles/r03_ggr_pmc_summary.json: ~1000 f64 instructions per k-point, "
+                                        "stores overlap); counter traffic 1.05x algorithmic"},
+             "unfused_round2_build_seconds": 1.37e-3}
+        Es = np.linspace(10.0, 15.0, 256)
+        rg.ggr(Es)
+        ctx.prof_enable(True, kernels=[L.K_GGR])
+        ctx.prof_reset()
+        t0 = time.perf_counter()
+        for _ in range(20):
+            dos = rg.ggr(Es)
+        dts = (time.perf_counter() - t0) / 20
+        ms, nl = ctx.prof_read(L.K_GGR)
+        ctx.prof_enable(False)
+        ks_ms = ms / 20
+        bytes_scan = 8 * n * (1 + d) + 8
+        g.update({"scan_energies": len(Es), "scan_seconds": dts, "scan_kE_per_sec": nk * len(Es) / dts, "scan_kernel_ms": ks_ms,
+                  "scan_algorithmic_bytes_per_kpoint": bytes_scan,
+                  "scan_roofline": {"bound": "hbm (read, one pass over the rule for all energies)",
+                                    "achieved_GBs": nk * bytes_scan / (ks_ms * 1e-3) / 1e9, "peak_GBs": HBM_PEAK_GBS,
+                                    "frac": nk * bytes_scan / (ks_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
+                  "all_pairs_round2_scan_seconds": 6.1e-3, "dos_mid": float(dos[128])})
+        rg.close()
+        out["ggr"] = g
+    except Exception as e:
+        out["ggr"] = {"error": str(e)}
     # configs 2 and 3 end to end (host loop + kernels + transfers; not the primary metric)
     try:
         cfg = {}

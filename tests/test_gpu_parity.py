@@ -1249,6 +1249,108 @@ def test_ggr_more_than_four_bands(abz):
         assert np.abs(u - ref).max() <= 1e-9 * max(1.0, np.abs(ref).max())
 
 
+def _ggr_rule_data(abz, s, npt, syms=None):
+    from autobzcore.jl_amd import _lib as L
+    rule = abz.DeviceRule(s.device(), npt, syms, L.WANT_EIG | L.WANT_VEL)
+    out = rule.export(x=False, w=False, eig=True, vel=True)
+    return rule, out["eig"], out["vel"]
+
+
+@pytest.mark.parametrize("d,n", [(1, 1), (1, 3), (2, 2), (2, 3), (2, 4), (3, 1), (3, 2), (3, 3), (3, 4)])
+def test_fused_ggr_build_matches_oracle_and_unfused_build(abz, d, n, monkeypatch):
+    """The one-kernel GGR build (kernels_ggr.hip: packed Hermitian sets, projector velocities) against the oracle's
+    get_ggr_data (ref: src/dos_ggr.jl:14-44) and against the unfused round-2 build, for every band count and dimension it
+    covers, grids that exercise whole passes, one-node-per-lane tails, odd line counts and the padding columns; also the
+    variant that reads level-1 families instead of contracting in the kernel (ABZ_GGR_FUSE2=0)."""
+    rng = np.random.default_rng(100 * d + n)
+    dims = (5, 7, 3)[:d]
+    c, first = rand_series(rng, dims, n, hermitian=True)
+    period = (1.0, 2.0, 0.5)[:d]
+    s, so = both(abz, c, first, period, ndim=d)
+    for npt in ((7, 33, 70, 100, 150) if d < 3 else (6, 33, 70)):
+        w, e, v = orc.get_ggr_data(so, npt, None)
+        scale, vscale = np.abs(e).max(), np.abs(v).max()
+        ok = np.min(np.diff(e, axis=1), axis=1) > 1e-6 * scale if n > 1 else np.ones(len(e), dtype=bool)
+        assert ok.mean() > 0.99
+        got = {}
+        for name, env in (("fused", {}), ("lines", {"ABZ_GGR_FUSE2": "0"}), ("unfused", {"ABZ_GGR_FUSED": "0"})):
+            for k_, v_ in env.items():
+                monkeypatch.setenv(k_, v_)
+            rule, E, V = _ggr_rule_data(abz, s, npt)
+            rule.close()
+            for k_ in env:
+                monkeypatch.delenv(k_)
+            got[name] = (E, V)
+            assert np.abs(E - e).max() <= 1e-12 * scale, (name, npt)
+            assert np.abs(V[ok] - v[ok]).max() <= 1e-9 * vscale, (name, npt)
+            assert np.abs(V.sum(axis=2) - v.sum(axis=2)).max() <= 1e-10 * vscale * n, (name, npt)
+        assert np.abs(got["fused"][0] - got["unfused"][0]).max() <= 1e-12 * scale
+        assert np.abs(got["fused"][1][ok] - got["unfused"][1][ok]).max() <= 1e-9 * vscale
+        assert np.array_equal(got["fused"][0], got["lines"][0]) or np.abs(got["fused"][0] - got["lines"][0]).max() <= 1e-13 * scale
+
+
+def test_fused_ggr_build_degenerate_and_clustered_bands(abz):
+    """Eigenvalues of the fused build to 1e-12 ||H|| for exactly / nearly degenerate 3-band spectra (constant series:
+    H(k) = c[0], velocities zero), and velocities that stay finite and sum to tr dH/dk_j on a model with symmetry-enforced
+    degeneracies (the SVO bands along the cube axes and diagonals)."""
+    rng = np.random.default_rng(7)
+    for gap in (0.0, 1e-14, 1e-10, 1e-7, 1e-5, 1e-4, 2e-3, 1e-2, 1.0):
+        for trip in range(4):
+            q, _ = np.linalg.qr(rng.standard_normal((3, 3)) + 1j * rng.standard_normal((3, 3)))
+            base = rng.uniform(-5, 5)
+            for ev in ([base, base + gap, base + 3.0], [base - 2.0, base, base + gap], [base, base + gap, base + 2 * gap]):
+                A = (q * np.array(ev)) @ q.conj().T
+                A = 0.5 * (A + A.conj().T)
+                s = abz.FourierSeries(A.reshape(1, 1, 3, 3), period=1.0, first=(0, 0), ndim=2)
+                rule, E, V = _ggr_rule_data(abz, s, 4)
+                rule.close()
+                ref = np.linalg.eigvalsh(A)
+                # 1e-12 ||H|| like every eigenvalue of the suite: roots of the characteristic cubic carry eps ||B||^3 / |p'(w)|,
+                # pairs closer than ~2e-3 of the scale go through the Jacobi iteration instead
+                assert np.abs(E - ref).max() <= 1e-12 * max(1.0, np.abs(ref).max()), (gap, ev)
+                assert np.abs(V).max() == 0.0
+    s = abz.load_w90_series(os.path.join(GOLD, "svo_hr.dat.gz"))
+    so = orc.FourierSeries(s.c, period=1.0, first=s.first, ndim=3)
+    rule, E, V = _ggr_rule_data(abz, s, 24)
+    rule.close()
+    w, e, v = orc.get_ggr_data(so, 24, None)
+    assert np.abs(E - e).max() < 1e-11
+    ok = np.min(np.diff(e, axis=1), axis=1) > 1e-6
+    assert 0.5 < ok.mean() < 1.0  # the grid does hit degenerate nodes
+    assert np.isfinite(V).all()
+    assert np.abs(V[ok] - v[ok]).max() < 1e-8
+    assert np.abs(V.sum(axis=2) - v.sum(axis=2)).max() < 1e-8
+
+
+def test_ggr_windowed_scan_equals_all_pairs_scan(abz, svo, monkeypatch):
+    """abz_rule_ggr: the windowed scan (each band's energy window, per-wave histograms) gives the sums of the all-pairs scan
+    (ABZ_GGR_SCAN=0) for unsorted energy lists with duplicates and values outside the band, beyond one 1024-energy chunk,
+    with symmetric-rule weights and for 1 / 2 / 3 dimensions.  ref: src/dos_ggr.jl:58-104."""
+    from autobzcore.jl_amd import _lib as L
+    s, _ = svo
+    rng = np.random.default_rng(3)
+    cases = [(s, 20, None), (s, 20, abz.load_bz(abz.CubicSymIBZ(), np.eye(3)).syms)]
+    for dd in (1, 2):
+        so = orc.tb_integer(dd)
+        cases.append((abz.FourierSeries(so.c, period=1.0, first=so.first, ndim=dd), 64, None))
+    for ser, npt, syms in cases:
+        rule = abz.DeviceRule(ser.device(), npt, syms, L.WANT_EIG | L.WANT_VEL)
+        E = rule.export(x=False, w=False, eig=True)["eig"]
+        lo, hi = E.min(), E.max()
+        for nE in (1, 7, 300, 2500):
+            Es = rng.uniform(lo - 0.3, hi + 0.3, size=nE)
+            if nE > 3:
+                Es[3] = Es[1]
+                Es[2] = lo - 10.0
+            a = rule.ggr(Es)
+            monkeypatch.setenv("ABZ_GGR_SCAN", "0")
+            b = rule.ggr(Es)
+            monkeypatch.delenv("ABZ_GGR_SCAN")
+            assert np.isfinite(b).all() and (nE < 300 or np.abs(b).max() > 0)
+            assert np.abs(a - b).max() <= 1e-12 * np.abs(b).max(), (npt, nE)
+        rule.close()
+
+
 def test_ggr_cache_invalidation(abz):
     """ref: test/dos.jl:114-132."""
     h = abz.FourierSeries(np.array([0.5, 0.0, 0.5]).reshape(3, 1, 1), period=1.0, offset=-2, ndim=1)
