@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cstdint>
 #include <cstdio>
 #include <string>
@@ -82,7 +83,7 @@ struct ProfSlot {
 // call marks the handle closed -- further API calls on it fail with ABZ_ERR_ARG while dependants still hold the
 // object -- and the memory goes when the last dependant is destroyed.
 struct abz_ctx {
-    int refs = 1;
+    std::atomic<int> refs{1};  // finalizers of a host language may release from another thread than the one that creates
     bool closed = false;
     int device = 0;
     hipStream_t stream = nullptr;
@@ -96,7 +97,7 @@ struct abz_ctx {
 };
 
 struct abz_series {
-    int refs = 1;
+    std::atomic<int> refs{1};
     bool closed = false;
     abz_ctx* ctx = nullptr;
     int d = 0, n = 0;

@@ -767,74 +767,81 @@ int IaiDriver::solve_level(int L, std::vector<Quad1D>& quads) {
                     });
                     return flat_enqueue(cn, buf);
                 };
-                const int64_t nchunks = (N + chunk - 1) / chunk;
-                for (int64_t ci = 0; ci <= nchunks; ++ci) {
-                    if (ci < nchunks) {
-                        const int64_t c0 = ci * chunk;
-                        int rc = describe_and_enqueue(c0, std::min(chunk, N - c0), (int)(ci & 1));
-                        if (rc) return rc;
-                    }
-                    if (ci > 0) {
-                        const int64_t c0 = (ci - 1) * chunk, cn = std::min(chunk, N - c0);
-                        redo_local.clear();
-                        int rc = flat_collect(cn, (int)((ci - 1) & 1), V + (size_t)(c0 * ncomp), NV + (size_t)c0, redo_local);
-                        if (rc) return rc;
-                        for (int64_t u : redo_local) redo_nodes.push_back(c0 + u);
-                    }
-                }
-                // integrals that overflowed the device segment store: their sets are contracted again (the pool has
-                // moved on) and the host loop integrates them
-                for (size_t r0 = 0; r0 < redo_nodes.size(); r0 += (size_t)chunk) {
-                    const int64_t rn = (int64_t)std::min<size_t>((size_t)chunk, redo_nodes.size() - r0);
-                    std::vector<int64_t> rp((size_t)rn);
-                    std::vector<double> rx((size_t)rn);
-                    kids.resize((size_t)rn);
-                    for (int64_t u = 0; u < rn; ++u) {
-                        const int64_t tn = redo_nodes[r0 + (size_t)u];
-                        const Quad1D& q = quads[Q[(size_t)tn]];
-                        Quad1D& k = kids[(size_t)u];
-                        const double x = X[(size_t)tn];
-                        rp[(size_t)u] = P[(size_t)tn];
-                        rx[(size_t)u] = x;
-                        k.slot = u;
-                        k.sweep = q.sweep;
-                        k.root = q.root;
-                        k.tail[0] = x;
-                        for (int j = 1; j < ABZ_MAX_DIM; ++j) k.tail[j] = q.tail[j - 1];
-                        k.lims = q.lims.fix(L, x);
-                        double lo1, hi1;
-                        if (!k.lims.range(1, lo1, hi1)) {
-                            std::vector<double> sg;
-                            k.lims.segs(1, sg);
-                            lo1 = sg.front();
-                            hi1 = sg.back();
+                // This rank's share.  In a sharded solve a failure here (a HIP error, out of memory) must not return before
+                // the exchange below: the other ranks would wait in the collective for ever.  The status travels with the data.
+                auto local_work = [&]() -> int {
+                    const int64_t nchunks = (N + chunk - 1) / chunk;
+                    for (int64_t ci = 0; ci <= nchunks; ++ci) {
+                        if (ci < nchunks) {
+                            const int64_t c0 = ci * chunk;
+                            int rc = describe_and_enqueue(c0, std::min(chunk, N - c0), (int)(ci & 1));
+                            if (rc) return rc;
                         }
-                        k.has_atol = q.has_atol;
-                        k.atol = q.has_atol ? q.atol / (hi1 - lo1) : 0.0;
+                        if (ci > 0) {
+                            const int64_t c0 = (ci - 1) * chunk, cn = std::min(chunk, N - c0);
+                            redo_local.clear();
+                            int rc = flat_collect(cn, (int)((ci - 1) & 1), V + (size_t)(c0 * ncomp), NV + (size_t)c0, redo_local);
+                            if (rc) return rc;
+                            for (int64_t u : redo_local) redo_nodes.push_back(c0 + u);
+                        }
                     }
-                    s->iai_used[L - 1] = 0;
-                    int rc = contract_nodes(L, rn, 0, 0, rp.data(), rx.data());
-                    if (rc) return rc;
-                    std::vector<int64_t> keep_par;
-                    std::vector<double> keep_x;
-                    std::vector<uint32_t> keep_q;
-                    keep_par.swap(h_parents);
-                    keep_x.swap(h_x);
-                    keep_q.swap(node_q);
-                    const bool keep = device_inner;
-                    device_inner = false;
-                    rc = solve_level(1, kids);
-                    device_inner = keep;
-                    h_parents.swap(keep_par);
-                    h_x.swap(keep_x);
-                    node_q.swap(keep_q);
-                    if (rc) return rc;
-                    for (int64_t u = 0; u < rn; ++u) {
-                        const int64_t tn = redo_nodes[r0 + (size_t)u];
-                        for (int c = 0; c < ncomp; ++c) V[(size_t)(tn * ncomp + c)] = kids[(size_t)u].I[(size_t)c];
-                        NV[(size_t)tn] = kids[(size_t)u].fevals;
+                    // integrals that overflowed the device segment store: their sets are contracted again (the pool has
+                    // moved on) and the host loop integrates them
+                    for (size_t r0 = 0; r0 < redo_nodes.size(); r0 += (size_t)chunk) {
+                        const int64_t rn = (int64_t)std::min<size_t>((size_t)chunk, redo_nodes.size() - r0);
+                        std::vector<int64_t> rp((size_t)rn);
+                        std::vector<double> rx((size_t)rn);
+                        kids.resize((size_t)rn);
+                        for (int64_t u = 0; u < rn; ++u) {
+                            const int64_t tn = redo_nodes[r0 + (size_t)u];
+                            const Quad1D& q = quads[Q[(size_t)tn]];
+                            Quad1D& k = kids[(size_t)u];
+                            const double x = X[(size_t)tn];
+                            rp[(size_t)u] = P[(size_t)tn];
+                            rx[(size_t)u] = x;
+                            k.slot = u;
+                            k.sweep = q.sweep;
+                            k.root = q.root;
+                            k.tail[0] = x;
+                            for (int j = 1; j < ABZ_MAX_DIM; ++j) k.tail[j] = q.tail[j - 1];
+                            k.lims = q.lims.fix(L, x);
+                            double lo1, hi1;
+                            if (!k.lims.range(1, lo1, hi1)) {
+                                std::vector<double> sg;
+                                k.lims.segs(1, sg);
+                                lo1 = sg.front();
+                                hi1 = sg.back();
+                            }
+                            k.has_atol = q.has_atol;
+                            k.atol = q.has_atol ? q.atol / (hi1 - lo1) : 0.0;
+                        }
+                        s->iai_used[L - 1] = 0;
+                        int rc = contract_nodes(L, rn, 0, 0, rp.data(), rx.data());
+                        if (rc) return rc;
+                        std::vector<int64_t> keep_par;
+                        std::vector<double> keep_x;
+                        std::vector<uint32_t> keep_q;
+                        keep_par.swap(h_parents);
+                        keep_x.swap(h_x);
+                        keep_q.swap(node_q);
+                        const bool keep = device_inner;
+                        device_inner = false;
+                        rc = solve_level(1, kids);
+                        device_inner = keep;
+                        h_parents.swap(keep_par);
+                        h_x.swap(keep_x);
+                        node_q.swap(keep_q);
+                        if (rc) return rc;
+                        for (int64_t u = 0; u < rn; ++u) {
+                            const int64_t tn = redo_nodes[r0 + (size_t)u];
+                            for (int c = 0; c < ncomp; ++c) V[(size_t)(tn * ncomp + c)] = kids[(size_t)u].I[(size_t)c];
+                            NV[(size_t)tn] = kids[(size_t)u].fevals;
+                        }
                     }
-                }
+                    return ABZ_OK;
+                };
+                const int local_rc = local_work();
+                if (!shard && local_rc) return local_rc;
                 if (shard) {
                     // all-gather: per rank `per` slots of (2 ncomp + 1) doubles -- values and evaluation counts of its nodes
                     int64_t per = 0;
@@ -844,30 +851,46 @@ int IaiDriver::solve_level(int L, std::vector<Quad1D>& quads) {
                         per = std::max(per, c);
                     }
                     const int rec = 2 * ncomp + 1;
-                    {   // pinned, so that a device-side all-gather (RCCL) stages it at PCIe rate
-                        int prc = pin_reserve(4, sizeof(double) * (size_t)(per * rec) * (size_t)W);
-                        if (prc) return prc;
+                    const int64_t seg = per * rec + 1;  // + one status word per rank: 0, or the ABZ_ERR_* code of its local failure
+                    // pinned, so that a device-side all-gather (RCCL) stages it at PCIe rate; pageable if pinning itself fails
+                    std::vector<double> ex_fallback;
+                    double* ex_buf;
+                    if (pin_reserve(4, sizeof(double) * (size_t)seg * (size_t)W) == ABZ_OK) {
+                        ex_buf = static_cast<double*>(s->iai_pin[4]);
+                    } else {
+                        ex_fallback.assign((size_t)seg * (size_t)W, 0.0);
+                        ex_buf = ex_fallback.data();
                     }
-                    double* const ex_buf = static_cast<double*>(s->iai_pin[4]);
-                    double* mine = ex_buf + (size_t)ex_rank * (size_t)(per * rec);
-                    for (int64_t i = N * rec; i < per * rec; ++i) mine[i] = 0.0;
-                    for (int64_t i = 0; i < N; ++i) {
-                        for (int c = 0; c < ncomp; ++c) {
-                            mine[i * rec + 2 * c] = V[(size_t)(i * ncomp + c)].real();
-                            mine[i * rec + 2 * c + 1] = V[(size_t)(i * ncomp + c)].imag();
+                    double* mine = ex_buf + (size_t)ex_rank * (size_t)seg;
+                    for (int64_t i = 0; i < seg; ++i) mine[i] = 0.0;
+                    if (local_rc == ABZ_OK) {
+                        for (int64_t i = 0; i < N; ++i) {
+                            for (int c = 0; c < ncomp; ++c) {
+                                mine[i * rec + 2 * c] = V[(size_t)(i * ncomp + c)].real();
+                                mine[i * rec + 2 * c + 1] = V[(size_t)(i * ncomp + c)].imag();
+                            }
+                            mine[i * rec + 2 * ncomp] = (double)NV[(size_t)i];  // exact below 2^53
                         }
-                        mine[i * rec + 2 * ncomp] = (double)NV[(size_t)i];  // exact below 2^53
                     }
+                    mine[per * rec] = (double)local_rc;
                     const auto te0 = std::chrono::steady_clock::now();
-                    if (ex_fn(ex_user, ex_buf, per * rec) != 0) {
+                    // the callback itself must fail on every rank or on none (it is the caller's collective)
+                    if (ex_fn(ex_user, ex_buf, seg) != 0) {
                         set_error("IAI: the exchange callback of a sharded solve failed");
                         return ABZ_ERR_HIP;
+                    }
+                    for (int rr = 0; rr < W; ++rr) {
+                        const int code = (int)ex_buf[(size_t)rr * (size_t)seg + (size_t)(per * rec)];
+                        if (code != 0) {  // every rank sees the same words and leaves with the same code
+                            if (rr != ex_rank) set_error("IAI: rank %d of the sharded solve failed with code %d", rr, code);
+                            return code;
+                        }
                     }
                     if (stats) st_exchange += std::chrono::duration<double>(std::chrono::steady_clock::now() - te0).count();
                     std::vector<int64_t> pos((size_t)W, 0);
                     for (int64_t tn = 0; tn < nn; ++tn) {
                         const int rr = owner(tn);
-                        const double* src = ex_buf + (size_t)rr * (size_t)(per * rec) + (size_t)(pos[(size_t)rr]++ * rec);
+                        const double* src = ex_buf + (size_t)rr * (size_t)seg + (size_t)(pos[(size_t)rr]++ * rec);
                         for (int c = 0; c < ncomp; ++c) vals[(size_t)(tn * ncomp + c)] = cd(src[2 * c], src[2 * c + 1]);
                         nev[(size_t)tn] = (int64_t)src[2 * ncomp];
                     }

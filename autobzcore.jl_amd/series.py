@@ -136,12 +136,20 @@ class DeviceSeries:
     def update(self, c=None):
         """Upload new coefficients of the same shape.  Every cached rule is stale from here on and is
         re-evaluated in place (abz_rule_rebuild, which also refreshes its Hermitian flag) before its next
-        use -- the reference rebuilds its rule from the current series on every solve."""
+        use -- the reference rebuilds its rule from the current series on every solve.  New coefficients
+        `c` replace the host series' array and go to EVERY live device copy of the series (the IAI sweep
+        lanes keep one per context): a copy left behind would integrate the old coefficients."""
         if c is not None:
             c = np.asarray(c, dtype=np.complex128)
             if c.shape != self.s.c.shape:
                 c = c.reshape(self.s.c.shape)
             self.s.c = np.array(c)
+            for dev in list(self.s._dev.values()):
+                if dev is not self and dev._h is not None:
+                    dev._upload()
+        self._upload()
+
+    def _upload(self):
         buf = np.ascontiguousarray(julia_coefficient_order(self.s.c, self.s.d).view(np.float64))
         L.check(L.lib().abz_series_update(self.h, buf.ctypes.data_as(L.c_f64p)))
         self.generation += 1

@@ -7,7 +7,11 @@
  * boundary.  Host arrays are owned by the caller (Julia must GC.@preserve them for the ccall);
  * device memory lives behind opaque handles owned by the library.  Handles are NOT thread-safe:
  * use one abz_ctx (one HIP stream) per host thread, like the reference gives every thread its own
- * workspace and deep-copied solver (src/fourier.jl:60-86, src/interfaces.jl:213).
+ * workspace and deep-copied solver (src/fourier.jl:60-86, src/interfaces.jl:213).  What MAY run
+ * concurrently: calls on handles of different contexts; and the abz_*_destroy calls on any handle
+ * beside other threads' work on the same context -- the context <- series <- rule reference counts
+ * are atomic, so a finalizer thread of a garbage-collected host language may release handles while
+ * another thread builds rules from the same series.  Everything else on one context is serial.
  *
  * Citations `ref:` are file:line into lxvm/AutoBZCore.jl v0.3.8 -- the reference interface each
  * entry point replaces.  The reference-side binding (Julia ccall shim) is in INTEGRATION.md and
@@ -246,6 +250,9 @@ int abz_iai_solve_many(abz_series* s, int lims_kind, const double* lim_a, const 
  * `buf` holds world * per_rank doubles, segment `rank` is filled on entry, all segments must be filled on return (RCCL
  * / MPI / gloo: the library does not link a communication layer).  Every rank returns the same value, bit-identical to the
  * single-GPU solve.  fn = NULL switches it off (world = 1 with a hook is allowed: a one-rank rehearsal of the transport).
+ * Errors: a rank whose share fails locally (HIP error, out of memory) still joins the collective -- every segment ends in a
+ * status word -- and ALL ranks return that rank's ABZ_ERR_* code after the exchange; nobody is left waiting.  `fn` itself
+ * must fail on every rank or on none (it is the caller's collective; return non-zero on all ranks to abort the solve).
  * Replaces: nothing in the reference (its parallelism is threads over parameters, src/interfaces.jl:210-222). */
 typedef int (*abz_exchange_fn)(void* user, double* buf, int64_t per_rank);
 int abz_iai_set_exchange(abz_series* s, abz_exchange_fn fn, void* user, int rank, int world);

@@ -467,6 +467,13 @@ def test_iai_sweep_lanes_change_nothing(abz, svo, monkeypatch):
     monkeypatch.setenv("ABZ_IAI_LANES", "1")
     b1, _ = sweep(sol6, om6)
     assert np.array_equal(b1, b2) and not np.array_equal(a1, b1)
+    # ... and so must coefficients handed to ONE device copy (DeviceSeries.update(c)): sweep, update, sweep
+    monkeypatch.setenv("ABZ_IAI_LANES", "2")
+    s6.device().update(s6.c * 3.0)
+    c2, _ = sweep(sol6, om6)
+    monkeypatch.setenv("ABZ_IAI_LANES", "1")
+    c1, _ = sweep(sol6, om6)
+    assert np.array_equal(c1, c2) and not np.array_equal(b1, c1)
 
 
 def test_kshard_partial_rules_sum_to_the_full_rule(abz, svo):
