@@ -42,6 +42,7 @@ PROTOTYPES = {
     "abz_rule_reduce_device": (C.c_int, [C.c_void_p, C.c_int, c_f64p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "abz_rule_values_ptr": (C.c_int, [C.c_void_p, c_vpp, c_i64p]),
     "abz_rule_ggr": (C.c_int, [C.c_void_p, c_f64p, C.c_int, c_f64p]),
+    "abz_mem_info": (C.c_int, [C.c_void_p, c_i64p]),
     "abz_symptr_rule": (C.c_int, [C.c_int, C.c_int, c_i32p, C.c_int, c_i64p, c_i32p, c_i64p]),
     "abz_symptr_rule_device": (C.c_int, [C.c_void_p, C.c_int, C.c_int, c_i32p, C.c_int, c_i64p, c_i32p, c_i64p]),
     "abz_contract_nodes": (C.c_int, [C.c_void_p, C.c_int, c_i64p, c_f64p, C.c_int64, c_i64p]),
@@ -151,6 +152,13 @@ class Context:
         """Record HIP events around the library's launches; `kernels`: iterable of K_* ids to restrict to."""
         mask = 0 if not on else (1 if kernels is None else sum(1 << (k + 1) for k in kernels))
         check(lib().abz_prof_enable(self.h, mask))
+
+    def mem_info(self):
+        """(live device bytes, cached device bytes, this context's scratch bytes, its pinned host bytes, live blocks):
+        the allocator's own bookkeeping (abz_mem_info)."""
+        info = (C.c_int64 * 5)()
+        check(lib().abz_mem_info(self.h, info))
+        return tuple(int(v) for v in info)
 
     def prof_reset(self):
         check(lib().abz_prof_reset(self.h))

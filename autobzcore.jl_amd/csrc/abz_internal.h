@@ -105,6 +105,7 @@ struct abz_series {
     int first[ABZ_MAX_DIM] = {0, 0, 0};
     double period[ABZ_MAX_DIM] = {1, 1, 1};
     bool hermitian = false;   // c(-R) == c(R)^dagger exactly  =>  H(k) Hermitian: half the Fourier work
+    size_t coef_cap = 0;
     double2* coef = nullptr;  // level d: [M_d]...[M_1][n*n] complex, i_1 fastest (Julia order)
     // pools of contracted coefficient sets: level j (1 <= j < d) holds (j)-dim series of
     // elems(j) = M_1*...*M_j*n*n complex numbers per slot.

@@ -1,5 +1,6 @@
 // Host side of the C ABI (include/abzhip.h): handles, rule construction plans, exports.
 #include <algorithm>
+#include <atomic>
 #include <cstdarg>
 #include <chrono>
 #include <cstring>
@@ -38,6 +39,8 @@ struct Block {
 std::mutex g_pool_mutex;
 std::vector<Block> g_pool;
 size_t g_pool_bytes = 0;
+std::atomic<int64_t> g_live_bytes{0};   // handed out by dev_alloc and not yet returned (abz_mem_info)
+std::atomic<int64_t> g_live_blocks{0};
 size_t pool_limit() {
     static const size_t lim = [] {
         const char* e = getenv("ABZ_POOL_MB");
@@ -73,6 +76,8 @@ int dev_alloc(void** out, size_t bytes, size_t* cap_out) {
             *out = g_pool[best].p;
             if (cap_out) *cap_out = g_pool[best].cap;
             g_pool_bytes -= g_pool[best].cap;
+            g_live_bytes += (int64_t)g_pool[best].cap;
+            g_live_blocks += 1;
             g_pool[best] = g_pool.back();
             g_pool.pop_back();
             return ABZ_OK;
@@ -91,11 +96,15 @@ int dev_alloc(void** out, size_t bytes, size_t* cap_out) {
         return ABZ_ERR_NOMEM;
     }
     if (cap_out) *cap_out = bytes;
+    g_live_bytes += (int64_t)bytes;
+    g_live_blocks += 1;
     return ABZ_OK;
 }
 
 void dev_free(void* p, size_t cap) {
     if (!p) return;
+    g_live_bytes -= (int64_t)cap;
+    g_live_blocks -= 1;
     int device = 0;
     (void)hipGetDevice(&device);  // = the owner's device: every destroy / release path selects it first (hipSetDevice)
     if (cap > 0 && cap <= pool_limit() / 4) {
@@ -460,7 +469,7 @@ static void series_release(abz_series* s) {
     for (auto& b : s->iai_io) b.release();
     for (auto& q : s->iai_pin)
         if (q) (void)hipHostFree(q);
-    if (s->coef) (void)hipFree(s->coef);
+    dev_free(s->coef, s->coef_cap);
     delete s;
     ctx_release(ctx);
 }
@@ -543,6 +552,23 @@ int abz_prof_enable(abz_ctx* ctx, int on) {
     return ABZ_OK;
 }
 
+int abz_mem_info(abz_ctx* ctx, int64_t* info) {
+    ABZ_REQUIRE(info, "abz_mem_info: null info");
+    {
+        std::lock_guard<std::mutex> lk(g_pool_mutex);
+        info[1] = (int64_t)g_pool_bytes;
+    }
+    info[0] = g_live_bytes.load();
+    info[2] = 0;
+    info[3] = 0;
+    info[4] = g_live_blocks.load();
+    if (ctx) {
+        for (const auto& b : ctx->scratch) info[2] += (int64_t)b.cap;
+        info[3] = (int64_t)ctx->pin_cap;
+    }
+    return ABZ_OK;
+}
+
 int abz_prof_reset(abz_ctx* ctx) {
     ABZ_REQUIRE(ctx, "null ctx");
     int rc = prof_collect(ctx);
@@ -588,15 +614,13 @@ int abz_series_create(abz_ctx* ctx, const double* coef_reim, int d, const int32_
         s->period[j] = period[j];
     }
     const size_t bytes = sizeof(double2) * (size_t)s->elems(d);
-    hipError_t e = hipMalloc((void**)&s->coef, bytes);
-    if (e != hipSuccess) {
+    if (dev_alloc((void**)&s->coef, bytes, &s->coef_cap)) {  // through the library's allocator: abz_mem_info sees it
         delete s;
-        set_error("hipMalloc(%zu) for coefficients failed: %s", bytes, hipGetErrorString(e));
         return ABZ_ERR_NOMEM;
     }
-    e = hipMemcpy(s->coef, coef_reim, bytes, hipMemcpyHostToDevice);
+    hipError_t e = hipMemcpy(s->coef, coef_reim, bytes, hipMemcpyHostToDevice);
     if (e != hipSuccess) {
-        (void)hipFree(s->coef);
+        dev_free(s->coef, s->coef_cap);
         delete s;
         set_error("coefficient upload failed: %s", hipGetErrorString(e));
         return ABZ_ERR_HIP;

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define ABZ_VERSION 200
+#define ABZ_VERSION 300
 
 /* status codes */
 #define ABZ_OK 0
@@ -84,6 +84,13 @@ typedef struct abz_rule abz_rule;     /* device-resident cached rule values (Fou
 #define ABZ_K_EIG 4        /* stand-alone Hermitian eigensolve                        */
 #define ABZ_K_GGRBUILD 5   /* fused GGR build: H, dH/dk, eig, velocities per node (get_ggr_data, ref src/dos_ggr.jl:14-44) */
 #define ABZ_K_COUNT 8
+
+/* The library's own view of its memory, for leak checks and capacity planning (no reference counterpart):
+ * info[0] device bytes handed out by its allocator and not yet returned (all contexts: coefficients, contracted
+ * sets, rule values, scratch), info[1] device bytes parked in its cache of freed blocks (ABZ_POOL_MB), info[2] the
+ * part of info[0] that is `ctx`'s grow-only scratch, info[3] `ctx`'s pinned host staging bytes, info[4] live blocks.
+ * ctx may be NULL (then info[2] = info[3] = 0). */
+int abz_mem_info(abz_ctx* ctx, int64_t* info);
 
 /* ---------------------------------------------------------------- library / context */
 const char* abz_last_error(void);

@@ -296,6 +296,13 @@ function ggr(h::FourierSeries{S,N}, bz::SymmetricBZ, Es::Vector{Float64}; npt=50
 end
 
 # ---------------------------------------------------------------- the rest of abzhip.h (housekeeping)
+"""(live device bytes, cached device bytes, this context's scratch bytes, its pinned host bytes, live blocks)"""
+function mem_info(; ctx::HIPContext=context())
+    info = zeros(Int64, 5)
+    check(ccall((:abz_mem_info, libabz), Cint, (Ptr{Cvoid}, Ptr{Int64}), ctx.h, info))
+    return Tuple(info)
+end
+
 version() = Int(ccall((:abz_version, libabz), Cint, ()))
 function device_count()
     n = Ref{Cint}(0)
@@ -380,7 +387,7 @@ function symptr_rule_device(npt, ::Val{d}, syms; ctx::HIPContext=context()) wher
 end
 
 "HIP-event timing of the library's own launches: `prof_enable(true)`, run, `prof_read(K_EVAL)` -> (ms, launches)."
-const K_CONTRACT, K_EVAL, K_REDUCE, K_GGR, K_EIG = Cint.(0:4)
+const K_CONTRACT, K_EVAL, K_REDUCE, K_GGR, K_EIG, K_GGRBUILD = Cint.(0:5)
 prof_enable(on::Bool=true; ctx::HIPContext=context()) =
     check(ccall((:abz_prof_enable, libabz), Cint, (Ptr{Cvoid}, Cint), ctx.h, on ? 1 : 0))
 prof_reset(; ctx::HIPContext=context()) = check(ccall((:abz_prof_reset, libabz), Cint, (Ptr{Cvoid},), ctx.h))

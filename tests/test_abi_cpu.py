@@ -26,7 +26,7 @@ def test_header_symbols_exported_and_bound(abz):
     h = _lib.lib()
     for name in declared:
         assert hasattr(h, name)
-    assert h.abz_version() == 200  # round 2: three more entry points, reference-counted handles
+    assert h.abz_version() == 300  # round 3: abz_mem_info, fused GGR build (ABZ_K_GGRBUILD), status word in the IAI exchange
 
 
 def test_fails_loudly_without_gpu(abz):
