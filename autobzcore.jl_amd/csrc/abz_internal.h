@@ -38,6 +38,8 @@ void set_error(const char* fmt, ...);
 // arrays took 15-27 ms; staged: < 2 ms).  Both calls return when the data has arrived.
 int stage_h2d(abz_ctx* ctx, void* dst_dev, const void* src_host, size_t bytes);
 int stage_d2h(abz_ctx* ctx, void* dst_host, const void* src_dev, size_t bytes);
+// the context's pinned, device-visible mailbox (ctx->mbox / mbox_dev / mbox_cap): small inputs and results of a call
+int mbox_reserve(abz_ctx* ctx);
 
 // caching device allocator (api.cpp): blocks freed with dev_free are reused by later dev_alloc calls
 int dev_alloc(void** out, size_t bytes, size_t* cap_out);
@@ -94,6 +96,11 @@ struct abz_ctx {
     abz::DevBuf scratch[6];  // phases, partials, staging...
     void* pin = nullptr;     // pinned host staging buffer (hipHostMalloc), grown on demand
     size_t pin_cap = 0;
+    // small pinned, device-visible mailbox: swept values go in through it without a synchronising pageable copy, and the
+    // last kernel of a reduction writes its few sums straight into it (zero copy) -- one stream synchronisation per call
+    void* mbox = nullptr;
+    void* mbox_dev = nullptr;  // the same memory as the device sees it
+    size_t mbox_cap = 0;
 };
 
 struct abz_series {
@@ -235,6 +242,8 @@ struct ReduceSpec {
     int n_sweep;
     double scale;
     double* out_dev = nullptr;  // device [n_sweep][ncomp][2]: leave the result in HBM, no host synchronisation
+    double2* out_map_dev = nullptr;         // host-io calls: device view of the pinned mailbox region the sums are written to ...
+    const double2* out_map_host = nullptr;  // ... and its host view (read after the stream synchronisation)
 };
 int integrand_ncomp(int integrand, int n, int d);
 // result: host out_reim [n_sweep][ncomp][2]

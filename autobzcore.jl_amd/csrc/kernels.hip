@@ -24,6 +24,7 @@
 #include "inner_adapt.h"
 
 #include <cmath>
+#include <cstring>
 #include <type_traits>
 #include <cstdlib>
 
@@ -1743,7 +1744,7 @@ static int launch_reduce_h(abz_ctx* ctx, const ReduceSpec& rs, const ReduceArgs&
                        ctx->scratch[1].as<double2>());
     ABZ_HIP(hipGetLastError());
     hipLaunchKernelGGL(final_reduce_kernel, dim3((unsigned)ncols), dim3(256), 0, ctx->stream, ctx->scratch[1].as<double2>(),
-                       nblocks, ncols, rs.scale, ctx->scratch[2].as<double2>());
+                       nblocks, ncols, rs.scale, rs.out_map_dev ? rs.out_map_dev : ctx->scratch[2].as<double2>());
     ABZ_HIP(hipGetLastError());
     return ABZ_OK;
 }
@@ -1817,6 +1818,11 @@ int launch_reduce(abz_ctx* ctx, const ReduceSpec& rs, double* out_reim) {
     }
     if (rs.out_dev) {  // the sums stay in HBM (they feed a collective on the same stream)
         ABZ_HIP(hipMemcpyAsync(rs.out_dev, outd, sizeof(double2) * (size_t)ncols, hipMemcpyDeviceToDevice, ctx->stream));
+        return ABZ_OK;
+    }
+    if (rs.out_map_dev) {  // the last kernel wrote the sums into the pinned mailbox: one synchronisation, no copy call
+        ABZ_HIP(hipStreamSynchronize(ctx->stream));
+        std::memcpy(out_reim, rs.out_map_host, sizeof(double2) * (size_t)ncols);
         return ABZ_OK;
     }
     ABZ_HIP(hipMemcpyAsync(out_reim, outd, sizeof(double2) * (size_t)ncols, hipMemcpyDeviceToHost, ctx->stream));

@@ -34,6 +34,7 @@
 
 #include <algorithm>
 #include <cstdlib>
+#include <cstring>
 #include <type_traits>
 #include <vector>
 
@@ -1120,7 +1121,18 @@ int launch_ggr(abz_ctx* ctx, int n, int d, int npt, PlaneView E, PlaneView V, co
     double* partial = ctx->scratch[1].as<double>();
     double* Es_dev = ctx->scratch[2].as<double>();
     double* outd = Es_dev + nE;
-    ABZ_HIP(hipMemcpyAsync(Es_dev, Es.data(), sizeof(double) * (size_t)nE, hipMemcpyHostToDevice, ctx->stream));
+    // energies in and sums out through the pinned mailbox: an asynchronous copy, the last kernel writes the sums into
+    // host memory itself, one stream synchronisation per call
+    const bool mb = mbox_reserve(ctx) == ABZ_OK && sizeof(double) * (size_t)nE <= ctx->mbox_cap / 2;
+    const double* res_host = res.data();
+    if (mb) {
+        std::memcpy(ctx->mbox, Es.data(), sizeof(double) * (size_t)nE);
+        ABZ_HIP(hipMemcpyAsync(Es_dev, ctx->mbox, sizeof(double) * (size_t)nE, hipMemcpyHostToDevice, ctx->stream));
+        outd = reinterpret_cast<double*>(static_cast<char*>(ctx->mbox_dev) + ctx->mbox_cap / 2);
+        res_host = reinterpret_cast<const double*>(static_cast<const char*>(ctx->mbox) + ctx->mbox_cap / 2);
+    } else {
+        ABZ_HIP(hipMemcpyAsync(Es_dev, Es.data(), sizeof(double) * (size_t)nE, hipMemcpyHostToDevice, ctx->stream));
+    }
     for (int s0 = 0; s0 < nE; s0 += CH) {
         const int cnt = std::min(CH, nE - s0);
         a.Es = Es_dev + s0;
@@ -1133,9 +1145,9 @@ int launch_ggr(abz_ctx* ctx, int n, int d, int npt, PlaneView E, PlaneView V, co
         hipLaunchKernelGGL(ggr_final_kernel, dim3((unsigned)cnt), dim3(256), 0, ctx->stream, partial, nrows, outd + s0);
         ABZ_HIP(hipGetLastError());
     }
-    ABZ_HIP(hipMemcpyAsync(res.data(), outd, sizeof(double) * (size_t)nE, hipMemcpyDeviceToHost, ctx->stream));
+    if (!mb) ABZ_HIP(hipMemcpyAsync(res.data(), outd, sizeof(double) * (size_t)nE, hipMemcpyDeviceToHost, ctx->stream));
     ABZ_HIP(hipStreamSynchronize(ctx->stream));
-    for (int i = 0; i < nE; ++i) out_host[perm[(size_t)i]] = res[(size_t)i];
+    for (int i = 0; i < nE; ++i) out_host[perm[(size_t)i]] = res_host[(size_t)i];
     return ABZ_OK;
 }
 #undef ABZ_GGR_D
