@@ -40,6 +40,8 @@ int stage_h2d(abz_ctx* ctx, void* dst_dev, const void* src_host, size_t bytes);
 int stage_d2h(abz_ctx* ctx, void* dst_host, const void* src_dev, size_t bytes);
 // the context's pinned, device-visible mailbox (ctx->mbox / mbox_dev / mbox_cap): small inputs and results of a call
 int mbox_reserve(abz_ctx* ctx);
+struct SymTables;
+int sym_tables_device(abz_ctx* ctx, int npt, int d, const int32_t* syms, int nsyms, SymTables& out);
 
 // caching device allocator (api.cpp): blocks freed with dev_free are reused by later dev_alloc calls
 int dev_alloc(void** out, size_t bytes, size_t* cap_out);
@@ -72,6 +74,22 @@ struct PlaneView {
     int row = 0;             // padded row length (multiple of 16 doubles = 128 B)
 };
 
+// Device-resident description of the nodes of a symmetric (irreducible-node) rule: grid indices, weights and the
+// contraction plan (kernels_symptr.hip).  Integer tables: they do not depend on the series and are cached per context.
+struct SymTables {
+    int npt = 0, d = 0;
+    int64_t nk = 0;
+    int64_t nitems[ABZ_MAX_DIM + 1] = {0, 0, 0, 0};
+    DevBuf arena;                    // one allocation; the tables below are views into it
+    int32_t* idx = nullptr;          // [d][nk]
+    double* w = nullptr;             // [nk]
+    int32_t* gi[ABZ_MAX_DIM + 1] = {nullptr, nullptr, nullptr, nullptr};      // [0] i_1 of the nodes, [L] i_{L+1} of the level-L items
+    int64_t* parent[ABZ_MAX_DIM + 1] = {nullptr, nullptr, nullptr, nullptr};  // [0] level-1 item of a node, [L] level-(L+1) item of a level-L item
+    int64_t* runs = nullptr;         // [nitems[1] + 1]: first node of every level-1 item (d >= 2)
+    std::vector<int32_t> syms;       // the key, with npt and d
+    void release();
+};
+
 struct ProfSlot {
     double ms = 0.0;
     int64_t launches = 0;
@@ -98,6 +116,7 @@ struct abz_ctx {
     size_t pin_cap = 0;
     // small pinned, device-visible mailbox: swept values go in through it without a synchronising pageable copy, and the
     // last kernel of a reduction writes its few sums straight into it (zero copy) -- one stream synchronisation per call
+    std::vector<abz::SymTables*> sym_cache;  // most recently used last
     void* mbox = nullptr;
     void* mbox_dev = nullptr;  // the same memory as the device sees it
     size_t mbox_cap = 0;

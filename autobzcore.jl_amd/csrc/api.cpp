@@ -278,6 +278,7 @@ struct Plan {
     std::vector<double> xs[ABZ_MAX_DIM + 1];    // same with coordinates
     std::vector<int64_t> parent[ABZ_MAX_DIM + 1];  // level L item -> item at level L+1; [0]: node -> level-1 item
     std::vector<int64_t> run_start;  // irregular lists, d >= 2: first node of every level-1 item (+ nk at the end)
+    int64_t nruns = 0;               // = number of level-1 items when the runs are known (host list above, or device tables)
 };
 
 static void plan_full(Plan& p, int d, int npt, int outer0, int outer_n) {
@@ -348,6 +349,7 @@ static void plan_runs(Plan& p, int d, int npt, const T* pts, int64_t nk, bool co
             if (k == 0 || p.parent[0][(size_t)k] != p.parent[0][(size_t)k - 1]) p.run_start.push_back(k);
         p.run_start.push_back(nk);
     }
+    p.nruns = p.run_start.empty() ? 0 : (int64_t)p.run_start.size() - 1;
 }
 
 struct PlanDev {
@@ -470,6 +472,11 @@ static void ctx_release(abz_ctx* ctx) {
     for (auto& b : ctx->scratch) b.release();
     if (ctx->pin) (void)hipHostFree(ctx->pin);
     if (ctx->mbox) (void)hipHostFree(ctx->mbox);
+    for (SymTables* c : ctx->sym_cache) {
+        c->release();
+        delete c;
+    }
+    ctx->sym_cache.clear();
     for (auto& sl : ctx->prof_slots)
         for (auto& pr : sl.pending) {
             (void)hipEventDestroy(pr.first);
@@ -823,9 +830,9 @@ static int rule_fill(abz_rule* r) {
         es.nk = r->nk;
         es.parents = r->full ? nullptr : rp->pd.parent[0].as<int64_t>();
         es.gi = r->full ? nullptr : rp->pd.gi[0].as<int32_t>();
-        if (!r->full && !plan.run_start.empty() && !plan.coords) {  // runs of nodes per level-1 set (row kernels, n > 4)
+        if (!r->full && plan.nruns > 0 && !plan.coords) {  // runs of nodes per level-1 set (row kernels, n > 4)
             es.run_start = rp->pd.runs.as<int64_t>();
-            es.nruns = (int64_t)plan.run_start.size() - 1;
+            es.nruns = plan.nruns;
         }
         es.x = nullptr;
         es.deriv = deriv;
@@ -915,7 +922,7 @@ static int rule_fill(abz_rule* r) {
     } while (0)
 
 static int rule_build(abz_series* s, int npt, int64_t nirr, const int32_t* irr_idx, const int64_t* wsym, int want,
-                      int outer0, int outer_n, abz_rule** out) {
+                      int outer0, int outer_n, abz_rule** out, const SymTables* st = nullptr) {
     int rc = check_series(s);
     if (rc) return rc;
     ABZ_REQUIRE(out, "null out");
@@ -923,6 +930,8 @@ static int rule_build(abz_series* s, int npt, int64_t nirr, const int32_t* irr_i
     ABZ_REQUIRE(npt >= 1, "npt = %d must be positive", npt);
     ABZ_REQUIRE((want & (ABZ_WANT_H | ABZ_WANT_EIG | ABZ_WANT_VEL)) != 0, "want = %d selects nothing", want);
     ABZ_REQUIRE((irr_idx == nullptr) == (wsym == nullptr), "irr_idx and wsym must be given together");
+    ABZ_REQUIRE(!st || (st->d == s->d && st->npt == npt && st->nk > 0), "symmetric rule tables do not fit the series");
+    if (st) nirr = st->nk;
     if (want & ABZ_WANT_VEL) want |= ABZ_WANT_EIG;
     abz_ctx* ctx = s->ctx;
     ABZ_HIP(hipSetDevice(ctx->device));
@@ -933,7 +942,7 @@ static int rule_build(abz_series* s, int npt, int64_t nirr, const int32_t* irr_i
     r->s = s;
     r->npt = npt;
     r->want = want;
-    r->full = irr_idx == nullptr;
+    r->full = irr_idx == nullptr && st == nullptr;
     // ABZ_DEBUG_TIMING=1: wall time of the build phases on stderr (host plan, uploads, allocation, fill)
     const bool dbg = getenv("ABZ_DEBUG_TIMING") != nullptr;
     auto tnow = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
@@ -951,6 +960,14 @@ static int rule_build(abz_series* s, int npt, int64_t nirr, const int32_t* irr_i
         plan_full(plan, d, npt, outer0, outer_n);
         r->k_offset = (int64_t)outer0;
         for (int j = 0; j + 1 < d; ++j) r->k_offset *= npt;
+    } else if (st) {  // device-resident node list and plan (sym_tables_device): nothing is walked or uploaded here
+        plan.d = d;
+        plan.full = false;
+        plan.coords = false;
+        plan.npt = npt;
+        plan.nk = st->nk;
+        for (int L = 0; L <= ABZ_MAX_DIM; ++L) plan.nitems[L] = st->nitems[L];
+        plan.nruns = d >= 2 ? st->nitems[1] : 0;
     } else {
         for (int64_t k = 0; k < nirr * d; ++k) {
             if (irr_idx[k] < 0 || irr_idx[k] >= npt) {
@@ -976,7 +993,24 @@ static int rule_build(abz_series* s, int npt, int64_t nirr, const int32_t* irr_i
     const bool planar = planar_on && r->full && (int64_t)r->ntiles * pitch < ((int64_t)1 << 31);
     const int64_t tile = planar ? (int64_t)pitch : (int64_t)r->planes * pitch;
     const int pstride = planar ? (int)(r->ntiles * pitch) : pitch;  // plane to plane
-    RULE_TRY(plan_upload(ctx, plan, rp->pd));
+    if (st) {  // device-to-device copies of the cached tables: the rule owns its plan like any other
+        auto d2d = [&](DevBuf& dst, const void* src, size_t bytes) -> int {
+            if (bytes == 0) return ABZ_OK;
+            int rc_ = dst.reserve(bytes);
+            if (rc_) return rc_;
+            ABZ_HIP(hipMemcpyAsync(dst.p, src, bytes, hipMemcpyDeviceToDevice, ctx->stream));
+            return ABZ_OK;
+        };
+        RULE_TRY(d2d(rp->pd.gi[0], st->gi[0], sizeof(int32_t) * (size_t)st->nk));
+        RULE_TRY(d2d(rp->pd.parent[0], st->parent[0], sizeof(int64_t) * (size_t)st->nk));
+        for (int L = 1; L < d; ++L) {
+            RULE_TRY(d2d(rp->pd.gi[L], st->gi[L], sizeof(int32_t) * (size_t)st->nitems[L]));
+            RULE_TRY(d2d(rp->pd.parent[L], st->parent[L], sizeof(int64_t) * (size_t)st->nitems[L]));
+        }
+        if (d >= 2) RULE_TRY(d2d(rp->pd.runs, st->runs, sizeof(int64_t) * (size_t)(st->nitems[1] + 1)));
+    } else {
+        RULE_TRY(plan_upload(ctx, plan, rp->pd));
+    }
     lap("plan_upload");
     RULE_TRY(make_phase_table(ctx, npt, rp->tab));
     lap("phase_table");
@@ -1019,7 +1053,12 @@ static int rule_build(abz_series* s, int npt, int64_t nirr, const int32_t* irr_i
     r->H = mkview(0, pH > 0);
     r->E = mkview(pH, pE > 0);
     r->V = mkview(pH + pE, pV > 0);
-    if (!r->full) {
+    if (st) {
+        RULE_TRY(dev_alloc((void**)&r->w, sizeof(double) * (size_t)st->nk, &r->w_cap));
+        RULE_HIP(hipMemcpyAsync(r->w, st->w, sizeof(double) * (size_t)st->nk, hipMemcpyDeviceToDevice, ctx->stream));
+        RULE_TRY(dev_alloc((void**)&r->idx, sizeof(int32_t) * (size_t)(st->nk * d), &r->idx_cap));
+        RULE_HIP(hipMemcpyAsync(r->idx, st->idx, sizeof(int32_t) * (size_t)(st->nk * d), hipMemcpyDeviceToDevice, ctx->stream));
+    } else if (!r->full) {
         std::vector<double> wd(std::max<int64_t>(nirr, 1));
         for (int64_t k = 0; k < nirr; ++k) wd[k] = (double)wsym[k];
         RULE_TRY(dev_alloc((void**)&r->w, sizeof(double) * wd.size(), &r->w_cap));
@@ -1053,6 +1092,49 @@ static int rule_build(abz_series* s, int npt, int64_t nirr, const int32_t* irr_i
 int abz_ptr_rule_build(abz_series* s, int npt, int64_t nirr, const int32_t* irr_idx, const int64_t* wsym, int want,
                        abz_rule** out) {
     return rule_build(s, npt, nirr, irr_idx, wsym, want, 0, npt, out);
+}
+
+int abz_ptr_rule_build_sym(abz_series* s, int npt, const int32_t* syms, int nsyms, int want, abz_rule** out) {
+    int rc = check_series(s);
+    if (rc) return rc;
+    ABZ_REQUIRE(out && syms && nsyms >= 1 && npt >= 1, "abz_ptr_rule_build_sym: bad arguments");
+    *out = nullptr;
+    abz_ctx* ctx = s->ctx;
+    ABZ_HIP(hipSetDevice(ctx->device));
+    const int d = s->d;
+    const size_t nsy = (size_t)nsyms * d * d;
+    SymTables* st = nullptr;
+    for (size_t i = 0; i < ctx->sym_cache.size(); ++i) {
+        SymTables* c = ctx->sym_cache[i];
+        if (c->npt == npt && c->d == d && c->syms.size() == nsy && std::equal(c->syms.begin(), c->syms.end(), syms)) {
+            st = c;
+            ctx->sym_cache.erase(ctx->sym_cache.begin() + (long)i);
+            break;
+        }
+    }
+    if (!st) {
+        st = new SymTables();
+        rc = sym_tables_device(ctx, npt, d, syms, nsyms, *st);
+        if (rc) {
+            st->release();
+            delete st;
+            return rc;
+        }
+    }
+    ctx->sym_cache.push_back(st);
+    // a few grids stay cached (AutoPTR walks npt = 50, 100, 150, ...): 32 B per irreducible node
+    size_t bytes = 0;
+    for (const SymTables* c : ctx->sym_cache) bytes += (size_t)c->nk * 40;
+    while (ctx->sym_cache.size() > 8 || (bytes > ((size_t)2 << 30) && ctx->sym_cache.size() > 1)) {
+        SymTables* old = ctx->sym_cache.front();
+        ctx->sym_cache.erase(ctx->sym_cache.begin());
+        bytes -= (size_t)old->nk * 40;
+        (void)hipStreamSynchronize(ctx->stream);
+        old->release();
+        delete old;
+    }
+    ABZ_REQUIRE(st->nk > 0, "the symmetry set leaves no node");
+    return rule_build(s, npt, 0, nullptr, nullptr, want, 0, npt, out, st);
 }
 
 int abz_ptr_rule_build_slab(abz_series* s, int npt, int outer_begin, int outer_end, int want, abz_rule** out) {

@@ -5,6 +5,7 @@ semantics, ref docs/src/examples.md:26-42, src/fourier.jl:56-86): all arithmetic
 libabzhip.so on the GPU.
 """
 import ctypes as C
+import os
 import weakref
 
 import numpy as np
@@ -308,6 +309,16 @@ class DeviceRule:
                 self.nk_local = (z1 - z0) * self.npt ** (d - 1)
                 if z1 > z0:
                     L.check(L.lib().abz_ptr_rule_build_slab(dev.h, self.npt, z0, z1, want, C.byref(h)))
+        elif world == 1 and len(syms) <= 48 and os.environ.get("ABZ_SYM_DEVICE", "1") != "0":
+            # orbit tables, contraction plan and values all on the device (abz_ptr_rule_build_sym): the node list
+            # never visits the host
+            S = np.ascontiguousarray(np.rint(np.asarray(syms)).astype(np.int32).reshape(-1, d, d))
+            if not np.allclose(S, np.asarray(syms).reshape(-1, d, d)):
+                raise ValueError("symmetries must be integer matrices in the lattice basis")
+            L.check(L.lib().abz_ptr_rule_build_sym(dev.h, self.npt, S.ctypes.data_as(L.c_i32p), len(S), want, C.byref(h)))
+            nk = C.c_int64(0)
+            L.check(L.lib().abz_rule_info(h, C.byref(nk), None, None, None, None))
+            self.nk = self.nk_local = int(nk.value)
         else:
             idx, w = symptr_rule(self.npt, d, syms, ctx=dev.ctx)
             self.nk = len(w)

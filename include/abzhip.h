@@ -146,6 +146,15 @@ int abz_eval_nodes(abz_series* s, const double* k, int64_t nk, int want, double*
 int abz_ptr_rule_build(abz_series* s, int npt, int64_t nirr, const int32_t* irr_idx,
                        const int64_t* wsym, int want, abz_rule** out);
 
+/* Symmetric rule built entirely on the device: orbit representatives, weights, the contraction plan of the node
+ * list and the values, from the symmetry matrices syms [nsyms][d][d] (row-major integers, a group).  Same nodes,
+ * weights and values as abz_symptr_rule + abz_ptr_rule_build, without the node list crossing PCIe twice; the integer
+ * tables of a grid are cached per context (they do not depend on the series).
+ * Replaces: the FourierMonkhorstPack constructor, which builds wsym / flags and fills the values in one go
+ * (src/fourier.jl:265-277). */
+int abz_ptr_rule_build_sym(abz_series* s, int npt, const int32_t* syms, int nsyms, int want,
+                           abz_rule** out);
+
 /* A slab of the full grid: only i_d in [outer_begin, outer_end) of the outermost variable (d >= 2),
  * i.e. one rank's share when a single solve is sharded over k (the recursion of fourier_ptr! is
  * independent per outer index, src/fourier.jl:148-164).  Weights and abz_rule_reduce's 1/npt^d

@@ -110,6 +110,15 @@ function rule!(hs::HIPSeries{d}, npt::Integer, syms, want::Cint) where {d}
                 (Ptr{Cvoid}, Cint, Int64, Ptr{Cint}, Ptr{Int64}, Cint, Ptr{Ptr{Cvoid}}),
                 hs.h, npt, 0, C_NULL, C_NULL, want, ref))
             nk, ns = npt^d, 1
+        elseif length(syms) <= 48
+            # orbit tables, contraction plan and values on the device: the node list never visits the host
+            S = Cint[round(Int, M[a, b]) for M in syms for a in 1:d for b in 1:d]   # row-major per matrix
+            check(ccall((:abz_ptr_rule_build_sym, libabz), Cint,
+                (Ptr{Cvoid}, Cint, Ptr{Cint}, Cint, Cint, Ptr{Ptr{Cvoid}}), hs.h, npt, S, length(syms), want, ref))
+            n = Ref{Int64}(0)
+            check(ccall((:abz_rule_info, libabz), Cint, (Ptr{Cvoid}, Ptr{Int64}, Ptr{Cint}, Ptr{Cint}, Ptr{Cint}, Ptr{Cint}),
+                ref[], n, C_NULL, C_NULL, C_NULL, C_NULL))
+            nk, ns = Int(n[]), length(syms)
         else
             idx, w = symptr_rule(npt, Val(d), syms)
             check(ccall((:abz_ptr_rule_build, libabz), Cint,

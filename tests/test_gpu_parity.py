@@ -1358,6 +1358,48 @@ def test_ggr_windowed_scan_equals_all_pairs_scan(abz, svo, monkeypatch):
         rule.close()
 
 
+@pytest.mark.parametrize("kind,d", [("InversionSymIBZ", 1), ("InversionSymIBZ", 2), ("CubicSymIBZ", 2), ("InversionSymIBZ", 3), ("CubicSymIBZ", 3)])
+def test_symmetric_rule_built_on_the_device_equals_the_host_built_rule(abz, kind, d, monkeypatch):
+    """abz_ptr_rule_build_sym (orbit tables, contraction plan and values on the device; ref: the FourierMonkhorstPack
+    constructor, src/fourier.jl:265-277) against abz_symptr_rule + abz_ptr_rule_build with the host's node list: nodes and
+    integer weights array_equal (and equal to the oracle's symptr_rule), values and rule sums bit-identical; grids with
+    even / odd npt, lines without nodes, one-node lines; a second series re-uses the cached tables."""
+    from autobzcore.jl_amd import _lib as L
+    rng = np.random.default_rng(5 * d + len(kind))
+    c, first = rand_series(rng, (3, 5, 3)[:d], 3, hermitian=True)
+    s, so = both(abz, c, first, 1.0, ndim=d)
+    kinds = {"InversionSymIBZ": abz.InversionSymIBZ(), "CubicSymIBZ": abz.CubicSymIBZ()}
+    syms = abz.load_bz(kinds[kind], np.eye(d)).syms
+    osyms = orc.load_bz(kind, np.eye(d)).syms
+    om = np.linspace(-1.0, 1.0, 5)
+    for npt in ((1, 2, 7, 24, 65, 150) if d < 3 else (1, 2, 7, 24, 33)):
+        for want in (L.WANT_H | L.WANT_EIG, L.WANT_EIG | L.WANT_VEL):
+            rd = abz.DeviceRule(s.device(), npt, syms, want)
+            monkeypatch.setenv("ABZ_SYM_DEVICE", "0")
+            rh = abz.DeviceRule(s.device(), npt, syms, want)
+            monkeypatch.delenv("ABZ_SYM_DEVICE")
+            assert rd.nk == rh.nk
+            a = rd.export(H=bool(want & L.WANT_H), eig=True, vel=bool(want & L.WANT_VEL))
+            b = rh.export(H=bool(want & L.WANT_H), eig=True, vel=bool(want & L.WANT_VEL))
+            for key in b:
+                assert np.array_equal(a[key], b[key]), (npt, want, key)
+            if want & L.WANT_H:
+                assert np.array_equal(rd.reduce(L.F_DOS, [0.3], om), rh.reduce(L.F_DOS, [0.3], om))
+            else:
+                assert np.array_equal(rd.ggr(om), rh.ggr(om))
+            rd.close()
+            rh.close()
+        wo, xo, _, idxo = orc.fourier_symptr(so, npt, osyms)
+        assert np.array_equal(a["x"], xo) and np.array_equal(a["w"], wo.astype(float))  # integer parity with the oracle
+    c2, _ = rand_series(rng, (3, 5, 3)[:d], 3, hermitian=True)
+    s2, _ = both(abz, c2, first, 1.0, ndim=d)
+    r2 = abz.DeviceRule(s2.device(), 24, syms, L.WANT_H)
+    monkeypatch.setenv("ABZ_SYM_DEVICE", "0")
+    r3 = abz.DeviceRule(s2.device(), 24, syms, L.WANT_H)
+    monkeypatch.delenv("ABZ_SYM_DEVICE")
+    assert np.array_equal(r2.reduce(L.F_DOS, [0.3], om), r3.reduce(L.F_DOS, [0.3], om))
+
+
 def test_ggr_cache_invalidation(abz):
     """ref: test/dos.jl:114-132."""
     h = abz.FourierSeries(np.array([0.5, 0.0, 0.5]).reshape(3, 1, 1), period=1.0, offset=-2, ndim=1)
