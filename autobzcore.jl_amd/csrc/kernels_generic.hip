@@ -757,6 +757,76 @@ __device__ __forceinline__ void panel_stage(double2* coef, const double2* __rest
     }
 }
 
+// ---- Hermitian series, symmetric frequency range (first = -F, M = 2 F + 1): H(x)_rj = c_0,rj + sum_{f=1..F} [c_f,rj z^f +
+// conj(c_f,jr) z^-f].  With s = c_f,rj + c_f,jr and t = c_f,rj - c_f,jr (staged instead of c_f and c_-f: the same LDS bytes)
+//   H_rj += (s.x pr - s.y pi) + i (t.x pi + t.y pr),   p = z^f = (pr, pi)
+// one FMA group serves +f and -f: half the series flops of panel_series_row, one sincospi per node instead of two.
+// Layout [1 + 2 F][NP * NP]: block 0 = c_0, block 2 f - 1 = s_f, block 2 f = t_f, element (row rr, column j) at j * NP + rr.
+template <int NP>
+__device__ __forceinline__ void panel_stage_fold(double2* coef, const double2* __restrict__ src, int n, int M) {
+    const int F = (M - 1) / 2, nn = n * n;
+    for (int t = threadIdx.x; t < M * NP * NP; t += blockDim.x) {
+        const int b = t / (NP * NP), e = t - b * (NP * NP);
+        const int rr = e % NP, j = e / NP;
+        double2 v = make_double2(0.0, 0.0);
+        if (rr < n && j < n) {
+            if (b == 0) {
+                v = src[(size_t)F * nn + rr + n * j];
+            } else {
+                const int f = (b + 1) >> 1;
+                const double2 c = src[(size_t)(F + f) * nn + rr + n * j], cp = src[(size_t)(F + f) * nn + j + n * rr];
+                v = (b & 1) ? make_double2(c.x + cp.x, c.y + cp.y) : make_double2(c.x - cp.x, c.y - cp.y);
+            }
+        }
+        coef[t] = v;
+    }
+}
+
+// row r of -H(x) from the folded set; (zr, zi) = e^{2 pi i x}
+template <int NP>
+__device__ __forceinline__ void panel_series_row_fold(const double2* coef, int M, double zr, double zi, int r, double (&ar)[NP],
+                                                      double (&ai)[NP]) {
+    const int F = (M - 1) / 2;
+    constexpr int nn = NP * NP;
+#pragma unroll
+    for (int j0 = 0; j0 < NP; j0 += 8) {
+        double2 c[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) c[j] = coef[r + NP * (j0 + j)];
+        pin8(c);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            ar[j0 + j] = -c[j].x;
+            ai[j0 + j] = -c[j].y;
+        }
+    }
+    double pr = 1.0, pi = 0.0;
+    for (int f = 1; f <= F; ++f) {
+        const double nr = pr * zr - pi * zi, ni = pr * zi + pi * zr;
+        pr = nr;
+        pi = ni;
+        const double2* __restrict__ sm = coef + (size_t)(2 * f - 1) * nn + r;
+        const double2* __restrict__ tm = sm + nn;
+#pragma unroll
+        for (int j0 = 0; j0 < NP; j0 += 8) {
+            double2 sv[8], tv[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) sv[j] = sm[NP * (j0 + j)];
+            pin8(sv);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) tv[j] = tm[NP * (j0 + j)];
+            pin8(tv);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {  // A = z I - H: accumulate -H
+                ar[j0 + j] = fma(-sv[j].x, pr, ar[j0 + j]);
+                ar[j0 + j] = fma(sv[j].y, pi, ar[j0 + j]);
+                ai[j0 + j] = fma(-tv[j].x, pi, ai[j0 + j]);
+                ai[j0 + j] = fma(-tv[j].y, pr, ai[j0 + j]);
+            }
+        }
+    }
+}
+
 // trace of the inverse from its rows (sum over the node's NP lanes; every lane gets it)
 template <int NP>
 __device__ __forceinline__ void panel_trace(const double (&ar)[NP], const double (&ai)[NP], int n, int r, double& tr,
@@ -2360,6 +2430,7 @@ struct GenInnerArgs {
     const double* sweep_arr;
     int64_t nint, maxevals;
     int n, M, first, d, ncomp, integrand, has_rtol;
+    int herm;  // Hermitian series with first = -(M - 1) / 2: +f and -f can be folded
     double inv_period, sweep, rtol_user;
     double p[4];
     double2* I_out;
@@ -2464,8 +2535,9 @@ __global__ __launch_bounds__(256) void gen_inner_adaptive_kernel(GenInnerArgs a,
 // Block-per-integral version of the above for the resolvent-trace integrands: the integral's coefficient
 // set is staged in LDS once and stays there for its whole adaptive loop; each round's 15 / 30 GK nodes
 // are evaluated 256/NP at a time by NP-lane groups (panel_inverse_row), thread 0 runs adapt_step.
-template <int NP, bool PAD, int NT, int WPE, int RPL = 1>
+template <int NP, bool PAD, int NT, int WPE, int RPL = 1, bool FOLD = false>
 __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(WPE ? WPE : 1, WPE ? WPE : 8))) void gen_inner_panel_kernel(GenInnerArgs a) {
+    static_assert(!FOLD || (PAD && RPL == 1), "the folded series is built for the zero-padded one-row-per-lane layout");
     extern __shared__ double2 lds_ip[];
     constexpr int LPN = NP / RPL;  // lanes per node (RPL = 2: the duo layout, PAD only)
     constexpr int SLOTS = NT / LPN;
@@ -2484,7 +2556,10 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(WPE ? WPE : 
     for (int64_t q = blockIdx.x; q < a.nint; q += gridDim.x) {
         AdaptStateT<1> st;
         __syncthreads();  // the previous integral's readers are done with coef / ctl
-        panel_stage<NP, PAD>(coef, a.src + a.slot[q] * ((int64_t)M * nn), n, M);
+        if constexpr (FOLD)
+            panel_stage_fold<NP>(coef, a.src + a.slot[q] * ((int64_t)M * nn), n, M);
+        else
+            panel_stage<NP, PAD>(coef, a.src + a.slot[q] * ((int64_t)M * nn), n, M);
         if (threadIdx.x == 0) {
             adapt_init(st, a.atol[q], a.has_rtol != 0, a.rtol_user, a.lo[q], a.hi[q], ctl);
             ctl[5] = 0.0;  // done flag
@@ -2504,6 +2579,14 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(WPE ? WPE : 
                 double tr, ti;
                 if constexpr (RPL == 2) {
                     duo_inverse_trace<NP>(coef, n, M, a.first, x * a.inv_period, swq, a.p[0], r, tr, ti);
+                } else if constexpr (FOLD) {
+                    double ar[NP], ai[NP];
+                    double zr, zi;
+                    sincospi(2.0 * (x * a.inv_period), &zi, &zr);
+                    panel_series_row_fold<NP>(coef, M, zr, zi, r, ar, ai);
+                    panel_shift_row<NP, PAD>(n, swq, a.p[0], r, ar, ai);
+                    panel_invert_rows<NP, PAD>(n, r, ar, ai);
+                    panel_trace<NP>(ar, ai, n, r, tr, ti);
                 } else {
                     double ar[NP], ai[NP];
                     panel_inverse_row<NP, PAD>(coef, n, M, a.first, x * a.inv_period, swq, a.p[0], r, ar, ai);
@@ -2583,6 +2666,7 @@ int launch_gen_inner_adaptive(abz_ctx* ctx, const InnerSpec& is) {
     a.ncomp = integrand_ncomp(is.integrand, is.n, is.d);
     a.integrand = is.integrand;
     a.has_rtol = is.has_rtol ? 1 : 0;
+    a.herm = (is.herm && (is.M & 1) && is.first == -((is.M - 1) / 2)) ? 1 : 0;
     a.inv_period = 1.0 / is.period;
     a.sweep = is.sweep;
     a.rtol_user = is.rtol_user;
@@ -2636,7 +2720,12 @@ int launch_gen_inner_adaptive(abz_ctx* ctx, const InnerSpec& is) {
             const int nt = gen_inner_panel_threads(np);
             static const int wpe_env = [] { const char* e = getenv("ABZ_IPANEL_WPE"); return e ? atoi(e) : 0; }();
             const int wpe = wpe_env ? wpe_env : ((nt == 512 && np <= 16) ? 4 : 0);  // 32 rows x 2 arrays alone fill 128 VGPRs
-            if (np == 8) {
+            const bool fold_off = [] { const char* e = getenv("ABZ_IPANEL_FOLD"); return e && e[0] == '0'; }();  // per call: tests compare both
+            if (np == 16 && pad && nt == 512 && wpe == 4 && a.herm && !fold_off) {  // config 5's shape
+                ABZ_HIP(hipFuncSetAttribute((const void*)gen_inner_panel_kernel<16, true, 512, 4, 1, true>,
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)plds));
+                hipLaunchKernelGGL((gen_inner_panel_kernel<16, true, 512, 4, 1, true>), dim3((unsigned)blocks), dim3(512), plds, ctx->stream, a);
+            } else if (np == 8) {
                 ABZ_IPANEL(8)
             } else if (np == 16) {
                 ABZ_IPANEL(16)
