@@ -1076,17 +1076,23 @@ def test_config5_synthetic_16_band(abz):
     ptr = abz.solve(abz.IntegralProblem(f, bz, abz.MixedParameters(0.2)), abz.PTR(npt=12)).u
     ref = orc.solve_ptr(so, orc.load_bz("FBZ", np.eye(3)), orc.f_dos(0.05, 0.2), npt=12).u
     assert abs(ptr - ref) <= 1e-9 * abs(ref)
-    # IAI at SURVEY 8d's / BASELINE's abstol = 1e-3 (2e-6 of the value ~ 481 = DOS * |det B|; 5.5e9 inner nodes in
-    # ~12 s) against store-free PTR sums on grids where the eta = 0.05 peaks are resolved (npt = 240 and 300 agree to
-    # 8e-4).  Nested GK accumulates the inner integrals' errors, so the bar is 3x the requested abstol.
+    # IAI at SURVEY 8d's / BASELINE's abstol = 1e-3 (2e-6 of the value ~ 481 = DOS * |det B|; 5.5e9 inner nodes in ~10 s)
+    # against a reference that is converged an order of magnitude below that tolerance: store-free PTR sums on the 500^3 and
+    # 600^3 grids (0.2 / 0.4 s) agree to 3e-8 per unit BZ volume = 8e-6 in the units of the solution (tools/c5_reference.py:
+    # 240 -> 300 -> 400 -> 500 -> 600 -> 720 differ by 3e-6, 2e-6, 4e-7, 3e-8, 3e-8).  north_star: "integrals within the
+    # solver's own abstol" -- the bar is abstol itself (measured error 4.9e-4).  Whether the panel decisions are the
+    # reference's is tested where the oracle can follow (3 x 3 x 3 R-vectors, 16 bands: panels array_equal, equal numevals).
     sol = abz.solve(abz.IntegralProblem(f, bz, abz.MixedParameters(0.2)), abz.EvalCounter(abz.IAI()), abstol=1e-3, reltol=0.0)
     dev = s.device()
-    big = dev.ptr_sum(300, abz._lib.F_DOS, [0.05], [0.2])[0, 0].real * abs(np.linalg.det(bz.B))
-    mid = dev.ptr_sum(240, abz._lib.F_DOS, [0.05], [0.2])[0, 0].real * abs(np.linalg.det(bz.B))
-    assert abs(big - mid) < 2e-3
-    assert abs(sol.u - big) < 3e-3 and sol.resid <= 1e-3
-    # the round-1 driver (one panel per round, 46.7 s) counted 5 499 590 985 at this tolerance: same decisions
-    assert abs(sol.numevals - 5499590985) <= 5499590985 // 1000
+    detB = abs(np.linalg.det(bz.B))
+    big = dev.ptr_sum(600, abz._lib.F_DOS, [0.05], [0.2])[0, 0].real * detB
+    mid = dev.ptr_sum(500, abz._lib.F_DOS, [0.05], [0.2])[0, 0].real * detB
+    assert abs(big - mid) < 1e-4
+    assert abs(sol.u - big) <= 1e-3 and sol.resid <= 1e-3
+    assert sol.numevals > 10**9
+    # a looser tolerance keeps its promise too (measured 3.1e-3 at abstol 1e-2)
+    sol2 = abz.solve(abz.IntegralProblem(f, bz, abz.MixedParameters(0.2)), abz.IAI(), abstol=1e-2, reltol=0.0)
+    assert abs(sol2.u - big) <= 1e-2
 
 
 # ------------------------------------------------------------------ SVO (configs 3 / 4)
