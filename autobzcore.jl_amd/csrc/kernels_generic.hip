@@ -368,8 +368,14 @@ __global__ __launch_bounds__(256) void gen_velocity_kernel(PlaneView Uv, PlaneVi
     Vv.base[view_off(Vv, k) + (int64_t)b * Vv.pitch] = v;
 }
 
+static bool launch_gen_velocity_rows(abz_ctx* ctx, int n, PlaneView U, PlaneView dH, PlaneView Vj, int64_t nk);
+
 int launch_gen_velocity(abz_ctx* ctx, int n, PlaneView U, PlaneView dH, PlaneView Vj, int64_t nk) {
     if (nk == 0) return ABZ_OK;
+    if (launch_gen_velocity_rows(ctx, n, U, dH, Vj, nk)) {
+        ABZ_HIP(hipGetLastError());
+        return ABZ_OK;
+    }
     hipLaunchKernelGGL(gen_velocity_kernel, dim3((unsigned)cdiv2(nk, 256), (unsigned)n), dim3(256), 0, ctx->stream, U, dH, Vj, nk, n);
     ABZ_HIP(hipGetLastError());
     return ABZ_OK;
@@ -1571,10 +1577,194 @@ static int launch_gen_sum_tri(abz_ctx* ctx, const SumSpec& ss, double* out_reim)
     return ABZ_OK;
 }
 
+// ------------------------------------------------------------------------------------------
+// Eigenvectors for 9..16 bands in the row layout (GGR builds; ref src/dos_ggr.jl:31-44 calls LAPACK's eigen there):
+// eigenvalues by Householder + bisection (above), then per band b INVERSE ITERATION with the machinery of the IAI panel
+// kernels -- X = inv(H - (lambda_b + i eps) I) by the in-register Gauss-Jordan elimination (the complex shift keeps every
+// leading minor regular, so no pivoting), x <- X x three times from a band-dependent start vector (contamination
+// (eps / gap)^k), modified Gram-Schmidt against earlier members of the same cluster (|lambda_b - lambda_c| <= 1e-8 scale:
+// degenerate bands, where any orthonormal basis of the eigenspace is an answer).  ~3 k instructions per band and four
+// matrices; the 16-row parallel-order Jacobi with accumulated rotations spilled 4.6 KB and the wave-per-node Jacobi
+// took 11.2 ms for 24^3 nodes.  Lane r ends with row r of U (component r of every eigenvector), band b in column b.
+// ------------------------------------------------------------------------------------------
+template <int NP, int... J>
+__device__ __forceinline__ void row_matvec(const double (&xr_)[NP], const double (&xi_)[NP], double vr, double vi, double& outr,
+                                           double& outi, std::integer_sequence<int, J...>) {
+    outr = 0.0;
+    outi = 0.0;
+    // out_r = sum_j X[r][j] v_j, v_j from lane j of the group
+    ((void)([&] {
+         const double br = group_bcast<NP, J>(vr), bi = group_bcast<NP, J>(vi);
+         outr = fma(xr_[J], br, outr);
+         outr = fma(-xi_[J], bi, outr);
+         outi = fma(xr_[J], bi, outi);
+         outi = fma(xi_[J], br, outi);
+     }()),
+     ...);
+}
+
+template <int NP>
+__device__ __forceinline__ void rows_eigvecs_invit(int n, int r, int lane, const double (&hr)[NP], const double (&hi)[NP], double myeig,
+                                                   double (&vr)[NP], double (&vi)[NP]) {
+    const int gbase = lane & ~(NP - 1);
+    // scale of the spectrum (for the shift and the cluster test)
+    double sc = fabs(myeig);
+#pragma unroll
+    for (int off = NP / 2; off > 0; off >>= 1) sc = fmax(sc, __shfl_xor(sc, off, 64));
+    double offd = 0.0;
+#pragma unroll
+    for (int j = 0; j < NP; ++j) offd += fabs(hr[j]) + fabs(hi[j]);
+#pragma unroll
+    for (int off = NP / 2; off > 0; off >>= 1) offd = fmax(offd, __shfl_xor(offd, off, 64));
+    sc = fmax(fmax(sc, offd), 1e-300);
+    const double eps = 1e-10 * sc, ctol = 1e-8 * sc;
+#pragma unroll
+    for (int j = 0; j < NP; ++j) {
+        vr[j] = 0.0;
+        vi[j] = 0.0;
+    }
+    for (int b = 0; b < n; ++b) {  // uniform
+        const double lam = __shfl(myeig, gbase + b, 64);
+        double wr[NP], wi[NP];
+#pragma unroll
+        for (int j = 0; j < NP; ++j) {
+            wr[j] = hr[j];
+            wi[j] = hi[j];
+            if (j == r) {  // rows >= n of the zero-padded matrix: identity rows, decoupled
+                wr[j] = r < n ? hr[j] - lam : 1.0;
+                wi[j] = r < n ? hi[j] - eps : 0.0;
+            }
+        }
+        panel_invert_rows<NP, true>(n, r, wr, wi);
+        // start vector: band dependent, so that the members of a degenerate cluster start differently
+        double xr = 0.0, xi = 0.0;
+#pragma unroll
+        for (int j = 0; j < NP; ++j) {
+            const double y = (j < n) ? 1.0 + 0.61803398874989484820 * (double)(((j + 1) * (b + 3)) % 7) : 0.0;
+            xr = fma(wr[j], y, xr);
+            xi = fma(wi[j], y, xi);
+        }
+        for (int it = 0; it < 3; ++it) {
+            if (it > 0) {
+                double yr, yi;
+                row_matvec<NP>(wr, wi, xr, xi, yr, yi, std::make_integer_sequence<int, NP>());
+                xr = yr;
+                xi = yi;
+            }
+            if (r >= n) {
+                xr = 0.0;
+                xi = 0.0;
+            }
+            // modified Gram-Schmidt against earlier bands of the same cluster (wave-uniform skip: clusters are rare)
+#pragma unroll
+            for (int c = 0; c < NP; ++c) {
+                const double lc = __shfl(myeig, gbase + (c < n ? c : 0), 64);
+                const bool need = c < b && fabs(lc - lam) <= ctol;
+                if (__builtin_amdgcn_ballot_w64(need) != 0) {
+                    double dr = vr[c] * xr + vi[c] * xi, di = vr[c] * xi - vi[c] * xr;  // conj(u_c) x, summed over the rows
+                    dr = group_sum<NP>(dr);
+                    di = group_sum<NP>(di);
+                    if (need) {
+                        xr -= dr * vr[c] - di * vi[c];
+                        xi -= dr * vi[c] + di * vr[c];
+                    }
+                }
+            }
+            const double nn = group_sum<NP>(xr * xr + xi * xi);
+            const double inv = nn > 0.0 ? rsqrt_nr(nn) : 0.0;
+            xr *= inv;
+            xi *= inv;
+        }
+#pragma unroll
+        for (int j = 0; j < NP; ++j) {
+            vr[j] = (j == b) ? xr : vr[j];
+            vi[j] = (j == b) ? xi : vi[j];
+        }
+    }
+}
+
+// Band velocities v_b = Re sum_{r,c} conj(U[r][b]) D[r][c] U[c][b], NP lanes per node, lane r owning row r of
+// T = D U: the node's U and D = dH/dk_j are staged in LDS ([slot][row][col], 16 B per element), the loop over c reads
+// D[r][c] (one element per lane) and the row U[c][.] (the same 16 B for all lanes of the node: broadcast reads) and
+// accumulates T[r][b] in registers; the sum over r is a group reduction per band.  One thread per (node, band) re-read
+// the whole D (4 KB at 16 bands) sixteen times per node: 0.25 ms per direction for 24^3 nodes.  (A register-only
+// version -- rows of U travelling by DPP broadcasts -- spilled 670 registers at 16 rows whatever the ordering.)
+template <int NP, int B>
+__device__ __forceinline__ void vel_store1(const double2* __restrict__ urow, const double (&tr)[NP], const double (&ti)[NP], bool act, int r,
+                                           double* __restrict__ vo, int pitch) {
+    const double2 u = urow[B];
+    const double v = group_sum<NP>(u.x * tr[B] + u.y * ti[B]);
+    if (act && r == B) vo[(int64_t)B * pitch] = v;
+}
+template <int NP, int... B>
+__device__ __forceinline__ void vel_store(const double2* __restrict__ urow, const double (&tr)[NP], const double (&ti)[NP], bool act, int r,
+                                          double* __restrict__ vo, int pitch, std::integer_sequence<int, B...>) {
+    (vel_store1<NP, B>(urow, tr, ti, act, r, vo, pitch), ...);
+}
+
+template <int NP>
+__global__ __launch_bounds__(128) void gen_velocity_rows_kernel(PlaneView Uv, PlaneView Dv, PlaneView Vv, int64_t nk, int n) {
+    extern __shared__ double2 lds_v[];  // [SLOTS][NP][NP] U | [SLOTS][NP][NP] D
+    constexpr int SLOTS = 128 / NP;
+    const int slot = threadIdx.x / NP, r = threadIdx.x % NP;
+    const int64_t k = (int64_t)blockIdx.x * SLOTS + slot;
+    const bool act = k < nk && r < n;
+    const int64_t kk = k < nk ? k : nk - 1;
+    double2* const us = lds_v + (size_t)slot * NP * NP;
+    double2* const ds = lds_v + (size_t)(SLOTS + slot) * NP * NP;
+    {
+        const double* __restrict__ u = Uv.base + view_off(Uv, kk);
+        const double* __restrict__ dm = Dv.base + view_off(Dv, kk);
+#pragma unroll
+        for (int j = 0; j < NP; ++j) {
+            const bool in = r < n && j < n;
+            const int rr = in ? r : 0, jj = in ? j : 0;
+            const double a0 = u[(int64_t)(2 * (rr + n * jj)) * Uv.pitch], a1 = u[(int64_t)(2 * (rr + n * jj) + 1) * Uv.pitch];
+            const double b0 = dm[(int64_t)(2 * (rr + n * jj)) * Dv.pitch], b1 = dm[(int64_t)(2 * (rr + n * jj) + 1) * Dv.pitch];
+            us[r * NP + j] = in ? make_double2(a0, a1) : make_double2(0.0, 0.0);
+            ds[r * NP + j] = in ? make_double2(b0, b1) : make_double2(0.0, 0.0);
+        }
+    }
+    __syncthreads();
+    double tr[NP], ti[NP];
+#pragma unroll
+    for (int b = 0; b < NP; ++b) {
+        tr[b] = 0.0;
+        ti[b] = 0.0;
+    }
+    for (int c = 0; c < n; ++c) {
+        const double2 dd = ds[r * NP + c];
+        const double2* __restrict__ uc = us + c * NP;
+#pragma unroll
+        for (int b = 0; b < NP; ++b) {
+            const double2 u = uc[b];
+            tr[b] = fma(dd.x, u.x, tr[b]);
+            tr[b] = fma(-dd.y, u.y, tr[b]);
+            ti[b] = fma(dd.x, u.y, ti[b]);
+            ti[b] = fma(dd.y, u.x, ti[b]);
+        }
+    }
+    double* __restrict__ vo = Vv.base + view_off(Vv, kk);
+    vel_store<NP>(us + r * NP, tr, ti, act, r, vo, Vv.pitch, std::make_integer_sequence<int, NP>());
+}
+
+static bool launch_gen_velocity_rows(abz_ctx* ctx, int n, PlaneView U, PlaneView dH, PlaneView Vj, int64_t nk) {
+    const bool off = [] { const char* e = getenv("ABZ_GEN_VEL_ROWS"); return e && e[0] == '0'; }();  // per call
+    if (off || n <= 4 || n > 16) return false;
+    if (n <= 8)
+        hipLaunchKernelGGL(gen_velocity_rows_kernel<8>, dim3((unsigned)cdiv2(nk, 16)), dim3(128), sizeof(double2) * 2 * 16 * 64, ctx->stream, U, dH,
+                           Vj, nk, n);
+    else
+        hipLaunchKernelGGL(gen_velocity_rows_kernel<16>, dim3((unsigned)cdiv2(nk, 8)), dim3(128), sizeof(double2) * 2 * 8 * 256, ctx->stream, U, dH,
+                           Vj, nk, n);
+    return true;
+}
+
 // TRI: eigenvalues only by Householder + Sturm bisection (its own instance: the Jacobi path of the same kernel costs
 // it 90 more registers and the second wave per SIMD)
 template <int NP, bool PAD, bool VEC, bool TRI>
-__global__ __launch_bounds__(256, TRI ? 2 : 1) void gen_grid_eig_kernel(GenEigArgs a) {
+__global__ __launch_bounds__(256, (TRI && !VEC) ? 2 : 1) void gen_grid_eig_kernel(GenEigArgs a) {
+    static_assert(!(VEC && TRI) || PAD, "inverse iteration works on the zero-padded layout");
     extern __shared__ double2 lds_ge[];
     constexpr int SLOTS = 256 / NP;
     const int n = a.n, nn = n * n, M = a.M;
@@ -1620,7 +1810,17 @@ __global__ __launch_bounds__(256, TRI ? 2 : 1) void gen_grid_eig_kernel(GenEigAr
             if (!a.E.base) continue;  // values only (uniform)
             double vr[NP], vi[NP], dg;
             int rank;
-            if constexpr (TRI) {  // eigenvalues only: Householder + Sturm bisection, lane r gets eigenvalue r
+            if constexpr (TRI && VEC) {  // eigenvalues as below, eigenvectors by inverse iteration on H itself
+                double tr_[NP], ti_[NP];
+#pragma unroll
+                for (int j = 0; j < NP; ++j) {
+                    tr_[j] = hr[j];
+                    ti_[j] = hi[j];
+                }
+                dg = rows_eigvals_tridiag<NP>(n, r, tr_, ti_);
+                rank = r;
+                rows_eigvecs_invit<NP>(n, r, lane, hr, hi, dg, vr, vi);
+            } else if constexpr (TRI) {  // eigenvalues only: Householder + Sturm bisection, lane r gets eigenvalue r
                 dg = rows_eigvals_tridiag<NP>(n, r, hr, hi);
                 rank = r;
             } else {
@@ -1629,7 +1829,12 @@ __global__ __launch_bounds__(256, TRI ? 2 : 1) void gen_grid_eig_kernel(GenEigAr
             if (wr) a.E.base[view_off(a.E, k) + (int64_t)rank * a.E.pitch] = dg;
             if constexpr (VEC) {
                 double ranks[NP];
-                group_gather<NP>((double)rank, ranks, std::make_integer_sequence<int, NP>());
+                if constexpr (TRI) {
+#pragma unroll
+                    for (int j = 0; j < NP; ++j) ranks[j] = (double)j;  // inverse iteration: column j is band j
+                } else {
+                    group_gather<NP>((double)rank, ranks, std::make_integer_sequence<int, NP>());
+                }
                 if (wr) {
                     double* uo = a.U.base + view_off(a.U, k);
 #pragma unroll
@@ -1653,13 +1858,14 @@ static bool gen_grid_eig_supported(const GenSpec& gs, int* np_out, size_t* lds_o
     if (off || !(gs.grid || runs) || gs.deriv || gs.values || gs.Haos || gs.Eaos || !(gs.Eplanes.base || gs.Hplanes.base)) return false;
     if (gs.Eplanes.base && !gs.herm) return false;  // the Jacobi works on full rows: H(k) must be Hermitian to rounding
     static const bool vec_on = [] { const char* e = getenv("ABZ_GEN_ROWEIG_VEC"); return e && e[0] == '1'; }();
-    if (gs.Uplanes.base && gs.n > 8 && !vec_on) return false;  // eigenvectors at 16 rows: the instance spills 4.6 KB, opt-in
+    (void)vec_on;  // 9..16 bands with eigenvectors: inverse iteration (needs the zero-padded layout, checked below)
     if (gs.n <= 4 || gs.n > 16 || gs.npt < 1 || gs.npt >= 65536) return false;
     const int np = gs.n <= 8 ? 8 : 16;
     size_t lds = sizeof(double2) * (size_t)gs.M * np * np;
     *pad_out = lds <= 150 * 1024;
     if (!*pad_out) lds = sizeof(double2) * (size_t)gs.M * gs.n * gs.n;
     if (lds > 150 * 1024) return false;
+    if (gs.Uplanes.base && gs.n > 8 && !*pad_out) return false;
     *np_out = np;
     *lds_out = lds;
     return true;
@@ -1685,13 +1891,16 @@ static int launch_gen_grid_eig(abz_ctx* ctx, const GenSpec& gs, int np, size_t l
     }
     const int64_t blocks = std::min<int64_t>(a.nlines, 256 * 4);
     const bool vec = gs.Uplanes.base != nullptr;
+    const bool jacobi_vec = [] { const char* e = getenv("ABZ_GEN_ROWEIG_VEC"); return e && e[0] == '1'; }();  // 16 rows: the spilling Jacobi (experiment)
     ProfScope ps(ctx, ABZ_K_EVAL);
 #define ABZ_GE3(NPV, PV, VV, TV)                                                                                              \
     ABZ_HIP(hipFuncSetAttribute((const void*)gen_grid_eig_kernel<NPV, PV, VV, TV>, hipFuncAttributeMaxDynamicSharedMemorySize, \
                                 (int)lds));                                                                                   \
     hipLaunchKernelGGL((gen_grid_eig_kernel<NPV, PV, VV, TV>), dim3((unsigned)blocks), dim3(256), lds, ctx->stream, a);
 #define ABZ_GE2(NPV, PV) \
-    if (vec) {           \
+    if (vec && NPV == 16 && PV && !jacobi_vec) { \
+        ABZ_GE3(NPV, true, true, true) \
+    } else if (vec) {    \
         ABZ_GE3(NPV, PV, true, false) \
     } else if (a.tridiag) { \
         ABZ_GE3(NPV, PV, false, true) \

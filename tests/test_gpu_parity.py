@@ -1241,10 +1241,12 @@ def test_ggr_velocities_match_oracle(abz, svo):
     assert np.abs(out["vel"].sum(axis=2) - v.sum(axis=2)).max() < 1e-8
 
 
-def test_ggr_more_than_four_bands(abz):
+@pytest.mark.parametrize("n", [6, 12, 16])
+def test_ggr_more_than_four_bands(abz, n):
     """GGR for n > 4 (ref: src/dos_ggr.jl:1-44 falls back to LAPACK's eigen there): eigenvalues, band velocities
-    and the scanned DOS of a 6-band model against the oracle."""
-    so = orc.synthetic_wannier(n=6, rmax=2, seed=7)
+    and the scanned DOS of 6-, 12- and 16-band models against the oracle (up to 8 bands: row-layout Jacobi with accumulated
+    rotations; 9..16: Householder + bisection eigenvalues and inverse-iteration eigenvectors)."""
+    so = orc.synthetic_wannier(n=n, rmax=2, seed=7)
     s = abz.FourierSeries(so.c, period=1.0, first=so.first, ndim=3)
     rule = s.device().rule(6, None, want=2 | 4)
     out = rule.export(eig=True, vel=True)
