@@ -132,6 +132,8 @@ struct abz_series {
     double period[ABZ_MAX_DIM] = {1, 1, 1};
     bool hermitian = false;   // c(-R) == c(R)^dagger exactly  =>  H(k) Hermitian: half the Fourier work
     size_t coef_cap = 0;
+    abz::DevBuf coef_pk;       // Hermitian series, n <= 4: the coefficients with the innermost variable packed (packed_herm.h)
+    bool coef_pk_valid = false;
     double2* coef = nullptr;  // level d: [M_d]...[M_1][n*n] complex, i_1 fastest (Julia order)
     // pools of contracted coefficient sets: level j (1 <= j < d) holds (j)-dim series of
     // elems(j) = M_1*...*M_j*n*n complex numbers per slot.
@@ -229,6 +231,7 @@ struct EvalSpec {
     const double* x;
     bool deriv;
     bool herm;  // series is Hermitian-symmetric and deriv is false: evaluate the upper triangle only
+    bool packed = false;  // grid mode: `src` holds PACKED Hermitian level-1 sets (packed_herm.h), Pk<n>::size((M - 1) / 2) numbers per line
     // outputs (tiled planar views), base == nullptr when not wanted
     PlaneView H;
     PlaneView E;
@@ -241,6 +244,10 @@ struct EvalSpec {
 };
 int launch_eval(abz_ctx* ctx, const EvalSpec& es);
 bool eval_can_fuse(int n, int M, int M2, int npt);
+bool eval_packed_supported(int n, int M, int npt);
+// rows [nrows][M n n] of full coefficients (innermost variable fastest) -> packed rows [nrows][P] (packed_herm.h)
+int launch_pack_rows(abz_ctx* ctx, int n, int M, const double2* src, int64_t nrows, double2* out);
+size_t packed_row_elems(int n, int M);
 
 int launch_eig_planes(abz_ctx* ctx, int n, PlaneView H, PlaneView E, PlaneView U, int64_t nk);
 // V[b](k) = Re sum_{a,c} conj(U[a,b]) dH[a,c] U[c,b]   (Vj: view of the n planes of one direction)

@@ -388,17 +388,29 @@ static int plan_upload(abz_ctx* ctx, const Plan& p, PlanDev& pd) {
 
 // Build the level-1 coefficient sets for a plan.  deriv_dim (1-based, 0 = none) applies the
 // derivative factor to that variable's phases.  Returns pointer to level-1 sets (or coef if d == 1).
+// packed: the chain runs on the coefficients with the innermost variable packed (Hermitian series, packed_herm.h): rows of
+// P = n (n + 1) / 2 + F n^2 numbers instead of M n^2 -- packing is linear and commutes with every contraction.
 static int build_chain(abz_series* s, const Plan& p, const PlanDev& pd, const double2* tab, int deriv_dim,
-                       const double2** level1, int last_level = 1, DevBuf* last_out = nullptr) {
+                       const double2** level1, int last_level = 1, DevBuf* last_out = nullptr, bool packed = false) {
     abz_ctx* ctx = s->ctx;
     const int d = s->d;
-    const double2* src = s->coef;
-    int64_t src_elems = s->elems(d);
+    const int64_t row_full = (int64_t)s->dims[0] * s->n * s->n;
+    const int64_t row_len = packed ? (int64_t)packed_row_elems(s->n, s->dims[0]) : row_full;
+    auto elems_of = [&](int level) { return s->elems(level) / row_full * row_len; };  // numbers per level-`level` set
+    if (packed && !s->coef_pk_valid) {
+        const int64_t nrows = s->elems(d) / row_full;
+        int rc = s->coef_pk.reserve(sizeof(double2) * (size_t)(nrows * row_len));
+        if (rc) return rc;
+        if ((rc = launch_pack_rows(ctx, s->n, s->dims[0], s->coef, nrows, s->coef_pk.as<double2>()))) return rc;
+        s->coef_pk_valid = true;
+    }
+    const double2* src = packed ? s->coef_pk.as<double2>() : s->coef;
+    int64_t src_elems = elems_of(d);
     for (int L = d - 1; L >= last_level; --L) {  // last_level = 2: stop at the level-2 sets (fused last contraction)
         // contract variable L+1 (0-based dim index L)
         const int64_t B = p.nitems[L];
         const int M = s->dims[L];
-        const int64_t Lrow = s->elems(L);
+        const int64_t Lrow = elems_of(L);
         // the sets of the last level go to `last_out` when given (several families alive at once: fused GGR build)
         DevBuf& ob = (L == last_level && last_out) ? *last_out : s->pool[L];
         int rc = ob.reserve(sizeof(double2) * (size_t)std::max<int64_t>(B * Lrow, 1));
@@ -498,6 +510,7 @@ static void series_release(abz_series* s) {
     for (auto& q : s->iai_pin)
         if (q) (void)hipHostFree(q);
     dev_free(s->coef, s->coef_cap);
+    s->coef_pk.release();
     delete s;
     ctx_release(ctx);
 }
@@ -697,6 +710,7 @@ int abz_series_update(abz_series* s, const double* coef_reim) {
                            s->ctx->stream));
     ABZ_HIP(hipStreamSynchronize(s->ctx->stream));
     s->hermitian = detect_hermitian(s, coef_reim);
+    s->coef_pk_valid = false;
     return ABZ_OK;
 }
 
@@ -816,6 +830,9 @@ static int rule_fill(abz_rule* r) {
         Dv = Uv;
         Dv.base = rp->tmpD.as<double>();
     }
+    // full grids of a Hermitian series (n <= 4, values / eigenvalues only): the chain and the grid kernel work on packed sets
+    const bool packed_chain = r->full && s->hermitian && !(r->want & ABZ_WANT_VEL) && eval_packed_supported(n, s->dims[0], r->npt) &&
+                              !(d >= 2 && eval_can_fuse(n, s->dims[0], s->dims[1], r->npt));
     auto run_eval = [&](const double2* level1, bool deriv, PlaneView Hout, PlaneView Eout, PlaneView Uout) -> int {
         EvalSpec es;
         es.n = n;
@@ -837,6 +854,7 @@ static int rule_fill(abz_rule* r) {
         es.x = nullptr;
         es.deriv = deriv;
         es.herm = s->hermitian;
+        es.packed = packed_chain && !deriv && !Uout.base;
         es.H = Hout;
         es.E = Eout;
         es.U = Uout;
@@ -878,7 +896,7 @@ static int rule_fill(abz_rule* r) {
         if ((rc = build_chain(s, plan, rp->pd, tab, 0, &level1, 2))) return rc;
         if ((rc = run_fused(level1, false, false, r->H, r->E, Uv))) return rc;
     } else {
-        if ((rc = build_chain(s, plan, rp->pd, tab, 0, &level1))) return rc;
+        if ((rc = build_chain(s, plan, rp->pd, tab, 0, &level1, 1, nullptr, packed_chain))) return rc;
         if ((rc = run_eval(level1, false, r->H, r->E, Uv))) return rc;
     }
     if (r->want & ABZ_WANT_VEL) {

@@ -22,6 +22,7 @@
 #include "device_math.h"
 #include "gk15.h"
 #include "inner_adapt.h"
+#include "packed_herm.h"
 
 #include <cmath>
 #include <cstring>
@@ -389,6 +390,7 @@ struct EvalArgs {
     int M, first, npt, deriv, herm;
     int nt;  // non-temporal stores (rule values larger than the Infinity Cache)
     int padw;  // write the padding columns npt..pitch-1 too (whole 128-B lines); 0: experiment ABZ_PAD_WRITE=0
+    int pk;    // the level-1 sets are PACKED Hermitian sets (packed_herm.h): Pk<N>::size((M - 1) / 2) numbers per line
     double inv_period;
     // fused last contraction (eval_grid_fused_kernel): level-2 sets and the contracted variable
     const double2* src2;
@@ -450,10 +452,89 @@ constexpr int EVAL_MAX_MNN = 256;  // complex coefficients per line held in LDS 
 // One unit of work of the grid kernels: pass `pass` (64 KPL nodes starting at i0) of line `line`, from the
 // line's coefficients c1 (LDS).  `mid` runs between the m-loop and the stores: the place where the next
 // unit's coefficients are handed to the other LDS buffer.
-template <int N, int KPL, bool HERM, class MID>
+template <int N, int KPL, bool HERM, class MID, bool PK = false>
 __device__ __forceinline__ void eval_unit_core(const EvalArgs& a, const double2* __restrict__ c1, const double2* tab_l, int fm,
                                                const int (&iz0)[KPL], const int (&iw0)[KPL], int npass, int i0, int lane,
                                                MID&& mid, CMat<N> (&H)[KPL]) {
+    if constexpr (PK) {
+        // packed Hermitian set (packed_herm.h): +f and -f in one FMA group, phases z^f from z alone -- half the Fourier
+        // work of the loop over 2 F + 1 terms below
+        static_assert(HERM, "packed sets exist for Hermitian series only");
+        const int F = (a.M - 1) / 2;
+        double zr[KPL], zi[KPL], pr[KPL], pi[KPL];
+#pragma unroll
+        for (int j = 0; j < KPL; ++j) {
+            int ic = iz0[j];
+            if (npass > 1) {
+                const int i1 = i0 + lane + 64 * j;
+                ic = i1 < a.npt ? i1 : 0;
+            }
+            const double2 z = tab_l[ic];
+            zr[j] = z.x;
+            zi[j] = z.y;
+            pr[j] = 1.0;
+            pi[j] = 0.0;
+        }
+#pragma unroll
+        for (int bb = 0; bb < N; ++bb) {
+#pragma unroll
+            for (int aa = 0; aa <= bb; ++aa) {
+                const double2 c = c1[Pk<N>::tri(aa, bb)];
+#pragma unroll
+                for (int j = 0; j < KPL; ++j) {
+                    H[j].re[aa][bb] = c.x;
+                    H[j].im[aa][bb] = (aa == bb) ? 0.0 : c.y;
+                }
+            }
+        }
+        for (int f = 1; f <= F; ++f) {
+#pragma unroll
+            for (int j = 0; j < KPL; ++j) {
+                const double nr = pr[j] * zr[j] - pi[j] * zi[j];
+                const double ni = pr[j] * zi[j] + pi[j] * zr[j];
+                pr[j] = nr;
+                pi[j] = ni;
+            }
+            const double2* __restrict__ cf = c1 + Pk<N>::blk(1) + (f - 1) * (N * N);
+#pragma unroll
+            for (int aa = 0; aa < N; ++aa) {
+                const double2 dd = cf[aa];
+#pragma unroll
+                for (int j = 0; j < KPL; ++j) {
+                    H[j].re[aa][aa] = fma(dd.x, pr[j], H[j].re[aa][aa]);
+                    H[j].re[aa][aa] = fma(-dd.y, pi[j], H[j].re[aa][aa]);
+                }
+            }
+#pragma unroll
+            for (int bb = 1; bb < N; ++bb) {
+#pragma unroll
+                for (int aa = 0; aa < bb; ++aa) {
+                    const double2 sv = cf[N + 2 * Pk<N>::pair(aa, bb)];
+                    const double2 tv = cf[N + 2 * Pk<N>::pair(aa, bb) + 1];
+#pragma unroll
+                    for (int j = 0; j < KPL; ++j) {
+                        H[j].re[aa][bb] = fma(sv.x, pr[j], H[j].re[aa][bb]);
+                        H[j].re[aa][bb] = fma(-sv.y, pi[j], H[j].re[aa][bb]);
+                        H[j].im[aa][bb] = fma(tv.x, pi[j], H[j].im[aa][bb]);
+                        H[j].im[aa][bb] = fma(tv.y, pr[j], H[j].im[aa][bb]);
+                    }
+                }
+            }
+        }
+        mid();
+#pragma unroll
+        for (int j = 0; j < KPL; ++j) {
+#pragma unroll
+            for (int bb = 0; bb < N; ++bb) {
+#pragma unroll
+                for (int aa = bb + 1; aa < N; ++aa) {
+                    H[j].re[aa][bb] = H[j].re[bb][aa];
+                    H[j].im[aa][bb] = -H[j].im[bb][aa];
+                }
+            }
+        }
+        return;
+    }
     double zr[KPL], zi[KPL], pr[KPL], pi[KPL];
 #pragma unroll
     for (int j = 0; j < KPL; ++j) {
@@ -571,12 +652,12 @@ __device__ __forceinline__ void eval_unit_store(const EvalArgs& a, CMat<N> (&H)[
     }
 }
 
-template <int N, int KPL, bool HERM, bool VEC, class MID>
+template <int N, int KPL, bool HERM, bool VEC, class MID, bool PK = false>
 __device__ __forceinline__ void eval_unit(const EvalArgs& a, const double2* __restrict__ c1, const double2* tab_l, int fm,
                                           const int (&iz0)[KPL], const int (&iw0)[KPL], int npass, int i0, int lane,
                                           int64_t line, MID&& mid) {
     CMat<N> H[KPL];
-    eval_unit_core<N, KPL, HERM>(a, c1, tab_l, fm, iz0, iw0, npass, i0, lane, mid, H);
+    eval_unit_core<N, KPL, HERM, MID&, PK>(a, c1, tab_l, fm, iz0, iw0, npass, i0, lane, mid, H);
     eval_unit_store<N, KPL, VEC>(a, H, i0, lane, line);
 }
 
@@ -586,13 +667,13 @@ __device__ __forceinline__ void wave_lds_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-template <int N, int KPL, bool HERM, bool VEC, int OCC>
+template <int N, int KPL, bool HERM, bool VEC, int OCC, bool PK = false>
 __global__ __launch_bounds__(256, OCC) void eval_grid_kernel(EvalArgs a) {
     extern __shared__ double2 lds_c[];  // [4 waves][2 buffers][MNN]
     // the wave index is made an SGPR value: every per-line quantity (tile base, coefficient row) is
     // then scalar arithmetic
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-    const int MNN = a.M * N * N;
+    const int MNN = PK ? Pk<N>::size((a.M - 1) / 2) : a.M * N * N;  // numbers per line
     // derivative series: coefficient m is scaled by 2 pi i (first + m) once, on its way into LDS
     auto stage = [&](double2 c, int idx) -> double2 {
         if (!a.deriv) return c;
@@ -647,8 +728,7 @@ __global__ __launch_bounds__(256, OCC) void eval_grid_kernel(EvalArgs a) {
             }
         }
         wave_lds_sync();
-        eval_unit<N, KPL, HERM, VEC>(a, mybuf + (size_t)cur * MNN, tab_l, fm, iz0, iw0, npass, pass * (64 * KPL), lane, line,
-                                     [&]() {
+        auto mid_fn = [&]() {
             // The one wait of the loop body: the fetched registers are consumed here, unconditionally and
             // before this unit's stores are issued (the asm pins the point; nothing is hoisted above it).
 #pragma unroll
@@ -661,7 +741,9 @@ __global__ __launch_bounds__(256, OCC) void eval_grid_kernel(EvalArgs a) {
                     if (idx < MNN) dst[idx] = stage(pre[t], idx);
                 }
             }
-        });
+        };
+        eval_unit<N, KPL, HERM, VEC, decltype(mid_fn)&, PK>(a, mybuf + (size_t)cur * MNN, tab_l, fm, iz0, iw0, npass, pass * (64 * KPL), lane, line,
+                                                            mid_fn);
         cur ^= 1;
         pass = last_pass ? 0 : pass + 1;
         line = nline;
@@ -841,6 +923,14 @@ bool eval_can_fuse(int n, int M, int M2, int npt) {
     return mnn <= EVAL_MAX_MNN && npt < 65536 && lds <= 48 * 1024;
 }
 
+// Can the grid kernel take packed Hermitian level-1 sets (packed_herm.h)?  Same limits as its LDS-staged path.
+bool eval_packed_supported(int n, int M, int npt) {
+    const bool off = [] { const char* e = getenv("ABZ_EVAL_PACKED"); return e && e[0] == '0'; }();  // per call: tests compare both chains
+    if (off || n < 1 || n > 4 || (M & 1) == 0) return false;
+    const size_t P = packed_row_elems(n, M);
+    return P <= (size_t)EVAL_MAX_MNN && npt < 65536 && sizeof(double2) * (4 * 2 * P + (size_t)npt) <= 64 * 1024;
+}
+
 static int eval_occ() {  // read per launch: tools/time_eval_blocks.py sweeps it on one buffer
     const char* e = getenv("ABZ_EVAL_OCC");
     const int v = e ? atoi(e) : 3;
@@ -909,6 +999,7 @@ int launch_eval(abz_ctx* ctx, const EvalSpec& es) {
         static const int padw = [] { const char* e = getenv("ABZ_PAD_WRITE"); return e ? atoi(e) : 1; }();
         a.padw = padw;
     }
+    a.pk = (es.packed && a.herm && !es.U.base && es.grid && !es.src2) ? 1 : 0;
     a.src2 = es.src2;
     a.M2 = es.M2;
     a.first2 = es.first2;
@@ -925,7 +1016,7 @@ int launch_eval(abz_ctx* ctx, const EvalSpec& es) {
         const int eval_blocks = [] { const char* e = getenv("ABZ_EVAL_BLOCKS"); return e ? atoi(e) : 0; }();  // per launch: the timing tool sweeps it
         const int64_t quads = cdiv(es.nlines, 4);
         int64_t blocks = std::min<int64_t>(quads, eval_blocks > 0 ? eval_blocks : (quads < 5000 ? 256 * 8 : 256 * 16));
-        const int mnn = es.M * es.n * es.n;
+        const int mnn = a.pk ? es.n * (es.n + 1) / 2 + ((es.M - 1) / 2) * es.n * es.n : es.M * es.n * es.n;  // numbers per line (packed_herm.h)
         // nodes per lane: minimise lane-rounds per line, ceil(npt / (64 kpl)) * kpl, weighted by the LDS
         // operand reads that are shared by the kpl nodes of a lane (200 points: 2 x 2 rounds, not 2 x 3)
         int kpl = 1;
@@ -978,7 +1069,9 @@ int launch_eval(abz_ctx* ctx, const EvalSpec& es) {
 #undef LKF
         } else if (mnn <= EVAL_MAX_MNN && lds <= 64 * 1024 && a.npt < 65536) {
 #define LKO(NN, KK, OO)                                                                                                        \
-    if (a.U.base)                                                                                                              \
+    if (a.pk)                                                                                                                  \
+        hipLaunchKernelGGL((eval_grid_kernel<NN, KK, true, false, OO, true>), dim3((unsigned)blocks), dim3(256), lds, ctx->stream, a); \
+    else if (a.U.base)                                                                                                         \
         hipLaunchKernelGGL((eval_grid_kernel<NN, KK, false, true, 2>), dim3((unsigned)blocks), dim3(256), lds, ctx->stream, a);  \
     else if (a.herm)                                                                                                           \
         hipLaunchKernelGGL((eval_grid_kernel<NN, KK, true, false, OO>), dim3((unsigned)blocks), dim3(256), lds, ctx->stream, a); \

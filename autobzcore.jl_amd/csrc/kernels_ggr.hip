@@ -40,6 +40,7 @@
 
 #include "abz_internal.h"
 #include "device_math.h"
+#include "packed_herm.h"
 
 namespace abz {
 
@@ -48,44 +49,6 @@ namespace {
 constexpr double TWO_PI = 6.283185307179586476925286766559;
 
 inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }
-
-// ---- packed Hermitian coefficient sets: element index of ...
-template <int N>
-struct Pk {
-    static constexpr int NT0 = N * (N + 1) / 2;                                   // elements of the f = 0 block
-    __host__ __device__ static constexpr int tri(int a, int b) { return b * (b + 1) / 2 + a; }  // c1[0]_ab, a <= b
-    __host__ __device__ static constexpr int blk(int f) { return NT0 + (f - 1) * N * N; }        // first element of block f >= 1
-    __host__ __device__ static constexpr int dd(int f, int a) { return blk(f) + a; }
-    __host__ __device__ static constexpr int pair(int a, int b) { return b * (b - 1) / 2 + a; }  // a < b
-    __host__ __device__ static constexpr int ss(int f, int a, int b) { return blk(f) + N + 2 * pair(a, b); }
-    __host__ __device__ static constexpr int tt(int f, int a, int b) { return ss(f, a, b) + 1; }
-    __host__ __device__ static constexpr int size(int F) { return NT0 + F * N * N; }
-};
-
-// packed element e of the set whose full coefficients are c[m][a + N b] (m = 0 .. 2F, frequency m - F)
-template <int N>
-__device__ __forceinline__ double2 pk_from_full(const double2* __restrict__ c, int F, int e) {
-    constexpr int NN = N * N;
-    if (e < Pk<N>::NT0) {
-        int b = 0;
-        while ((b + 1) * (b + 2) / 2 <= e) ++b;
-        const int a = e - b * (b + 1) / 2;
-        return c[F * NN + a + N * b];
-    }
-    const int r = e - Pk<N>::NT0;
-    const int f = r / NN + 1, q = r - (f - 1) * NN;
-    const double2* __restrict__ cf = c + (F + f) * NN;
-    if (q < N) {
-        const double2 v = cf[q + N * q];
-        return make_double2(2.0 * v.x, 2.0 * v.y);
-    }
-    const int pi = (q - N) >> 1;
-    int b = 1;
-    while ((b + 1) * b / 2 <= pi) ++b;
-    const int a = pi - b * (b - 1) / 2;
-    const double2 u = cf[a + N * b], v = cf[b + N * a];
-    return ((q - N) & 1) ? make_double2(u.x - v.x, u.y - v.y) : make_double2(u.x + v.x, u.y + v.y);
-}
 
 struct GgrBuildArgs {
     const double2* src[3];   // !FUSE: level-1 sets, slot stride M n n: [0] plain, [j-1] derivative on variable j
@@ -685,6 +648,35 @@ __global__ __launch_bounds__(256) void ggr_build_nodes_kernel(GgrBuildArgs a) {
 }
 
 }  // namespace
+
+// rows of full coefficients [M][n n] -> packed rows (packed_herm.h); linear, so it commutes with every contraction
+template <int N>
+__global__ __launch_bounds__(256) void pack_rows_kernel(const double2* __restrict__ src, int64_t nrows, int M, double2* __restrict__ out) {
+    const int F = (M - 1) / 2;
+    const int P = Pk<N>::size(F);
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= nrows * P) return;
+    const int64_t row = t / P;
+    const int e = (int)(t - row * P);
+    out[t] = pk_from_full<N>(src + row * ((int64_t)M * N * N), F, e);
+}
+
+size_t packed_row_elems(int n, int M) { return (size_t)(n * (n + 1) / 2 + ((M - 1) / 2) * n * n); }
+
+int launch_pack_rows(abz_ctx* ctx, int n, int M, const double2* src, int64_t nrows, double2* out) {
+    const int64_t tot = nrows * (int64_t)packed_row_elems(n, M);
+    if (tot == 0) return ABZ_OK;
+    const unsigned blocks = (unsigned)cdiv64(tot, 256);
+    switch (n) {
+        case 1: hipLaunchKernelGGL(pack_rows_kernel<1>, dim3(blocks), dim3(256), 0, ctx->stream, src, nrows, M, out); break;
+        case 2: hipLaunchKernelGGL(pack_rows_kernel<2>, dim3(blocks), dim3(256), 0, ctx->stream, src, nrows, M, out); break;
+        case 3: hipLaunchKernelGGL(pack_rows_kernel<3>, dim3(blocks), dim3(256), 0, ctx->stream, src, nrows, M, out); break;
+        case 4: hipLaunchKernelGGL(pack_rows_kernel<4>, dim3(blocks), dim3(256), 0, ctx->stream, src, nrows, M, out); break;
+        default: set_error("packed rows exist for n <= 4"); return ABZ_ERR_UNSUPPORTED;
+    }
+    ABZ_HIP(hipGetLastError());
+    return ABZ_OK;
+}
 
 // LDS bytes of the kernels
 static size_t ggr_packed(int n, int M) { return (size_t)(n * (n + 1) / 2 + ((M - 1) / 2) * n * n); }
