@@ -1374,7 +1374,8 @@ int abz_ptr_sum(abz_series* s, int npt, int outer_begin, int outer_end, int inte
         if ((rc = launch_phases(ctx, ps, pd.phg[L].as<double2>()))) return done(rc);
     }
     const double2* level1 = nullptr;
-    if ((rc = build_chain(s, plan, pd, tab.as<double2>(), 0, &level1))) return done(rc);
+    // n <= 4: the store-free kernel takes packed Hermitian sets (eval_sum_supported requires a Hermitian series)
+    if ((rc = build_chain(s, plan, pd, tab.as<double2>(), 0, &level1, 1, nullptr, !generic))) return done(rc);
     SumSpec ss;
     ss.n = n;
     ss.d = d;

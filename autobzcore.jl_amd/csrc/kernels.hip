@@ -1527,7 +1527,8 @@ __global__ __launch_bounds__(256, 2) void eval_sum_grid_kernel(EvalArgs a, SumAr
     extern __shared__ double2 lds_c[];  // [4 waves][2 buffers][MNN] | [npt] table
     constexpr int NC = NComp<FID>::template value<N>();
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-    const int MNN = a.M * N * N;
+    // the level-1 sets are PACKED Hermitian sets (packed_herm.h): this kernel serves Hermitian series only
+    const int MNN = Pk<N>::size((a.M - 1) / 2);
     double2* const mybuf = lds_c + (size_t)wave * 2 * MNN;
     int fm = a.first % a.npt;
     if (fm < 0) fm += a.npt;
@@ -1579,7 +1580,7 @@ __global__ __launch_bounds__(256, 2) void eval_sum_grid_kernel(EvalArgs a, SumAr
         wave_lds_sync();
         const int i0 = pass * (64 * KPL);
         CMat<N> H[KPL];
-        eval_unit_core<N, KPL, HERM>(a, mybuf + (size_t)cur * MNN, tab_l, fm, iz0, iw0, npass, i0, lane, [=]() {
+        auto mid_fn = [=]() {  // by value: by reference the prefetched registers made an 80-B scratch round trip per unit
             if (have_next) {
                 double2* dst = mybuf + (size_t)(cur ^ 1) * MNN;
 #pragma unroll
@@ -1588,7 +1589,8 @@ __global__ __launch_bounds__(256, 2) void eval_sum_grid_kernel(EvalArgs a, SumAr
                     if (idx < MNN) dst[idx] = pre[t];
                 }
             }
-        }, H);
+        };
+        eval_unit_core<N, KPL, HERM, decltype(mid_fn)&, true>(a, mybuf + (size_t)cur * MNN, tab_l, fm, iz0, iw0, npass, i0, lane, mid_fn, H);
         // integrand at the unit's nodes
 #pragma unroll
         for (int j = 0; j < KPL; ++j) {
@@ -1732,7 +1734,7 @@ int launch_eval_sum(abz_ctx* ctx, const SumSpec& ss, double* out_reim) {
             }
         }
     }
-    const int mnn = ss.M * ss.n * ss.n;
+    const int mnn = (int)packed_row_elems(ss.n, ss.M);  // packed Hermitian level-1 sets (packed_herm.h)
     const size_t lds = sizeof(double2) * (4 * 2 * (size_t)mnn + (size_t)ss.npt);
     const int64_t blocks = std::min<int64_t>(cdiv(ss.nlines, 4), 256 * 8);
     // scalar integrands: up to 8 sweep values share the H(k) of a node (must match the NW of the dispatch below)
