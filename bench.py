@@ -84,10 +84,10 @@ def spawn_ranks(a):
 
 def pmc_traffic(npt):
     """HBM bytes per launch of the Fourier-eval kernel from the committed rocprofv3 PMC passes
-    (profiles/r02_traffic.json or r01_traffic.json, written by tools/collect_profiles.sh: WRITE_SIZE and
+    (profiles/r03_traffic.json (or an earlier round's), written by tools/collect_profiles.sh: WRITE_SIZE and
     FETCH_SIZE in separate --pmc runs, FETCH_SIZE doubled per the gfx950 correction).  None if not
     collected for this grid size: counters cannot be read from inside an un-profiled bench run."""
-    for name in ("r02_traffic.json", "r01_traffic.json"):
+    for name in ("r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):
         try:
             t = json.load(open(os.path.join(ROOT, "profiles", name)))
             if int(t.get("npt", -1)) == int(npt):
