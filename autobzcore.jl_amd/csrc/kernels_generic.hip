@@ -571,6 +571,138 @@ __device__ __forceinline__ void panel_invert_rows(int n, int r, double (&ar)[NP]
     panel_pivots<NP, !PAD>(n, r, ar, ai, std::make_integer_sequence<int, NP>());
 }
 
+// sin(pi t), cos(pi t) for finite |t| < 2^30: t = k/2 + r, |r| <= 1/4, Taylor polynomials in r (|pi r| <= 0.785:
+// 8 + 8 terms, 1 ulp), quadrant by k.  The library routine costs twice the instructions and keeps its coefficients in
+// VGPRs that this kernel has to spill; here they are kernel arguments (scalar operands of the FMAs).
+__device__ __forceinline__ void sincospi_poly(const double (&sc)[16], double t, double& s, double& c) {
+    const double k = rint(t + t);
+    const double r = fma(-0.5, k, t);
+    const int q = (int)k;
+    const double r2 = r * r;
+    double p = sc[7];
+#pragma unroll
+    for (int i = 6; i >= 1; --i) p = fma(p, r2, sc[i]);
+    const double sn = fma(r * r2, p, r * sc[0]);
+    double u = sc[15];
+#pragma unroll
+    for (int i = 14; i >= 8; --i) u = fma(u, r2, sc[i]);
+    const double cs = fma(r2, u, 1.0);
+    const bool odd = q & 1;
+    const double ss = odd ? cs : sn, cc = odd ? sn : cs;
+    s = __hiloint2double(__double2hiint(ss) ^ ((q & 2) << 30), __double2loint(ss));
+    c = __hiloint2double(__double2hiint(cc) ^ (((q + 1) & 2) << 30), __double2loint(cc));
+}
+
+// ---- Gauss-Jordan with the pivot-row broadcast folded INTO the FMAs (16 lanes per node, trace of the inverse only) ----
+// `v_fmac_f64_dpp dst, src0, src1 row_newbcast:C` computes dst += src0[lane C of the row] * src1: no separate broadcast
+// move (panel_pivot above: 2 moves + 4 FMAs per complex column, here 4 FMAs).  Reading the pivot row straight out of the
+// registers that the same FMAs update is only legal if lane C's row does NOT change while the others read it, so the
+// pivot row's own scaling by 1/p is deferred: lane C runs the column updates with g = 0 (a + 0 * b = a, its registers
+// are rewritten with the same values) and keeps q = 1/p; the row it holds from then on is p times the true row, which
+// the later pivots' updates preserve (g_C' = -a_CC'/p' on the stored row is p times the true multiplier), and the
+// diagonal element of the inverse is a_rr * q_r at the end.  The compiler does not fold `v_mov_b64_dpp` into the FMA by
+// itself and its hazard recogniser does not look inside inline asm: every asm block starts with the two wait states a
+// DPP read needs after a VALU write of its source (`s_nop 1`); inside a block the only DPP reads of a register written
+// one instruction earlier are reads of lane C's unchanged values.
+template <int C>
+__device__ __forceinline__ void fmac_col_bcast(double& xr, double& xi, double gr, double gi, double ngi) {
+    asm("s_nop 1\n\t"
+        "v_fmac_f64_dpp %0, %0, %2 row_newbcast:%5 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f64_dpp %0, %1, %4 row_newbcast:%5 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f64_dpp %1, %1, %2 row_newbcast:%5 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f64_dpp %1, %0, %3 row_newbcast:%5 row_mask:0xf bank_mask:0xf"
+        : "+v"(xr), "+v"(xi)
+        : "v"(gr), "v"(gi), "v"(ngi), "n"(C));
+}
+
+template <int C>
+__device__ __forceinline__ void pivot_bcast(double ar, double ai, double& pr, double& pi) {
+    asm("s_nop 1\n\t"
+        "v_mov_b64_dpp %0, %2 row_newbcast:%4 row_mask:0xf bank_mask:0xf\n\t"
+        "v_mov_b64_dpp %1, %3 row_newbcast:%4 row_mask:0xf bank_mask:0xf"
+        : "=&v"(pr), "=&v"(pi)
+        : "v"(ar), "v"(ai), "n"(C));
+}
+
+// Lane C's special cases of pivot C in one exec-masked block (lane C of each 16-lane row): g = 0, q = 1/p.  Five
+// `v_mov_b64` under a scalar exec switch instead of a dozen `v_cndmask_b32`; the scalar instructions issue beside the
+// other waves' VALU work.  No DPP instruction runs under the narrowed exec.
+template <int C>
+__device__ __forceinline__ void pivot_lane_fixup(double& gr, double& gi, double& ngi, double& qr, double& qi, double ipr, double ipi) {
+    constexpr unsigned long long mask = 0x0001000100010001ull << C;
+    unsigned long long saved;
+    asm("s_mov_b64 %[sv], exec\n\t"
+        "s_and_b64 exec, %[sv], %[mk]\n\t"
+        "v_mov_b64 %[gr], 0\n\t"
+        "v_mov_b64 %[gi], 0\n\t"
+        "v_mov_b64 %[ngi], 0\n\t"
+        "v_mov_b64 %[qr], %[ipr]\n\t"
+        "v_mov_b64 %[qi], %[ipi]\n\t"
+        "s_mov_b64 exec, %[sv]"
+        : [gr] "+v"(gr), [gi] "+v"(gi), [ngi] "+v"(ngi), [qr] "+v"(qr), [qi] "+v"(qi), [sv] "=&s"(saved)
+        : [mk] "s"(mask), [ipr] "v"(ipr), [ipi] "v"(ipi)
+        : "scc");
+}
+
+template <int C>
+__device__ __forceinline__ void fmac_pivot(int r, double (&ar)[16], double (&ai)[16], double& qr, double& qi) {
+    double pr, pi;
+    pivot_bcast<C>(ar[C], ai[C], pr, pi);
+    const double inv = rcp_nr(pr * pr + pi * pi);
+    const double ipr = pr * inv, ipi = -pi * inv;  // 1 / pivot
+    const double fr = ar[C], fi = ai[C];
+    double gr = -(fr * ipr - fi * ipi);
+    double ngi = fr * ipi + fi * ipr;
+    double gi = -ngi;
+    pivot_lane_fixup<C>(gr, gi, ngi, qr, qi, ipr, ipi);
+#pragma unroll
+    for (int j = 0; j < 16; ++j)
+        if (j != C) fmac_col_bcast<C>(ar[j], ai[j], gr, gi, ngi);
+    // column C: the multipliers; the pivot row stays unscaled, its column-C element is p * (1/p) = 1 (g = 0 there: only
+    // the high word differs from the multiplier's)
+    ar[C] = __hiloint2double(r == C ? 0x3ff00000 : __double2hiint(gr), __double2loint(gr));
+    ai[C] = gi;
+}
+
+template <int... C>
+__device__ __forceinline__ void fmac_pivots(int r, double (&ar)[16], double (&ai)[16], double& qr, double& qi,
+                                            std::integer_sequence<int, C...>) {
+    (fmac_pivot<C>(r, ar, ai, qr, qi), ...);
+}
+
+#define ABZ_DIAG_STEP(j) "s_and_b64 exec, %[sv], %[mk]\n\tv_mov_b64 %[dr], %[r" #j "]\n\tv_mov_b64 %[di], %[i" #j "]\n\ts_lshl_b64 %[mk], %[mk], 1\n\t"
+template <int J0>
+__device__ __forceinline__ void diag_capture8(const double (&ar)[16], const double (&ai)[16], double& dr, double& di) {
+    unsigned long long mask = 0x0001000100010001ull << J0, saved;
+    asm("s_mov_b64 %[sv], exec\n\t"
+        ABZ_DIAG_STEP(0) ABZ_DIAG_STEP(1) ABZ_DIAG_STEP(2) ABZ_DIAG_STEP(3) ABZ_DIAG_STEP(4) ABZ_DIAG_STEP(5) ABZ_DIAG_STEP(6) ABZ_DIAG_STEP(7)
+        "s_mov_b64 exec, %[sv]"
+        : [dr] "+v"(dr), [di] "+v"(di), [mk] "+s"(mask), [sv] "=&s"(saved)
+        : [r0] "v"(ar[J0]), [r1] "v"(ar[J0 + 1]), [r2] "v"(ar[J0 + 2]), [r3] "v"(ar[J0 + 3]), [r4] "v"(ar[J0 + 4]), [r5] "v"(ar[J0 + 5]),
+          [r6] "v"(ar[J0 + 6]), [r7] "v"(ar[J0 + 7]), [i0] "v"(ai[J0]), [i1] "v"(ai[J0 + 1]), [i2] "v"(ai[J0 + 2]), [i3] "v"(ai[J0 + 3]),
+          [i4] "v"(ai[J0 + 4]), [i5] "v"(ai[J0 + 5]), [i6] "v"(ai[J0 + 6]), [i7] "v"(ai[J0 + 7])
+        : "scc");
+}
+#undef ABZ_DIAG_STEP
+
+// trace of the inverse of the zero-padded 16 x 16 matrix whose row r this lane holds (rows >= n: identity rows)
+__device__ __forceinline__ void panel_inverse_trace_fmac(int n, int r, double (&ar)[16], double (&ai)[16], double& tr, double& ti) {
+    double qr = 1.0, qi = 0.0;
+    fmac_pivots(r, ar, ai, qr, qi, std::make_integer_sequence<int, 16>());
+    // lane r's diagonal element a_rr: two moves per column under the exec mask of lane j of every row (a select chain
+    // costs four `v_cndmask_b32` per column)
+    double dr = 0.0, di = 0.0;
+    diag_capture8<0>(ar, ai, dr, di);
+    diag_capture8<8>(ar, ai, dr, di);
+    tr = r < n ? dr * qr - di * qi : 0.0;
+    ti = r < n ? dr * qi + di * qr : 0.0;
+#pragma unroll
+    for (int off = 8; off > 0; off >>= 1) {
+        tr += __shfl_xor(tr, off, 64);
+        ti += __shfl_xor(ti, off, 64);
+    }
+}
+
 template <int NP, bool PAD>
 __device__ __forceinline__ void panel_inverse_row(const double2* coef, int n, int M, int first,
                                                   double xx, double sw, double eta, int r, double (&ar)[NP],
@@ -767,17 +899,21 @@ __device__ __forceinline__ void panel_stage(double2* coef, const double2* __rest
 // conj(c_f,jr) z^-f].  With s = c_f,rj + c_f,jr and t = c_f,rj - c_f,jr (staged instead of c_f and c_-f: the same LDS bytes)
 //   H_rj += (s.x pr - s.y pi) + i (t.x pi + t.y pr),   p = z^f = (pr, pi)
 // one FMA group serves +f and -f: half the series flops of panel_series_row, one sincospi per node instead of two.
-// Layout [1 + 2 F][NP * NP]: block 0 = c_0, block 2 f - 1 = s_f, block 2 f = t_f, element (row rr, column j) at j * NP + rr.
+// Layout [1 + 2 F][NP * NP]: block 0 = (sw + i eta) I - c_0 with identity rows in the padding (the integral's shift is
+// constant over its whole adaptive loop: no per-node diagonal select), block 2 f - 1 = s_f, block 2 f = t_f, element
+// (row rr, column j) at j * NP + rr.
 template <int NP>
-__device__ __forceinline__ void panel_stage_fold(double2* coef, const double2* __restrict__ src, int n, int M) {
+__device__ __forceinline__ void panel_stage_fold(double2* coef, const double2* __restrict__ src, int n, int M, double sw, double eta) {
     const int F = (M - 1) / 2, nn = n * n;
     for (int t = threadIdx.x; t < M * NP * NP; t += blockDim.x) {
         const int b = t / (NP * NP), e = t - b * (NP * NP);
         const int rr = e % NP, j = e / NP;
         double2 v = make_double2(0.0, 0.0);
+        if (b == 0 && rr == j) v = rr < n ? make_double2(sw, eta) : make_double2(1.0, 0.0);
         if (rr < n && j < n) {
             if (b == 0) {
-                v = src[(size_t)F * nn + rr + n * j];
+                const double2 c = src[(size_t)F * nn + rr + n * j];
+                v = make_double2(v.x - c.x, v.y - c.y);
             } else {
                 const int f = (b + 1) >> 1;
                 const double2 c = src[(size_t)(F + f) * nn + rr + n * j], cp = src[(size_t)(F + f) * nn + j + n * rr];
@@ -788,7 +924,7 @@ __device__ __forceinline__ void panel_stage_fold(double2* coef, const double2* _
     }
 }
 
-// row r of -H(x) from the folded set; (zr, zi) = e^{2 pi i x}
+// row r of (sw + i eta) I - H(x) from the folded set; (zr, zi) = e^{2 pi i x}
 template <int NP>
 __device__ __forceinline__ void panel_series_row_fold(const double2* coef, int M, double zr, double zi, int r, double (&ar)[NP],
                                                       double (&ai)[NP]) {
@@ -802,8 +938,8 @@ __device__ __forceinline__ void panel_series_row_fold(const double2* coef, int M
         pin8(c);
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            ar[j0 + j] = -c[j].x;
-            ai[j0 + j] = -c[j].y;
+            ar[j0 + j] = c[j].x;
+            ai[j0 + j] = c[j].y;
         }
     }
     double pr = 1.0, pi = 0.0;
@@ -815,17 +951,22 @@ __device__ __forceinline__ void panel_series_row_fold(const double2* coef, int M
         const double2* __restrict__ tm = sm + nn;
 #pragma unroll
         for (int j0 = 0; j0 < NP; j0 += 8) {
-            double2 sv[8], tv[8];
+            // eight reads in flight at a time (32 VGPRs beside the 64 of the row: sixteen would spill it at 4 waves/SIMD)
+            double2 sv[8];
 #pragma unroll
             for (int j = 0; j < 8; ++j) sv[j] = sm[NP * (j0 + j)];
             pin8(sv);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) tv[j] = tm[NP * (j0 + j)];
-            pin8(tv);
-#pragma unroll
             for (int j = 0; j < 8; ++j) {  // A = z I - H: accumulate -H
                 ar[j0 + j] = fma(-sv[j].x, pr, ar[j0 + j]);
                 ar[j0 + j] = fma(sv[j].y, pi, ar[j0 + j]);
+            }
+            double2 tv[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) tv[j] = tm[NP * (j0 + j)];
+            pin8(tv);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
                 ai[j0 + j] = fma(-tv[j].x, pi, ai[j0 + j]);
                 ai[j0 + j] = fma(-tv[j].y, pr, ai[j0 + j]);
             }
@@ -2646,7 +2787,11 @@ struct GenInnerArgs {
     double* E_out;
     int64_t* nev_out;
     int* status_out;
+    double sc[16];  // sincospi_poly's coefficients (kernel arguments stay in scalar registers / the scalar cache)
 };
+
+// Taylor coefficients of sin(pi r) / r^(2k+1), k = 0..7, and of cos(pi r) / r^(2k), k = 1..8
+static const double kSinCosPiCoef[16] = {3.141592653589793, -5.16771278004997, 2.5501640398773455, -0.5992645293207921, 0.08214588661112823, -0.0073704309457143504, 0.00046630280576761255, -2.1915353447830217e-05, -4.934802200544679, 4.0587121264167685, -1.3352627688545895, 0.2353306303588932, -0.02580689139001406, 0.0019295743094039231, -0.0001046381049248457, 4.303069587032947e-06};
 
 __host__ __device__ inline size_t gen_inner_wave_doubles(int n, int M, int ncomp) {
     // H, W, X (complex n*n each), ph (complex M), ev (n) rounded to even, then the adapt group
@@ -2744,8 +2889,9 @@ __global__ __launch_bounds__(256) void gen_inner_adaptive_kernel(GenInnerArgs a,
 // Block-per-integral version of the above for the resolvent-trace integrands: the integral's coefficient
 // set is staged in LDS once and stays there for its whole adaptive loop; each round's 15 / 30 GK nodes
 // are evaluated 256/NP at a time by NP-lane groups (panel_inverse_row), thread 0 runs adapt_step.
-template <int NP, bool PAD, int NT, int WPE, int RPL = 1, bool FOLD = false>
+template <int NP, bool PAD, int NT, int WPE, int RPL = 1, bool FOLD = false, bool FMAC = false>
 __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(WPE ? WPE : 1, WPE ? WPE : 8))) void gen_inner_panel_kernel(GenInnerArgs a) {
+    static_assert(!FMAC || (FOLD && NP == 16), "the FMA-with-broadcast inversion is written for 16 lanes per node");
     static_assert(!FOLD || (PAD && RPL == 1), "the folded series is built for the zero-padded one-row-per-lane layout");
     extern __shared__ double2 lds_ip[];
     constexpr int LPN = NP / RPL;  // lanes per node (RPL = 2: the duo layout, PAD only)
@@ -2766,7 +2912,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(WPE ? WPE : 
         AdaptStateT<1> st;
         __syncthreads();  // the previous integral's readers are done with coef / ctl
         if constexpr (FOLD)
-            panel_stage_fold<NP>(coef, a.src + a.slot[q] * ((int64_t)M * nn), n, M);
+            panel_stage_fold<NP>(coef, a.src + a.slot[q] * ((int64_t)M * nn), n, M, a.sweep_arr ? a.sweep_arr[q] : a.sweep, a.p[0]);
         else
             panel_stage<NP, PAD>(coef, a.src + a.slot[q] * ((int64_t)M * nn), n, M);
         if (threadIdx.x == 0) {
@@ -2791,11 +2937,17 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(WPE ? WPE : 
                 } else if constexpr (FOLD) {
                     double ar[NP], ai[NP];
                     double zr, zi;
-                    sincospi(2.0 * (x * a.inv_period), &zi, &zr);
+                    if constexpr (FMAC)
+                        sincospi_poly(a.sc, 2.0 * (x * a.inv_period), zi, zr);
+                    else
+                        sincospi(2.0 * (x * a.inv_period), &zi, &zr);
                     panel_series_row_fold<NP>(coef, M, zr, zi, r, ar, ai);
-                    panel_shift_row<NP, PAD>(n, swq, a.p[0], r, ar, ai);
-                    panel_invert_rows<NP, PAD>(n, r, ar, ai);
-                    panel_trace<NP>(ar, ai, n, r, tr, ti);
+                    if constexpr (FMAC) {
+                        panel_inverse_trace_fmac(n, r, ar, ai, tr, ti);
+                    } else {
+                        panel_invert_rows<NP, PAD>(n, r, ar, ai);
+                        panel_trace<NP>(ar, ai, n, r, tr, ti);
+                    }
                 } else {
                     double ar[NP], ai[NP];
                     panel_inverse_row<NP, PAD>(coef, n, M, a.first, x * a.inv_period, swq, a.p[0], r, ar, ai);
@@ -2884,6 +3036,7 @@ int launch_gen_inner_adaptive(abz_ctx* ctx, const InnerSpec& is) {
     a.E_out = is.E_out;
     a.nev_out = is.nev_out;
     a.status_out = is.status_out;
+    for (int i = 0; i < 16; ++i) a.sc[i] = kSinCosPiCoef[i];
     {
         int np = 0;
         size_t plds = 0;
@@ -2930,7 +3083,12 @@ int launch_gen_inner_adaptive(abz_ctx* ctx, const InnerSpec& is) {
             static const int wpe_env = [] { const char* e = getenv("ABZ_IPANEL_WPE"); return e ? atoi(e) : 0; }();
             const int wpe = wpe_env ? wpe_env : ((nt == 512 && np <= 16) ? 4 : 0);  // 32 rows x 2 arrays alone fill 128 VGPRs
             const bool fold_off = [] { const char* e = getenv("ABZ_IPANEL_FOLD"); return e && e[0] == '0'; }();  // per call: tests compare both
-            if (np == 16 && pad && nt == 512 && wpe == 4 && a.herm && !fold_off) {  // config 5's shape
+            const bool fmac_off = [] { const char* e = getenv("ABZ_IPANEL_FMAC"); return e && e[0] == '0'; }();  // per call, like FOLD
+            if (np == 16 && pad && nt == 512 && wpe == 4 && a.herm && !fold_off && !fmac_off) {  // config 5's shape
+                ABZ_HIP(hipFuncSetAttribute((const void*)gen_inner_panel_kernel<16, true, 512, 4, 1, true, true>,
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)plds));
+                hipLaunchKernelGGL((gen_inner_panel_kernel<16, true, 512, 4, 1, true, true>), dim3((unsigned)blocks), dim3(512), plds, ctx->stream, a);
+            } else if (np == 16 && pad && nt == 512 && wpe == 4 && a.herm && !fold_off) {  // the same with the pivot rows broadcast by separate DPP moves
                 ABZ_HIP(hipFuncSetAttribute((const void*)gen_inner_panel_kernel<16, true, 512, 4, 1, true>,
                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)plds));
                 hipLaunchKernelGGL((gen_inner_panel_kernel<16, true, 512, 4, 1, true>), dim3((unsigned)blocks), dim3(512), plds, ctx->stream, a);
