@@ -204,6 +204,160 @@ __device__ inline bool adapt_step(AdaptStateT<MAXC>& st, int nc_, double* seg_a,
     return true;
 }
 
+// The same step for a scalar integrand, restructured around the LDS latency that dominates it when ONE lane walks the
+// data (the block-per-integral kernel: every other wave of the workgroup waits at the barrier meanwhile).  Called by
+// lanes 0 and 1 of a wave: lane l applies the rule to pending panel l with its fifteen values pulled into registers
+// by back-to-back reads; lane 0 then runs the heap.  `heapE[i]` mirrors seg_E[heap[i]], so a heap level costs one LDS
+// round trip instead of the dependent pair heap[j] -> seg_E[heap[j]]; the popped parent's (I, E) are read at pop
+// time.  Same arithmetic in the same order as adapt_step: identical (I, E), identical heap decisions.
+// `pI*` / `pE`: the popped parent's values, carried by the caller between steps (lane 0's copy is the one used).
+struct AdaptParent {
+    double Ir = 0.0, Ii = 0.0, E = 0.0;
+};
+
+template <int MS>
+__device__ inline bool adapt_step_pair(AdaptStateT<1>& st, AdaptParent& par, int lane, double* seg_a, double* seg_b, double* seg_E,
+                                       gkc* seg_I, const gkc* vals, int* heap, double* heapE, double* ctl, long long maxevals,
+                                       const InnerOut& out) {
+    const int np = (int)ctl[0];
+    const double a1 = ctl[1], b1 = ctl[2], a2 = ctl[3], b2 = ctl[4];
+    const int pl = lane < np ? lane : 0;  // the panel of this lane
+    gkc rv[15];
+#pragma unroll
+    for (int i = 0; i < 15; ++i) rv[i] = vals[15 * pl + i];
+    gkc Il;
+    const double El = gk15_rule(rv, 1, pl ? a2 : a1, pl ? b2 : b1, &Il);
+    const double I2r = __shfl(Il.re, 1, 64), I2i = __shfl(Il.im, 1, 64), E2 = __shfl(El, 1, 64);
+    if (lane != 0) return false;
+    int newseg[2] = {-1, -1};
+    for (int pnl = 0; pnl < np; ++pnl) {
+        int sl;  // the popped parent's slot is reused for the first child
+        if (pnl == 0 && st.popped >= 0)
+            sl = st.popped;
+        else
+            sl = st.nseg++;
+        if (sl >= MS) {
+            st.status = 1;
+            sl = MS - 1;
+        }
+        newseg[pnl] = sl;
+    }
+    if (st.first) {
+        st.first = false;
+        const int sl = newseg[0];
+        seg_a[sl] = a1;
+        seg_b[sl] = b1;
+        seg_E[sl] = El;
+        seg_I[sl] = Il;
+        st.Ir[0] = Il.re;
+        st.Ii[0] = Il.im;
+        st.E = El;
+        st.numevals = 15;
+        heap[0] = sl;
+        heapE[0] = El;
+        st.nheap = 1;
+    } else {
+        const int s1 = newseg[0], s2 = newseg[1];
+        seg_a[s1] = a1;
+        seg_b[s1] = b1;
+        seg_a[s2] = a2;
+        seg_b[s2] = b2;
+        seg_I[s1] = Il;
+        gkc I2;
+        I2.re = I2r;
+        I2.im = I2i;
+        seg_I[s2] = I2;
+        seg_E[s1] = El;
+        seg_E[s2] = E2;
+        {
+#pragma clang fp contract(off)
+            st.Ir[0] = ((st.Ir[0] - par.Ir) + Il.re) + I2r;
+            st.Ii[0] = ((st.Ii[0] - par.Ii) + Il.im) + I2i;
+            st.E = ((st.E - par.E) + El) + E2;
+        }
+        for (int t = 0; t < 2; ++t) {  // heappush (percolate_up)
+            const int x = t == 0 ? s1 : s2;
+            const double Ex = t == 0 ? El : E2;
+            int i = st.nheap++;
+            while (i > 0) {
+                const int j = (i - 1) / 2;
+                const double Ej = heapE[j];
+                const int hj = heap[j];
+                if (!(Ej < Ex)) break;
+                heap[i] = hj;
+                heapE[i] = Ej;
+                i = j;
+            }
+            heap[i] = x;
+            heapE[i] = Ex;
+        }
+    }
+    double tol = st.atol;
+    if (st.rtol != 0.0) {  // (rtol = 0: max(atol, 0 * |I|) = atol, no square root)
+#pragma clang fp contract(off)
+        const double t1 = st.Ir[0] * st.Ir[0], t2 = st.Ii[0] * st.Ii[0];
+        const double t3 = t1 + t2;
+        const double nrm = sqrt(0.0 + t3);
+        tol = fmax(st.atol, st.rtol * nrm);
+    }
+    if (st.E > tol && st.numevals < maxevals && st.status == 0) {
+        // heappop: root out, last to root, percolate_down
+        const int x = heap[0];
+        const int nh = --st.nheap;
+        const int y = heap[nh];
+        const double Ey = heapE[nh];
+        const gkc Ix = seg_I[x];
+        const double pa = seg_a[x], pb = seg_b[x];
+        par.E = heapE[0];
+        par.Ir = Ix.re;
+        par.Ii = Ix.im;
+        if (nh > 0) {
+            int i = 0;
+            while (true) {
+                const int lc = 2 * i + 1;
+                if (lc >= nh) break;
+                const int rc = lc + 1;
+                const int rcs = rc < nh ? rc : lc;  // a readable index when the right child does not exist
+                const double El_ = heapE[lc], Er_ = heapE[rcs];
+                const int hl = heap[lc], hr = heap[rcs];
+                const bool left = rc >= nh || Er_ < El_;
+                const double Ej = left ? El_ : Er_;
+                if (!(Ey < Ej)) break;
+                heap[i] = left ? hl : hr;
+                heapE[i] = Ej;
+                i = left ? lc : rc;
+            }
+            heap[i] = y;
+            heapE[i] = Ey;
+        }
+        st.popped = x;
+        st.numevals += 30;
+        const double mid = (pa + pb) / 2;
+        ctl[0] = 2.0;
+        ctl[1] = pa;
+        ctl[2] = mid;
+        ctl[3] = mid;
+        ctl[4] = pb;
+        return false;
+    }
+    {  // re-sum over the heap in storage order (QuadGK does this after adapt)
+#pragma clang fp contract(off)
+        st.Ir[0] = seg_I[heap[0]].re;
+        st.Ii[0] = seg_I[heap[0]].im;
+        st.E = heapE[0];
+        for (int h = 1; h < st.nheap; ++h) {
+            st.Ir[0] = st.Ir[0] + seg_I[heap[h]].re;
+            st.Ii[0] = st.Ii[0] + seg_I[heap[h]].im;
+            st.E = st.E + heapE[h];
+        }
+    }
+    out.I[0] = make_double2(st.Ir[0], st.Ii[0]);
+    *out.E = st.E;
+    *out.nev = st.numevals;
+    *out.status = st.status;
+    return true;
+}
+
 // LDS doubles of one integral in flight: seg_a, seg_b, seg_E | seg_I | vals[30] | heap | ctl
 __host__ __device__ inline int inner_group_doubles(int ncomp, int ms = ABZ_INNER_MAXSEG) {
     return 3 * ms + 2 * ncomp * ms + 2 * ncomp * 30 + ms / 2 + 8;

@@ -605,14 +605,14 @@ __device__ __forceinline__ void sincospi_poly(const double (&sc)[16], double t, 
 // DPP read needs after a VALU write of its source (`s_nop 1`); inside a block the only DPP reads of a register written
 // one instruction earlier are reads of lane C's unchanged values.
 template <int C>
-__device__ __forceinline__ void fmac_col_bcast(double& xr, double& xi, double gr, double gi, double ngi) {
+__device__ __forceinline__ void fmac_col_bcast(double& xr, double& xi, double gr, double gi) {
     asm("s_nop 1\n\t"
-        "v_fmac_f64_dpp %0, %0, %2 row_newbcast:%5 row_mask:0xf bank_mask:0xf\n\t"
-        "v_fmac_f64_dpp %0, %1, %4 row_newbcast:%5 row_mask:0xf bank_mask:0xf\n\t"
-        "v_fmac_f64_dpp %1, %1, %2 row_newbcast:%5 row_mask:0xf bank_mask:0xf\n\t"
-        "v_fmac_f64_dpp %1, %0, %3 row_newbcast:%5 row_mask:0xf bank_mask:0xf"
+        "v_fmac_f64_dpp %0, %0, %2 row_newbcast:%4 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f64_dpp %0, %1, -%3 row_newbcast:%4 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f64_dpp %1, %1, %2 row_newbcast:%4 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f64_dpp %1, %0, %3 row_newbcast:%4 row_mask:0xf bank_mask:0xf"
         : "+v"(xr), "+v"(xi)
-        : "v"(gr), "v"(gi), "v"(ngi), "n"(C));
+        : "v"(gr), "v"(gi), "n"(C));
 }
 
 template <int C>
@@ -624,23 +624,23 @@ __device__ __forceinline__ void pivot_bcast(double ar, double ai, double& pr, do
         : "v"(ar), "v"(ai), "n"(C));
 }
 
-// Lane C's special cases of pivot C in one exec-masked block (lane C of each 16-lane row): g = 0, q = 1/p.  Five
+// Lane C's special cases of pivot C in one exec-masked block (lane C of each 16-lane row): g = 0, q = 1/p.  Four
 // `v_mov_b64` under a scalar exec switch instead of a dozen `v_cndmask_b32`; the scalar instructions issue beside the
 // other waves' VALU work.  No DPP instruction runs under the narrowed exec.
 template <int C>
-__device__ __forceinline__ void pivot_lane_fixup(double& gr, double& gi, double& ngi, double& qr, double& qi, double ipr, double ipi) {
-    constexpr unsigned long long mask = 0x0001000100010001ull << C;
+__device__ __forceinline__ void pivot_lane_fixup(double& gr, double& gi, double& qr, double& qi, double ipr, double ipi) {
+    constexpr unsigned half = 0x00010001u << C;  // lane C of the two rows of each half of the wave
     unsigned long long saved;
     asm("s_mov_b64 %[sv], exec\n\t"
-        "s_and_b64 exec, %[sv], %[mk]\n\t"
+        "s_and_b32 exec_lo, exec_lo, %[hm]\n\t"
+        "s_and_b32 exec_hi, exec_hi, %[hm]\n\t"
         "v_mov_b64 %[gr], 0\n\t"
         "v_mov_b64 %[gi], 0\n\t"
-        "v_mov_b64 %[ngi], 0\n\t"
         "v_mov_b64 %[qr], %[ipr]\n\t"
         "v_mov_b64 %[qi], %[ipi]\n\t"
         "s_mov_b64 exec, %[sv]"
-        : [gr] "+v"(gr), [gi] "+v"(gi), [ngi] "+v"(ngi), [qr] "+v"(qr), [qi] "+v"(qi), [sv] "=&s"(saved)
-        : [mk] "s"(mask), [ipr] "v"(ipr), [ipi] "v"(ipi)
+        : [gr] "+v"(gr), [gi] "+v"(gi), [qr] "+v"(qr), [qi] "+v"(qi), [sv] "=&s"(saved)
+        : [hm] "n"(half), [ipr] "v"(ipr), [ipi] "v"(ipi)
         : "scc");
 }
 
@@ -652,12 +652,11 @@ __device__ __forceinline__ void fmac_pivot(int r, double (&ar)[16], double (&ai)
     const double ipr = pr * inv, ipi = -pi * inv;  // 1 / pivot
     const double fr = ar[C], fi = ai[C];
     double gr = -(fr * ipr - fi * ipi);
-    double ngi = fr * ipi + fi * ipr;
-    double gi = -ngi;
-    pivot_lane_fixup<C>(gr, gi, ngi, qr, qi, ipr, ipi);
+    double gi = -(fr * ipi + fi * ipr);
+    pivot_lane_fixup<C>(gr, gi, qr, qi, ipr, ipi);
 #pragma unroll
     for (int j = 0; j < 16; ++j)
-        if (j != C) fmac_col_bcast<C>(ar[j], ai[j], gr, gi, ngi);
+        if (j != C) fmac_col_bcast<C>(ar[j], ai[j], gr, gi);
     // column C: the multipliers; the pivot row stays unscaled, its column-C element is p * (1/p) = 1 (g = 0 there: only
     // the high word differs from the multiplier's)
     ar[C] = __hiloint2double(r == C ? 0x3ff00000 : __double2hiint(gr), __double2loint(gr));
@@ -670,17 +669,22 @@ __device__ __forceinline__ void fmac_pivots(int r, double (&ar)[16], double (&ai
     (fmac_pivot<C>(r, ar, ai, qr, qi), ...);
 }
 
-#define ABZ_DIAG_STEP(j) "s_and_b64 exec, %[sv], %[mk]\n\tv_mov_b64 %[dr], %[r" #j "]\n\tv_mov_b64 %[di], %[i" #j "]\n\ts_lshl_b64 %[mk], %[mk], 1\n\t"
+#define ABZ_DIAG_STEP(j) "v_mov_b64 %[dr], %[r" #j "]\n\tv_mov_b64 %[di], %[i" #j "]\n\ts_lshl_b64 exec, exec, 1\n\t"
+// the exec mask walks from lane J0 of every row upwards (the wave runs with all lanes on here: the shifted mask never
+// turns on a lane the caller had off)
 template <int J0>
 __device__ __forceinline__ void diag_capture8(const double (&ar)[16], const double (&ai)[16], double& dr, double& di) {
-    unsigned long long mask = 0x0001000100010001ull << J0, saved;
+    constexpr unsigned half = 0x00010001u << J0;
+    unsigned long long saved;
     asm("s_mov_b64 %[sv], exec\n\t"
+        "s_and_b32 exec_lo, exec_lo, %[hm]\n\t"
+        "s_and_b32 exec_hi, exec_hi, %[hm]\n\t"
         ABZ_DIAG_STEP(0) ABZ_DIAG_STEP(1) ABZ_DIAG_STEP(2) ABZ_DIAG_STEP(3) ABZ_DIAG_STEP(4) ABZ_DIAG_STEP(5) ABZ_DIAG_STEP(6) ABZ_DIAG_STEP(7)
         "s_mov_b64 exec, %[sv]"
-        : [dr] "+v"(dr), [di] "+v"(di), [mk] "+s"(mask), [sv] "=&s"(saved)
-        : [r0] "v"(ar[J0]), [r1] "v"(ar[J0 + 1]), [r2] "v"(ar[J0 + 2]), [r3] "v"(ar[J0 + 3]), [r4] "v"(ar[J0 + 4]), [r5] "v"(ar[J0 + 5]),
-          [r6] "v"(ar[J0 + 6]), [r7] "v"(ar[J0 + 7]), [i0] "v"(ai[J0]), [i1] "v"(ai[J0 + 1]), [i2] "v"(ai[J0 + 2]), [i3] "v"(ai[J0 + 3]),
-          [i4] "v"(ai[J0 + 4]), [i5] "v"(ai[J0 + 5]), [i6] "v"(ai[J0 + 6]), [i7] "v"(ai[J0 + 7])
+        : [dr] "+v"(dr), [di] "+v"(di), [sv] "=&s"(saved)
+        : [hm] "n"(half), [r0] "v"(ar[J0]), [r1] "v"(ar[J0 + 1]), [r2] "v"(ar[J0 + 2]), [r3] "v"(ar[J0 + 3]), [r4] "v"(ar[J0 + 4]),
+          [r5] "v"(ar[J0 + 5]), [r6] "v"(ar[J0 + 6]), [r7] "v"(ar[J0 + 7]), [i0] "v"(ai[J0]), [i1] "v"(ai[J0 + 1]), [i2] "v"(ai[J0 + 2]),
+          [i3] "v"(ai[J0 + 3]), [i4] "v"(ai[J0 + 4]), [i5] "v"(ai[J0 + 5]), [i6] "v"(ai[J0 + 6]), [i7] "v"(ai[J0 + 7])
         : "scc");
 }
 #undef ABZ_DIAG_STEP
@@ -2787,6 +2791,7 @@ struct GenInnerArgs {
     double* E_out;
     int64_t* nev_out;
     int* status_out;
+    int pair;       // adapt_step_pair instead of adapt_step (ABZ_IPANEL_PAIR=0: the one-lane step)
     double sc[16];  // sincospi_poly's coefficients (kernel arguments stay in scalar registers / the scalar cache)
 };
 
@@ -2907,9 +2912,11 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(WPE ? WPE : 
     gkc* vals = seg_I + (size_t)MS * nc;
     int* heap = reinterpret_cast<int*>(vals + (size_t)30 * nc);
     double* ctl = reinterpret_cast<double*>(heap + MS);
+    double* heapE = ctl + 8;  // adapt_step_pair's mirror of seg_E[heap[.]]
     const int slot = threadIdx.x / LPN, r = threadIdx.x % LPN;
     for (int64_t q = blockIdx.x; q < a.nint; q += gridDim.x) {
         AdaptStateT<1> st;
+        AdaptParent par;
         __syncthreads();  // the previous integral's readers are done with coef / ctl
         if constexpr (FOLD)
             panel_stage_fold<NP>(coef, a.src + a.slot[q] * ((int64_t)M * nn), n, M, a.sweep_arr ? a.sweep_arr[q] : a.sweep, a.p[0]);
@@ -2964,13 +2971,18 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(WPE ? WPE : 
                 }
             }
             __syncthreads();
-            if (threadIdx.x == 0) {
+            if (threadIdx.x < 2) {
                 InnerOut out;
                 out.I = a.I_out + q * nc;
                 out.E = a.E_out + q;
                 out.nev = a.nev_out + q;
                 out.status = a.status_out + q;
-                if (adapt_step<false, 1, MS>(st, nc, seg_a, seg_b, seg_E, seg_I, vals, heap, ctl, a.maxevals, out)) ctl[5] = 1.0;
+                if (a.pair) {  // uniform: lanes 0 and 1 share the two panel rules
+                    if (adapt_step_pair<MS>(st, par, (int)threadIdx.x, seg_a, seg_b, seg_E, seg_I, vals, heap, heapE, ctl, a.maxevals, out))
+                        ctl[5] = 1.0;
+                } else if (threadIdx.x == 0) {
+                    if (adapt_step<false, 1, MS>(st, nc, seg_a, seg_b, seg_E, seg_I, vals, heap, ctl, a.maxevals, out)) ctl[5] = 1.0;
+                }
             }
         }
     }
@@ -2986,7 +2998,7 @@ static int gen_inner_panel_threads(int np) {
 static bool gen_inner_panel_fits(int n, int M, int integrand, int* np_out, size_t* lds_out, bool* pad_out) {
     if (!(integrand == ABZ_F_DOS || integrand == ABZ_F_TRGLOC)) return false;
     const int np = n <= 8 ? 8 : (n <= 16 ? 16 : 32);
-    const size_t rest = sizeof(double) * (size_t)inner_group_doubles(1, ABZ_PANEL_MAXSEG);
+    const size_t rest = sizeof(double) * ((size_t)inner_group_doubles(1, ABZ_PANEL_MAXSEG) + ABZ_PANEL_MAXSEG);  // + heapE
     size_t lds = sizeof(double2) * (size_t)M * np * np + rest;  // zero-padded set
     const bool pad = lds <= 150 * 1024;
     if (!pad) lds = sizeof(double2) * (size_t)M * n * n + rest;
@@ -3038,12 +3050,20 @@ int launch_gen_inner_adaptive(abz_ctx* ctx, const InnerSpec& is) {
     a.status_out = is.status_out;
     for (int i = 0; i < 16; ++i) a.sc[i] = kSinCosPiCoef[i];
     {
+        const char* e = getenv("ABZ_IPANEL_PAIR");  // per call: tests compare both
+        a.pair = !(e && e[0] == '0');
+    }
+    {
         int np = 0;
         size_t plds = 0;
         bool pad = false;
         static const bool off = [] { const char* e = getenv("ABZ_GEN_PANEL"); return e && e[0] == '0'; }();
         if (!off && gen_inner_panel_fits(is.n, is.M, is.integrand, &np, &plds, &pad)) {
-            const int64_t blocks = std::min<int64_t>(is.nint, 256 * 8);
+            // one workgroup per integral up to a large grid: the dispatcher hands the next integral to whichever CU frees a
+            // slot (a static share of integrals per persistent workgroup left the second half of a launch half empty:
+            // 3.1 of 4 wave slots occupied on average).  ABZ_IPANEL_BLOCKS caps the grid (2048 = the static shares)
+            static const int64_t cap = [] { const char* e = getenv("ABZ_IPANEL_BLOCKS"); return e ? atoll(e) : (int64_t)1 << 20; }();
+            const int64_t blocks = std::min<int64_t>(is.nint, std::max<int64_t>(cap, 1));
             ProfScope ps(ctx, ABZ_K_EVAL);
 #define ABZ_IPANEL3(NPV, PV, NTV, WV)                                                                          \
     ABZ_HIP(hipFuncSetAttribute((const void*)gen_inner_panel_kernel<NPV, PV, NTV, WV>,                        \

@@ -967,6 +967,42 @@ def test_generic_n_iai_3d_16_band_matches_oracle(abz):
     assert abs(sol.resid - ref.resid) <= 1e-6 * abs(ref.resid) + 1e-12
 
 
+@pytest.mark.parametrize("n,dims", [(16, (5, 5)), (12, (3, 3, 3)), (9, (5, 3))])
+def test_16_lane_panel_kernel_variants_agree(abz, monkeypatch, n, dims):
+    """The workgroup-per-integral kernel of 9..16 bands has three generations that stay selectable: the unfolded series
+    (ABZ_IPANEL_FOLD=0), the folded series with separate pivot-row broadcasts (ABZ_IPANEL_FMAC=0) and the default (pivot
+    rows broadcast inside `v_fmac_f64_dpp`, pivot-row scaling deferred to the trace, polynomial sincospi); the adaptive
+    step runs on one lane (ABZ_IPANEL_PAIR=0) or two.  The step variants must agree to the bit; the arithmetic variants
+    round differently and must agree to 1e-12 with the same panels.  n < 16: the padded identity rows take part."""
+    rng = np.random.default_rng(900 + n)
+    c, first = rand_series(rng, dims, n, hermitian=True)
+    c = c / (n / 2)
+    d = len(dims)
+    s = abz.FourierSeries(c, period=1.0, first=first, ndim=d)
+    bz = abz.load_bz(abz.FBZ(), np.eye(d))
+    f = abz.FourierIntegrand(abz.DOSIntegrand(), s, 0.1)
+    keys = ("ABZ_IPANEL_FOLD", "ABZ_IPANEL_FMAC", "ABZ_IPANEL_PAIR")
+    runs = {}
+    for tag, env in (("default", {}), ("one_lane_step", {"ABZ_IPANEL_PAIR": "0"}), ("dpp_moves", {"ABZ_IPANEL_FMAC": "0"}),
+                     ("unfolded", {"ABZ_IPANEL_FOLD": "0"})):
+        for k in keys:
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        sol = abz.do_solve(f, bz, abz.MixedParameters(0.15), abz.EvalCounter(abz.IAI()), abstol=1e-4 if d == 2 else 1e-2, reltol=0.0,
+                           _panels=True)
+        runs[tag] = (sol.u, sol.resid, sol.numevals, sol.extra["panels"])
+    for k in keys:
+        monkeypatch.delenv(k, raising=False)
+    ref = runs["default"]
+    assert ref[2] > 15**d * 4
+    assert runs["one_lane_step"][0] == ref[0] and runs["one_lane_step"][1] == ref[1] and runs["one_lane_step"][2] == ref[2]
+    assert np.array_equal(runs["one_lane_step"][3], ref[3])
+    for tag in ("dpp_moves", "unfolded"):
+        assert abs(runs[tag][0] - ref[0]) <= 1e-12 * abs(ref[0]), tag
+        assert runs[tag][2] == ref[2] and np.allclose(runs[tag][3], ref[3], rtol=1e-10, atol=1e-13), tag
+
+
 @pytest.mark.parametrize("n,dims,eta,abstol", [(3, (3, 3, 3), 0.2, 0.3), (16, (3, 3, 3), 0.3, 0.5), (2, (7, 5), 0.05, 1e-3)])
 def test_iai_speculative_requests_change_nothing(abz, monkeypatch, n, dims, eta, abstol):
     """The driver requests the halves of every panel that is certain to be popped in one round; pops are replayed in

@@ -5,6 +5,10 @@
 //   3: 16 x v_mfma_f64_16x16x4_f64 (4 independent accumulators)
 //   4: 16 x v_mfma_f64_16x16x4_f64 interleaved with 64 x v_fma_f64  (matrix + vector co-issue)
 //   5: 64 x v_fma_f64 + 64 x v_mov_b32 quad_perm   (1 : 1, the 16-lanes-per-node ratio)
+//   6: 64 x v_fmac_f64_dpp row_newbcast:3, independent accumulators (the broadcast folded into the FMA)
+//   7: 16 x [s_nop 1 + 4 x v_fmac_f64_dpp] in the Gauss-Jordan column pattern (two accumulators per block, dependent)
+//   8: 64 x v_fmac_f64 (VOP2, no DPP)
+//   9: 64 x v_fma_f64 + 32 x v_mov_b64_dpp row_newbcast:3    (the round-2 pivot pattern: 2 moves per 4 FMAs)
 // Reports shader clocks per body per wave for 1, 2 and 4 waves per SIMD.
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -15,6 +19,10 @@ typedef double d4 __attribute__((ext_vector_type(4)));
 #define DPPQ(i) asm volatile("v_mov_b32_dpp %0, %1 quad_perm:[0,0,0,0] row_mask:0xf bank_mask:0xf" : "=v"(t[i]) : "v"(s[i]))
 #define DPPR(i) asm volatile("v_mov_b32_dpp %0, %1 row_newbcast:3 row_mask:0xf bank_mask:0xf" : "=v"(t[i]) : "v"(s[i]))
 #define MFMA(i) asm volatile("v_mfma_f64_16x16x4_f64 %0, %1, %2, %0" : "+v"(m[i]) : "v"(a), "v"(b))
+#define FMACD(i) asm volatile("v_fmac_f64_dpp %0, %1, %2 row_newbcast:3 row_mask:0xf bank_mask:0xf" : "+v"(acc[i]) : "v"(a), "v"(b))
+#define FMAC2(i) asm volatile("v_fmac_f64_e32 %0, %1, %2" : "+v"(acc[i]) : "v"(a), "v"(b))
+#define COLB(i) asm volatile("s_nop 1\n\tv_fmac_f64_dpp %0, %0, %2 row_newbcast:3 row_mask:0xf bank_mask:0xf\n\tv_fmac_f64_dpp %0, %1, -%3 row_newbcast:3 row_mask:0xf bank_mask:0xf\n\tv_fmac_f64_dpp %1, %1, %2 row_newbcast:3 row_mask:0xf bank_mask:0xf\n\tv_fmac_f64_dpp %1, %0, %3 row_newbcast:3 row_mask:0xf bank_mask:0xf" : "+v"(acc[(2 * (i)) % 16]), "+v"(acc[(2 * (i) + 1) % 16]) : "v"(a), "v"(b))
+#define MOV64D(i) asm volatile("v_mov_b64_dpp %0, %1 row_newbcast:3 row_mask:0xf bank_mask:0xf" : "=v"(u[i]) : "v"(acc[i]))
 #define R16(M) M(0); M(1); M(2); M(3); M(4); M(5); M(6); M(7); M(8); M(9); M(10); M(11); M(12); M(13); M(14); M(15)
 
 template <int MODE, int NT>
@@ -22,6 +30,8 @@ __global__ __launch_bounds__(NT) void k(double* out, int iters) {
     double acc[16];
     float s[16], t[16];
     d4 m[4];
+    double u[16];
+    for (int i = 0; i < 16; ++i) u[i] = 0.0;
     double a = 1.0 + 1e-9 * threadIdx.x, b = 1.0 - 1e-9 * threadIdx.x;
     for (int i = 0; i < 16; ++i) { acc[i] = i; s[i] = (float)(i + threadIdx.x); t[i] = 0.f; }
     for (int i = 0; i < 4; ++i) m[i] = d4{0, 0, 0, 0};
@@ -36,10 +46,14 @@ __global__ __launch_bounds__(NT) void k(double* out, int iters) {
             MFMA(0); FMA(0); FMA(1); FMA(2); FMA(3); MFMA(1); FMA(4); FMA(5); FMA(6); FMA(7); MFMA(2); FMA(8); FMA(9); FMA(10); FMA(11); MFMA(3); FMA(12); FMA(13); FMA(14); FMA(15);
             MFMA(0); FMA(0); FMA(1); FMA(2); FMA(3); MFMA(1); FMA(4); FMA(5); FMA(6); FMA(7); MFMA(2); FMA(8); FMA(9); FMA(10); FMA(11); MFMA(3); FMA(12); FMA(13); FMA(14); FMA(15);
         }
+        if (MODE == 6) { R16(FMACD); R16(FMACD); R16(FMACD); R16(FMACD); }
+        if (MODE == 7) { R16(COLB); }
+        if (MODE == 8) { R16(FMAC2); R16(FMAC2); R16(FMAC2); R16(FMAC2); }
+        if (MODE == 9) { R16(MOV64D); R16(FMA); R16(FMA); R16(MOV64D); R16(FMA); R16(FMA); }
         if (MODE == 5) { R16(FMA); R16(DPPQ); R16(FMA); R16(DPPQ); R16(FMA); R16(DPPQ); R16(FMA); R16(DPPQ); }
     }
     double r = 0;
-    for (int i = 0; i < 16; ++i) r += acc[i] + t[i];
+    for (int i = 0; i < 16; ++i) r += acc[i] + t[i] + u[i];
     for (int i = 0; i < 4; ++i) r += m[i].x + m[i].y + m[i].z + m[i].w;
     if (out) out[blockIdx.x * NT + threadIdx.x] = r;
 }
@@ -78,7 +92,11 @@ int main() {
     run<2, NT>("64 v_fma_f64 + 16 v_mov_b32 dpp row_newbcast", W, ghz);              \
     run<5, NT>("64 v_fma_f64 + 64 v_mov_b32 dpp quad_perm", W, ghz);                 \
     run<3, NT>("16 v_mfma_f64_16x16x4_f64", W, ghz);                                 \
-    run<4, NT>("16 v_mfma_f64_16x16x4_f64 interleaved with 64 v_fma_f64", W, ghz);
+    run<4, NT>("16 v_mfma_f64_16x16x4_f64 interleaved with 64 v_fma_f64", W, ghz);  \
+    run<6, NT>("64 v_fmac_f64_dpp row_newbcast", W, ghz);                             \
+    run<7, NT>("16 x (s_nop 1 + 4 dependent v_fmac_f64_dpp)", W, ghz);                \
+    run<8, NT>("64 v_fmac_f64 (VOP2)", W, ghz);                                       \
+    run<9, NT>("64 v_fma_f64 + 32 v_mov_b64_dpp row_newbcast", W, ghz);
     ALL(256, 1)
     ALL(256, 2)
     ALL(256, 4)
