@@ -663,10 +663,11 @@ __device__ __forceinline__ void fmac_pivot(int r, double (&ar)[16], double (&ai)
     ai[C] = gi;
 }
 
-template <int... C>
-__device__ __forceinline__ void fmac_pivots(int r, double (&ar)[16], double (&ai)[16], double& qr, double& qi,
+template <bool GUARD, int... C>
+__device__ __forceinline__ void fmac_pivots(int n, int r, double (&ar)[16], double (&ai)[16], double& qr, double& qi,
                                             std::integer_sequence<int, C...>) {
-    (fmac_pivot<C>(r, ar, ai, qr, qi), ...);
+    // GUARD: the pivots of the identity rows >= n are skipped (uniform), as in panel_pivots
+    ((!GUARD || C < n ? fmac_pivot<C>(r, ar, ai, qr, qi) : (void)0), ...);
 }
 
 #define ABZ_DIAG_STEP(j) "v_mov_b64 %[dr], %[r" #j "]\n\tv_mov_b64 %[di], %[i" #j "]\n\ts_lshl_b64 exec, exec, 1\n\t"
@@ -690,9 +691,10 @@ __device__ __forceinline__ void diag_capture8(const double (&ar)[16], const doub
 #undef ABZ_DIAG_STEP
 
 // trace of the inverse of the zero-padded 16 x 16 matrix whose row r this lane holds (rows >= n: identity rows)
+template <bool GUARD = false>
 __device__ __forceinline__ void panel_inverse_trace_fmac(int n, int r, double (&ar)[16], double (&ai)[16], double& tr, double& ti) {
     double qr = 1.0, qi = 0.0;
-    fmac_pivots(r, ar, ai, qr, qi, std::make_integer_sequence<int, 16>());
+    fmac_pivots<GUARD>(n, r, ar, ai, qr, qi, std::make_integer_sequence<int, 16>());
     // lane r's diagonal element a_rr: two moves per column under the exec mask of lane j of every row (a select chain
     // costs four `v_cndmask_b32` per column)
     double dr = 0.0, di = 0.0;
@@ -1086,9 +1088,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 4))) voi
                     ai[j] = hi[j];
                 }
                 panel_shift_row<NP, PAD>(n, a.sweep[q], a.eta, r, ar, ai);
-                panel_invert_rows<NP, PAD>(n, r, ar, ai);
                 double tr, ti;
-                panel_trace<NP>(ar, ai, n, r, tr, ti);
+                if constexpr (NP == 16) {  // broadcast inside the FMAs, trace only (see panel_inverse_trace_fmac)
+                    panel_inverse_trace_fmac<!PAD>(n, r, ar, ai, tr, ti);
+                } else {
+                    panel_invert_rows<NP, PAD>(n, r, ar, ai);
+                    panel_trace<NP>(ar, ai, n, r, tr, ti);
+                }
                 const double dr = !act ? 0.0 : (a.is_dos ? -ti * 0.31830988618379067153776752674503 : tr);
                 const double di = (!act || a.is_dos) ? 0.0 : ti;
 #pragma unroll
@@ -2339,9 +2345,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 4))) voi
                     ai[j] = hi[j];
                 }
                 panel_shift_row<NP, false>(n, a.sweep[s0 + q], a.eta, r, ar, ai);
-                panel_invert_rows<NP, false>(n, r, ar, ai);
                 double tr, ti;
-                panel_trace<NP>(ar, ai, n, r, tr, ti);
+                if constexpr (NP == 16) {
+                    panel_inverse_trace_fmac<true>(n, r, ar, ai, tr, ti);
+                } else {
+                    panel_invert_rows<NP, false>(n, r, ar, ai);
+                    panel_trace<NP>(ar, ai, n, r, tr, ti);
+                }
                 const double dr = wk * (a.is_dos ? -ti * 0.31830988618379067153776752674503 : tr);
                 const double di = a.is_dos ? 0.0 : wk * ti;
 #pragma unroll
