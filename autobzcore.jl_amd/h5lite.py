@@ -121,6 +121,10 @@ def lib():
             _proto(handle)
             if handle.H5open() < 0:
                 raise OSError("H5open failed")
+            # the binding assumes the 64-bit hid_t of HDF5 >= 1.10 (1.8: 32-bit ids, other H5T_NATIVE_*_g widths)
+            a, b, c = C.c_uint(), C.c_uint(), C.c_uint()
+            if handle.H5get_libversion(C.byref(a), C.byref(b), C.byref(c)) < 0 or (a.value, b.value) < (1, 10):
+                raise OSError(f"HDF5 {a.value}.{b.value}.{c.value} is older than 1.10 (32-bit hid_t)")
             handle.H5Eset_auto2(0, None, None)  # errors come back as negative ids; no stack dump on stderr
             _lib = handle
             return _lib
