@@ -1510,6 +1510,182 @@ __global__ __launch_bounds__(256) void final_reduce_kernel(const double2* __rest
 }
 
 // ------------------------------------------------------------------------------------------
+// DOS scans of 3-band rules (Phase B of a frequency sweep; ref: quadsum over the cached rule, src/fourier.jl:204-207, with
+// the DOS integrand -Im tr inv((w + i eta) I - H(k)) / pi of aps_example/aps_example.jl:30).  One thread keeps the state of KT
+// nodes -- three doubles each: (q, p1, p0) of the real characteristic cubic of H - (tr H / 3) I, or the three
+// eigenvalues -- and walks the sweep.
+//  MODE 0, Hermitian H:  z = x + i eta, x = w - q,  p(z) = z^3 + p1 z + p0,  u' = x^2 - 3 eta^2:
+//        Re p = x (u' + p1) + p0,   Im p = eta B,   B = 3 u' + p1 + 8 eta^2,   Re p' = B - 2 eta^2,   Im p' = 6 x eta
+//        Im (p'/p) = eta [6 x Re p - (B - 2 eta^2) B] / (Re p^2 + eta^2 B^2)
+//    19 instructions per (node, value): the common factor -eta/pi goes into the final scale.
+//  MODE 1, cached eigenvalues: sum_b 1/x_b, x_b = (w - e_b)^2 + eta^2, over ONE reciprocal: 16 instructions.
+// Per swept value a lane's partial sum goes into a wave-private LDS tile [16 values][64 lanes]; every 16 values the
+// tile is summed transposed (lane = (value, quarter of the lanes): 16 reads + 2 shuffles) -- 0.4 instructions per
+// (node, value) where a shuffle reduction per value costs 30 / KT.  Pairs of nodes share one reciprocal.
+// ------------------------------------------------------------------------------------------
+constexpr int DOS3_C = 16;    // swept values per transposed reduction
+constexpr int DOS3_TP = 66;   // row pitch of the tile in doubles
+constexpr int DOS3_CH = 128;  // swept values per block-level pass (LDS partial rows)
+
+template <int KT, int MODE>
+__global__ __launch_bounds__(256, 3) void dos3_scan_kernel(ReduceArgs a, double three, double six, double2* __restrict__ partial) {
+    extern __shared__ double lds_d[];  // [DOS3_CH][4 waves] | [4 waves][DOS3_C][DOS3_TP]
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    double* const P = lds_d;
+    double* const T = lds_d + DOS3_CH * 4 + wave * (DOS3_C * DOS3_TP);
+    const int64_t base = (int64_t)blockIdx.x * (256 * KT);
+    double c0[KT], c1[KT], c2[KT], wk[KT];
+    const int LL = (MODE == 0 ? a.H : a.E).line_len;
+    const int64_t tile = (MODE == 0 ? a.H : a.E).tile;
+    int64_t vline = (base + threadIdx.x) / LL;
+    unsigned vcol = (unsigned)((base + threadIdx.x) - vline * LL);
+#pragma unroll
+    for (int j = 0; j < KT; ++j) {
+        const int64_t k = base + threadIdx.x + 256 * j;
+        const bool ok = k < a.nk;
+        const int64_t voff = ok ? vline * tile + vcol : 0;
+        {
+            vcol += 256u;
+            const unsigned qd = vcol / (unsigned)LL;
+            vline += qd;
+            vcol -= qd * (unsigned)LL;
+        }
+        wk[j] = ok ? (a.w ? a.w[k] : 1.0) : 0.0;
+        if constexpr (MODE == 0) {
+            const double* __restrict__ in = a.H.base + voff;
+            const int64_t pp = a.H.pitch;
+            CharPolyH cp;  // plane of Re H[r][c] is 2 (r + 3 c), Im the next one
+            charpoly_init_h3(in[0], in[8 * pp], in[16 * pp], in[6 * pp], in[7 * pp], in[12 * pp], in[13 * pp], in[14 * pp],
+                             in[15 * pp], cp);
+            c0[j] = cp.q;
+            c1[j] = cp.p1;
+            c2[j] = cp.p0;
+        } else {
+            const double* __restrict__ ei = a.E.base + voff;
+            c0[j] = ei[0];
+            c1[j] = ei[a.E.pitch];
+            c2[j] = ei[2 * (int64_t)a.E.pitch];
+        }
+    }
+    const double eta = a.p[0], e2 = eta * eta;
+    const double m3e2 = -3.0 * e2, p8e2 = 8.0 * e2, p6e2 = 6.0 * e2;
+    // nodes of weight one (full grids, all of the block inside the rule): the weight multiplication is dropped
+    const bool weighted = a.w != nullptr || base + 256 * KT > a.nk;
+    const int sw_lo = (int)blockIdx.y * a.sweep_per_row;
+    const int sw_hi = min(a.n_sweep, sw_lo + a.sweep_per_row);
+    auto value = [&](auto wtag, double sw) -> double {
+        constexpr bool W = decltype(wtag)::value;
+        double acc = 0.0;
+        double num[KT], den[KT];
+#pragma unroll
+        for (int j = 0; j < KT; ++j) {
+            if constexpr (MODE == 0) {
+                const double x = sw - c0[j];
+                const double up = fma(x, x, m3e2);
+                const double A = up + c1[j];
+                const double dr = fma(x, A, c2[j]);
+                const double B0 = fma(three, up, c1[j]);
+                const double B = B0 + p8e2;
+                const double Bm = B0 + p6e2;
+                const double m = Bm * B;
+                const double t1 = x * dr;
+                num[j] = fma(six, t1, -m);
+                den[j] = fma(e2 * B, B, dr * dr);
+            } else {
+                const double d0 = sw - c0[j], d1 = sw - c1[j], d2 = sw - c2[j];
+                const double x0 = fma(d0, d0, e2), x1 = fma(d1, d1, e2), x2 = fma(d2, d2, e2);
+                const double x12 = x1 * x2;
+                num[j] = fma(x0, x1 + x2, x12);
+                den[j] = x0 * x12;
+            }
+            if constexpr (W) num[j] *= wk[j];
+        }
+        // one reciprocal per PAIR of nodes, n1/d1 + n2/d2 = (n1 d2 + n2 d1) / (d1 d2): v_rcp_f64 issues at a quarter of
+        // the FMA rate and carries two Newton steps.  The denominators are |p(z)|^2 (or products of three Lorentzian
+        // denominators): a product of two stays far inside the double range for any sane energy scale.
+#pragma unroll
+        for (int j = 0; j + 1 < KT; j += 2) {
+            const double t = fma(num[j + 1], den[j], num[j] * den[j + 1]);
+            acc = fma(t, fast_rcp(den[j] * den[j + 1]), acc);
+        }
+        if constexpr (KT & 1) acc = fma(num[KT - 1], fast_rcp(den[KT - 1]), acc);
+        return acc;
+    };
+    auto fill = [&](auto wtag, int sb, int cnt) {  // partial sums of `cnt` swept values into the wave's tile
+        double sw = a.sweep[sb];
+        for (int i = 0; i < cnt; ++i) {
+            const double sw_next = a.sweep[min(sb + i + 1, a.n_sweep - 1)];  // scalar load one value ahead
+            T[i * DOS3_TP + lane] = value(wtag, sw);
+            sw = sw_next;
+        }
+    };
+    for (int s0 = sw_lo; s0 < sw_hi; s0 += DOS3_CH) {
+        const int s1 = min(sw_hi, s0 + DOS3_CH);
+        for (int sb = s0; sb < s1; sb += DOS3_C) {
+            const int cnt = min(DOS3_C, s1 - sb);
+            if (weighted)
+                fill(std::true_type{}, sb, cnt);
+            else
+                fill(std::false_type{}, sb, cnt);
+            wave_lds_sync();
+            {
+                const double* __restrict__ row = T + (lane & 15) * DOS3_TP + (lane >> 4) * 16;
+                double sum = 0.0;  // rows >= cnt hold older values: summed, never written out
+#pragma unroll
+                for (int i = 0; i < 16; ++i) sum += row[i];
+                sum += __shfl_xor(sum, 16, 64);
+                sum += __shfl_xor(sum, 32, 64);
+                if (lane < cnt) P[(sb - s0 + lane) * 4 + wave] = sum;
+            }
+            wave_lds_sync();
+        }
+        __syncthreads();
+        for (int t = threadIdx.x; t < s1 - s0; t += 256) {
+            const double v = (P[t * 4] + P[t * 4 + 1]) + (P[t * 4 + 2] + P[t * 4 + 3]);
+            partial[(int64_t)blockIdx.x * (int64_t)a.n_sweep + (s0 + t)] = make_double2(v, 0.0);
+        }
+        __syncthreads();
+    }
+}
+
+// mode 0: ABZ_F_DOS on the H planes of a Hermitian rule; mode 1: ABZ_F_DOS_EIG on the eigenvalue planes
+static int launch_dos3(abz_ctx* ctx, const ReduceSpec& rs, const ReduceArgs& a0, int mode) {
+    ReduceArgs a = a0;
+    // KT = 8 nodes per thread at 3 waves per SIMD (KT = 4 ... 7, and 6 or 4 at 4 waves per SIMD, measured the same to 3 % at
+    // 150^3: the kernel is bound by VALU issue).  Small rules (one rank's slab of a k-sharded grid) split the SWEEP over
+    // blockIdx.y as well, >= 16 values per row; long sweeps take two rows (256 values: -5 %, the tail of the last blocks).
+    constexpr int kt = 8;
+    int rows = 1;
+    {
+        const int force = [] { const char* e = getenv("ABZ_REDUCE_ROWS"); return e ? atoi(e) : 0; }();  // per call (tests, tools)
+        const int max_rows = (int)cdiv(rs.n_sweep, 16);
+        const int want = force > 0 ? force : std::max((int)cdiv(1024, cdiv(rs.nk, 256 * kt)), rs.n_sweep >= 192 ? 2 : 1);
+        rows = std::max(1, std::min(want, max_rows));
+        const int per = (int)cdiv(rs.n_sweep, rows);
+        a.sweep_per_row = per;
+        rows = (int)cdiv(rs.n_sweep, per);
+    }
+    const int64_t nblocks = cdiv(rs.nk, 256 * kt);
+    const int64_t ncols = rs.n_sweep;
+    int rc = ctx->scratch[1].reserve(sizeof(double2) * (size_t)(nblocks * ncols));
+    if (rc) return rc;
+    const size_t lds = sizeof(double) * ((size_t)DOS3_CH * 4 + (size_t)4 * DOS3_C * DOS3_TP);
+    const double pi = 3.14159265358979323846;
+    const double scale = rs.scale * (mode == 0 ? -rs.params[0] / pi : rs.params[0] / pi);
+    if (mode == 0)
+        hipLaunchKernelGGL((dos3_scan_kernel<kt, 0>), dim3((unsigned)nblocks, (unsigned)rows), dim3(256), lds, ctx->stream, a, 3.0, 6.0,
+                           ctx->scratch[1].as<double2>());
+    else
+        hipLaunchKernelGGL((dos3_scan_kernel<kt, 1>), dim3((unsigned)nblocks, (unsigned)rows), dim3(256), lds, ctx->stream, a, 3.0, 6.0,
+                           ctx->scratch[1].as<double2>());
+    ABZ_HIP(hipGetLastError());
+    hipLaunchKernelGGL(final_reduce_kernel, dim3((unsigned)ncols), dim3(256), 0, ctx->stream, ctx->scratch[1].as<double2>(),
+                       nblocks, ncols, scale, rs.out_map_dev ? rs.out_map_dev : ctx->scratch[2].as<double2>());
+    ABZ_HIP(hipGetLastError());
+    return ABZ_OK;
+}
+
+// ------------------------------------------------------------------------------------------
 // Store-free PTR: rule(f, B) without materialising the rule.  Same work loop as eval_grid_kernel, but a
 // unit's H(k) go straight into the integrand and the per-lane partial sums; nothing is written per node.
 // For grids that are used once (an AutoPTR refinement step, a single omega) or do not fit in HBM
@@ -1848,6 +2024,10 @@ static int launch_reduce_h(abz_ctx* ctx, const ReduceSpec& rs, const ReduceArgs&
 template <int N, int FID>
 static int launch_reduce_t(abz_ctx* ctx, const ReduceSpec& rs, const ReduceArgs& a) {
     constexpr bool canH = ((N == 2 || N == 3 || N == 4) && (FID == ABZ_F_DOS || FID == ABZ_F_TRGLOC)) || ((N == 3 || N == 4) && FID == ABZ_F_GLOC);
+    if constexpr (N == 3 && (FID == ABZ_F_DOS || FID == ABZ_F_DOS_EIG)) {  // the sweep kernel of 3-band DOS scans
+        const bool off = [] { const char* e = getenv("ABZ_DOS3_SCAN"); return e && e[0] == '0'; }();  // per call: tests compare both
+        if (!off && (FID == ABZ_F_DOS_EIG || rs.herm)) return launch_dos3(ctx, rs, a, FID == ABZ_F_DOS ? 0 : 1);
+    }
     if (canH && rs.herm) return launch_reduce_h<N, FID, canH>(ctx, rs, a);
     return launch_reduce_h<N, FID, false>(ctx, rs, a);
 }

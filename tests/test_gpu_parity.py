@@ -205,6 +205,42 @@ def test_rule_reduce_matches_oracle_dos(abz):
             assert abs(t[i] - np.trace(ref)) <= 1e-11 * abs(np.trace(ref))
 
 
+def test_dos3_sweep_kernel_against_oracle_and_generic_scan(abz, monkeypatch):
+    """The 3-band DOS sweep kernel (dos3_scan_kernel: real cubic / one-reciprocal eigenvalue form, transposed LDS
+    reduction, one reciprocal per pair of nodes) against the oracle's quadsum (src/fourier.jl:204-207 with
+    the DOS integrand) and against the generic scan (ABZ_DOS3_SCAN=0): full grid and symmetric rule (weights), sweep
+    lengths around the 16-value tiles and beyond one 256-value pass, forced sweep rows,
+    small eta (poles close to the axis)."""
+    from autobzcore.jl_amd import _lib as L
+    rng = np.random.default_rng(77)
+    c, first = rand_series(rng, (3, 3, 3), 3, hermitian=True)
+    s, so = both(abz, c, first)
+    cubic = abz.load_bz(abz.CubicSymIBZ(), np.eye(3)).syms
+    for syms, npt in ((None, 13), (cubic, 14)):
+        rule = s.device().rule(npt, syms, want=3)
+        for eta in (0.2, 1e-3):
+            for nw in (1, 15, 16, 17, 33, 300):
+                omegas = np.sort(rng.uniform(-3.5, 3.5, size=nw))
+                for fid, tol in ((L.F_DOS, 2e-12), (L.F_DOS_EIG, 1e-10)):
+                    a = rule.reduce(fid, [eta], omegas)[:, 0]
+                    monkeypatch.setenv("ABZ_DOS3_SCAN", "0")
+                    b = rule.reduce(fid, [eta], omegas)[:, 0]
+                    monkeypatch.delenv("ABZ_DOS3_SCAN")
+                    assert np.all(a.imag == 0) and np.isfinite(a.real).all()
+                    assert np.abs(a - b).max() <= tol * np.abs(b).max(), (npt, eta, nw, fid)
+        omegas = np.linspace(-3, 3, 37)
+        ref = np.array([orc._ptr_rule_sum(so, npt, syms, orc.f_dos(0.2, om))[0] for om in omegas[::9]])
+        base = rule.reduce(L.F_DOS, [0.2], omegas)[:, 0].real
+        assert np.abs(base[::9] - ref).max() <= 1e-11 * np.abs(ref).max()
+        for rows in (2, 3):
+            monkeypatch.setenv("ABZ_REDUCE_ROWS", str(rows))
+            for fid in (L.F_DOS, L.F_DOS_EIG):
+                got = rule.reduce(fid, [0.2], omegas)[:, 0].real
+                assert np.abs(got - base).max() <= (1e-12 if fid == L.F_DOS else 1e-10) * np.abs(base).max(), (rows, fid)
+            monkeypatch.delenv("ABZ_REDUCE_ROWS")
+        rule.close()
+
+
 @pytest.mark.parametrize("n", [2, 3])
 def test_rule_reduce_non_hermitian_series(abz, n):
     """A series that is NOT Hermitian (e.g. H + a k-dependent self-energy) takes the general paths:
