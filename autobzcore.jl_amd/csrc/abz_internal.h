@@ -72,6 +72,7 @@ struct PlaneView {
     int pitch = 0;           // doubles from one plane to the next
     int line_len = 1;
     int row = 0;             // padded row length (multiple of 16 doubles = 128 B)
+    int compact = 0;         // H planes of a Hermitian rule stored as the upper triangle only (ABZ_WANT_H_COMPACT): = n
 };
 
 // Device-resident description of the nodes of a symmetric (irreducible-node) rule: grid indices, weights and the

@@ -777,6 +777,10 @@ static int rule_fill(abz_rule* r) {
     const int d = s->d, n = s->n;
     const double2* tab = rp->tab.as<double2>();
     r->herm = s->hermitian;
+    if (r->H.compact && !s->hermitian) {
+        set_error("the rule keeps H(k) as an upper triangle (ABZ_WANT_H_COMPACT) and the series is no longer Hermitian: build a new rule");
+        return ABZ_ERR_ARG;
+    }
     if (rule_ggr_fused(r)) {
         // Fused GGR build (kernels_ggr.hip): H, every dH/dk_j, the eigensolve and the velocities in one kernel; only
         // (e, v) reach HBM.  ref: src/dos_ggr.jl:14-44
@@ -1002,7 +1006,10 @@ static int rule_build(abz_series* s, int npt, int64_t nirr, const int32_t* irr_i
     const int line_len = r->full ? npt : 64;
     const int pitch = (line_len + 15) / 16 * 16;  // whole 128-B lines: 64-B and 16-B quanta measured 25-40 % slower
     r->ntiles = std::max<int64_t>(1, (plan.nk + line_len - 1) / line_len);
-    const int pH = (want & ABZ_WANT_H) ? 2 * n * n : 0;
+    // Hermitian-compact H planes (abzhip.h): the upper triangle only
+    const bool compact = (want & ABZ_WANT_H) && (want & ABZ_WANT_H_COMPACT) && s->hermitian && n <= 4;
+    if (!compact) r->want = (want &= ~ABZ_WANT_H_COMPACT);
+    const int pH = (want & ABZ_WANT_H) ? (compact ? n * n : 2 * n * n) : 0;
     const int pE = (want & ABZ_WANT_EIG) ? n : 0;
     const int pV = (want & ABZ_WANT_VEL) ? d * n : 0;
     r->planes = pH + pE + pV;
@@ -1069,6 +1076,7 @@ static int rule_build(abz_series* s, int npt, int64_t nirr, const int32_t* irr_i
         return v;
     };
     r->H = mkview(0, pH > 0);
+    r->H.compact = compact ? n : 0;
     r->E = mkview(pH, pE > 0);
     r->V = mkview(pH + pE, pV > 0);
     if (st) {

@@ -330,28 +330,34 @@ __device__ __forceinline__ int64_t view_off(const PlaneView& v, int64_t k) {
     return line * v.tile + (k - line * v.line_len);
 }
 
+// Plane of Re H[a][b], a <= b, in a view (Im is the next plane).  Full layout, the reference's SMatrix order:
+// 2 (a + N b).  Hermitian-compact layout (PlaneView::compact, ABZ_WANT_H_COMPACT in abzhip.h): the upper triangle column
+// by column, b^2 + 2 a; the real diagonal entry H[b][b] is the single plane b^2 + 2 b.
+template <int N>
+__device__ __forceinline__ int hplane(const PlaneView& v, int a, int b) {
+    return v.compact ? b * b + 2 * a : 2 * (a + N * b);
+}
+
 template <int N>
 __device__ __forceinline__ void store_planes(const CMat<N>& H, const PlaneView& v, int64_t off) {
     double* __restrict__ out = v.base + off;
+    if (v.compact) {
+#pragma unroll
+        for (int b = 0; b < N; ++b) {
+#pragma unroll
+            for (int a = 0; a <= b; ++a) {
+                out[(int64_t)(b * b + 2 * a) * v.pitch] = H.re[a][b];
+                if (a < b) out[(int64_t)(b * b + 2 * a + 1) * v.pitch] = H.im[a][b];
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int b = 0; b < N; ++b) {
 #pragma unroll
         for (int a = 0; a < N; ++a) {
             out[(int64_t)(2 * (a + N * b)) * v.pitch] = H.re[a][b];
             out[(int64_t)(2 * (a + N * b) + 1) * v.pitch] = H.im[a][b];
-        }
-    }
-}
-
-template <int N>
-__device__ __forceinline__ void load_planes(CMat<N>& H, const PlaneView& v, int64_t off) {
-    const double* __restrict__ in = v.base + off;
-#pragma unroll
-    for (int b = 0; b < N; ++b) {
-#pragma unroll
-        for (int a = 0; a < N; ++a) {
-            H.re[a][b] = in[(int64_t)(2 * (a + N * b)) * v.pitch];
-            H.im[a][b] = in[(int64_t)(2 * (a + N * b) + 1) * v.pitch];
         }
     }
 }
@@ -364,8 +370,9 @@ __device__ __forceinline__ void load_planes_herm(CMat<N>& H, const PlaneView& v,
     for (int b = 0; b < N; ++b) {
 #pragma unroll
         for (int a = 0; a <= b; ++a) {
-            H.re[a][b] = in[(int64_t)(2 * (a + N * b)) * v.pitch];
-            H.im[a][b] = (a == b) ? 0.0 : in[(int64_t)(2 * (a + N * b) + 1) * v.pitch];
+            const int pl = hplane<N>(v, a, b);
+            H.re[a][b] = in[(int64_t)pl * v.pitch];
+            H.im[a][b] = (a == b) ? 0.0 : in[(int64_t)(pl + 1) * v.pitch];
         }
     }
 #pragma unroll
@@ -374,6 +381,23 @@ __device__ __forceinline__ void load_planes_herm(CMat<N>& H, const PlaneView& v,
         for (int a = b + 1; a < N; ++a) {
             H.re[a][b] = H.re[b][a];
             H.im[a][b] = -H.im[b][a];
+        }
+    }
+}
+
+template <int N>
+__device__ __forceinline__ void load_planes(CMat<N>& H, const PlaneView& v, int64_t off) {
+    if (v.compact) {  // only the upper triangle exists
+        load_planes_herm<N>(H, v, off);
+        return;
+    }
+    const double* __restrict__ in = v.base + off;
+#pragma unroll
+    for (int b = 0; b < N; ++b) {
+#pragma unroll
+        for (int a = 0; a < N; ++a) {
+            H.re[a][b] = in[(int64_t)(2 * (a + N * b)) * v.pitch];
+            H.im[a][b] = in[(int64_t)(2 * (a + N * b) + 1) * v.pitch];
         }
     }
 }
@@ -407,23 +431,39 @@ __device__ __forceinline__ void store_f64(double* p, double v) {
     else
         *p = v;
 }
-template <int N, bool NT = false>
+template <int N, bool NT = false, bool HC = false>
 __device__ __forceinline__ void store_planes_at(const CMat<N>& H, const PlaneView& v, int64_t line, int i1) {
     double* __restrict__ row = v.base + line * v.tile;
     const unsigned u = (unsigned)i1;
+    if constexpr (HC) {  // Hermitian-compact planes: the upper triangle
 #pragma unroll
-    for (int b = 0; b < N; ++b) {
+        for (int b = 0; b < N; ++b) {
 #pragma unroll
-        for (int a = 0; a < N; ++a) {
-            store_f64<NT>((row + (int64_t)(2 * (a + N * b)) * v.pitch) + u, H.re[a][b]);
-            store_f64<NT>((row + (int64_t)(2 * (a + N * b) + 1) * v.pitch) + u, H.im[a][b]);
+            for (int a = 0; a <= b; ++a) {
+                store_f64<NT>((row + (int64_t)(b * b + 2 * a) * v.pitch) + u, H.re[a][b]);
+                if (a < b) store_f64<NT>((row + (int64_t)(b * b + 2 * a + 1) * v.pitch) + u, H.im[a][b]);
+            }
+        }
+    } else {
+#pragma unroll
+        for (int b = 0; b < N; ++b) {
+#pragma unroll
+            for (int a = 0; a < N; ++a) {
+                store_f64<NT>((row + (int64_t)(2 * (a + N * b)) * v.pitch) + u, H.re[a][b]);
+                store_f64<NT>((row + (int64_t)(2 * (a + N * b) + 1) * v.pitch) + u, H.im[a][b]);
+            }
         }
     }
 }
 
 template <int N, bool VEC = true>
 __device__ __forceinline__ void eval_epilogue(const EvalArgs& a, CMat<N>& H, int64_t line, int i1) {
-    if (a.H.base) store_planes_at<N>(H, a.H, line, i1);
+    if (a.H.base) {
+        if (a.H.compact)
+            store_planes_at<N, false, true>(H, a.H, line, i1);
+        else
+            store_planes_at<N>(H, a.H, line, i1);
+    }
     if (a.E.base || (VEC && a.U.base)) {
         double e[N];
         CMat<N> V;
@@ -621,13 +661,14 @@ __device__ __forceinline__ void eval_unit_store(const EvalArgs& a, CMat<N> (&H)[
         // Cache this is worth 19 % at 150^3 (neither change alone is: the interleaved order leaves the
         // store queue empty during every eigensolve, and temporal stores make the 605 MB fight for L2/MALL).
         const int pitch = a.padw ? (a.H.base ? a.H.row : a.E.row) : a.npt;
-        auto epilogue = [&](auto nt) {
+        auto epilogue = [&](auto nt, auto hc) {
             constexpr bool NT = decltype(nt)::value;
+            constexpr bool HC = decltype(hc)::value;
             if (a.H.base) {
 #pragma unroll
                 for (int j = 0; j < KPL; ++j) {
                     const int i1 = i0 + lane + 64 * j;
-                    if (i1 < pitch) store_planes_at<N, NT>(H[j], a.H, line, i1);
+                    if (i1 < pitch) store_planes_at<N, NT, HC>(H[j], a.H, line, i1);
                 }
             }
             if (a.E.base) {
@@ -645,10 +686,15 @@ __device__ __forceinline__ void eval_unit_store(const EvalArgs& a, CMat<N> (&H)[
                 }
             }
         };
-        if (a.nt)
-            epilogue(std::true_type{});
+        if (a.H.compact) {
+            if (a.nt)
+                epilogue(std::true_type{}, std::true_type{});
+            else
+                epilogue(std::false_type{}, std::true_type{});
+        } else if (a.nt)
+            epilogue(std::true_type{}, std::false_type{});
         else
-            epilogue(std::false_type{});
+            epilogue(std::false_type{}, std::false_type{});
     }
 }
 
@@ -993,7 +1039,7 @@ int launch_eval(abz_ctx* ctx, const EvalSpec& es) {
         // (npt = 100, 168 MB: 7 % slower with them; 150, 605 MB: 19 % faster)
         const int force = [] { const char* e = getenv("ABZ_NT_STORES"); return e ? atoi(e) : -1; }();  // per launch (tools sweep it)
         const PlaneView& pv = es.H.base ? es.H : es.E;
-        const double planes_out = (es.H.base ? 2.0 * es.n * es.n : 0.0) + (es.E.base ? (double)es.n : 0.0) + (es.U.base ? 2.0 * es.n * es.n : 0.0);
+        const double planes_out = (es.H.base ? (es.H.compact ? 1.0 : 2.0) * es.n * es.n : 0.0) + (es.E.base ? (double)es.n : 0.0) + (es.U.base ? 2.0 * es.n * es.n : 0.0);
         const double bytes = 8.0 * planes_out * (double)pv.row * (double)(es.grid ? es.nlines : (es.nk + 63) / 64);
         a.nt = force >= 0 ? force : (bytes > 256.0 * 1024 * 1024 ? 1 : 0);
         static const int padw = [] { const char* e = getenv("ABZ_PAD_WRITE"); return e ? atoi(e) : 1; }();
@@ -1337,17 +1383,20 @@ __global__ __launch_bounds__(256, FID == ABZ_F_GLOC ? (HERM ? 2 : 1) : ((HERM ||
         if constexpr (adjG) {
             const double* __restrict__ in = a.H.base + voff;
             const int64_t pp = a.H.pitch;
-            adj_init_h3(in[0], in[8 * pp], in[16 * pp], in[6 * pp], in[7 * pp], in[12 * pp], in[13 * pp], in[14 * pp],
-                        in[15 * pp], adj[j]);
+            const int p01 = hplane<3>(a.H, 0, 1), p02 = hplane<3>(a.H, 0, 2), p12 = hplane<3>(a.H, 1, 2);
+            adj_init_h3(in[0], in[hplane<3>(a.H, 1, 1) * pp], in[hplane<3>(a.H, 2, 2) * pp], in[p01 * pp], in[(p01 + 1) * pp], in[p02 * pp],
+                        in[(p02 + 1) * pp], in[p12 * pp], in[(p12 + 1) * pp], adj[j]);
         } else if constexpr (polyH) {
             const double* __restrict__ in = a.H.base + voff;
             const int64_t pp = a.H.pitch;
-            // plane of Re H[r][c] is 2 (r + N c), Im the next one
+            // plane of Re H[r][c]: hplane (full or Hermitian-compact layout), Im the next one
             if constexpr (N == 3) {
-                charpoly_init_h3(in[0], in[8 * pp], in[16 * pp], in[6 * pp], in[7 * pp], in[12 * pp], in[13 * pp],
-                                 in[14 * pp], in[15 * pp], cph[j]);
+                const int p01 = hplane<3>(a.H, 0, 1), p02 = hplane<3>(a.H, 0, 2), p12 = hplane<3>(a.H, 1, 2);
+                charpoly_init_h3(in[0], in[hplane<3>(a.H, 1, 1) * pp], in[hplane<3>(a.H, 2, 2) * pp], in[p01 * pp], in[(p01 + 1) * pp],
+                                 in[p02 * pp], in[(p02 + 1) * pp], in[p12 * pp], in[(p12 + 1) * pp], cph[j]);
             } else {
-                charpoly_init_h2(in[0], in[6 * pp], in[4 * pp], in[5 * pp], cph[j]);
+                const int p01 = hplane<2>(a.H, 0, 1);
+                charpoly_init_h2(in[0], in[hplane<2>(a.H, 1, 1) * pp], in[p01 * pp], in[(p01 + 1) * pp], cph[j]);
             }
         } else if constexpr (adjG4) {
             load_planes_herm<N>(H[0], a.H, voff);
@@ -1554,9 +1603,10 @@ __global__ __launch_bounds__(256, 3) void dos3_scan_kernel(ReduceArgs a, double 
         if constexpr (MODE == 0) {
             const double* __restrict__ in = a.H.base + voff;
             const int64_t pp = a.H.pitch;
-            CharPolyH cp;  // plane of Re H[r][c] is 2 (r + 3 c), Im the next one
-            charpoly_init_h3(in[0], in[8 * pp], in[16 * pp], in[6 * pp], in[7 * pp], in[12 * pp], in[13 * pp], in[14 * pp],
-                             in[15 * pp], cp);
+            CharPolyH cp;  // plane of Re H[r][c]: hplane (full or Hermitian-compact layout), Im the next one
+            const int p01 = hplane<3>(a.H, 0, 1), p02 = hplane<3>(a.H, 0, 2), p12 = hplane<3>(a.H, 1, 2);
+            charpoly_init_h3(in[0], in[hplane<3>(a.H, 1, 1) * pp], in[hplane<3>(a.H, 2, 2) * pp], in[p01 * pp], in[(p01 + 1) * pp],
+                             in[p02 * pp], in[(p02 + 1) * pp], in[p12 * pp], in[(p12 + 1) * pp], cp);
             c0[j] = cp.q;
             c1[j] = cp.p1;
             c2[j] = cp.p0;
@@ -2113,6 +2163,15 @@ __global__ void export_kernel(PlaneView v, int ncomp, int64_t nk, double* __rest
     if (t >= nk * ncomp) return;
     const int64_t k = t / ncomp;
     const int c = (int)(t - k * ncomp);
+    if (v.compact) {  // upper-triangle planes -> the full matrix in the reference's order, component 2 (a + n b) + {re, im}
+        const int n = v.compact, im = c & 1, ab = c >> 1;
+        const int a = ab % n, b = ab / n;
+        const int lo = a < b ? a : b, hi = a < b ? b : a;
+        double val = 0.0;
+        if (!(im && a == b)) val = v.base[view_off(v, k) + (int64_t)(hi * hi + 2 * lo + im) * v.pitch];
+        out[t] = (im && a > b) ? -val : val;
+        return;
+    }
     out[t] = v.base[view_off(v, k) + (int64_t)c * v.pitch];
 }
 

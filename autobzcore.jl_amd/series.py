@@ -154,6 +154,8 @@ class DeviceSeries:
         buf = np.ascontiguousarray(julia_coefficient_order(self.s.c, self.s.d).view(np.float64))
         L.check(L.lib().abz_series_update(self.h, buf.ctypes.data_as(L.c_f64p)))
         self.generation += 1
+        if any(r.want & L.WANT_H_COMPACT for r in self.rules.values()) and not self.hermitian():
+            self.drop_rules()  # upper-triangle rules cannot hold the values of a series that stopped being Hermitian
 
     # ---- arbitrary nodes (BatchIntegrand body / fallback evaluator)
     def eval_nodes(self, k, want=L.WANT_H):
@@ -219,6 +221,11 @@ class DeviceSeries:
         """Cached rule.  With `self.kshard = (rank, world)` set (dist.kshard) the rule holds this rank's
         share of the nodes only -- a slab of the outermost variable of a full grid, or every world-th
         irreducible node -- and its reductions are summed over the ranks by `self.allreduce`."""
+        # rules of a Hermitian series keep H(k) as its upper triangle (n^2 planes instead of 2 n^2: every built-in
+        # integrand reads those planes only, export() still returns full matrices); ABZ_RULE_COMPACT=0: the reference's
+        # full SMatrix layout
+        if (want & L.WANT_H) and self.s.n <= 4 and os.environ.get("ABZ_RULE_COMPACT", "1") != "0" and self.hermitian():
+            want |= L.WANT_H_COMPACT
         key = (int(npt), _syms_key(syms), int(want), self.kshard)
         r = self.rules.pop(key, None)
         if r is None:
@@ -332,7 +339,11 @@ class DeviceRule:
         self._h = h if h.value else None
         self._closed = False
         self.generation = dev.generation
-        per = (2 * n * n if want & L.WANT_H else 0) + (n if want & (L.WANT_EIG | L.WANT_VEL) else 0) + \
+        if self._h is not None and want & L.WANT_H_COMPACT:  # the library drops the bit when the layout does not apply
+            got = C.c_int(0)
+            L.check(L.lib().abz_rule_info(self._h, None, None, None, None, C.byref(got)))
+            self.want = want = int(got.value)
+        per = ((n * n if want & L.WANT_H_COMPACT else 2 * n * n) if want & L.WANT_H else 0) + (n if want & (L.WANT_EIG | L.WANT_VEL) else 0) + \
               (d * n if want & L.WANT_VEL else 0)
         self.nbytes = 8 * per * self.nk_local
         self._fin = weakref.finalize(self, DeviceRule._destroy, self._h)

@@ -1615,6 +1615,70 @@ def test_single_iai_solve_sharded_over_two_ranks():
     assert p.stdout.count("sharded IAI ok") == 2
 
 
+@pytest.mark.parametrize("n", [1, 2, 3, 4])
+def test_hermitian_compact_rule_layout_equals_full_layout(abz, n, monkeypatch):
+    """ABZ_WANT_H_COMPACT (rules of a Hermitian series keep H(k) as its upper triangle; the host mirror asks for it by
+    default): exported matrices, eigenvalues and every built-in rule sum are BIT-identical to the reference's full
+    SMatrix layout (FourierPTR's vals, src/fourier.jl:127-174) on full grids and equal to rounding on symmetric rules,
+    with and without the packed chain; the value block shrinks to n^2 + n planes; a series that stops being Hermitian drops such rules; a
+    non-Hermitian series never gets the layout."""
+    from autobzcore.jl_amd import _lib as L
+    rng = np.random.default_rng(900 + n)
+    c, first = rand_series(rng, (3, 5, 3), n, hermitian=True)
+    s, so = both(abz, c, first)
+    dev = s.device()
+    cubic = abz.load_bz(abz.CubicSymIBZ(), np.eye(3)).syms
+    omegas = np.linspace(-2.5, 2.5, 19)
+    fids = [(L.F_DOS, [0.3], omegas), (L.F_TRGLOC, [0.3], omegas), (L.F_GLOC, [0.3], omegas[:5]), (L.F_DOS_EIG, [0.3], omegas)]
+    if n == 1:
+        fids += [(L.F_LINEAR, [1.3, 1.0], None), (L.F_LINEAR_X, [1.3, 0.5], None)]
+    for npt, syms in ((10, None), (150, None), (12, cubic)):
+        if npt == 150 and n not in (1, 3):
+            continue
+        full = abz.DeviceRule(dev, npt, syms, L.WANT_H | L.WANT_EIG)
+        comp = abz.DeviceRule(dev, npt, syms, L.WANT_H | L.WANT_EIG | L.WANT_H_COMPACT)
+        assert comp.want & L.WANT_H_COMPACT and not full.want & L.WANT_H_COMPACT
+        bf, bc = full.values_ptr()[1], comp.values_ptr()[1]
+        assert bc * (2 * n * n + n) == bf * (n * n + n)
+        ef = full.export(x=False, w=False, H=True, eig=True)
+        ec = comp.export(x=False, w=False, H=True, eig=True)
+        # full grids: the grid kernel mirrors the upper triangle, so both layouts hold the same bits.  Node lists: the
+        # full layout keeps an independently rounded lower triangle (and a diagonal imaginary part of rounding size)
+        same = (lambda a, b: np.array_equal(a, b)) if syms is None else \
+            (lambda a, b: np.abs(a - b).max() <= 1e-14 * max(np.abs(a).max(), 1e-300))
+        assert same(ef["H"], ec["H"]) and np.array_equal(ef["eig"], ec["eig"])
+        assert np.array_equal(ec["H"], np.conj(np.swapaxes(ec["H"], -1, -2))) or n == 1
+        for fid, params, sw in fids:
+            a, b = full.reduce(fid, params, sw), comp.reduce(fid, params, sw)
+            assert same(a, b), (n, npt, fid)
+        if npt == 10:  # the unpacked chain gives the same planes
+            monkeypatch.setenv("ABZ_EVAL_PACKED", "0")
+            comp.rebuild()
+            monkeypatch.delenv("ABZ_EVAL_PACKED")
+            e2 = comp.export(x=False, w=False, H=True)
+            assert np.abs(e2["H"] - ec["H"]).max() <= 1e-13 * np.abs(ec["H"]).max()
+        full.close()
+        comp.close()
+    # the host mirror asks for the compact layout by itself, and drops such rules when the series stops being Hermitian
+    r = dev.rule(8, None, want=L.WANT_H)
+    assert r.want & L.WANT_H_COMPACT
+    ref = np.array([orc._ptr_rule_sum(so, 8, None, orc.f_dos(0.3, om))[0] for om in omegas[:3]])
+    assert np.abs(r.reduce(L.F_DOS, [0.3], omegas[:3])[:, 0].real - ref).max() <= 1e-11 * np.abs(ref).max()
+    extra, _ = rand_series(rng, (3, 5, 3), n, hermitian=False)
+    with pytest.raises(ValueError):  # the library refuses to refill an upper-triangle rule from such a series
+        keep = abz.DeviceRule(dev, 6, None, L.WANT_H | L.WANT_H_COMPACT)
+        L.check(L.lib().abz_series_update(dev.h, np.ascontiguousarray(
+            abz.series.julia_coefficient_order(c + 0.05 * extra, 3).view(np.float64)).ctypes.data_as(L.c_f64p)))
+        keep.rebuild()
+    dev.update(c + 0.05 * extra)
+    assert not dev.rules and not dev.hermitian()
+    r2 = dev.rule(8, None, want=L.WANT_H)
+    assert not r2.want & L.WANT_H_COMPACT
+    so2 = orc.FourierSeries(c + 0.05 * extra, period=1.0, first=first, ndim=3)
+    ref = np.array([orc._ptr_rule_sum(so2, 8, None, orc.f_dos(0.6, om))[0] for om in omegas[:3]])
+    assert np.abs(r2.reduce(L.F_DOS, [0.6], omegas[:3])[:, 0].real - ref).max() <= 1e-10 * np.abs(ref).max()
+
+
 # ------------------------------------------------------------------ errors
 def test_padded_planar_rule_layout_option():
     """ABZ_RULE_PLANAR=1 lays full-grid rules out as [plane][line][row] instead of tiles [line][plane][row] (the same
