@@ -187,7 +187,16 @@ class DeviceSeries:
                 not (fid in (L.F_LINEAR, L.F_LINEAR_X) and s.n != 1))
 
     def hermitian(self):
-        """H_{-R} = H_R^dagger on the stored coefficient array (what the library detects at upload)."""
+        """H_{-R} = H_R^dagger on the stored coefficient array (what the library detects at upload); cached per
+        coefficient generation."""
+        cached = getattr(self, "_herm", None)
+        if cached is not None and cached[0] == self.generation and cached[1] is self.s.c:
+            return cached[2]
+        v = self._hermitian_now()
+        self._herm = (self.generation, self.s.c, v)
+        return v
+
+    def _hermitian_now(self):
         c = self.s.c
         flip = c[tuple(slice(None, None, -1) for _ in range(self.s.d))]
         sym = all(2 * f + m - 1 == 0 for f, m in zip(np.atleast_1d(self.s.first), c.shape[:self.s.d]))

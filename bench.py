@@ -57,6 +57,9 @@ def parse_args():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-iai", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="primary metric + sharded jobs only")
+    ap.add_argument("--no-ref-layout", action="store_true",
+                    help="skip the reference-layout and eigenvalues-only legs (profiling runs: the kernel trace then holds "
+                         "one layout per instance of the Fourier-eval kernel)")
     ap.add_argument("--force-dist", action="store_true",
                     help="rehearsal: initialise the process group and run the sharded jobs even at world size 1 "
                          "(under `python -m torch.distributed.run --nproc-per-node 1`): the RCCL calls on one GPU")
@@ -82,12 +85,13 @@ def spawn_ranks(a):
     return p.returncode
 
 
-def pmc_traffic(npt):
+def pmc_traffic(npt, compact=False):
     """HBM bytes per launch of the Fourier-eval kernel from the committed rocprofv3 PMC passes
-    (profiles/r03_traffic.json (or an earlier round's), written by tools/collect_profiles.sh: WRITE_SIZE and
-    FETCH_SIZE in separate --pmc runs, FETCH_SIZE doubled per the gfx950 correction).  None if not
-    collected for this grid size: counters cannot be read from inside an un-profiled bench run."""
-    for name in ("r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):
+    (profiles/r03_traffic[_compact].json (or an earlier round's), written by tools/collect_profiles.sh: WRITE_SIZE and
+    FETCH_SIZE in separate --pmc runs, FETCH_SIZE doubled per the gfx950 correction), for the rule layout that was
+    timed.  None if not collected for this grid size: counters cannot be read from inside an un-profiled bench run."""
+    names = ("r03_traffic_compact.json",) if compact else ("r03_traffic.json", "r02_traffic.json", "r01_traffic.json")
+    for name in names:
         try:
             t = json.load(open(os.path.join(ROOT, "profiles", name)))
             if int(t.get("npt", -1)) == int(npt):
@@ -218,7 +222,13 @@ def rank_main(a):
     npt = a.npt
     nk = npt**3
     n = 3
-    rule = dev.rule(npt, None, L.WANT_H | L.WANT_EIG)  # inputs + rule buffers resident before timing
+    # inputs + rule buffers resident before timing.  dev.rule() is the host mirror's own call: rules of a Hermitian series
+    # keep H(k) as its upper triangle (ABZ_WANT_H_COMPACT, 96 B per k-point with the eigenvalues instead of the
+    # reference layout's 168); ABZ_RULE_COMPACT=0 times the reference layout as the primary number instead
+    rule = dev.rule(npt, None, L.WANT_H | L.WANT_EIG)
+    WANT = rule.want
+    compact = bool(WANT & L.WANT_H_COMPACT)
+    bpk = 8 * (n * n + n) if compact else 16 * n * n + 8 * n  # bytes one k-point leaves in HBM (H + eigenvalues)
     base_addr, rule_bytes = rule.values_ptr()
     n_total = a.omegas_per_rank * world
     omegas_all = np.linspace(10.0, 15.0, n_total)
@@ -250,6 +260,45 @@ def rank_main(a):
     ctx.prof_enable(False)
     step_ms = np.diff([t0] + block_ms) * 1e3 if block_ms else np.array([tA * 1e3 / a.steps])
 
+    # the same passes with H(k) in the reference's full SMatrix layout (168 B per k-point): the numbers of rounds 1-2
+    ref_layout = None
+    if compact and world == 1 and not a.force_dist and not a.no_ref_layout:
+        rfull = abz.DeviceRule(dev, npt, None, L.WANT_H | L.WANT_EIG)
+        for _ in range(max(a.warmup, 1) * 8):
+            rfull.rebuild()
+        ctx.sync()
+        ctx.prof_enable(True, kernels=[L.K_EVAL])
+        ctx.prof_reset()
+        nrep = max(a.steps * P // 4, 8)
+        t0 = time.perf_counter()
+        for _ in range(nrep):
+            rfull.rebuild()
+        ctx.sync()
+        tF = time.perf_counter() - t0
+        msF, nF = ctx.prof_read(L.K_EVAL)
+        ctx.prof_enable(False)
+        fb = 16 * n * n + 8 * n
+        ref_layout = {"what": "the same rebuild passes with H(k) stored as the reference does (full n x n complex matrix per node, "
+                              "FourierPTR's vals, src/fourier.jl:127-174): 168 B per k-point",
+                      "value": nk * nrep / tF, "ms_per_pass": 1e3 * tF / nrep, "avg_launch_ms": msF / max(nF, 1), "launches": nF,
+                      "algorithmic_bytes_per_kpoint": fb, "achieved_GBs": nk * fb / ((msF / max(nF, 1)) * 1e-3) / 1e9,
+                      "frac": nk * fb / ((msF / max(nF, 1)) * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": pmc_traffic(npt, False),
+                      "rule_bytes": rfull.values_ptr()[1]}
+        rfull.close()
+        reig = abz.DeviceRule(dev, npt, None, L.WANT_EIG)  # the kernel without its H stores: the compute floor
+        for _ in range(max(a.warmup, 1) * 8):
+            reig.rebuild()
+        ctx.sync()
+        ctx.prof_enable(True, kernels=[L.K_EVAL])
+        ctx.prof_reset()
+        for _ in range(nrep):
+            reig.rebuild()
+        ctx.sync()
+        msE, nE = ctx.prof_read(L.K_EVAL)
+        ctx.prof_enable(False)
+        reig.close()
+        ref_layout["eigenvalues_only_avg_launch_ms"] = msE / max(nE, 1)
+
     # the same rebuild with the last contraction fused into the Fourier-eval kernel (ABZ_FUSE2=1, opt-in)
     two = None
     if world == 1 and not a.no_extras and not a.force_dist:
@@ -270,7 +319,7 @@ def rank_main(a):
         rule.rebuild()
         ctx.sync()
         two = {"ms_per_pass": 1e3 * t2 / (a.steps * 8), "eval_kernel_avg_ms": ms2 / max(n2, 1),
-               "frac": nk * 168 / ((ms2 / max(n2, 1)) * 1e-3) / 1e9 / 8000.0 if n2 else None,
+               "frac": nk * bpk / ((ms2 / max(n2, 1)) * 1e-3) / 1e9 / 8000.0 if n2 else None,
                "note": "opt-in variant ABZ_FUSE2=1: contract x1 + eval_grid_fused_kernel (level-1 sets never leave the CU)"}
 
     # ---------------- Phase B: fused sweeps over this rank's omegas (matrix-cached, reference-faithful)
@@ -350,7 +399,7 @@ def rank_main(a):
 
         # (2) k-sharded: a slab of the outermost grid variable per rank, all 256 omega, one all_reduce(sum)
         dev.kshard = (rank, world)
-        rule_k = abz.DeviceRule(dev, npt, None, L.WANT_H | L.WANT_EIG)
+        rule_k = abz.DeviceRule(dev, npt, None, WANT)
         dev.kshard = None
         acc = torch.zeros(256, 2, dtype=torch.float64, device=f"cuda:{local}")
 
@@ -384,7 +433,7 @@ def rank_main(a):
     big_job = None
     if not a.no_big_job:
         try:
-            big_job = big_dos_job(a, abz, L, torch, dist, dev, rank, world, local, distributed, cdev, barrier, timed)
+            big_job = big_dos_job(a, abz, L, torch, dist, dev, rank, world, local, distributed, cdev, barrier, timed, WANT)
         except Exception as e:
             big_job = {"error": str(e)}
 
@@ -457,7 +506,7 @@ def rank_main(a):
     if rank == 0:
         kps = world * nk * P * a.steps / tA
         eval_avg_s = (eval_ms / max(eval_n, 1)) * 1e-3
-        achieved = nk * (16 * n * n + 8 * n) / eval_avg_s / 1e9 if eval_avg_s > 0 else 0.0
+        achieved = nk * bpk / eval_avg_s / 1e9 if eval_avg_s > 0 else 0.0
         build_ms = 1e3 * tA / (a.steps * P)
         out = {
             "metric": "k-point evals/sec (H(k)+eig)", "value": kps, "unit": "k-points/s",
@@ -469,6 +518,9 @@ def rank_main(a):
                                    f"one step = {P} passes over the grid",
                        "npt": npt, "nk_per_gpu": nk, "passes_per_step": P, "n_bands": 3, "n_R": 1331,
                        "omegas_per_gpu": a.omegas_per_rank,
+                       "rule_layout": ("hermitian-compact: upper triangle of H(k) + eigenvalues, 96 B per k-point (the host mirror's default "
+                                       "for Hermitian series; exports and rule sums bit-identical to the full layout)") if compact else
+                                      "reference: full H(k) + eigenvalues, 168 B per k-point",
                        "parallelism": f"omega-sharded x{world}, coefficient+rule replicas"},
             "n_ranks_seen": n_ranks_seen, "backend": ("rccl(nccl)" if backend == "nccl" else backend) if distributed else None,
             "rehearsal_ranks_share_one_gpu": bool(rehearsal),
@@ -493,15 +545,23 @@ def rank_main(a):
             "iai_sweep_432_omega": iai_job,
             "iai_config5_sharded": c5_job,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(npt),
-                         "store_pattern_ceiling_GBs": 5830.0,
-                         "frac_of_store_pattern_ceiling": achieved / 5830.0,
-                         "store_pattern_note": "bare store pattern of this kernel's tiled planar layout without any compute "
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(npt, compact),
+                         "compute_floor_note": ("the same kernel storing eigenvalues only (no H planes) takes "
+                                                f"{ref_layout['eigenvalues_only_avg_launch_ms']:.4f} ms: with the compact layout the H stores are almost "
+                                                "hidden behind the Fourier sums and the eigensolves, the kernel sits between its f64-VALU floor and its HBM-write floor")
+                                               if ref_layout else None,
+                         "store_pattern_note": "reference layout: bare store pattern of this kernel's tiled planar layout without any compute "
                                                "(tools/micro/placement.hip, profiles/r02_placement_microbench.txt): 6.2 TB/s = 5.83 TB/s of useful bytes with temporal stores, "
                                                "5.2-5.6 TB/s with the non-temporal stores the kernel needs (allocation-dependent); a linear memset 8.2 TB/s",
-                         "traffic_note": "HBM bytes per launch from rocprofv3 PMC passes (profiles/r0x_traffic.json); algorithmic bytes per launch = nk*168",
+                         "traffic_note": f"HBM bytes per launch from rocprofv3 PMC passes (profiles/r03_traffic{'_compact' if compact else ''}.json); "
+                                         f"algorithmic bytes per launch = nk*{bpk}",
+                         "reference_layout": ref_layout,
+                         "survey_8d_accounting_note": ("SURVEY 8(d) prices a k-point at 168 B because the reference stores the full matrix; this "
+                                                       "launch writes the 96 B a Hermitian matrix + its eigenvalues need, so `achieved` and `frac` "
+                                                       "use 96 B (168 B x this rate would exceed the HBM peak and is not claimed); the reference "
+                                                       "layout's own time and fraction are in `reference_layout`") if compact else None,
                          "kernel": "eval_grid_kernel<3> (Fourier-eval + fused eig)",
-                         "algorithmic_bytes_per_kpoint": 16 * n * n + 8 * n,
+                         "algorithmic_bytes_per_kpoint": bpk,
                          "avg_launch_ms": eval_ms / max(eval_n, 1), "launches": eval_n,
                          "fused_contraction_variant": two,
                          "contract_avg_ms": con_ms / max(con_n, 1),
@@ -528,7 +588,7 @@ def rank_main(a):
         dist.destroy_process_group()
 
 
-def big_dos_job(a, abz, L, torch, dist, dev, rank, world, local, distributed, cdev, barrier, timed):
+def big_dos_job(a, abz, L, torch, dist, dev, rank, world, local, distributed, cdev, barrier, timed, WANT=None):
     """Fixed job with enough work to divide by 8: the 256-omega DOS sweep at eta = 0.01 eV (the value of
     aps_example/aps_example.jl:29) on the --big-npt^3 full-BZ grid (400^3 = 6.4e7 k-points, 10.8 GB of rule values:
     a PTR grid that resolves eta = 0.01), k-sharded: 1/N slab per rank, all 256 omega, one all_reduce(sum).
@@ -537,11 +597,12 @@ def big_dos_job(a, abz, L, torch, dist, dev, rank, world, local, distributed, cd
     om256 = np.linspace(10.0, 15.0, 256)
     om_dev = torch.from_numpy(om256).to(f"cuda:{local}")
     reps = 5
+    WANT = WANT or (L.WANT_H | L.WANT_EIG)
     res = {"what": f"rule build on the {npt}^3 grid + DOS at 256 omega, eta = {eta} + collective + results on the host",
-           "npt": npt, "nk": npt**3, "eta": eta, "rule_bytes_n1": npt**3 * 168}
+           "npt": npt, "nk": npt**3, "eta": eta, "rule_bytes_n1": npt**3 * (96 if WANT & L.WANT_H_COMPACT else 168)}
     ref = None
     if rank == 0:
-        full = abz.DeviceRule(dev, npt, None, L.WANT_H | L.WANT_EIG)
+        full = abz.DeviceRule(dev, npt, None, WANT)
         out = torch.zeros(256, 2, dtype=torch.float64, device=f"cuda:{local}")
 
         def job1():
@@ -555,7 +616,7 @@ def big_dos_job(a, abz, L, torch, dist, dev, rank, world, local, distributed, cd
     barrier()
     if distributed:
         dev.kshard = (rank, world)
-        rk = abz.DeviceRule(dev, npt, None, L.WANT_H | L.WANT_EIG)
+        rk = abz.DeviceRule(dev, npt, None, WANT)
         dev.kshard = None
         acc = torch.zeros(256, 2, dtype=torch.float64, device=f"cuda:{local}")
 

@@ -51,8 +51,10 @@ for k, ent in summary.items():
 json.dump(summary, open(os.path.join(dst, f"{tag}_pmc_summary.json"), "w"), indent=1, sort_keys=True)
 for k, ent in summary.items():
     if ("eval_grid_kernel" in k or "eval_grid_fused_kernel" in k) and "hbm_bytes_per_launch" in ent:
-        json.dump({"kernel": k, "npt": 150, "tag": tag, "hbm_bytes_per_launch": ent["hbm_bytes_per_launch"],
+        compact = os.environ.get("ABZ_RULE_COMPACT", "1") != "0"  # the layout tools/prof_eval.py built (the host mirror's default)
+        json.dump({"kernel": k, "npt": 150, "tag": tag, "layout": "hermitian-compact (96 B/k)" if compact else "reference (168 B/k)",
+                   "hbm_bytes_per_launch": ent["hbm_bytes_per_launch"],
                    "WRITE_SIZE_KB": ent["WRITE_SIZE"], "FETCH_SIZE_KB": ent["FETCH_SIZE"], "note": ent["hbm_bytes_note"],
-                   "algorithmic_bytes_per_launch": 150**3 * 168},
-                  open(os.path.join(dst, f"{tag[:3]}_traffic.json"), "w"), indent=1)
+                   "algorithmic_bytes_per_launch": 150**3 * (96 if compact else 168)},
+                  open(os.path.join(dst, f"{tag[:3]}_traffic{'_compact' if compact else ''}.json"), "w"), indent=1)
 print(json.dumps({k: v for k, v in summary.items() if "eval_grid" in k}, indent=1))
