@@ -42,6 +42,7 @@ int stage_d2h(abz_ctx* ctx, void* dst_host, const void* src_dev, size_t bytes);
 int mbox_reserve(abz_ctx* ctx);
 struct SymTables;
 int sym_tables_device(abz_ctx* ctx, int npt, int d, const int32_t* syms, int nsyms, SymTables& out);
+void preload_symptr_code();  // kernels_symptr.hip: force the lazy code-object load
 
 // caching device allocator (api.cpp): blocks freed with dev_free are reused by later dev_alloc calls
 int dev_alloc(void** out, size_t bytes, size_t* cap_out);
