@@ -23,6 +23,10 @@ const libabz = "libabzhip"   # autobzcore.jl_amd/libabzhip.so on the loader path
 
 # ---------------------------------------------------------------- constants of abzhip.h
 const WANT_H, WANT_EIG, WANT_VEL = Cint(1), Cint(2), Cint(4)
+# rules of a Hermitian series (n <= 4) keep H(k) as its upper triangle: n^2 value planes instead of 2 n^2; ignored otherwise.
+# Device integrands read those planes, abz_rule_export still returns full matrices (abzhip.h).
+const WANT_H_COMPACT = Cint(8)
+const WANT_HC = WANT_H | WANT_H_COMPACT
 const F_ONE, F_LINEAR, F_LINEAR_X, F_DOS, F_TRGLOC, F_GLOC, F_DOS_EIG = Cint.(0:6)
 const LIMS_CUBIC, LIMS_TETRAHEDRAL, LIMS_POLYHEDRAL, LIMS_POLYGON = Cint(0), Cint(1), Cint(2), Cint(3)
 
@@ -170,7 +174,7 @@ AutoBZCore.init_cacheval(f::HIPFourierIntegrand, bz::SymmetricBZ, p, ::Union{PTR
 function AutoBZCore.do_solve(f::HIPFourierIntegrand, bz::SymmetricBZ, p, alg::PTR, hs::HIPSeries;
     abstol=nothing, reltol=nothing, maxiters=typemax(Int))
     j = abs(det(bz.B))                                   # src/brillouin.jl:340
-    r = rule!(hs, alg.npt, bz.syms, WANT_H)
+    r = rule!(hs, alg.npt, bz.syms, WANT_HC)
     params, omega = bind(f.f.f, merge(f.f.p, p))
     u = reduce_rule(r, f.f.f, params, [omega], 1)[1, 1]
     return IntegralSolution(j * nsyms(bz) * real(u), nothing, true, r.nk)   # TrivialRep: src/brillouin.jl:107
@@ -185,11 +189,11 @@ function AutoBZCore.do_solve(f::HIPFourierIntegrand, bz::SymmetricBZ, p, alg::Au
     dn = clamp(round(Int, alg.Δn / alg.a), alg.nmin, alg.nmax)
     params, omega = bind(f.f.f, merge(f.f.p, p))
     npt = n0; numevals = 0
-    rule = rule!(hs, npt, bz.syms, WANT_H); numevals += rule.nk
+    rule = rule!(hs, npt, bz.syms, WANT_HC); numevals += rule.nk
     I1 = nsyms(bz) * real(reduce_rule(rule, f.f.f, params, [omega], 1)[1, 1])
     while true
         npt += dn
-        rule = rule!(hs, npt, bz.syms, WANT_H); numevals += rule.nk
+        rule = rule!(hs, npt, bz.syms, WANT_HC); numevals += rule.nk
         I2 = nsyms(bz) * real(reduce_rule(rule, f.f.f, params, [omega], 1)[1, 1])
         err = abs(I2 - I1)
         (err <= max(atol, rtol * abs(I2)) || numevals >= maxiters) && return IntegralSolution(I2 * j, err * j, true, numevals)
@@ -242,7 +246,7 @@ end
 function AutoBZCore.batchsolve(s::IntegralSolver{<:HIPFourierIntegrand,<:SymmetricBZ,<:PTR}, omegas::AbstractVector{<:Real})
     f, bz = s.f, s.dom
     hs = HIPSeries(f.w.series)
-    r = rule!(hs, s.alg.npt, bz.syms, WANT_H)
+    r = rule!(hs, s.alg.npt, bz.syms, WANT_HC)
     params, _ = bind(f.f.f, merge(f.f.p, MixedParameters(first(omegas))))
     u = reduce_rule(r, f.f.f, params, Float64.(omegas), 1)
     return abs(det(bz.B)) * nsyms(bz) .* real.(vec(u))
@@ -324,7 +328,14 @@ synchronize(ctx::HIPContext=context()) = check(ccall((:abz_ctx_sync, libabz), Ci
 function update!(hs::HIPSeries, s::FourierSeries)
     coef = reinterpret(Float64, vec(s.c))
     GC.@preserve coef check(ccall((:abz_series_update, libabz), Cint, (Ptr{Cvoid}, Ptr{Float64}), hs.h, coef))
-    foreach(rebuild!, values(hs.rules))   # cached rule values follow the coefficients (the reference rebuilds its rule per solve)
+    try
+        foreach(rebuild!, values(hs.rules))   # cached rule values follow the coefficients (the reference rebuilds its rule per solve)
+    catch err
+        # an upper-triangle (WANT_H_COMPACT) rule cannot be refilled from a series that stopped being Hermitian
+        # (ABZ_ERR_ARG -> ArgumentError): drop the cache, the next solve builds full-layout rules
+        err isa ArgumentError || rethrow()
+        empty!(hs.rules)
+    end
     return hs
 end
 "Context on a stream the caller owns (e.g. AMDGPU.jl's task-local HIP stream): launches are ordered with the caller's work."
