@@ -33,6 +33,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cmath>
 #include <cstdlib>
 #include <cstring>
 #include <type_traits>
@@ -917,6 +918,7 @@ struct GgrArgs {
     int n, d, nE;
     int vstride;  // planes between the velocity components of a band (= number of bands of the rule)
     double b;
+    double inv_step = 0.0;  // > 0: the energies are equispaced (a linspace sweep): Es[i] = Es[0] + i / inv_step to rounding
 };
 
 // Every formula is zero outside |E - e| <= b (|v_1| + ... + |v_d|) (the last branch of each ggr_formula method), a
@@ -956,12 +958,22 @@ __global__ __launch_bounds__(256) void ggr_window_kernel(GgrArgs a, double* __re
             // a little wider than the formula's own test, which then decides exactly
             const double slack = 8.0 * 2.220446049250313e-16 * (fabs(e[bnd]) + top);
             const double lo = e[bnd] - top - slack, hi = e[bnd] + top + slack;
-            int i0 = 0, len = a.nE;  // first energy >= lo
-            while (len > 0) {
-                const int half = len >> 1;
-                const bool right = Esl[i0 + half] < lo;
-                i0 = right ? i0 + half + 1 : i0;
-                len = right ? len - half - 1 : half;
+            int i0 = 0;  // first energy >= lo
+            if (a.inv_step > 0.0) {
+                // equispaced sweep: the index by arithmetic, made exact against the list itself (two LDS reads instead of
+                // the log2(nE) dependent ones of the search)
+                const double g = (lo - Esl[0]) * a.inv_step;
+                i0 = g <= 0.0 ? 0 : (g >= (double)a.nE ? a.nE : (int)g);
+                while (i0 > 0 && Esl[i0 - 1] >= lo) --i0;
+                while (i0 < a.nE && Esl[i0] < lo) ++i0;
+            } else {
+                int len = a.nE;
+                while (len > 0) {
+                    const int half = len >> 1;
+                    const bool right = Esl[i0 + half] < lo;
+                    i0 = right ? i0 + half + 1 : i0;
+                    len = right ? len - half - 1 : half;
+                }
             }
             for (int i = i0; i < a.nE; ++i) {
                 const double En = Esl[i];
@@ -1124,6 +1136,14 @@ int launch_ggr(abz_ctx* ctx, int n, int d, int npt, PlaneView E, PlaneView V, co
         res_host = reinterpret_cast<const double*>(static_cast<const char*>(ctx->mbox) + ctx->mbox_cap / 2);
     } else {
         ABZ_HIP(hipMemcpyAsync(Es_dev, Es.data(), sizeof(double) * (size_t)nE, hipMemcpyHostToDevice, ctx->stream));
+    }
+    // an equispaced list (the usual linspace sweep) lets a thread compute its window's first index instead of searching
+    {
+        const bool off = [] { const char* e = getenv("ABZ_GGR_UNIFORM"); return e && e[0] == '0'; }();  // per call: tests compare both
+        const double step = nE >= 2 ? (Es[(size_t)nE - 1] - Es[0]) / (double)(nE - 1) : 0.0;
+        bool uni = !off && nE >= 8 && step > 0.0;
+        for (int i = 0; i < nE && uni; ++i) uni = std::fabs(Es[(size_t)i] - (Es[0] + (double)i * step)) <= 1e-6 * step;
+        a.inv_step = uni ? 1.0 / step : 0.0;
     }
     for (int s0 = 0; s0 < nE; s0 += CH) {
         const int cnt = std::min(CH, nE - s0);

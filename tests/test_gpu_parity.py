@@ -1435,6 +1435,13 @@ def test_ggr_windowed_scan_equals_all_pairs_scan(abz, svo, monkeypatch):
             monkeypatch.delenv("ABZ_GGR_SCAN")
             assert np.isfinite(b).all() and (nE < 300 or np.abs(b).max() > 0)
             assert np.abs(a - b).max() <= 1e-12 * np.abs(b).max(), (npt, nE)
+        # equispaced sweeps: the window's first index comes from arithmetic instead of the search -- the same sums to the bit
+        for Es in (np.linspace(lo - 0.2, hi + 0.2, 257), np.linspace(lo + 0.3 * (hi - lo), lo + 0.31 * (hi - lo), 1500)):
+            a = rule.ggr(Es)
+            monkeypatch.setenv("ABZ_GGR_UNIFORM", "0")
+            b = rule.ggr(Es)
+            monkeypatch.delenv("ABZ_GGR_UNIFORM")
+            assert np.array_equal(a, b) and np.abs(a).max() > 0
         rule.close()
 
 
