@@ -1061,7 +1061,8 @@ int launch_eval(abz_ctx* ctx, const EvalSpec& es) {
         // better with 8 per CU, 180 and 400 lose 2-3 % with 16).  ABZ_EVAL_BLOCKS overrides.
         const int eval_blocks = [] { const char* e = getenv("ABZ_EVAL_BLOCKS"); return e ? atoi(e) : 0; }();  // per launch: the timing tool sweeps it
         const int64_t quads = cdiv(es.nlines, 4);
-        int64_t blocks = std::min<int64_t>(quads, eval_blocks > 0 ? eval_blocks : (quads < 5000 ? 256 * 8 : 256 * 16));
+        // (compact H planes: 24 per CU -- at 150^3 one line per wave -- measured 1.5 % better than 16, the same at 200^3)
+        int64_t blocks = std::min<int64_t>(quads, eval_blocks > 0 ? eval_blocks : (quads < 5000 ? 256 * 8 : (es.H.compact ? 256 * 24 : 256 * 16)));
         const int mnn = a.pk ? es.n * (es.n + 1) / 2 + ((es.M - 1) / 2) * es.n * es.n : es.M * es.n * es.n;  // numbers per line (packed_herm.h)
         // nodes per lane: minimise lane-rounds per line, ceil(npt / (64 kpl)) * kpl, weighted by the LDS
         // operand reads that are shared by the kpl nodes of a lane (200 points: 2 x 2 rounds, not 2 x 3)

@@ -13,7 +13,7 @@ cands = [int(v) for v in os.environ.get("CANDS", "2048,3072,4096,6144,8192").spl
 for npt in [int(v) for v in sys.argv[1:]]:
     keep = []
     for alloc in range(3):
-        rule = abz.DeviceRule(dev, npt, None, L.WANT_H | L.WANT_EIG)
+        rule = abz.DeviceRule(dev, npt, None, L.WANT_H | L.WANT_EIG | (0 if os.environ.get("FULL_LAYOUT") else L.WANT_H_COMPACT))
         base, nb = rule.values_ptr()
         for _ in range(30): rule.rebuild()
         ctx.sync()
