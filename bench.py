@@ -324,7 +324,9 @@ def rank_main(a):
 
     # ---------------- Phase B: fused sweeps over this rank's omegas (matrix-cached, reference-faithful)
     nB = a.steps * 50
-    for _ in range(max(1, a.warmup)):
+    # warm-up: the scan is f64-VALU bound while Phase A is HBM-write bound, and the GPU's clocks take ~0.1 s of the new
+    # load to settle (the first ~1000 calls after Phase A average 0.157 ms, every later thousand 0.112 ms)
+    for _ in range(max(1, a.warmup) * 400):
         rule.reduce(L.F_DOS, [a.eta], mine)
     barrier()
     t0 = time.perf_counter()
