@@ -1668,7 +1668,7 @@ def test_hermitian_compact_rule_layout_equals_full_layout(abz, n, monkeypatch):
         comp.close()
     # the host mirror asks for the compact layout by itself, and drops such rules when the series stops being Hermitian
     r = dev.rule(8, None, want=L.WANT_H)
-    assert r.want & L.WANT_H_COMPACT
+    assert bool(r.want & L.WANT_H_COMPACT) == (os.environ.get("ABZ_RULE_COMPACT", "1") != "0")
     ref = np.array([orc._ptr_rule_sum(so, 8, None, orc.f_dos(0.3, om))[0] for om in omegas[:3]])
     assert np.abs(r.reduce(L.F_DOS, [0.3], omegas[:3])[:, 0].real - ref).max() <= 1e-11 * np.abs(ref).max()
     extra, _ = rand_series(rng, (3, 5, 3), n, hermitian=False)
