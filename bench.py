@@ -529,6 +529,7 @@ def rank_main(a):
                        "parallelism": f"omega-sharded x{world}, coefficient+rule replicas"},
             "n_ranks_seen": n_ranks_seen, "backend": ("rccl(nccl)" if backend == "nccl" else backend) if distributed else None,
             "rehearsal_ranks_share_one_gpu": bool(rehearsal),
+            "value_reference_layout": ref_layout["value"] if ref_layout else None,  # the same metric with the full 168-B layout of rounds 1-2
             "timed_region_seconds": tA, "ms_per_pass": build_ms,
             "ms_per_step_min_median_max": [float(step_ms.min()), float(np.median(step_ms)), float(step_ms.max())],
             "rule_buffer": {"base_address": hex(base_addr), "bytes": rule_bytes, "base_mod_2MiB": base_addr % (2 << 20),
