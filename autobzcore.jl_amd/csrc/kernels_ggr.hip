@@ -921,6 +921,13 @@ struct GgrArgs {
     double inv_step = 0.0;  // > 0: the energies are equispaced (a linspace sweep): Es[i] = Es[0] + i / inv_step to rounding
 };
 
+// The 3-d formula with everything that does not depend on the energy taken out of the energy loop (ref: src/dos_ggr.jl:90-104,
+// same regions in the same order): per (node, band) the sorted |v|, the four break points w1 <= w2 <= w3 <= w4 and, per
+// region, the coefficients of f(dw) = A + B dw + C dw^2 with the three reciprocals (1/v1, 1/(v1 v2), 1/(v1 v2 v3)) formed
+// ONCE; an energy then costs |E - e|, four compares, the selects and two FMAs instead of the sort, ten products and an
+// IEEE division.  The last region keeps its squared form t^2 / (2 p), t = w4 - dw (no cancellation at the edge of the
+// window).  Plain local variables in the kernel below: as members of a struct they went to scratch (104 B) and the scan
+// took twice as long.
 // Every formula is zero outside |E - e| <= b (|v_1| + ... + |v_d|) (the last branch of each ggr_formula method), a
 // window of ~2 b |v| around the band energy: with 256 energies over the band width a (node, band) pair meets one
 // or two of them.  So a thread finds the first energy of its window in the ASCENDING list (binary search in LDS),
@@ -975,11 +982,41 @@ __global__ __launch_bounds__(256) void ggr_window_kernel(GgrArgs a, double* __re
                     len = right ? len - half - 1 : half;
                 }
             }
-            for (int i = i0; i < a.nE; ++i) {
-                const double En = Esl[i];
-                if (!(En <= hi)) break;
-                const double f = ggr_formula<D>(a.b, En, e[bnd], v[bnd]);
-                if (f != 0.0) __hip_atomic_fetch_add(hist + i, wk * f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if constexpr (D == 3) {
+                if (i0 < a.nE && Esl[i0] <= hi) {  // most windows of a coarse sweep hold no energy at all
+                    const double b = a.b, b2 = b * b;
+                    const double va = fabs(v[bnd][0]), vb = fabs(v[bnd][1]), vc = fabs(v[bnd][2]);
+                    const double v1 = fmax(va, fmax(vb, vc)), v3 = fmin(va, fmin(vb, vc));
+                    const double v2 = (va + vb + vc) - v1 - v3;
+                    const double w1 = b * fabs(v1 - v2 - v3), w2 = b * (v1 - v2 + v3), w3 = b * (v1 + v2 - v3), w4 = b * (v1 + v2 + v3);
+                    const double vn2 = v1 * v1 + v2 * v2 + v3 * v3, v12 = v1 * v2;
+                    const double ip = 1.0 / (v12 * v3), i12 = 1.0 / v12;
+                    const double s2 = v12 + v2 * v3 + v3 * v1;
+                    const bool thin = v1 >= v2 + v3;
+                    const double A1 = thin ? 4.0 * b2 / v1 : b2 * (2.0 * s2 - vn2) * ip, C1 = thin ? 0.0 : -ip;
+                    const double A3 = b2 * ((s2 + 2.0 * v2 * v3) - 0.5 * vn2) * ip, B3 = -b * (-v1 + v2 + v3) * ip, C3 = -0.5 * ip;
+                    const double A4 = 2.0 * b2 * (v1 + v2) * i12, B4 = -2.0 * b * i12, h5 = 0.5 * ip;
+                    for (int i = i0; i < a.nE; ++i) {
+                        const double En = Esl[i];
+                        if (!(En <= hi)) break;
+                        const double dw = fabs(En - e[bnd]);
+                        const bool r1 = dw <= w1, r3 = dw <= w2, r4 = dw <= w3, r5 = dw <= w4;
+                        const double A = r1 ? A1 : (r3 ? A3 : A4);
+                        const double B = r1 ? 0.0 : (r3 ? B3 : B4);
+                        const double C = r1 ? C1 : (r3 ? C3 : 0.0);
+                        const double t = w4 - dw;
+                        const double fp = fma(fma(C, dw, B), dw, A);
+                        const double f = r4 ? fp : (r5 ? t * t * h5 : 0.0);
+                        if (f != 0.0) __hip_atomic_fetch_add(hist + i, wk * f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    }
+                }
+            } else {
+                for (int i = i0; i < a.nE; ++i) {
+                    const double En = Esl[i];
+                    if (!(En <= hi)) break;
+                    const double f = ggr_formula<D>(a.b, En, e[bnd], v[bnd]);
+                    if (f != 0.0) __hip_atomic_fetch_add(hist + i, wk * f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
             }
         }
     }
