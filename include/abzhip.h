@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define ABZ_VERSION 300
+#define ABZ_VERSION 301
 
 /* status codes */
 #define ABZ_OK 0
@@ -195,7 +195,8 @@ int abz_rule_reduce(abz_rule* r, int integrand, const double* params, int nparam
  * straight into the RCCL all_gather / all_reduce (src/interfaces.jl:210-222's fan-in). */
 int abz_rule_reduce_device(abz_rule* r, int integrand, const double* params, int nparams,
                            const double* sweep_dev, int n_sweep, int nsyms, double* out_dev_reim);
-/* Device address and size in bytes of the rule's value block (tiled planar layout):
+/* Device address and size in bytes of the rule's value block (tiled planar layout; with
+ * ABZ_WANT_H_COMPACT the H planes of a tile are the n^2 upper-triangle planes in the order given at that flag):
  * zero-copy views for a device-side harness, and the placement log of bench.py. */
 int abz_rule_values_ptr(const abz_rule* r, void** base, int64_t* nbytes);
 

@@ -26,7 +26,7 @@ def test_header_symbols_exported_and_bound(abz):
     h = _lib.lib()
     for name in declared:
         assert hasattr(h, name)
-    assert h.abz_version() == 300  # round 3: abz_mem_info, fused GGR build (ABZ_K_GGRBUILD), status word in the IAI exchange
+    assert h.abz_version() == 301  # round 3: abz_mem_info, fused GGR build (ABZ_K_GGRBUILD), status word in the IAI exchange; 301: ABZ_WANT_H_COMPACT
 
 
 def test_fails_loudly_without_gpu(abz):
