@@ -1832,7 +1832,41 @@ __global__ __launch_bounds__(256, 2) void eval_sum_grid_kernel(EvalArgs a, SumAr
                         r /= a.npt;
                     }
                 }
-                if constexpr (HERM && (N == 2 || N == 3) && (FID == ABZ_F_DOS || FID == ABZ_F_TRGLOC)) {
+                if constexpr (HERM && N == 3 && FID == ABZ_F_DOS) {
+                    // the arithmetic of dos3_scan_kernel: numerator and denominator of Im p'/p in 13 instructions, one
+                    // reciprocal per pair of swept values, the factor -eta/pi applied once per lane after the loop
+                    CharPolyH cp;
+                    charpoly_init_h3(H[j].re[0][0], H[j].re[1][1], H[j].re[2][2], H[j].re[0][1], H[j].im[0][1], H[j].re[0][2],
+                                     H[j].im[0][2], H[j].re[1][2], H[j].im[1][2], cp);
+                    double num[NW], den[NW];
+#pragma unroll
+                    for (int w = 0; w < NW; ++w) {
+                        num[w] = 0.0;
+                        den[w] = 1.0;
+                        if (w < q.nw) {
+                            const double x = q.sweep[w] - cp.q;
+                            const double up = fma(x, x, -3.0 * eta2);
+                            const double dr = fma(x, up + cp.p1, cp.p0);
+                            const double B0 = fma(3.0, up, cp.p1);
+                            const double B = B0 + 8.0 * eta2;
+                            num[w] = fma(6.0, x * dr, -((B0 + 6.0 * eta2) * B));
+                            den[w] = fma(eta2 * B, B, dr * dr);
+                        }
+                    }
+#pragma unroll
+                    for (int w = 0; w + 1 < NW; w += 2) {
+                        if (w + 1 < q.nw) {
+                            const double r = fast_rcp(den[w] * den[w + 1]);
+                            accr[w][0] = fma(num[w] * den[w + 1], r, accr[w][0]);
+                            accr[w + 1][0] = fma(num[w + 1] * den[w], r, accr[w + 1][0]);
+                        } else if (w < q.nw) {
+                            accr[w][0] = fma(num[w], fast_rcp(den[w]), accr[w][0]);
+                        }
+                    }
+                    if constexpr (NW & 1) {
+                        if (NW - 1 < q.nw) accr[NW - 1][0] = fma(num[NW - 1], fast_rcp(den[NW - 1]), accr[NW - 1][0]);
+                    }
+                } else if constexpr (HERM && (N == 2 || N == 3) && (FID == ABZ_F_DOS || FID == ABZ_F_TRGLOC)) {
                     CharPolyH cp;
                     if constexpr (N == 3)
                         charpoly_init_h3(H[j].re[0][0], H[j].re[1][1], H[j].re[2][2], H[j].re[0][1], H[j].im[0][1], H[j].re[0][2],
@@ -1886,6 +1920,11 @@ __global__ __launch_bounds__(256, 2) void eval_sum_grid_kernel(EvalArgs a, SumAr
         cur ^= 1;
         pass = last_pass ? 0 : pass + 1;
         line = nline;
+    }
+    if constexpr (HERM && N == 3 && FID == ABZ_F_DOS) {  // the common factor of the 3-band DOS terms (see the node loop)
+        const double fac = -q.p[0] * 0.31830988618379067153776752674503;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) accr[w][0] *= fac;
     }
     // block partial sums: wave shuffles, then the 4 waves through LDS (after everyone is done with it)
     __syncthreads();
