@@ -216,7 +216,7 @@ def test_dos3_sweep_kernel_against_oracle_and_generic_scan(abz, monkeypatch):
     c, first = rand_series(rng, (3, 3, 3), 3, hermitian=True)
     s, so = both(abz, c, first)
     cubic = abz.load_bz(abz.CubicSymIBZ(), np.eye(3)).syms
-    for syms, npt in ((None, 13), (cubic, 14)):
+    for syms, npt in ((None, 13), (cubic, 14), (None, 1), (None, 2), (cubic, 3)):  # incl. rules of 1 ... 8 nodes
         rule = s.device().rule(npt, syms, want=3)
         for eta in (0.2, 1e-3):
             for nw in (1, 15, 16, 17, 33, 300):
