@@ -9,6 +9,8 @@
 //   7: 16 x [s_nop 1 + 4 x v_fmac_f64_dpp] in the Gauss-Jordan column pattern (two accumulators per block, dependent)
 //   8: 64 x v_fmac_f64 (VOP2, no DPP)
 //   9: 64 x v_fma_f64 + 32 x v_mov_b64_dpp row_newbcast:3    (the round-2 pivot pattern: 2 moves per 4 FMAs)
+//  10: 64 x v_rcp_f64 (independent)                          (the reciprocal of the DOS scan kernels)
+//  11: 64 x v_fma_f64 + 8 x v_rcp_f64                         (the scan kernels' ratio before the reciprocals were paired)
 // Reports shader clocks per body per wave for 1, 2 and 4 waves per SIMD.
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -23,6 +25,7 @@ typedef double d4 __attribute__((ext_vector_type(4)));
 #define FMAC2(i) asm volatile("v_fmac_f64_e32 %0, %1, %2" : "+v"(acc[i]) : "v"(a), "v"(b))
 #define COLB(i) asm volatile("s_nop 1\n\tv_fmac_f64_dpp %0, %0, %2 row_newbcast:3 row_mask:0xf bank_mask:0xf\n\tv_fmac_f64_dpp %0, %1, -%3 row_newbcast:3 row_mask:0xf bank_mask:0xf\n\tv_fmac_f64_dpp %1, %1, %2 row_newbcast:3 row_mask:0xf bank_mask:0xf\n\tv_fmac_f64_dpp %1, %0, %3 row_newbcast:3 row_mask:0xf bank_mask:0xf" : "+v"(acc[(2 * (i)) % 16]), "+v"(acc[(2 * (i) + 1) % 16]) : "v"(a), "v"(b))
 #define MOV64D(i) asm volatile("v_mov_b64_dpp %0, %1 row_newbcast:3 row_mask:0xf bank_mask:0xf" : "=v"(u[i]) : "v"(acc[i]))
+#define RCP(i) asm volatile("v_rcp_f64 %0, %1" : "=v"(u[i]) : "v"(acc[i]))
 #define R16(M) M(0); M(1); M(2); M(3); M(4); M(5); M(6); M(7); M(8); M(9); M(10); M(11); M(12); M(13); M(14); M(15)
 
 template <int MODE, int NT>
@@ -50,6 +53,8 @@ __global__ __launch_bounds__(NT) void k(double* out, int iters) {
         if (MODE == 7) { R16(COLB); }
         if (MODE == 8) { R16(FMAC2); R16(FMAC2); R16(FMAC2); R16(FMAC2); }
         if (MODE == 9) { R16(MOV64D); R16(FMA); R16(FMA); R16(MOV64D); R16(FMA); R16(FMA); }
+        if (MODE == 10) { R16(RCP); R16(RCP); R16(RCP); R16(RCP); }
+        if (MODE == 11) { R16(FMA); RCP(0); RCP(1); R16(FMA); RCP(2); RCP(3); R16(FMA); RCP(4); RCP(5); R16(FMA); RCP(6); RCP(7); }
         if (MODE == 5) { R16(FMA); R16(DPPQ); R16(FMA); R16(DPPQ); R16(FMA); R16(DPPQ); R16(FMA); R16(DPPQ); }
     }
     double r = 0;
@@ -96,7 +101,9 @@ int main() {
     run<6, NT>("64 v_fmac_f64_dpp row_newbcast", W, ghz);                             \
     run<7, NT>("16 x (s_nop 1 + 4 dependent v_fmac_f64_dpp)", W, ghz);                \
     run<8, NT>("64 v_fmac_f64 (VOP2)", W, ghz);                                       \
-    run<9, NT>("64 v_fma_f64 + 32 v_mov_b64_dpp row_newbcast", W, ghz);
+    run<9, NT>("64 v_fma_f64 + 32 v_mov_b64_dpp row_newbcast", W, ghz);               \
+    run<10, NT>("64 v_rcp_f64", W, ghz);                                              \
+    run<11, NT>("64 v_fma_f64 + 8 v_rcp_f64", W, ghz);
     ALL(256, 1)
     ALL(256, 2)
     ALL(256, 4)
