@@ -215,10 +215,12 @@ struct AdaptParent {
     double Ir = 0.0, Ii = 0.0, E = 0.0;
 };
 
+// `lane`: 0 or 1, the caller's position in its pair; `lane1`: the wave lane that plays lane 1 (the half-wave kernel of
+// n <= 4 runs two integrals per wave: pairs (0, 1) and (32, 33)).
 template <int MS>
 __device__ inline bool adapt_step_pair(AdaptStateT<1>& st, AdaptParent& par, int lane, double* seg_a, double* seg_b, double* seg_E,
                                        gkc* seg_I, const gkc* vals, int* heap, double* heapE, double* ctl, long long maxevals,
-                                       const InnerOut& out) {
+                                       const InnerOut& out, int lane1 = 1) {
     const int np = (int)ctl[0];
     const double a1 = ctl[1], b1 = ctl[2], a2 = ctl[3], b2 = ctl[4];
     const int pl = lane < np ? lane : 0;  // the panel of this lane
@@ -227,7 +229,7 @@ __device__ inline bool adapt_step_pair(AdaptStateT<1>& st, AdaptParent& par, int
     for (int i = 0; i < 15; ++i) rv[i] = vals[15 * pl + i];
     gkc Il;
     const double El = gk15_rule(rv, 1, pl ? a2 : a1, pl ? b2 : b1, &Il);
-    const double I2r = __shfl(Il.re, 1, 64), I2i = __shfl(Il.im, 1, 64), E2 = __shfl(El, 1, 64);
+    const double I2r = __shfl(Il.re, lane1, 64), I2i = __shfl(Il.im, lane1, 64), E2 = __shfl(El, lane1, 64);
     if (lane != 0) return false;
     int newseg[2] = {-1, -1};
     for (int pnl = 0; pnl < np; ++pnl) {

@@ -2404,7 +2404,8 @@ __device__ __forceinline__ void series_lane_lds(const double2* c1, int M, double
 }
 
 // LDS doubles of one integral of inner_adaptive_kernel: the adaptive state + its coefficient set
-__host__ __device__ inline int inner_group_stride(int ncomp, int mnn) { return inner_group_doubles(ncomp) + 2 * mnn; }
+// (+ ABZ_INNER_MAXSEG doubles: adapt_step_pair's mirror of the heap's error estimates)
+__host__ __device__ inline int inner_group_stride(int ncomp, int mnn) { return inner_group_doubles(ncomp) + ABZ_INNER_MAXSEG + 2 * mnn; }
 
 struct InnerArgs {
     const double2* src;
@@ -2416,6 +2417,9 @@ struct InnerArgs {
     const double* sweep_arr;
     int64_t nint, maxevals;
     int M, first, d, ncomp, has_rtol;
+    int pair;  // scalar integrands: the two-lane adaptive step (inner_adapt.h)
+    int poly;  // sincospi_poly (device_math.h) for the node phases instead of the library routine
+    double sc[16];
     double inv_period, sweep, rtol_user;
     double p[4];
     double2* I_out;
@@ -2433,7 +2437,7 @@ __global__ __launch_bounds__(256) void inner_adaptive_kernel(InnerArgs a) {
     const int nc = a.ncomp;
     const int MNN = a.M * N * N;
     double* g = lds_in + (size_t)group * inner_group_stride(nc, MNN);
-    double2* const cl = reinterpret_cast<double2*>(g + inner_group_doubles(nc));  // this integral's coefficients
+    double2* const cl = reinterpret_cast<double2*>(g + inner_group_doubles(nc) + MS);  // this integral's coefficients
     double* seg_a = g;
     double* seg_b = seg_a + MS;
     double* seg_E = seg_b + MS;
@@ -2441,12 +2445,17 @@ __global__ __launch_bounds__(256) void inner_adaptive_kernel(InnerArgs a) {
     gkc* vals = seg_I + (size_t)MS * nc;
     int* heap = reinterpret_cast<int*>(vals + (size_t)30 * nc);
     double* ctl = reinterpret_cast<double*>(heap + MS);
+    double* heapE = ctl + 8;  // adapt_step_pair's mirror of seg_E[heap[.]]
+    // scalar integrands: lanes 0 and 1 of the half-wave share the serial step (two GK rules side by side, one LDS round
+    // trip per heap level); a.pair = 0 (ABZ_INNER_PAIR=0): the one-lane step, same numbers
+    const bool pair = NC == 1 && a.pair;
     const int64_t gstride = (int64_t)gridDim.x * 8;
     for (int64_t q0 = (int64_t)blockIdx.x * 8; q0 < a.nint; q0 += gstride) {
         const int64_t q = q0 + group;
         const bool live = q < a.nint;  // the whole group shares it; both groups of a wave loop together
         // ---- lane 0 state
         AdaptStateT<NC> st;
+        [[maybe_unused]] AdaptParent par;
         bool done = !live;
         double tailv[ABZ_MAX_DIM] = {0.0, 0.0, 0.0};
         double swq = a.sweep;
@@ -2476,8 +2485,13 @@ __global__ __launch_bounds__(256) void inner_adaptive_kernel(InnerArgs a) {
                     const double x = gk15_node(pa, pb, i);
                     const double xx = x * a.inv_period;
                     double zr, zi, wr, wi;
-                    sincospi(2.0 * xx, &zi, &zr);
-                    sincospi(2.0 * ((double)a.first * xx), &wi, &wr);
+                    if (a.poly) {
+                        sincospi_poly(a.sc, 2.0 * xx, zi, zr);
+                        sincospi_poly(a.sc, 2.0 * ((double)a.first * xx), wi, wr);
+                    } else {
+                        sincospi(2.0 * xx, &zi, &zr);
+                        sincospi(2.0 * ((double)a.first * xx), &wi, &wr);
+                    }
                     CMat<N> H;
                     series_lane_lds<N, HERM>(cl, a.M, zr, zi, wr, wi, H);
                     double e[N];
@@ -2513,13 +2527,23 @@ __global__ __launch_bounds__(256) void inner_adaptive_kernel(InnerArgs a) {
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            if (!grp_done && l == 0) {
+            if (!grp_done && l < (pair ? 2 : 1)) {
                 InnerOut out;
                 out.I = a.I_out + q * nc;
                 out.E = a.E_out + q;
                 out.nev = a.nev_out + q;
                 out.status = a.status_out + q;
-                done = adapt_step<true, NC>(st, nc, seg_a, seg_b, seg_E, seg_I, vals, heap, ctl, a.maxevals, out);
+                if constexpr (NC == 1) {
+                    if (pair) {
+                        const bool d2 = adapt_step_pair<MS>(st, par, l, seg_a, seg_b, seg_E, seg_I, vals, heap, heapE, ctl, a.maxevals, out,
+                                                            (int)(threadIdx.x & 32u) + 1);
+                        if (l == 0) done = d2;
+                    } else {
+                        done = adapt_step<true, NC>(st, nc, seg_a, seg_b, seg_E, seg_I, vals, heap, ctl, a.maxevals, out);
+                    }
+                } else {
+                    done = adapt_step<true, NC>(st, nc, seg_a, seg_b, seg_E, seg_I, vals, heap, ctl, a.maxevals, out);
+                }
             }
         }
     }
@@ -2558,6 +2582,11 @@ int launch_inner_adaptive(abz_ctx* ctx, const InnerSpec& is) {
     a.d = is.d;
     a.ncomp = ncomp;
     a.has_rtol = is.has_rtol ? 1 : 0;
+    a.pair = [] { const char* e = getenv("ABZ_INNER_PAIR"); return !(e && e[0] == '0'); }() ? 1 : 0;  // per call: tests compare both
+    // polynomial sincospi: measured 31.3 against 32.0 ms on the SVO full-BZ solve (the phases are not what bounds a round),
+    // so the library routine stays the default; ABZ_INNER_SINCOS=1 switches (recorded experiment)
+    a.poly = [] { const char* e = getenv("ABZ_INNER_SINCOS"); return e && e[0] == '1'; }() ? 1 : 0;  // per call
+    for (int i = 0; i < 16; ++i) a.sc[i] = kSinCosPiCoef[i];
     a.inv_period = 1.0 / is.period;
     a.sweep = is.sweep;
     a.rtol_user = is.rtol_user;

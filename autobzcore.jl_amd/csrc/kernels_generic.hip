@@ -15,6 +15,7 @@
 
 #include "abz_internal.h"
 #include "inner_adapt.h"
+#include "device_math.h"
 
 namespace abz {
 
@@ -571,27 +572,6 @@ __device__ __forceinline__ void panel_invert_rows(int n, int r, double (&ar)[NP]
     panel_pivots<NP, !PAD>(n, r, ar, ai, std::make_integer_sequence<int, NP>());
 }
 
-// sin(pi t), cos(pi t) for finite |t| < 2^30: t = k/2 + r, |r| <= 1/4, Taylor polynomials in r (|pi r| <= 0.785:
-// 8 + 8 terms, 1 ulp), quadrant by k.  The library routine costs twice the instructions and keeps its coefficients in
-// VGPRs that this kernel has to spill; here they are kernel arguments (scalar operands of the FMAs).
-__device__ __forceinline__ void sincospi_poly(const double (&sc)[16], double t, double& s, double& c) {
-    const double k = rint(t + t);
-    const double r = fma(-0.5, k, t);
-    const int q = (int)k;
-    const double r2 = r * r;
-    double p = sc[7];
-#pragma unroll
-    for (int i = 6; i >= 1; --i) p = fma(p, r2, sc[i]);
-    const double sn = fma(r * r2, p, r * sc[0]);
-    double u = sc[15];
-#pragma unroll
-    for (int i = 14; i >= 8; --i) u = fma(u, r2, sc[i]);
-    const double cs = fma(r2, u, 1.0);
-    const bool odd = q & 1;
-    const double ss = odd ? cs : sn, cc = odd ? sn : cs;
-    s = __hiloint2double(__double2hiint(ss) ^ ((q & 2) << 30), __double2loint(ss));
-    c = __hiloint2double(__double2hiint(cc) ^ (((q + 1) & 2) << 30), __double2loint(cc));
-}
 
 // ---- Gauss-Jordan with the pivot-row broadcast folded INTO the FMAs (16 lanes per node, trace of the inverse only) ----
 // `v_fmac_f64_dpp dst, src0, src1 row_newbcast:C` computes dst += src0[lane C of the row] * src1: no separate broadcast
@@ -2805,8 +2785,6 @@ struct GenInnerArgs {
     double sc[16];  // sincospi_poly's coefficients (kernel arguments stay in scalar registers / the scalar cache)
 };
 
-// Taylor coefficients of sin(pi r) / r^(2k+1), k = 0..7, and of cos(pi r) / r^(2k), k = 1..8
-static const double kSinCosPiCoef[16] = {3.141592653589793, -5.16771278004997, 2.5501640398773455, -0.5992645293207921, 0.08214588661112823, -0.0073704309457143504, 0.00046630280576761255, -2.1915353447830217e-05, -4.934802200544679, 4.0587121264167685, -1.3352627688545895, 0.2353306303588932, -0.02580689139001406, 0.0019295743094039231, -0.0001046381049248457, 4.303069587032947e-06};
 
 __host__ __device__ inline size_t gen_inner_wave_doubles(int n, int M, int ncomp) {
     // H, W, X (complex n*n each), ph (complex M), ev (n) rounded to even, then the adapt group

@@ -1052,14 +1052,15 @@ def test_iai_speculative_requests_change_nothing(abz, monkeypatch, n, dims, eta,
     bz = abz.load_bz(abz.FBZ(), np.eye(d))
     f = abz.FourierIntegrand(abz.DOSIntegrand(), s, eta)
     runs = {}
-    for tag, env in (("spec", {}), ("serial", {"ABZ_IAI_SPECULATE": "0"}), ("chunks", {"ABZ_IAI_POOL_MB": "1"})):
-        for k in ("ABZ_IAI_SPECULATE", "ABZ_IAI_POOL_MB"):
+    for tag, env in (("spec", {}), ("serial", {"ABZ_IAI_SPECULATE": "0"}), ("chunks", {"ABZ_IAI_POOL_MB": "1"}),
+                     ("onelane", {"ABZ_INNER_PAIR": "0"})):  # n <= 4: the one-lane adaptive step of the innermost kernel
+        for k in ("ABZ_IAI_SPECULATE", "ABZ_IAI_POOL_MB", "ABZ_INNER_PAIR"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
         sol = abz.do_solve(f, bz, abz.MixedParameters(0.1), abz.EvalCounter(abz.IAI()), abstol=abstol, reltol=0.0, _panels=True)
         runs[tag] = (sol.u, sol.resid, sol.numevals, sol.extra["panels"])
-    for tag in ("serial", "chunks"):
+    for tag in ("serial", "chunks", "onelane"):
         assert runs[tag][0] == runs["spec"][0] and runs[tag][1] == runs["spec"][1] and runs[tag][2] == runs["spec"][2]
         assert np.array_equal(runs[tag][3], runs["spec"][3])
     assert runs["spec"][2] > 15**d and len(runs["spec"][3]) >= 2
