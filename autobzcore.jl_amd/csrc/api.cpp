@@ -869,6 +869,9 @@ static int rule_fill(abz_rule* r) {
     };
     // full grids of d >= 2 variables: the last contraction (variable 2) runs inside the grid kernel
     const bool fuse = r->full && d >= 2 && eval_can_fuse(n, s->dims[0], s->dims[1], r->npt);
+    // ... on packed Hermitian level-2 sets when the plain values / eigenvalues are all that is built
+    const bool packed_fused = r->full && d >= 2 && s->hermitian && !(r->want & ABZ_WANT_VEL) &&
+                              eval_packed_supported(n, s->dims[0], r->npt) && eval_can_fuse(n, s->dims[0], s->dims[1], r->npt);
     auto run_fused = [&](const double2* level2, bool deriv1, bool deriv2, PlaneView Hout, PlaneView Eout, PlaneView Uout) -> int {
         EvalSpec es;
         es.n = n;
@@ -889,6 +892,7 @@ static int rule_fill(abz_rule* r) {
         es.H = Hout;
         es.E = Eout;
         es.U = Uout;
+        es.packed = packed_fused && !deriv1 && !deriv2 && !Uout.base;
         es.src2 = level2;
         es.M2 = s->dims[1];
         es.first2 = s->first[1];
@@ -900,7 +904,7 @@ static int rule_fill(abz_rule* r) {
     const double2* level1 = nullptr;
     int rc;
     if (fuse) {
-        if ((rc = build_chain(s, plan, rp->pd, tab, 0, &level1, 2))) return rc;
+        if ((rc = build_chain(s, plan, rp->pd, tab, 0, &level1, 2, nullptr, packed_fused))) return rc;
         if ((rc = run_fused(level1, false, false, r->H, r->E, Uv))) return rc;
     } else {
         if ((rc = build_chain(s, plan, rp->pd, tab, 0, &level1, 1, nullptr, packed_chain))) return rc;

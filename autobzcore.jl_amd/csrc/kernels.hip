@@ -800,11 +800,12 @@ __global__ __launch_bounds__(256, OCC) void eval_grid_kernel(EvalArgs a) {
 // read from HBM but computed by the wave from its block's level-2 set c2 (M2 M n^2 complex, staged in LDS
 // once per block), so the work loop holds no global load at all.  A block owns a segment of the i2 range
 // of one parent (level-2 item); wave w takes every 4th line of it.
-template <int N, int KPL, bool HERM, bool VEC, int OCC>
+template <int N, int KPL, bool HERM, bool VEC, int OCC, bool PK = false>
 __global__ __launch_bounds__(256, OCC) void eval_grid_fused_kernel(EvalArgs a) {
     extern __shared__ double2 lds_f[];  // [M2][MNN] level-2 set | [npt] phase table | [4 waves][2][MNN]
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-    const int MNN = a.M * N * N;
+    // PK: the level-2 sets are packed Hermitian rows (packed_herm.h; packing commutes with the contraction)
+    const int MNN = PK ? Pk<N>::size((a.M - 1) / 2) : a.M * N * N;
     double2* const c2s = lds_f;
     double2* const tab_l = c2s + (size_t)a.M2 * MNN;
     double2* const mybuf = tab_l + a.npt + (size_t)wave * 2 * MNN;
@@ -858,9 +859,11 @@ __global__ __launch_bounds__(256, OCC) void eval_grid_fused_kernel(EvalArgs a) {
             const int idx = lane + 64 * t;
             if (idx < MNN) {
                 double2 v = make_double2(accr[t], acci[t]);
-                if (a.deriv) {
-                    const double f = 6.283185307179586476925286766559 * (double)(a.first + idx / (N * N));
-                    v = make_double2(-f * v.y, f * v.x);
+                if constexpr (!PK) {
+                    if (a.deriv) {
+                        const double f = 6.283185307179586476925286766559 * (double)(a.first + idx / (N * N));
+                        v = make_double2(-f * v.y, f * v.x);
+                    }
                 }
                 dst[idx] = v;
             }
@@ -882,8 +885,9 @@ __global__ __launch_bounds__(256, OCC) void eval_grid_fused_kernel(EvalArgs a) {
         const int ni2 = last_pass ? i2 + 4 : i2;
         const int64_t line = parent * a.gcnt + (i2 - a.gbeg);
         wave_lds_sync();
-        eval_unit<N, KPL, HERM, VEC>(a, mybuf + (size_t)cur * MNN, tab_l, fm, iz0, iw0, npass, pass * (64 * KPL), lane, line,
-                                     [] {});
+        auto nothing = [] {};
+        eval_unit<N, KPL, HERM, VEC, decltype(nothing)&, PK>(a, mybuf + (size_t)cur * MNN, tab_l, fm, iz0, iw0, npass, pass * (64 * KPL), lane,
+                                                             line, nothing);
         // after the stores are issued: the next line's contraction overlaps their drain
         if (last_pass && ni2 < hi) contract_line(ni2, mybuf + (size_t)(cur ^ 1) * MNN);
         if (last_pass) cur ^= 1;
@@ -1045,7 +1049,7 @@ int launch_eval(abz_ctx* ctx, const EvalSpec& es) {
         static const int padw = [] { const char* e = getenv("ABZ_PAD_WRITE"); return e ? atoi(e) : 1; }();
         a.padw = padw;
     }
-    a.pk = (es.packed && a.herm && !es.U.base && es.grid && !es.src2) ? 1 : 0;
+    a.pk = (es.packed && a.herm && !es.U.base && es.grid && !(es.src2 && es.deriv2)) ? 1 : 0;
     a.src2 = es.src2;
     a.M2 = es.M2;
     a.first2 = es.first2;
@@ -1090,7 +1094,9 @@ int launch_eval(abz_ctx* ctx, const EvalSpec& es) {
             a.nseg = (int)nseg;
             blocks = nparents * nseg;
 #define LKF(NN, KK, OO)                                                                                                          \
-    if (a.U.base)                                                                                                                \
+    if (a.pk)                                                                                                                    \
+        hipLaunchKernelGGL((eval_grid_fused_kernel<NN, KK, true, false, OO, true>), dim3((unsigned)blocks), dim3(256), lds, ctx->stream, a); \
+    else if (a.U.base)                                                                                                           \
         hipLaunchKernelGGL((eval_grid_fused_kernel<NN, KK, false, true, 2>), dim3((unsigned)blocks), dim3(256), lds, ctx->stream, a);  \
     else if (a.herm)                                                                                                             \
         hipLaunchKernelGGL((eval_grid_fused_kernel<NN, KK, true, false, OO>), dim3((unsigned)blocks), dim3(256), lds, ctx->stream, a); \
