@@ -54,6 +54,18 @@ for d, n, npt in cases:
         # the rule value then amplifies the 1e-16 differences of H by |G|^2 |H| / |mean tr G|
         amp = (np.abs(zi).max() ** 2) * max(np.abs(ref).max(), 1.0) / max(np.abs(tr).max(), 1e-300)
         errR = errR / max(1.0, amp)
+        if herm and npt <= 300:
+            # the Hermitian-compact layout (upper-triangle planes) and the DOS scans on it (n = 3: the sweep kernel)
+            comp = abz.DeviceRule(s.device(), npt, None, want | L.WANT_H_COMPACT)
+            exc = comp.export(x=False, w=False, H=True)
+            errH = max(errH, np.abs(exc["H"].reshape(-1, n, n) - ref).max() / scale)
+            om3 = np.linspace(-0.8, 0.9, 19)
+            z3 = (om3 + 1j * eta)[:, None, None, None] * np.eye(n) - ref[None]
+            dos = -np.trace(np.linalg.inv(z3), axis1=-2, axis2=-1).imag.mean(axis=1) / np.pi
+            for fid in (L.F_DOS, L.F_DOS_EIG):
+                gd = comp.reduce(fid, [eta], om3)[:, 0].real
+                errR = max(errR, np.abs(gd - dos).max() / max(np.abs(dos).max(), 1e-300) / (1.0 if fid == L.F_DOS else 10.0))
+            comp.close()
         rule.close()
         worst = max(worst, errH, errE, errR)
         flag = "" if max(errH, errR) < 1e-11 and errE < 1e-11 else "   <-- CHECK"
