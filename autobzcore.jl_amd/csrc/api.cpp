@@ -489,6 +489,8 @@ static void ctx_release(abz_ctx* ctx) {
         delete c;
     }
     ctx->sym_cache.clear();
+    for (auto& e : ctx->phase_cache) e.second.release();
+    ctx->phase_cache.clear();
     for (auto& sl : ctx->prof_slots)
         for (auto& pr : sl.pending) {
             (void)hipEventDestroy(pr.first);
