@@ -253,6 +253,7 @@ bool eval_packed_supported(int n, int M, int npt);
 // rows [nrows][M n n] of full coefficients (innermost variable fastest) -> packed rows [nrows][P] (packed_herm.h)
 int launch_pack_rows(abz_ctx* ctx, int n, int M, const double2* src, int64_t nrows, double2* out);
 size_t packed_row_elems(int n, int M);
+int series_ensure_packed(abz_series* s);  // api.cpp: the packed copy of the coefficients (coef_pk) is current
 
 int launch_eig_planes(abz_ctx* ctx, int n, PlaneView H, PlaneView E, PlaneView U, int64_t nk);
 // V[b](k) = Re sum_{a,c} conj(U[a,b]) dH[a,c] U[c,b]   (Vj: view of the n planes of one direction)
@@ -327,6 +328,7 @@ struct NodeEvalSpec {
     double sweep;
     const double* sweep_arr = nullptr;  // device [nnodes]: per-node sweep value (overrides `sweep`)
     bool panels15 = false;  // every aligned run of 15 nodes is one GK(7,15) panel (same parent)
+    bool packed = false;  // `src` holds PACKED Hermitian level-1 sets (packed_herm.h), n <= 4
 };
 int launch_node_integrand(abz_ctx* ctx, const NodeEvalSpec& ns, double2* values_dev);
 
@@ -348,6 +350,7 @@ struct InnerSpec {
     double sweep;
     const double* sweep_arr = nullptr;  // device [nint]: per-integral sweep value (overrides `sweep`)
     bool herm = false;  // the series is Hermitian: upper-triangle series, real characteristic polynomial
+    bool packed = false;  // `src` holds PACKED Hermitian level-1 sets (packed_herm.h), n <= 4
     bool has_rtol;
     double rtol_user;
     int64_t maxevals;

@@ -390,6 +390,19 @@ static int plan_upload(abz_ctx* ctx, const Plan& p, PlanDev& pd) {
 // derivative factor to that variable's phases.  Returns pointer to level-1 sets (or coef if d == 1).
 // packed: the chain runs on the coefficients with the innermost variable packed (Hermitian series, packed_herm.h): rows of
 // P = n (n + 1) / 2 + F n^2 numbers instead of M n^2 -- packing is linear and commutes with every contraction.
+// the series' coefficients with the innermost variable packed (packed_herm.h), rebuilt after an update
+int series_ensure_packed(abz_series* s) {
+    if (s->coef_pk_valid) return ABZ_OK;
+    const int64_t row_full = (int64_t)s->dims[0] * s->n * s->n;
+    const int64_t row_len = (int64_t)packed_row_elems(s->n, s->dims[0]);
+    const int64_t nrows = s->elems(s->d) / row_full;
+    int rc = s->coef_pk.reserve(sizeof(double2) * (size_t)(nrows * row_len));
+    if (rc) return rc;
+    if ((rc = launch_pack_rows(s->ctx, s->n, s->dims[0], s->coef, nrows, s->coef_pk.as<double2>()))) return rc;
+    s->coef_pk_valid = true;
+    return ABZ_OK;
+}
+
 static int build_chain(abz_series* s, const Plan& p, const PlanDev& pd, const double2* tab, int deriv_dim,
                        const double2** level1, int last_level = 1, DevBuf* last_out = nullptr, bool packed = false) {
     abz_ctx* ctx = s->ctx;
@@ -397,12 +410,9 @@ static int build_chain(abz_series* s, const Plan& p, const PlanDev& pd, const do
     const int64_t row_full = (int64_t)s->dims[0] * s->n * s->n;
     const int64_t row_len = packed ? (int64_t)packed_row_elems(s->n, s->dims[0]) : row_full;
     auto elems_of = [&](int level) { return s->elems(level) / row_full * row_len; };  // numbers per level-`level` set
-    if (packed && !s->coef_pk_valid) {
-        const int64_t nrows = s->elems(d) / row_full;
-        int rc = s->coef_pk.reserve(sizeof(double2) * (size_t)(nrows * row_len));
+    if (packed) {
+        int rc = series_ensure_packed(s);
         if (rc) return rc;
-        if ((rc = launch_pack_rows(ctx, s->n, s->dims[0], s->coef, nrows, s->coef_pk.as<double2>()))) return rc;
-        s->coef_pk_valid = true;
     }
     const double2* src = packed ? s->coef_pk.as<double2>() : s->coef;
     int64_t src_elems = elems_of(d);

@@ -370,6 +370,15 @@ struct IaiDriver {
 
     bool device_inner = false;  // innermost adaptive loops on the GPU (scalar refinement, n <= 4)
 
+    // Hermitian series of n <= 4 bands: the whole chain runs on PACKED coefficient rows (packed_herm.h; packing commutes with
+    // the contraction of the outer variables): half the contraction work and level-1 sets of 51 instead of 99 numbers (SVO),
+    // and the innermost kernels evaluate the folded series (half the terms, no seed phase)
+    bool pk = false;
+    int64_t set_elems(int level) const {  // numbers per level-`level` coefficient set in this solve's layout
+        const int64_t row_full = (int64_t)s->dims[0] * s->n * s->n;
+        return pk ? s->elems(level) / row_full * (int64_t)packed_row_elems(s->n, s->dims[0]) : s->elems(level);
+    }
+    const double2* top_coef() const { return pk ? s->coef_pk.as<double2>() : s->coef; }
     int contract_nodes(int L, int64_t nn, int64_t base_slot, int64_t off = 0, const int64_t* par = nullptr, const double* x = nullptr);
     int eval_nodes(int64_t nn);
     int solve_level(int L, std::vector<Quad1D>& quads);
@@ -449,7 +458,7 @@ int IaiDriver::flat_layout(int64_t cn, bool need_tail, int buf) {
 // upload h_parents/h_x, contract level-L sets into level-(L-1) pool slots base_slot..base_slot+nn-1
 int IaiDriver::contract_nodes(int L, int64_t nn, int64_t base_slot, int64_t off, const int64_t* par, const double* x) {
     const int M = s->dims[L - 1];
-    const int64_t Lrow = s->elems(L - 1);
+    const int64_t Lrow = set_elems(L - 1);
     int rc;
     if ((rc = s->iai_io[0].reserve(sizeof(int64_t) * (size_t)nn))) return rc;
     if ((rc = s->iai_io[1].reserve(sizeof(double) * (size_t)nn))) return rc;
@@ -469,9 +478,9 @@ int IaiDriver::contract_nodes(int L, int64_t nn, int64_t base_slot, int64_t off,
     ps.period = s->period[L - 1];
     ps.deriv = false;
     if ((rc = launch_phases(ctx, ps, s->iai_io[4].as<double2>()))) return rc;
-    const double2* src = (L == d) ? s->coef : s->iai_pool[L].as<double2>();
+    const double2* src = (L == d) ? top_coef() : s->iai_pool[L].as<double2>();
     double2* out = s->iai_pool[L - 1].as<double2>() + base_slot * Lrow;
-    return launch_contract(ctx, src, s->elems(L), s->iai_io[0].as<int64_t>(), 1, s->iai_io[4].as<double2>(), out, nn,
+    return launch_contract(ctx, src, set_elems(L), s->iai_io[0].as<int64_t>(), 1, s->iai_io[4].as<double2>(), out, nn,
                            Lrow, M);
 }
 
@@ -500,7 +509,8 @@ int IaiDriver::eval_nodes(int64_t nn) {
     ns.M = s->dims[0];
     ns.first = s->first[0];
     ns.period = s->period[0];
-    ns.src = (d == 1) ? s->coef : s->iai_pool[1].as<double2>();
+    ns.src = (d == 1) ? top_coef() : s->iai_pool[1].as<double2>();
+    ns.packed = pk;
     ns.parents = s->iai_io[0].as<int64_t>();
     ns.x = s->iai_io[1].as<double>();
     ns.tail = need_tail ? s->iai_io[2].as<double>() : nullptr;
@@ -552,7 +562,8 @@ int IaiDriver::flat_enqueue(int64_t nq, int buf) {
     is.M = s->dims[0];
     is.first = s->first[0];
     is.period = s->period[0];
-    is.src = (d == 1) ? s->coef : s->iai_pool[1].as<double2>();
+    is.src = (d == 1) ? top_coef() : s->iai_pool[1].as<double2>();
+    is.packed = pk;
     is.nint = nq;
     is.slot = d_slot;
     is.lo = d_lo;
@@ -696,7 +707,7 @@ int IaiDriver::solve_level(int L, std::vector<Quad1D>& quads) {
             std::fill(nev.begin(), nev.end(), (int64_t)1);
         } else {
             // chunks: the level-(L-1) sets of a chunk are contracted, integrated over and then overwritten
-            const int64_t set_bytes = (int64_t)sizeof(double2) * s->elems(L - 1);
+            const int64_t set_bytes = (int64_t)sizeof(double2) * set_elems(L - 1);
             // (and of at most ~2.6e5 nodes: the per-chunk host arrays stay in cache, a launch still fills the chip)
             int64_t chunk = std::max<int64_t>(15, std::min<int64_t>(pool_cap_bytes / std::max<int64_t>(set_bytes, 1), 262140) / 15 * 15);
             const bool flat = (L - 1 == 1) && device_inner;
@@ -1220,6 +1231,14 @@ int abz_iai_solve_many(abz_series* s, int lims_kind, const double* lim_a, const 
                                     (gen_inner_supported(s->n, s->dims[0], integrand) && e && e[0] == '2'))
                                  : inner_adaptive_supported(s->n, s->dims[0], integrand);
         drv.device_inner = max_batch <= 0 && s->d >= 2 && ok && !(e && e[0] == '0');
+    }
+    {
+        const char* e = getenv("ABZ_IAI_PACKED");  // 0: the full coefficient rows (per call: tests compare both)
+        drv.pk = !(e && e[0] == '0') && s->n <= 4 && s->hermitian && (s->dims[0] & 1) && s->first[0] == -(s->dims[0] - 1) / 2;
+        if (drv.pk) {
+            int rcp = series_ensure_packed(s);
+            if (rcp) return rcp;
+        }
     }
     // one top-level integral per sweep value; they advance in lock-step like any other siblings
     std::vector<Quad1D> top((size_t)n_sweep);

@@ -2251,6 +2251,57 @@ int export_planes(abz_ctx* ctx, PlaneView v, int ncomp, int64_t nk, double* host
 // ------------------------------------------------------------------------------------------
 // IAI innermost nodes: series + integrand, one lane per node
 // ------------------------------------------------------------------------------------------
+// H(k) of a Hermitian series at ONE point from a PACKED coefficient set (packed_herm.h; LDS or constant-address-space
+// pointer): z = e^{2 pi i x}, p = z^f by recurrence, one FMA group for +f and -f, the lower triangle mirrored.  The
+// arithmetic of eval_unit_core's packed branch for a single node: the IAI kernels' series (half the terms of the
+// 2 F + 1 loop, and no seed phase z^first).
+template <int N, class PTR>
+__device__ __forceinline__ void series_point_pk(PTR c1, int F, double zr, double zi, CMat<N>& H) {
+#pragma unroll
+    for (int bb = 0; bb < N; ++bb) {
+#pragma unroll
+        for (int aa = 0; aa <= bb; ++aa) {
+            const double cx = c1[Pk<N>::tri(aa, bb)].x, cy = c1[Pk<N>::tri(aa, bb)].y;
+            H.re[aa][bb] = cx;
+            H.im[aa][bb] = (aa == bb) ? 0.0 : cy;
+        }
+    }
+    double pr = 1.0, pi = 0.0;
+    for (int f = 1; f <= F; ++f) {
+        const double nr = pr * zr - pi * zi;
+        const double ni = pr * zi + pi * zr;
+        pr = nr;
+        pi = ni;
+        const int o = Pk<N>::blk(1) + (f - 1) * (N * N);
+#pragma unroll
+        for (int aa = 0; aa < N; ++aa) {
+            const double dx = c1[o + aa].x, dy = c1[o + aa].y;
+            H.re[aa][aa] = fma(dx, pr, H.re[aa][aa]);
+            H.re[aa][aa] = fma(-dy, pi, H.re[aa][aa]);
+        }
+#pragma unroll
+        for (int bb = 1; bb < N; ++bb) {
+#pragma unroll
+            for (int aa = 0; aa < bb; ++aa) {
+                const int q = o + N + 2 * Pk<N>::pair(aa, bb);
+                const double sx = c1[q].x, sy = c1[q].y, tx = c1[q + 1].x, ty = c1[q + 1].y;
+                H.re[aa][bb] = fma(sx, pr, H.re[aa][bb]);
+                H.re[aa][bb] = fma(-sy, pi, H.re[aa][bb]);
+                H.im[aa][bb] = fma(tx, pi, H.im[aa][bb]);
+                H.im[aa][bb] = fma(ty, pr, H.im[aa][bb]);
+            }
+        }
+    }
+#pragma unroll
+    for (int bb = 0; bb < N; ++bb) {
+#pragma unroll
+        for (int aa = bb + 1; aa < N; ++aa) {
+            H.re[aa][bb] = H.re[bb][aa];
+            H.im[aa][bb] = -H.im[bb][aa];
+        }
+    }
+}
+
 struct NodeArgs {
     const double2* src;
     const int64_t* parents;
@@ -2259,6 +2310,7 @@ struct NodeArgs {
     const double* sweep_arr;
     int64_t nnodes;
     int M, first, d, ncomp;
+    int pk;  // the level-1 sets are packed Hermitian rows (packed_herm.h)
     double inv_period, sweep;
     double p[4];
 };
@@ -2267,13 +2319,18 @@ template <int N, int FID>
 __global__ __launch_bounds__(256) void node_integrand_kernel(NodeArgs a, double2* __restrict__ values) {
     const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= a.nnodes) return;
-    cptr_t c1 = as_const(a.src + a.parents[k] * ((int64_t)a.M * N * N));
     const double xx = a.x[k] * a.inv_period;
     double zr, zi, wr, wi;
     sincospi(2.0 * xx, &zi, &zr);
-    sincospi(2.0 * ((double)a.first * xx), &wi, &wr);
     CMat<N> H;
-    series_lane<N>(c1, a.M, a.first, zr, zi, wr, wi, false, H);
+    if (a.pk) {
+        const int F = (a.M - 1) / 2;
+        series_point_pk<N>(as_const(a.src + a.parents[k] * (int64_t)Pk<N>::size(F)), F, zr, zi, H);
+    } else {
+        cptr_t c1 = as_const(a.src + a.parents[k] * ((int64_t)a.M * N * N));
+        sincospi(2.0 * ((double)a.first * xx), &wi, &wr);
+        series_lane<N>(c1, a.M, a.first, zr, zi, wr, wi, false, H);
+    }
     double e[N];
     if constexpr (FID == ABZ_F_DOS_EIG) {
         herm_eig_values<N>(H, e);
@@ -2343,6 +2400,7 @@ int launch_node_integrand(abz_ctx* ctx, const NodeEvalSpec& ns, double2* values_
     a.first = ns.first;
     a.d = ns.d;
     a.ncomp = ncomp;
+    a.pk = ns.packed ? 1 : 0;
     a.inv_period = 1.0 / ns.period;
     a.sweep = ns.sweep;
     a.sweep_arr = ns.sweep_arr;
@@ -2441,6 +2499,7 @@ struct InnerArgs {
     int M, first, d, ncomp, has_rtol;
     int pair;  // scalar integrands: the two-lane adaptive step (inner_adapt.h)
     int poly;  // sincospi_poly (device_math.h) for the node phases instead of the library routine
+    int pk;    // the level-1 sets are packed Hermitian rows (packed_herm.h): folded series, no seed phase
     double sc[16];
     double inv_period, sweep, rtol_user;
     double p[4];
@@ -2457,7 +2516,7 @@ __global__ __launch_bounds__(256) void inner_adaptive_kernel(InnerArgs a) {
     constexpr int NC = NComp<FID>::template value<N>();  // >= a.ncomp; 1 for the scalar integrands
     const int group = threadIdx.x >> 5, l = threadIdx.x & 31;
     const int nc = a.ncomp;
-    const int MNN = a.M * N * N;
+    const int MNN = a.pk ? Pk<N>::size((a.M - 1) / 2) : a.M * N * N;
     double* g = lds_in + (size_t)group * inner_group_stride(nc, MNN);
     double2* const cl = reinterpret_cast<double2*>(g + inner_group_doubles(nc) + MS);  // this integral's coefficients
     double* seg_a = g;
@@ -2507,15 +2566,20 @@ __global__ __launch_bounds__(256) void inner_adaptive_kernel(InnerArgs a) {
                     const double x = gk15_node(pa, pb, i);
                     const double xx = x * a.inv_period;
                     double zr, zi, wr, wi;
-                    if (a.poly) {
-                        sincospi_poly(a.sc, 2.0 * xx, zi, zr);
-                        sincospi_poly(a.sc, 2.0 * ((double)a.first * xx), wi, wr);
-                    } else {
-                        sincospi(2.0 * xx, &zi, &zr);
-                        sincospi(2.0 * ((double)a.first * xx), &wi, &wr);
-                    }
                     CMat<N> H;
-                    series_lane_lds<N, HERM>(cl, a.M, zr, zi, wr, wi, H);
+                    if (HERM && a.pk) {
+                        sincospi(2.0 * xx, &zi, &zr);
+                        series_point_pk<N>((const double2*)cl, (a.M - 1) / 2, zr, zi, H);
+                    } else {
+                        if (a.poly) {
+                            sincospi_poly(a.sc, 2.0 * xx, zi, zr);
+                            sincospi_poly(a.sc, 2.0 * ((double)a.first * xx), wi, wr);
+                        } else {
+                            sincospi(2.0 * xx, &zi, &zr);
+                            sincospi(2.0 * ((double)a.first * xx), &wi, &wr);
+                        }
+                        series_lane_lds<N, HERM>(cl, a.M, zr, zi, wr, wi, H);
+                    }
                     double e[N];
                     if constexpr (FID == ABZ_F_DOS_EIG) {
                         herm_eig_values<N>(H, e);
@@ -2609,6 +2673,7 @@ int launch_inner_adaptive(abz_ctx* ctx, const InnerSpec& is) {
     // so the library routine stays the default; ABZ_INNER_SINCOS=1 switches (recorded experiment)
     a.poly = [] { const char* e = getenv("ABZ_INNER_SINCOS"); return e && e[0] == '1'; }() ? 1 : 0;  // per call
     for (int i = 0; i < 16; ++i) a.sc[i] = kSinCosPiCoef[i];
+    a.pk = (is.packed && is.herm) ? 1 : 0;
     a.inv_period = 1.0 / is.period;
     a.sweep = is.sweep;
     a.rtol_user = is.rtol_user;
@@ -2618,7 +2683,7 @@ int launch_inner_adaptive(abz_ctx* ctx, const InnerSpec& is) {
     a.nev_out = is.nev_out;
     a.status_out = is.status_out;
     ProfScope ps(ctx, ABZ_K_EVAL);
-    const int mnn = is.M * is.n * is.n;
+    const int mnn = a.pk ? (int)packed_row_elems(is.n, is.M) : is.M * is.n * is.n;
     if (mnn > EVAL_MAX_MNN) {
         set_error("inner adaptive kernel: %d coefficients per line exceed the LDS budget", mnn);
         return ABZ_ERR_UNSUPPORTED;

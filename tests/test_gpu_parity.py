@@ -1053,8 +1053,9 @@ def test_iai_speculative_requests_change_nothing(abz, monkeypatch, n, dims, eta,
     f = abz.FourierIntegrand(abz.DOSIntegrand(), s, eta)
     runs = {}
     for tag, env in (("spec", {}), ("serial", {"ABZ_IAI_SPECULATE": "0"}), ("chunks", {"ABZ_IAI_POOL_MB": "1"}),
-                     ("onelane", {"ABZ_INNER_PAIR": "0"})):  # n <= 4: the one-lane adaptive step of the innermost kernel
-        for k in ("ABZ_IAI_SPECULATE", "ABZ_IAI_POOL_MB", "ABZ_INNER_PAIR"):
+                     ("onelane", {"ABZ_INNER_PAIR": "0"}),  # n <= 4: the one-lane adaptive step of the innermost kernel
+                     ("fullrows", {"ABZ_IAI_PACKED": "0"})):  # n <= 4: the chain on full instead of packed Hermitian rows
+        for k in ("ABZ_IAI_SPECULATE", "ABZ_IAI_POOL_MB", "ABZ_INNER_PAIR", "ABZ_IAI_PACKED"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
@@ -1063,6 +1064,9 @@ def test_iai_speculative_requests_change_nothing(abz, monkeypatch, n, dims, eta,
     for tag in ("serial", "chunks", "onelane"):
         assert runs[tag][0] == runs["spec"][0] and runs[tag][1] == runs["spec"][1] and runs[tag][2] == runs["spec"][2]
         assert np.array_equal(runs[tag][3], runs["spec"][3])
+    # packed and full rows sum the same terms in a different order: same panels and counts, values equal to rounding
+    assert runs["fullrows"][2] == runs["spec"][2] and np.array_equal(runs["fullrows"][3], runs["spec"][3])
+    assert abs(runs["fullrows"][0] - runs["spec"][0]) <= 1e-12 * abs(runs["spec"][0])
     assert runs["spec"][2] > 15**d and len(runs["spec"][3]) >= 2
 
 
