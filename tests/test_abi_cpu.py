@@ -29,6 +29,20 @@ def test_header_symbols_exported_and_bound(abz):
     assert h.abz_version() == 301  # round 3: abz_mem_info, fused GGR build (ABZ_K_GGRBUILD), status word in the IAI exchange; 301: ABZ_WANT_H_COMPACT
 
 
+def test_header_constants_match_the_bindings(abz):
+    """The `want` bits, integrand ids and limits kinds of include/abzhip.h against the ctypes mirror and the Julia shim."""
+    from autobzcore.jl_amd import _lib as L
+    hdr = open(os.path.join(ROOT, "include", "abzhip.h")).read()
+    defs = {k: int(v) for k, v in re.findall(r"^#define (ABZ_\w+) (-?\d+)\b", hdr, flags=re.M)}
+    assert (defs["ABZ_WANT_H"], defs["ABZ_WANT_EIG"], defs["ABZ_WANT_VEL"], defs["ABZ_WANT_H_COMPACT"]) == \
+        (L.WANT_H, L.WANT_EIG, L.WANT_VEL, L.WANT_H_COMPACT) == (1, 2, 4, 8)
+    ids = [defs[k] for k in ("ABZ_F_ONE", "ABZ_F_LINEAR", "ABZ_F_LINEAR_X", "ABZ_F_DOS", "ABZ_F_TRGLOC", "ABZ_F_GLOC", "ABZ_F_DOS_EIG")]
+    assert ids == [L.F_ONE, L.F_LINEAR, L.F_LINEAR_X, L.F_DOS, L.F_TRGLOC, L.F_GLOC, L.F_DOS_EIG] == list(range(7))
+    jl = open(os.path.join(ROOT, "julia", "AutoBZCoreHIP.jl")).read()
+    assert "const WANT_H, WANT_EIG, WANT_VEL = Cint(1), Cint(2), Cint(4)" in jl and "const WANT_H_COMPACT = Cint(8)" in jl
+    assert defs["ABZ_VERSION"] == 301
+
+
 def test_fails_loudly_without_gpu(abz):
     import torch
     if torch.cuda.is_available():
