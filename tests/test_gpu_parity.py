@@ -1683,7 +1683,7 @@ def test_hermitian_compact_rule_layout_equals_full_layout(abz, n, monkeypatch):
             abz.series.julia_coefficient_order(c + 0.05 * extra, 3).view(np.float64)).ctypes.data_as(L.c_f64p)))
         keep.rebuild()
     dev.update(c + 0.05 * extra)
-    assert not dev.rules and not dev.hermitian()
+    assert not dev.hermitian() and (not dev.rules or os.environ.get("ABZ_RULE_COMPACT", "1") == "0")
     r2 = dev.rule(8, None, want=L.WANT_H)
     assert not r2.want & L.WANT_H_COMPACT
     so2 = orc.FourierSeries(c + 0.05 * extra, period=1.0, first=first, ndim=3)
