@@ -32,6 +32,33 @@ void set_error(const char* fmt, ...);
         }                                 \
     } while (0)
 
+// ---- environment switches -------------------------------------------------------------------------------------------
+// Every switch the library reads, in one table (api.cpp: name, default, meaning; DESIGN.md section 12 repeats it).  They
+// exist for two reasons only: a test compares two code paths that must agree (the switch selects the one that is not the
+// default), or an operator sizes a resource.  Values are read per call -- tests flip them at run time.
+enum Switch {
+    SW_POOL_MB,          // ABZ_POOL_MB         cap of the caching device allocator
+    SW_DEBUG_TIMING,     // ABZ_DEBUG_TIMING    wall time of the rule-build phases on stderr
+    SW_EVAL_PACKED,      // ABZ_EVAL_PACKED     full-grid chains of Hermitian series on packed sets (packed_herm.h)
+    SW_DOS3_SCAN,        // ABZ_DOS3_SCAN       3-band DOS sweeps through dos3_scan_kernel (0: the generic reduce_kernel)
+    SW_REDUCE_ROWS,      // ABZ_REDUCE_ROWS     rows of blocks a sweep is split over (0: chosen by the launch)
+    SW_ADAPT_PAIR,       // ABZ_ADAPT_PAIR      two-lane adaptive step of the device-side GK loops (0: one lane)
+    SW_GEN_SUM_TRI,      // ABZ_GEN_SUM_TRI     5...16-band sweeps by tridiagonal resolvents (0: one inversion per value)
+    SW_IPANEL_FOLD,      // ABZ_IPANEL_FOLD     16-lane panel kernel: folded series
+    SW_IPANEL_FMAC,      // ABZ_IPANEL_FMAC     16-lane panel kernel: pivot broadcast inside v_fmac_f64_dpp
+    SW_GGR_FUSED,        // ABZ_GGR_FUSED       one-kernel GGR build (0: eigenvectors + one velocity launch per variable)
+    SW_GGR_FUSE2,        // ABZ_GGR_FUSE2       ... contracting variable 2 inside the kernel (0: level-1 families)
+    SW_GGR_UNIFORM,      // ABZ_GGR_UNIFORM     GGR scans index equispaced energy lists by arithmetic
+    SW_IAI_SPECULATE,    // ABZ_IAI_SPECULATE   requests ahead of the pops in the nested IAI driver
+    SW_IAI_PACKED,       // ABZ_IAI_PACKED      IAI chains of Hermitian series (n <= 4) on packed rows
+    SW_IAI_POOL_MB,      // ABZ_IAI_POOL_MB     size of a chunk of level sets in the IAI driver
+    SW_IAI_DEVICE_INNER, // ABZ_IAI_DEVICE_INNER innermost adaptive loops on the device (0: host-driven rounds)
+    SW_IAI_STATS,        // ABZ_IAI_STATS       per-solve statistics of the IAI driver on stderr
+    SW_HOST_THREADS,     // ABZ_HOST_THREADS    host threads for the per-integral bookkeeping of IAI sweeps
+    SW_COUNT
+};
+int abz_switch(Switch s);  // the switch's integer value from the environment, or its default
+
 // Device buffer that grows but never shrinks (scratch); freed with its owner.
 // Host <-> device copies of arrays beyond a few hundred KB go through the context's pinned staging buffer:
 // ROCm pins pageable memory on the fly for such copies, which costs milliseconds per call (5 MB of plan

@@ -24,6 +24,42 @@ void set_error(const char* fmt, ...) {
 }
 
 // ------------------------------------------------------------------------------------------
+// Environment switches: the one place the library reads the environment (abz_internal.h: enum Switch).
+// ------------------------------------------------------------------------------------------
+namespace {
+struct SwitchDef {
+    const char* name;
+    int dflt;
+    const char* what;
+};
+const SwitchDef g_switches[SW_COUNT] = {
+    {"ABZ_POOL_MB", 4096, "MB of freed device blocks the caching allocator keeps per device"},
+    {"ABZ_DEBUG_TIMING", 0, "1: wall time of the rule-build phases on stderr (synchronises after each)"},
+    {"ABZ_EVAL_PACKED", 1, "0: full-grid chains on plain coefficient sets instead of packed Hermitian sets"},
+    {"ABZ_DOS3_SCAN", 1, "0: 3-band DOS sweeps through the generic reduce_kernel"},
+    {"ABZ_REDUCE_ROWS", 0, "> 0: rows of blocks a sweep is split over in the scan kernels"},
+    {"ABZ_ADAPT_PAIR", 1, "0: one-lane adaptive step in the device-side GK loops"},
+    {"ABZ_GEN_SUM_TRI", 1, "0: 5...16-band sweeps with one inversion per swept value"},
+    {"ABZ_IPANEL_FOLD", 1, "0: 16-lane panel kernel on the unfolded series"},
+    {"ABZ_IPANEL_FMAC", 1, "0: 16-lane panel kernel with separate pivot-row broadcasts"},
+    {"ABZ_GGR_FUSED", 1, "0: GGR build by eigenvectors + one velocity launch per variable"},
+    {"ABZ_GGR_FUSE2", 1, "0: fused GGR build reads level-1 families instead of contracting variable 2 itself"},
+    {"ABZ_GGR_UNIFORM", 1, "0: GGR scans search the energy window even in equispaced lists"},
+    {"ABZ_IAI_SPECULATE", 1, "0: nested IAI driver requests one panel per integral and round"},
+    {"ABZ_IAI_PACKED", 1, "0: IAI chains on plain coefficient sets"},
+    {"ABZ_IAI_POOL_MB", 0, "> 0: MB per chunk of level sets in the IAI driver (default: sized from free memory)"},
+    {"ABZ_IAI_DEVICE_INNER", 1, "0: innermost GK loops driven from the host, one launch per round"},
+    {"ABZ_IAI_STATS", 0, "1: per-solve statistics of the IAI driver on stderr"},
+    {"ABZ_HOST_THREADS", 0, "> 0: host threads for the per-integral bookkeeping of IAI sweeps"},
+};
+}  // namespace
+
+int abz_switch(Switch s) {
+    const char* e = getenv(g_switches[s].name);
+    return (e && *e) ? atoi(e) : g_switches[s].dflt;
+}
+
+// ------------------------------------------------------------------------------------------
 // Caching device allocator.  hipMalloc / hipFree of MB-sized blocks cost milliseconds each (and hipFree
 // synchronises the device); rule builds, symmetric-rule plans and the IAI pools allocate and free such
 // blocks all the time (a cold symmetric 150^3 rule spent 20 of its 30 ms there).  Freed blocks are kept
@@ -42,10 +78,7 @@ size_t g_pool_bytes = 0;
 std::atomic<int64_t> g_live_bytes{0};   // handed out by dev_alloc and not yet returned (abz_mem_info)
 std::atomic<int64_t> g_live_blocks{0};
 size_t pool_limit() {
-    static const size_t lim = [] {
-        const char* e = getenv("ABZ_POOL_MB");
-        return (size_t)(e ? std::max(0, atoi(e)) : 4096) << 20;
-    }();
+    static const size_t lim = (size_t)std::max(0, abz_switch(SW_POOL_MB)) << 20;
     return lim;
 }
 void pool_flush(int device) {  // give everything cached for `device` back to the driver
@@ -1083,9 +1116,12 @@ static int rule_build(abz_series* s, int npt, int64_t nirr, const int32_t* irr_i
     // fill kernels below (and could land on top of their results)
     // Irregular node lists: the last tile is partly empty and kernels that walk whole tiles multiply its slots by a zero
     // weight -- they must hold finite numbers.  Full grids have no partial tile (nk = lines x npt) and no kernel addresses
-    // the padding columns npt .. pitch-1 of a row (the grid kernel writes them as filler anyway), so the 346 MB memset of
-    // a 150^3 rule (0.045 ms, 0.8 ms at 400^3) is skipped.
-    if (!r->full) RULE_HIP(hipMemsetAsync(r->vals, 0, bytes, ctx->stream));
+    // the padding columns npt .. pitch-1 of a row; the grid kernel of 1...4 bands writes them as filler anyway, so the
+    // 346 MB memset of a 150^3 rule (0.045 ms, 0.8 ms at 400^3) is skipped there.  The other fill kernels (GGR builds,
+    // 5...32 bands, velocity planes) leave the padding alone: the block comes from a recycling pool, and a client of
+    // abz_rule_values_ptr sees the whole block, so it is zeroed once here (abzhip.h: padding is zero or filler, finite).
+    const bool filler_written = r->full && n <= 4 && !(want & ABZ_WANT_VEL);
+    if (!(r->full && (pitch == line_len || filler_written))) RULE_HIP(hipMemsetAsync(r->vals, 0, bytes, ctx->stream));
     if (getenv("ABZ_DEBUG_ALLOC")) fprintf(stderr, "[abz] rule values %p (%zu bytes)\n", (void*)r->vals, bytes);
     auto mkview = [&](int plane0, bool present) {
         PlaneView v;

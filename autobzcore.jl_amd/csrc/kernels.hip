@@ -9,7 +9,6 @@
 //                           slot, one load group and one wait per unit of work (in-order vmcnt), fused
 //                           Hermitian eigensolve, tiled-planar stores (H first, non-temporal on large rules)
 //                           = workspace_evaluate! in fourier_ptr!  (ref src/fourier.jl:132-147)
-//   eval_grid_fused_kernel  opt-in: the same with the last contraction computed by the wave itself
 //   eval_node_kernel        the series at explicit nodes (symmetric rules, abz_eval_nodes)
 //   reduce_kernel           sum_k w_k f(H(k); omega_i) for all omega_i of a sweep in one pass over the cached
 //                           rule = quadsum (ref src/fourier.jl:204-207,289-292); Hermitian rules: real
@@ -429,12 +428,8 @@ struct EvalArgs {
     int64_t line0;  // store-free sums on a slab: global index of line 0 (for node coordinates)
     int M, first, npt, deriv, herm;
     int nt;  // non-temporal stores (rule values larger than the Infinity Cache)
-    int padw;  // write the padding columns npt..pitch-1 too (whole 128-B lines); 0: experiment ABZ_PAD_WRITE=0
     int pk;    // the level-1 sets are PACKED Hermitian sets (packed_herm.h): Pk<N>::size((M - 1) / 2) numbers per line
     double inv_period;
-    // fused last contraction (eval_grid_fused_kernel): level-2 sets and the contracted variable
-    const double2* src2;
-    int M2, first2, deriv2, gbeg, gcnt, nseg;
 };
 
 // planes of one node at column i1 of tile `line`; with a wave-uniform line every plane row is a scalar
@@ -671,12 +666,12 @@ __device__ __forceinline__ void eval_unit_store(const EvalArgs& a, CMat<N> (&H)[
     }
     if constexpr (!VEC) {
         // columns npt..pitch-1 are padding: written (finite filler) so every 128-B line of the
-        // tile leaves the CU whole; never read back.
+        // tile leaves the CU whole; never read back (leaving them unwritten measured 17 % slower: partial lines).
         // Order: ALL H(k) stores of the unit first, then the eigensolves (they overlap the drain of those
         // stores), then the eigenvalue stores.  With non-temporal stores on rules larger than the Infinity
         // Cache this is worth 19 % at 150^3 (neither change alone is: the interleaved order leaves the
         // store queue empty during every eigensolve, and temporal stores make the 605 MB fight for L2/MALL).
-        const int pitch = a.padw ? (a.H.base ? a.H.row : a.E.row) : a.npt;
+        const int pitch = a.H.base ? a.H.row : a.E.row;
         auto epilogue = [&](auto nt, auto hc) {
             constexpr bool NT = decltype(nt)::value;
             constexpr bool HC = decltype(hc)::value;
@@ -812,106 +807,6 @@ __global__ __launch_bounds__(256, OCC) void eval_grid_kernel(EvalArgs a) {
     }
 }
 
-// The same with the LAST CONTRACTION FUSED IN: the level-1 sets c1[i2] = sum_m2 ph2[i2][m2] c2[m2] are not
-// read from HBM but computed by the wave from its block's level-2 set c2 (M2 M n^2 complex, staged in LDS
-// once per block), so the work loop holds no global load at all.  A block owns a segment of the i2 range
-// of one parent (level-2 item); wave w takes every 4th line of it.
-template <int N, int KPL, bool HERM, bool VEC, int OCC, bool PK = false>
-__global__ __launch_bounds__(256, OCC) void eval_grid_fused_kernel(EvalArgs a) {
-    extern __shared__ double2 lds_f[];  // [M2][MNN] level-2 set | [npt] phase table | [4 waves][2][MNN]
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-    // PK: the level-2 sets are packed Hermitian rows (packed_herm.h; packing commutes with the contraction)
-    const int MNN = PK ? Pk<N>::size((a.M - 1) / 2) : a.M * N * N;
-    double2* const c2s = lds_f;
-    double2* const tab_l = c2s + (size_t)a.M2 * MNN;
-    double2* const mybuf = tab_l + a.npt + (size_t)wave * 2 * MNN;
-    int fm = a.first % a.npt;
-    if (fm < 0) fm += a.npt;
-    int fm2 = a.first2 % a.npt;
-    if (fm2 < 0) fm2 += a.npt;
-    const int npass = (a.npt + 64 * KPL - 1) / (64 * KPL);
-    const int64_t parent = blockIdx.x / a.nseg;
-    const int seg = blockIdx.x - (int)(parent * a.nseg);
-    {
-        const double2* __restrict__ src2 = a.src2 + parent * ((int64_t)a.M2 * MNN);
-        for (int i = threadIdx.x; i < a.M2 * MNN; i += 256) c2s[i] = src2[i];
-        for (int i = threadIdx.x; i < a.npt; i += 256) tab_l[i] = a.tab[i];
-    }
-    __syncthreads();
-    const int lo = a.gbeg + (int)(((int64_t)a.gcnt * seg) / a.nseg);
-    const int hi = a.gbeg + (int)(((int64_t)a.gcnt * (seg + 1)) / a.nseg);
-    // c1 of grid index i2 into dst: lane t-th elements idx = lane + 64 t
-    auto contract_line = [&](int i2, double2* dst) {
-        unsigned ip = (unsigned)(((unsigned)fm2 * (unsigned)i2) % (unsigned)a.npt);
-        double accr[EVAL_MAX_MNN / 64], acci[EVAL_MAX_MNN / 64];
-#pragma unroll
-        for (int t = 0; t < EVAL_MAX_MNN / 64; ++t) {
-            accr[t] = 0.0;
-            acci[t] = 0.0;
-        }
-        for (int m2 = 0; m2 < a.M2; ++m2) {
-            double2 ph = tab_l[ip];
-            if (a.deriv2) {
-                const double f = 6.283185307179586476925286766559 * (double)(a.first2 + m2);
-                ph = make_double2(-f * ph.y, f * ph.x);
-            }
-            const double2* __restrict__ row = c2s + (size_t)m2 * MNN;
-#pragma unroll
-            for (int t = 0; t < EVAL_MAX_MNN / 64; ++t) {
-                if (64 * t < MNN) {  // uniform
-                    const int idx = lane + 64 * t;
-                    const double2 c = row[idx < MNN ? idx : MNN - 1];
-                    accr[t] = fma(c.x, ph.x, accr[t]);
-                    accr[t] = fma(-c.y, ph.y, accr[t]);
-                    acci[t] = fma(c.x, ph.y, acci[t]);
-                    acci[t] = fma(c.y, ph.x, acci[t]);
-                }
-            }
-            ip += (unsigned)i2;
-            if (ip >= (unsigned)a.npt) ip -= (unsigned)a.npt;
-        }
-#pragma unroll
-        for (int t = 0; t < EVAL_MAX_MNN / 64; ++t) {
-            const int idx = lane + 64 * t;
-            if (idx < MNN) {
-                double2 v = make_double2(accr[t], acci[t]);
-                if constexpr (!PK) {
-                    if (a.deriv) {
-                        const double f = 6.283185307179586476925286766559 * (double)(a.first + idx / (N * N));
-                        v = make_double2(-f * v.y, f * v.x);
-                    }
-                }
-                dst[idx] = v;
-            }
-        }
-    };
-    int i2 = lo + wave;
-    if (i2 >= hi) return;
-    contract_line(i2, mybuf);
-    int iz0[KPL], iw0[KPL];
-#pragma unroll
-    for (int j = 0; j < KPL; ++j) {
-        const int i1 = lane + 64 * j;
-        iz0[j] = i1 < a.npt ? i1 : 0;
-        iw0[j] = (int)(((unsigned)fm * (unsigned)iz0[j]) % (unsigned)a.npt);
-    }
-    int cur = 0, pass = 0;
-    while (i2 < hi) {
-        const bool last_pass = pass + 1 >= npass;
-        const int ni2 = last_pass ? i2 + 4 : i2;
-        const int64_t line = parent * a.gcnt + (i2 - a.gbeg);
-        wave_lds_sync();
-        auto nothing = [] {};
-        eval_unit<N, KPL, HERM, VEC, decltype(nothing)&, PK>(a, mybuf + (size_t)cur * MNN, tab_l, fm, iz0, iw0, npass, pass * (64 * KPL), lane,
-                                                             line, nothing);
-        // after the stores are issued: the next line's contraction overlaps their drain
-        if (last_pass && ni2 < hi) contract_line(ni2, mybuf + (size_t)(cur ^ 1) * MNN);
-        if (last_pass) cur ^= 1;
-        pass = last_pass ? 0 : pass + 1;
-        i2 = ni2;
-    }
-}
-
 // Fallback for coefficient sets too large for the LDS staging above: wave-uniform scalar loads.
 template <int N>
 __global__ __launch_bounds__(256) void eval_grid_kernel_scalar(EvalArgs a) {
@@ -976,31 +871,11 @@ __global__ __launch_bounds__(256) void eval_node_kernel(EvalArgs a) {
             return ABZ_ERR_UNSUPPORTED;                             \
     }
 
-// Can the last contraction (variable 2, M2 coefficients) be fused into the grid kernel?  The level-2 set
-// must fit in LDS beside the phase table and the wave buffers (three blocks per CU).
-bool eval_can_fuse(int n, int M, int M2, int npt) {
-    // Opt-in (ABZ_FUSE2=1, read per call so that bench.py can time both variants in one process): the fused
-    // kernel saves one launch and the 36 MB round trip of the level-1 sets but carries ~7 % more work;
-    // measured 3-9 % faster per rebuild depending on the box, with a lower roofline fraction of its own.
-    const char* e = getenv("ABZ_FUSE2");
-    if (!(e && e[0] == '1') || n > 4) return false;
-    const int mnn = M * n * n;
-    const size_t lds = sizeof(double2) * ((size_t)M2 * mnn + (size_t)npt + 4 * 2 * (size_t)mnn);
-    return mnn <= EVAL_MAX_MNN && npt < 65536 && lds <= 48 * 1024;
-}
-
 // Can the grid kernel take packed Hermitian level-1 sets (packed_herm.h)?  Same limits as its LDS-staged path.
 bool eval_packed_supported(int n, int M, int npt) {
-    const bool off = [] { const char* e = getenv("ABZ_EVAL_PACKED"); return e && e[0] == '0'; }();  // per call: tests compare both chains
-    if (off || n < 1 || n > 4 || (M & 1) == 0) return false;
+    if (!abz_switch(SW_EVAL_PACKED) || n < 1 || n > 4 || (M & 1) == 0) return false;
     const size_t P = packed_row_elems(n, M);
     return P <= (size_t)EVAL_MAX_MNN && npt < 65536 && sizeof(double2) * (4 * 2 * P + (size_t)npt) <= 64 * 1024;
-}
-
-static int eval_occ() {  // read per launch: tools/time_eval_blocks.py sweeps it on one buffer
-    const char* e = getenv("ABZ_EVAL_OCC");
-    const int v = e ? atoi(e) : 3;
-    return (v == 2 || v == 3 || v == 4) ? v : 3;
 }
 
 int launch_eval(abz_ctx* ctx, const EvalSpec& es) {
@@ -1057,32 +932,21 @@ int launch_eval(abz_ctx* ctx, const EvalSpec& es) {
     {
         // streaming stores once the values written by this launch exceed the 256 MB Infinity Cache
         // (npt = 100, 168 MB: 7 % slower with them; 150, 605 MB: 19 % faster)
-        const int force = [] { const char* e = getenv("ABZ_NT_STORES"); return e ? atoi(e) : -1; }();  // per launch (tools sweep it)
         const PlaneView& pv = es.H.base ? es.H : es.E;
         const double planes_out = (es.H.base ? (es.H.compact ? 1.0 : 2.0) * es.n * es.n : 0.0) + (es.E.base ? (double)es.n : 0.0) + (es.U.base ? 2.0 * es.n * es.n : 0.0);
         const double bytes = 8.0 * planes_out * (double)pv.row * (double)(es.grid ? es.nlines : (es.nk + 63) / 64);
-        a.nt = force >= 0 ? force : (bytes > 256.0 * 1024 * 1024 ? 1 : 0);
-        static const int padw = [] { const char* e = getenv("ABZ_PAD_WRITE"); return e ? atoi(e) : 1; }();
-        a.padw = padw;
+        a.nt = bytes > 256.0 * 1024 * 1024 ? 1 : 0;
     }
-    a.pk = (es.packed && a.herm && !es.U.base && es.grid && !(es.src2 && es.deriv2)) ? 1 : 0;
-    a.src2 = es.src2;
-    a.M2 = es.M2;
-    a.first2 = es.first2;
-    a.deriv2 = es.deriv2 ? 1 : 0;
-    a.gbeg = es.gbeg;
-    a.gcnt = es.gcnt;
-    a.nseg = 1;
+    a.pk = (es.packed && a.herm && !es.U.base && es.grid) ? 1 : 0;
     ProfScope ps(ctx, ABZ_K_EVAL);
     if (es.grid) {
         if (es.nlines == 0) return ABZ_OK;
-        // Workgroups: 8 per CU up to ~140^3, 16 per CU beyond (tools/time_eval_blocks.py, 3 bands: npt 150 0.1133 -> 0.1101 ms
-        // on a fast box, 0.1234 -> 0.1175 on a slow one; 200 -6 %, 250 -15 %, 300 -3 %, 500 -6 %; 110 / 128 are 3-5 %
-        // better with 8 per CU, 180 and 400 lose 2-3 % with 16).  ABZ_EVAL_BLOCKS overrides.
-        const int eval_blocks = [] { const char* e = getenv("ABZ_EVAL_BLOCKS"); return e ? atoi(e) : 0; }();  // per launch: the timing tool sweeps it
+        // Workgroups: 8 per CU up to ~140^3, 16 per CU beyond (3 bands: npt 150 0.1133 -> 0.1101 ms on a fast box,
+        // 0.1234 -> 0.1175 on a slow one; 200 -6 %, 250 -15 %, 300 -3 %, 500 -6 %; 110 / 128 are 3-5 % better with 8 per
+        // CU, 180 and 400 lose 2-3 % with 16); compact H planes: 24 per CU -- at 150^3 one line per wave -- measured
+        // 1.5 % better than 16, the same at 200^3
         const int64_t quads = cdiv(es.nlines, 4);
-        // (compact H planes: 24 per CU -- at 150^3 one line per wave -- measured 1.5 % better than 16, the same at 200^3)
-        int64_t blocks = std::min<int64_t>(quads, eval_blocks > 0 ? eval_blocks : (quads < 5000 ? 256 * 8 : (es.H.compact ? 256 * 24 : 256 * 16)));
+        const int64_t blocks = std::min<int64_t>(quads, quads < 5000 ? 256 * 8 : (es.H.compact ? 256 * 24 : 256 * 16));
         const int mnn = a.pk ? es.n * (es.n + 1) / 2 + ((es.M - 1) / 2) * es.n * es.n : es.M * es.n * es.n;  // numbers per line (packed_herm.h)
         // nodes per lane: minimise lane-rounds per line, ceil(npt / (64 kpl)) * kpl, weighted by the LDS
         // operand reads that are shared by the kpl nodes of a lane (200 points: 2 x 2 rounds, not 2 x 3)
@@ -1098,62 +962,21 @@ int launch_eval(abz_ctx* ctx, const EvalSpec& es) {
             }
         }
         // + an LDS copy of the phase table (fm * i1 < npt^2 must fit 32 bits)
-        size_t lds = sizeof(double2) * (4 * 2 * (size_t)mnn + (size_t)a.npt);
-        if (es.src2) {  // fused last contraction: caller checked eval_can_fuse()
-            lds += sizeof(double2) * (size_t)es.M2 * mnn;
-            // segments of the i2 range per parent: enough blocks to fill the chip, >= 2 lines per wave
-            const int64_t nparents = es.nlines / std::max(es.gcnt, 1);
-            // two waves of resident blocks (3 per CU) measured best; each wave of a block gets >= 2 lines
-            static const int target = [] { const char* e = getenv("ABZ_FUSE_BLOCKS"); return e ? atoi(e) : 1536; }();
-            int64_t nseg = std::max<int64_t>(1, target / std::max<int64_t>(nparents, 1));
-            nseg = std::max<int64_t>(1, std::min<int64_t>(nseg, cdiv(es.gcnt, 8)));
-            a.nseg = (int)nseg;
-            blocks = nparents * nseg;
-#define LKF(NN, KK, OO)                                                                                                          \
-    if (a.pk)                                                                                                                    \
-        hipLaunchKernelGGL((eval_grid_fused_kernel<NN, KK, true, false, OO, true>), dim3((unsigned)blocks), dim3(256), lds, ctx->stream, a); \
-    else if (a.U.base)                                                                                                           \
-        hipLaunchKernelGGL((eval_grid_fused_kernel<NN, KK, false, true, 2>), dim3((unsigned)blocks), dim3(256), lds, ctx->stream, a);  \
-    else if (a.herm)                                                                                                             \
-        hipLaunchKernelGGL((eval_grid_fused_kernel<NN, KK, true, false, OO>), dim3((unsigned)blocks), dim3(256), lds, ctx->stream, a); \
-    else                                                                                                                         \
-        hipLaunchKernelGGL((eval_grid_fused_kernel<NN, KK, false, false, 2>), dim3((unsigned)blocks), dim3(256), lds, ctx->stream, a);
-#define LK(NN, KK)                         \
-    if (NN == 3 && eval_occ() == 3) {      \
-        LKF(NN, KK, 3)                     \
-    } else if (NN == 3 && eval_occ() == 4) { \
-        LKF(NN, KK, 4)                     \
-    } else {                               \
-        LKF(NN, KK, 2)                     \
-    }
-#define FN(NN)                    \
-    switch (kpl) {                \
-        case 1: LK(NN, 1) break;  \
-        case 2: LK(NN, 2) break;  \
-        default: LK(NN, 3) break; \
-    }
-            ABZ_DISPATCH_N(es.n, FN)
-#undef FN
-#undef LK
-#undef LKF
-        } else if (mnn <= EVAL_MAX_MNN && lds <= 64 * 1024 && a.npt < 65536) {
-#define LKO(NN, KK, OO)                                                                                                        \
-    if (a.pk)                                                                                                                  \
-        hipLaunchKernelGGL((eval_grid_kernel<NN, KK, true, false, OO, true>), dim3((unsigned)blocks), dim3(256), lds, ctx->stream, a); \
-    else if (a.U.base)                                                                                                         \
-        hipLaunchKernelGGL((eval_grid_kernel<NN, KK, false, true, 2>), dim3((unsigned)blocks), dim3(256), lds, ctx->stream, a);  \
-    else if (a.herm)                                                                                                           \
-        hipLaunchKernelGGL((eval_grid_kernel<NN, KK, true, false, OO>), dim3((unsigned)blocks), dim3(256), lds, ctx->stream, a); \
-    else                                                                                                                       \
-        hipLaunchKernelGGL((eval_grid_kernel<NN, KK, false, false, 2>), dim3((unsigned)blocks), dim3(256), lds, ctx->stream, a);
-// waves per SIMD the register allocator is asked for (Hermitian n = 3 path only; ABZ_EVAL_OCC=2|3|4)
-#define LK(NN, KK)                         \
-    if (NN == 3 && eval_occ() == 3) {      \
-        LKO(NN, KK, 3)                     \
-    } else if (NN == 3 && eval_occ() == 4) { \
-        LKO(NN, KK, 4)                     \
-    } else {                               \
-        LKO(NN, KK, 2)                     \
+        const size_t lds = sizeof(double2) * (4 * 2 * (size_t)mnn + (size_t)a.npt);
+        if (mnn <= EVAL_MAX_MNN && lds <= 64 * 1024 && a.npt < 65536) {
+            // waves per SIMD the register allocator is asked for: 3 on the Hermitian 3-band paths (2 and 4 measured
+            // slower there), 2 elsewhere
+#define LK(NN, KK)                                                                                                             \
+    {                                                                                                                          \
+        constexpr int OO = NN == 3 ? 3 : 2;                                                                                    \
+        if (a.pk)                                                                                                              \
+            hipLaunchKernelGGL((eval_grid_kernel<NN, KK, true, false, OO, true>), dim3((unsigned)blocks), dim3(256), lds, ctx->stream, a); \
+        else if (a.U.base)                                                                                                     \
+            hipLaunchKernelGGL((eval_grid_kernel<NN, KK, false, true, 2>), dim3((unsigned)blocks), dim3(256), lds, ctx->stream, a);  \
+        else if (a.herm)                                                                                                       \
+            hipLaunchKernelGGL((eval_grid_kernel<NN, KK, true, false, OO>), dim3((unsigned)blocks), dim3(256), lds, ctx->stream, a); \
+        else                                                                                                                   \
+            hipLaunchKernelGGL((eval_grid_kernel<NN, KK, false, false, 2>), dim3((unsigned)blocks), dim3(256), lds, ctx->stream, a); \
     }
 #define FN(NN)                    \
     switch (kpl) {                \

@@ -792,15 +792,24 @@ int launch_ggr_build(abz_ctx* ctx, const GgrBuildSpec& gs) {
             a.nseg = (int)std::max<int64_t>(1, std::min<int64_t>(cdiv64(ppp, ppb), ppp));
             blocks = (unsigned)(nparents * a.nseg);
         }
-#define GF(NN, DD)                                                                                                        \
-    if (kb == 1 && a.nt)                                                                                                  \
-        hipLaunchKernelGGL((ggr_build_fused_kernel<NN, DD, true, 1>), dim3(blocks), dim3(256), lds, ctx->stream, a);     \
-    else if (kb == 1)                                                                                                     \
-        hipLaunchKernelGGL((ggr_build_fused_kernel<NN, DD, false, 1>), dim3(blocks), dim3(256), lds, ctx->stream, a);    \
-    else if (a.nt)                                                                                                        \
-        hipLaunchKernelGGL((ggr_build_fused_kernel<NN, DD, true, 2>), dim3(blocks), dim3(256), lds, ctx->stream, a);     \
-    else                                                                                                                  \
-        hipLaunchKernelGGL((ggr_build_fused_kernel<NN, DD, false, 2>), dim3(blocks), dim3(256), lds, ctx->stream, a)
+        // above 64 KB of dynamic LDS a launch is rejected unless the function was told so (every other launch of that
+        // size in the library does the same); a 4-band d = 3 model with M = M2 = 11 at npt = 150 needs 68.6 KB
+#define GF1(NN, DD, NT, KB)                                                                                               \
+    do {                                                                                                                  \
+        auto kfn = ggr_build_fused_kernel<NN, DD, NT, KB>;                                                                \
+        if (lds > 64 * 1024)                                                                                              \
+            ABZ_HIP(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));         \
+        hipLaunchKernelGGL(kfn, dim3(blocks), dim3(256), lds, ctx->stream, a);                                            \
+    } while (0)
+#define GF(NN, DD)                     \
+    if (kb == 1 && a.nt)               \
+        GF1(NN, DD, true, 1);          \
+    else if (kb == 1)                  \
+        GF1(NN, DD, false, 1);         \
+    else if (a.nt)                     \
+        GF1(NN, DD, true, 2);          \
+    else                               \
+        GF1(NN, DD, false, 2)
 #define GFD(NN)              \
     if (d == 2) {            \
         GF(NN, 2);           \
@@ -815,6 +824,7 @@ int launch_ggr_build(abz_ctx* ctx, const GgrBuildSpec& gs) {
         }
 #undef GFD
 #undef GF
+#undef GF1
     } else {
         const size_t lds = ggr_lines_lds(n, d, gs.M, gs.npt);
         const int64_t npairs = (gs.nlines + 1) / 2;

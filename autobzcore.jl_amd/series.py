@@ -233,14 +233,13 @@ class DeviceSeries:
         # rules of a Hermitian series keep H(k) as its upper triangle (n^2 planes instead of 2 n^2: every built-in
         # integrand reads those planes only, export() still returns full matrices); ABZ_RULE_COMPACT=0: the reference's
         # full SMatrix layout
-        if (want & L.WANT_H) and self.s.n <= 4 and os.environ.get("ABZ_RULE_COMPACT", "1") != "0" and self.hermitian():
-            want |= L.WANT_H_COMPACT
+        want = self._layout_want(want)
         key = (int(npt), _syms_key(syms), int(want), self.kshard)
         r = self.rules.pop(key, None)
         if r is None:
             # a cached superset also serves
             for (n2, s2, w2, k2), r2 in list(self.rules.items()):
-                if n2 == key[0] and s2 == key[1] and (w2 & want) == want and k2 == self.kshard:
+                if n2 == key[0] and s2 == key[1] and self._serves(w2, want) and k2 == self.kshard:
                     r = self.rules.pop((n2, s2, w2, k2))
                     key = (n2, s2, w2, k2)
                     break
@@ -257,8 +256,20 @@ class DeviceSeries:
 
     def has_rule(self, npt, syms=None, want=L.WANT_H):
         """Is a rule serving this request already resident?"""
-        k0, k1 = int(npt), _syms_key(syms)
-        return any(n2 == k0 and s2 == k1 and (w2 & want) == want and k2 == self.kshard for (n2, s2, w2, k2) in self.rules)
+        k0, k1, want = int(npt), _syms_key(syms), self._layout_want(want)
+        return any(n2 == k0 and s2 == k1 and self._serves(w2, want) and k2 == self.kshard for (n2, s2, w2, k2) in self.rules)
+
+    def _layout_want(self, want):
+        if (want & L.WANT_H) and self.s.n <= 4 and os.environ.get("ABZ_RULE_COMPACT", "1") != "0" and self.hermitian():
+            want |= L.WANT_H_COMPACT
+        return int(want)
+
+    @staticmethod
+    def _serves(have, want):
+        """A cached rule with planes `have` serves a request for `want`: every requested plane family is there and, when
+        H planes are requested, in the requested layout (full SMatrix order or upper triangle) -- a zero-copy client of
+        values_ptr must not be handed the other one."""
+        return (have & want) == want and (not (want & L.WANT_H) or (have & L.WANT_H_COMPACT) == (want & L.WANT_H_COMPACT))
 
     def drop_rules(self):
         for r in self.rules.values():

@@ -246,3 +246,17 @@ def test_contour_deformation_and_pole_subtraction_quadratures():
             abz.solve(abz.IntegralProblem(abz.BatchIntegrand(lambda y, x, q: None, float), (0.0, 1.0)), alg)
         with pytest.raises(ValueError):
             abz.solve(abz.IntegralProblem(abz.InplaceIntegrand(lambda y, x, q: None, np.zeros(1)), (0.0, 1.0)), alg)
+
+
+def test_quickstart_doc_values():
+    """The reference's printed quickstart outputs, docs/src/problems.md:18-25 (`QuadGKJL()`, default tolerances):
+    0.14887836958131329 at p = 0.3, then the cache re-used at p = 0.4: 0.1973475149927873 -- one GK(7,15) panel each,
+    so these pin the rule table of the product's host loop to the last bit or two of a 15-term sum."""
+    prob = abz.IntegralProblem(lambda x, p: math.sin(p * x), (0.0, 1.0), 0.3)
+    cache = abz.init(prob, abz.QuadGKJL())
+    sol = abz.solve_(cache)
+    assert abs(sol.u - 0.14887836958131329) <= 1e-16
+    cache.p = 0.4
+    assert abs(abz.solve_(cache).u - 0.1973475149927873) <= 1e-16
+    sol = abz.solve(prob, abz.EvalCounter(abz.QuadGKJL()))
+    assert sol.numevals == 15
