@@ -154,6 +154,18 @@ struct abz_ctx {
     size_t mbox_cap = 0;
 };
 
+namespace abz {
+// a rule kept by its series for the whole-solve entry points (abz_autoptr_solve*): owned by the series (it holds no
+// reference on it), refreshed when the coefficients change
+struct SeriesRule {
+    int npt = 0, want = 0;
+    std::vector<int32_t> syms;  // [nsyms][d][d], empty: full grid
+    abz_rule* r = nullptr;
+    uint64_t generation = 0;    // the series' generation its values were filled at
+    uint64_t stamp = 0;         // last use
+};
+}  // namespace abz
+
 struct abz_series {
     std::atomic<int> refs{1};
     bool closed = false;
@@ -178,6 +190,10 @@ struct abz_series {
     int ex_rank = 0, ex_world = 1;
     void* iai_pin[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};  // pinned host blocks of the IAI driver: chunk inputs [0,1] / outputs [2,3] / exchange [4]
     size_t iai_pin_cap[5] = {0, 0, 0, 0, 0};
+    uint64_t generation = 0;                  // bumped by abz_series_update
+    std::vector<abz::SeriesRule> kept_rules;  // rules of abz_autoptr_solve*, most recently used last
+    uint64_t kept_stamp = 0;
+    abz::DevBuf auto_io;                      // swept values in / sums out of abz_autoptr_solve*
     int64_t elems(int level) const {
         int64_t e = (int64_t)n * n;
         for (int j = 0; j < level; ++j) e *= dims[j];
@@ -268,14 +284,8 @@ struct EvalSpec {
     PlaneView H;
     PlaneView E;
     PlaneView U;  // eigenvector planes 2*(a + n*b) + {re, im}: component a of vector b
-    // grid mode with the last contraction fused in (src2 != nullptr, see eval_can_fuse): level-2 sets
-    // [nlines / gcnt][M2][M n n]; line = parent * gcnt + (i2 - gbeg); `src` is unused
-    const double2* src2 = nullptr;
-    int M2 = 0, first2 = 0, gbeg = 0, gcnt = 0;
-    bool deriv2 = false;
 };
 int launch_eval(abz_ctx* ctx, const EvalSpec& es);
-bool eval_can_fuse(int n, int M, int M2, int npt);
 bool eval_packed_supported(int n, int M, int npt);
 // rows [nrows][M n n] of full coefficients (innermost variable fastest) -> packed rows [nrows][P] (packed_herm.h)
 int launch_pack_rows(abz_ctx* ctx, int n, int M, const double2* src, int64_t nrows, double2* out);
@@ -393,7 +403,6 @@ constexpr int ABZ_INNER_MAXSEG = 48;
 constexpr int ABZ_PANEL_MAXSEG = 384;
 bool inner_adaptive_supported(int n, int M, int integrand);
 int launch_inner_adaptive(abz_ctx* ctx, const InnerSpec& is);
-bool gen_inner_supported(int n, int M, int integrand);  // n > 4: one wavefront per 1-D integral
 bool gen_inner_panel_supported(int n, int M, int integrand);  // n > 4: one workgroup per 1-D integral, set in LDS
 int launch_gen_inner_adaptive(abz_ctx* ctx, const InnerSpec& is);
 

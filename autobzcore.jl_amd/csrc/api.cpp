@@ -50,7 +50,7 @@ const SwitchDef g_switches[SW_COUNT] = {
     {"ABZ_IAI_POOL_MB", 0, "> 0: MB per chunk of level sets in the IAI driver (default: sized from free memory)"},
     {"ABZ_IAI_DEVICE_INNER", 1, "0: innermost GK loops driven from the host, one launch per round"},
     {"ABZ_IAI_STATS", 0, "1: per-solve statistics of the IAI driver on stderr"},
-    {"ABZ_HOST_THREADS", 0, "> 0: host threads for the per-integral bookkeeping of IAI sweeps"},
+    {"ABZ_HOST_THREADS", 8, "host threads for the per-integral bookkeeping of IAI sweeps (capped at half the cores)"},
 };
 }  // namespace
 
@@ -556,6 +556,7 @@ static void series_release(abz_series* s) {
         if (q) (void)hipHostFree(q);
     dev_free(s->coef, s->coef_cap);
     s->coef_pk.release();
+    s->auto_io.release();
     delete s;
     ctx_release(ctx);
 }
@@ -759,13 +760,31 @@ int abz_series_update(abz_series* s, const double* coef_reim) {
     ABZ_HIP(hipStreamSynchronize(s->ctx->stream));
     s->hermitian = detect_hermitian(s, coef_reim);
     s->coef_pk_valid = false;
+    s->generation += 1;  // rules kept by the series refill themselves at their next use
     return ABZ_OK;
+}
+
+static void rule_free(abz_rule* r);
+static void series_drop_kept_rules(abz_series* s) {
+    if (s->kept_rules.empty()) return;
+    (void)hipSetDevice(s->ctx->device);
+    (void)hipStreamSynchronize(s->ctx->stream);
+    for (auto& k : s->kept_rules) rule_free(k.r);  // they hold no reference on the series
+    s->kept_rules.clear();
 }
 
 int abz_series_destroy(abz_series* s) {
     if (!s || s->closed) return ABZ_OK;
+    series_drop_kept_rules(s);
     s->closed = true;
     series_release(s);  // freed once the last rule built from it is gone
+    return ABZ_OK;
+}
+
+int abz_series_drop_rules(abz_series* s) {
+    int rc = check_series(s);
+    if (rc) return rc;
+    series_drop_kept_rules(s);
     return ABZ_OK;
 }
 
@@ -811,8 +830,7 @@ int abz_rule_destroy(abz_rule* r) {
 // eigenvalues + velocities only, Hermitian series, n <= 4: the fused GGR build applies
 static bool rule_ggr_fused(const abz_rule* r) {
     const abz_series* s = r->s;
-    static const bool planar_on = [] { const char* e = getenv("ABZ_RULE_PLANAR"); return e && e[0] == '1'; }();
-    return (r->want & ABZ_WANT_VEL) && !(r->want & ABZ_WANT_H) && !planar_on &&
+    return (r->want & ABZ_WANT_VEL) && !(r->want & ABZ_WANT_H) &&
            ggr_build_supported(s->n, s->d, s->dims[0], r->npt, s->hermitian);
 }
 
@@ -883,8 +901,7 @@ static int rule_fill(abz_rule* r) {
         Dv.base = rp->tmpD.as<double>();
     }
     // full grids of a Hermitian series (n <= 4, values / eigenvalues only): the chain and the grid kernel work on packed sets
-    const bool packed_chain = r->full && s->hermitian && !(r->want & ABZ_WANT_VEL) && eval_packed_supported(n, s->dims[0], r->npt) &&
-                              !(d >= 2 && eval_can_fuse(n, s->dims[0], s->dims[1], r->npt));
+    const bool packed_chain = r->full && s->hermitian && !(r->want & ABZ_WANT_VEL) && eval_packed_supported(n, s->dims[0], r->npt);
     auto run_eval = [&](const double2* level1, bool deriv, PlaneView Hout, PlaneView Eout, PlaneView Uout) -> int {
         EvalSpec es;
         es.n = n;
@@ -912,63 +929,17 @@ static int rule_fill(abz_rule* r) {
         es.U = Uout;
         return launch_eval(ctx, es);
     };
-    // full grids of d >= 2 variables: the last contraction (variable 2) runs inside the grid kernel
-    const bool fuse = r->full && d >= 2 && eval_can_fuse(n, s->dims[0], s->dims[1], r->npt);
-    // ... on packed Hermitian level-2 sets when the plain values / eigenvalues are all that is built
-    const bool packed_fused = r->full && d >= 2 && s->hermitian && !(r->want & ABZ_WANT_VEL) &&
-                              eval_packed_supported(n, s->dims[0], r->npt) && eval_can_fuse(n, s->dims[0], s->dims[1], r->npt);
-    auto run_fused = [&](const double2* level2, bool deriv1, bool deriv2, PlaneView Hout, PlaneView Eout, PlaneView Uout) -> int {
-        EvalSpec es;
-        es.n = n;
-        es.M = s->dims[0];
-        es.first = s->first[0];
-        es.period = s->period[0];
-        es.src = nullptr;
-        es.grid = true;
-        es.npt = r->npt;
-        es.nlines = plan.nitems[1];
-        es.tab = tab;
-        es.nk = r->nk;
-        es.parents = nullptr;
-        es.gi = nullptr;
-        es.x = nullptr;
-        es.deriv = deriv1;
-        es.herm = s->hermitian && !deriv2;
-        es.H = Hout;
-        es.E = Eout;
-        es.U = Uout;
-        es.packed = packed_fused && !deriv1 && !deriv2 && !Uout.base;
-        es.src2 = level2;
-        es.M2 = s->dims[1];
-        es.first2 = s->first[1];
-        es.deriv2 = deriv2;
-        es.gbeg = (d == 2) ? plan.outer0 : 0;
-        es.gcnt = (d == 2) ? plan.outer_n : r->npt;
-        return launch_eval(ctx, es);
-    };
     const double2* level1 = nullptr;
     int rc;
-    if (fuse) {
-        if ((rc = build_chain(s, plan, rp->pd, tab, 0, &level1, 2, nullptr, packed_fused))) return rc;
-        if ((rc = run_fused(level1, false, false, r->H, r->E, Uv))) return rc;
-    } else {
-        if ((rc = build_chain(s, plan, rp->pd, tab, 0, &level1, 1, nullptr, packed_chain))) return rc;
-        if ((rc = run_eval(level1, false, r->H, r->E, Uv))) return rc;
-    }
+    if ((rc = build_chain(s, plan, rp->pd, tab, 0, &level1, 1, nullptr, packed_chain))) return rc;
+    if ((rc = run_eval(level1, false, r->H, r->E, Uv))) return rc;
     if (r->want & ABZ_WANT_VEL) {
         // d/dx_1 reuses the level-1 sets; d/dx_j (j >= 2) rebuilds the chain with the derivative
         // factor on variable j (JacobianSeries, ref src/dos_ggr.jl:6-7)
         for (int j = 1; j <= d; ++j) {
-            if (fuse) {
-                // variables 1 and 2 are differentiated inside the kernel; j >= 3 needs its own level-2 sets
-                if (j >= 3)
-                    if ((rc = build_chain(s, plan, rp->pd, tab, j, &level1, 2))) return rc;
-                if ((rc = run_fused(level1, j == 1, j == 2, Dv, PlaneView(), PlaneView()))) return rc;
-            } else {
-                if (j >= 2)
-                    if ((rc = build_chain(s, plan, rp->pd, tab, j, &level1))) return rc;
-                if ((rc = run_eval(level1, j == 1, Dv, PlaneView(), PlaneView()))) return rc;
-            }
+            if (j >= 2)
+                if ((rc = build_chain(s, plan, rp->pd, tab, j, &level1))) return rc;
+            if ((rc = run_eval(level1, j == 1, Dv, PlaneView(), PlaneView()))) return rc;
             PlaneView Vj = r->V;
             Vj.base += (int64_t)(j - 1) * n * Vj.pitch;
             if ((rc = launch_velocity(ctx, n, Uv, Dv, Vj, r->nk))) return rc;
@@ -1018,7 +989,7 @@ static int rule_build(abz_series* s, int npt, int64_t nirr, const int32_t* irr_i
     r->want = want;
     r->full = irr_idx == nullptr && st == nullptr;
     // ABZ_DEBUG_TIMING=1: wall time of the build phases on stderr (host plan, uploads, allocation, fill)
-    const bool dbg = getenv("ABZ_DEBUG_TIMING") != nullptr;
+    const bool dbg = abz_switch(SW_DEBUG_TIMING) != 0;
     auto tnow = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     double tdbg = tnow();
     auto lap = [&](const char* what) {
@@ -1065,11 +1036,10 @@ static int rule_build(abz_series* s, int npt, int64_t nirr, const int32_t* irr_i
     const int pE = (want & ABZ_WANT_EIG) ? n : 0;
     const int pV = (want & ABZ_WANT_VEL) ? d * n : 0;
     r->planes = pH + pE + pV;
-    // layout of the value planes: tiles [line][plane][row] or, for full grids on request, padded planar [plane][line][row]
-    static const bool planar_on = [] { const char* e = getenv("ABZ_RULE_PLANAR"); return e && e[0] == '1'; }();
-    const bool planar = planar_on && r->full && (int64_t)r->ntiles * pitch < ((int64_t)1 << 31);
-    const int64_t tile = planar ? (int64_t)pitch : (int64_t)r->planes * pitch;
-    const int pstride = planar ? (int)(r->ntiles * pitch) : pitch;  // plane to plane
+    // layout of the value planes: tiles [line][plane][row] (a padded planar layout [plane][line][row] was built and measured
+    // no better in the real kernel; PlaneView still carries both strides)
+    const int64_t tile = (int64_t)r->planes * pitch;
+    const int pstride = pitch;  // plane to plane
     if (st) {  // device-to-device copies of the cached tables: the rule owns its plan like any other
         auto d2d = [&](DevBuf& dst, const void* src, size_t bytes) -> int {
             if (bytes == 0) return ABZ_OK;
@@ -1122,7 +1092,6 @@ static int rule_build(abz_series* s, int npt, int64_t nirr, const int32_t* irr_i
     // abz_rule_values_ptr sees the whole block, so it is zeroed once here (abzhip.h: padding is zero or filler, finite).
     const bool filler_written = r->full && n <= 4 && !(want & ABZ_WANT_VEL);
     if (!(r->full && (pitch == line_len || filler_written))) RULE_HIP(hipMemsetAsync(r->vals, 0, bytes, ctx->stream));
-    if (getenv("ABZ_DEBUG_ALLOC")) fprintf(stderr, "[abz] rule values %p (%zu bytes)\n", (void*)r->vals, bytes);
     auto mkview = [&](int plane0, bool present) {
         PlaneView v;
         if (present) {
@@ -1464,6 +1433,254 @@ int abz_ptr_sum(abz_series* s, int npt, int outer_begin, int outer_end, int inte
     rc = generic ? launch_gen_sum(ctx, ss, out_reim) : launch_eval_sum(ctx, ss, out_reim);
     (void)hipStreamSynchronize(ctx->stream);
     return done(rc);
+}
+
+// ---------------------------------------------------------------- whole AutoPTR solves
+// The rule of grid `npt` kept by the series (built on first use, refilled after abz_series_update).  `keep` = false: a
+// rule for one use; the caller frees it with rule_free.
+static int series_rule(abz_series* s, int npt, const int32_t* syms, int nsyms, int want, bool keep, abz_rule** out, bool* owned) {
+    const size_t nsy = syms ? (size_t)nsyms * s->d * s->d : 0;
+    *owned = false;
+    for (size_t i = 0; i < s->kept_rules.size(); ++i) {
+        SeriesRule& k = s->kept_rules[i];
+        if (k.npt != npt || (k.want & want) != want || k.syms.size() != nsy || !std::equal(k.syms.begin(), k.syms.end(), syms)) continue;
+        if (k.generation != s->generation) {
+            if (k.r->H.compact && !s->hermitian) {  // the series stopped being Hermitian: an upper-triangle rule cannot hold it
+                rule_free(k.r);
+                s->kept_rules.erase(s->kept_rules.begin() + (long)i);
+                break;
+            }
+            int rc = rule_fill(k.r);
+            if (rc) return rc;
+            k.generation = s->generation;
+        }
+        k.stamp = ++s->kept_stamp;
+        *out = k.r;
+        return ABZ_OK;
+    }
+    abz_rule* r = nullptr;
+    int rc = syms ? abz_ptr_rule_build_sym(s, npt, syms, nsyms, want, &r) : rule_build(s, npt, 0, nullptr, nullptr, want, 0, npt, &r);
+    if (rc) return rc;
+    s->refs -= 1;  // owned by the series or by the caller of this function: no reference cycle
+    if (keep) {
+        SeriesRule k;
+        k.npt = npt;
+        k.want = r->want;
+        if (syms) k.syms.assign(syms, syms + nsy);
+        k.r = r;
+        k.generation = s->generation;
+        k.stamp = ++s->kept_stamp;
+        s->kept_rules.push_back(std::move(k));
+    } else {
+        *owned = true;
+    }
+    *out = r;
+    return ABZ_OK;
+}
+
+static size_t rule_value_bytes(const abz_series* s, int npt, int64_t nk, int want) {
+    const int n = s->n;
+    const bool compact = (want & ABZ_WANT_H_COMPACT) && s->hermitian && n <= 4;
+    const size_t per = 8 * (size_t)(((want & ABZ_WANT_H) ? (compact ? n * n : 2 * n * n) : 0) + ((want & ABZ_WANT_EIG) ? n : 0));
+    return per * (size_t)nk;
+}
+
+/* AutoSymPTR.autosymptr for the library's own integrands: I1 = rule(n0), I2 = rule(n0 + dn), err = norm(I2 - I1), refine
+ * until err <= max(abstol, reltol norm(I2)) or numevals >= maxevals -- for n_sweep values of the swept parameter in
+ * lock-step (every grid is built or found once and scanned for all solves that have not converged).
+ * ref: src/algorithms.jl:418-432, src/fourier.jl:381-389, SURVEY A.2. */
+int abz_autoptr_solve_many(abz_series* s, const int32_t* syms, int nsyms, int integrand, const double* params, int nparams,
+                           const double* sweeps, int n_sweep, int n0, int dn, double abstol, double reltol, int64_t maxevals,
+                           int keepmost, double value_factor, double* out_reim, double* err_out, int64_t* numevals_out,
+                           int32_t* npt_out) {
+    int rc = check_series(s);
+    if (rc) return rc;
+    ABZ_REQUIRE(out_reim && n_sweep >= 1 && n0 >= 1 && dn >= 1, "abz_autoptr_solve_many: bad arguments (n0 = %d, dn = %d, n_sweep = %d)", n0, dn, n_sweep);
+    ABZ_REQUIRE((syms == nullptr) == (nsyms <= 0) || (syms == nullptr && nsyms == 1), "syms and nsyms must be given together");
+    ABZ_REQUIRE(nparams >= 0 && nparams <= 4, "nparams = %d not in 0..4", nparams);
+    const int d = s->d, n = s->n;
+    const int ncomp = integrand_ncomp(integrand, n, d);
+    ABZ_REQUIRE(ncomp > 0, "unknown integrand id %d", integrand);
+    const bool swept = integrand == ABZ_F_DOS || integrand == ABZ_F_TRGLOC || integrand == ABZ_F_GLOC || integrand == ABZ_F_DOS_EIG;
+    ABZ_REQUIRE(!swept || sweeps, "sweep values required for integrand %d", integrand);
+    ABZ_REQUIRE(swept || n_sweep == 1, "integrand %d has no swept parameter: n_sweep must be 1", integrand);
+    abz_ctx* ctx = s->ctx;
+    ABZ_HIP(hipSetDevice(ctx->device));
+    const int ns_eff = syms ? nsyms : 1;
+    if (maxevals <= 0) maxevals = (int64_t)1 << 62;
+    double rtol, atol;
+    if (abstol < 0 && reltol < 0) {
+        rtol = std::sqrt(2.220446049250313e-16);
+        atol = 0.0;
+    } else {
+        rtol = reltol < 0 ? 0.0 : reltol;
+        atol = abstol < 0 ? 0.0 : abstol;
+    }
+    // rules of a Hermitian series keep the upper triangle of H(k): every built-in integrand reads those planes only
+    int want = integrand == ABZ_F_DOS_EIG ? ABZ_WANT_EIG : ABZ_WANT_H;
+    if ((want & ABZ_WANT_H) && s->hermitian && n <= 4) want |= ABZ_WANT_H_COMPACT;
+    const size_t ncs = (size_t)ncomp;
+    std::vector<double2> I1((size_t)n_sweep * ncs), I2((size_t)n_sweep * ncs), vals((size_t)n_sweep * ncs);
+    std::vector<double> sw((size_t)n_sweep);
+    std::vector<int> active((size_t)n_sweep);
+    for (int i = 0; i < n_sweep; ++i) active[(size_t)i] = i;
+    std::vector<int64_t> nev((size_t)n_sweep, 0);
+    // device staging: [2 grids][n_sweep] swept values | [2 grids][n_sweep][ncomp] sums
+    const size_t sw_bytes = sizeof(double) * (size_t)n_sweep, out_bytes = sizeof(double2) * (size_t)n_sweep * ncs;
+    if ((rc = s->auto_io.reserve(2 * (sw_bytes + out_bytes)))) return rc;
+    char* const io = static_cast<char*>(s->auto_io.p);
+    const bool mb = mbox_reserve(ctx) == ABZ_OK && 2 * (sw_bytes + out_bytes) <= ctx->mbox_cap;
+    std::vector<char> host_io(mb ? 0 : 2 * (sw_bytes + out_bytes));
+    char* const hio = mb ? static_cast<char*>(ctx->mbox) : host_io.data();
+    size_t free_b = 0, total_b = 0;
+    (void)hipMemGetInfo(&free_b, &total_b);
+
+    // Value of the rule of grid `npt` for the active solves.  `slot` 0 / 1: staging halves, so that the first two grids can be
+    // in flight together.  Rule-based grids leave their sums in HBM (`pending`), store-free ones return them on the host.
+    struct Pending {
+        bool on_device = false;
+        int nact = 0;
+    };
+    auto grid_value = [&](int npt, int gindex, int slot, const std::vector<int>& act, double2* host_vals, int64_t* nk_out, Pending* pend) -> int {
+        const int na = (int)act.size();
+        int64_t nk_full = 1;
+        for (int j = 0; j < d; ++j) nk_full *= npt;
+        double* const sw_h = reinterpret_cast<double*>(hio + (size_t)slot * sw_bytes);
+        for (int i = 0; i < na; ++i) sw_h[i] = swept ? sweeps[act[(size_t)i]] : 0.0;
+        bool have = false;
+        for (const SeriesRule& k : s->kept_rules)
+            have = have || (k.npt == npt && (k.want & want) == want && k.syms.size() == (syms ? (size_t)nsyms * d * d : 0) &&
+                            std::equal(k.syms.begin(), k.syms.end(), syms));
+        const size_t rbytes = rule_value_bytes(s, npt, nk_full, want);  // upper bound for symmetric rules
+        const bool fits = rbytes < free_b / 2;
+        const bool keep = gindex < keepmost && fits;
+        const bool sum_ok = !syms && (n > 4 ? gen_sum_supported(n, s->dims[0], npt, integrand, s->hermitian)
+                                            : eval_sum_supported(n, s->dims[0], npt, integrand, s->hermitian));
+        // a grid used once: on the fly when few values share it (the store-free kernel takes 8 per pass), when it would not
+        // fit, or above four bands (the panel kernels beat build + scan at any size)
+        if (!have && !keep && sum_ok && (na <= 8 || !fits || n > 4)) {
+            int rc2 = abz_ptr_sum(s, npt, 0, npt, integrand, params, nparams, sw_h, na, ns_eff, reinterpret_cast<double*>(host_vals));
+            if (rc2 == ABZ_OK) {
+                *nk_out = nk_full;
+                pend->on_device = false;
+                return ABZ_OK;
+            }
+            if (rc2 != ABZ_ERR_UNSUPPORTED) return rc2;
+        }
+        abz_rule* r = nullptr;
+        bool owned = false;
+        int rc2 = series_rule(s, npt, syms, nsyms, want, keep, &r, &owned);
+        if (rc2) return rc2;
+        *nk_out = r->nk;
+        double* const sw_d = reinterpret_cast<double*>(io + (size_t)slot * sw_bytes);
+        double* const out_d = reinterpret_cast<double*>(io + 2 * sw_bytes + (size_t)slot * out_bytes);
+        if (swept) {
+            if (mb) {
+                rc2 = hipMemcpyAsync(sw_d, sw_h, sizeof(double) * (size_t)na, hipMemcpyHostToDevice, ctx->stream) == hipSuccess ? ABZ_OK : ABZ_ERR_HIP;
+            } else {
+                rc2 = hipMemcpy(sw_d, sw_h, sizeof(double) * (size_t)na, hipMemcpyHostToDevice) == hipSuccess ? ABZ_OK : ABZ_ERR_HIP;
+            }
+            if (rc2) set_error("abz_autoptr_solve_many: upload of the swept values failed");
+        }
+        if (!rc2) rc2 = rule_reduce(r, integrand, params, nparams, sw_d, swept ? na : 1, ns_eff, out_d, true);
+        if (owned) {  // a rule for this grid only: its blocks go back to the allocator once the stream has drained
+            (void)hipStreamSynchronize(ctx->stream);
+            rule_free(r);
+        }
+        if (rc2) return rc2;
+        pend->on_device = true;
+        pend->nact = na;
+        return ABZ_OK;
+    };
+    // sums of the pending slots to the host: one copy + one synchronisation
+    auto fetch = [&](int first_slot, int nslots) -> int {
+        char* const src = io + 2 * sw_bytes + (size_t)first_slot * out_bytes;
+        char* const dst = hio + 2 * sw_bytes + (size_t)first_slot * out_bytes;
+        ABZ_HIP(hipMemcpyAsync(dst, src, (size_t)nslots * out_bytes, hipMemcpyDeviceToHost, ctx->stream));
+        ABZ_HIP(hipStreamSynchronize(ctx->stream));
+        return ABZ_OK;
+    };
+    auto host_out = [&](int slot) { return reinterpret_cast<const double2*>(hio + 2 * sw_bytes + (size_t)slot * out_bytes); };
+    auto norm_of = [&](const double2* v) {
+        double acc = 0.0;
+        for (size_t c = 0; c < ncs; ++c) acc += v[c].x * v[c].x + v[c].y * v[c].y;
+        return ncs == 1 ? std::hypot(v[0].x, v[0].y) : std::sqrt(acc);
+    };
+
+    // ---- the first two grids, in flight together when both are rule-based
+    int npt = n0;
+    Pending p0, p1;
+    int64_t nk0 = 0, nk1 = 0;
+    std::vector<double2> hv0((size_t)n_sweep * ncs), hv1((size_t)n_sweep * ncs);
+    if ((rc = grid_value(npt, 0, 0, active, hv0.data(), &nk0, &p0))) return rc;
+    npt += dn;
+    if ((rc = grid_value(npt, 1, 1, active, hv1.data(), &nk1, &p1))) return rc;
+    if (p0.on_device || p1.on_device) {
+        if ((rc = fetch(p0.on_device ? 0 : 1, (p0.on_device && p1.on_device) ? 2 : 1))) return rc;
+        if (p0.on_device) std::memcpy(hv0.data(), host_out(0), out_bytes);
+        if (p1.on_device) std::memcpy(hv1.data(), host_out(1), out_bytes);
+    }
+    for (int i = 0; i < n_sweep; ++i) {
+        for (size_t c = 0; c < ncs; ++c) {
+            const double2 a = hv0[(size_t)i * ncs + c], b = hv1[(size_t)i * ncs + c];
+            I1[(size_t)i * ncs + c] = make_double2(a.x * value_factor, a.y * value_factor);
+            I2[(size_t)i * ncs + c] = make_double2(b.x * value_factor, b.y * value_factor);
+        }
+        nev[(size_t)i] = nk0 + nk1;
+    }
+    int gindex = 1;
+    while (true) {
+        std::vector<int> next;
+        for (int i : active) {
+            double2 diff[ABZ_MAX_BANDS * ABZ_MAX_BANDS > 16 ? 16 : 16];
+            (void)diff;
+            double e2 = 0.0;
+            double2 dv0 = make_double2(0.0, 0.0);
+            for (size_t c = 0; c < ncs; ++c) {
+                const double dx = I2[(size_t)i * ncs + c].x - I1[(size_t)i * ncs + c].x;
+                const double dy = I2[(size_t)i * ncs + c].y - I1[(size_t)i * ncs + c].y;
+                if (c == 0) dv0 = make_double2(dx, dy);
+                e2 += dx * dx + dy * dy;
+            }
+            const double err = ncs == 1 ? std::hypot(dv0.x, dv0.y) : std::sqrt(e2);
+            const bool done = err <= std::max(atol, rtol * norm_of(&I2[(size_t)i * ncs])) || nev[(size_t)i] >= maxevals || !std::isfinite(err);
+            if (done) {
+                std::memcpy(out_reim + 2 * (size_t)i * ncs, &I2[(size_t)i * ncs], sizeof(double2) * ncs);
+                if (err_out) err_out[i] = err;
+                if (numevals_out) numevals_out[i] = nev[(size_t)i];
+                if (npt_out) npt_out[i] = npt;
+            } else {
+                next.push_back(i);
+            }
+        }
+        active.swap(next);
+        if (active.empty()) break;
+        npt += dn;
+        gindex += 1;
+        Pending pp;
+        int64_t nk = 0;
+        if ((rc = grid_value(npt, gindex, 0, active, vals.data(), &nk, &pp))) return rc;
+        if (pp.on_device) {
+            if ((rc = fetch(0, 1))) return rc;
+            std::memcpy(vals.data(), host_out(0), sizeof(double2) * active.size() * ncs);
+        }
+        for (size_t a = 0; a < active.size(); ++a) {
+            const int i = active[a];
+            for (size_t c = 0; c < ncs; ++c) {
+                I1[(size_t)i * ncs + c] = I2[(size_t)i * ncs + c];
+                I2[(size_t)i * ncs + c] = make_double2(vals[a * ncs + c].x * value_factor, vals[a * ncs + c].y * value_factor);
+            }
+            nev[(size_t)i] += nk;
+        }
+    }
+    return ABZ_OK;
+}
+
+int abz_autoptr_solve(abz_series* s, const int32_t* syms, int nsyms, int integrand, const double* params, int nparams, double sweep,
+                      int n0, int dn, double abstol, double reltol, int64_t maxevals, int keepmost, double value_factor,
+                      double* out_reim, double* err_out, int64_t* numevals_out, int32_t* npt_out) {
+    return abz_autoptr_solve_many(s, syms, nsyms, integrand, params, nparams, &sweep, 1, n0, dn, abstol, reltol, maxevals, keepmost,
+                                  value_factor, out_reim, err_out, numevals_out, npt_out);
 }
 
 int abz_rule_ggr(abz_rule* r, const double* E, int nE, double* out) {

@@ -1206,35 +1206,29 @@ int abz_iai_solve_many(abz_series* s, int lims_kind, const double* lim_a, const 
     drv.maxevals = maxevals > 0 ? maxevals : (int64_t)1 << 62;
     drv.max_batch = max_batch;
     {
-        const char* e = getenv("ABZ_IAI_SPECULATE");  // 0: one panel per integral per round (the round-1 driver)
-        drv.speculate = !(e && e[0] == '0');
+        drv.speculate = abz_switch(SW_IAI_SPECULATE) != 0;  // 0: one panel per integral per round (the round-1 driver)
         drv.ex_fn = s->ex_fn;
         drv.ex_user = s->ex_user;
         drv.ex_rank = s->ex_rank;
         drv.ex_world = s->ex_world;
-        const char* ht = getenv("ABZ_HOST_THREADS");
         const int hw = (int)std::thread::hardware_concurrency();
-        int nth = ht ? atoi(ht) : 8;
+        int nth = abz_switch(SW_HOST_THREADS);
         if (hw > 0) nth = std::min(nth, std::max(1, hw / 2));
         if (nth > 1 && n_sweep >= 8) drv.pool.reset(new HostPool(nth));  // single solves stay serial: their rounds are small
-        const char* st = getenv("ABZ_IAI_STATS");
-        drv.stats = st && st[0] == '1';
-        const char* m = getenv("ABZ_IAI_POOL_MB");
-        if (m && atoll(m) > 0) drv.pool_cap_bytes = (int64_t)atoll(m) << 20;
+        drv.stats = abz_switch(SW_IAI_STATS) == 1;
+        const int pool_mb = abz_switch(SW_IAI_POOL_MB);
+        if (pool_mb > 0) drv.pool_cap_bytes = (int64_t)pool_mb << 20;
     }
     {
-        const char* e = getenv("ABZ_IAI_DEVICE_INNER");  // 0 forces the host loop at every level
-        // n > 4: the workgroup-per-integral kernel (coefficient set in LDS) runs by default where it
-        // applies; the older wave-per-integral kernel is slower than the host-driven loop at 16 bands
-        // and stays opt-in (ABZ_IAI_DEVICE_INNER=2)
-        const bool ok = s->n > 4 ? (gen_inner_panel_supported(s->n, s->dims[0], integrand) ||
-                                    (gen_inner_supported(s->n, s->dims[0], integrand) && e && e[0] == '2'))
+        // n > 4: the workgroup-per-integral kernel (coefficient set in LDS); ABZ_IAI_DEVICE_INNER=0 forces the host loop
+        // at every level
+        const bool ok = s->n > 4 ? gen_inner_panel_supported(s->n, s->dims[0], integrand)
                                  : inner_adaptive_supported(s->n, s->dims[0], integrand);
-        drv.device_inner = max_batch <= 0 && s->d >= 2 && ok && !(e && e[0] == '0');
+        drv.device_inner = max_batch <= 0 && s->d >= 2 && ok && abz_switch(SW_IAI_DEVICE_INNER) != 0;
     }
     {
-        const char* e = getenv("ABZ_IAI_PACKED");  // 0: the full coefficient rows (per call: tests compare both)
-        drv.pk = !(e && e[0] == '0') && s->n <= 4 && s->hermitian && (s->dims[0] & 1) && s->first[0] == -(s->dims[0] - 1) / 2;
+        // ABZ_IAI_PACKED=0: the full coefficient rows (per call: tests compare both)
+        drv.pk = abz_switch(SW_IAI_PACKED) != 0 && s->n <= 4 && s->hermitian && (s->dims[0] & 1) && s->first[0] == -(s->dims[0] - 1) / 2;
         if (drv.pk) {
             int rcp = series_ensure_packed(s);
             if (rcp) return rcp;

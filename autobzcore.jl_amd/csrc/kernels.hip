@@ -261,7 +261,7 @@ int launch_contract_grid(abz_ctx* ctx, const double2* src, int64_t src_slot_elem
     ProfScope ps(ctx, ABZ_K_CONTRACT);
     const int64_t gx = cdiv(L, 128);
     // enough blocks to fill the chip, at least ~4 grid indices per thread to amortise the loads
-    static const int target_blocks = [] { const char* e = getenv("ABZ_CONTRACT_BLOCKS"); return e ? atoi(e) : 4096; }();
+    const int target_blocks = 4096;
     int64_t nsplit = std::max<int64_t>(1, std::min<int64_t>(cdiv(gcnt, 4), cdiv(target_blocks, gx * nparents)));
     const int chunk = (int)cdiv(gcnt, nsplit);
     nsplit = cdiv(gcnt, chunk);
@@ -269,8 +269,7 @@ int launch_contract_grid(abz_ctx* ctx, const double2* src, int64_t src_slot_elem
         set_error("contract_grid: grid too large");
         return ABZ_ERR_UNSUPPORTED;
     }
-    static const bool scalar_ok = [] { const char* e = getenv("ABZ_CONTRACT_SCALAR"); return !(e && e[0] == '0'); }();
-    if (phs_table && !deriv && scalar_ok) {
+    if (phs_table && !deriv) {
 #define CS(MM)                                                                                                         \
     case MM:                                                                                                           \
         hipLaunchKernelGGL(contract_grid_s_kernel<MM>, dim3((unsigned)gx, (unsigned)nparents, (unsigned)nsplit), dim3(128), 0, \
@@ -1553,7 +1552,7 @@ static int launch_dos3(abz_ctx* ctx, const ReduceSpec& rs, const ReduceArgs& a0,
     constexpr int kt = 8;
     int rows = 1;
     {
-        const int force = [] { const char* e = getenv("ABZ_REDUCE_ROWS"); return e ? atoi(e) : 0; }();  // per call (tests, tools)
+        const int force = abz_switch(SW_REDUCE_ROWS);  // per call (tests)
         const int max_rows = (int)cdiv(rs.n_sweep, 16);
         const int want = force > 0 ? force : std::max((int)cdiv(1024, cdiv(rs.nk, 256 * kt)), rs.n_sweep >= 192 ? 2 : 1);
         rows = std::max(1, std::min(want, max_rows));
@@ -1832,7 +1831,6 @@ int launch_eval_sum(abz_ctx* ctx, const SumSpec& ss, double* out_reim) {
     a.deriv = 0;
     a.herm = 1;
     a.nt = 0;
-    a.padw = 1;
     a.inv_period = 1.0;
     int kpl = 2;
     {
@@ -1934,7 +1932,7 @@ static int launch_reduce_h(abz_ctx* ctx, const ReduceSpec& rs, const ReduceArgs&
     using RS = ReduceShape<NC>;
     int rows = 1;
     {
-        static const int force = [] { const char* e = getenv("ABZ_REDUCE_ROWS"); return e ? atoi(e) : 0; }();
+        const int force = abz_switch(SW_REDUCE_ROWS);
         const int max_rows = (int)cdiv(rs.n_sweep, 16);  // at least 16 swept values per row: the node set-up stays < 15 %
         const int want = force > 0 ? force : (int)cdiv(1024, nblocks);
         rows = std::max(1, std::min(want, max_rows));
@@ -1960,8 +1958,7 @@ template <int N, int FID>
 static int launch_reduce_t(abz_ctx* ctx, const ReduceSpec& rs, const ReduceArgs& a) {
     constexpr bool canH = ((N == 2 || N == 3 || N == 4) && (FID == ABZ_F_DOS || FID == ABZ_F_TRGLOC)) || ((N == 3 || N == 4) && FID == ABZ_F_GLOC);
     if constexpr (N == 3 && (FID == ABZ_F_DOS || FID == ABZ_F_DOS_EIG)) {  // the sweep kernel of 3-band DOS scans
-        const bool off = [] { const char* e = getenv("ABZ_DOS3_SCAN"); return e && e[0] == '0'; }();  // per call: tests compare both
-        if (!off && (FID == ABZ_F_DOS_EIG || rs.herm)) return launch_dos3(ctx, rs, a, FID == ABZ_F_DOS ? 0 : 1);
+        if (abz_switch(SW_DOS3_SCAN) && (FID == ABZ_F_DOS_EIG || rs.herm)) return launch_dos3(ctx, rs, a, FID == ABZ_F_DOS ? 0 : 1);
     }
     if (canH && rs.herm) return launch_reduce_h<N, FID, canH>(ctx, rs, a);
     return launch_reduce_h<N, FID, false>(ctx, rs, a);
@@ -2321,9 +2318,7 @@ struct InnerArgs {
     int64_t nint, maxevals;
     int M, first, d, ncomp, has_rtol;
     int pair;  // scalar integrands: the two-lane adaptive step (inner_adapt.h)
-    int poly;  // sincospi_poly (device_math.h) for the node phases instead of the library routine
     int pk;    // the level-1 sets are packed Hermitian rows (packed_herm.h): folded series, no seed phase
-    double sc[16];
     double inv_period, sweep, rtol_user;
     double p[4];
     double2* I_out;
@@ -2351,7 +2346,7 @@ __global__ __launch_bounds__(256) void inner_adaptive_kernel(InnerArgs a) {
     double* ctl = reinterpret_cast<double*>(heap + MS);
     double* heapE = ctl + 8;  // adapt_step_pair's mirror of seg_E[heap[.]]
     // scalar integrands: lanes 0 and 1 of the half-wave share the serial step (two GK rules side by side, one LDS round
-    // trip per heap level); a.pair = 0 (ABZ_INNER_PAIR=0): the one-lane step, same numbers
+    // trip per heap level); a.pair = 0 (ABZ_ADAPT_PAIR=0): the one-lane step, same numbers
     const bool pair = NC == 1 && a.pair;
     const int64_t gstride = (int64_t)gridDim.x * 8;
     for (int64_t q0 = (int64_t)blockIdx.x * 8; q0 < a.nint; q0 += gstride) {
@@ -2394,13 +2389,8 @@ __global__ __launch_bounds__(256) void inner_adaptive_kernel(InnerArgs a) {
                         sincospi(2.0 * xx, &zi, &zr);
                         series_point_pk<N>((const double2*)cl, (a.M - 1) / 2, zr, zi, H);
                     } else {
-                        if (a.poly) {
-                            sincospi_poly(a.sc, 2.0 * xx, zi, zr);
-                            sincospi_poly(a.sc, 2.0 * ((double)a.first * xx), wi, wr);
-                        } else {
-                            sincospi(2.0 * xx, &zi, &zr);
-                            sincospi(2.0 * ((double)a.first * xx), &wi, &wr);
-                        }
+                        sincospi(2.0 * xx, &zi, &zr);
+                        sincospi(2.0 * ((double)a.first * xx), &wi, &wr);
                         series_lane_lds<N, HERM>(cl, a.M, zr, zi, wr, wi, H);
                     }
                     double e[N];
@@ -2491,11 +2481,9 @@ int launch_inner_adaptive(abz_ctx* ctx, const InnerSpec& is) {
     a.d = is.d;
     a.ncomp = ncomp;
     a.has_rtol = is.has_rtol ? 1 : 0;
-    a.pair = [] { const char* e = getenv("ABZ_INNER_PAIR"); return !(e && e[0] == '0'); }() ? 1 : 0;  // per call: tests compare both
-    // polynomial sincospi: measured 31.3 against 32.0 ms on the SVO full-BZ solve (the phases are not what bounds a round),
-    // so the library routine stays the default; ABZ_INNER_SINCOS=1 switches (recorded experiment)
-    a.poly = [] { const char* e = getenv("ABZ_INNER_SINCOS"); return e && e[0] == '1'; }() ? 1 : 0;  // per call
-    for (int i = 0; i < 16; ++i) a.sc[i] = kSinCosPiCoef[i];
+    a.pair = abz_switch(SW_ADAPT_PAIR) ? 1 : 0;  // per call: tests compare both
+    // (a polynomial sincospi for the node phases measured 31.3 against 32.0 ms on the SVO full-BZ solve: the phases are
+    // not what bounds a round; the library routine stays)
     a.pk = (is.packed && is.herm) ? 1 : 0;
     a.inv_period = 1.0 / is.period;
     a.sweep = is.sweep;

@@ -702,170 +702,9 @@ __device__ __forceinline__ void panel_inverse_row(const double2* coef, int n, in
 }
 
 
-// ------------------------------------------------------------------------------------------
-// "Duo" layout of the panel kernels: a node is owned by LPN = NP/2 lanes, lane q holding rows q and q + LPN of the
-// zero-padded NP x NP matrix.  The Gauss-Jordan pivot row is broadcast ONCE per pivot for the two rows it updates in
-// every lane, so the cross-lane traffic per node halves: with one row per lane the kernels sat at ~57 % VALU and ~57 %
-// LDS-crossbar occupancy at the same time (profiles/r02a_bands16_pmc_summary.json: 0.48 LDS instructions -- mostly
-// ds_swizzle -- per VALU instruction), i.e. bounded by the sum of the two; f64 MFMA does not help here: it issues on
-// the same f64 units as v_fma_f64 (tools/micro/valutest.hip: 16 MFMA 16x16x4 + 64 FMA take the SUM of their times).
-// Registers: 4 x NP doubles for the rows + the travelling pivot row chunk: 2 waves/SIMD at NP = 16.
-// ------------------------------------------------------------------------------------------
-template <int NP>
-__device__ __forceinline__ void duo_series_rows(const double2* coef, int M, double zr, double zi, double pr, double pi, int q,
-                                                double (&a0r)[NP], double (&a0i)[NP], double (&a1r)[NP], double (&a1i)[NP]) {
-    constexpr int LPN = NP / 2;
-#pragma unroll
-    for (int j = 0; j < NP; ++j) {
-        a0r[j] = 0.0;
-        a0i[j] = 0.0;
-        a1r[j] = 0.0;
-        a1i[j] = 0.0;
-    }
-    for (int m = 0; m < M; ++m) {
-        const double2* __restrict__ cm = coef + (size_t)m * (NP * NP) + q;
-#pragma unroll
-        for (int j0 = 0; j0 < NP; j0 += 4) {
-            double2 c[8];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                c[2 * j] = cm[NP * (j0 + j)];
-                c[2 * j + 1] = cm[NP * (j0 + j) + LPN];
-            }
-            pin8(c);  // eight reads in flight, one wait
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {  // A = z I - H: accumulate -H
-                a0r[j0 + j] = fma(-c[2 * j].x, pr, a0r[j0 + j]);
-                a0r[j0 + j] = fma(c[2 * j].y, pi, a0r[j0 + j]);
-                a0i[j0 + j] = fma(-c[2 * j].x, pi, a0i[j0 + j]);
-                a0i[j0 + j] = fma(-c[2 * j].y, pr, a0i[j0 + j]);
-                a1r[j0 + j] = fma(-c[2 * j + 1].x, pr, a1r[j0 + j]);
-                a1r[j0 + j] = fma(c[2 * j + 1].y, pi, a1r[j0 + j]);
-                a1i[j0 + j] = fma(-c[2 * j + 1].x, pi, a1i[j0 + j]);
-                a1i[j0 + j] = fma(-c[2 * j + 1].y, pr, a1i[j0 + j]);
-            }
-        }
-        const double nr = pr * zr - pi * zi, ni = pr * zi + pi * zr;
-        pr = nr;
-        pi = ni;
-    }
-}
-
-// rows q and q + LPN of A = (sw + i eta) I - H from the rows of -H; padding rows (>= n) are identity rows
-template <int NP>
-__device__ __forceinline__ void duo_shift_rows(int n, double sw, double eta, int q, double (&a0r)[NP], double (&a0i)[NP],
-                                               double (&a1r)[NP], double (&a1i)[NP]) {
-    constexpr int LPN = NP / 2;
-    const double d0r = (q < n) ? sw : 1.0, d0i = (q < n) ? eta : 0.0;
-    const double d1r = (q + LPN < n) ? sw : 1.0, d1i = (q + LPN < n) ? eta : 0.0;
-#pragma unroll
-    for (int j = 0; j < LPN; ++j) {
-        a0r[j] += (j == q) ? d0r : 0.0;
-        a0i[j] += (j == q) ? d0i : 0.0;
-        a1r[j + LPN] += (j == q) ? d1r : 0.0;
-        a1i[j + LPN] += (j == q) ? d1i : 0.0;
-    }
-}
-
-// one Gauss-Jordan pivot (column C): the pivot row is row C / LPN of lane C % LPN; it travels CH columns at a time
-// (the chunk that holds the pivot first)
-template <int NP, int C>
-__device__ __forceinline__ void duo_pivot(int q, double (&a0r)[NP], double (&a0i)[NP], double (&a1r)[NP], double (&a1i)[NP]) {
-    constexpr int LPN = NP / 2, OWN = C % LPN, WHICH = C / LPN;
-    constexpr int CH = NP >= 16 ? 4 : 8;
-    constexpr int NB = NP / CH;
-    double g0r = 0.0, g0i = 0.0, g1r = 0.0, g1i = 0.0, ipr = 0.0, ipi = 0.0;
-#pragma unroll
-    for (int b = 0; b < NB; ++b) {
-        const int j0 = CH * ((C / CH + b) % NB);
-        double ur[CH], ui[CH];
-#pragma unroll
-        for (int j = 0; j < CH; ++j) {
-            ur[j] = group_bcast<LPN, OWN>(WHICH ? a1r[j0 + j] : a0r[j0 + j]);
-            ui[j] = group_bcast<LPN, OWN>(WHICH ? a1i[j0 + j] : a0i[j0 + j]);
-        }
-        if (b == 0) {
-            const double pr = ur[C % CH], pi = ui[C % CH];
-            const double inv = rcp_nr(pr * pr + pi * pi);
-            ipr = pr * inv;
-            ipi = -pi * inv;  // 1 / pivot
-            // g = -f / p for the other rows, 1/p - 1 for the pivot row itself
-            g0r = -(a0r[C] * ipr - a0i[C] * ipi);
-            g0i = -(a0r[C] * ipi + a0i[C] * ipr);
-            g1r = -(a1r[C] * ipr - a1i[C] * ipi);
-            g1i = -(a1r[C] * ipi + a1i[C] * ipr);
-            const bool mine = q == OWN;
-            if (WHICH == 0) {
-                g0r = mine ? ipr - 1.0 : g0r;
-                g0i = mine ? ipi : g0i;
-            } else {
-                g1r = mine ? ipr - 1.0 : g1r;
-                g1i = mine ? ipi : g1i;
-            }
-        }
-#pragma unroll
-        for (int j = 0; j < CH; ++j) {
-            if (j0 + j != C) {
-                a0r[j0 + j] = fma(g0r, ur[j], a0r[j0 + j]);
-                a0r[j0 + j] = fma(-g0i, ui[j], a0r[j0 + j]);
-                a0i[j0 + j] = fma(g0r, ui[j], a0i[j0 + j]);
-                a0i[j0 + j] = fma(g0i, ur[j], a0i[j0 + j]);
-                a1r[j0 + j] = fma(g1r, ur[j], a1r[j0 + j]);
-                a1r[j0 + j] = fma(-g1i, ui[j], a1r[j0 + j]);
-                a1i[j0 + j] = fma(g1r, ui[j], a1i[j0 + j]);
-                a1i[j0 + j] = fma(g1i, ur[j], a1i[j0 + j]);
-            }
-        }
-    }
-    const bool mine = q == OWN;
-    a0r[C] = (mine && WHICH == 0) ? ipr : g0r;
-    a0i[C] = (mine && WHICH == 0) ? ipi : g0i;
-    a1r[C] = (mine && WHICH == 1) ? ipr : g1r;
-    a1i[C] = (mine && WHICH == 1) ? ipi : g1i;
-}
-
-template <int NP, int... C>
-__device__ __forceinline__ void duo_pivots(int q, double (&a0r)[NP], double (&a0i)[NP], double (&a1r)[NP], double (&a1i)[NP],
-                                           std::integer_sequence<int, C...>) {
-    (duo_pivot<NP, C>(q, a0r, a0i, a1r, a1i), ...);
-}
-
-// trace of the inverse over the real n x n block (sum over the node's LPN lanes; every lane gets it)
-template <int NP>
-__device__ __forceinline__ void duo_trace(const double (&a0r)[NP], const double (&a0i)[NP], const double (&a1r)[NP],
-                                          const double (&a1i)[NP], int n, int q, double& tr, double& ti) {
-    constexpr int LPN = NP / 2;
-    tr = 0.0;
-    ti = 0.0;
-    // (plain selects: nested branches on the lane-dependent row index here cost the kernel 60 registers)
-    const double m0 = q < n ? 1.0 : 0.0, m1 = q + LPN < n ? 1.0 : 0.0;
-#pragma unroll
-    for (int j = 0; j < LPN; ++j) {
-        tr += (j == q) ? m0 * a0r[j] + m1 * a1r[j + LPN] : 0.0;
-        ti += (j == q) ? m0 * a0i[j] + m1 * a1i[j + LPN] : 0.0;
-    }
-#pragma unroll
-    for (int off = LPN / 2; off > 0; off >>= 1) {
-        tr += __shfl_xor(tr, off, 64);
-        ti += __shfl_xor(ti, off, 64);
-    }
-}
-
-// tr inv((sw + i eta) I - H(x)) for the node owned by this lane's LPN-lane group (zero-padded staged set).
-// Not inlined: as part of the adaptive kernel's body the register allocator spilled ~260 VGPRs at the 256-register
-// budget of 2 waves/SIMD, on its own the function needs ~200.
-template <int NP>
-__device__ __attribute__((noinline)) void duo_inverse_trace(const double2* coef, int n, int M, int first, double xx, double sw,
-                                                            double eta, int q, double& tr, double& ti) {
-    double zr, zi, pr, pi;
-    sincospi(2.0 * xx, &zi, &zr);
-    sincospi(2.0 * ((double)first * xx), &pi, &pr);
-    double a0r[NP], a0i[NP], a1r[NP], a1i[NP];
-    duo_series_rows<NP>(coef, M, zr, zi, pr, pi, q, a0r, a0i, a1r, a1i);
-    duo_shift_rows<NP>(n, sw, eta, q, a0r, a0i, a1r, a1i);
-    duo_pivots<NP>(q, a0r, a0i, a1r, a1i, std::make_integer_sequence<int, NP>());
-    duo_trace<NP>(a0r, a0i, a1r, a1i, n, q, tr, ti);
-}
+// (A "duo" layout -- 8 lanes per node, two rows per lane, one pivot broadcast for both -- was built and measured in round 2:
+// 255 against 420 M nodes/s on config 5; at 256 registers it runs 2 waves/SIMD, which no longer hide the broadcast -> FMA
+// latency of the pivot chain.  DESIGN.md section 4.)
 
 // stage one coefficient set [M][n*n] into LDS, zero-padded to [M][NP*NP] when PAD
 template <int NP, bool PAD>
@@ -1376,7 +1215,6 @@ struct GenEigArgs {
     const int64_t* run_start = nullptr;  // irregular lists: line l owns nodes [run_start[l], run_start[l + 1]) with grid indices gi
     const int32_t* gi = nullptr;
     int n, M, first, npt;
-    int tridiag = 1;  // eigenvalues only: Householder + Sturm bisection (0: the Jacobi, ABZ_GEN_EIG_JACOBI=1)
 };
 
 
@@ -1648,8 +1486,7 @@ __global__ __launch_bounds__(256) void gen_grid_sum_tri_kernel(GenSumTriArgs a) 
 
 // sweeps of at least 3 values on 5..16 bands take the tridiagonal route
 static bool gen_sum_tri_wanted(const SumSpec& ss) {
-    const bool off = [] { const char* e = getenv("ABZ_GEN_SUM_TRI"); return e && e[0] == '0'; }();  // per call: tests switch it
-    return !off && ss.n > 4 && ss.n <= 16 && ss.n_sweep >= 3;
+    return abz_switch(SW_GEN_SUM_TRI) && ss.n > 4 && ss.n <= 16 && ss.n_sweep >= 3;
 }
 
 static int launch_gen_sum_tri(abz_ctx* ctx, const SumSpec& ss, double* out_reim) {
@@ -1880,8 +1717,7 @@ __global__ __launch_bounds__(128) void gen_velocity_rows_kernel(PlaneView Uv, Pl
 }
 
 static bool launch_gen_velocity_rows(abz_ctx* ctx, int n, PlaneView U, PlaneView dH, PlaneView Vj, int64_t nk) {
-    const bool off = [] { const char* e = getenv("ABZ_GEN_VEL_ROWS"); return e && e[0] == '0'; }();  // per call
-    if (off || n <= 4 || n > 16) return false;
+    if (n <= 4 || n > 16) return false;
     if (n <= 8)
         hipLaunchKernelGGL(gen_velocity_rows_kernel<8>, dim3((unsigned)cdiv2(nk, 16)), dim3(128), sizeof(double2) * 2 * 16 * 64, ctx->stream, U, dH,
                            Vj, nk, n);
@@ -1984,12 +1820,10 @@ __global__ __launch_bounds__(256, (TRI && !VEC) ? 2 : 1) void gen_grid_eig_kerne
 
 // full-grid rule values (and eigenvalues, Hermitian series) for 5..16 bands
 static bool gen_grid_eig_supported(const GenSpec& gs, int* np_out, size_t* lds_out, bool* pad_out) {
-    static const bool off = [] { const char* e = getenv("ABZ_GEN_ROWEIG"); return e && e[0] == '0'; }();
     const bool runs = !gs.grid && gs.run_start && gs.gi && !gs.x && gs.nruns > 0;  // symmetric rules: runs of grid-index nodes
-    if (off || !(gs.grid || runs) || gs.deriv || gs.values || gs.Haos || gs.Eaos || !(gs.Eplanes.base || gs.Hplanes.base)) return false;
+    if (!(gs.grid || runs) || gs.deriv || gs.values || gs.Haos || gs.Eaos || !(gs.Eplanes.base || gs.Hplanes.base)) return false;
     if (gs.Eplanes.base && !gs.herm) return false;  // the Jacobi works on full rows: H(k) must be Hermitian to rounding
-    static const bool vec_on = [] { const char* e = getenv("ABZ_GEN_ROWEIG_VEC"); return e && e[0] == '1'; }();
-    (void)vec_on;  // 9..16 bands with eigenvectors: inverse iteration (needs the zero-padded layout, checked below)
+    // 9..16 bands with eigenvectors: inverse iteration (needs the zero-padded layout, checked below)
     if (gs.n <= 4 || gs.n > 16 || gs.npt < 1 || gs.npt >= 65536) return false;
     const int np = gs.n <= 8 ? 8 : 16;
     size_t lds = sizeof(double2) * (size_t)gs.M * np * np;
@@ -2016,41 +1850,28 @@ static int launch_gen_grid_eig(abz_ctx* ctx, const GenSpec& gs, int np, size_t l
     a.M = gs.M;
     a.first = gs.first;
     a.npt = gs.npt;
-    {
-        static const bool jac = [] { const char* e = getenv("ABZ_GEN_EIG_JACOBI"); return e && e[0] == '1'; }();
-        a.tridiag = jac ? 0 : 1;
-    }
     const int64_t blocks = std::min<int64_t>(a.nlines, 256 * 4);
     const bool vec = gs.Uplanes.base != nullptr;
-    const bool jacobi_vec = [] { const char* e = getenv("ABZ_GEN_ROWEIG_VEC"); return e && e[0] == '1'; }();  // 16 rows: the spilling Jacobi (experiment)
     ProfScope ps(ctx, ABZ_K_EVAL);
+    // eigenvalues only: Householder + Sturm bisection (TRI); with eigenvectors: the parallel-order Jacobi up to 8 bands,
+    // inverse iteration on the zero-padded layout for 9...16 (the 16-row Jacobi with accumulated rotations spilled 4.6 KB)
 #define ABZ_GE3(NPV, PV, VV, TV)                                                                                              \
-    ABZ_HIP(hipFuncSetAttribute((const void*)gen_grid_eig_kernel<NPV, PV, VV, TV>, hipFuncAttributeMaxDynamicSharedMemorySize, \
-                                (int)lds));                                                                                   \
-    hipLaunchKernelGGL((gen_grid_eig_kernel<NPV, PV, VV, TV>), dim3((unsigned)blocks), dim3(256), lds, ctx->stream, a);
-#define ABZ_GE2(NPV, PV) \
-    if (vec && NPV == 16 && PV && !jacobi_vec) { \
-        ABZ_GE3(NPV, true, true, true) \
-    } else if (vec) {    \
-        ABZ_GE3(NPV, PV, true, false) \
-    } else if (a.tridiag) { \
-        ABZ_GE3(NPV, PV, false, true) \
-    } else {             \
-        ABZ_GE3(NPV, PV, false, false) \
+    {                                                                                                                         \
+        ABZ_HIP(hipFuncSetAttribute((const void*)gen_grid_eig_kernel<NPV, PV, VV, TV>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                    (int)lds));                                                                               \
+        hipLaunchKernelGGL((gen_grid_eig_kernel<NPV, PV, VV, TV>), dim3((unsigned)blocks), dim3(256), lds, ctx->stream, a);   \
     }
-#define ABZ_GE(NPV) \
-    if (pad) {      \
-        ABZ_GE2(NPV, true) \
-    } else {        \
-        ABZ_GE2(NPV, false) \
-    }
-    if (np == 8) {
-        ABZ_GE(8)
+    if (!vec) {
+        if (np == 8 && pad) ABZ_GE3(8, true, false, true)
+        else if (np == 8) ABZ_GE3(8, false, false, true)
+        else if (pad) ABZ_GE3(16, true, false, true)
+        else ABZ_GE3(16, false, false, true)
+    } else if (np == 8) {
+        if (pad) ABZ_GE3(8, true, true, false)
+        else ABZ_GE3(8, false, true, false)
     } else {
-        ABZ_GE(16)
+        ABZ_GE3(16, true, true, true)  // gen_grid_eig_supported: pad is set
     }
-#undef ABZ_GE
-#undef ABZ_GE2
 #undef ABZ_GE3
     ABZ_HIP(hipGetLastError());
     return ABZ_OK;
@@ -2128,8 +1949,7 @@ int launch_gen_nodes(abz_ctx* ctx, const GenSpec& gs) {
         int np = 0;
         size_t plds = 0;
         bool pad = false;
-        static const bool off = [] { const char* e = getenv("ABZ_GEN_PANEL"); return e && e[0] == '0'; }();
-        if (!off && gen_panel_supported(gs, &np, &plds, &pad)) {
+        if (gen_panel_supported(gs, &np, &plds, &pad)) {
             const int64_t blocks = std::min<int64_t>(gs.nnodes / 15, 256 * 8);
             ProfScope ps(ctx, ABZ_K_EVAL);
 #define ABZ_PANEL2(NPV, PV)                                                                                                  \
@@ -2523,8 +2343,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 4))) voi
 }
 
 static bool gen_rows_reduce_supported(const ReduceSpec& rs) {
-    static const bool off = [] { const char* e = getenv("ABZ_GEN_ROWREDUCE"); return e && e[0] == '0'; }();
-    return !off && rs.herm && rs.H.base && rs.n > 4 && rs.n <= 16 &&
+    return rs.herm && rs.H.base && rs.n > 4 && rs.n <= 16 &&
            (rs.integrand == ABZ_F_DOS || rs.integrand == ABZ_F_TRGLOC || rs.integrand == ABZ_F_GLOC);
 }
 
@@ -2589,8 +2408,7 @@ static int launch_gen_rows_reduce(abz_ctx* ctx, const ReduceSpec& rs, double* ou
     double2* outd = ctx->scratch[2].as<double2>();
     {
         ProfScope ps(ctx, ABZ_K_REDUCE);
-        const bool tri_off = [] { const char* e = getenv("ABZ_GEN_SUM_TRI"); return e && e[0] == '0'; }();
-        const bool tri = !tri_off && rs.n_sweep >= 3;  // sweeps: tridiagonalise once, p'/p per swept value
+        const bool tri = abz_switch(SW_GEN_SUM_TRI) && rs.n_sweep >= 3;  // sweeps: tridiagonalise once, p'/p per swept value
         if (tri && np == 8)
             hipLaunchKernelGGL(gen_rows_reduce_tri_kernel<8>, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, a);
         else if (tri)
@@ -2761,9 +2579,9 @@ int launch_gen_reduce(abz_ctx* ctx, const ReduceSpec& rs, double* out_reim) {
 }
 
 // ------------------------------------------------------------------------------------------
-// IAI innermost level on the device for n > 4: ONE WAVEFRONT per 1-D integral; the 15 / 30 nodes of a
-// round are evaluated one after the other by the whole wave (series value into LDS, Gauss-Jordan /
-// Jacobi as above), then lane 0 runs the shared adapt_step.
+// IAI innermost level on the device for n > 4: one WORKGROUP per 1-D integral (gen_inner_panel_kernel).  (The first
+// version, one wavefront per integral with the node's matrices in LDS, was slower than the host-driven loop at 16
+// bands and is gone.)
 // ------------------------------------------------------------------------------------------
 struct GenInnerArgs {
     const double2* src;
@@ -2781,113 +2599,20 @@ struct GenInnerArgs {
     double* E_out;
     int64_t* nev_out;
     int* status_out;
-    int pair;       // adapt_step_pair instead of adapt_step (ABZ_IPANEL_PAIR=0: the one-lane step)
+    int pair;       // adapt_step_pair instead of adapt_step (ABZ_ADAPT_PAIR=0: the one-lane step)
     double sc[16];  // sincospi_poly's coefficients (kernel arguments stay in scalar registers / the scalar cache)
 };
 
 
-__host__ __device__ inline size_t gen_inner_wave_doubles(int n, int M, int ncomp) {
-    // H, W, X (complex n*n each), ph (complex M), ev (n) rounded to even, then the adapt group
-    return (size_t)2 * (3 * n * n + M) + (size_t)((n + 1) / 2) * 2 + (size_t)inner_group_doubles(ncomp);
-}
-
-__global__ __launch_bounds__(256) void gen_inner_adaptive_kernel(GenInnerArgs a, int waves_per_block) {
-    extern __shared__ double lds_gi[];
-    constexpr int MS = ABZ_INNER_MAXSEG;
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    if (wave >= waves_per_block) return;
-    const int n = a.n, nn = n * n, nc = a.ncomp;
-    double* base = lds_gi + (size_t)wave * gen_inner_wave_doubles(n, a.M, nc);
-    double2* H = reinterpret_cast<double2*>(base);
-    double2* W = H + nn;
-    double2* X = W + nn;
-    double2* ph = X + nn;
-    double* ev = reinterpret_cast<double*>(ph + a.M);
-    double* g = ev + ((n + 1) / 2) * 2;
-    double* seg_a = g;
-    double* seg_b = seg_a + MS;
-    double* seg_E = seg_b + MS;
-    gkc* seg_I = reinterpret_cast<gkc*>(seg_E + MS);
-    gkc* vals = seg_I + (size_t)MS * nc;
-    int* heap = reinterpret_cast<int*>(vals + (size_t)30 * nc);
-    double* ctl = reinterpret_cast<double*>(heap + MS);
-    GenArgs ga;  // the fields gen_integrand reads
-    ga.n = n;
-    ga.integrand = a.integrand;
-    for (int i = 0; i < 4; ++i) ga.p[i] = a.p[i];
-    const int64_t wstride = (int64_t)gridDim.x * waves_per_block;
-    for (int64_t q = (int64_t)blockIdx.x * waves_per_block + wave; q < a.nint; q += wstride) {
-        AdaptState st;
-        if (lane == 0) {
-            adapt_init(st, a.atol[q], a.has_rtol != 0, a.rtol_user, a.lo[q], a.hi[q], ctl);
-            ctl[5] = 0.0;  // done flag
-        }
-        const double2* __restrict__ c1 = a.src + a.slot[q] * ((int64_t)a.M * nn);
-        const double swq = a.sweep_arr ? a.sweep_arr[q] : a.sweep;
-        while (true) {
-            wave_sync();
-            if (ctl[5] != 0.0) break;
-            const int np = (int)ctl[0];
-            for (int t = 0; t < 15 * np; ++t) {
-                const int pnl = t / 15, i = t - 15 * pnl;
-                const double x = gk15_node(ctl[1 + 2 * pnl], ctl[2 + 2 * pnl], i);
-                const double xx = x * a.inv_period;
-                double zr, zi, wr, wi;
-                sincospi(2.0 * xx, &zi, &zr);
-                sincospi(2.0 * ((double)a.first * xx), &wi, &wr);
-                {
-                    double pr = wr, pi = wi;
-                    for (int m = 0; m < a.M; ++m) {
-                        if (lane == (m & 63)) ph[m] = make_double2(pr, pi);
-                        const double nr = pr * zr - pi * zi, ni = pr * zi + pi * zr;
-                        pr = nr;
-                        pi = ni;
-                    }
-                }
-                wave_sync();
-                for (int e = lane; e < nn; e += 64) {
-                    double hr = 0.0, hi = 0.0;
-                    for (int m = 0; m < a.M; ++m) {
-                        const double2 c = c1[(int64_t)m * nn + e];
-                        const double2 qq = ph[m];
-                        hr = fma(c.x, qq.x, hr);
-                        hr = fma(-c.y, qq.y, hr);
-                        hi = fma(c.x, qq.y, hi);
-                        hi = fma(c.y, qq.x, hi);
-                    }
-                    H[e] = make_double2(hr, hi);
-                }
-                wave_sync();
-                if (a.integrand == ABZ_F_DOS_EIG) {
-                    for (int e = lane; e < nn; e += 64) W[e] = H[e];
-                    wave_sync();
-                    wave_eig(W, ev, n, lane);
-                }
-                gen_integrand(ga, H, W, X, ev, swq, lane, reinterpret_cast<double2*>(vals + (size_t)t * nc));
-                wave_sync();
-            }
-            if (lane == 0) {
-                InnerOut out;
-                out.I = a.I_out + q * nc;
-                out.E = a.E_out + q;
-                out.nev = a.nev_out + q;
-                out.status = a.status_out + q;
-                if (adapt_step(st, nc, seg_a, seg_b, seg_E, seg_I, vals, heap, ctl, a.maxevals, out)) ctl[5] = 1.0;
-            }
-        }
-        wave_sync();
-    }
-}
-
-// Block-per-integral version of the above for the resolvent-trace integrands: the integral's coefficient
+// Resolvent-trace integrands: the integral's coefficient
 // set is staged in LDS once and stays there for its whole adaptive loop; each round's 15 / 30 GK nodes
 // are evaluated 256/NP at a time by NP-lane groups (panel_inverse_row), thread 0 runs adapt_step.
-template <int NP, bool PAD, int NT, int WPE, int RPL = 1, bool FOLD = false, bool FMAC = false>
+template <int NP, bool PAD, int NT, int WPE, bool FOLD = false, bool FMAC = false>
 __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(WPE ? WPE : 1, WPE ? WPE : 8))) void gen_inner_panel_kernel(GenInnerArgs a) {
     static_assert(!FMAC || (FOLD && NP == 16), "the FMA-with-broadcast inversion is written for 16 lanes per node");
-    static_assert(!FOLD || (PAD && RPL == 1), "the folded series is built for the zero-padded one-row-per-lane layout");
+    static_assert(!FOLD || PAD, "the folded series is built for the zero-padded layout");
     extern __shared__ double2 lds_ip[];
-    constexpr int LPN = NP / RPL;  // lanes per node (RPL = 2: the duo layout, PAD only)
+    constexpr int LPN = NP;  // lanes per node: lane r owns row r
     constexpr int SLOTS = NT / LPN;
     constexpr int MS = ABZ_PANEL_MAXSEG;
     const int n = a.n, nn = n * n, M = a.M, nc = a.ncomp;  // nc = 1 (DOS, TRGLOC)
@@ -2927,9 +2652,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(WPE ? WPE : 
                 const int pnl = tt / 15, i = tt - 15 * pnl;
                 const double x = gk15_node(ctl[1 + 2 * pnl], ctl[2 + 2 * pnl], i);
                 double tr, ti;
-                if constexpr (RPL == 2) {
-                    duo_inverse_trace<NP>(coef, n, M, a.first, x * a.inv_period, swq, a.p[0], r, tr, ti);
-                } else if constexpr (FOLD) {
+                if constexpr (FOLD) {
                     double ar[NP], ai[NP];
                     double zr, zi;
                     if constexpr (FMAC)
@@ -2976,13 +2699,6 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(WPE ? WPE : 
     }
 }
 
-// threads of a gen_inner_panel_kernel workgroup: a round's 30 nodes in one pass where the lane groups allow it
-static int gen_inner_panel_threads(int np) {
-    static const int forced = [] { const char* e = getenv("ABZ_IPANEL_THREADS"); return e ? atoi(e) : 0; }();
-    if (forced == 256 || forced == 512) return forced;
-    return np >= 16 ? 512 : 256;
-}
-
 static bool gen_inner_panel_fits(int n, int M, int integrand, int* np_out, size_t* lds_out, bool* pad_out) {
     if (!(integrand == ABZ_F_DOS || integrand == ABZ_F_TRGLOC)) return false;
     const int np = n <= 8 ? 8 : (n <= 16 ? 16 : 32);
@@ -3000,13 +2716,6 @@ static bool gen_inner_panel_fits(int n, int M, int integrand, int* np_out, size_
 // the block-per-integral kernel is the one worth running by default (see iai_host.cpp)
 bool gen_inner_panel_supported(int n, int M, int integrand) {
     return n > 4 && n <= ABZ_MAX_BANDS && gen_inner_panel_fits(n, M, integrand, nullptr, nullptr, nullptr);
-}
-
-bool gen_inner_supported(int n, int M, int integrand) {
-    const int nc = integrand_ncomp(integrand, n, 3);
-    if (n <= 4 || n > ABZ_MAX_BANDS || nc <= 0 || nc > ADAPT_MAXC) return false;
-    if (integrand == ABZ_F_LINEAR || integrand == ABZ_F_LINEAR_X) return false;
-    return sizeof(double) * gen_inner_wave_doubles(n, M, nc) <= 150 * 1024;
 }
 
 int launch_gen_inner_adaptive(abz_ctx* ctx, const InnerSpec& is) {
@@ -3037,92 +2746,42 @@ int launch_gen_inner_adaptive(abz_ctx* ctx, const InnerSpec& is) {
     a.nev_out = is.nev_out;
     a.status_out = is.status_out;
     for (int i = 0; i < 16; ++i) a.sc[i] = kSinCosPiCoef[i];
-    {
-        const char* e = getenv("ABZ_IPANEL_PAIR");  // per call: tests compare both
-        a.pair = !(e && e[0] == '0');
+    a.pair = abz_switch(SW_ADAPT_PAIR) != 0;  // per call: tests compare both
+    int np = 0;
+    size_t plds = 0;
+    bool pad = false;
+    if (!gen_inner_panel_fits(is.n, is.M, is.integrand, &np, &plds, &pad)) {
+        set_error("inner panel kernel: n = %d, M = %d, integrand %d do not fit (the caller falls back to host-driven rounds)", is.n, is.M, is.integrand);
+        return ABZ_ERR_UNSUPPORTED;
     }
-    {
-        int np = 0;
-        size_t plds = 0;
-        bool pad = false;
-        static const bool off = [] { const char* e = getenv("ABZ_GEN_PANEL"); return e && e[0] == '0'; }();
-        if (!off && gen_inner_panel_fits(is.n, is.M, is.integrand, &np, &plds, &pad)) {
-            // one workgroup per integral up to a large grid: the dispatcher hands the next integral to whichever CU frees a
-            // slot (a static share of integrals per persistent workgroup left the second half of a launch half empty:
-            // 3.1 of 4 wave slots occupied on average).  ABZ_IPANEL_BLOCKS caps the grid (2048 = the static shares)
-            static const int64_t cap = [] { const char* e = getenv("ABZ_IPANEL_BLOCKS"); return e ? atoll(e) : (int64_t)1 << 20; }();
-            const int64_t blocks = std::min<int64_t>(is.nint, std::max<int64_t>(cap, 1));
-            ProfScope ps(ctx, ABZ_K_EVAL);
-#define ABZ_IPANEL3(NPV, PV, NTV, WV)                                                                          \
-    ABZ_HIP(hipFuncSetAttribute((const void*)gen_inner_panel_kernel<NPV, PV, NTV, WV>,                        \
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)plds));                      \
-    hipLaunchKernelGGL((gen_inner_panel_kernel<NPV, PV, NTV, WV>), dim3((unsigned)blocks), dim3(NTV), plds, ctx->stream, a);
-#define ABZ_IPANEL2(NPV, PV)                    \
-    if (nt == 512 && wpe == 4) {                \
-        ABZ_IPANEL3(NPV, PV, 512, 4)            \
-    } else if (nt == 512) {                     \
-        ABZ_IPANEL3(NPV, PV, 512, 0)            \
-    } else {                                    \
-        ABZ_IPANEL3(NPV, PV, 256, 0)            \
-    }
-#define ABZ_IPANEL(NPV) \
-    if (pad) {          \
-        ABZ_IPANEL2(NPV, true) \
-    } else {            \
-        ABZ_IPANEL2(NPV, false) \
-    }
-            // opt-in (ABZ_GEN_DUO=1): measured SLOWER than one row per lane (config 5: 255 vs 420 M nodes/s) -- 2 waves/SIMD do
-            // not hide the swizzle -> FMA latency of the pivot chain and the body spills; kept as the recorded experiment
-            static const bool duo_on = [] { const char* e = getenv("ABZ_GEN_DUO"); return e && e[0] == '1'; }();
-            if (pad && np <= 16 && duo_on) {
-                // duo layout: 2 rows per lane, np / 2 lanes per node, 256 threads = a round's 30 nodes in one pass at np = 16
-                const int64_t dblocks = std::min<int64_t>(is.nint, 256 * 8);
-                if (np == 8) {
-                    ABZ_HIP(hipFuncSetAttribute((const void*)gen_inner_panel_kernel<8, true, 128, 0, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)plds));
-                    hipLaunchKernelGGL((gen_inner_panel_kernel<8, true, 128, 0, 2>), dim3((unsigned)dblocks), dim3(128), plds, ctx->stream, a);
-                } else {
-                    ABZ_HIP(hipFuncSetAttribute((const void*)gen_inner_panel_kernel<16, true, 256, 2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)plds));
-                    hipLaunchKernelGGL((gen_inner_panel_kernel<16, true, 256, 2, 2>), dim3((unsigned)dblocks), dim3(256), plds, ctx->stream, a);
-                }
-                ABZ_HIP(hipGetLastError());
-                return ABZ_OK;
-            }
-            const int nt = gen_inner_panel_threads(np);
-            static const int wpe_env = [] { const char* e = getenv("ABZ_IPANEL_WPE"); return e ? atoi(e) : 0; }();
-            const int wpe = wpe_env ? wpe_env : ((nt == 512 && np <= 16) ? 4 : 0);  // 32 rows x 2 arrays alone fill 128 VGPRs
-            const bool fold_off = [] { const char* e = getenv("ABZ_IPANEL_FOLD"); return e && e[0] == '0'; }();  // per call: tests compare both
-            const bool fmac_off = [] { const char* e = getenv("ABZ_IPANEL_FMAC"); return e && e[0] == '0'; }();  // per call, like FOLD
-            if (np == 16 && pad && nt == 512 && wpe == 4 && a.herm && !fold_off && !fmac_off) {  // config 5's shape
-                ABZ_HIP(hipFuncSetAttribute((const void*)gen_inner_panel_kernel<16, true, 512, 4, 1, true, true>,
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)plds));
-                hipLaunchKernelGGL((gen_inner_panel_kernel<16, true, 512, 4, 1, true, true>), dim3((unsigned)blocks), dim3(512), plds, ctx->stream, a);
-            } else if (np == 16 && pad && nt == 512 && wpe == 4 && a.herm && !fold_off) {  // the same with the pivot rows broadcast by separate DPP moves
-                ABZ_HIP(hipFuncSetAttribute((const void*)gen_inner_panel_kernel<16, true, 512, 4, 1, true>,
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)plds));
-                hipLaunchKernelGGL((gen_inner_panel_kernel<16, true, 512, 4, 1, true>), dim3((unsigned)blocks), dim3(512), plds, ctx->stream, a);
-            } else if (np == 8) {
-                ABZ_IPANEL(8)
-            } else if (np == 16) {
-                ABZ_IPANEL(16)
-            } else {
-                ABZ_IPANEL(32)
-            }
-#undef ABZ_IPANEL
-#undef ABZ_IPANEL3
-#undef ABZ_IPANEL2
-            ABZ_HIP(hipGetLastError());
-            return ABZ_OK;
-        }
-    }
-    const size_t per = sizeof(double) * gen_inner_wave_doubles(is.n, is.M, a.ncomp);
-    int wpb = (int)((150 * 1024) / per);
-    if (wpb > 4) wpb = 4;
-    if (wpb < 1) wpb = 1;
-    const size_t lds = per * wpb;
-    const int64_t blocks = std::min<int64_t>(cdiv2(is.nint, wpb), 256 * 16);
+    // one workgroup per integral: the dispatcher hands the next integral to whichever CU frees a slot (a static share of
+    // integrals per persistent workgroup left the second half of a launch half empty: 3.1 of 4 wave slots occupied)
+    const int64_t blocks = std::min<int64_t>(is.nint, (int64_t)1 << 20);
     ProfScope ps(ctx, ABZ_K_EVAL);
-    ABZ_HIP(hipFuncSetAttribute((const void*)gen_inner_adaptive_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(gen_inner_adaptive_kernel, dim3((unsigned)blocks), dim3(256), lds, ctx->stream, a, wpb);
+    // workgroup: a round's 30 nodes in one pass where the lane groups allow it -- 256 threads = 32 nodes of 8 lanes, 512
+    // threads = 32 nodes of 16 lanes at 4 waves per SIMD (32 rows x 2 arrays alone fill 128 VGPRs: no bound there)
+#define ABZ_IPANEL3(NPV, PV, NTV, WV, ...)                                                                                \
+    {                                                                                                                     \
+        auto kfn = gen_inner_panel_kernel<NPV, PV, NTV, WV, ##__VA_ARGS__>;                                               \
+        ABZ_HIP(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)plds));            \
+        hipLaunchKernelGGL(kfn, dim3((unsigned)blocks), dim3(NTV), plds, ctx->stream, a);                                 \
+    }
+    const bool fold = abz_switch(SW_IPANEL_FOLD) != 0, fmac = abz_switch(SW_IPANEL_FMAC) != 0;  // per call: tests compare the variants
+    if (np == 16 && pad && a.herm && fold && fmac) {  // config 5's shape
+        ABZ_IPANEL3(16, true, 512, 4, true, true)
+    } else if (np == 16 && pad && a.herm && fold) {  // the same with the pivot rows broadcast by separate DPP moves
+        ABZ_IPANEL3(16, true, 512, 4, true)
+    } else if (np == 8) {
+        if (pad) ABZ_IPANEL3(8, true, 256, 0)
+        else ABZ_IPANEL3(8, false, 256, 0)
+    } else if (np == 16) {
+        if (pad) ABZ_IPANEL3(16, true, 512, 4)
+        else ABZ_IPANEL3(16, false, 512, 4)
+    } else {
+        if (pad) ABZ_IPANEL3(32, true, 512, 0)
+        else ABZ_IPANEL3(32, false, 512, 0)
+    }
+#undef ABZ_IPANEL3
     ABZ_HIP(hipGetLastError());
     return ABZ_OK;
 }

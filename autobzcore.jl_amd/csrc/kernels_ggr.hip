@@ -60,7 +60,6 @@ struct GgrBuildArgs {
     int M, first, npt;
     int M2, first2, gbeg, gcnt, nseg;
     int nt;     // non-temporal stores
-    int dbg;    // experiments (ABZ_GGR_DEBUG): bit 0 skip the node solve, bit 1 one frequency only, bit 2 skip the contraction, bit 3 skip the stores
     int pitch;  // padded row length: columns npt..pitch-1 are written too (whole 128-B lines)
     // Constants of the 3-band solve that are no inline operands: as kernel arguments they sit in scalar registers.  As
     // literals the compiler kept them in VGPR pairs hoisted to the kernel's entry, across the accumulation loops, and
@@ -267,8 +266,7 @@ __device__ __forceinline__ void ggr_accumulate(const GgrBuildArgs& a, const doub
             }
         }
     }
-    const int Frun = (a.dbg & 2) ? (F > 0 ? 1 : 0) : F;
-    for (int f = 1; f <= Frun; ++f) {
+    for (int f = 1; f <= F; ++f) {
         const double tf = TWO_PI * (double)f;
         double qr[KPL], qi[KPL];  // 2 pi i f p: phase of d/dx_1
 #pragma unroll
@@ -352,27 +350,17 @@ __device__ __forceinline__ void ggr_unit(const GgrBuildArgs& a, const double2* _
         __builtin_amdgcn_sched_barrier(0);  // one node after the other: interleaved solves need both working sets
         if (active && i1 < a.pitch) {
             double e[N], v[D][N];
-            if (a.dbg & 1) {
-#pragma unroll
-                for (int b = 0; b < N; ++b) {
-                    e[b] = A[j][0].re[b][b] + A[j][0].im[0][N - 1] + A[j][0].re[0][N - 1];
-#pragma unroll
-                    for (int jj = 0; jj < D; ++jj) v[jj][b] = A[j][jj + 1].re[b][b] + A[j][jj + 1].im[0][N - 1] + A[j][jj + 1].re[0][N - 1];
-                }
-            } else {
-                if (ggr_node_fast<N, D>(a, A[j], e, v)) ggr_node_jacobi<N, D>(A[j], e, v);
-            }
+            if (ggr_node_fast<N, D>(a, A[j], e, v)) ggr_node_jacobi<N, D>(A[j], e, v);
             unsigned u = lane_off;
             asm volatile("" : "+v"(u));
             u += (unsigned)(i0 + 32 * j);
-            if ((a.dbg & 8) && e[0] != 1.2345e300) continue;  // experiment: no stores
             ggr_store<N, D, NT>(a, erow, vrow, u, e, v);
         }
     }
 }
 
 // all passes of a pair of lines whose packed sets are staged in the wave's LDS buffer
-template <int N, int D, bool NT, int KB>
+template <int N, int D, bool NT>
 __device__ __forceinline__ void ggr_line_pair(const GgrBuildArgs& a, const double2* wbuf, int F, int P, const double2* tab_l,
                                               int lane, int64_t lineA, bool haveB) {
     // per-lane values are re-derived from `lane` for every pair of lines (a handful of integer operations): as loop
@@ -382,7 +370,7 @@ __device__ __forceinline__ void ggr_line_pair(const GgrBuildArgs& a, const doubl
     const int half = lane >> 5, sub = lane & 31;
     const double2* cset = wbuf + (size_t)half * D * P;
     const bool active = half == 0 || haveB;
-    if constexpr (N <= 3 && KB == 2) {
+    if constexpr (N <= 3) {  // two nodes per lane share every broadcast coefficient read (one per lane at 3 waves/SIMD measured the same)
         const int nfull = a.pitch / 64;
         const int rem = a.pitch - 64 * nfull;  // pitch is a multiple of 16: rem in {0, 16, 32, 48}
         for (int p = 0; p < nfull; ++p) ggr_unit<N, D, 2, NT>(a, cset, F, P, tab_l, 64 * p, sub, lineA, half, active);
@@ -398,8 +386,8 @@ __device__ __forceinline__ void ggr_line_pair(const GgrBuildArgs& a, const doubl
 constexpr int GGR_MAX_P = 256;  // packed elements per set
 
 // ---- FUSE: block = (parent, segment of the i2 range); packed level-2 sets of the parent in LDS
-template <int N, int D, bool NT, int KB>
-__global__ __launch_bounds__(256, (KB == 1 && N <= 3) ? 3 : 2) void ggr_build_fused_kernel(GgrBuildArgs a) {
+template <int N, int D, bool NT>
+__global__ __launch_bounds__(256, 2) void ggr_build_fused_kernel(GgrBuildArgs a) {
     static_assert(D >= 2, "the fused build contracts variable 2 in the kernel");
     extern __shared__ double2 lds_g[];  // [D-1][M2][P] packed level-2 sets | [npt] phase table | [4 waves][2 lines][D][P]
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
@@ -412,18 +400,13 @@ __global__ __launch_bounds__(256, (KB == 1 && N <= 3) ? 3 : 2) void ggr_build_fu
     int fm2 = a.first2 % a.npt;
     if (fm2 < 0) fm2 += a.npt;
     for (int i = threadIdx.x; i < a.npt; i += 256) tab_l[i] = a.tab[i];
-    // This block's share of the global list of line pairs (parent-major), contiguous and of equal length for every
-    // block: one round of resident blocks, no tail (segments of a parent dealt to 3 rounds of blocks left the SIMDs
-    // with 1.5 of their 2 waves on average).  A share spans one or two parents; the waves take its pairs round-robin.
+    // block = (parent, segment of its line pairs): many more blocks than resident slots, dealt by the dispatcher (one
+    // round of resident blocks with equal contiguous shares measured 15 % slower: launch_ggr_build)
     const int ppp = (a.gcnt + 1) / 2;  // pairs per parent
-    const int64_t npairs_all = (a.nlines / a.gcnt) * ppp;
-    int64_t g0 = (npairs_all * blockIdx.x) / gridDim.x, g1 = (npairs_all * (blockIdx.x + 1)) / gridDim.x;
-    if (a.nseg > 0) {  // block = (parent, segment of its pairs): many more blocks than resident slots, dealt by the dispatcher
-        const int64_t par = blockIdx.x / a.nseg;
-        const int seg = blockIdx.x - (int)(par * a.nseg);
-        g0 = par * ppp + ((int64_t)ppp * seg) / a.nseg;
-        g1 = par * ppp + ((int64_t)ppp * (seg + 1)) / a.nseg;
-    }
+    const int64_t par = blockIdx.x / a.nseg;
+    const int seg = blockIdx.x - (int)(par * a.nseg);
+    const int64_t g0 = par * ppp + ((int64_t)ppp * seg) / a.nseg;
+    const int64_t g1 = par * ppp + ((int64_t)ppp * (seg + 1)) / a.nseg;
     const int nT = (P + 63) / 64;
     // packed level-1 sets of grid indices i2 (line A) and i2 + dB (line B) into dst[line][set][e]: set 0 plain, set 1
     // derivative on variable 2, set 2 from c2s'.  Both lines share every coefficient read.
@@ -496,10 +479,10 @@ __global__ __launch_bounds__(256, (KB == 1 && N <= 3) ? 3 : 2) void ggr_build_fu
             const int i2 = a.gbeg + 2 * p;
             const bool haveB = 2 * p + 1 < a.gcnt;
             wave_lds_fence();  // the previous pair's reads of wbuf are done
-            if (!(a.dbg & 4)) contract_pair(i2, haveB ? 1 : 0, wbuf);
+            contract_pair(i2, haveB ? 1 : 0, wbuf);
             wave_lds_fence();
             const int64_t lineA = parent * a.gcnt + 2 * p;
-            ggr_line_pair<N, D, NT, KB>(a, wbuf, F, P, tab_l, lane, lineA, haveB);
+            ggr_line_pair<N, D, NT>(a, wbuf, F, P, tab_l, lane, lineA, haveB);
         }
         g = gend;
     }
@@ -524,7 +507,7 @@ __global__ __launch_bounds__(256) void ggr_pack2_kernel(const double2* __restric
 }
 
 // ---- !FUSE: level-1 families from HBM, packed on their way into LDS; pairs of consecutive lines, grid-strided
-template <int N, int D, bool NT, int KB>
+template <int N, int D, bool NT>
 __global__ __launch_bounds__(256, 2) void ggr_build_lines_kernel(GgrBuildArgs a) {
     extern __shared__ double2 lds_g[];  // [npt] phase table | [4 waves][2 lines][D][P]
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
@@ -551,7 +534,7 @@ __global__ __launch_bounds__(256, 2) void ggr_build_lines_kernel(GgrBuildArgs a)
             }
         }
         wave_lds_fence();
-        ggr_line_pair<N, D, NT, KB>(a, wbuf, F, P, tab_l, lane, lineA, haveB);
+        ggr_line_pair<N, D, NT>(a, wbuf, F, P, tab_l, lane, lineA, haveB);
     }
 }
 
@@ -690,7 +673,7 @@ static size_t ggr_lines_lds(int n, int d, int M, int npt) {
 }
 
 bool ggr_build_supported(int n, int d, int M, int npt, bool herm) {
-    const bool off = [] { const char* e = getenv("ABZ_GGR_FUSED"); return e && e[0] == '0'; }();  // per call: tests compare both builds
+    const bool off = !abz_switch(SW_GGR_FUSED);  // per call: tests compare both builds
     // Hermitian series have an odd number of symmetric frequencies per variable (detect_hermitian, api.cpp)
     if (off || !herm || (M & 1) == 0 || n < 1 || n > 4 || d < 1 || d > 3 || npt >= 65536) return false;
     return ggr_packed(n, M) <= (size_t)GGR_MAX_P && ggr_lines_lds(n, d, M, npt) <= 64 * 1024;
@@ -701,7 +684,7 @@ size_t ggr_build_pack2_elems(int n, int d, int M, int M2, int64_t nparents) {
 }
 
 bool ggr_build_can_fuse(int n, int d, int M, int M2, int npt) {
-    const bool off = [] { const char* e = getenv("ABZ_GGR_FUSE2"); return e && e[0] == '0'; }();  // per call
+    const bool off = !abz_switch(SW_GGR_FUSE2);  // per call
     // two blocks per CU must fit the 160 KB of LDS
     return !off && d >= 2 && ggr_fused_lds(n, d, M, M2, npt) <= 78 * 1024;
 }
@@ -728,13 +711,11 @@ int launch_ggr_build(abz_ctx* ctx, const GgrBuildSpec& gs) {
     a.gi = gs.gi;
     a.nk = gs.nk;
     const int n = gs.n, d = gs.d;
-    a.dbg = [] { const char* e = getenv("ABZ_GGR_DEBUG"); return e ? atoi(e) : 0; }();
     {
         const double cq[8] = {-0.008198810912827986, 0.03528472977563877, -0.09201052271579181, 0.33285803676124615,
                               1.732059706718476, 1.0 / 3.0, 1.0 / 6.0, 1e-6};
         for (int i = 0; i < 8; ++i) a.cq[i] = cq[i];
     }
-    const int kb = [] { const char* e = getenv("ABZ_GGR_KB"); return e ? atoi(e) : 2; }();  // nodes per lane in body passes
     ProfScope ps(ctx, ABZ_K_GGRBUILD);
     if (!gs.grid) {
         if (gs.nk == 0) return ABZ_OK;
@@ -759,9 +740,8 @@ int launch_ggr_build(abz_ctx* ctx, const GgrBuildSpec& gs) {
     }
     if (gs.nlines == 0) return ABZ_OK;
     {
-        const int force = [] { const char* e = getenv("ABZ_NT_STORES"); return e ? atoi(e) : -1; }();
         const double bytes = 8.0 * (double)(n * (1 + d)) * (double)gs.E.row * (double)gs.nlines;
-        a.nt = force >= 0 ? force : (bytes > 256.0 * 1024 * 1024 ? 1 : 0);
+        a.nt = bytes > 256.0 * 1024 * 1024 ? 1 : 0;
     }
     if (gs.fuse) {
         const size_t lds = ggr_fused_lds(n, d, gs.M, gs.M2, gs.npt);
@@ -779,37 +759,26 @@ int launch_ggr_build(abz_ctx* ctx, const GgrBuildSpec& gs) {
             a.src2[0] = gs.pack2;
             a.src2[1] = nullptr;
         }
-        // one round of resident blocks, each with an equal contiguous share of the line pairs
-        const int64_t npairs_all = nparents * ((gs.gcnt + 1) / 2);
-        const int occ = (kb == 1 && n <= 3) ? 3 : 2;
-        const int per_cu = (int)std::max<size_t>(1, std::min<size_t>((size_t)occ, (160 * 1024) / lds));
-        const int bmul = [] { const char* e = getenv("ABZ_GGR_ROUNDS"); return e ? atoi(e) : 1; }();
-        unsigned blocks = (unsigned)std::max<int64_t>(1, std::min<int64_t>(npairs_all, (int64_t)256 * per_cu * std::max(bmul, 1)));
-        a.nseg = 0;
-        const int ppb = [] { const char* e = getenv("ABZ_GGR_PAIRS_PER_BLOCK"); return e ? atoi(e) : 8; }();  // 0: one round of equal shares
-        if (ppb > 0) {
-            const int ppp = (gs.gcnt + 1) / 2;
-            a.nseg = (int)std::max<int64_t>(1, std::min<int64_t>(cdiv64(ppp, ppb), ppp));
-            blocks = (unsigned)(nparents * a.nseg);
-        }
+        // block = (parent, segment of ~8 of its line pairs), dealt by the dispatcher: a single round of resident blocks
+        // with equal contiguous shares was 15 % slower (the lines of the k_3 = 0, 1/2 planes all take the Jacobi redo and
+        // one static share held 22 of them)
+        const int ppp = (gs.gcnt + 1) / 2;
+        a.nseg = (int)std::max<int64_t>(1, std::min<int64_t>(cdiv64(ppp, 8), ppp));
+        const unsigned blocks = (unsigned)(nparents * a.nseg);
         // above 64 KB of dynamic LDS a launch is rejected unless the function was told so (every other launch of that
         // size in the library does the same); a 4-band d = 3 model with M = M2 = 11 at npt = 150 needs 68.6 KB
-#define GF1(NN, DD, NT, KB)                                                                                               \
+#define GF1(NN, DD, NT)                                                                                                   \
     do {                                                                                                                  \
-        auto kfn = ggr_build_fused_kernel<NN, DD, NT, KB>;                                                                \
+        auto kfn = ggr_build_fused_kernel<NN, DD, NT>;                                                                    \
         if (lds > 64 * 1024)                                                                                              \
             ABZ_HIP(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));         \
         hipLaunchKernelGGL(kfn, dim3(blocks), dim3(256), lds, ctx->stream, a);                                            \
     } while (0)
-#define GF(NN, DD)                     \
-    if (kb == 1 && a.nt)               \
-        GF1(NN, DD, true, 1);          \
-    else if (kb == 1)                  \
-        GF1(NN, DD, false, 1);         \
-    else if (a.nt)                     \
-        GF1(NN, DD, true, 2);          \
-    else                               \
-        GF1(NN, DD, false, 2)
+#define GF(NN, DD)        \
+    if (a.nt)             \
+        GF1(NN, DD, true);  \
+    else                  \
+        GF1(NN, DD, false)
 #define GFD(NN)              \
     if (d == 2) {            \
         GF(NN, 2);           \
@@ -829,15 +798,11 @@ int launch_ggr_build(abz_ctx* ctx, const GgrBuildSpec& gs) {
         const size_t lds = ggr_lines_lds(n, d, gs.M, gs.npt);
         const int64_t npairs = (gs.nlines + 1) / 2;
         const unsigned blocks = (unsigned)std::min<int64_t>(cdiv64(npairs, 4), 256 * 12);
-#define GL(NN, DD)                                                                                                        \
-    if (kb == 1 && a.nt)                                                                                                  \
-        hipLaunchKernelGGL((ggr_build_lines_kernel<NN, DD, true, 1>), dim3(blocks), dim3(256), lds, ctx->stream, a);     \
-    else if (kb == 1)                                                                                                     \
-        hipLaunchKernelGGL((ggr_build_lines_kernel<NN, DD, false, 1>), dim3(blocks), dim3(256), lds, ctx->stream, a);    \
-    else if (a.nt)                                                                                                        \
-        hipLaunchKernelGGL((ggr_build_lines_kernel<NN, DD, true, 2>), dim3(blocks), dim3(256), lds, ctx->stream, a);     \
-    else                                                                                                                  \
-        hipLaunchKernelGGL((ggr_build_lines_kernel<NN, DD, false, 2>), dim3(blocks), dim3(256), lds, ctx->stream, a)
+#define GL(NN, DD)                                                                                                      \
+    if (a.nt)                                                                                                           \
+        hipLaunchKernelGGL((ggr_build_lines_kernel<NN, DD, true>), dim3(blocks), dim3(256), lds, ctx->stream, a);      \
+    else                                                                                                                \
+        hipLaunchKernelGGL((ggr_build_lines_kernel<NN, DD, false>), dim3(blocks), dim3(256), lds, ctx->stream, a)
 #define GLD(NN)                    \
     switch (d) {                   \
         case 1: GL(NN, 1); break;  \
@@ -1053,54 +1018,6 @@ __global__ __launch_bounds__(256) void ggr_final_kernel(const double* __restrict
     if (threadIdx.x == 0) out[blockIdx.x] = red[0];
 }
 
-// The all-pairs scan of rounds 1-2 (ABZ_GGR_SCAN=0; unsorted energy lists need no permutation here): every thread
-// evaluates every energy for its node.
-template <int N, int D>
-__global__ __launch_bounds__(256) void ggr_allpairs_kernel(GgrArgs a, double* __restrict__ partial) {
-    extern __shared__ double ldsd[];  // [nE chunk][4]
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    const bool ok = k < a.nk;
-    const int64_t kk = ok ? k : 0;
-    const double wk = ok ? (a.w ? a.w[kk] : 1.0) : 0.0;
-    double e[N];
-    double v[N][D];
-    const double* __restrict__ ei = a.E.base + plane_off(a.E, kk) + (int64_t)blockIdx.y * a.E.pitch;
-    const double* __restrict__ vi = a.V.base + plane_off(a.V, kk) + (int64_t)blockIdx.y * a.V.pitch;
-#pragma unroll
-    for (int bnd = 0; bnd < N; ++bnd) {
-        e[bnd] = ei[(int64_t)bnd * a.E.pitch];
-#pragma unroll
-        for (int j = 0; j < D; ++j) v[bnd][j] = vi[(int64_t)(j * a.vstride + bnd) * a.V.pitch];
-    }
-    const int64_t prow = (int64_t)blockIdx.y * gridDim.x + blockIdx.x;
-    const int chunk = 1024;
-    for (int s0 = 0; s0 < a.nE; s0 += chunk) {
-        const int s1 = min(a.nE, s0 + chunk);
-        for (int s = s0; s < s1; ++s) {
-            const double En = a.Es[s];
-            double acc = 0.0;
-#pragma unroll
-            for (int bnd = 0; bnd < N; ++bnd) acc += ggr_formula<D>(a.b, En, e[bnd], v[bnd]);
-            acc = wave_sum(wk * acc);
-            if (lane == 0) ldsd[(s - s0) * 4 + wave] = acc;
-        }
-        __syncthreads();
-        for (int t = threadIdx.x; t < s1 - s0; t += 256)
-            partial[prow * a.nE + s0 + t] = ldsd[t * 4] + ldsd[t * 4 + 1] + ldsd[t * 4 + 2] + ldsd[t * 4 + 3];
-        __syncthreads();
-    }
-}
-
-__global__ void final_reduce_real_kernel(const double* __restrict__ partial, int64_t nblocks, int64_t ncols,
-                                         double* __restrict__ out) {
-    const int64_t col = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (col >= ncols) return;
-    double s = 0.0;
-    for (int64_t b = 0; b < nblocks; ++b) s += partial[b * ncols + col];
-    out[col] = s;
-}
-
 }  // namespace
 
 #define ABZ_GGR_ND(KERNEL, ...)                                          \
@@ -1121,7 +1038,6 @@ __global__ void final_reduce_real_kernel(const double* __restrict__ partial, int
 
 int launch_ggr(abz_ctx* ctx, int n, int d, int npt, PlaneView E, PlaneView V, const double* w, int64_t nk,
                const double* Es_host, int nE, double* out_host) {
-    const bool windowed = [] { const char* e = getenv("ABZ_GGR_SCAN"); return !(e && e[0] == '0'); }();  // per call
     const int brows = n > 4 ? n : 1;  // n > 4: one block row per band
     GgrArgs a;
     a.E = E;
@@ -1132,31 +1048,6 @@ int launch_ggr(abz_ctx* ctx, int n, int d, int npt, PlaneView E, PlaneView V, co
     a.d = d;
     a.vstride = n;
     a.b = 1.0 / (2.0 * (double)npt);
-    if (!windowed) {
-        const int64_t nblocks = cdiv64(nk, 256);
-        int rc = ctx->scratch[1].reserve(sizeof(double) * (size_t)(nblocks * brows * nE));
-        if (rc) return rc;
-        if ((rc = ctx->scratch[2].reserve(sizeof(double) * (size_t)nE * 2))) return rc;
-        double* partial = ctx->scratch[1].as<double>();
-        double* Es_dev = ctx->scratch[2].as<double>();
-        double* outd = Es_dev + nE;
-        ABZ_HIP(hipMemcpyAsync(Es_dev, Es_host, sizeof(double) * (size_t)nE, hipMemcpyHostToDevice, ctx->stream));
-        a.Es = Es_dev;
-        a.nE = nE;
-        {
-            ProfScope ps(ctx, ABZ_K_GGR);
-            const size_t lds = sizeof(double) * 4 * (size_t)std::min(nE, 1024);
-            const dim3 grid((unsigned)nblocks, (unsigned)brows);
-            ABZ_GGR_ND(ggr_allpairs_kernel, a, partial);
-            ABZ_HIP(hipGetLastError());
-            hipLaunchKernelGGL(final_reduce_real_kernel, dim3((unsigned)cdiv64(nE, 256)), dim3(256), 0, ctx->stream, partial,
-                               nblocks * brows, (int64_t)nE, outd);
-            ABZ_HIP(hipGetLastError());
-        }
-        ABZ_HIP(hipMemcpyAsync(out_host, outd, sizeof(double) * (size_t)nE, hipMemcpyDeviceToHost, ctx->stream));
-        ABZ_HIP(hipStreamSynchronize(ctx->stream));
-        return ABZ_OK;
-    }
     // ascending energies (stable order of equal ones), results go back through the permutation
     std::vector<int> perm((size_t)nE);
     for (int i = 0; i < nE; ++i) perm[(size_t)i] = i;
@@ -1186,7 +1077,7 @@ int launch_ggr(abz_ctx* ctx, int n, int d, int npt, PlaneView E, PlaneView V, co
     }
     // an equispaced list (the usual linspace sweep) lets a thread compute its window's first index instead of searching
     {
-        const bool off = [] { const char* e = getenv("ABZ_GGR_UNIFORM"); return e && e[0] == '0'; }();  // per call: tests compare both
+        const bool off = !abz_switch(SW_GGR_UNIFORM);  // per call: tests compare both
         const double step = nE >= 2 ? (Es[(size_t)nE - 1] - Es[0]) / (double)(nE - 1) : 0.0;
         bool uni = !off && nE >= 8 && step > 0.0;
         for (int i = 0; i < nE && uni; ++i) uni = std::fabs(Es[(size_t)i] - (Es[0] + (double)i * step)) <= 1e-6 * step;

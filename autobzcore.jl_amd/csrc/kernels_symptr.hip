@@ -474,7 +474,7 @@ int sym_tables_device(abz_ctx* ctx, int npt, int d, const int32_t* syms, int nsy
     int64_t* tot_dev = reinterpret_cast<int64_t*>(static_cast<char*>(ctx->mbox_dev) + ctx->mbox_cap / 2);
     volatile int64_t* tot_host = reinterpret_cast<volatile int64_t*>(static_cast<char*>(ctx->mbox) + ctx->mbox_cap / 2);
     hipStream_t st_ = ctx->stream;
-    const bool dbg = getenv("ABZ_DEBUG_TIMING") != nullptr;
+    const bool dbg = abz_switch(SW_DEBUG_TIMING) != 0;
     auto tnow = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     double tdbg = tnow();
     auto lap = [&](const char* what) {

@@ -299,29 +299,6 @@ def rank_main(a):
         reig.close()
         ref_layout["eigenvalues_only_avg_launch_ms"] = msE / max(nE, 1)
 
-    # the same rebuild with the last contraction fused into the Fourier-eval kernel (ABZ_FUSE2=1, opt-in)
-    two = None
-    if world == 1 and not a.no_extras and not a.force_dist:
-        os.environ["ABZ_FUSE2"] = "1"
-        for _ in range(max(a.warmup, 1)):
-            rule.rebuild()
-        ctx.sync()
-        ctx.prof_enable(True, kernels=[L.K_EVAL])
-        ctx.prof_reset()
-        t0 = time.perf_counter()
-        for _ in range(a.steps * 8):
-            rule.rebuild()
-        ctx.sync()
-        t2 = time.perf_counter() - t0
-        ms2, n2 = ctx.prof_read(L.K_EVAL)
-        ctx.prof_enable(False)
-        del os.environ["ABZ_FUSE2"]
-        rule.rebuild()
-        ctx.sync()
-        two = {"ms_per_pass": 1e3 * t2 / (a.steps * 8), "eval_kernel_avg_ms": ms2 / max(n2, 1),
-               "frac": nk * bpk / ((ms2 / max(n2, 1)) * 1e-3) / 1e9 / 8000.0 if n2 else None,
-               "note": "opt-in variant ABZ_FUSE2=1: contract x1 + eval_grid_fused_kernel (level-1 sets never leave the CU)"}
-
     # ---------------- Phase B: fused sweeps over this rank's omegas (matrix-cached, reference-faithful)
     nB = a.steps * 50
     # warm-up: the scan is f64-VALU bound while Phase A is HBM-write bound, and the GPU's clocks take ~0.1 s of the new
@@ -569,7 +546,6 @@ def rank_main(a):
                          "kernel": "eval_grid_kernel<3> (Fourier-eval + fused eig)",
                          "algorithmic_bytes_per_kpoint": bpk,
                          "avg_launch_ms": eval_ms / max(eval_n, 1), "launches": eval_n,
-                         "fused_contraction_variant": two,
                          "contract_avg_ms": con_ms / max(con_n, 1),
                          "reduce_avg_ms": red_ms / max(red_n, 1),
                          # Hermitian rule: the scan reads the upper triangle only, n^2 doubles per k-point

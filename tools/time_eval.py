@@ -1,5 +1,5 @@
 """Fourier-eval kernel timing (HIP events on the library's stream) for a few grid sizes: avg launch ms and fraction of the
-8 TB/s HBM peak at 168 B per k-point.  Env switches of the experiment are read by the library (ABZ_PAD_WRITE, ABZ_NT_STORES)."""
+8 TB/s HBM peak at 168 B per k-point.  Env switches of the experiment are read by the library."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -27,5 +27,5 @@ for npt in [int(v) for v in (sys.argv[1:] or ["150", "160", "200"])]:
     nk = npt**3
     base, nb = rule.values_ptr()
     print(f"npt {npt}: eval kernel {min(res):.4f} .. {max(res):.4f} ms -> {nk*168/min(res)*1e-6:.0f} GB/s = {nk*168/min(res)*1e-6/8000:.3f} of peak; "
-          f"rule {nb/1e6:.0f} MB (algorithmic {nk*168/1e6:.0f} MB) pad_write={os.environ.get('ABZ_PAD_WRITE','1')}", flush=True)
+          f"rule {nb/1e6:.0f} MB (algorithmic {nk*168/1e6:.0f} MB)", flush=True)
     rule.close()

@@ -1,7 +1,7 @@
 """GGR build (eigenvalues + band velocities, abz_ptr_rule_build(WANT_EIG | WANT_VEL)) and energy scan on the SVO model:
 time per rebuild from the library's own HIP events, checksums of (e, v) and of the scanned DOS so that two builds of the
 library (ABZ_GGR_FUSED=0: the unfused round-2 path) can be compared value for value.
-Usage: time_ggr.py [npt ...]      env: ABZ_GGR_FUSED, ABZ_GGR_FUSE2, ABZ_GGR_PAIRS_PER_BLOCK, SYMS=1 (cubic IBZ too)"""
+Usage: time_ggr.py [npt ...]      env: ABZ_GGR_FUSED, ABZ_GGR_FUSE2, SYMS=1 (cubic IBZ too)"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)

@@ -17,6 +17,5 @@ for npt in (48, 100):
             r.rebuild()
         dev.ctx.sync()
         dt = (time.perf_counter() - t0) / 5
-        print(f"16 bands, cubic IBZ npt={npt}: {r.nk} irreducible nodes, rebuild {name:6s} {1e3*dt:8.3f} ms = {r.nk/dt/1e6:7.2f} M nodes/s "
-              f"(row kernel {'off' if os.environ.get('ABZ_GEN_ROWEIG') == '0' else 'on'})", flush=True)
+        print(f"16 bands, cubic IBZ npt={npt}: {r.nk} irreducible nodes, rebuild {name:6s} {1e3*dt:8.3f} ms = {r.nk/dt/1e6:7.2f} M nodes/s", flush=True)
         r.close()
