@@ -34,6 +34,11 @@ PROTOTYPES = {
     "abz_ptr_rule_build": (C.c_int, [C.c_void_p, C.c_int, C.c_int64, c_i32p, c_i64p, C.c_int, c_vpp]),
     "abz_ptr_rule_build_sym": (C.c_int, [C.c_void_p, C.c_int, c_i32p, C.c_int, C.c_int, c_vpp]),
     "abz_ptr_sum": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, c_f64p, C.c_int, c_f64p, C.c_int, C.c_int, c_f64p]),
+    "abz_autoptr_solve": (C.c_int, [C.c_void_p, c_i32p, C.c_int, C.c_int, c_f64p, C.c_int, C.c_double, C.c_int, C.c_int, C.c_double,
+                                    C.c_double, C.c_int64, C.c_int, C.c_double, c_f64p, c_f64p, c_i64p, c_i32p]),
+    "abz_autoptr_solve_many": (C.c_int, [C.c_void_p, c_i32p, C.c_int, C.c_int, c_f64p, C.c_int, c_f64p, C.c_int, C.c_int, C.c_int,
+                                         C.c_double, C.c_double, C.c_int64, C.c_int, C.c_double, c_f64p, c_f64p, c_i64p, c_i32p]),
+    "abz_series_drop_rules": (C.c_int, [C.c_void_p]),
     "abz_ptr_rule_build_slab": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, c_vpp]),
     "abz_rule_destroy": (C.c_int, [C.c_void_p]),
     "abz_rule_rebuild": (C.c_int, [C.c_void_p]),

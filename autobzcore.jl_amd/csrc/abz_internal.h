@@ -193,7 +193,11 @@ struct abz_series {
     uint64_t generation = 0;                  // bumped by abz_series_update
     std::vector<abz::SeriesRule> kept_rules;  // rules of abz_autoptr_solve*, most recently used last
     uint64_t kept_stamp = 0;
+    std::vector<int> summed_once;             // full grids beyond `keepmost` that were summed on the fly once already
     abz::DevBuf auto_io;                      // swept values in / sums out of abz_autoptr_solve*
+    void* auto_pin = nullptr;                 // ... and their pinned, device-visible host block (zero-copy results)
+    void* auto_pin_dev = nullptr;
+    size_t auto_pin_cap = 0;
     int64_t elems(int level) const {
         int64_t e = (int64_t)n * n;
         for (int j = 0; j < level; ++j) e *= dims[j];
@@ -312,7 +316,8 @@ struct ReduceSpec {
     double scale;
     double* out_dev = nullptr;  // device [n_sweep][ncomp][2]: leave the result in HBM, no host synchronisation
     double2* out_map_dev = nullptr;         // host-io calls: device view of the pinned mailbox region the sums are written to ...
-    const double2* out_map_host = nullptr;  // ... and its host view (read after the stream synchronisation)
+    const double2* out_map_host = nullptr;  // ... and its host view (read after the stream synchronisation; null with
+                                            // out_map_dev set: the launch returns without synchronising, n <= 4)
 };
 int integrand_ncomp(int integrand, int n, int d);
 // result: host out_reim [n_sweep][ncomp][2]

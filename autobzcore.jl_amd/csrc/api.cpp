@@ -557,6 +557,7 @@ static void series_release(abz_series* s) {
     dev_free(s->coef, s->coef_cap);
     s->coef_pk.release();
     s->auto_io.release();
+    if (s->auto_pin) (void)hipHostFree(s->auto_pin);
     delete s;
     ctx_release(ctx);
 }
@@ -771,6 +772,7 @@ static void series_drop_kept_rules(abz_series* s) {
     (void)hipStreamSynchronize(s->ctx->stream);
     for (auto& k : s->kept_rules) rule_free(k.r);  // they hold no reference on the series
     s->kept_rules.clear();
+    s->summed_once.clear();
 }
 
 int abz_series_destroy(abz_series* s) {
@@ -1274,7 +1276,7 @@ int abz_rule_export(abz_rule* r, double* x, double* w, double* H, double* eig, d
 }
 
 static int rule_reduce(abz_rule* r, int integrand, const double* params, int nparams, const double* sweep, int n_sweep,
-                       int nsyms, double* out_reim, bool device_io);
+                       int nsyms, double* out_reim, bool device_io, double2* map_dev = nullptr);
 
 int abz_rule_reduce(abz_rule* r, int integrand, const double* params, int nparams, const double* sweep, int n_sweep,
                     int nsyms, double* out_reim) {
@@ -1294,11 +1296,13 @@ int abz_rule_values_ptr(const abz_rule* r, void** base, int64_t* nbytes) {
     return ABZ_OK;
 }
 
+// device_io: `sweep` and `out_reim` are device pointers, nothing is synchronised; with `map_dev` (n <= 4) the sums are
+// written by the last kernel straight into that device-visible host address instead of `out_reim`
 static int rule_reduce(abz_rule* r, int integrand, const double* params, int nparams, const double* sweep, int n_sweep,
-                       int nsyms, double* out_reim, bool device_io) {
+                       int nsyms, double* out_reim, bool device_io, double2* map_dev) {
     int rc0 = check_rule(r);
     if (rc0) return rc0;
-    ABZ_REQUIRE(out_reim, "null out");
+    ABZ_REQUIRE(out_reim || map_dev, "null out");
     ABZ_REQUIRE(nparams >= 0 && nparams <= 4, "nparams = %d not in 0..4", nparams);
     ABZ_REQUIRE(nsyms >= 1, "nsyms must be >= 1");
     abz_ctx* ctx = r->s->ctx;
@@ -1348,7 +1352,10 @@ static int rule_reduce(abz_rule* r, int integrand, const double* params, int npa
     double vol = 1.0;
     for (int j = 0; j < rs.d; ++j) vol *= (double)r->npt;
     rs.scale = 1.0 / (vol * (double)nsyms);
-    if (device_io) rs.out_dev = out_reim;
+    if (device_io && map_dev && rs.n <= 4)
+        rs.out_map_dev = map_dev;
+    else if (device_io)
+        rs.out_dev = out_reim;
     if (!device_io && rs.n <= 4 && ctx->mbox) {  // sums land in the second half of the mailbox (zero copy)
         const int nc = integrand_ncomp(integrand, rs.n, rs.d);
         if (nc > 0 && sizeof(double2) * (size_t)ns * (size_t)nc <= ctx->mbox_cap / 2) {
@@ -1525,44 +1532,95 @@ int abz_autoptr_solve_many(abz_series* s, const int32_t* syms, int nsyms, int in
     std::vector<int> active((size_t)n_sweep);
     for (int i = 0; i < n_sweep; ++i) active[(size_t)i] = i;
     std::vector<int64_t> nev((size_t)n_sweep, 0);
-    // device staging: [2 grids][n_sweep] swept values | [2 grids][n_sweep][ncomp] sums
+    // staging: swept values of the active solves (one upload serves the first two grids) and, per grid in flight, the sums --
+    // written by the scan's last kernel straight into the pinned mailbox where they fit (no copy call), else left in HBM and
+    // fetched by one copy
     const size_t sw_bytes = sizeof(double) * (size_t)n_sweep, out_bytes = sizeof(double2) * (size_t)n_sweep * ncs;
-    if ((rc = s->auto_io.reserve(2 * (sw_bytes + out_bytes)))) return rc;
+    if ((rc = s->auto_io.reserve(sw_bytes + 2 * out_bytes))) return rc;
     char* const io = static_cast<char*>(s->auto_io.p);
-    const bool mb = mbox_reserve(ctx) == ABZ_OK && 2 * (sw_bytes + out_bytes) <= ctx->mbox_cap;
-    std::vector<char> host_io(mb ? 0 : 2 * (sw_bytes + out_bytes));
-    char* const hio = mb ? static_cast<char*>(ctx->mbox) : host_io.data();
-    size_t free_b = 0, total_b = 0;
-    (void)hipMemGetInfo(&free_b, &total_b);
+    // (a block of its own: the context's mailbox serves the calls made below -- abz_ptr_sum -- while sums are pending here)
+    const size_t pin_need = sw_bytes + 2 * out_bytes;
+    if (s->auto_pin_cap < pin_need) {
+        (void)hipStreamSynchronize(ctx->stream);
+        if (s->auto_pin) (void)hipHostFree(s->auto_pin);
+        s->auto_pin = s->auto_pin_dev = nullptr;
+        s->auto_pin_cap = 0;
+        void *hp = nullptr, *dp = nullptr;
+        const size_t cap = std::max<size_t>(pin_need, (size_t)16 << 10);
+        if (hipHostMalloc(&hp, cap, hipHostMallocDefault) == hipSuccess && hipHostGetDevicePointer(&dp, hp, 0) == hipSuccess && dp) {
+            s->auto_pin = hp;
+            s->auto_pin_dev = dp;
+            s->auto_pin_cap = cap;
+        } else {
+            (void)hipGetLastError();
+            if (hp) (void)hipHostFree(hp);
+        }
+    }
+    const bool mb = s->auto_pin != nullptr;
+    const bool mapped = mb && n <= 4;
+    std::vector<char> host_io(mb ? 0 : pin_need);
+    char* const hbase = mb ? static_cast<char*>(s->auto_pin) : host_io.data();
+    double* const sw_h = reinterpret_cast<double*>(hbase);
+    char* const out_h = hbase + sw_bytes;
+    char* const out_map = mb ? static_cast<char*>(s->auto_pin_dev) + sw_bytes : nullptr;
+    double* const sw_d = reinterpret_cast<double*>(io);
+    size_t free_b = 0, total_b = 0;               // asked for when a rule has to be built
+    const uint64_t call_stamp = s->kept_stamp + 1;  // rules stamped from here on serve this call
+    bool sweeps_current = false;                    // sw_d holds the values of `active`
 
-    // Value of the rule of grid `npt` for the active solves.  `slot` 0 / 1: staging halves, so that the first two grids can be
-    // in flight together.  Rule-based grids leave their sums in HBM (`pending`), store-free ones return them on the host.
+    // Value of the rule of grid `npt` for the active solves.  `slot` 0 / 1: so that the first two grids can be in flight
+    // together.  Rule-based grids leave their sums pending (mailbox or HBM), store-free ones return them on the host.
     struct Pending {
-        bool on_device = false;
-        int nact = 0;
+        bool pending = false;
     };
     auto grid_value = [&](int npt, int gindex, int slot, const std::vector<int>& act, double2* host_vals, int64_t* nk_out, Pending* pend) -> int {
         const int na = (int)act.size();
         int64_t nk_full = 1;
         for (int j = 0; j < d; ++j) nk_full *= npt;
-        double* const sw_h = reinterpret_cast<double*>(hio + (size_t)slot * sw_bytes);
-        for (int i = 0; i < na; ++i) sw_h[i] = swept ? sweeps[act[(size_t)i]] : 0.0;
         bool have = false;
         for (const SeriesRule& k : s->kept_rules)
             have = have || (k.npt == npt && (k.want & want) == want && k.syms.size() == (syms ? (size_t)nsyms * d * d : 0) &&
                             std::equal(k.syms.begin(), k.syms.end(), syms));
-        const size_t rbytes = rule_value_bytes(s, npt, nk_full, want);  // upper bound for symmetric rules
-        const bool fits = rbytes < free_b / 2;
-        const bool keep = gindex < keepmost && fits;
         const bool sum_ok = !syms && (n > 4 ? gen_sum_supported(n, s->dims[0], npt, integrand, s->hermitian)
                                             : eval_sum_supported(n, s->dims[0], npt, integrand, s->hermitian));
+        const size_t rbytes = rule_value_bytes(s, npt, nk_full, want);  // upper bound for symmetric rules
+        if (!have && free_b == 0) (void)hipMemGetInfo(&free_b, &total_b);
+        const bool fits = have || rbytes < free_b / 2;
+        // kept: the first `keepmost` grids like the reference's cache, and any further one while the series' kept rules
+        // stay below a quarter of the device memory (288 GB of HBM are there to keep rule values resident: a sweep or a
+        // repeated solve then finds every grid of its sequence) -- least recently used rules of other grids make room
+        bool keep = fits && gindex < keepmost;
+        if (!have && fits && !keep) {
+            size_t kept = 0;
+            for (const SeriesRule& k : s->kept_rules) kept += (size_t)(sizeof(double) * k.r->ntiles * k.r->planes * (k.r->H.base ? k.r->H.row : k.r->E.row));
+            const size_t budget = total_b / 4;
+            while (kept + rbytes > budget && !s->kept_rules.empty()) {
+                size_t victim = s->kept_rules.size();
+                for (size_t i = 0; i < s->kept_rules.size(); ++i)
+                    if (s->kept_rules[i].stamp < call_stamp && (victim == s->kept_rules.size() || s->kept_rules[i].stamp < s->kept_rules[victim].stamp)) victim = i;
+                if (victim == s->kept_rules.size()) break;  // everything left serves this very call
+                abz_rule* vr = s->kept_rules[victim].r;
+                kept -= (size_t)(sizeof(double) * vr->ntiles * vr->planes * (vr->H.base ? vr->H.row : vr->E.row));
+                (void)hipStreamSynchronize(ctx->stream);
+                rule_free(vr);
+                s->kept_rules.erase(s->kept_rules.begin() + (long)victim);
+            }
+            keep = kept + rbytes <= budget;
+            // ... from its SECOND visit on where it can be summed on the fly: a one-off solve should not pay for storing it
+            if (keep && sum_ok && na <= 8 && n <= 4 && std::find(s->summed_once.begin(), s->summed_once.end(), npt) == s->summed_once.end()) {
+                keep = false;
+                if (s->summed_once.size() < 64) s->summed_once.push_back(npt);
+            }
+        }
         // a grid used once: on the fly when few values share it (the store-free kernel takes 8 per pass), when it would not
         // fit, or above four bands (the panel kernels beat build + scan at any size)
         if (!have && !keep && sum_ok && (na <= 8 || !fits || n > 4)) {
-            int rc2 = abz_ptr_sum(s, npt, 0, npt, integrand, params, nparams, sw_h, na, ns_eff, reinterpret_cast<double*>(host_vals));
+            std::vector<double> swv((size_t)na);
+            for (int i = 0; i < na; ++i) swv[(size_t)i] = swept ? sweeps[act[(size_t)i]] : 0.0;
+            int rc2 = abz_ptr_sum(s, npt, 0, npt, integrand, params, nparams, swv.data(), na, ns_eff, reinterpret_cast<double*>(host_vals));
             if (rc2 == ABZ_OK) {
                 *nk_out = nk_full;
-                pend->on_device = false;
+                pend->pending = false;
                 return ABZ_OK;
             }
             if (rc2 != ABZ_ERR_UNSUPPORTED) return rc2;
@@ -1572,35 +1630,36 @@ int abz_autoptr_solve_many(abz_series* s, const int32_t* syms, int nsyms, int in
         int rc2 = series_rule(s, npt, syms, nsyms, want, keep, &r, &owned);
         if (rc2) return rc2;
         *nk_out = r->nk;
-        double* const sw_d = reinterpret_cast<double*>(io + (size_t)slot * sw_bytes);
-        double* const out_d = reinterpret_cast<double*>(io + 2 * sw_bytes + (size_t)slot * out_bytes);
-        if (swept) {
-            if (mb) {
-                rc2 = hipMemcpyAsync(sw_d, sw_h, sizeof(double) * (size_t)na, hipMemcpyHostToDevice, ctx->stream) == hipSuccess ? ABZ_OK : ABZ_ERR_HIP;
-            } else {
-                rc2 = hipMemcpy(sw_d, sw_h, sizeof(double) * (size_t)na, hipMemcpyHostToDevice) == hipSuccess ? ABZ_OK : ABZ_ERR_HIP;
+        if (swept && !sweeps_current) {
+            for (int i = 0; i < na; ++i) sw_h[i] = sweeps[act[(size_t)i]];
+            hipError_t he = mb ? hipMemcpyAsync(sw_d, sw_h, sizeof(double) * (size_t)na, hipMemcpyHostToDevice, ctx->stream)
+                               : hipMemcpy(sw_d, sw_h, sizeof(double) * (size_t)na, hipMemcpyHostToDevice);
+            if (he != hipSuccess) {
+                set_error("abz_autoptr_solve_many: upload of the swept values failed: %s", hipGetErrorString(he));
+                rc2 = ABZ_ERR_HIP;
             }
-            if (rc2) set_error("abz_autoptr_solve_many: upload of the swept values failed");
+            sweeps_current = true;
         }
-        if (!rc2) rc2 = rule_reduce(r, integrand, params, nparams, sw_d, swept ? na : 1, ns_eff, out_d, true);
+        double* const out_d = reinterpret_cast<double*>(io + sw_bytes + (size_t)slot * out_bytes);
+        double2* const map = mapped ? reinterpret_cast<double2*>(out_map + (size_t)slot * out_bytes) : nullptr;
+        if (!rc2) rc2 = rule_reduce(r, integrand, params, nparams, sw_d, swept ? na : 1, ns_eff, out_d, true, map);
         if (owned) {  // a rule for this grid only: its blocks go back to the allocator once the stream has drained
             (void)hipStreamSynchronize(ctx->stream);
             rule_free(r);
         }
         if (rc2) return rc2;
-        pend->on_device = true;
-        pend->nact = na;
+        pend->pending = true;
         return ABZ_OK;
     };
-    // sums of the pending slots to the host: one copy + one synchronisation
+    // sums of the pending slots to the host: one synchronisation (+ one copy when they were left in HBM)
     auto fetch = [&](int first_slot, int nslots) -> int {
-        char* const src = io + 2 * sw_bytes + (size_t)first_slot * out_bytes;
-        char* const dst = hio + 2 * sw_bytes + (size_t)first_slot * out_bytes;
-        ABZ_HIP(hipMemcpyAsync(dst, src, (size_t)nslots * out_bytes, hipMemcpyDeviceToHost, ctx->stream));
+        if (!mapped)
+            ABZ_HIP(hipMemcpyAsync(out_h + (size_t)first_slot * out_bytes, io + sw_bytes + (size_t)first_slot * out_bytes,
+                                   (size_t)nslots * out_bytes, hipMemcpyDeviceToHost, ctx->stream));
         ABZ_HIP(hipStreamSynchronize(ctx->stream));
         return ABZ_OK;
     };
-    auto host_out = [&](int slot) { return reinterpret_cast<const double2*>(hio + 2 * sw_bytes + (size_t)slot * out_bytes); };
+    auto host_out = [&](int slot) { return reinterpret_cast<const double2*>(out_h + (size_t)slot * out_bytes); };
     auto norm_of = [&](const double2* v) {
         double acc = 0.0;
         for (size_t c = 0; c < ncs; ++c) acc += v[c].x * v[c].x + v[c].y * v[c].y;
@@ -1615,10 +1674,10 @@ int abz_autoptr_solve_many(abz_series* s, const int32_t* syms, int nsyms, int in
     if ((rc = grid_value(npt, 0, 0, active, hv0.data(), &nk0, &p0))) return rc;
     npt += dn;
     if ((rc = grid_value(npt, 1, 1, active, hv1.data(), &nk1, &p1))) return rc;
-    if (p0.on_device || p1.on_device) {
-        if ((rc = fetch(p0.on_device ? 0 : 1, (p0.on_device && p1.on_device) ? 2 : 1))) return rc;
-        if (p0.on_device) std::memcpy(hv0.data(), host_out(0), out_bytes);
-        if (p1.on_device) std::memcpy(hv1.data(), host_out(1), out_bytes);
+    if (p0.pending || p1.pending) {
+        if ((rc = fetch(p0.pending ? 0 : 1, (p0.pending && p1.pending) ? 2 : 1))) return rc;
+        if (p0.pending) std::memcpy(hv0.data(), host_out(0), out_bytes);
+        if (p1.pending) std::memcpy(hv1.data(), host_out(1), out_bytes);
     }
     for (int i = 0; i < n_sweep; ++i) {
         for (size_t c = 0; c < ncs; ++c) {
@@ -1632,8 +1691,6 @@ int abz_autoptr_solve_many(abz_series* s, const int32_t* syms, int nsyms, int in
     while (true) {
         std::vector<int> next;
         for (int i : active) {
-            double2 diff[ABZ_MAX_BANDS * ABZ_MAX_BANDS > 16 ? 16 : 16];
-            (void)diff;
             double e2 = 0.0;
             double2 dv0 = make_double2(0.0, 0.0);
             for (size_t c = 0; c < ncs; ++c) {
@@ -1659,8 +1716,9 @@ int abz_autoptr_solve_many(abz_series* s, const int32_t* syms, int nsyms, int in
         gindex += 1;
         Pending pp;
         int64_t nk = 0;
+        sweeps_current = false;  // the active set shrank (or the staging was reused)
         if ((rc = grid_value(npt, gindex, 0, active, vals.data(), &nk, &pp))) return rc;
-        if (pp.on_device) {
+        if (pp.pending) {
             if ((rc = fetch(0, 1))) return rc;
             std::memcpy(vals.data(), host_out(0), sizeof(double2) * active.size() * ncs);
         }

@@ -2028,6 +2028,7 @@ int launch_reduce(abz_ctx* ctx, const ReduceSpec& rs, double* out_reim) {
         return ABZ_OK;
     }
     if (rs.out_map_dev) {  // the last kernel wrote the sums into the pinned mailbox: one synchronisation, no copy call
+        if (!rs.out_map_host) return ABZ_OK;  // ... which the caller does itself, after enqueueing more work
         ABZ_HIP(hipStreamSynchronize(ctx->stream));
         std::memcpy(out_reim, rs.out_map_host, sizeof(double2) * (size_t)ncols);
         return ABZ_OK;

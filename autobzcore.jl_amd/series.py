@@ -276,6 +276,8 @@ class DeviceSeries:
             r.close()
         self.rules.clear()
         self.rule_bytes = 0
+        if self._h is not None:  # ... and the rules the library keeps for its whole-solve entry points
+            L.check(L.lib().abz_series_drop_rules(self.h))
 
 
 def slab_range(n, rank, world):

@@ -575,6 +575,11 @@ def _shape_value(f: FourierIntegrand, vals):
     return complex(v)
 
 
+def _ncomp(fi, n, d):
+    """Components of a device integrand's value (integrand_ncomp of the library)."""
+    return {L.F_GLOC: n * n, L.F_LINEAR_X: d}.get(fi.fid, 1)
+
+
 def _want_for(fi):
     return L.WANT_EIG if isinstance(fi, DOSIntegrand) and fi.form == "eig" else L.WANT_H
 
@@ -973,6 +978,52 @@ def _do_solve_generic(f, dom, p, alg, counter, abstol, reltol, maxiters):
     return IntegralSolution(u, err, True, nev if counter else -1)
 
 
+def _autoptr_library(f, dev, bz, plist, alg, abstol, reltol, maxiters, symmetrize, j, scale_tol):
+    """The whole AutoPTR loop inside the library (abz_autoptr_solve_many: grid sequence, rules kept by the series,
+    store-free sums for grids used once, error test, numevals -- one C call per batch of parameter sets, one stream
+    synchronisation per converged two-grid solve).  Applies to the library's own integrands with the default norm on an
+    unsharded series whose symmetrisation is a number (TrivialRep: the value of every rule times nsyms,
+    src/brillouin.jl:127-130); returns None otherwise and the host loop below drives the same rules one call at a time."""
+    fi = f.f.f
+    if not isinstance(fi, DeviceIntegrand) or alg.norm is not None or dev.kshard is not None:
+        return None
+    if symmetrize and bz.syms is not None and fi.matrix:
+        return None  # matrix-valued integrals on a symmetric BZ: UnknownRep (redo on the FBZ) or a user representation
+    bound = [fi.bind(p) for p in plist]
+    if any(tuple(b[0]) != tuple(bound[0][0]) for b in bound):
+        return None
+    params = np.ascontiguousarray(bound[0][0], dtype=np.float64)
+    if fi.swept:
+        sweeps = np.ascontiguousarray([b[1] for b in bound], dtype=np.float64)
+        nsolve = len(plist)
+    else:
+        sweeps = np.zeros(1)
+        nsolve = 1  # no swept parameter: every entry of plist is the same integral
+    n0, dn = alg.npt_sequence()
+    atol = -1.0 if abstol is None else (abstol / j if scale_tol else abstol)
+    rtol = -1.0 if reltol is None else float(reltol)
+    syms = None if bz.syms is None else np.ascontiguousarray(np.asarray(bz.syms), dtype=np.int32)
+    nsy = 0 if syms is None else len(bz.syms)
+    factor = float(nsyms(bz)) if (symmetrize and bz.syms is not None) else 1.0
+    ncomp = _ncomp(fi, f.w.n, f.w.d)
+    out = np.zeros((nsolve, ncomp), dtype=np.complex128)
+    err = np.zeros(nsolve)
+    nev = np.zeros(nsolve, dtype=np.int64)
+    npt = np.zeros(nsolve, dtype=np.int32)
+    L.check(L.lib().abz_autoptr_solve_many(
+        dev.h, None if syms is None else syms.ctypes.data_as(L.c_i32p), nsy, fi.fid, params.ctypes.data_as(L.c_f64p), len(params),
+        sweeps.ctypes.data_as(L.c_f64p), nsolve, n0, dn, atol, rtol, int(min(maxiters, 2**62)), int(alg.keepmost), factor,
+        out.view(np.float64).ctypes.data_as(L.c_f64p), err.ctypes.data_as(L.c_f64p), nev.ctypes.data_as(L.c_i64p),
+        npt.ctypes.data_as(L.c_i32p)))
+    sols = []
+    for i in range(len(plist)):
+        k = i if fi.swept else 0
+        sol = IntegralSolution(_shape_value(f, out[k]) * j, float(err[k]) * j, True, int(nev[k]))
+        sol.extra = {"npt": int(npt[k])}
+        sols.append(sol)
+    return sols
+
+
 def _autoptr_many(f, dev, bz, plist, alg: AutoPTR, abstol, reltol, maxiters, symmetrize=True, jac=None,
                   scale_tol=True):
     """autosymptr for a batch of parameter sets in lockstep: every grid is built (or found in the
@@ -985,6 +1036,9 @@ def _autoptr_many(f, dev, bz, plist, alg: AutoPTR, abstol, reltol, maxiters, sym
     norm = alg.norm or _norm
     j = abs(np.linalg.det(bz.B)) if jac is None else jac
     ns = nsyms(bz) if symmetrize else 1
+    fast = _autoptr_library(f, dev, bz, plist, alg, abstol, reltol, maxiters, symmetrize, j, scale_tol)
+    if fast is not None:
+        return fast
     if abstol is None and reltol is None:
         rtol, atol = math.sqrt(np.finfo(float).eps), 0.0
     else:

@@ -65,6 +65,7 @@ def parse_args():
                          "(under `python -m torch.distributed.run --nproc-per-node 1`): the RCCL calls on one GPU")
     ap.add_argument("--big-npt", type=int, default=400, help="grid of the fine-grid 256-omega job (eta = 0.01)")
     ap.add_argument("--no-big-job", action="store_true")
+    ap.add_argument("--no-scaling-model", action="store_true", help="skip the 8-GPU scaling model from one-GPU shard timings (N = 1; ~40 s)")
     ap.add_argument("--no-c5-shard", action="store_true", help="skip config 5 as one sharded solve (N > 1 only; ~11 s for its N = 1 leg)")
     ap.add_argument("--c5-abstol", type=float, default=1e-3, help="config 5 (16-band IAI) tolerance; SURVEY 8d: 1e-3")
     return ap.parse_args()
@@ -553,6 +554,12 @@ def rank_main(a):
         }
         if world == 1 and not a.no_extras and not a.force_dist:
             extras(a, abz, L, s, ctx, out, nk)
+            if not a.no_scaling_model:
+                try:
+                    dev.drop_rules()  # the model's jobs build their own rules (the 400^3 one needs the room)
+                    out["scaling_model"] = scaling_model(a, abz, L, torch, s, ctx, dev, npt, local)
+                except Exception as e:
+                    out["scaling_model"] = {"error": repr(e)}
         if not a.no_cpu and world == 1 and not a.force_dist:  # the CPU leg is timed at N = 1 only
             try:
                 cb = cpu_baseline(npt, s, a.eta)
@@ -622,6 +629,257 @@ def big_dos_job(a, abz, L, torch, dist, dev, rank, world, local, distributed, cd
             res["k_sharded"] = {"seconds": tk, "speedup_vs_n1": res["seconds_n1"] / tk, "max_rel_diff_vs_n1": err,
                                 "kpoint_omega_per_sec": npt**3 * 256 / tk}
     return res if rank == 0 else None
+
+
+def virtual_rank_iai(abz, L, W, make_series, eta, omega, abstol, lims):
+    """ONE IAI solve sharded over W virtual ranks on ONE GPU, the ranks' shares computed one after another.
+
+    Every virtual rank is a host thread with its own device context and its own copy of the series, wired to the library's
+    exchange hook (abz_iai_set_exchange(rank = r, world = W)) exactly like a rank process of `dist.iaishard`; the all-gather
+    is a shared host buffer.  A token serialises the ranks: rank r holds it from the moment a round's gather is complete
+    until it has computed its own share of the next round and written it -- so the wall time a rank holds the token is its
+    per-round cost (replicated host bookkeeping + its kernels) with the GPU to itself.  Returns per-rank seconds, exchanges,
+    the value and numevals (identical on every rank by construction)."""
+    import ctypes as C
+    import threading
+    from autobzcore.jl_amd import solver as S
+    cond = threading.Condition()
+    st = {"turn": 0, "round": 0, "written": 0, "shared": None, "err": None}
+    held = [0.0] * W
+    t_got = [0.0] * W
+    rounds = [0] * W
+    results = [None] * W
+
+    def take(r):
+        with cond:
+            cond.wait_for(lambda: st["turn"] == r or st["err"])
+            t_got[r] = time.perf_counter()
+
+    def make_cb(r):
+        def cb(user, buf, per):
+            try:
+                arr = np.ctypeslib.as_array(buf, shape=(W * per,))
+                with cond:
+                    if st["shared"] is None or len(st["shared"]) != W * per:
+                        st["shared"] = np.zeros(W * per)
+                    st["shared"][r * per:(r + 1) * per] = arr[r * per:(r + 1) * per]
+                    st["written"] += 1
+                    held[r] += time.perf_counter() - t_got[r]
+                    rounds[r] += 1
+                    my_round = st["round"]
+                    if st["written"] == W:  # the last rank of the round completes the gather
+                        st["written"] = 0
+                        st["round"] += 1
+                        st["full"] = st["shared"].copy()
+                        st["shared"] = None
+                        st["turn"] = 0
+                    else:
+                        st["turn"] = r + 1
+                    cond.notify_all()
+                    cond.wait_for(lambda: st["round"] > my_round or st["err"])
+                    arr[:] = st["full"]
+                    cond.wait_for(lambda: st["turn"] == r or st["err"])  # my turn for the next round
+                    t_got[r] = time.perf_counter()
+                    if st["err"]:
+                        return 1
+                return 0
+            except Exception as e:  # never let an exception cross the C boundary
+                with cond:
+                    st["err"] = repr(e)
+                    cond.notify_all()
+                return 1
+        return cb
+
+    bar = threading.Barrier(W)
+
+    def worker(r):
+        try:
+            ctx = L.Context()
+            sr = make_series()
+            dev = sr.device(ctx)
+            cb = L.EXCHANGE_FN(make_cb(r))
+            L.check(L.lib().abz_iai_set_exchange(dev.h, cb, None, r, W))
+            f = abz.FourierIntegrand(abz.DOSIntegrand(), sr, eta)
+            for rep in range(2):  # the first pass sizes every pool and staging buffer of the rank's context
+                bar.wait()
+                if r == 0:
+                    with cond:
+                        st.update({"turn": 0, "round": 0, "written": 0, "shared": None})
+                bar.wait()
+                held[r] = 0.0
+                rounds[r] = 0
+                take(r)
+                u, err, nev, _ = S._iai_device(f, dev, lims, f.f.p.merge(abz.MixedParameters(omega)), abstol, 0.0, 2**62)
+                with cond:  # the tail after the last exchange (every rank finishes the solve on its own)
+                    held[r] += time.perf_counter() - t_got[r]
+                    st["turn"] = r + 1
+                    cond.notify_all()
+                results[r] = (u, err, nev)
+            L.check(L.lib().abz_iai_set_exchange(dev.h, None, None, 0, 1))
+            dev.close()
+            ctx.close()
+        except Exception as e:
+            with cond:
+                st["err"] = repr(e)
+                cond.notify_all()
+            try:
+                bar.abort()
+            except Exception:
+                pass
+
+    threads = [threading.Thread(target=worker, args=(r,)) for r in range(W)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    if st["err"]:
+        raise RuntimeError(st["err"])
+    assert all(res == results[0] for res in results), "virtual ranks disagree"
+    return {"per_rank_s": held, "exchanges": rounds[0], "u": results[0][0], "numevals": results[0][2]}
+
+
+def scaling_model(a, abz, L, torch, s, ctx, dev, npt, local):
+    """An 8-GPU scaling MODEL from one-GPU shard timings: every virtual rank's share of each sharded job
+    is timed alone on this GPU, one after another; predicted time at W = 8 = the slowest share + collectives x latency."""
+    W = 8
+    out = {"label": "MODEL, NOT MEASUREMENT: shares of W = 8 virtual ranks timed one after another on ONE MI355X; predicted_s = "
+                    "max(per_rank_s) + collectives * latency; predicted_speedup_8 = n1_s / predicted_s.  The collective latency of an "
+                    "8-GPU xGMI node was not measurable here: the model is evaluated for the RCCL call cost measured at ONE rank (a "
+                    "lower bound) and for an assumed 30 us per small-message collective", "world": W}
+    # --- cost of one small RCCL collective at ONE rank (call + kernel on the stream; no wire)
+    lat = None
+    try:
+        import torch.distributed as dist
+        own = not dist.is_initialized()
+        if own:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", str(29500 + (os.getpid() % 2000)))
+            dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device(f"cuda:{local}"))
+        t = torch.zeros(256, 2, dtype=torch.float64, device=f"cuda:{local}")
+        g = torch.zeros(32, 2, dtype=torch.float64, device=f"cuda:{local}")
+        go = [torch.zeros_like(g)]
+        for _ in range(20):
+            dist.all_reduce(t)
+            dist.all_gather(go, g)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(200):
+            dist.all_reduce(t)
+            torch.cuda.synchronize()
+        lat_ar = (time.perf_counter() - t0) / 200
+        t0 = time.perf_counter()
+        for _ in range(200):
+            dist.all_gather(go, g)
+            torch.cuda.synchronize()
+        lat_ag = (time.perf_counter() - t0) / 200
+        lat = {"all_reduce_4KB_s": lat_ar, "all_gather_512B_s": lat_ag, "ranks": 1,
+               "note": "RCCL at world size 1 incl. the stream synchronisation that follows it in the jobs"}
+        if own:
+            dist.destroy_process_group()
+    except Exception as e:
+        lat = {"error": repr(e)}
+    out["rccl_latency_s"] = lat
+    lat1 = (lat or {}).get("all_reduce_4KB_s") or 20e-6
+    ASSUMED = 30e-6
+
+    def predict(n1, per, ncoll):
+        mx, mean = max(per), sum(per) / len(per)
+        return {"n1_s": n1, "per_rank_s": per, "imbalance_max_over_mean": mx / mean, "collectives": ncoll,
+                "predicted_s_at_measured_1rank_latency": mx + ncoll * lat1, "predicted_speedup_8_at_measured_1rank_latency": n1 / (mx + ncoll * lat1),
+                "predicted_s_at_30us": mx + ncoll * ASSUMED, "predicted_speedup_8_at_30us": n1 / (mx + ncoll * ASSUMED)}
+
+    om256 = np.linspace(10.0, 15.0, 256)
+    om_dev = torch.from_numpy(om256).to(f"cuda:{local}")
+    acc = torch.zeros(256, 2, dtype=torch.float64, device=f"cuda:{local}")
+    WANT = L.WANT_H | L.WANT_EIG
+
+    def dos_job(grid, eta, reps):
+        def run(rule):
+            def job():
+                rule.rebuild()
+                rule.reduce_device(L.F_DOS, [eta], om_dev.data_ptr(), 256, acc.data_ptr())
+                return acc[:, 0].cpu().numpy()
+            for _ in range(3):
+                job()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                r = job()
+            return (time.perf_counter() - t0) / reps, r
+        full = dev.rule(grid, None, WANT)
+        n1, ref = run(full)
+        dev.drop_rules()
+        per, tot = [], np.zeros(256)
+        for r in range(W):
+            dev.kshard = (r, W)
+            rk = abz.DeviceRule(dev, grid, None, WANT)
+            dev.kshard = None
+            t, v = run(rk)
+            rk.close()
+            per.append(t)
+            tot += v
+        assert np.abs(tot - ref).max() <= 1e-11 * np.abs(ref).max()
+        return predict(n1, per, 1)
+
+    try:
+        m = dos_job(npt, a.eta, 40)
+        m["what"] = f"(a) 256-omega DOS job on the {npt}^3 grid, k-sharded (slab of the outermost variable per rank, one all_reduce of 256 sums)"
+        out["job_256_omega_k_sharded"] = m
+    except Exception as e:
+        out["job_256_omega_k_sharded"] = {"error": repr(e)}
+    if not a.no_big_job:
+        try:
+            m = dos_job(a.big_npt, 0.01, 4)
+            m["what"] = f"(b) the same at eta = 0.01 on the {a.big_npt}^3 grid"
+            out["job_256_omega_fine_grid_k_sharded"] = m
+        except Exception as e:
+            out["job_256_omega_fine_grid_k_sharded"] = {"error": repr(e)}
+    if not a.no_iai:
+        # (c) config 5 as one solve sharded over the ranks: the driver's dealing rule, per-round exchange
+        try:
+            s16 = abz.synthetic_wannier()
+            f16 = abz.FourierIntegrand(abz.DOSIntegrand(), s16, 0.05)
+            lims = abz.load_bz(abz.FBZ(), np.eye(3)).lims
+            from autobzcore.jl_amd import solver as S
+            pm16 = f16.f.p.merge(abz.MixedParameters(0.2))
+            S._iai_device(f16, s16.device(), lims, pm16, 10.0, 0.0, 2**62)
+            t0 = time.perf_counter()
+            u1, _, nev1, _ = S._iai_device(f16, s16.device(), lims, pm16, a.c5_abstol, 0.0, 2**62)
+            n1 = time.perf_counter() - t0
+            vr = virtual_rank_iai(abz, L, W, abz.synthetic_wannier, 0.05, 0.2, a.c5_abstol, lims)
+            assert vr["u"] == u1 and vr["numevals"] == nev1, (vr["u"], u1)
+            m = predict(n1, vr["per_rank_s"], vr["exchanges"])
+            m.update({"what": "(c) config 5 (synthetic 16-band IAI, abstol %g) as ONE solve: every round's innermost integrals dealt to the "
+                              "ranks in blocks of 64 nodes (owner(t) = (t >> 6) mod W), one all-gather per round; a rank's seconds = its "
+                              "replicated host bookkeeping + its own kernels, alone on the GPU" % a.c5_abstol,
+                      "exchanges": vr["exchanges"], "numevals": vr["numevals"], "bit_identical_to_n1": True})
+            out["iai_config5_one_solve_sharded"] = m
+        except Exception as e:
+            out["iai_config5_one_solve_sharded"] = {"error": repr(e)}
+        # (d) the 432-omega IAI sweep of the reference's example, round-robin like batchparam
+        try:
+            fiai = abz.FourierIntegrand(abz.DOSIntegrand(), s, 0.01)
+            bzc = abz.load_bz(abz.CubicSymIBZ(), 3.85856 * np.eye(3))
+            sol_iai = abz.IntegralSolver(fiai, bzc, abz.IAI(), abstol=1e-3)
+            om432 = np.linspace(10.0, 15.0, 432)
+            abz.batchsolve(sol_iai, om432)
+            t0 = time.perf_counter()
+            r1 = abz.batchsolve(sol_iai, om432)
+            n1 = time.perf_counter() - t0
+            per = []
+            got = np.zeros(432)
+            for r in range(W):
+                abz.batchsolve(sol_iai, om432[r::W])
+                t0 = time.perf_counter()
+                got[r::W] = abz.batchsolve(sol_iai, om432[r::W])
+                per.append(time.perf_counter() - t0)
+            assert np.array_equal(got, np.asarray(r1, dtype=float))
+            m = predict(n1, per, 1)
+            m["what"] = "(d) 432-omega IAI sweep on the cubic IBZ, rank r solves omega[r::8] (batchparam), one all_gather of 54 results"
+            out["iai_sweep_432_omega_sharded"] = m
+        except Exception as e:
+            out["iai_sweep_432_omega_sharded"] = {"error": repr(e)}
+    return out
 
 
 def extras(a, abz, L, s, ctx, out, nk):
@@ -717,11 +975,25 @@ def extras(a, abz, L, s, ctx, out, nk):
             s.device().drop_rules()
             t0 = time.perf_counter()
             r3 = sol3.solve_p(abz.MixedParameters(12.5))
-            tc = time.perf_counter() - t0
+            tfirst = time.perf_counter() - t0  # the first solve of its kind in the process (symmetric tables, staging blocks)
+            s.device().drop_rules()
             t0 = time.perf_counter()
             r3 = sol3.solve_p(abz.MixedParameters(12.5))
-            cfg["config3_svo_autoptr_" + kind] = {"u": r3.u, "resid": r3.resid, "numevals": r3.numevals,
-                                                 "seconds_cold": tc, "seconds_cached_rules": time.perf_counter() - t0}
+            tc = time.perf_counter() - t0
+            # cached: the rules of the grid sequence are resident (a grid beyond `keepmost` is kept from its second visit on)
+            for _ in range(3):
+                r3 = sol3.solve_p(abz.MixedParameters(12.5))
+            tcs = []
+            for _ in range(50):
+                t0 = time.perf_counter()
+                r3 = sol3.solve_p(abz.MixedParameters(12.5))
+                tcs.append(time.perf_counter() - t0)
+            cfg["config3_svo_autoptr_" + kind] = {"u": r3.u, "resid": r3.resid, "numevals": r3.numevals, "grids": r3.extra.get("npt"),
+                                                 "seconds_first_in_process": tfirst, "seconds_cold": tc,
+                                                 "seconds_cached_rules": sorted(tcs)[len(tcs) // 2],
+                                                 "note": "one abz_autoptr_solve_many call per solve (grid sequence, error test, numevals in "
+                                                         "the library); first = incl. the symmetric-rule tables and staging blocks of the "
+                                                         "context; cold = every rule dropped, tables cached; cached = median of 50"}
         out["configs_end_to_end"] = cfg
     except Exception as e:
         out["configs_end_to_end"] = {"error": str(e)}

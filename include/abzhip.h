@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define ABZ_VERSION 301
+#define ABZ_VERSION 401
 
 /* status codes */
 #define ABZ_OK 0
@@ -199,6 +199,33 @@ int abz_rule_reduce_device(abz_rule* r, int integrand, const double* params, int
  * ABZ_WANT_H_COMPACT the H planes of a tile are the n^2 upper-triangle planes in the order given at that flag):
  * zero-copy views for a device-side harness, and the placement log of bench.py. */
 int abz_rule_values_ptr(const abz_rule* r, void** base, int64_t* nbytes);
+
+/* Whole AutoPTR solve(s) inside the library: the p-adaptive loop of AutoSymPTR.autosymptr on the library's own integrands.
+ * Replaces: do_solve(::FourierIntegrand, ::Basis, p, ::AutoSymPTRJL, cacheval) (src/fourier.jl:385-389, src/algorithms.jl:
+ * 418-432) with its rule family (src/fourier.jl:296-321): I1 = rule(n0), I2 = rule(n0 + dn), err = norm(I2 - I1); while
+ * err > max(abstol, reltol norm(I2)) and numevals < maxevals: I1 = I2, I2 = rule(next npt).  n0 / dn are the INTEGERS of
+ * MonkhorstPackRule (defaults 50 / 50).  abstol < 0 / reltol < 0 mean `nothing` (both nothing: reltol = sqrt(eps)).
+ * syms [nsyms][d][d] row-major (NULL: the full grid): symmetric rules with integer weights, dvol = 1 / (npt^d nsyms)
+ * (src/fourier.jl:289-292); every rule value is multiplied by `value_factor` before the error is formed -- nsyms for the
+ * TrivialRep symmetrisation inside a SymmetricRule (src/brillouin.jl:127-130), 1 otherwise.  The caller applies |det B|
+ * (abstol / |det B| in, I |det B| out: src/brillouin.jl:429-444).
+ * Rules of the first `keepmost` grids (the reference's `keepmost` = 2) stay with the series and serve every later call
+ * (they refill themselves after abz_series_update); a larger grid is summed on the fly where the store-free kernel applies
+ * and few values share it, otherwise built, scanned and dropped.  The first two grids are in flight together: a converged
+ * solve with cached rules costs two scan launches and ONE stream synchronisation.
+ * The _many form solves for n_sweep values of the swept parameter in lock-step (batchsolve, src/interfaces.jl:210-222):
+ * each solve makes exactly the decisions it would make alone; a grid is visited once for all solves still active.
+ * out_reim [n_sweep][ncomp][2], err [n_sweep] (norm(I2 - I1), nullable), numevals [n_sweep] (sum of the node counts of the
+ * rules used, nullable), npt_last [n_sweep] (nullable). */
+int abz_autoptr_solve(abz_series* s, const int32_t* syms, int nsyms, int integrand, const double* params, int nparams,
+                      double sweep, int n0, int dn, double abstol, double reltol, int64_t maxevals, int keepmost,
+                      double value_factor, double* out_reim, double* err, int64_t* numevals, int32_t* npt_last);
+int abz_autoptr_solve_many(abz_series* s, const int32_t* syms, int nsyms, int integrand, const double* params, int nparams,
+                           const double* sweeps, int n_sweep, int n0, int dn, double abstol, double reltol,
+                           int64_t maxevals, int keepmost, double value_factor, double* out_reim, double* err,
+                           int64_t* numevals, int32_t* npt_last);
+/* Drop the rules the series keeps for abz_autoptr_solve* (they are also dropped by abz_series_destroy). */
+int abz_series_drop_rules(abz_series* s);
 
 /* Store-free rule value: the same number as abz_rule_reduce on the full grid (or on the slab
  * [outer_begin, outer_end) of its outermost variable), computed without materialising H(k): the

@@ -180,25 +180,38 @@ function AutoBZCore.do_solve(f::HIPFourierIntegrand, bz::SymmetricBZ, p, alg::PT
     return IntegralSolution(j * nsyms(bz) * real(u), nothing, true, r.nk)   # TrivialRep: src/brillouin.jl:107
 end
 
+"""
+The p-adaptive loop of `AutoPTR` runs inside the library (`abz_autoptr_solve_many`: grid sequence, rules kept by the series,
+store-free sums for grids used once, error test, `numevals`) -- the ONE implementation the Python mirror and its tests
+drive as well (round 3 had a second, untested copy of the loop here).  `omegas`: one solve per swept value, in lock-step.
+"""
+function autoptr_solve(hs::HIPSeries{d}, f::HIPIntegrand, params::Vector{Float64}, omegas::Vector{Float64}, bz::SymmetricBZ,
+    alg::AutoPTR; abstol=nothing, reltol=nothing, maxiters=typemax(Int)) where {d}
+    j = abs(det(bz.B))
+    n0 = clamp(round(Int, alg.n₀ / alg.a), alg.nmin, alg.nmax)       # MonkhorstPackRule's integers, src/fourier.jl:301-321
+    dn = clamp(round(Int, alg.Δn / alg.a), alg.nmin, alg.nmax)
+    syms = bz.syms === nothing ? Cint[] : Cint[round(Int, M[a, b]) for M in bz.syms for a in 1:d for b in 1:d]
+    ns = bz.syms === nothing ? 0 : length(bz.syms)
+    nsolve = length(omegas)
+    out = Vector{ComplexF64}(undef, nsolve); err = Vector{Float64}(undef, nsolve)
+    nev = Vector{Int64}(undef, nsolve); npt = Vector{Cint}(undef, nsolve)
+    GC.@preserve syms params omegas out err nev npt begin
+        check(ccall((:abz_autoptr_solve_many, libabz), Cint,
+            (Ptr{Cvoid}, Ptr{Cint}, Cint, Cint, Ptr{Float64}, Cint, Ptr{Float64}, Cint, Cint, Cint, Float64, Float64, Int64, Cint,
+             Float64, Ptr{ComplexF64}, Ptr{Float64}, Ptr{Int64}, Ptr{Cint}),
+            hs.h, ns == 0 ? C_NULL : pointer(syms), ns, fid(f), params, length(params), omegas, nsolve, n0, dn,
+            abstol === nothing ? -1.0 : abstol / j,                  # src/brillouin.jl:433
+            reltol === nothing ? -1.0 : reltol, min(maxiters, typemax(Int64) >> 1), alg.keepmost,
+            Float64(nsyms(bz)),                                      # TrivialRep inside every rule: src/brillouin.jl:127-130
+            out, err, nev, npt))
+    end
+    return [IntegralSolution(real(out[i]) * j, err[i] * j, true, Int(nev[i])) for i in 1:nsolve]
+end
+
 function AutoBZCore.do_solve(f::HIPFourierIntegrand, bz::SymmetricBZ, p, alg::AutoPTR, hs::HIPSeries;
     abstol=nothing, reltol=nothing, maxiters=typemax(Int))
-    j = abs(det(bz.B))
-    atol = abstol === nothing ? 0.0 : abstol / j          # src/brillouin.jl:433
-    rtol = reltol === nothing ? (abstol === nothing ? sqrt(eps()) : 0.0) : reltol
-    n0 = clamp(round(Int, alg.n₀ / alg.a), alg.nmin, alg.nmax)
-    dn = clamp(round(Int, alg.Δn / alg.a), alg.nmin, alg.nmax)
     params, omega = bind(f.f.f, merge(f.f.p, p))
-    npt = n0; numevals = 0
-    rule = rule!(hs, npt, bz.syms, WANT_HC); numevals += rule.nk
-    I1 = nsyms(bz) * real(reduce_rule(rule, f.f.f, params, [omega], 1)[1, 1])
-    while true
-        npt += dn
-        rule = rule!(hs, npt, bz.syms, WANT_HC); numevals += rule.nk
-        I2 = nsyms(bz) * real(reduce_rule(rule, f.f.f, params, [omega], 1)[1, 1])
-        err = abs(I2 - I1)
-        (err <= max(atol, rtol * abs(I2)) || numevals >= maxiters) && return IntegralSolution(I2 * j, err * j, true, numevals)
-        I1 = I2
-    end
+    return autoptr_solve(hs, f.f.f, params, [omega], bz, alg; abstol, reltol, maxiters)[1]
 end
 
 function AutoBZCore.do_solve(f::HIPFourierIntegrand, bz::SymmetricBZ, p, alg::IAI, hs::HIPSeries{d};
@@ -250,6 +263,16 @@ function AutoBZCore.batchsolve(s::IntegralSolver{<:HIPFourierIntegrand,<:Symmetr
     params, _ = bind(f.f.f, merge(f.f.p, MixedParameters(first(omegas))))
     u = reduce_rule(r, f.f.f, params, Float64.(omegas), 1)
     return abs(det(bz.B)) * nsyms(bz) .* real.(vec(u))
+end
+
+"batchsolve for a HIP integrand under AutoPTR: the solves refine in lock-step, every grid is visited once for all that are still active."
+function AutoBZCore.batchsolve(s::IntegralSolver{<:HIPFourierIntegrand,<:SymmetricBZ,<:AutoPTR}, omegas::AbstractVector{<:Real})
+    f, bz = s.f, s.dom
+    hs = HIPSeries(f.w.series)
+    params, _ = bind(f.f.f, merge(f.f.p, MixedParameters(first(omegas))))
+    sols = autoptr_solve(hs, f.f.f, params, Float64.(omegas), bz, s.alg; abstol=get(s.kwargs, :abstol, nothing),
+        reltol=get(s.kwargs, :reltol, nothing), maxiters=get(s.kwargs, :maxiters, typemax(Int)))
+    return [sol.u for sol in sols]
 end
 
 "batchsolve for a HIP integrand under IAI: all solves advance in lock-step and share their launches."
@@ -307,6 +330,52 @@ function ggr(h::FourierSeries{S,N}, bz::SymmetricBZ, Es::Vector{Float64}; npt=50
     check(ccall((:abz_rule_ggr, libabz), Cint, (Ptr{Cvoid}, Ptr{Float64}, Cint, Ptr{Float64}), r.h, Es, length(Es), out))
     return out
 end
+
+# ---------------------------------------------------------------- cached rule -> the reference's own containers
+"""
+    export_rule(r, hs; H=true, eig=false, vel=false)
+
+Host copies of a cached rule in the reference's layout -- `(x, w, H, eig, vel)` with `x :: Vector{SVector{d}}`, integer-valued
+weights `w`, `H :: Vector{SMatrix{n,n,ComplexF64}}` -- i.e. what iterating a `FourierPTR` / `FourierMonkhorstPack` yields
+(src/fourier.jl:177-207,279-292).  A user closure under `PTR` is fed from the cached rule through this:
+`sum(w[i] * f(FourierValue(x[i], H[i]), p...) for i in eachindex(x)) / (npt^d * nsyms)`.
+"""
+function export_rule(r::HIPRule, hs::HIPSeries{d}; H::Bool=true, eig::Bool=false, vel::Bool=false) where {d}
+    n = hs.n
+    x = Matrix{Float64}(undef, d, r.nk); w = Vector{Float64}(undef, r.nk)
+    Hb = H ? Array{ComplexF64}(undef, n, n, r.nk) : ComplexF64[]
+    Eb = eig ? Matrix{Float64}(undef, n, r.nk) : Float64[]
+    Vb = vel ? Array{Float64}(undef, n, d, r.nk) : Float64[]
+    GC.@preserve x w Hb Eb Vb begin
+        check(ccall((:abz_rule_export, libabz), Cint,
+            (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ptr{ComplexF64}, Ptr{Float64}, Ptr{Float64}),
+            r.h, x, w, H ? pointer(Hb) : C_NULL, eig ? pointer(Eb) : C_NULL, vel ? pointer(Vb) : C_NULL))
+    end
+    xs = [SVector{d,Float64}(view(x, :, k)) for k in 1:r.nk]
+    Hs = H ? [SMatrix{n,n,ComplexF64}(view(Hb, :, :, k)) for k in 1:r.nk] : nothing
+    return (x=xs, w=w, H=Hs, eig=eig ? Eb : nothing, vel=vel ? Vb : nothing)
+end
+
+"A plain-function integrand under `PTR` fed from the cached rule (src/fourier.jl:204-207): `rule(f, B)`."
+function rule_sum(f, r::HIPRule, hs::HIPSeries{d}, args...; kws...) where {d}
+    ex = export_rule(r, hs)
+    acc = sum(ex.w[i] * f(FourierValue(ex.x[i], ex.H[i]), args...; kws...) for i in eachindex(ex.x))
+    return acc / (r.npt^d * r.nsyms)
+end
+
+"Store-free rule value (abz_ptr_sum): the number `reduce_rule` gives on the full grid, without materialising H(k)."
+function ptr_sum(hs::HIPSeries, npt::Integer, f::HIPIntegrand, params::Vector{Float64}, sweep::Vector{Float64}; nsyms::Integer=1)
+    out = Vector{ComplexF64}(undef, length(sweep))
+    GC.@preserve params sweep out begin
+        check(ccall((:abz_ptr_sum, libabz), Cint,
+            (Ptr{Cvoid}, Cint, Cint, Cint, Cint, Ptr{Float64}, Cint, Ptr{Float64}, Cint, Cint, Ptr{ComplexF64}),
+            hs.h, npt, 0, npt, fid(f), params, length(params), sweep, length(sweep), nsyms, out))
+    end
+    return out
+end
+
+"Drop the rules the library keeps with the series for `abz_autoptr_solve*`."
+drop_rules!(hs::HIPSeries) = check(ccall((:abz_series_drop_rules, libabz), Cint, (Ptr{Cvoid},), hs.h))
 
 # ---------------------------------------------------------------- the rest of abzhip.h (housekeeping)
 """(live device bytes, cached device bytes, this context's scratch bytes, its pinned host bytes, live blocks)"""

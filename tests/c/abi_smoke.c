@@ -1,7 +1,7 @@
 /* Plain-C client of the C ABI (include/abzhip.h): no Python, no C++ -- the way a host language binds it.
  * Config 1 of BASELINE.json: s(x) = cos(2 pi x) (coefficients [0.5, 0, 0.5], offset -2 .. here first = -1),
- * f = 1.3 s + 1 integrates to 1 per unit cell, through PTR (rule + reduce), the store-free sum, IAI and
- * abz_eval_nodes.  Exit code 0 = all checks passed, 77 = no GPU (ABZ_ERR_NOGPU), anything else = failure. */
+ * f = 1.3 s + 1 integrates to 1 per unit cell, through PTR (rule + reduce), the store-free sum, IAI, AutoPTR
+ * and abz_eval_nodes.  Exit code 0 = all checks passed, 77 = no GPU (ABZ_ERR_NOGPU), anything else = failure. */
 #include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -64,8 +64,19 @@ int main(void) {
         fprintf(stderr, "iai_solve: %.17g err %g numevals %lld\n", out[0], err, (long long)nev);
         return 5;
     }
+    /* AutoPTR: the whole p-adaptive loop in the library (grids 50, 100, ...): twice, the second solve from the kept rules */
+    int64_t nev_auto = 0;
+    int32_t npt_last = 0;
+    for (int rep = 0; rep < 2; ++rep) {
+        CHECK(abz_autoptr_solve(s, NULL, 0, ABZ_F_LINEAR, p, 2, 0.0, 50, 50, 1e-10, -1.0, 0, 2, 1.0, out, &err, &nev_auto, &npt_last));
+        if (fabs(out[0] - 1.0) > 1e-13 || nev_auto != 150 || npt_last != 100 || err > 1e-13) {
+            fprintf(stderr, "autoptr_solve: %.17g err %g numevals %lld npt %d\n", out[0], err, (long long)nev_auto, (int)npt_last);
+            return 6;
+        }
+    }
+    CHECK(abz_series_drop_rules(s));
     CHECK(abz_series_destroy(s));
     CHECK(abz_ctx_destroy(ctx));
-    printf("abi_smoke ok: numevals(IAI) = %lld, library version %d\n", (long long)nev, abz_version());
+    printf("abi_smoke ok: numevals(IAI) = %lld, numevals(AutoPTR) = %lld, library version %d\n", (long long)nev, (long long)nev_auto, abz_version());
     return 0;
 }

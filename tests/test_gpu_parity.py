@@ -1222,6 +1222,77 @@ def test_svo_autoptr_off_band_value(abz, svo):
     assert abs(sol_f.u - sol.u) < 1e-6
 
 
+@pytest.mark.parametrize("kind,d", [("FBZ", 2), ("InversionSymIBZ", 2), ("CubicSymIBZ", 2), ("FBZ", 3)])
+def test_autoptr_loop_inside_the_library(abz, kind, d, monkeypatch):
+    """abz_autoptr_solve_many (grid sequence, rules kept by the series, store-free sums for grids used once, error test,
+    numevals -- ref: src/algorithms.jl:418-432, src/fourier.jl:381-389) against the oracle's autosymptr and against the host
+    loop that drives the same rules one call at a time (solver._autoptr_many with the library path switched off):
+    equal integer `numevals` and grid sequence, values to 1e-11; a batch in lock-step takes the decisions of the solves one by
+    one (values to the rounding of a scan that carries several swept values); new coefficients reach the kept rules;
+    `keepmost` changes no value.  The 3-D case walks npt = 60, 100, 140: its third grid is summed on the fly."""
+    from autobzcore.jl_amd import solver as S
+    rng = np.random.default_rng(77)
+    A = rng.standard_normal((3, 3)) + 1j * rng.standard_normal((3, 3))
+    A = 0.5 * (A + A.conj().T)
+    c = np.zeros((3,) * d + (3, 3), dtype=np.complex128)  # H(k) = sum_j cos(2 pi k_j) A + B: the cubic point group
+    for i in range(d):
+        for e_ in (0, 2):
+            idx = [1] * d
+            idx[i] = e_
+            c[tuple(idx)] += 0.5 * A
+    c[(1,) * d] += np.diag([0.3, -0.2, 0.1])
+    s, so = both(abz, c, (-1,) * d)
+    bzk = {"FBZ": abz.FBZ(), "InversionSymIBZ": abz.InversionSymIBZ(), "CubicSymIBZ": abz.CubicSymIBZ()}[kind]
+    bz, bzo = abz.load_bz(bzk, 1.3 * np.eye(d)), orc.load_bz(kind, 1.3 * np.eye(d))
+    if d == 2:
+        seq = dict(nmin=5, n0=7.0, dn=6.0)  # npt = 7, 13, 19, ...: some thirty refinements, the oracle stays fast
+        eta, omegas, tol = 0.12, [-0.4, 0.1, 0.8, 2.5], 1e-4
+    else:
+        seq = dict(nmin=40, n0=60.0, dn=40.0)  # |I(100) - I(60)| = 1.9e-4 at omega = 0.1 and 3.7e-5 at 2.5: three grids and two
+        eta, omegas, tol = 0.2, [0.1, 2.5], 1e-4 * abs(np.linalg.det(bz.B))  # (abstol is divided by |det B|, src/brillouin.jl:433)
+    alg = abz.AutoPTR(a=1.0, keepmost=2, **seq)
+    f = abz.FourierIntegrand(abz.DOSIntegrand(), s, eta)
+    lib = [abz.solve(abz.IntegralProblem(f, bz, abz.MixedParameters(om)), abz.EvalCounter(alg), abstol=tol) for om in omegas]
+    monkeypatch.setattr(S, "_autoptr_library", lambda *a, **k: None)
+    host = [abz.solve(abz.IntegralProblem(f, bz, abz.MixedParameters(om)), abz.EvalCounter(alg), abstol=tol) for om in omegas]
+    monkeypatch.undo()
+    grids = set()
+    for om, a, b in zip(omegas, lib, host):
+        assert a.numevals == b.numevals and a.extra["npt"] == b.extra["npt"] and abs(a.u - b.u) <= 1e-13 * abs(b.u)
+        grids.add(a.extra["npt"])
+        if d == 3 and om != omegas[0]:
+            continue  # (the numpy oracle needs ~10 s per million nodes of a 3-D grid)
+        ref = orc.solve_autoptr(so, bzo, orc.f_dos(eta, om), abstol=tol, **seq)
+        assert a.numevals == ref.numevals, (om, a.numevals, ref.numevals)
+        assert a.extra["npt"] == ref.extra["grids"][-1]
+        assert abs(a.u - ref.u) <= 1e-11 * abs(ref.u)
+        assert abs(a.resid - ref.resid) <= 1e-9 * abs(ref.u) + 1e-3 * ref.resid
+    assert len(grids) >= 2  # the solves stop at different grids: the lock-step really shrinks
+    if d == 3:
+        assert lib[0].extra["npt"] == 140 and lib[0].numevals == 60**3 + 100**3 + 140**3
+    solver = abz.IntegralSolver(f, bz, abz.EvalCounter(alg), abstol=tol)
+    batch = abz.batchsolve(solver, np.array(omegas))
+    assert all(abs(batch[i] - lib[i].u) <= 1e-13 * abs(lib[i].u) for i in range(len(omegas)))
+    # keepmost = 0 (nothing kept: every grid on the fly or built and dropped) and a large one: the same numbers
+    for km in (0, 9):
+        alg2 = abz.AutoPTR(a=1.0, keepmost=km, **seq)
+        s.device().drop_rules()
+        for om, a in zip(omegas, lib):
+            got = abz.solve(abz.IntegralProblem(f, bz, abz.MixedParameters(om)), abz.EvalCounter(alg2), abstol=tol)
+            assert got.numevals == a.numevals and abs(got.u - a.u) <= 1e-13 * abs(a.u), (km, om)
+    if d == 3:
+        return
+    # new coefficients of the same shape: the rules the series keeps refill themselves before their next use
+    c2 = c.copy()
+    c2[(1,) * d] += np.diag([0.05, 0.0, -0.05])
+    s.device().update(c2)
+    so2 = orc.FourierSeries(c2, period=1.0, first=(-1,) * d, ndim=d)
+    got = abz.solve(abz.IntegralProblem(f, bz, abz.MixedParameters(0.1)), abz.EvalCounter(alg), abstol=tol)
+    ref = orc.solve_autoptr(so2, bzo, orc.f_dos(eta, 0.1), abstol=tol, **seq)
+    assert got.numevals == ref.numevals and abs(got.u - ref.u) <= 1e-11 * abs(ref.u)
+    assert abs(got.u - lib[omegas.index(0.1)].u) > 1e-6 * abs(ref.u)  # ... and the value did move
+
+
 def test_full_size_properties_config3(abz, svo):
     """BASELINE full size (SVO, 150^3 = 3.375 M nodes, 567 MB of rule values): size-independent
     properties instead of a node-by-node oracle comparison.

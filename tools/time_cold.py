@@ -22,4 +22,8 @@ for kind, bzk in (("FBZ", abz.FBZ()), ("CubicSymIBZ", abz.CubicSymIBZ())):
     t0 = time.perf_counter(); r = solver.solve_p(abz.MixedParameters(12.5)); t1 = time.perf_counter()
     print(f"{kind}: rules dropped {1e3*(t1-t0):.3f} ms", flush=True)
     t0 = time.perf_counter(); r = solver.solve_p(abz.MixedParameters(12.5)); t1 = time.perf_counter()
-    print(f"{kind}: cached {1e3*(t1-t0):.3f} ms", flush=True)
+    print(f"{kind}: cached {1e3*(t1-t0):.3f} ms   u = {r.u!r} resid {r.resid:.3e} numevals {r.numevals} last npt {r.extra['npt']}", flush=True)
+    ts = []
+    for _ in range(200):
+        t0 = time.perf_counter(); solver.solve_p(abz.MixedParameters(12.5)); ts.append(time.perf_counter() - t0)
+    print(f"{kind}: cached, 200 solves: min {1e3*min(ts):.3f} median {1e3*sorted(ts)[100]:.3f} ms", flush=True)
