@@ -2318,7 +2318,6 @@ struct InnerArgs {
     const double* sweep_arr;
     int64_t nint, maxevals;
     int M, first, d, ncomp, has_rtol;
-    int pair;  // scalar integrands: the two-lane adaptive step (inner_adapt.h)
     int pk;    // the level-1 sets are packed Hermitian rows (packed_herm.h): folded series, no seed phase
     double inv_period, sweep, rtol_user;
     double p[4];
@@ -2345,17 +2344,12 @@ __global__ __launch_bounds__(256) void inner_adaptive_kernel(InnerArgs a) {
     gkc* vals = seg_I + (size_t)MS * nc;
     int* heap = reinterpret_cast<int*>(vals + (size_t)30 * nc);
     double* ctl = reinterpret_cast<double*>(heap + MS);
-    double* heapE = ctl + 8;  // adapt_step_pair's mirror of seg_E[heap[.]]
-    // scalar integrands: lanes 0 and 1 of the half-wave share the serial step (two GK rules side by side, one LDS round
-    // trip per heap level); a.pair = 0 (ABZ_ADAPT_PAIR=0): the one-lane step, same numbers
-    const bool pair = NC == 1 && a.pair;
     const int64_t gstride = (int64_t)gridDim.x * 8;
     for (int64_t q0 = (int64_t)blockIdx.x * 8; q0 < a.nint; q0 += gstride) {
         const int64_t q = q0 + group;
         const bool live = q < a.nint;  // the whole group shares it; both groups of a wave loop together
         // ---- lane 0 state
         AdaptStateT<NC> st;
-        [[maybe_unused]] AdaptParent par;
         bool done = !live;
         double tailv[ABZ_MAX_DIM] = {0.0, 0.0, 0.0};
         double swq = a.sweep;
@@ -2427,24 +2421,260 @@ __global__ __launch_bounds__(256) void inner_adaptive_kernel(InnerArgs a) {
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            if (!grp_done && l < (pair ? 2 : 1)) {
+            if (!grp_done && l == 0) {
                 InnerOut out;
                 out.I = a.I_out + q * nc;
                 out.E = a.E_out + q;
                 out.nev = a.nev_out + q;
                 out.status = a.status_out + q;
-                if constexpr (NC == 1) {
-                    if (pair) {
-                        const bool d2 = adapt_step_pair<MS>(st, par, l, seg_a, seg_b, seg_E, seg_I, vals, heap, heapE, ctl, a.maxevals, out,
-                                                            (int)(threadIdx.x & 32u) + 1);
-                        if (l == 0) done = d2;
-                    } else {
-                        done = adapt_step<true, NC>(st, nc, seg_a, seg_b, seg_E, seg_I, vals, heap, ctl, a.maxevals, out);
-                    }
+                done = adapt_step<true, NC>(st, nc, seg_a, seg_b, seg_E, seg_I, vals, heap, ctl, a.maxevals, out);
+            }
+        }
+    }
+}
+
+// ---- the same loop with the adaptive state in REGISTERS: one wavefront per integral (scalar integrands) ----
+// inner_adaptive_kernel keeps an integral's segments and heap in LDS and lets one lane walk them: in-kernel stamps on the
+// reference example's solve (SVO, eta = 0.01: launches of 16 ... 4096 integrals, i.e. a nearly empty chip where only the
+// length of a round counts) gave 2 490 cycles for the 30 node values of a round and 5 090 for that serial step -- a chain of
+// dependent LDS round trips (ctl, the fifteen values, the heap levels, the popped parent).  Here the state never leaves the
+// wave's registers: lane j holds heap position j (error, segment slot) and segment slot j (a, b, I); everything the step
+// decides is wave-uniform, so heap levels are v_readlane / v_writelane with scalar indices (a few cycles each) and the
+// branches are scalar.  Lanes 0 and 1 apply the GK rule to the two pending panels, whose fifteen values they pull from
+// their owners' registers (ds_bpermute, no LDS storage).  The arithmetic and its order are those of adapt_step: identical
+// (I, E), identical heap decisions (DataStructures.jl percolate semantics), identical counts.  The segment store is the
+// wave (lanes 0 ... ABZ_INNER_MAXSEG - 1, the LDS kernel's capacity: an integral that needs more is redone by the host loop,
+// whose node kernel evaluates the integrand by another formula -- the same integrals must take that road in both kernels).
+// (clang has no __builtin_amdgcn_writelane: the LLVM intrinsic by its name; on gfx9 it lowers to s_mov_b32 m0, lane +
+// v_writelane_b32 v, value, m0 -- one SGPR on the constant bus, and no VALU-written lane select)
+extern "C" __device__ int abz_writelane_i32(int val, int lane, int old) __asm("llvm.amdgcn.writelane.i32");
+__device__ __forceinline__ double rl_f64(double v, int lane) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ void wl_f64(double& v, int lane, double x) {
+    const int lo = abz_writelane_i32(__double2loint(x), lane, __double2loint(v));
+    const int hi = abz_writelane_i32(__double2hiint(x), lane, __double2hiint(v));
+    v = __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ int rl_i32(int v, int lane) { return __builtin_amdgcn_readlane(v, lane); }
+__device__ __forceinline__ void wl_i32(int& v, int lane, int x) { v = abz_writelane_i32(x, lane, v); }
+
+template <int N, int FID, bool HERM>
+__global__ __launch_bounds__(256) void inner_adaptive_wave_kernel(InnerArgs a) {
+    static_assert(NComp<FID>::template value<N>() == 1, "one complex value per node");
+    extern __shared__ double lds_iw[];  // [4 waves][MNN] complex: the integrals' coefficient sets, nothing else
+    constexpr int MS = ABZ_INNER_MAXSEG;  // like the LDS kernel: the same integrals go to the host loop whichever kernel runs
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), l = threadIdx.x & 63;
+    const int MNN = a.pk ? Pk<N>::size((a.M - 1) / 2) : a.M * N * N;
+    double2* const cl = reinterpret_cast<double2*>(lds_iw) + (size_t)wave * MNN;
+    for (int64_t q = (int64_t)blockIdx.x * 4 + wave; q < a.nint; q += (int64_t)gridDim.x * 4) {
+        wave_lds_sync();  // the previous integral's readers of cl are done
+        {
+            const double2* __restrict__ src = a.src + a.slot[q] * (int64_t)MNN;
+            for (int idx = l; idx < MNN; idx += 64) cl[idx] = src[idx];
+        }
+        wave_lds_sync();
+        const double swq = a.sweep_arr ? a.sweep_arr[q] : a.sweep;
+        // per-lane state
+        double hE = 0.0, sA = 0.0, sB = 0.0, sIr = 0.0, sIi = 0.0;
+        int hS = 0;
+        // wave-uniform state (AdaptStateT<1> + ctl of the LDS kernel)
+        int nseg = 0, nheap = 0, popped = -1, status = 0;
+        bool first = true;
+        double E = 0.0, Ir = 0.0, Ii = 0.0, parE = 0.0, parIr = 0.0, parIi = 0.0;
+        long long numevals = 0;
+        const double at_in = a.atol[q];
+        const double atol = at_in >= 0.0 ? at_in : 0.0;
+        const double rtol = a.has_rtol ? a.rtol_user : ((at_in > 0.0) ? 0.0 : 1.4901161193847656e-08);  // sqrt(eps)
+        int np = 1;
+        double a1 = a.lo[q], b1 = a.hi[q], a2 = 0.0, b2 = 0.0;
+        while (true) {
+            // ---- the nodes of the pending panels: lanes 0-14 panel 0, 16-30 panel 1
+            const int pnl = l >> 4, i = l & 15;
+            double vr = 0.0, vi = 0.0;
+            if (pnl < np && i < 15) {
+                const double x = gk15_node(pnl ? a2 : a1, pnl ? b2 : b1, i);
+                const double xx = x * a.inv_period;
+                double zr, zi, wr, wi;
+                CMat<N> H;
+                if (HERM && a.pk) {
+                    sincospi(2.0 * xx, &zi, &zr);
+                    series_point_pk<N>((const double2*)cl, (a.M - 1) / 2, zr, zi, H);
                 } else {
-                    done = adapt_step<true, NC>(st, nc, seg_a, seg_b, seg_E, seg_I, vals, heap, ctl, a.maxevals, out);
+                    sincospi(2.0 * xx, &zi, &zr);
+                    sincospi(2.0 * ((double)a.first * xx), &wi, &wr);
+                    series_lane_lds<N, HERM>(cl, a.M, zr, zi, wr, wi, H);
+                }
+                double e[N];
+                if constexpr (FID == ABZ_F_DOS_EIG) {
+                    herm_eig_values<N>(H, e);
+                }
+                double xk[ABZ_MAX_DIM] = {x, 0.0, 0.0};
+                double wr_[MAXC], wi_[MAXC];
+                if constexpr (HERM && (N == 2 || N == 3) && (FID == ABZ_F_DOS || FID == ABZ_F_TRGLOC)) {
+                    // Hermitian H: resolvent trace from the real characteristic polynomial
+                    CharPolyH cp;
+                    if constexpr (N == 3)
+                        charpoly_init_h3(H.re[0][0], H.re[1][1], H.re[2][2], H.re[0][1], H.im[0][1], H.re[0][2], H.im[0][2],
+                                         H.re[1][2], H.im[1][2], cp);
+                    else
+                        charpoly_init_h2(H.re[0][0], H.re[1][1], H.re[0][1], H.im[0][1], cp);
+                    double tr, ti;
+                    charpoly_trace_h<N, true>(cp, swq, a.p[0], a.p[0] * a.p[0], 2.0 * a.p[0], tr, ti);
+                    wr_[0] = (FID == ABZ_F_DOS) ? -ti * 0.31830988618379067153776752674503 : tr;
+                    wi_[0] = (FID == ABZ_F_DOS) ? 0.0 : ti;
+                } else {
+                    integrand_value<N, FID>(H, e, xk, a.d, a.p, swq, wr_, wi_);
+                }
+                vr = wr_[0];
+                vi = wi_[0];
+            }
+            // ---- the GK rule: lane p takes pending panel p, its fifteen values come from their owners' registers
+            const int pl = l < np ? l : 0;
+            gkc rv[15];
+#pragma unroll
+            for (int t = 0; t < 15; ++t) {
+                rv[t].re = __shfl(vr, 16 * pl + t, 64);
+                rv[t].im = __shfl(vi, 16 * pl + t, 64);
+            }
+            gkc Il;
+            const double El = gk15_rule(rv, 1, pl ? a2 : a1, pl ? b2 : b1, &Il);
+            const double E1 = rl_f64(El, 0), I1r = rl_f64(Il.re, 0), I1i = rl_f64(Il.im, 0);
+            const double E2 = rl_f64(El, 1), I2r = rl_f64(Il.re, 1), I2i = rl_f64(Il.im, 1);
+            // ---- the step, on wave-uniform values (adapt_step's operations in adapt_step's order)
+            int s1, s2 = -1;
+            if (popped >= 0)
+                s1 = popped;  // the popped parent's slot is reused for the first child
+            else
+                s1 = nseg++;
+            if (s1 >= MS) {
+                status = 1;
+                s1 = MS - 1;
+            }
+            if (np == 2) {
+                s2 = nseg++;
+                if (s2 >= MS) {
+                    status = 1;
+                    s2 = MS - 1;
                 }
             }
+            if (first) {
+                first = false;
+                wl_f64(sA, s1, a1);
+                wl_f64(sB, s1, b1);
+                wl_f64(sIr, s1, I1r);
+                wl_f64(sIi, s1, I1i);
+                Ir = I1r;
+                Ii = I1i;
+                E = E1;
+                numevals = 15;
+                wl_i32(hS, 0, s1);
+                wl_f64(hE, 0, E1);
+                nheap = 1;
+            } else {
+                wl_f64(sA, s1, a1);
+                wl_f64(sB, s1, b1);
+                wl_f64(sIr, s1, I1r);
+                wl_f64(sIi, s1, I1i);
+                wl_f64(sA, s2, a2);
+                wl_f64(sB, s2, b2);
+                wl_f64(sIr, s2, I2r);
+                wl_f64(sIi, s2, I2i);
+                {
+#pragma clang fp contract(off)
+                    Ir = ((Ir - parIr) + I1r) + I2r;
+                    Ii = ((Ii - parIi) + I1i) + I2i;
+                    E = ((E - parE) + E1) + E2;
+                }
+                for (int t = 0; t < 2; ++t) {  // heappush (percolate_up)
+                    const int xs = t == 0 ? s1 : s2;
+                    const double Ex = t == 0 ? E1 : E2;
+                    int h = nheap++;
+                    while (h > 0) {
+                        const int j = (h - 1) / 2;
+                        const double Ej = rl_f64(hE, j);
+                        if (!(Ej < Ex)) break;
+                        wl_i32(hS, h, rl_i32(hS, j));
+                        wl_f64(hE, h, Ej);
+                        h = j;
+                    }
+                    wl_i32(hS, h, xs);
+                    wl_f64(hE, h, Ex);
+                }
+            }
+            double tol = atol;
+            if (rtol != 0.0) {  // (rtol = 0: max(atol, 0 * |I|) = atol, no square root)
+#pragma clang fp contract(off)
+                const double t1 = Ir * Ir, t2 = Ii * Ii;
+                const double t3 = t1 + t2;
+                const double nrm = sqrt(0.0 + t3);
+                tol = fmax(atol, rtol * nrm);
+            }
+            if (E > tol && numevals < a.maxevals && status == 0) {
+                // heappop: root out, last to root, percolate_down
+                const int xs = rl_i32(hS, 0);
+                parE = rl_f64(hE, 0);
+                const int nh = --nheap;
+                const int y = rl_i32(hS, nh);
+                const double Ey = rl_f64(hE, nh);
+                parIr = rl_f64(sIr, xs);
+                parIi = rl_f64(sIi, xs);
+                const double pa = rl_f64(sA, xs), pb = rl_f64(sB, xs);
+                if (nh > 0) {
+                    int h = 0;
+                    while (true) {
+                        const int lc = 2 * h + 1;
+                        if (lc >= nh) break;
+                        const int rc = lc + 1;
+                        const double Elc = rl_f64(hE, lc);
+                        bool left = true;
+                        double Ej = Elc;
+                        if (rc < nh) {
+                            const double Erc = rl_f64(hE, rc);
+                            left = Erc < Elc;
+                            Ej = left ? Elc : Erc;
+                        }
+                        if (!(Ey < Ej)) break;
+                        const int j = left ? lc : rc;
+                        wl_i32(hS, h, rl_i32(hS, j));
+                        wl_f64(hE, h, Ej);
+                        h = j;
+                    }
+                    wl_i32(hS, h, y);
+                    wl_f64(hE, h, Ey);
+                }
+                popped = xs;
+                numevals += 30;
+                const double mid = (pa + pb) / 2;
+                np = 2;
+                a1 = pa;
+                b1 = mid;
+                a2 = mid;
+                b2 = pb;
+                continue;
+            }
+            {  // re-sum over the heap in storage order (QuadGK does this after adapt)
+#pragma clang fp contract(off)
+                const int s0 = rl_i32(hS, 0);
+                Ir = rl_f64(sIr, s0);
+                Ii = rl_f64(sIi, s0);
+                E = rl_f64(hE, 0);
+                for (int h = 1; h < nheap; ++h) {
+                    const int sh = rl_i32(hS, h);
+                    Ir = Ir + rl_f64(sIr, sh);
+                    Ii = Ii + rl_f64(sIi, sh);
+                    E = E + rl_f64(hE, h);
+                }
+            }
+            if (l == 0) {
+                a.I_out[q] = make_double2(Ir, Ii);
+                a.E_out[q] = E;
+                a.nev_out[q] = numevals;
+                a.status_out[q] = status;
+            }
+            break;
         }
     }
 }
@@ -2482,7 +2712,6 @@ int launch_inner_adaptive(abz_ctx* ctx, const InnerSpec& is) {
     a.d = is.d;
     a.ncomp = ncomp;
     a.has_rtol = is.has_rtol ? 1 : 0;
-    a.pair = abz_switch(SW_ADAPT_PAIR) ? 1 : 0;  // per call: tests compare both
     // (a polynomial sincospi for the node phases measured 31.3 against 32.0 ms on the SVO full-BZ solve: the phases are
     // not what bounds a round; the library routine stays)
     a.pk = (is.packed && is.herm) ? 1 : 0;
@@ -2500,14 +2729,27 @@ int launch_inner_adaptive(abz_ctx* ctx, const InnerSpec& is) {
         set_error("inner adaptive kernel: %d coefficients per line exceed the LDS budget", mnn);
         return ABZ_ERR_UNSUPPORTED;
     }
-    const size_t lds = sizeof(double) * (size_t)inner_group_stride(ncomp, mnn) * 8;
-    const unsigned blocks = (unsigned)std::min<int64_t>(cdiv(is.nint, 8), 256 * 16);
-#define LAUNCH_INNER2(NN, FID, HH)                                                                                    \
+    // one complex value per node: the adaptive state lives in the registers of one wavefront per integral
+    // (inner_adaptive_wave_kernel); ABZ_ADAPT_PAIR=0 (tests) and the multi-component integrands: the LDS kernel
+    const bool wave_state = ncomp == 1 && abz_switch(SW_ADAPT_PAIR) != 0;
+    const size_t lds = wave_state ? sizeof(double2) * (size_t)mnn * 4 : sizeof(double) * (size_t)inner_group_stride(ncomp, mnn) * 8;
+    const unsigned blocks = (unsigned)std::min<int64_t>(cdiv(is.nint, wave_state ? 4 : 8), 256 * 16);
+#define LAUNCH_INNER_LDS(NN, FID, HH)                                                                                 \
     {                                                                                                                 \
         if (lds > 48 * 1024)                                                                                          \
             ABZ_HIP(hipFuncSetAttribute((const void*)inner_adaptive_kernel<NN, FID, HH>,                              \
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                       \
         hipLaunchKernelGGL((inner_adaptive_kernel<NN, FID, HH>), dim3(blocks), dim3(256), lds, ctx->stream, a);       \
+    }
+#define LAUNCH_INNER2(NN, FID, HH)                                                                                    \
+    {                                                                                                                 \
+        if constexpr (NComp<FID>::template value<NN>() == 1) {                                                        \
+            if (wave_state) {                                                                                         \
+                hipLaunchKernelGGL((inner_adaptive_wave_kernel<NN, FID, HH>), dim3(blocks), dim3(256), lds, ctx->stream, a); \
+            } else                                                                                                    \
+                LAUNCH_INNER_LDS(NN, FID, HH)                                                                         \
+        } else                                                                                                        \
+            LAUNCH_INNER_LDS(NN, FID, HH)                                                                             \
     }
 #define LAUNCH_INNER(NN, FID)             \
     if (is.herm) {                        \
@@ -2537,6 +2779,7 @@ int launch_inner_adaptive(abz_ctx* ctx, const InnerSpec& is) {
 #undef CASE
 #undef LAUNCH_INNER
 #undef LAUNCH_INNER2
+#undef LAUNCH_INNER_LDS
     ABZ_HIP(hipGetLastError());
     return ABZ_OK;
 }
