@@ -53,6 +53,7 @@ enum Switch {
     SW_IAI_PACKED,       // ABZ_IAI_PACKED      IAI chains of Hermitian series (n <= 4) on packed rows
     SW_IAI_POOL_MB,      // ABZ_IAI_POOL_MB     size of a chunk of level sets in the IAI driver
     SW_IAI_DEVICE_INNER, // ABZ_IAI_DEVICE_INNER innermost adaptive loops on the device (0: host-driven rounds)
+    SW_IAI_PANELS,       // ABZ_IAI_PANELS      level above the innermost: panels, not nodes, cross PCIe (0: nodes)
     SW_IAI_STATS,        // ABZ_IAI_STATS       per-solve statistics of the IAI driver on stderr
     SW_HOST_THREADS,     // ABZ_HOST_THREADS    host threads for the per-integral bookkeeping of IAI sweeps
     SW_COUNT
@@ -190,6 +191,7 @@ struct abz_series {
     int ex_rank = 0, ex_world = 1;
     void* iai_pin[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};  // pinned host blocks of the IAI driver: chunk inputs [0,1] / outputs [2,3] / exchange [4]
     size_t iai_pin_cap[5] = {0, 0, 0, 0, 0};
+    void* iai_pin_dev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};  // device-visible addresses of the same blocks (zero-copy)
     uint64_t generation = 0;                  // bumped by abz_series_update
     std::vector<abz::SeriesRule> kept_rules;  // rules of abz_autoptr_solve*, most recently used last
     uint64_t kept_stamp = 0;
@@ -408,6 +410,39 @@ constexpr int ABZ_INNER_MAXSEG = 48;
 constexpr int ABZ_PANEL_MAXSEG = 384;
 bool inner_adaptive_supported(int n, int M, int integrand);
 int launch_inner_adaptive(abz_ctx* ctx, const InnerSpec& is);
+
+// The level above the innermost one, panel by panel (iai_host.cpp: the host keeps that level's heaps and ships PANELS, not
+// nodes): a panel (a, b) of a level-2 integral becomes its fifteen GK nodes -- coordinate and parent set for the contraction,
+// limits / tolerance / swept value of the innermost integral beneath each node -- on the device, and the fifteen innermost
+// results are folded back into the panel's (I_K s, E, evaluation count) by the shared gk15.h rule: 15 x less traffic over
+// PCIe and 15 x fewer words for the host to touch per round.  Iterated limits in closed form only (CubicLimits,
+// TetrahedralLimits): the arithmetic is Lims::fix / Lims::range of iai_host.cpp operation for operation.
+struct PanelNodesSpec {
+    int64_t npanels;
+    const int64_t* p_slot;  // device-visible [npanels]: level-2 coefficient set of the panel's integral
+    const double *p_a, *p_b, *p_at, *p_sw;  // device-visible [npanels]: panel limits, the integral's tolerance (< 0: none), swept value
+    int lims_kind;          // ABZ_LIMS_CUBIC: innermost limits (a0, b0); ABZ_LIMS_TETRAHEDRAL: (0, a0 * (x / aL))
+    double a0, b0, aL;
+    int64_t* n_slot;        // device [15 npanels] out: level-1 set of the innermost integral beneath every node (= node index)
+    double *n_lo, *n_hi, *n_at, *n_sw;
+};
+// nodes + phases + contraction of the level-L sets `src` (slot_elems numbers each, M coefficients of variable L starting at
+// frequency `first`) into out[node][Lrow]
+int launch_panel_contract(abz_ctx* ctx, const PanelNodesSpec& ps, const double2* src, int64_t slot_elems, int M, int first, double period,
+                          double2* out, int64_t Lrow);
+struct PanelRuleSpec {
+    int64_t npanels;
+    int ncomp;
+    const double *p_a, *p_b;   // device [npanels]
+    const double2* n_I;        // device [15 npanels][ncomp]: innermost integrals
+    const int64_t* n_nev;      // device [15 npanels]
+    const int* n_status;       // device [15 npanels]
+    double2* p_I;              // device [npanels][ncomp] out
+    double* p_E;               // device [npanels] out
+    int64_t* p_nev;            // device [npanels] out: evaluations beneath the panel
+    int* p_status;             // device [npanels] out: != 0 if any of its innermost integrals overflowed the device store
+};
+int launch_panel_rule(abz_ctx* ctx, const PanelRuleSpec& ps);
 bool gen_inner_panel_supported(int n, int M, int integrand);  // n > 4: one workgroup per 1-D integral, set in LDS
 int launch_gen_inner_adaptive(abz_ctx* ctx, const InnerSpec& is);
 

@@ -49,6 +49,7 @@ const SwitchDef g_switches[SW_COUNT] = {
     {"ABZ_IAI_PACKED", 1, "0: IAI chains on plain coefficient sets"},
     {"ABZ_IAI_POOL_MB", 0, "> 0: MB per chunk of level sets in the IAI driver (default: sized from free memory)"},
     {"ABZ_IAI_DEVICE_INNER", 1, "0: innermost GK loops driven from the host, one launch per round"},
+    {"ABZ_IAI_PANELS", 1, "0: the level above the innermost one ships nodes instead of panels (GK rule of that level on the host)"},
     {"ABZ_IAI_STATS", 0, "1: per-solve statistics of the IAI driver on stderr"},
     {"ABZ_HOST_THREADS", 8, "host threads for the per-integral bookkeeping of IAI sweeps (capped at half the cores)"},
 };

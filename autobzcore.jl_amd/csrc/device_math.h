@@ -629,27 +629,32 @@ struct CharPolyH {
 };
 
 // N = 3: diagonal d0 d1 d2, upper triangle b = H01, c = H02, d = H12.  N = 2: d0 d1 and b = H01.
+// (Every multiply-add below is spelled out and contraction is off: `a * b + c * d` left to the compiler is fused one way in
+// one kernel and the other way in the next -- the kernels that share these functions then disagree in the last bit.)
 __device__ __forceinline__ void charpoly_init_h3(double d0, double d1, double d2, double br, double bi, double cr,
                                                  double ci, double dr, double di, CharPolyH& cp) {
+#pragma clang fp contract(off)
     const double q = (d0 + d1 + d2) * (1.0 / 3.0);
     d0 -= q;
     d1 -= q;
     d2 -= q;
-    const double nb = br * br + bi * bi, nc = cr * cr + ci * ci, nd = dr * dr + di * di;
+    const double nb = fma(br, br, bi * bi), nc = fma(cr, cr, ci * ci), nd = fma(dr, dr, di * di);
     cp.q = q;
-    cp.p1 = (d0 * d1 - nb) + (d0 * d2 - nc) + (d1 * d2 - nd);
+    cp.p1 = (fma(d0, d1, -nb) + fma(d0, d2, -nc)) + fma(d1, d2, -nd);
     // det B = d0 d1 d2 + 2 Re(b d conj(c)) - d0 |d|^2 - d1 |c|^2 - d2 |b|^2
-    const double bdr = br * dr - bi * di, bdi = br * di + bi * dr;
-    const double det = d0 * d1 * d2 + 2.0 * (bdr * cr + bdi * ci) - d0 * nd - d1 * nc - d2 * nb;
+    const double bdr = fma(br, dr, -(bi * di)), bdi = fma(br, di, bi * dr);
+    const double t = fma(bdr, cr, bdi * ci);
+    const double det = fma(-d2, nb, fma(-d1, nc, fma(-d0, nd, fma(d0 * d1, d2, 2.0 * t))));
     cp.p0 = -det;
 }
 __device__ __forceinline__ void charpoly_init_h2(double d0, double d1, double br, double bi, CharPolyH& cp) {
+#pragma clang fp contract(off)
     const double q = 0.5 * (d0 + d1);
     d0 -= q;
     d1 -= q;
     cp.q = q;
     cp.p1 = 0.0;
-    cp.p0 = d0 * d1 - (br * br + bi * bi);
+    cp.p0 = fma(d0, d1, -fma(br, br, bi * bi));
 }
 
 // tr inv((w + i eta) I - H) = p'(z) / p(z), z = (w - q) + i eta.  eta2 = eta^2, teta = 2 eta.
@@ -657,6 +662,7 @@ __device__ __forceinline__ void charpoly_init_h2(double d0, double d1, double br
 template <int N, bool NEED_RE>
 __device__ __forceinline__ void charpoly_trace_h(const CharPolyH& cp, double w, double eta, double eta2, double teta,
                                                  double& tr, double& ti) {
+#pragma clang fp contract(off)
     const double zr = w - cp.q;
     const double z2r = fma(zr, zr, -eta2), z2i = teta * zr;
     double nr, ni, dr, di;

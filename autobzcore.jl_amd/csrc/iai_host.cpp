@@ -379,7 +379,18 @@ struct IaiDriver {
         return pk ? s->elems(level) / row_full * (int64_t)packed_row_elems(s->n, s->dims[0]) : s->elems(level);
     }
     const double2* top_coef() const { return pk ? s->coef_pk.as<double2>() : s->coef; }
-    int contract_nodes(int L, int64_t nn, int64_t base_slot, int64_t off = 0, const int64_t* par = nullptr, const double* x = nullptr);
+    int contract_nodes(int L, int64_t nn, int64_t base_slot, int64_t off = 0, const int64_t* par = nullptr, const double* x = nullptr,
+                       const int64_t* par_dev = nullptr, const double* x_dev = nullptr);
+    int panels_enqueue(int L, int64_t c0p, int64_t cnp, int buf, const Lims& lims);
+    int panels_collect(int64_t c0p, int64_t cnp, int buf, std::vector<int64_t>& redo);
+    // panels of a round of the level above the innermost one (solve_level, panel mode): inputs gathered per round ...
+    std::vector<int64_t> pp_slot;
+    std::vector<double> pp_a, pp_b, pp_at, pp_sw;
+    std::vector<uint32_t> pp_q;  // the integral a panel belongs to (index into the level's integrals)
+    // ... and what comes back per panel: I_K s [ncomp], E, evaluations beneath it
+    std::vector<cd> pI;
+    std::vector<double> pE;
+    std::vector<int64_t> pnev;
     int eval_nodes(int64_t nn);
     int solve_level(int L, std::vector<Quad1D>& quads);
     int flat_enqueue(int64_t nq, int buf);
@@ -425,7 +436,10 @@ struct IaiDriver {
 
 int IaiDriver::pin_reserve(int which, size_t bytes) {
     if (bytes <= s->iai_pin_cap[which]) return ABZ_OK;
-    if (s->iai_pin[which]) (void)hipHostFree(s->iai_pin[which]);
+    if (s->iai_pin[which]) {
+        (void)hipStreamSynchronize(ctx->stream);  // kernels may still read / write the block in place
+        (void)hipHostFree(s->iai_pin[which]);
+    }
     s->iai_pin[which] = nullptr;
     s->iai_pin_cap[which] = 0;
     const size_t want = bytes + (bytes >> 2) + 4096;
@@ -435,6 +449,11 @@ int IaiDriver::pin_reserve(int which, size_t bytes) {
         return ABZ_ERR_NOMEM;
     }
     s->iai_pin_cap[which] = want;
+    s->iai_pin_dev[which] = nullptr;
+    if (hipHostGetDevicePointer(&s->iai_pin_dev[which], s->iai_pin[which], 0) != hipSuccess) {
+        (void)hipGetLastError();
+        s->iai_pin_dev[which] = nullptr;  // the panel path then copies instead of reading / writing the block in place
+    }
     return ABZ_OK;
 }
 
@@ -455,24 +474,32 @@ int IaiDriver::flat_layout(int64_t cn, bool need_tail, int buf) {
     return ABZ_OK;
 }
 
-// upload h_parents/h_x, contract level-L sets into level-(L-1) pool slots base_slot..base_slot+nn-1
-int IaiDriver::contract_nodes(int L, int64_t nn, int64_t base_slot, int64_t off, const int64_t* par, const double* x) {
+// upload h_parents/h_x (or take them where they are on the device), contract level-L sets into level-(L-1) pool slots
+// base_slot..base_slot+nn-1
+int IaiDriver::contract_nodes(int L, int64_t nn, int64_t base_slot, int64_t off, const int64_t* par, const double* x,
+                              const int64_t* par_dev, const double* x_dev) {
     const int M = s->dims[L - 1];
     const int64_t Lrow = set_elems(L - 1);
     int rc;
-    if ((rc = s->iai_io[0].reserve(sizeof(int64_t) * (size_t)nn))) return rc;
-    if ((rc = s->iai_io[1].reserve(sizeof(double) * (size_t)nn))) return rc;
+    if (!par_dev) {
+        if ((rc = s->iai_io[0].reserve(sizeof(int64_t) * (size_t)nn))) return rc;
+        if ((rc = s->iai_io[1].reserve(sizeof(double) * (size_t)nn))) return rc;
+    }
     if ((rc = s->iai_io[4].reserve(sizeof(double2) * (size_t)(nn * M)))) return rc;
     if ((rc = s->iai_pool[L - 1].reserve(sizeof(double2) * (size_t)((base_slot + nn) * Lrow)))) return rc;
-    ABZ_HIP(hipMemcpyAsync(s->iai_io[0].p, par ? par : h_parents.data() + off, sizeof(int64_t) * (size_t)nn, hipMemcpyHostToDevice,
-                           ctx->stream));
-    ABZ_HIP(hipMemcpyAsync(s->iai_io[1].p, x ? x : h_x.data() + off, sizeof(double) * (size_t)nn, hipMemcpyHostToDevice, ctx->stream));
+    if (!par_dev) {
+        ABZ_HIP(hipMemcpyAsync(s->iai_io[0].p, par ? par : h_parents.data() + off, sizeof(int64_t) * (size_t)nn, hipMemcpyHostToDevice,
+                               ctx->stream));
+        ABZ_HIP(hipMemcpyAsync(s->iai_io[1].p, x ? x : h_x.data() + off, sizeof(double) * (size_t)nn, hipMemcpyHostToDevice, ctx->stream));
+        par_dev = s->iai_io[0].as<int64_t>();
+        x_dev = s->iai_io[1].as<double>();
+    }
     PhaseSpec ps;
     ps.B = nn;
     ps.M = M;
     ps.first = s->first[L - 1];
     ps.gi = nullptr;
-    ps.x = s->iai_io[1].as<double>();
+    ps.x = x_dev;
     ps.tab = nullptr;
     ps.npt = 0;
     ps.period = s->period[L - 1];
@@ -480,8 +507,142 @@ int IaiDriver::contract_nodes(int L, int64_t nn, int64_t base_slot, int64_t off,
     if ((rc = launch_phases(ctx, ps, s->iai_io[4].as<double2>()))) return rc;
     const double2* src = (L == d) ? top_coef() : s->iai_pool[L].as<double2>();
     double2* out = s->iai_pool[L - 1].as<double2>() + base_slot * Lrow;
-    return launch_contract(ctx, src, set_elems(L), s->iai_io[0].as<int64_t>(), 1, s->iai_io[4].as<double2>(), out, nn,
-                           Lrow, M);
+    return launch_contract(ctx, src, set_elems(L), par_dev, 1, s->iai_io[4].as<double2>(), out, nn, Lrow, M);
+}
+
+// Panel mode of the level above the innermost one: panels [c0p, c0p + cnp) of the round (pp_*) go to the device as they
+// are -- 40 B each -- and the device makes their nodes (panel_nodes_kernel), contracts the nodes' coefficient sets, runs
+// the innermost adaptive loops and folds their results back into one (I, E, count, status) per panel (panel_rule_kernel):
+// 16 ncomp + 20 B come back.  Enqueue only; panels_collect waits.
+int IaiDriver::panels_enqueue(int L, int64_t c0p, int64_t cnp, int buf, const Lims& lims) {
+    launches += 1;
+    const int64_t cn = 15 * cnp;
+    int rc;
+    // pinned input block [slot | a | b | at | sw], one asynchronous copy
+    const size_t in_bytes = sizeof(double) * 5 * (size_t)cnp;
+    if ((rc = pin_reserve(buf, in_bytes))) return rc;
+    {
+        char* b = static_cast<char*>(s->iai_pin[buf]);
+        std::memcpy(b, pp_slot.data() + c0p, sizeof(int64_t) * (size_t)cnp);
+        double* f = reinterpret_cast<double*>(b) + cnp;
+        std::memcpy(f, pp_a.data() + c0p, sizeof(double) * (size_t)cnp);
+        std::memcpy(f + cnp, pp_b.data() + c0p, sizeof(double) * (size_t)cnp);
+        std::memcpy(f + 2 * cnp, pp_at.data() + c0p, sizeof(double) * (size_t)cnp);
+        std::memcpy(f + 3 * cnp, pp_sw.data() + c0p, sizeof(double) * (size_t)cnp);
+    }
+    // the kernel reads the panels where the host wrote them (pinned, device-visible: no copy operation in the stream)
+    const char* in_dev = static_cast<const char*>(s->iai_pin_dev[buf]);
+    if (!in_dev) {
+        if ((rc = s->iai_io[2].reserve(in_bytes))) return rc;
+        ABZ_HIP(hipMemcpyAsync(s->iai_io[2].p, s->iai_pin[buf], in_bytes, hipMemcpyHostToDevice, ctx->stream));
+        in_dev = static_cast<const char*>(s->iai_io[2].p);
+    }
+    // [slot | lo | hi | at | sw] of the innermost loops, per node
+    if ((rc = s->iai_io[0].reserve(sizeof(double) * 5 * (size_t)cn))) return rc;
+    PanelNodesSpec pn;
+    pn.npanels = cnp;
+    pn.p_slot = reinterpret_cast<const int64_t*>(in_dev);
+    pn.p_a = reinterpret_cast<const double*>(in_dev) + cnp;
+    pn.p_b = pn.p_a + cnp;
+    pn.p_at = pn.p_b + cnp;
+    pn.p_sw = pn.p_at + cnp;
+    pn.lims_kind = lims.kind;
+    pn.a0 = lims.a[0];
+    pn.b0 = lims.b[0];
+    pn.aL = lims.a[L - 1];
+    pn.n_slot = s->iai_io[0].as<int64_t>();
+    pn.n_lo = s->iai_io[0].as<double>() + cn;
+    pn.n_hi = pn.n_lo + cn;
+    pn.n_at = pn.n_hi + cn;
+    pn.n_sw = pn.n_at + cn;
+    s->iai_used[L - 1] = 0;  // sets of the previous chunk are dead (stream order)
+    {
+        const int64_t Lrow = set_elems(L - 1);
+        if ((rc = s->iai_pool[L - 1].reserve(sizeof(double2) * (size_t)(cn * Lrow)))) return rc;
+        const double2* src = (L == d) ? top_coef() : s->iai_pool[L].as<double2>();
+        if ((rc = launch_panel_contract(ctx, pn, src, set_elems(L), s->dims[L - 1], s->first[L - 1], s->period[L - 1],
+                                        s->iai_pool[L - 1].as<double2>(), Lrow)))
+            return rc;
+    }
+    // innermost loops: node outputs, then the panel outputs behind them
+    const size_t node_out = flat_out_bytes(cn);
+    const size_t node_out_al = (node_out + 15) / 16 * 16;
+    const size_t pan_out = sizeof(double2) * (size_t)(cnp * ncomp) + sizeof(double) * (size_t)cnp + sizeof(int64_t) * (size_t)cnp + sizeof(int) * (size_t)cnp;
+    if ((rc = s->iai_io[3].reserve(node_out_al + pan_out))) return rc;
+    char* ob = static_cast<char*>(s->iai_io[3].p);
+    InnerSpec is;
+    is.n = n;
+    is.d = d;
+    is.M = s->dims[0];
+    is.first = s->first[0];
+    is.period = s->period[0];
+    is.src = s->iai_pool[1].as<double2>();
+    is.packed = pk;
+    is.nint = cn;
+    is.slot = pn.n_slot;
+    is.lo = pn.n_lo;
+    is.hi = pn.n_hi;
+    is.atol = pn.n_at;
+    is.tail = nullptr;
+    is.integrand = integrand;
+    for (int i = 0; i < 4; ++i) is.params[i] = params[i];
+    is.sweep = sweep;
+    is.sweep_arr = pn.n_sw;
+    is.herm = s->hermitian;
+    is.has_rtol = has_rtol;
+    is.rtol_user = rtol_user;
+    is.maxevals = maxevals;
+    is.I_out = reinterpret_cast<double2*>(ob);
+    is.E_out = reinterpret_cast<double*>(ob + sizeof(double2) * (size_t)(cn * ncomp));
+    is.nev_out = reinterpret_cast<int64_t*>(is.E_out + cn);
+    is.status_out = reinterpret_cast<int*>(is.nev_out + cn);
+    if ((rc = (n > 4 ? launch_gen_inner_adaptive(ctx, is) : launch_inner_adaptive(ctx, is)))) return rc;
+    PanelRuleSpec pr;
+    pr.npanels = cnp;
+    pr.ncomp = ncomp;
+    pr.p_a = pn.p_a;
+    pr.p_b = pn.p_b;
+    pr.n_I = is.I_out;
+    pr.n_nev = is.nev_out;
+    pr.n_status = is.status_out;
+    // ... written by the rule kernel straight into the pinned output block where that is device-visible
+    if ((rc = pin_reserve(2 + buf, pan_out))) return rc;
+    char* const pb_map = static_cast<char*>(s->iai_pin_dev[2 + buf]);
+    char* pb = pb_map ? pb_map : ob + node_out_al;
+    pr.p_I = reinterpret_cast<double2*>(pb);
+    pr.p_E = reinterpret_cast<double*>(pb + sizeof(double2) * (size_t)(cnp * ncomp));
+    pr.p_nev = reinterpret_cast<int64_t*>(pr.p_E + cnp);
+    pr.p_status = reinterpret_cast<int*>(pr.p_nev + cnp);
+    if ((rc = launch_panel_rule(ctx, pr))) return rc;
+    if (!pb_map) ABZ_HIP(hipMemcpyAsync(s->iai_pin[2 + buf], pb, pan_out, hipMemcpyDeviceToHost, ctx->stream));
+    if (!ev[buf]) ABZ_HIP(hipEventCreateWithFlags(&ev[buf], hipEventDisableTiming));
+    ABZ_HIP(hipEventRecord(ev[buf], ctx->stream));
+    if (stats) {
+        int b = 0;
+        while (((int64_t)1 << (b + 1)) <= cn) ++b;
+        st_cnt[b] += 1;
+        st_int[b] += cn;
+    }
+    return ABZ_OK;
+}
+
+// Wait for the panel chunk in `buf`; its results go to pI / pE / pnev at round positions c0p...; panels one of whose
+// innermost integrals overflowed the device store are listed in `redo` (round positions)
+int IaiDriver::panels_collect(int64_t c0p, int64_t cnp, int buf, std::vector<int64_t>& redo) {
+    const auto t0 = std::chrono::steady_clock::now();
+    ABZ_HIP(hipEventSynchronize(ev[buf]));
+    if (stats) st_wait += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    const char* f_out = static_cast<const char*>(s->iai_pin[2 + buf]);
+    const cd* hI = reinterpret_cast<const cd*>(f_out);
+    const double* hE = reinterpret_cast<const double*>(f_out + sizeof(double2) * (size_t)(cnp * ncomp));
+    const int64_t* hN = reinterpret_cast<const int64_t*>(hE + cnp);
+    const int* hS = reinterpret_cast<const int*>(hN + cnp);
+    std::memcpy(pI.data() + (size_t)(c0p * ncomp), hI, sizeof(cd) * (size_t)(cnp * ncomp));
+    std::memcpy(pE.data() + (size_t)c0p, hE, sizeof(double) * (size_t)cnp);
+    std::memcpy(pnev.data() + (size_t)c0p, hN, sizeof(int64_t) * (size_t)cnp);
+    for (int64_t i = 0; i < cnp; ++i)
+        if (hS[i] != 0) redo.push_back(c0p + i);
+    return ABZ_OK;
 }
 
 // innermost: h_parents / h_x / h_tail -> h_values [nn][ncomp]
@@ -667,13 +828,45 @@ int IaiDriver::solve_level(int L, std::vector<Quad1D>& quads) {
             act_off[ai] = nn;
             nn += 15 * (int64_t)quads[active[ai]].pend.size();
         }
+        const bool plain_lims = quads[active[0]].lims.kind <= ABZ_LIMS_TETRAHEDRAL;
+        // Panel mode of the level above the innermost one (closed-form limits, the whole round on this GPU): the round's PANELS
+        // go to the device, which makes their nodes, runs the innermost loops and returns one GK sum per panel
+        // (panels_enqueue) -- the host never sees a node.  Values, errors and counts are those of the node path: same
+        // gk15_node, same kernels, same gk15_rule, on the other side of the bus.
+        const bool panel_mode = L == 2 && device_inner && plain_lims && nn > 0 && !(integrand == ABZ_F_LINEAR_X && d > 1) &&
+                                !(ex_fn != nullptr && nn >= (int64_t)64 * ex_world) && abz_switch(SW_IAI_PANELS) != 0;
+        if (panel_mode) {
+            const int64_t npan = nn / 15;
+            pp_slot.resize((size_t)npan);
+            pp_a.resize((size_t)npan);
+            pp_b.resize((size_t)npan);
+            pp_at.resize((size_t)npan);
+            pp_sw.resize((size_t)npan);
+            pp_q.resize((size_t)npan);
+            pI.resize((size_t)(npan * ncomp));
+            pE.resize((size_t)npan);
+            pnev.resize((size_t)npan);
+            par((int64_t)active.size(), true, [&](int64_t b, int64_t e, int) {
+                for (int64_t ai = b; ai < e; ++ai) {
+                    const size_t qi = active[(size_t)ai];
+                    const Quad1D& q = quads[qi];
+                    int64_t pi = act_off[(size_t)ai] / 15;
+                    for (size_t p = 0; p < q.pend.size(); ++p, ++pi) {
+                        pp_slot[(size_t)pi] = q.slot;
+                        pp_a[(size_t)pi] = q.pend[p].a;
+                        pp_b[(size_t)pi] = q.pend[p].b;
+                        pp_at[(size_t)pi] = q.has_atol ? q.atol : -1.0;
+                        pp_sw[(size_t)pi] = q.sweep;
+                        pp_q[(size_t)pi] = (uint32_t)qi;
+                    }
+                }
+            });
+        } else {
         h_parents.resize((size_t)nn);
         h_x.resize((size_t)nn);
         node_q.resize((size_t)nn);
         if (L == 1) h_sweep.resize((size_t)nn);
         if (d > 1) h_tail.resize((size_t)(nn * (d - 1)));
-        int64_t t = 0;
-        const bool plain_lims = quads[active[0]].lims.kind <= ABZ_LIMS_TETRAHEDRAL;
         par((int64_t)active.size(), true, [&](int64_t b, int64_t e, int) {
             double x15[15];
             for (int64_t ai = b; ai < e; ++ai) {
@@ -695,10 +888,12 @@ int IaiDriver::solve_level(int L, std::vector<Quad1D>& quads) {
         });
         vals.resize((size_t)(nn * ncomp));
         nev.resize((size_t)nn);
+        }
         if (stats) st_gather += std::chrono::duration<double>(std::chrono::steady_clock::now() - tg0).count();
         // requests ahead of the pops pay when a round is small (a single solve's stragglers); a round that fills the
         // chip anyway (a 432-omega sweep: 4e5 nodes per round) only pays their bookkeeping (+20 % host time measured)
         const bool spec_round = speculate && nn < spec_cap_nodes;
+        bool panel_round = false;  // this round's GK sums were formed on the device (pI, pE, pnev per panel)
         // ---- evaluate them
         if (L == 1) {
             int rc = eval_nodes(nn);
@@ -738,12 +933,14 @@ int IaiDriver::solve_level(int L, std::vector<Quad1D>& quads) {
                     l_vals.resize(l_x.size() * (size_t)ncomp);
                     l_nev.resize(l_x.size());
                 }
-                const int64_t N = shard ? (int64_t)l_x.size() : nn;  // nodes this rank integrates
-                const int64_t* const P = shard ? l_par.data() : h_parents.data();
-                const double* const X = shard ? l_x.data() : h_x.data();
-                const uint32_t* const Q = shard ? l_q.data() : node_q.data();
-                cd* const V = shard ? l_vals.data() : vals.data();
-                int64_t* const NV = shard ? l_nev.data() : nev.data();
+                // the nodes this rank integrates node by node (all of them, its share of a sharded solve, or -- panel mode --
+                // the nodes of the few panels that have to be redone)
+                int64_t N = shard ? (int64_t)l_x.size() : nn;
+                const int64_t* P = shard ? l_par.data() : h_parents.data();
+                const double* X = shard ? l_x.data() : h_x.data();
+                const uint32_t* Q = shard ? l_q.data() : node_q.data();
+                cd* V = shard ? l_vals.data() : vals.data();
+                int64_t* NV = shard ? l_nev.data() : nev.data();
                 auto describe_and_enqueue = [&](int64_t c0, int64_t cn, int buf) -> int {
                     const auto td0 = std::chrono::steady_clock::now();
                     struct Acc { double& a; std::chrono::steady_clock::time_point t0; bool on; ~Acc() { if (on) a += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); } } acc_{st_describe, td0, stats};
@@ -851,7 +1048,61 @@ int IaiDriver::solve_level(int L, std::vector<Quad1D>& quads) {
                     }
                     return ABZ_OK;
                 };
-                const int local_rc = local_work();
+                int local_rc = ABZ_OK;
+                if (panel_mode) {
+                    const int64_t npan = nn / 15;
+                    const Lims& lims0 = quads[active[0]].lims;  // closed-form limits: a, b are those of the solve
+                    const int64_t pchunk = chunk / 15;
+                    const int64_t nchunks = (npan + pchunk - 1) / pchunk;
+                    std::vector<int64_t> redo_pan;
+                    for (int64_t ci = 0; ci <= nchunks && local_rc == ABZ_OK; ++ci) {
+                        if (ci < nchunks) {
+                            const auto td0 = std::chrono::steady_clock::now();
+                            local_rc = panels_enqueue(L, ci * pchunk, std::min(pchunk, npan - ci * pchunk), (int)(ci & 1), lims0);
+                            if (stats) st_describe += std::chrono::duration<double>(std::chrono::steady_clock::now() - td0).count();
+                        }
+                        if (ci > 0 && local_rc == ABZ_OK)
+                            local_rc = panels_collect((ci - 1) * pchunk, std::min(pchunk, npan - (ci - 1) * pchunk), (int)((ci - 1) & 1), redo_pan);
+                    }
+                    if (local_rc) return local_rc;
+                    panel_round = true;
+                    if (!redo_pan.empty()) {
+                        // a panel with an innermost integral beyond the device's segment store: its fifteen nodes take the
+                        // node path (whose own overflow handling sends them to the host loop), the host applies the rule
+                        l_par.clear();
+                        l_x.clear();
+                        l_q.clear();
+                        for (int64_t pi : redo_pan) {
+                            double x15[15];
+                            gk15_nodes(pp_a[(size_t)pi], pp_b[(size_t)pi], x15);
+                            for (int i = 0; i < 15; ++i) {
+                                l_par.push_back(pp_slot[(size_t)pi]);
+                                l_x.push_back(x15[i]);
+                                l_q.push_back(pp_q[(size_t)pi]);
+                            }
+                        }
+                        l_vals.resize(l_x.size() * (size_t)ncomp);
+                        l_nev.resize(l_x.size());
+                        N = (int64_t)l_x.size();
+                        P = l_par.data();
+                        X = l_x.data();
+                        Q = l_q.data();
+                        V = l_vals.data();
+                        NV = l_nev.data();
+                        redo_nodes.clear();
+                        local_rc = local_work();
+                        if (local_rc) return local_rc;
+                        for (size_t r = 0; r < redo_pan.size(); ++r) {
+                            const int64_t pi = redo_pan[r];
+                            gk15_evalrule(&l_vals[r * 15 * (size_t)ncomp], ncomp, pp_a[(size_t)pi], pp_b[(size_t)pi], &pI[(size_t)(pi * ncomp)], &pE[(size_t)pi]);
+                            int64_t tot = 0;
+                            for (int i = 0; i < 15; ++i) tot += l_nev[r * 15 + (size_t)i];
+                            pnev[(size_t)pi] = tot;
+                        }
+                    }
+                } else {
+                    local_rc = local_work();
+                }
                 if (!shard && local_rc) return local_rc;
                 if (shard) {
                     // all-gather: per rank `per` slots of (2 ncomp + 1) doubles -- values and evaluation counts of its nodes
@@ -970,7 +1221,12 @@ int IaiDriver::solve_level(int L, std::vector<Quad1D>& quads) {
             got.resize(q.pend.size());
             for (size_t p = 0; p < q.pend.size(); ++p, t += 15) {
                 Seg sg = q.pend[p];
-                gk15_evalrule(&vals[(size_t)(t * ncomp)], ncomp, sg.a, sg.b, Iseg.data(), &sg.E);
+                if (panel_round) {
+                    for (int c = 0; c < ncomp; ++c) Iseg[(size_t)c] = pI[(size_t)((t / 15) * ncomp + c)];
+                    sg.E = pE[(size_t)(t / 15)];
+                } else {
+                    gk15_evalrule(&vals[(size_t)(t * ncomp)], ncomp, sg.a, sg.b, Iseg.data(), &sg.E);
+                }
                 if (!std::isfinite(sg.E)) {
                     std::lock_guard<std::mutex> lk(bad_m);
                     if (!bad.exchange(1)) {
@@ -981,7 +1237,10 @@ int IaiDriver::solve_level(int L, std::vector<Quad1D>& quads) {
                 }
                 sg.ioff = (int64_t)q.store.size();
                 sg.nev = 0;
-                for (int i = 0; i < 15; ++i) sg.nev += nev[(size_t)(t + i)];
+                if (panel_round)
+                    sg.nev = pnev[(size_t)(t / 15)];
+                else
+                    for (int i = 0; i < 15; ++i) sg.nev += nev[(size_t)(t + i)];
                 q.store.insert(q.store.end(), Iseg.begin(), Iseg.end());
                 got[p] = sg;
             }

@@ -2089,8 +2089,10 @@ __device__ __forceinline__ void series_point_pk(PTR c1, int F, double zr, double
     }
     double pr = 1.0, pi = 0.0;
     for (int f = 1; f <= F; ++f) {
-        const double nr = pr * zr - pi * zi;
-        const double ni = pr * zi + pi * zr;
+        // every multiply-add is spelled out: left to the compiler, `a * b + c * d` is contracted one way in one kernel and
+        // the other way in the next, and the IAI kernels that share this function stop agreeing to the bit
+        const double nr = fma(pr, zr, -(pi * zi));
+        const double ni = fma(pr, zi, pi * zr);
         pr = nr;
         pi = ni;
         const int o = Pk<N>::blk(1) + (f - 1) * (N * N);
@@ -2287,8 +2289,8 @@ __device__ __forceinline__ void series_lane_lds(const double2* c1, int M, double
                 }
             }
         }
-        const double nr = pr * zr - pi * zi;
-        const double ni = pr * zi + pi * zr;
+        const double nr = fma(pr, zr, -(pi * zi));
+        const double ni = fma(pr, zi, pi * zr);
         pr = nr;
         pi = ni;
     }
@@ -2319,6 +2321,7 @@ struct InnerArgs {
     int64_t nint, maxevals;
     int M, first, d, ncomp, has_rtol;
     int pk;    // the level-1 sets are packed Hermitian rows (packed_herm.h): folded series, no seed phase
+    double sc[16];  // sincospi_poly's coefficients (kernel arguments: scalar operands of the FMAs)
     double inv_period, sweep, rtol_user;
     double p[4];
     double2* I_out;
@@ -2380,12 +2383,11 @@ __global__ __launch_bounds__(256) void inner_adaptive_kernel(InnerArgs a) {
                     const double xx = x * a.inv_period;
                     double zr, zi, wr, wi;
                     CMat<N> H;
+                    sincospi_poly(a.sc, 2.0 * xx, zi, zr);  // the same phases as inner_adaptive_wave_kernel: the two kernels agree to the bit
                     if (HERM && a.pk) {
-                        sincospi(2.0 * xx, &zi, &zr);
                         series_point_pk<N>((const double2*)cl, (a.M - 1) / 2, zr, zi, H);
                     } else {
-                        sincospi(2.0 * xx, &zi, &zr);
-                        sincospi(2.0 * ((double)a.first * xx), &wi, &wr);
+                        sincospi_poly(a.sc, 2.0 * ((double)a.first * xx), wi, wr);
                         series_lane_lds<N, HERM>(cl, a.M, zr, zi, wr, wi, H);
                     }
                     double e[N];
@@ -2439,27 +2441,19 @@ __global__ __launch_bounds__(256) void inner_adaptive_kernel(InnerArgs a) {
 // length of a round counts) gave 2 490 cycles for the 30 node values of a round and 5 090 for that serial step -- a chain of
 // dependent LDS round trips (ctl, the fifteen values, the heap levels, the popped parent).  Here the state never leaves the
 // wave's registers: lane j holds heap position j (error, segment slot) and segment slot j (a, b, I); everything the step
-// decides is wave-uniform, so heap levels are v_readlane / v_writelane with scalar indices (a few cycles each) and the
-// branches are scalar.  Lanes 0 and 1 apply the GK rule to the two pending panels, whose fifteen values they pull from
+// decides is wave-uniform, so heap levels are v_readlane with scalar indices (a few cycles each), writes are compare-selects by the
+// lane index (a v_writelane needs its value and lane in scalar registers: three times the instructions) and the branches
+// are scalar.  Lanes 0 and 1 apply the GK rule to the two pending panels, whose fifteen values they pull from
 // their owners' registers (ds_bpermute, no LDS storage).  The arithmetic and its order are those of adapt_step: identical
 // (I, E), identical heap decisions (DataStructures.jl percolate semantics), identical counts.  The segment store is the
 // wave (lanes 0 ... ABZ_INNER_MAXSEG - 1, the LDS kernel's capacity: an integral that needs more is redone by the host loop,
 // whose node kernel evaluates the integrand by another formula -- the same integrals must take that road in both kernels).
-// (clang has no __builtin_amdgcn_writelane: the LLVM intrinsic by its name; on gfx9 it lowers to s_mov_b32 m0, lane +
-// v_writelane_b32 v, value, m0 -- one SGPR on the constant bus, and no VALU-written lane select)
-extern "C" __device__ int abz_writelane_i32(int val, int lane, int old) __asm("llvm.amdgcn.writelane.i32");
 __device__ __forceinline__ double rl_f64(double v, int lane) {
     const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
     const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
     return __hiloint2double(hi, lo);
 }
-__device__ __forceinline__ void wl_f64(double& v, int lane, double x) {
-    const int lo = abz_writelane_i32(__double2loint(x), lane, __double2loint(v));
-    const int hi = abz_writelane_i32(__double2hiint(x), lane, __double2hiint(v));
-    v = __hiloint2double(hi, lo);
-}
 __device__ __forceinline__ int rl_i32(int v, int lane) { return __builtin_amdgcn_readlane(v, lane); }
-__device__ __forceinline__ void wl_i32(int& v, int lane, int x) { v = abz_writelane_i32(x, lane, v); }
 
 template <int N, int FID, bool HERM>
 __global__ __launch_bounds__(256) void inner_adaptive_wave_kernel(InnerArgs a) {
@@ -2499,12 +2493,11 @@ __global__ __launch_bounds__(256) void inner_adaptive_wave_kernel(InnerArgs a) {
                 const double xx = x * a.inv_period;
                 double zr, zi, wr, wi;
                 CMat<N> H;
+                sincospi_poly(a.sc, 2.0 * xx, zi, zr);  // (the library routine: 880 of a round's 5 600 cycles; this one 1 ulp, a quarter of that)
                 if (HERM && a.pk) {
-                    sincospi(2.0 * xx, &zi, &zr);
                     series_point_pk<N>((const double2*)cl, (a.M - 1) / 2, zr, zi, H);
                 } else {
-                    sincospi(2.0 * xx, &zi, &zr);
-                    sincospi(2.0 * ((double)a.first * xx), &wi, &wr);
+                    sincospi_poly(a.sc, 2.0 * ((double)a.first * xx), wi, wr);
                     series_lane_lds<N, HERM>(cl, a.M, zr, zi, wr, wi, H);
                 }
                 double e[N];
@@ -2562,26 +2555,26 @@ __global__ __launch_bounds__(256) void inner_adaptive_wave_kernel(InnerArgs a) {
             }
             if (first) {
                 first = false;
-                wl_f64(sA, s1, a1);
-                wl_f64(sB, s1, b1);
-                wl_f64(sIr, s1, I1r);
-                wl_f64(sIi, s1, I1i);
+                sA = l == s1 ? a1 : sA;
+                sB = l == s1 ? b1 : sB;
+                sIr = l == s1 ? I1r : sIr;
+                sIi = l == s1 ? I1i : sIi;
                 Ir = I1r;
                 Ii = I1i;
                 E = E1;
                 numevals = 15;
-                wl_i32(hS, 0, s1);
-                wl_f64(hE, 0, E1);
+                hS = l == 0 ? s1 : hS;
+                hE = l == 0 ? E1 : hE;
                 nheap = 1;
             } else {
-                wl_f64(sA, s1, a1);
-                wl_f64(sB, s1, b1);
-                wl_f64(sIr, s1, I1r);
-                wl_f64(sIi, s1, I1i);
-                wl_f64(sA, s2, a2);
-                wl_f64(sB, s2, b2);
-                wl_f64(sIr, s2, I2r);
-                wl_f64(sIi, s2, I2i);
+                sA = l == s1 ? a1 : sA;
+                sB = l == s1 ? b1 : sB;
+                sIr = l == s1 ? I1r : sIr;
+                sIi = l == s1 ? I1i : sIi;
+                sA = l == s2 ? a2 : sA;
+                sB = l == s2 ? b2 : sB;
+                sIr = l == s2 ? I2r : sIr;
+                sIi = l == s2 ? I2i : sIi;
                 {
 #pragma clang fp contract(off)
                     Ir = ((Ir - parIr) + I1r) + I2r;
@@ -2596,12 +2589,15 @@ __global__ __launch_bounds__(256) void inner_adaptive_wave_kernel(InnerArgs a) {
                         const int j = (h - 1) / 2;
                         const double Ej = rl_f64(hE, j);
                         if (!(Ej < Ex)) break;
-                        wl_i32(hS, h, rl_i32(hS, j));
-                        wl_f64(hE, h, Ej);
+                        {
+                            const int hj = rl_i32(hS, j);
+                            hS = l == h ? hj : hS;
+                            hE = l == h ? Ej : hE;
+                        }
                         h = j;
                     }
-                    wl_i32(hS, h, xs);
-                    wl_f64(hE, h, Ex);
+                    hS = l == h ? xs : hS;
+                    hE = l == h ? Ex : hE;
                 }
             }
             double tol = atol;
@@ -2638,12 +2634,15 @@ __global__ __launch_bounds__(256) void inner_adaptive_wave_kernel(InnerArgs a) {
                         }
                         if (!(Ey < Ej)) break;
                         const int j = left ? lc : rc;
-                        wl_i32(hS, h, rl_i32(hS, j));
-                        wl_f64(hE, h, Ej);
+                        {
+                            const int hj = rl_i32(hS, j);
+                            hS = l == h ? hj : hS;
+                            hE = l == h ? Ej : hE;
+                        }
                         h = j;
                     }
-                    wl_i32(hS, h, y);
-                    wl_f64(hE, h, Ey);
+                    hS = l == h ? y : hS;
+                    hE = l == h ? Ey : hE;
                 }
                 popped = xs;
                 numevals += 30;
@@ -2677,6 +2676,98 @@ __global__ __launch_bounds__(256) void inner_adaptive_wave_kernel(InnerArgs a) {
             break;
         }
     }
+}
+
+// ---- panels of the level above the innermost one (abz_internal.h: PanelNodesSpec / PanelRuleSpec) ----
+// One block per node of a panel: the node's coordinate (gk15_node), the limits / tolerance / swept value of the innermost
+// integral beneath it (Lims::fix + range of iai_host.cpp, operation for operation), its M phases (phase_kernel's expression)
+// and the contraction of its parent's coefficient set (contract_kernel's sum, term for term) -- three launches of the node
+// path in one, fed by 40 B per PANEL that the kernel reads where the host wrote them (pinned, device-visible memory).
+__global__ void panel_contract_kernel(PanelNodesSpec a, const double2* __restrict__ src, int64_t slot_elems, int M, int first,
+                                      double inv_period, double2* __restrict__ out, int64_t Lrow) {
+    extern __shared__ double2 pc_phs[];  // [M]
+    const int64_t t = blockIdx.x;
+    const int64_t p = t / 15;
+    const int i = (int)(t - 15 * p);
+    double x;
+    {
+#pragma clang fp contract(off)
+        x = gk15_node(a.p_a[p], a.p_b[p], i);
+        if (threadIdx.x == 0 && blockIdx.y == 0) {
+            // Lims::fix(L, x) + range(1): CubicLimits (a0, b0); TetrahedralLimits s = x / a[L - 1], (0, a[0] * s)
+            double lo = a.a0, hi = a.b0;
+            if (a.lims_kind == ABZ_LIMS_TETRAHEDRAL) {
+                const double sc = x / a.aL;
+                lo = 0.0;
+                hi = a.a0 * sc;
+            }
+            const double at = a.p_at[p];
+            a.n_slot[t] = t;
+            a.n_lo[t] = lo;
+            a.n_hi[t] = hi;
+            a.n_at[t] = at >= 0.0 ? at / (hi - lo) : -1.0;  // ref src/fourier.jl:479-480
+            a.n_sw[t] = a.p_sw[p];
+        }
+    }
+    for (int m = threadIdx.x; m < M; m += blockDim.x) {
+        double c, sn;
+        sincospi(2.0 * ((double)(first + m) * x * inv_period), &sn, &c);
+        pc_phs[m] = make_double2(c, sn);
+    }
+    __syncthreads();
+    const int64_t l = (int64_t)blockIdx.y * blockDim.x + threadIdx.x;
+    if (l >= Lrow) return;
+    const double2* __restrict__ sp = src + a.p_slot[p] * slot_elems + l;
+    double ar = 0.0, ai = 0.0;
+    for (int m = 0; m < M; ++m) {
+        const double2 c = sp[(int64_t)m * Lrow];
+        const double2 ph = pc_phs[m];
+        ar = fma(c.x, ph.x, ar);
+        ar = fma(-c.y, ph.y, ar);
+        ai = fma(c.x, ph.y, ai);
+        ai = fma(c.y, ph.x, ai);
+    }
+    out[t * Lrow + l] = make_double2(ar, ai);
+}
+
+int launch_panel_contract(abz_ctx* ctx, const PanelNodesSpec& ps, const double2* src, int64_t slot_elems, int M, int first, double period,
+                          double2* out, int64_t Lrow) {
+    if (ps.npanels == 0) return ABZ_OK;
+    ProfScope pf(ctx, ABZ_K_CONTRACT);
+    const int bs = Lrow <= 64 ? 64 : (Lrow <= 128 ? 128 : 256);
+    const int64_t gy = cdiv(Lrow, bs);
+    if (gy > 65535) {
+        set_error("panel_contract: row length %lld too large", (long long)Lrow);
+        return ABZ_ERR_UNSUPPORTED;
+    }
+    hipLaunchKernelGGL(panel_contract_kernel, dim3((unsigned)(15 * ps.npanels), (unsigned)gy), dim3(bs), sizeof(double2) * (size_t)M, ctx->stream,
+                       ps, src, slot_elems, M, first, 1.0 / period, out, Lrow);
+    ABZ_HIP(hipGetLastError());
+    return ABZ_OK;
+}
+
+__global__ __launch_bounds__(256) void panel_rule_kernel(PanelRuleSpec a) {
+    const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (p >= a.npanels) return;
+    // the shared rule on the panel's fifteen innermost integrals (node-major, ncomp components each): what the host's
+    // gk15_evalrule computes from the same numbers
+    const gkc* fv = reinterpret_cast<const gkc*>(a.n_I + (size_t)(15 * p) * a.ncomp);
+    a.p_E[p] = gk15_rule(fv, a.ncomp, a.p_a[p], a.p_b[p], reinterpret_cast<gkc*>(a.p_I + (size_t)p * a.ncomp));
+    int64_t nev = 0;
+    int st = 0;
+    for (int i = 0; i < 15; ++i) {
+        nev += a.n_nev[15 * p + i];
+        st |= a.n_status[15 * p + i];
+    }
+    a.p_nev[p] = nev;
+    a.p_status[p] = st;
+}
+
+int launch_panel_rule(abz_ctx* ctx, const PanelRuleSpec& ps) {
+    if (ps.npanels == 0) return ABZ_OK;
+    hipLaunchKernelGGL(panel_rule_kernel, dim3((unsigned)cdiv(ps.npanels, 256)), dim3(256), 0, ctx->stream, ps);
+    ABZ_HIP(hipGetLastError());
+    return ABZ_OK;
 }
 
 bool inner_adaptive_supported(int n, int M, int integrand) {
@@ -2715,6 +2806,7 @@ int launch_inner_adaptive(abz_ctx* ctx, const InnerSpec& is) {
     // (a polynomial sincospi for the node phases measured 31.3 against 32.0 ms on the SVO full-BZ solve: the phases are
     // not what bounds a round; the library routine stays)
     a.pk = (is.packed && is.herm) ? 1 : 0;
+    for (int i = 0; i < 16; ++i) a.sc[i] = kSinCosPiCoef[i];
     a.inv_period = 1.0 / is.period;
     a.sweep = is.sweep;
     a.rtol_user = is.rtol_user;

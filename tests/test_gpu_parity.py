@@ -1049,16 +1049,18 @@ def test_iai_speculative_requests_change_nothing(abz, monkeypatch, n, dims, eta,
     f = abz.FourierIntegrand(abz.DOSIntegrand(), s, eta)
     runs = {}
     for tag, env in (("spec", {}), ("serial", {"ABZ_IAI_SPECULATE": "0"}), ("chunks", {"ABZ_IAI_POOL_MB": "1"}),
-                     ("onelane", {"ABZ_ADAPT_PAIR": "0"}),  # n <= 4: the one-lane adaptive step of the innermost kernel
+                     ("onelane", {"ABZ_ADAPT_PAIR": "0"}),  # n <= 4: the LDS kernel with its one-lane step instead of the register-resident one
+                     ("nodes", {"ABZ_IAI_PANELS": "0"}),  # the level above the innermost one ships nodes, the host applies its GK rule
+                     ("nodes_chunks", {"ABZ_IAI_PANELS": "0", "ABZ_IAI_POOL_MB": "1"}),
                      ("fullrows", {"ABZ_IAI_PACKED": "0"})):  # n <= 4: the chain on full instead of packed Hermitian rows
-        for k in ("ABZ_IAI_SPECULATE", "ABZ_IAI_POOL_MB", "ABZ_ADAPT_PAIR", "ABZ_IAI_PACKED"):
+        for k in ("ABZ_IAI_SPECULATE", "ABZ_IAI_POOL_MB", "ABZ_ADAPT_PAIR", "ABZ_IAI_PACKED", "ABZ_IAI_PANELS"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
         sol = abz.do_solve(f, bz, abz.MixedParameters(0.1), abz.EvalCounter(abz.IAI()), abstol=abstol, reltol=0.0, _panels=True)
         runs[tag] = (sol.u, sol.resid, sol.numevals, sol.extra["panels"])
-    for tag in ("serial", "chunks", "onelane"):
-        assert runs[tag][0] == runs["spec"][0] and runs[tag][1] == runs["spec"][1] and runs[tag][2] == runs["spec"][2]
+    for tag in ("serial", "chunks", "onelane", "nodes", "nodes_chunks"):
+        assert runs[tag][0] == runs["spec"][0] and runs[tag][1] == runs["spec"][1] and runs[tag][2] == runs["spec"][2], tag
         assert np.array_equal(runs[tag][3], runs["spec"][3])
     # packed and full rows sum the same terms in a different order: same panels and counts, values equal to rounding
     assert runs["fullrows"][2] == runs["spec"][2] and np.array_equal(runs["fullrows"][3], runs["spec"][3])
