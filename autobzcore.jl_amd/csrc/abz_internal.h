@@ -494,6 +494,9 @@ int launch_eval_sum(abz_ctx* ctx, const SumSpec& ss, double* out_reim);
 int launch_final_reduce(abz_ctx* ctx, const double2* partial, int64_t nblocks, int64_t ncols, double scale, double2* out);
 // the same for 5..32 bands (kernels_generic.hip): resolvent-trace integrands, one workgroup per grid line
 bool gen_sum_supported(int n, int M, int npt, int integrand, bool herm);
+// 5...16 bands: can a rule of a Hermitian series keep H(k) as its upper triangle (ABZ_WANT_H_COMPACT)?  True when the row
+// kernel gen_grid_eig_kernel fills it (and every scan of kernels_generic.hip reads either layout)
+bool gen_compact_supported(int n, int M, int npt);
 int launch_gen_sum(abz_ctx* ctx, const SumSpec& ss, double* out_reim);
 int launch_gen_reduce(abz_ctx* ctx, const ReduceSpec& rs, double* out_reim);
 

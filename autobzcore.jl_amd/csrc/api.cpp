@@ -1033,7 +1033,10 @@ static int rule_build(abz_series* s, int npt, int64_t nirr, const int32_t* irr_i
     const int pitch = (line_len + 15) / 16 * 16;  // whole 128-B lines: 64-B and 16-B quanta measured 25-40 % slower
     r->ntiles = std::max<int64_t>(1, (plan.nk + line_len - 1) / line_len);
     // Hermitian-compact H planes (abzhip.h): the upper triangle only
-    const bool compact = (want & ABZ_WANT_H) && (want & ABZ_WANT_H_COMPACT) && s->hermitian && n <= 4;
+    // (1...4 bands: the grid / node kernels of kernels.hip; 5...16 bands: the row kernel of kernels_generic.hip, full grids and
+    // node lists with runs -- the wave-per-node fallback writes the full layout only)
+    const bool compact = (want & ABZ_WANT_H) && (want & ABZ_WANT_H_COMPACT) && s->hermitian &&
+                         (n <= 4 || (!(want & ABZ_WANT_VEL) && (r->full || d >= 2) && gen_compact_supported(n, s->dims[0], npt)));
     if (!compact) r->want = (want &= ~ABZ_WANT_H_COMPACT);
     const int pH = (want & ABZ_WANT_H) ? (compact ? n * n : 2 * n * n) : 0;
     const int pE = (want & ABZ_WANT_EIG) ? n : 0;
@@ -1488,7 +1491,7 @@ static int series_rule(abz_series* s, int npt, const int32_t* syms, int nsyms, i
 
 static size_t rule_value_bytes(const abz_series* s, int npt, int64_t nk, int want) {
     const int n = s->n;
-    const bool compact = (want & ABZ_WANT_H_COMPACT) && s->hermitian && n <= 4;
+    const bool compact = (want & ABZ_WANT_H_COMPACT) && s->hermitian && (n <= 4 || gen_compact_supported(n, s->dims[0], npt));
     const size_t per = 8 * (size_t)(((want & ABZ_WANT_H) ? (compact ? n * n : 2 * n * n) : 0) + ((want & ABZ_WANT_EIG) ? n : 0));
     return per * (size_t)nk;
 }
@@ -1526,7 +1529,7 @@ int abz_autoptr_solve_many(abz_series* s, const int32_t* syms, int nsyms, int in
     }
     // rules of a Hermitian series keep the upper triangle of H(k): every built-in integrand reads those planes only
     int want = integrand == ABZ_F_DOS_EIG ? ABZ_WANT_EIG : ABZ_WANT_H;
-    if ((want & ABZ_WANT_H) && s->hermitian && n <= 4) want |= ABZ_WANT_H_COMPACT;
+    if ((want & ABZ_WANT_H) && s->hermitian) want |= ABZ_WANT_H_COMPACT;  // (ignored where no compact kernel exists)
     const size_t ncs = (size_t)ncomp;
     std::vector<double2> I1((size_t)n_sweep * ncs), I2((size_t)n_sweep * ncs), vals((size_t)n_sweep * ncs);
     std::vector<double> sw((size_t)n_sweep);

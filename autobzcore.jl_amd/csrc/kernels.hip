@@ -26,6 +26,7 @@
 #include <cmath>
 #include <cstring>
 #include <type_traits>
+#include <utility>
 #include <cstdlib>
 
 namespace abz {
@@ -2076,8 +2077,11 @@ int export_planes(abz_ctx* ctx, PlaneView v, int ncomp, int64_t nk, double* host
 // pointer): z = e^{2 pi i x}, p = z^f by recurrence, one FMA group for +f and -f, the lower triangle mirrored.  The
 // arithmetic of eval_unit_core's packed branch for a single node: the IAI kernels' series (half the terms of the
 // 2 F + 1 loop, and no seed phase z^first).
-template <int N, class PTR>
-__device__ __forceinline__ void series_point_pk(PTR c1, int F, double zr, double zi, CMat<N>& H) {
+// FC > 0: the number of frequency pairs is known at compile time (the loop unrolls and the coefficient reads of the later
+// frequencies are issued while the earlier ones are summed); the same operations in the same order either way.
+template <int N, class PTR, int FC = 0>
+__device__ __forceinline__ void series_point_pk(PTR c1, int F_, double zr, double zi, CMat<N>& H) {
+    const int F = FC > 0 ? FC : F_;
 #pragma unroll
     for (int bb = 0; bb < N; ++bb) {
 #pragma unroll
@@ -2088,6 +2092,7 @@ __device__ __forceinline__ void series_point_pk(PTR c1, int F, double zr, double
         }
     }
     double pr = 1.0, pi = 0.0;
+#pragma unroll
     for (int f = 1; f <= F; ++f) {
         // every multiply-add is spelled out: left to the compiler, `a * b + c * d` is contracted one way in one kernel and
         // the other way in the next, and the IAI kernels that share this function stop agreeing to the bit
@@ -2448,6 +2453,20 @@ __global__ __launch_bounds__(256) void inner_adaptive_kernel(InnerArgs a) {
 // (I, E), identical heap decisions (DataStructures.jl percolate semantics), identical counts.  The segment store is the
 // wave (lanes 0 ... ABZ_INNER_MAXSEG - 1, the LDS kernel's capacity: an integral that needs more is redone by the host loop,
 // whose node kernel evaluates the integrand by another formula -- the same integrals must take that road in both kernels).
+// value of `v` in lane C of this lane's 16-lane row (v_mov_b64_dpp row_newbcast:C, gfx90a+)
+template <int C>
+__device__ __forceinline__ double row16_bcast(double v) {
+#if defined(__HIP_DEVICE_COMPILE__)  // the host pass of hipcc only knows the 32-bit signature of the builtin
+    const long long x = __builtin_bit_cast(long long, v);
+    return __builtin_bit_cast(double, (long long)__builtin_amdgcn_mov_dpp(x, 0x150 + C, 0xf, 0xf, false));
+#else
+    return v;
+#endif
+}
+template <int... T>
+__device__ __forceinline__ void gk_row_values(double vr, double vi, gkc (&rv)[15], std::integer_sequence<int, T...>) {
+    ((rv[T].re = row16_bcast<T>(vr), rv[T].im = row16_bcast<T>(vi)), ...);
+}
 __device__ __forceinline__ double rl_f64(double v, int lane) {
     const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
     const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
@@ -2495,7 +2514,11 @@ __global__ __launch_bounds__(256) void inner_adaptive_wave_kernel(InnerArgs a) {
                 CMat<N> H;
                 sincospi_poly(a.sc, 2.0 * xx, zi, zr);  // (the library routine: 880 of a round's 5 600 cycles; this one 1 ulp, a quarter of that)
                 if (HERM && a.pk) {
-                    series_point_pk<N>((const double2*)cl, (a.M - 1) / 2, zr, zi, H);
+                    const int F = (a.M - 1) / 2;
+                    if (F == 5)  // 11 coefficients per variable (Wannier90 models on R in [-5, 5]^d, the reference's example)
+                        series_point_pk<N, const double2*, 5>((const double2*)cl, 5, zr, zi, H);
+                    else
+                        series_point_pk<N>((const double2*)cl, F, zr, zi, H);
                 } else {
                     sincospi_poly(a.sc, 2.0 * ((double)a.first * xx), wi, wr);
                     series_lane_lds<N, HERM>(cl, a.M, zr, zi, wr, wi, H);
@@ -2524,18 +2547,16 @@ __global__ __launch_bounds__(256) void inner_adaptive_wave_kernel(InnerArgs a) {
                 vr = wr_[0];
                 vi = wi_[0];
             }
-            // ---- the GK rule: lane p takes pending panel p, its fifteen values come from their owners' registers
-            const int pl = l < np ? l : 0;
+            // ---- the GK rule: a panel's fifteen values sit in the first fifteen lanes of a 16-lane row, so every lane of the row
+            // gets them by row broadcasts on the VALU (v_mov_b64_dpp row_newbcast: one instruction per value, no LDS crossbar)
+            // and applies the rule; rows 0 and 1 hold the two pending panels
+            const int pl = (pnl < np) ? pnl : 0;
             gkc rv[15];
-#pragma unroll
-            for (int t = 0; t < 15; ++t) {
-                rv[t].re = __shfl(vr, 16 * pl + t, 64);
-                rv[t].im = __shfl(vi, 16 * pl + t, 64);
-            }
+            gk_row_values(vr, vi, rv, std::make_integer_sequence<int, 15>());
             gkc Il;
             const double El = gk15_rule(rv, 1, pl ? a2 : a1, pl ? b2 : b1, &Il);
             const double E1 = rl_f64(El, 0), I1r = rl_f64(Il.re, 0), I1i = rl_f64(Il.im, 0);
-            const double E2 = rl_f64(El, 1), I2r = rl_f64(Il.re, 1), I2i = rl_f64(Il.im, 1);
+            const double E2 = rl_f64(El, 16), I2r = rl_f64(Il.re, 16), I2i = rl_f64(Il.im, 16);
             // ---- the step, on wave-uniform values (adapt_step's operations in adapt_step's order)
             int s1, s2 = -1;
             if (popped >= 0)

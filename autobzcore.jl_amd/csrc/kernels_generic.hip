@@ -1215,6 +1215,7 @@ struct GenEigArgs {
     const int64_t* run_start = nullptr;  // irregular lists: line l owns nodes [run_start[l], run_start[l + 1]) with grid indices gi
     const int32_t* gi = nullptr;
     int n, M, first, npt;
+    int herm = 0;  // Hermitian series: H(k) leaves the kernel as its upper triangle (mirrored into the full layout's lower planes)
 };
 
 
@@ -1734,8 +1735,11 @@ __global__ __launch_bounds__(256, (TRI && !VEC) ? 2 : 1) void gen_grid_eig_kerne
     static_assert(!(VEC && TRI) || PAD, "inverse iteration works on the zero-padded layout");
     extern __shared__ double2 lds_ge[];
     constexpr int SLOTS = 256 / NP;
+    constexpr int TS = SLOTS + 1;        // tile row stride (doubles): one bank further per plane
+    constexpr int PC = NP == 16 ? 144 : 64;  // planes per tile pass: columns 0...11 of 16 rows (16 nodes) / all 64 of 8 rows (32 nodes)
     const int n = a.n, nn = n * n, M = a.M;
     double2* coef = lds_ge;
+    double* const tile = reinterpret_cast<double*>(coef + (size_t)M * (PAD ? NP * NP : nn));  // [PC][TS]
     const int slot = threadIdx.x / NP, r = threadIdx.x % NP, lane = threadIdx.x & 63;
     int fm = a.first % a.npt;
     if (fm < 0) fm += a.npt;
@@ -1747,24 +1751,78 @@ __global__ __launch_bounds__(256, (TRI && !VEC) ? 2 : 1) void gen_grid_eig_kerne
         const int64_t kbase = a.run_start ? a.run_start[line] : line * a.npt;
         const int count = a.run_start ? (int)(a.run_start[line + 1] - kbase) : a.npt;
         for (int i0 = 0; i0 < count; i0 += SLOTS) {
-            if (i0 + (int)(threadIdx.x >> 6) * (64 / NP) >= count) continue;  // no node for this wave (only wave-level sync below)
+            // a wave without a node in this pass computes nothing but keeps the block's barriers (the stores go through LDS)
+            const bool wave_on = i0 + (int)(threadIdx.x >> 6) * (64 / NP) < count;
             const int i1 = i0 + slot;
             const bool act = i1 < count;
             const int ii = act ? i1 : 0;
-            const int ic = a.gi ? a.gi[kbase + ii] : ii;
-            const double2 z = a.tab[ic];
-            const double2 w = a.tab[(int)(((unsigned)fm * (unsigned)ic) % (unsigned)a.npt)];
-            double hr[NP], hi[NP];
-            panel_series_row<NP, PAD>(coef, n, M, z.x, z.y, w.x, w.y, r, hr, hi);  // row r of -H(k)
-#pragma unroll
-            for (int j = 0; j < NP; ++j) {
-                const bool real = PAD || (r < n && j < n);
-                hr[j] = real ? -hr[j] : 0.0;
-                hi[j] = real ? -hi[j] : 0.0;
-            }
             const int64_t k = kbase + ii;
             const bool wr = act && r < n;
-            if (a.H.base && wr) {
+            double hr[NP], hi[NP];
+            if (wave_on) {
+                const int ic = a.gi ? a.gi[kbase + ii] : ii;
+                const double2 z = a.tab[ic];
+                const double2 w = a.tab[(int)(((unsigned)fm * (unsigned)ic) % (unsigned)a.npt)];
+                panel_series_row<NP, PAD>(coef, n, M, z.x, z.y, w.x, w.y, r, hr, hi);  // row r of -H(k)
+#pragma unroll
+                for (int j = 0; j < NP; ++j) {
+                    const bool real = PAD || (r < n && j < n);
+                    hr[j] = real ? -hr[j] : 0.0;
+                    hi[j] = real ? -hi[j] : 0.0;
+                }
+            }
+            if (a.H.base && a.herm) {
+                // Hermitian H(k): the upper triangle (compact plane order: Re / Im of H[a][b], a < b, at b^2 + 2a, + 1; H[b][b]
+                // at b^2 + 2b) goes through an LDS tile [plane][node] so that every plane row leaves the block as runs of SLOTS
+                // consecutive nodes (whole 128-B lines; lane-by-lane each store instruction wrote sixteen 32-B pieces).
+                // Full layout: the lower triangle is the conjugate of the same numbers, the diagonal's imaginary plane 0.
+                // Two tile passes by COLUMNS (16 rows: columns 0...11 = planes 0...143, then 12...15 = planes 144...255; 8 rows:
+                // one pass), so that plane indices are compile-time offsets from one lane-dependent address.
+                auto pass = [&](auto j0c, auto j1c) {
+                    constexpr int J0 = decltype(j0c)::value, J1 = decltype(j1c)::value;
+                    if (n <= J0) return;  // uniform
+                    if (wave_on && wr) {
+                        double* const tp = tile + (2 * r) * TS + slot;
+#pragma unroll
+                        for (int j = J0; j < J1; ++j) {
+                            if (j < n && r <= j) {
+                                tp[(j * j - J0 * J0) * TS] = hr[j];
+                                if (r < j) tp[(j * j - J0 * J0 + 1) * TS] = hi[j];
+                            }
+                        }
+                    }
+                    __syncthreads();
+                    const int jend = n < J1 ? n : J1;
+                    const int npl = jend * jend - J0 * J0;
+                    for (int idx = threadIdx.x; idx < npl * SLOTS; idx += 256) {
+                        const int pl = idx / SLOTS, sl = idx - pl * SLOTS;
+                        if (i0 + sl >= count) continue;
+                        const double val = tile[pl * TS + sl];
+                        const int pc = J0 * J0 + pl;
+                        double* ho = a.H.base + view_off(a.H, kbase + i0 + sl);
+                        if (a.H.compact) {
+                            ho[(int64_t)pc * a.H.pitch] = val;
+                        } else {
+                            int bb = (int)sqrtf((float)pc);
+                            bb -= (bb * bb > pc) ? 1 : 0;
+                            bb += ((bb + 1) * (bb + 1) <= pc) ? 1 : 0;
+                            const int rem = pc - bb * bb, aa = rem >> 1, im = rem & 1;
+                            ho[(int64_t)(2 * (aa + n * bb) + im) * a.H.pitch] = val;
+                            if (aa != bb)
+                                ho[(int64_t)(2 * (bb + n * aa) + im) * a.H.pitch] = im ? -val : val;
+                            else
+                                ho[(int64_t)(2 * (aa + n * aa) + 1) * a.H.pitch] = 0.0;
+                        }
+                    }
+                    __syncthreads();
+                };
+                if constexpr (NP == 16) {
+                    pass(std::integral_constant<int, 0>{}, std::integral_constant<int, 12>{});
+                    pass(std::integral_constant<int, 12>{}, std::integral_constant<int, 16>{});
+                } else {
+                    pass(std::integral_constant<int, 0>{}, std::integral_constant<int, NP>{});
+                }
+            } else if (a.H.base && wave_on && wr) {  // a series that is not Hermitian: the rows as they are
                 double* ho = a.H.base + view_off(a.H, k);
 #pragma unroll
                 for (int j = 0; j < NP; ++j) {
@@ -1775,8 +1833,9 @@ __global__ __launch_bounds__(256, (TRI && !VEC) ? 2 : 1) void gen_grid_eig_kerne
                 }
             }
             if (!a.E.base) continue;  // values only (uniform)
-            double vr[NP], vi[NP], dg;
-            int rank;
+            double vr[NP], vi[NP], dg = 0.0;
+            int rank = r;
+            if (wave_on) {
             if constexpr (TRI && VEC) {  // eigenvalues as below, eigenvectors by inverse iteration on H itself
                 double tr_[NP], ti_[NP];
 #pragma unroll
@@ -1793,7 +1852,17 @@ __global__ __launch_bounds__(256, (TRI && !VEC) ? 2 : 1) void gen_grid_eig_kerne
             } else {
                 rows_eig<NP, VEC>(n, r, lane, hr, hi, vr, vi, dg, rank);
             }
-            if (wr) a.E.base[view_off(a.E, k) + (int64_t)rank * a.E.pitch] = dg;
+            }
+            {  // eigenvalue planes: through the tile as well ([band][node] -> SLOTS consecutive nodes per band)
+                if (wave_on && wr) tile[rank * TS + slot] = dg;
+                __syncthreads();
+                for (int idx = threadIdx.x; idx < n * SLOTS; idx += 256) {
+                    const int pl = idx / SLOTS, sl = idx - pl * SLOTS;
+                    if (i0 + sl < count) a.E.base[view_off(a.E, kbase + i0 + sl) + (int64_t)pl * a.E.pitch] = tile[pl * TS + sl];
+                }
+                __syncthreads();
+            }
+            if (!wave_on) continue;
             if constexpr (VEC) {
                 double ranks[NP];
                 if constexpr (TRI) {
@@ -1826,14 +1895,22 @@ static bool gen_grid_eig_supported(const GenSpec& gs, int* np_out, size_t* lds_o
     // 9..16 bands with eigenvectors: inverse iteration (needs the zero-padded layout, checked below)
     if (gs.n <= 4 || gs.n > 16 || gs.npt < 1 || gs.npt >= 65536) return false;
     const int np = gs.n <= 8 ? 8 : 16;
-    size_t lds = sizeof(double2) * (size_t)gs.M * np * np;
+    const size_t tile_bytes = sizeof(double) * (size_t)(np == 16 ? 144 : 64) * (size_t)(256 / np + 1);  // the store tile [PC][TS]
+    size_t lds = sizeof(double2) * (size_t)gs.M * np * np + tile_bytes;
     *pad_out = lds <= 150 * 1024;
-    if (!*pad_out) lds = sizeof(double2) * (size_t)gs.M * gs.n * gs.n;
+    if (!*pad_out) lds = sizeof(double2) * (size_t)gs.M * gs.n * gs.n + tile_bytes;
     if (lds > 150 * 1024) return false;
     if (gs.Uplanes.base && gs.n > 8 && !*pad_out) return false;
     *np_out = np;
     *lds_out = lds;
     return true;
+}
+
+bool gen_compact_supported(int n, int M, int npt) {
+    if (n <= 4 || n > 16 || npt < 1 || npt >= 65536) return false;
+    const int np = n <= 8 ? 8 : 16;
+    const size_t tile_bytes = sizeof(double) * (size_t)(np == 16 ? 144 : 64) * (size_t)(256 / np + 1);
+    return sizeof(double2) * (size_t)M * n * n + tile_bytes <= 150 * 1024;  // gen_grid_eig_supported's bound (unpadded set)
 }
 
 static int launch_gen_grid_eig(abz_ctx* ctx, const GenSpec& gs, int np, size_t lds, bool pad) {
@@ -1850,6 +1927,7 @@ static int launch_gen_grid_eig(abz_ctx* ctx, const GenSpec& gs, int np, size_t l
     a.M = gs.M;
     a.first = gs.first;
     a.npt = gs.npt;
+    a.herm = gs.herm ? 1 : 0;
     const int64_t blocks = std::min<int64_t>(a.nlines, 256 * 4);
     const bool vec = gs.Uplanes.base != nullptr;
     ProfScope ps(ctx, ABZ_K_EVAL);
@@ -1975,6 +2053,10 @@ int launch_gen_nodes(abz_ctx* ctx, const GenSpec& gs) {
             return ABZ_OK;
         }
     }
+    if (gs.Hplanes.base && gs.Hplanes.compact) {
+        set_error("internal: an upper-triangle rule reached the wave-per-node kernel (full layout only)");
+        return ABZ_ERR_UNSUPPORTED;
+    }
     const int wpb = gen_waves_per_block(gs.n, gs.M);
     const size_t lds = sizeof(double2) * (size_t)(3 * gs.n * gs.n + gs.M + (gs.n + 1) / 2) * wpb;
     const int64_t blocks = std::min<int64_t>(cdiv2(gs.nnodes, wpb), 256 * 16);
@@ -1988,6 +2070,20 @@ int launch_gen_nodes(abz_ctx* ctx, const GenSpec& gs) {
 // ------------------------------------------------------------------------------------------
 // reduce over a cached rule, n > 4: one wave per node chunk, per-omega partial sums in LDS
 // ------------------------------------------------------------------------------------------
+// element (r, j) of the rule's H(k) at a node whose plane 0 is `hin`: full layout 2 (r + n j) + {re, im}; upper-triangle
+// layout (PlaneView::compact): Re / Im of H[a][b], a < b, at b^2 + 2a, + 1, H[b][b] at b^2 + 2b, lower = conjugate
+__device__ __forceinline__ void rule_h_elem(const PlaneView& v, const double* __restrict__ hin, int n, int r, int j, double& vr, double& vi) {
+    if (v.compact) {
+        const int lo = r < j ? r : j, hi = r < j ? j : r;
+        vr = hin[(int64_t)(hi * hi + 2 * lo) * v.pitch];
+        const double t = (r == j) ? 0.0 : hin[(int64_t)(hi * hi + 2 * lo + 1) * v.pitch];
+        vi = r > j ? -t : t;
+    } else {
+        vr = hin[(int64_t)(2 * (r + n * j)) * v.pitch];
+        vi = hin[(int64_t)(2 * (r + n * j) + 1) * v.pitch];
+    }
+}
+
 struct GenReduceArgs {
     PlaneView Hplanes;
     PlaneView Eplanes;
@@ -2023,8 +2119,11 @@ __global__ __launch_bounds__(256) void gen_reduce_kernel(GenReduceArgs a, int wa
             for (int b = lane; b < n; b += 64) ev[b] = ei[(int64_t)b * a.Eplanes.pitch];
         } else if (a.integrand != ABZ_F_ONE) {
             const double* hi_ = a.Hplanes.base + view_off(a.Hplanes, k);
-            for (int t = lane; t < nn; t += 64)
-                H[t] = make_double2(hi_[(int64_t)(2 * t) * a.Hplanes.pitch], hi_[(int64_t)(2 * t + 1) * a.Hplanes.pitch]);
+            for (int t = lane; t < nn; t += 64) {
+                double vr, vi;
+                rule_h_elem(a.Hplanes, hi_, n, t % n, t / n, vr, vi);  // H[t]: row t % n, column t / n
+                H[t] = make_double2(vr, vi);
+            }
         }
         wave_sync();
         for (int s = 0; s < a.n_sweep; ++s) {
@@ -2132,7 +2231,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 4))) voi
             for (int j = 0; j < NP; ++j) {
                 const bool real = r < n && j < n;
                 const int jj = j < n ? j : 0;
-                const double vr = hin[(int64_t)(2 * (rr + n * jj)) * a.H.pitch], vi = hin[(int64_t)(2 * (rr + n * jj) + 1) * a.H.pitch];
+                double vr, vi;
+                rule_h_elem(a.H, hin, n, rr, jj, vr, vi);
                 hr[j] = real ? -vr : 0.0;
                 hi[j] = real ? -vi : 0.0;
             }
@@ -2209,7 +2309,8 @@ __global__ __launch_bounds__(256, 2) void gen_rows_reduce_tri_kernel(GenRowsRedu
             for (int j = 0; j < NP; ++j) {
                 const bool real = r < n && j < n;
                 const int jj = j < n ? j : 0;
-                const double vr = hin[(int64_t)(2 * (rr + n * jj)) * a.H.pitch], vi = hin[(int64_t)(2 * (rr + n * jj) + 1) * a.H.pitch];
+                double vr, vi;
+                rule_h_elem(a.H, hin, n, rr, jj, vr, vi);
                 hr[j] = real ? -vr : 0.0;
                 hi[j] = real ? -vi : 0.0;
             }
@@ -2306,7 +2407,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 4))) voi
             for (int j = 0; j < NP; ++j) {
                 const bool real = r < n && j < n;
                 const int jj = j < n ? j : 0;
-                const double vr = hin[(int64_t)(2 * (rr + n * jj)) * a.H.pitch], vi = hin[(int64_t)(2 * (rr + n * jj) + 1) * a.H.pitch];
+                double vr, vi;
+                rule_h_elem(a.H, hin, n, rr, jj, vr, vi);
                 ar[j] = real ? -vr : 0.0;
                 ai[j] = real ? -vi : 0.0;
             }

@@ -260,7 +260,8 @@ class DeviceSeries:
         return any(n2 == k0 and s2 == k1 and self._serves(w2, want) and k2 == self.kshard for (n2, s2, w2, k2) in self.rules)
 
     def _layout_want(self, want):
-        if (want & L.WANT_H) and self.s.n <= 4 and os.environ.get("ABZ_RULE_COMPACT", "1") != "0" and self.hermitian():
+        # (1...16 bands; the library ignores the bit where it has no upper-triangle kernel and reports the layout it built)
+        if (want & L.WANT_H) and self.s.n <= 16 and os.environ.get("ABZ_RULE_COMPACT", "1") != "0" and self.hermitian():
             want |= L.WANT_H_COMPACT
         return int(want)
 

@@ -1066,14 +1066,24 @@ def extras(a, abz, L, s, ctx, out, nk):
         fl = 8 * 16 * 16 * 13 + 8 * 16**3  # one omega: series + one inversion per k-point
         b16["store_free_96cubed_1_omega"] = {"seconds": dt1, "kpoints_per_sec": 96**3 / dt1, "f64_tflops": 96**3 * fl / dt1 / 1e12,
                                              "frac_of_f64_peak": 96**3 * fl / dt1 / 1e12 / F64_PEAK_TFLOPS}
-        r16 = abz.DeviceRule(dev16, 48, None, L.WANT_H | L.WANT_EIG)
-        dev16.ctx.sync()
-        t0 = time.perf_counter()
-        for _ in range(5):
-            r16.rebuild()
-        dev16.ctx.sync()
-        dt = (time.perf_counter() - t0) / 5
-        b16["rule_48cubed_H_and_eig"] = {"seconds": dt, "kpoints_per_sec": 48**3 / dt}
+        def build_time(want):
+            rr = abz.DeviceRule(dev16, 48, None, want)
+            for _ in range(3):
+                rr.rebuild()
+            dev16.ctx.sync()
+            t0_ = time.perf_counter()
+            for _ in range(10):
+                rr.rebuild()
+            dev16.ctx.sync()
+            return rr, (time.perf_counter() - t0_) / 10
+        r16, dt = build_time(L.WANT_H | L.WANT_EIG | L.WANT_H_COMPACT)  # the host mirror's layout for a Hermitian series
+        b16["rule_48cubed_H_and_eig"] = {"seconds": dt, "kpoints_per_sec": 48**3 / dt, "bytes_per_kpoint": 8 * (16 * 16 + 16),
+                                         "layout": "upper triangle of H(k) + eigenvalues (ABZ_WANT_H_COMPACT), stores through an LDS tile"}
+        for name, want in (("rule_48cubed_H_and_eig_reference_layout", L.WANT_H | L.WANT_EIG), ("rule_48cubed_H_only", L.WANT_H | L.WANT_H_COMPACT),
+                           ("rule_48cubed_eig_only", L.WANT_EIG)):
+            rx, dtx = build_time(want)
+            rx.close()
+            b16[name] = {"seconds": dtx, "kpoints_per_sec": 48**3 / dtx}
         r16.reduce(L.F_DOS, [0.05], om16)
         t0 = time.perf_counter()
         r16.reduce(L.F_DOS, [0.05], om16)

@@ -9,11 +9,18 @@ s = abz.synthetic_wannier()
 dev = s.device(); ctx = dev.ctx
 for npt in (24, 48):
     nk = npt**3
-    for want, name in ((L.WANT_H, "H"), (L.WANT_H | L.WANT_EIG, "H+EIG")):
+    for want, name in ((L.WANT_H, "H"), (L.WANT_H | L.WANT_EIG, "H+EIG"), (L.WANT_H | L.WANT_H_COMPACT, "Hc"),
+                       (L.WANT_H | L.WANT_EIG | L.WANT_H_COMPACT, "Hc+EIG"), (L.WANT_EIG, "EIG")):
         r = abz.DeviceRule(dev, npt, None, want); ctx.sync()
-        t0 = time.perf_counter(); r.rebuild(); ctx.sync(); dt = time.perf_counter() - t0
+        for _ in range(3):
+            r.rebuild()
+        ctx.sync()
+        t0 = time.perf_counter()
+        for _ in range(10):
+            r.rebuild()
+        ctx.sync(); dt = (time.perf_counter() - t0) / 10
         print(f"n=16 npt={npt} rebuild {name:6s}: {1e3*dt:9.2f} ms  {nk/dt/1e6:8.2f} M k/s")
-        if want & L.WANT_EIG:
+        if want == (L.WANT_H | L.WANT_EIG):
             for fid, nm in ((L.F_DOS, "DOS (inverse)"), (L.F_DOS_EIG, "DOS (eig)")):
                 for nw in (1, 16):
                     om = np.linspace(-1, 1, nw)
