@@ -33,7 +33,7 @@ void set_error(const char* fmt, ...);
     } while (0)
 
 // ---- environment switches -------------------------------------------------------------------------------------------
-// Every switch the library reads, in one table (api.cpp: name, default, meaning; DESIGN.md section 12 repeats it).  They
+// Every switch the library reads, in one table (api.cpp: name, default, meaning; DESIGN.md section 11 repeats it).  They
 // exist for two reasons only: a test compares two code paths that must agree (the switch selects the one that is not the
 // default), or an operator sizes a resource.  Values are read per call -- tests flip them at run time.
 enum Switch {
