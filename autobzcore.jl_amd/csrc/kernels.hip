@@ -2490,9 +2490,11 @@ __global__ __launch_bounds__(256) void inner_adaptive_wave_kernel(InnerArgs a) {
         }
         wave_lds_sync();
         const double swq = a.sweep_arr ? a.sweep_arr[q] : a.sweep;
-        // per-lane state
+        // per-lane state: heap position l (error, segment slot); segment slot l (a, b, I) and, when the slot's panel had its
+        // halves evaluated AHEAD of its pop, their GK sums (rdy)
         double hE = 0.0, sA = 0.0, sB = 0.0, sIr = 0.0, sIi = 0.0;
-        int hS = 0;
+        double cE1 = 0.0, cI1r = 0.0, cI1i = 0.0, cE2 = 0.0, cI2r = 0.0, cI2i = 0.0;
+        int hS = 0, rdy = 0;
         // wave-uniform state (AdaptStateT<1> + ctl of the LDS kernel)
         int nseg = 0, nheap = 0, popped = -1, status = 0;
         bool first = true;
@@ -2503,12 +2505,24 @@ __global__ __launch_bounds__(256) void inner_adaptive_wave_kernel(InnerArgs a) {
         const double rtol = a.has_rtol ? a.rtol_user : ((at_in > 0.0) ? 0.0 : 1.4901161193847656e-08);  // sqrt(eps)
         int np = 1;
         double a1 = a.lo[q], b1 = a.hi[q], a2 = 0.0, b2 = 0.0;
-        while (true) {
-            // ---- the nodes of the pending panels: lanes 0-14 panel 0, 16-30 panel 1
+        // A second panel per round (rows 2 and 3 of the wave, idle otherwise): the largest panel left in the heap, when it is
+        // CERTAIN to be popped -- the errors of everything still in the heap add up to more than a fixed tolerance, and they
+        // cannot leave it before that panel does (iai_host.cpp's argument for its requests ahead of the pops).  Its halves'
+        // sums wait in its segment's lane; when the panel reaches the top its pop is replayed without a round of node
+        // evaluations.  The pops, their order and every sum are those of the one-panel-per-round loop.
+        int qslot = -1;
+        double qa = 0.0, qm = 0.0, qb = 0.0;
+        bool finished = false;
+        while (!finished) {
+            // ---- the nodes of the pending panels: row r of the wave = panel r (rows 0, 1: the popped panel's halves; 2, 3: the
+            // speculative one's)
             const int pnl = l >> 4, i = l & 15;
+            const bool row_on = pnl < np || (pnl >= 2 && qslot >= 0);
+            const double ra = pnl == 0 ? a1 : (pnl == 1 ? a2 : (pnl == 2 ? qa : qm));
+            const double rb = pnl == 0 ? b1 : (pnl == 1 ? b2 : (pnl == 2 ? qm : qb));
             double vr = 0.0, vi = 0.0;
-            if (pnl < np && i < 15) {
-                const double x = gk15_node(pnl ? a2 : a1, pnl ? b2 : b1, i);
+            if (row_on && i < 15) {
+                const double x = gk15_node(ra, rb, i);
                 const double xx = x * a.inv_period;
                 double zr, zi, wr, wi;
                 CMat<N> H;
@@ -2549,87 +2563,110 @@ __global__ __launch_bounds__(256) void inner_adaptive_wave_kernel(InnerArgs a) {
             }
             // ---- the GK rule: a panel's fifteen values sit in the first fifteen lanes of a 16-lane row, so every lane of the row
             // gets them by row broadcasts on the VALU (v_mov_b64_dpp row_newbcast: one instruction per value, no LDS crossbar)
-            // and applies the rule; rows 0 and 1 hold the two pending panels
-            const int pl = (pnl < np) ? pnl : 0;
+            // and applies the rule of its row's panel
             gkc rv[15];
             gk_row_values(vr, vi, rv, std::make_integer_sequence<int, 15>());
             gkc Il;
-            const double El = gk15_rule(rv, 1, pl ? a2 : a1, pl ? b2 : b1, &Il);
+            const double El = gk15_rule(rv, 1, ra, rb, &Il);
             const double E1 = rl_f64(El, 0), I1r = rl_f64(Il.re, 0), I1i = rl_f64(Il.im, 0);
             const double E2 = rl_f64(El, 16), I2r = rl_f64(Il.re, 16), I2i = rl_f64(Il.im, 16);
-            // ---- the step, on wave-uniform values (adapt_step's operations in adapt_step's order)
-            int s1, s2 = -1;
-            if (popped >= 0)
-                s1 = popped;  // the popped parent's slot is reused for the first child
-            else
-                s1 = nseg++;
-            if (s1 >= MS) {
-                status = 1;
-                s1 = MS - 1;
+            if (qslot >= 0) {  // the speculative panel's halves: parked in its segment's lane
+                const double Q1 = rl_f64(El, 32), Q1r = rl_f64(Il.re, 32), Q1i = rl_f64(Il.im, 32);
+                const double Q2 = rl_f64(El, 48), Q2r = rl_f64(Il.re, 48), Q2i = rl_f64(Il.im, 48);
+                const bool mine = l == qslot;
+                cE1 = mine ? Q1 : cE1;
+                cI1r = mine ? Q1r : cI1r;
+                cI1i = mine ? Q1i : cI1i;
+                cE2 = mine ? Q2 : cE2;
+                cI2r = mine ? Q2r : cI2r;
+                cI2i = mine ? Q2i : cI2i;
+                rdy = mine ? 1 : rdy;
+                qslot = -1;
             }
-            if (np == 2) {
-                s2 = nseg++;
-                if (s2 >= MS) {
+            // ---- the step, on wave-uniform values (adapt_step's operations in adapt_step's order): first the panel(s) just
+            // evaluated, then every pop whose halves are already known
+            double n1E = E1, n1r = I1r, n1i = I1i, n2E = E2, n2r = I2r, n2i = I2i;  // the halves being inserted
+            double na1 = a1, nb1 = b1, na2 = a2, nb2 = b2;
+            while (true) {
+                int s1, s2 = -1;
+                if (popped >= 0)
+                    s1 = popped;  // the popped parent's slot is reused for the first child
+                else
+                    s1 = nseg++;
+                if (s1 >= MS) {
                     status = 1;
-                    s2 = MS - 1;
+                    s1 = MS - 1;
                 }
-            }
-            if (first) {
-                first = false;
-                sA = l == s1 ? a1 : sA;
-                sB = l == s1 ? b1 : sB;
-                sIr = l == s1 ? I1r : sIr;
-                sIi = l == s1 ? I1i : sIi;
-                Ir = I1r;
-                Ii = I1i;
-                E = E1;
-                numevals = 15;
-                hS = l == 0 ? s1 : hS;
-                hE = l == 0 ? E1 : hE;
-                nheap = 1;
-            } else {
-                sA = l == s1 ? a1 : sA;
-                sB = l == s1 ? b1 : sB;
-                sIr = l == s1 ? I1r : sIr;
-                sIi = l == s1 ? I1i : sIi;
-                sA = l == s2 ? a2 : sA;
-                sB = l == s2 ? b2 : sB;
-                sIr = l == s2 ? I2r : sIr;
-                sIi = l == s2 ? I2i : sIi;
-                {
-#pragma clang fp contract(off)
-                    Ir = ((Ir - parIr) + I1r) + I2r;
-                    Ii = ((Ii - parIi) + I1i) + I2i;
-                    E = ((E - parE) + E1) + E2;
-                }
-                for (int t = 0; t < 2; ++t) {  // heappush (percolate_up)
-                    const int xs = t == 0 ? s1 : s2;
-                    const double Ex = t == 0 ? E1 : E2;
-                    int h = nheap++;
-                    while (h > 0) {
-                        const int j = (h - 1) / 2;
-                        const double Ej = rl_f64(hE, j);
-                        if (!(Ej < Ex)) break;
-                        {
-                            const int hj = rl_i32(hS, j);
-                            hS = l == h ? hj : hS;
-                            hE = l == h ? Ej : hE;
-                        }
-                        h = j;
+                if (!first) {
+                    s2 = nseg++;
+                    if (s2 >= MS) {
+                        status = 1;
+                        s2 = MS - 1;
                     }
-                    hS = l == h ? xs : hS;
-                    hE = l == h ? Ex : hE;
                 }
-            }
-            double tol = atol;
-            if (rtol != 0.0) {  // (rtol = 0: max(atol, 0 * |I|) = atol, no square root)
+                {
+                    const bool m1 = l == s1;
+                    sA = m1 ? na1 : sA;
+                    sB = m1 ? nb1 : sB;
+                    sIr = m1 ? n1r : sIr;
+                    sIi = m1 ? n1i : sIi;
+                    rdy = m1 ? 0 : rdy;
+                }
+                if (first) {
+                    first = false;
+                    Ir = n1r;
+                    Ii = n1i;
+                    E = n1E;
+                    numevals = 15;
+                    hS = l == 0 ? s1 : hS;
+                    hE = l == 0 ? n1E : hE;
+                    nheap = 1;
+                } else {
+                    {
+                        const bool m2 = l == s2;
+                        sA = m2 ? na2 : sA;
+                        sB = m2 ? nb2 : sB;
+                        sIr = m2 ? n2r : sIr;
+                        sIi = m2 ? n2i : sIi;
+                        rdy = m2 ? 0 : rdy;
+                    }
+                    {
 #pragma clang fp contract(off)
-                const double t1 = Ir * Ir, t2 = Ii * Ii;
-                const double t3 = t1 + t2;
-                const double nrm = sqrt(0.0 + t3);
-                tol = fmax(atol, rtol * nrm);
-            }
-            if (E > tol && numevals < a.maxevals && status == 0) {
+                        Ir = ((Ir - parIr) + n1r) + n2r;
+                        Ii = ((Ii - parIi) + n1i) + n2i;
+                        E = ((E - parE) + n1E) + n2E;
+                    }
+                    for (int t = 0; t < 2; ++t) {  // heappush (percolate_up)
+                        const int xs = t == 0 ? s1 : s2;
+                        const double Ex = t == 0 ? n1E : n2E;
+                        int h = nheap++;
+                        while (h > 0) {
+                            const int j = (h - 1) / 2;
+                            const double Ej = rl_f64(hE, j);
+                            if (!(Ej < Ex)) break;
+                            {
+                                const int hj = rl_i32(hS, j);
+                                hS = l == h ? hj : hS;
+                                hE = l == h ? Ej : hE;
+                            }
+                            h = j;
+                        }
+                        hS = l == h ? xs : hS;
+                        hE = l == h ? Ex : hE;
+                    }
+                }
+                double tol = atol;
+                if (rtol != 0.0) {  // (rtol = 0: max(atol, 0 * |I|) = atol, no square root)
+#pragma clang fp contract(off)
+                    const double t1 = Ir * Ir, t2 = Ii * Ii;
+                    const double t3 = t1 + t2;
+                    const double nrm = sqrt(0.0 + t3);
+                    tol = fmax(atol, rtol * nrm);
+                }
+                if (!(E > tol && numevals < a.maxevals && status == 0)) {
+                    finished = true;
+                    break;
+                }
                 // heappop: root out, last to root, percolate_down
                 const int xs = rl_i32(hS, 0);
                 parE = rl_f64(hE, 0);
@@ -2668,127 +2705,58 @@ __global__ __launch_bounds__(256) void inner_adaptive_wave_kernel(InnerArgs a) {
                 popped = xs;
                 numevals += 30;
                 const double mid = (pa + pb) / 2;
+                na1 = pa;
+                nb1 = mid;
+                na2 = mid;
+                nb2 = pb;
+                if (rl_i32(rdy, xs) != 0) {  // its halves were evaluated ahead: replay the pop at once
+                    n1E = rl_f64(cE1, xs);
+                    n1r = rl_f64(cI1r, xs);
+                    n1i = rl_f64(cI1i, xs);
+                    n2E = rl_f64(cE2, xs);
+                    n2r = rl_f64(cI2r, xs);
+                    n2i = rl_f64(cI2i, xs);
+                    continue;
+                }
+                // the next round evaluates this panel's halves ...
                 np = 2;
                 a1 = pa;
                 b1 = mid;
                 a2 = mid;
                 b2 = pb;
-                continue;
-            }
-            {  // re-sum over the heap in storage order (QuadGK does this after adapt)
-#pragma clang fp contract(off)
-                const int s0 = rl_i32(hS, 0);
-                Ir = rl_f64(sIr, s0);
-                Ii = rl_f64(sIi, s0);
-                E = rl_f64(hE, 0);
-                for (int h = 1; h < nheap; ++h) {
-                    const int sh = rl_i32(hS, h);
-                    Ir = Ir + rl_f64(sIr, sh);
-                    Ii = Ii + rl_f64(sIi, sh);
-                    E = E + rl_f64(hE, h);
+                // ... and those of the largest panel left, if it is certain to be popped (fixed tolerance only)
+                if (rtol == 0.0 && nheap > 0 && a.maxevals >= (1ll << 62) && (E - parE) > tol * (1.0 + 1e-9)) {
+                    const int top = rl_i32(hS, 0);
+                    if (rl_i32(rdy, top) == 0) {
+                        qslot = top;
+                        qa = rl_f64(sA, top);
+                        qb = rl_f64(sB, top);
+                        qm = (qa + qb) / 2;
+                    }
                 }
+                break;
             }
-            if (l == 0) {
-                a.I_out[q] = make_double2(Ir, Ii);
-                a.E_out[q] = E;
-                a.nev_out[q] = numevals;
-                a.status_out[q] = status;
-            }
-            break;
         }
-    }
-}
-
-// ---- panels of the level above the innermost one (abz_internal.h: PanelNodesSpec / PanelRuleSpec) ----
-// One block per node of a panel: the node's coordinate (gk15_node), the limits / tolerance / swept value of the innermost
-// integral beneath it (Lims::fix + range of iai_host.cpp, operation for operation), its M phases (phase_kernel's expression)
-// and the contraction of its parent's coefficient set (contract_kernel's sum, term for term) -- three launches of the node
-// path in one, fed by 40 B per PANEL that the kernel reads where the host wrote them (pinned, device-visible memory).
-__global__ void panel_contract_kernel(PanelNodesSpec a, const double2* __restrict__ src, int64_t slot_elems, int M, int first,
-                                      double inv_period, double2* __restrict__ out, int64_t Lrow) {
-    extern __shared__ double2 pc_phs[];  // [M]
-    const int64_t t = blockIdx.x;
-    const int64_t p = t / 15;
-    const int i = (int)(t - 15 * p);
-    double x;
-    {
+        {  // re-sum over the heap in storage order (QuadGK does this after adapt)
 #pragma clang fp contract(off)
-        x = gk15_node(a.p_a[p], a.p_b[p], i);
-        if (threadIdx.x == 0 && blockIdx.y == 0) {
-            // Lims::fix(L, x) + range(1): CubicLimits (a0, b0); TetrahedralLimits s = x / a[L - 1], (0, a[0] * s)
-            double lo = a.a0, hi = a.b0;
-            if (a.lims_kind == ABZ_LIMS_TETRAHEDRAL) {
-                const double sc = x / a.aL;
-                lo = 0.0;
-                hi = a.a0 * sc;
+            const int s0 = rl_i32(hS, 0);
+            Ir = rl_f64(sIr, s0);
+            Ii = rl_f64(sIi, s0);
+            E = rl_f64(hE, 0);
+            for (int h = 1; h < nheap; ++h) {
+                const int sh = rl_i32(hS, h);
+                Ir = Ir + rl_f64(sIr, sh);
+                Ii = Ii + rl_f64(sIi, sh);
+                E = E + rl_f64(hE, h);
             }
-            const double at = a.p_at[p];
-            a.n_slot[t] = t;
-            a.n_lo[t] = lo;
-            a.n_hi[t] = hi;
-            a.n_at[t] = at >= 0.0 ? at / (hi - lo) : -1.0;  // ref src/fourier.jl:479-480
-            a.n_sw[t] = a.p_sw[p];
+        }
+        if (l == 0) {
+            a.I_out[q] = make_double2(Ir, Ii);
+            a.E_out[q] = E;
+            a.nev_out[q] = numevals;
+            a.status_out[q] = status;
         }
     }
-    for (int m = threadIdx.x; m < M; m += blockDim.x) {
-        double c, sn;
-        sincospi(2.0 * ((double)(first + m) * x * inv_period), &sn, &c);
-        pc_phs[m] = make_double2(c, sn);
-    }
-    __syncthreads();
-    const int64_t l = (int64_t)blockIdx.y * blockDim.x + threadIdx.x;
-    if (l >= Lrow) return;
-    const double2* __restrict__ sp = src + a.p_slot[p] * slot_elems + l;
-    double ar = 0.0, ai = 0.0;
-    for (int m = 0; m < M; ++m) {
-        const double2 c = sp[(int64_t)m * Lrow];
-        const double2 ph = pc_phs[m];
-        ar = fma(c.x, ph.x, ar);
-        ar = fma(-c.y, ph.y, ar);
-        ai = fma(c.x, ph.y, ai);
-        ai = fma(c.y, ph.x, ai);
-    }
-    out[t * Lrow + l] = make_double2(ar, ai);
-}
-
-int launch_panel_contract(abz_ctx* ctx, const PanelNodesSpec& ps, const double2* src, int64_t slot_elems, int M, int first, double period,
-                          double2* out, int64_t Lrow) {
-    if (ps.npanels == 0) return ABZ_OK;
-    ProfScope pf(ctx, ABZ_K_CONTRACT);
-    const int bs = Lrow <= 64 ? 64 : (Lrow <= 128 ? 128 : 256);
-    const int64_t gy = cdiv(Lrow, bs);
-    if (gy > 65535) {
-        set_error("panel_contract: row length %lld too large", (long long)Lrow);
-        return ABZ_ERR_UNSUPPORTED;
-    }
-    hipLaunchKernelGGL(panel_contract_kernel, dim3((unsigned)(15 * ps.npanels), (unsigned)gy), dim3(bs), sizeof(double2) * (size_t)M, ctx->stream,
-                       ps, src, slot_elems, M, first, 1.0 / period, out, Lrow);
-    ABZ_HIP(hipGetLastError());
-    return ABZ_OK;
-}
-
-__global__ __launch_bounds__(256) void panel_rule_kernel(PanelRuleSpec a) {
-    const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (p >= a.npanels) return;
-    // the shared rule on the panel's fifteen innermost integrals (node-major, ncomp components each): what the host's
-    // gk15_evalrule computes from the same numbers
-    const gkc* fv = reinterpret_cast<const gkc*>(a.n_I + (size_t)(15 * p) * a.ncomp);
-    a.p_E[p] = gk15_rule(fv, a.ncomp, a.p_a[p], a.p_b[p], reinterpret_cast<gkc*>(a.p_I + (size_t)p * a.ncomp));
-    int64_t nev = 0;
-    int st = 0;
-    for (int i = 0; i < 15; ++i) {
-        nev += a.n_nev[15 * p + i];
-        st |= a.n_status[15 * p + i];
-    }
-    a.p_nev[p] = nev;
-    a.p_status[p] = st;
-}
-
-int launch_panel_rule(abz_ctx* ctx, const PanelRuleSpec& ps) {
-    if (ps.npanels == 0) return ABZ_OK;
-    hipLaunchKernelGGL(panel_rule_kernel, dim3((unsigned)cdiv(ps.npanels, 256)), dim3(256), 0, ctx->stream, ps);
-    ABZ_HIP(hipGetLastError());
-    return ABZ_OK;
 }
 
 bool inner_adaptive_supported(int n, int M, int integrand) {
