@@ -56,6 +56,8 @@ enum Switch {
     SW_IAI_PANELS,       // ABZ_IAI_PANELS      level above the innermost: panels, not nodes, cross PCIe (0: nodes)
     SW_IAI_STATS,        // ABZ_IAI_STATS       per-solve statistics of the IAI driver on stderr
     SW_HOST_THREADS,     // ABZ_HOST_THREADS    host threads for the per-integral bookkeeping of IAI sweeps
+    SW_IAI_LANES,        // ABZ_IAI_LANES       lanes (host thread + stream each) an IAI sweep is split over
+    SW_IAI_LANE_MIN,     // ABZ_IAI_LANE_MIN    solves a lane needs before a sweep is split further
     SW_COUNT
 };
 int abz_switch(Switch s);  // the switch's integer value from the environment, or its default
@@ -180,6 +182,8 @@ struct abz_series {
     abz::DevBuf coef_pk;       // Hermitian series, n <= 4: the coefficients with the innermost variable packed (packed_herm.h)
     bool coef_pk_valid = false;
     double2* coef = nullptr;  // level d: [M_d]...[M_1][n*n] complex, i_1 fastest (Julia order)
+    bool coef_borrowed = false;       // a lane view: `coef` is its parent's block
+    std::vector<abz_series*> lanes;   // views of this series on contexts (streams) of their own: the sweep lanes of abz_iai_solve_many
     // pools of contracted coefficient sets: level j (1 <= j < d) holds (j)-dim series of
     // elems(j) = M_1*...*M_j*n*n complex numbers per slot.
     abz::DevBuf pool[ABZ_MAX_DIM + 1];      // rule builds / abz_eval_nodes
@@ -206,6 +210,11 @@ struct abz_series {
         return e;
     }
 };
+
+namespace abz {
+// at least `count` lane views of s (same device coefficients, own context / stream / pools); owned by s
+int series_lane_views(abz_series* s, int count);
+}  // namespace abz
 
 struct abz_rule {
     abz_series* s = nullptr;

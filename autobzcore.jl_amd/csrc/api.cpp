@@ -52,6 +52,8 @@ const SwitchDef g_switches[SW_COUNT] = {
     {"ABZ_IAI_PANELS", 1, "0: the level above the innermost one ships nodes instead of panels (GK rule of that level on the host)"},
     {"ABZ_IAI_STATS", 0, "1: per-solve statistics of the IAI driver on stderr"},
     {"ABZ_HOST_THREADS", 8, "host threads for the per-integral bookkeeping of IAI sweeps (capped at half the cores)"},
+    {"ABZ_IAI_LANES", 4, "lanes (host thread + stream each) a sweep of independent IAI solves is split over; 1: off"},
+    {"ABZ_IAI_LANE_MIN", 16, "solves per lane below which a sweep is not split further"},
 };
 }  // namespace
 
@@ -555,7 +557,14 @@ static void series_release(abz_series* s) {
     for (auto& b : s->iai_io) b.release();
     for (auto& q : s->iai_pin)
         if (q) (void)hipHostFree(q);
-    dev_free(s->coef, s->coef_cap);
+    for (abz_series* v : s->lanes) {  // the views go with their series, and each one's context with it
+        abz_ctx* vc = v->ctx;
+        v->closed = true;
+        series_release(v);
+        (void)abz_ctx_destroy(vc);
+        (void)hipSetDevice(ctx->device);
+    }
+    if (!s->coef_borrowed) dev_free(s->coef, s->coef_cap);
     s->coef_pk.release();
     s->auto_io.release();
     if (s->auto_pin) (void)hipHostFree(s->auto_pin);
@@ -763,8 +772,42 @@ int abz_series_update(abz_series* s, const double* coef_reim) {
     s->hermitian = detect_hermitian(s, coef_reim);
     s->coef_pk_valid = false;
     s->generation += 1;  // rules kept by the series refill themselves at their next use
+    for (abz_series* v : s->lanes) {
+        v->hermitian = s->hermitian;
+        v->coef_pk_valid = false;
+        v->generation += 1;
+    }
     return ABZ_OK;
 }
+
+}  // extern "C"
+
+namespace abz {
+int series_lane_views(abz_series* s, int count) {
+    while ((int)s->lanes.size() < count) {
+        abz_ctx* c = nullptr;
+        int rc = abz_ctx_create(s->ctx->device, &c);
+        if (rc) return rc;
+        abz_series* v = new abz_series();
+        v->ctx = c;
+        v->d = s->d;
+        v->n = s->n;
+        for (int j = 0; j < ABZ_MAX_DIM; ++j) {
+            v->dims[j] = s->dims[j];
+            v->first[j] = s->first[j];
+            v->period[j] = s->period[j];
+        }
+        v->hermitian = s->hermitian;
+        v->coef = s->coef;
+        v->coef_borrowed = true;
+        c->refs += 1;
+        s->lanes.push_back(v);
+    }
+    return ABZ_OK;
+}
+}  // namespace abz
+
+extern "C" {
 
 static void rule_free(abz_rule* r);
 static void series_drop_kept_rules(abz_series* s) {

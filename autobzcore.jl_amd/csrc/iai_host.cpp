@@ -1420,10 +1420,10 @@ int abz_gk15_batch(const double* ab, const double* values_reim, int64_t npanels,
     return ABZ_OK;
 }
 
-int abz_iai_solve_many(abz_series* s, int lims_kind, const double* lim_a, const double* lim_b, int integrand,
-                       const double* params, int nparams, const double* sweeps, int n_sweep, double abstol, double reltol,
-                       int64_t maxevals, int64_t max_batch, double* out_reim, double* err, int64_t* numevals,
-                       double* panels, int64_t max_panels, int64_t* npanels) {
+static int iai_solve_lane(abz_series* s, int lims_kind, const double* lim_a, const double* lim_b, int integrand,
+                          const double* params, int nparams, const double* sweeps, int n_sweep, double abstol, double reltol,
+                          int64_t maxevals, int64_t max_batch, double* out_reim, double* err, int64_t* numevals,
+                          double* panels, int64_t max_panels, int64_t* npanels) {
     ABZ_REQUIRE(s && s->ctx && !s->closed && !s->ctx->closed && lim_a && out_reim, "abz_iai_solve: null argument");
     ABZ_REQUIRE(n_sweep >= 1 && sweeps, "abz_iai_solve: at least one sweep value");
     ABZ_REQUIRE(lims_kind >= ABZ_LIMS_CUBIC && lims_kind <= ABZ_LIMS_POLYGON, "unknown limits kind %d", lims_kind);
@@ -1544,6 +1544,60 @@ int abz_iai_solve_many(abz_series* s, int lims_kind, const double* lim_a, const 
             panels[2 * i] = pn[(size_t)i].first;
             panels[2 * i + 1] = pn[(size_t)i].second;
         }
+    }
+    return ABZ_OK;
+}
+
+// A sweep of independent solves is dealt round-robin to LANES: host threads that each drive a view of the series on a
+// stream of its own, so one lane's host rounds (gather, heaps, delivery) run beside the other lanes' kernels -- a round of
+// a solve cannot overlap its own kernels, the next panels depend on them.  Every solve makes the decisions it would make
+// alone, so the split changes no result (tests/test_gpu_parity.py::test_iai_lanes_*).
+int abz_iai_solve_many(abz_series* s, int lims_kind, const double* lim_a, const double* lim_b, int integrand,
+                       const double* params, int nparams, const double* sweeps, int n_sweep, double abstol, double reltol,
+                       int64_t maxevals, int64_t max_batch, double* out_reim, double* err, int64_t* numevals,
+                       double* panels, int64_t max_panels, int64_t* npanels) {
+    int lanes = 1, ncomp = 0;
+    if (s && s->ctx && !s->closed && !s->ctx->closed && sweeps && out_reim && lim_a && !panels && !s->ex_fn && !s->coef_borrowed &&
+        (ncomp = integrand_ncomp(integrand, s->n, s->d)) > 0)
+        lanes = std::max(1, std::min(abz_switch(SW_IAI_LANES), n_sweep / std::max(1, abz_switch(SW_IAI_LANE_MIN))));
+    if (lanes > 1 && series_lane_views(s, lanes - 1) != ABZ_OK) lanes = 1;
+    if (lanes == 1)
+        return iai_solve_lane(s, lims_kind, lim_a, lim_b, integrand, params, nparams, sweeps, n_sweep, abstol, reltol, maxevals,
+                              max_batch, out_reim, err, numevals, panels, max_panels, npanels);
+    struct LaneJob {
+        std::vector<double> sw, out, err;
+        std::vector<int64_t> nev;
+        int rc = ABZ_OK;
+        std::string msg;
+    };
+    std::vector<LaneJob> jobs((size_t)lanes);
+    for (int r = 0; r < n_sweep; ++r) jobs[(size_t)(r % lanes)].sw.push_back(sweeps[r]);
+    auto run = [&](int j) {
+        LaneJob& q = jobs[(size_t)j];
+        const int m = (int)q.sw.size();
+        q.out.resize((size_t)m * ncomp * 2);
+        q.err.resize((size_t)m);
+        q.nev.resize((size_t)m);
+        q.rc = iai_solve_lane(j == 0 ? s : s->lanes[(size_t)j - 1], lims_kind, lim_a, lim_b, integrand, params, nparams, q.sw.data(), m,
+                              abstol, reltol, maxevals, max_batch, q.out.data(), q.err.data(), q.nev.data(), nullptr, 0,
+                              j == 0 ? npanels : nullptr);
+        if (q.rc) q.msg = abz_last_error();  // (the message is per thread)
+    };
+    std::vector<std::thread> th;
+    for (int j = 1; j < lanes; ++j) th.emplace_back(run, j);
+    run(0);
+    for (auto& t : th) t.join();
+    for (auto& q : jobs)
+        if (q.rc) {
+            set_error("%s", q.msg.c_str());
+            return q.rc;
+        }
+    for (int r = 0; r < n_sweep; ++r) {
+        const LaneJob& q = jobs[(size_t)(r % lanes)];
+        const size_t i = (size_t)(r / lanes);
+        std::copy(q.out.begin() + (ptrdiff_t)(i * ncomp * 2), q.out.begin() + (ptrdiff_t)((i + 1) * ncomp * 2), out_reim + (size_t)r * ncomp * 2);
+        if (err) err[r] = q.err[i];
+        if (numevals) numevals[r] = q.nev[i];
     }
     return ABZ_OK;
 }

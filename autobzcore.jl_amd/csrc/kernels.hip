@@ -2505,11 +2505,11 @@ __global__ __launch_bounds__(256) void inner_adaptive_wave_kernel(InnerArgs a) {
         const double rtol = a.has_rtol ? a.rtol_user : ((at_in > 0.0) ? 0.0 : 1.4901161193847656e-08);  // sqrt(eps)
         int np = 1;
         double a1 = a.lo[q], b1 = a.hi[q], a2 = 0.0, b2 = 0.0;
-        // A second panel per round (rows 2 and 3 of the wave, idle otherwise): the largest panel left in the heap, when it is
-        // CERTAIN to be popped -- the errors of everything still in the heap add up to more than a fixed tolerance, and they
-        // cannot leave it before that panel does (iai_host.cpp's argument for its requests ahead of the pops).  Its halves'
-        // sums wait in its segment's lane; when the panel reaches the top its pop is replayed without a round of node
-        // evaluations.  The pops, their order and every sum are those of the one-panel-per-round loop.
+        // A second panel per round (rows 2 and 3 of the wave, idle otherwise): the largest panel left in the heap once the
+        // current one is out -- the next pop unless a half of the current panel overtakes it.  Its halves' sums wait in its
+        // segment's lane; when the panel reaches the top its pop is replayed without a round of node evaluations, and if the
+        // loop ends first they are dropped (numevals counts pops).  The pops, their order and every sum are those of the
+        // one-panel-per-round loop.
         int qslot = -1;
         double qa = 0.0, qm = 0.0, qb = 0.0;
         bool finished = false;
@@ -2724,8 +2724,8 @@ __global__ __launch_bounds__(256) void inner_adaptive_wave_kernel(InnerArgs a) {
                 b1 = mid;
                 a2 = mid;
                 b2 = pb;
-                // ... and those of the largest panel left, if it is certain to be popped (fixed tolerance only)
-                if (rtol == 0.0 && nheap > 0 && a.maxevals >= (1ll << 62) && (E - parE) > tol * (1.0 + 1e-9)) {
+                // ... and those of the largest panel left: the likely next pop (its lanes cost the wave nothing)
+                if (nheap > 0) {
                     const int top = rl_i32(hS, 0);
                     if (rl_i32(rdy, top) == 0) {
                         qslot = top;
@@ -2757,6 +2757,98 @@ __global__ __launch_bounds__(256) void inner_adaptive_wave_kernel(InnerArgs a) {
             a.status_out[q] = status;
         }
     }
+}
+
+// ---- panels of the level above the innermost one (abz_internal.h: PanelNodesSpec / PanelRuleSpec) ----
+// One block per node of a panel: the node's coordinate (gk15_node), the limits / tolerance / swept value of the innermost
+// integral beneath it (Lims::fix + range of iai_host.cpp, operation for operation), its M phases (phase_kernel's expression)
+// and the contraction of its parent's coefficient set (contract_kernel's sum, term for term) -- three launches of the node
+// path in one, fed by 40 B per PANEL that the kernel reads where the host wrote them (pinned, device-visible memory).
+__global__ void panel_contract_kernel(PanelNodesSpec a, const double2* __restrict__ src, int64_t slot_elems, int M, int first,
+                                      double inv_period, double2* __restrict__ out, int64_t Lrow) {
+    extern __shared__ double2 pc_phs[];  // [M]
+    const int64_t t = blockIdx.x;
+    const int64_t p = t / 15;
+    const int i = (int)(t - 15 * p);
+    double x;
+    {
+#pragma clang fp contract(off)
+        x = gk15_node(a.p_a[p], a.p_b[p], i);
+        if (threadIdx.x == 0 && blockIdx.y == 0) {
+            // Lims::fix(L, x) + range(1): CubicLimits (a0, b0); TetrahedralLimits s = x / a[L - 1], (0, a[0] * s)
+            double lo = a.a0, hi = a.b0;
+            if (a.lims_kind == ABZ_LIMS_TETRAHEDRAL) {
+                const double sc = x / a.aL;
+                lo = 0.0;
+                hi = a.a0 * sc;
+            }
+            const double at = a.p_at[p];
+            a.n_slot[t] = t;
+            a.n_lo[t] = lo;
+            a.n_hi[t] = hi;
+            a.n_at[t] = at >= 0.0 ? at / (hi - lo) : -1.0;  // ref src/fourier.jl:479-480
+            a.n_sw[t] = a.p_sw[p];
+        }
+    }
+    for (int m = threadIdx.x; m < M; m += blockDim.x) {
+        double c, sn;
+        sincospi(2.0 * ((double)(first + m) * x * inv_period), &sn, &c);
+        pc_phs[m] = make_double2(c, sn);
+    }
+    __syncthreads();
+    const int64_t l = (int64_t)blockIdx.y * blockDim.x + threadIdx.x;
+    if (l >= Lrow) return;
+    const double2* __restrict__ sp = src + a.p_slot[p] * slot_elems + l;
+    double ar = 0.0, ai = 0.0;
+    for (int m = 0; m < M; ++m) {
+        const double2 c = sp[(int64_t)m * Lrow];
+        const double2 ph = pc_phs[m];
+        ar = fma(c.x, ph.x, ar);
+        ar = fma(-c.y, ph.y, ar);
+        ai = fma(c.x, ph.y, ai);
+        ai = fma(c.y, ph.x, ai);
+    }
+    out[t * Lrow + l] = make_double2(ar, ai);
+}
+
+int launch_panel_contract(abz_ctx* ctx, const PanelNodesSpec& ps, const double2* src, int64_t slot_elems, int M, int first, double period,
+                          double2* out, int64_t Lrow) {
+    if (ps.npanels == 0) return ABZ_OK;
+    ProfScope pf(ctx, ABZ_K_CONTRACT);
+    const int bs = Lrow <= 64 ? 64 : (Lrow <= 128 ? 128 : 256);
+    const int64_t gy = cdiv(Lrow, bs);
+    if (gy > 65535) {
+        set_error("panel_contract: row length %lld too large", (long long)Lrow);
+        return ABZ_ERR_UNSUPPORTED;
+    }
+    hipLaunchKernelGGL(panel_contract_kernel, dim3((unsigned)(15 * ps.npanels), (unsigned)gy), dim3(bs), sizeof(double2) * (size_t)M, ctx->stream,
+                       ps, src, slot_elems, M, first, 1.0 / period, out, Lrow);
+    ABZ_HIP(hipGetLastError());
+    return ABZ_OK;
+}
+
+__global__ __launch_bounds__(256) void panel_rule_kernel(PanelRuleSpec a) {
+    const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (p >= a.npanels) return;
+    // the shared rule on the panel's fifteen innermost integrals (node-major, ncomp components each): what the host's
+    // gk15_evalrule computes from the same numbers
+    const gkc* fv = reinterpret_cast<const gkc*>(a.n_I + (size_t)(15 * p) * a.ncomp);
+    a.p_E[p] = gk15_rule(fv, a.ncomp, a.p_a[p], a.p_b[p], reinterpret_cast<gkc*>(a.p_I + (size_t)p * a.ncomp));
+    int64_t nev = 0;
+    int st = 0;
+    for (int i = 0; i < 15; ++i) {
+        nev += a.n_nev[15 * p + i];
+        st |= a.n_status[15 * p + i];
+    }
+    a.p_nev[p] = nev;
+    a.p_status[p] = st;
+}
+
+int launch_panel_rule(abz_ctx* ctx, const PanelRuleSpec& ps) {
+    if (ps.npanels == 0) return ABZ_OK;
+    hipLaunchKernelGGL(panel_rule_kernel, dim3((unsigned)cdiv(ps.npanels, 256)), dim3(256), 0, ctx->stream, ps);
+    ABZ_HIP(hipGetLastError());
+    return ABZ_OK;
 }
 
 bool inner_adaptive_supported(int n, int M, int integrand) {

@@ -138,8 +138,8 @@ class DeviceSeries:
         """Upload new coefficients of the same shape.  Every cached rule is stale from here on and is
         re-evaluated in place (abz_rule_rebuild, which also refreshes its Hermitian flag) before its next
         use -- the reference rebuilds its rule from the current series on every solve.  New coefficients
-        `c` replace the host series' array and go to EVERY live device copy of the series (the IAI sweep
-        lanes keep one per context): a copy left behind would integrate the old coefficients."""
+        `c` replace the host series' array and go to EVERY live device copy of the series (one per context
+        it was used on): a copy left behind would integrate the old coefficients."""
         if c is not None:
             c = np.asarray(c, dtype=np.complex128)
             if c.shape != self.s.c.shape:

@@ -709,55 +709,10 @@ def _redo_on_fbz(f, bz, p, alg, kws):
     return do_solve(f, fbz, p, alg, init_cacheval(f, fbz, p, alg), **kws)
 
 
-_LANE_CTX = {}  # device id -> extra contexts (own streams) of the sweep lanes
-
-
-def _iai_lanes(dev, nsolves, want_panels):
-    """How many lanes a sweep of `nsolves` independent IAI solves is split into (ABZ_IAI_LANES, default up to 4 with
-    at least ABZ_IAI_LANE_MIN = 16 solves each; 1 = off; tools/time_iai_lanes.py).  A lane = a host thread driving its
-    own device context (stream) and its own copy of the device-resident series, so one lane's host rounds (gather, heaps, delivery) overlap the other lanes' kernels: the
-    432-solve sweep of the reference's example was 0.11 s with 0.055 s of it waiting on the GPU.  Every solve makes the
-    decisions it would make alone, so the split changes no result."""
-    import os
-    if want_panels or getattr(dev, "iai_exchange", False) or dev.kshard is not None:
-        return 1
-    want = int(os.environ.get("ABZ_IAI_LANES", "4"))
-    per = max(1, int(os.environ.get("ABZ_IAI_LANE_MIN", "16")))  # at least this many solves per lane
-    return max(1, min(want, nsolves // per))
-
-
 def _iai_device_many(f: FourierIntegrand, dev, lims, plist, abstol, reltol, maxiters, want_panels=False):
     """IAI for several parameter sets at once (abz_iai_solve_many): solves that differ only in the
-    swept parameter share every launch.  Returns [(value, err, numevals, extra)] in plist order."""
-    lanes = _iai_lanes(dev, len(plist), want_panels)
-    if lanes > 1:
-        import threading
-        ctxs = _LANE_CTX.setdefault(dev.ctx.device, [])
-        while len(ctxs) < lanes - 1:
-            ctxs.append(L.Context(dev.ctx.device))
-        devs = [dev] + [f.w.device(c) for c in ctxs[: lanes - 1]]
-        res = [None] * len(plist)
-        errs = []
-
-        def run(j):
-            try:
-                part = _iai_device_lane(f, devs[j], lims, plist[j::lanes], abstol, reltol, maxiters, False)
-                res[j::lanes] = part
-            except BaseException as e:  # re-raised on the caller's thread
-                errs.append(e)
-        threads = [threading.Thread(target=run, args=(j,)) for j in range(1, lanes)]
-        for t in threads:
-            t.start()
-        run(0)
-        for t in threads:
-            t.join()
-        if errs:
-            raise errs[0]
-        return res
-    return _iai_device_lane(f, dev, lims, plist, abstol, reltol, maxiters, want_panels)
-
-
-def _iai_device_lane(f: FourierIntegrand, dev, lims, plist, abstol, reltol, maxiters, want_panels=False):
+    swept parameter share every launch, and sweeps of >= 32 of them are dealt to lanes inside the library (host thread +
+    stream each: ABZ_IAI_LANES, ABZ_IAI_LANE_MIN).  Returns [(value, err, numevals, extra)] in plist order."""
     fi = f.f.f
     max_batch = 0 if f.nest is None else min(f.nest.max_batch, 2**62)
     d, n = f.w.d, f.w.n

@@ -508,7 +508,6 @@ def test_iai_sweep_lanes_change_nothing(abz, svo, monkeypatch):
     monkeypatch.setenv("ABZ_IAI_LANES", "3")
     v3, m3 = sweep(solver, om)
     assert np.array_equal(v1, v2) and m1 == m2 and np.array_equal(v1, v3) and m1 == m3
-    assert len(s._dev) >= 3  # the lanes' copies of the device series exist
     rng = np.random.default_rng(77)
     c, first = rand_series(rng, (3, 3), 6, hermitian=True)
     s6, _ = both(abz, c / np.sqrt(6), first)
@@ -520,7 +519,7 @@ def test_iai_sweep_lanes_change_nothing(abz, svo, monkeypatch):
     monkeypatch.setenv("ABZ_IAI_LANES", "2")
     a2, n2 = sweep(sol6, om6)
     assert np.array_equal(a1, a2) and n1 == n2
-    # new coefficients must reach the second lane's copy as well
+    # new coefficients must reach the second lane's view as well
     s6.c[...] = s6.c * 0.5
     s6.invalidate()
     b2, _ = sweep(sol6, om6)

@@ -11,7 +11,7 @@ om = np.linspace(10, 15, 432)
 for nsol in (432, 216, 108, 54, 27):
     sub = om[:: 432 // nsol][:nsol]
     row = []
-    for lanes in (1, 2, 3, 4):
+    for lanes in (1, 2, 4, 6, 8):
         os.environ["ABZ_IAI_LANES"] = str(lanes)
         os.environ["ABZ_IAI_LANE_MIN"] = "1"
         abz.batchsolve(solver, sub)
@@ -19,4 +19,4 @@ for nsol in (432, 216, 108, 54, 27):
         for rep in range(3):
             t0 = time.perf_counter(); abz.batchsolve(solver, sub); best = min(best, time.perf_counter() - t0)
         row.append(best)
-    print(f"{nsol:4d} solves: " + "  ".join(f"{l} lanes {1e3*t:6.1f} ms" for l, t in zip((1, 2, 3, 4), row)), flush=True)
+    print(f"{nsol:4d} solves: " + "  ".join(f"{l} lanes {1e3*t:6.1f} ms" for l, t in zip((1, 2, 4, 6, 8), row)), flush=True)
