@@ -1163,11 +1163,32 @@ __device__ __forceinline__ void group_gather(double v, double (&out)[NP], std::i
 }
 
 // sum over the NP lanes of a node (every lane gets it)
+// (8 and 16 lanes: mirror steps inside the 16-lane DPP row -- row_mirror i <-> 15 - i, row_half_mirror i <-> 7 - i, then the
+// two quad permutations; two 32-bit DPP moves and an add per step on the VALU instead of two `ds_bpermute_b32` and their
+// wait on the LDS crossbar.  The Householder steps below run three of these sums per column.)
+template <int CTRL>
+__device__ __forceinline__ double dpp_perm_f64(double v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), CTRL, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), CTRL, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+#else
+    return v;
+#endif
+}
 template <int NP>
 __device__ __forceinline__ double group_sum(double v) {
+    if constexpr (NP == 16 || NP == 8) {
+        if constexpr (NP == 16) v += dpp_perm_f64<0x140>(v);  // row_mirror
+        v += dpp_perm_f64<0x141>(v);                          // row_half_mirror
+        v += dpp_perm_f64<0x1b>(v);                           // quad_perm [3, 2, 1, 0]
+        v += dpp_perm_f64<0xb1>(v);                           // quad_perm [1, 0, 3, 2]
+        return v;
+    } else {
 #pragma unroll
-    for (int off = NP / 2; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-    return v;
+        for (int off = NP / 2; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+        return v;
+    }
 }
 
 // Eigenvalues (ascending rank of this lane's eigenvalue in `rank`, the value in `dg`) of the Hermitian matrix whose
@@ -1233,23 +1254,53 @@ struct GenEigArgs {
 //       stebz), degenerate spectra included.
 // ~13 k instructions per four matrices.  Eigenvector builds (GGR) keep the Jacobi.
 // ------------------------------------------------------------------------------------------
-// column j of the two j-loops of a Householder step (j is a template parameter: `group_bcast` patterns are immediates)
+// column j of the two j-loops of a Householder step (j is a template parameter: `group_bcast` patterns are immediates).
+// 16 lanes: v_j and q_j are read from lane j INSIDE the FMAs (`v_fmac_f64_dpp ... row_newbcast:j`, see fmac_col_bcast
+// above for the idiom and its wait states): 12 instructions per complex column instead of 4 broadcasts + 16, and no
+// registers for the broadcast copies of v.
 template <int NP, int J>
 __device__ __forceinline__ void hh_col_p(const double (&ar)[NP], const double (&ai)[NP], double vr, double vi, double (&vjr)[NP],
                                          double (&vji)[NP], double& pr, double& pi) {
-    vjr[J] = group_bcast<NP, J>(vr);
-    vji[J] = group_bcast<NP, J>(vi);
-    pr = fma(ar[J], vjr[J], pr);
-    pr = fma(-ai[J], vji[J], pr);
-    pi = fma(ar[J], vji[J], pi);
-    pi = fma(ai[J], vjr[J], pi);
+    if constexpr (NP == 16) {
+        // p += A[r][J] v_J:  pr += vJr ar - vJi ai,  pi += vJi ar + vJr ai
+        asm("s_nop 1\n\t"
+            "v_fmac_f64_dpp %0, %2, %4 row_newbcast:%6 row_mask:0xf bank_mask:0xf\n\t"
+            "v_fmac_f64_dpp %0, %3, -%5 row_newbcast:%6 row_mask:0xf bank_mask:0xf\n\t"
+            "v_fmac_f64_dpp %1, %3, %4 row_newbcast:%6 row_mask:0xf bank_mask:0xf\n\t"
+            "v_fmac_f64_dpp %1, %2, %5 row_newbcast:%6 row_mask:0xf bank_mask:0xf"
+            : "+v"(pr), "+v"(pi)
+            : "v"(vr), "v"(vi), "v"(ar[J]), "v"(ai[J]), "n"(J));
+    } else {
+        vjr[J] = group_bcast<NP, J>(vr);
+        vji[J] = group_bcast<NP, J>(vi);
+        pr = fma(ar[J], vjr[J], pr);
+        pr = fma(-ai[J], vji[J], pr);
+        pi = fma(ar[J], vji[J], pi);
+        pi = fma(ai[J], vjr[J], pi);
+    }
 }
 template <int NP, int J>
 __device__ __forceinline__ void hh_col_upd(double (&ar)[NP], double (&ai)[NP], double vr, double vi, double qr, double qi,
                                            const double (&vjr)[NP], const double (&vji)[NP]) {
-    const double qjr = group_bcast<NP, J>(qr), qji = group_bcast<NP, J>(qi);
-    ar[J] -= (vr * qjr + vi * qji) + (qr * vjr[J] + qi * vji[J]);
-    ai[J] -= (vi * qjr - vr * qji) + (qi * vjr[J] - qr * vji[J]);
+    if constexpr (NP == 16) {
+        // A[r][J] -= v_r conj(q_J) + q_r conj(v_J):
+        //   ar -= qJr vr + qJi vi + vJr qr + vJi qi,   ai -= qJr vi - qJi vr + vJr qi - vJi qr
+        asm("s_nop 1\n\t"
+            "v_fmac_f64_dpp %0, %4, -%2 row_newbcast:%6 row_mask:0xf bank_mask:0xf\n\t"
+            "v_fmac_f64_dpp %1, %4, -%3 row_newbcast:%6 row_mask:0xf bank_mask:0xf\n\t"
+            "v_fmac_f64_dpp %0, %5, -%3 row_newbcast:%6 row_mask:0xf bank_mask:0xf\n\t"
+            "v_fmac_f64_dpp %1, %5, %2 row_newbcast:%6 row_mask:0xf bank_mask:0xf\n\t"
+            "v_fmac_f64_dpp %0, %2, -%4 row_newbcast:%6 row_mask:0xf bank_mask:0xf\n\t"
+            "v_fmac_f64_dpp %1, %2, -%5 row_newbcast:%6 row_mask:0xf bank_mask:0xf\n\t"
+            "v_fmac_f64_dpp %0, %3, -%5 row_newbcast:%6 row_mask:0xf bank_mask:0xf\n\t"
+            "v_fmac_f64_dpp %1, %3, %4 row_newbcast:%6 row_mask:0xf bank_mask:0xf"
+            : "+v"(ar[J]), "+v"(ai[J])
+            : "v"(vr), "v"(vi), "v"(qr), "v"(qi), "n"(J));
+    } else {
+        const double qjr = group_bcast<NP, J>(qr), qji = group_bcast<NP, J>(qi);
+        ar[J] -= (vr * qjr + vi * qji) + (qr * vjr[J] + qi * vji[J]);
+        ai[J] -= (vi * qjr - vr * qji) + (qi * vjr[J] - qr * vji[J]);
+    }
 }
 template <int NP, int K, int... JJ>
 __device__ __forceinline__ void hh_cols_p(const double (&ar)[NP], const double (&ai)[NP], double vr, double vi, double (&vjr)[NP],
@@ -1274,12 +1325,20 @@ __device__ __forceinline__ void hh_step(int n, int r, double (&ar)[NP], double (
         if constexpr (K + 2 < NP) {
             if (K + 2 >= n) return;  // the last off-diagonal: nothing left to eliminate (uniform)
             const double x1r = group_bcast<NP, K + 1>(xr), x1i = group_bcast<NP, K + 1>(xi);
-            const double a1 = sqrt(x1r * x1r + x1i * x1i), nrm = sqrt(sigma);
-            const double ia1 = a1 > 0.0 ? 1.0 / a1 : 0.0;
-            const double phr = a1 > 0.0 ? x1r * ia1 : 1.0, phi = a1 > 0.0 ? x1i * ia1 : 0.0;
-            // v = x + phase ||x|| e_1 (no cancellation), beta = 2 / ||v||^2 = 1 / (||x|| (||x|| + |x_1|)); sigma = 0: beta = 0, a no-op
-            const double vr = (r == K + 1) ? phr * (a1 + nrm) : xr, vi = (r == K + 1) ? phi * (a1 + nrm) : xi;
-            const double den = nrm * (nrm + a1);
+            // v = x + phase ||x|| e_1 (no cancellation), beta = 2 / ||v||^2 = 1 / (||x|| (||x|| + |x_1|)); sigma = 0: beta = 0, a
+            // no-op.  With s = ||x|| |x_1| = sqrt(sigma |x_1|^2):  v_1 = x_1 (1 + s / |x_1|^2),  1 / beta = sigma + s -- one
+            // square root per step; x_1 = 0 (v_1 = ||x||) takes a second one under a uniform branch.
+            const double a1sq = x1r * x1r + x1i * x1i;
+            const double sx = sqrt(sigma * a1sq);
+            const double fac = a1sq > 0.0 ? 1.0 + sx / a1sq : 0.0;
+            double v1r = x1r * fac, v1i = x1i * fac;
+            if (__any(a1sq == 0.0 && sigma > 0.0)) {
+                const double nrm = sqrt(sigma);
+                v1r = a1sq == 0.0 ? nrm : v1r;
+                v1i = a1sq == 0.0 ? 0.0 : v1i;
+            }
+            const double vr = (r == K + 1) ? v1r : xr, vi = (r == K + 1) ? v1i : xi;
+            const double den = sigma + sx;
             const double beta = den > 0.0 ? 1.0 / den : 0.0;
             double vjr[NP], vji[NP];
             double pr = 0.0, pi = 0.0;  // p_r = beta sum_{j > K} A[r][j] v_j
@@ -1344,30 +1403,81 @@ __device__ __forceinline__ double rows_eigvals_tridiag(int n, int r, double (&ar
     lo *= sc;
     hi *= sc;
     const int want = r < n ? r : n - 1;
-    for (int it = 0; it < 48; ++it) {
-        const double x = 0.5 * (lo + hi);
+    // count of eigenvalues below x and the value p_n(x) of the characteristic polynomial (free: the last minor).  The
+    // signs of the minors are shifted into one word (v_alignbit_b32: one instruction per step) and their changes counted
+    // at the end: 4 instructions per step (subtract, multiply, FMA, shift)
+    const unsigned smask = ((1u << n) - 1u) >> 1;  // n - 1 neighbouring pairs of n signs (n <= 16)
+    auto sturm = [&](double x, int& cnt, double& pv) {
         double pm = 1.0, p = ds[0] - x;
-        int hprev = __double2hiint(p);
-        int cnt = (int)((unsigned)hprev >> 31);
+        unsigned bits = (unsigned)__double2hiint(p) >> 31;
 #pragma unroll
         for (int i = 1; i < NP; ++i) {
             if (i < n) {  // uniform
                 const double pn = fma(ds[i] - x, p, -(es[i - 1] * pm));
-                const int h = __double2hiint(pn);
-                cnt += (int)((unsigned)(h ^ hprev) >> 31);
-                hprev = h;
+                bits = __builtin_amdgcn_alignbit(bits, (unsigned)__double2hiint(pn), 31);  // (bits << 1) | sign
                 pm = p;
                 p = pn;
             }
         }
-        if (cnt > want)
-            hi = x;
-        else
-            lo = x;
+        // sign of p_1 (p_0 = 1 is positive) + the changes between neighbours
+        cnt = (int)((bits >> (n - 1)) & 1u) + __popc((bits ^ (bits >> 1)) & smask);
+        pv = p;
+    };
+    // Bisection on the count until this lane's eigenvalue is ALONE in its bracket (counts at the ends differ by one: p_n
+    // changes sign across it), then interpolation on p_n -- inverse quadratic through the two ends and the end replaced
+    // last, false position while there is no third point -- inside a bracket that the counts keep valid whatever the
+    // rounding of p_n does.  Each interpolated point is pushed 0.4 tol towards the far end of the bracket, so that once
+    // the iterates sit on the root the far end jumps next to it and the WIDTH of the bracket is the stopping test, as in
+    // plain bisection (tol = what 48 halvings leave).  Three interpolated passes in a row that do not halve the bracket
+    // are followed by a bisection pass; after 30 passes, and for clusters that never separate (degenerate levels), it is
+    // bisection all the way like before.  The loop is wave-uniform: ~19 passes for random spectra instead of 48.
+    const double tol = 7.1e-15;  // 2 * 2^-48: the width 48 halvings leave of a Gershgorin interval of (scaled) length 2
+    double plo = 0.0, phi = 0.0, xo = 0.0, po = 0.0;
+    int clo = 0, chi = n, slow = 0;
+    bool klo = false, khi = false, ko = false;  // p_n known at the end / a third point is there
+    for (int it = 0; it < 200; ++it) {
+        const double w = hi - lo;
+        const bool ip = klo && khi && chi - clo == 1 && ((__double2hiint(plo) ^ __double2hiint(phi)) < 0) && slow < 3 && it < 30;
+        double x = 0.5 * (lo + hi);
+        if (ip) {
+            // false position, or (three distinct values) inverse quadratic interpolation: one division either way
+            double num = lo * phi - hi * plo, den = phi - plo;
+            if (ko && po != plo && po != phi) {
+                const double dab = plo - phi, dac = plo - po, dbc = phi - po;
+                num = (lo * phi * po) * dbc - (hi * plo * po) * dac + (xo * plo * phi) * dab;
+                den = dab * dac * dbc;
+            }
+            double xs = num / den;
+            if (!(xs > lo && xs < hi)) xs = (lo * phi - hi * plo) / (phi - plo);  // (rare: the parabola left the bracket)
+            xs += (xs - lo < hi - xs) ? 0.4 * tol : -0.4 * tol;
+            if (xs > lo && xs < hi) x = xs;
+        }
+        int cnt;
+        double pv;
+        sturm(x, cnt, pv);
+        if (w > tol) {
+            if (cnt > want) {
+                xo = hi;
+                po = phi;
+                ko = khi;
+                hi = x;
+                chi = cnt;
+                phi = pv;
+                khi = true;
+            } else {
+                xo = lo;
+                po = plo;
+                ko = klo;
+                lo = x;
+                clo = cnt;
+                plo = pv;
+                klo = true;
+            }
+            slow = (ip && hi - lo > 0.5 * w) ? slow + 1 : 0;
+        }
+        if (!__any(hi - lo > tol)) break;
     }
-    lo *= span;
-    hi *= span;
-    return 0.5 * (lo + hi);
+    return 0.5 * (lo + hi) * span;
 }
 
 
