@@ -1237,6 +1237,8 @@ struct GenEigArgs {
     const int32_t* gi = nullptr;
     int n, M, first, npt;
     int herm = 0;  // Hermitian series: H(k) leaves the kernel as its upper triangle (mirrored into the full layout's lower planes)
+    double* tri = nullptr;  // eigenvalues only: the tridiagonals (d | |e|^2, [2 NP][tri_nk]) for tri_eig_kernel instead of E
+    int64_t tri_nk = 0;
 };
 
 
@@ -1956,12 +1958,33 @@ __global__ __launch_bounds__(256, (TRI && !VEC) ? 2 : 1) void gen_grid_eig_kerne
                 dg = rows_eigvals_tridiag<NP>(n, r, tr_, ti_);
                 rank = r;
                 rows_eigvecs_invit<NP>(n, r, lane, hr, hi, dg, vr, vi);
-            } else if constexpr (TRI) {  // eigenvalues only: Householder + Sturm bisection, lane r gets eigenvalue r
-                dg = rows_eigvals_tridiag<NP>(n, r, hr, hi);
-                rank = r;
+            } else if constexpr (TRI) {  // eigenvalues only
+                if (a.tri) {
+                    // Householder here, the eigenvalues of the tridiagonals in tri_eig_kernel (one LANE per matrix there: a
+                    // fraction of the instructions of the bisection below, which keeps 16 lanes busy per matrix)
+                    double e2[NP], d[NP];
+                    hh_steps<NP>(n, r, hr, hi, e2, std::make_integer_sequence<int, NP>());
+                    diag_gather<NP>(hr, d, std::make_integer_sequence<int, NP>());
+                    double dr = 0.0, er = 0.0;
+#pragma unroll
+                    for (int j = 0; j < NP; ++j) {
+                        dr = (j == r) ? d[j] : dr;
+                        er = (j == r) ? e2[j] : er;
+                    }
+                    if (wr) {
+                        a.tri[(int64_t)r * a.tri_nk + k] = dr;
+                        a.tri[(int64_t)(NP + r) * a.tri_nk + k] = er;
+                    }
+                } else {
+                    dg = rows_eigvals_tridiag<NP>(n, r, hr, hi);  // Householder + Sturm bisection, lane r gets eigenvalue r
+                    rank = r;
+                }
             } else {
                 rows_eig<NP, VEC>(n, r, lane, hr, hi, vr, vi, dg, rank);
             }
+            }
+            if constexpr (TRI && !VEC) {
+                if (a.tri) continue;  // (uniform over the block: no barrier below is skipped by a part of it)
             }
             {  // eigenvalue planes: through the tile as well ([band][node] -> SLOTS consecutive nodes per band)
                 if (wave_on && wr) tile[rank * TS + slot] = dg;
@@ -1994,6 +2017,100 @@ __global__ __launch_bounds__(256, (TRI && !VEC) ? 2 : 1) void gen_grid_eig_kerne
                 }
             }
         }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Eigenvalues of the real symmetric tridiagonals (d, |e|^2) that gen_grid_eig_kernel leaves behind: ONE LANE PER MATRIX,
+// the root-free QR iteration of Pal, Walker and Kahan as LAPACK's dsterf runs it (its "QR iteration" branch: Wilkinson
+// shift from the bottom 2 x 2, one sweep of rational rotations on d and e^2 -- no square roots in the sweep --, deflation
+// at the bottom), on the whole leading block [0, L] (interior splits are not looked for: a rotation across a zero
+// coupling is the identity).  ~1.7 sweeps per eigenvalue, ~60 instructions per rotation: ~30 k instructions per 64
+// matrices against ~4 k per FOUR for the bisection in the row layout.  The arrays of a lane live in LDS ([j][lane]: the
+// bottom index L differs from lane to lane), sorted at the end by an odd-even transposition network in registers.
+// ------------------------------------------------------------------------------------------
+template <int NP>
+__global__ __launch_bounds__(64) void tri_eig_kernel(const double* __restrict__ tri, int64_t tri_nk, int64_t nk, int n, PlaneView E) {
+    __shared__ double ld[NP][64], le[NP][64];
+    const int lane = threadIdx.x;
+    const int64_t k = (int64_t)blockIdx.x * 64 + lane;
+    const bool act = k < nk;
+    const int64_t kk = act ? k : nk - 1;
+    double anorm2 = 0.0;
+#pragma unroll
+    for (int j = 0; j < NP; ++j) {
+        const double dj = j < n ? tri[(int64_t)j * tri_nk + kk] : 0.0;
+        const double ej = j + 1 < n ? tri[(int64_t)(NP + j) * tri_nk + kk] : 0.0;
+        ld[j][lane] = dj;
+        le[j][lane] = ej;
+        anorm2 = fmax(anorm2, fmax(dj * dj, ej));
+    }
+    const double eps2 = 1.2325951644078309e-32;  // (2^-53)^2
+    const double floor2 = eps2 * 1e-2 * anorm2;  // |e| <= 0.1 eps ||T||: a coupling that small moves no eigenvalue by more than that
+    int L = n - 1;        // bottom of the block that is still coupled
+    int budget = 30 * n;  // dsterf's iteration limit
+    while (__any(L > 0 && budget > 0)) {
+        if (L > 0 && budget > 0) {
+            const double dL = ld[L][lane], dm = ld[L - 1][lane], eb = le[L - 1][lane];
+            if (eb <= eps2 * fabs(dL * dm) + floor2) {
+                le[L - 1][lane] = 0.0;
+                --L;
+            } else {
+                --budget;
+                // shift: the eigenvalue of the bottom 2 x 2 closer to d_L
+                const double rte = sqrt(eb);
+                double sg = (dm - dL) / (2.0 * rte);
+                const double rr = sqrt(fma(sg, sg, 1.0));
+                sg = dL - rte / (sg + copysign(rr, sg));
+                // The sweep is one dependent chain per lane (and the kernel has under two waves per SIMD to hide it behind):
+                // reciprocals by estimate + Newton instead of IEEE division sequences, 1 / c = r / p_old beside 1 / r
+                // instead of after it, and the next step's two LDS reads issued before this step's arithmetic.
+                double c = 1.0, sn = 0.0, gamma = ld[0][lane] - sg, pp = gamma * gamma;
+                double bb = le[0][lane], alpha = ld[1][lane];
+                for (int i = 0; i < L; ++i) {
+                    double bbn = 0.0, alphan = 0.0;
+                    if (i + 1 < L) {
+                        bbn = le[i + 1][lane];
+                        alphan = ld[i + 2][lane];
+                    }
+                    const double r2 = pp + bb;
+                    if (i != 0) le[i - 1][lane] = sn * r2;
+                    const double oldc = c;
+                    const bool fast = pp >= 1e-280 && r2 <= 1e280;  // (else: the same quantities by true divisions)
+                    const double ir = fast ? rcp_nr(r2) : (r2 != 0.0 ? 1.0 / r2 : 0.0);
+                    const double ip = fast ? rcp_nr(pp) : 0.0;
+                    c = r2 != 0.0 ? pp * ir : 1.0;
+                    sn = bb * ir;
+                    const double oldgam = gamma;
+                    gamma = c * (alpha - sg) - sn * oldgam;
+                    ld[i][lane] = oldgam + (alpha - gamma);
+                    const double g2 = gamma * gamma;
+                    pp = fast ? g2 * (r2 * ip) : (c != 0.0 ? g2 / c : oldc * bb);
+                    bb = bbn;
+                    alpha = alphan;
+                }
+                le[L - 1][lane] = sn * pp;
+                ld[L][lane] = sg + gamma;
+            }
+        }
+    }
+    double v[NP];
+#pragma unroll
+    for (int j = 0; j < NP; ++j) v[j] = j < n ? ld[j][lane] : __builtin_huge_val();
+#pragma unroll
+    for (int pass = 0; pass < NP; ++pass) {
+#pragma unroll
+        for (int j = pass & 1; j + 1 < NP; j += 2) {
+            const double lo = fmin(v[j], v[j + 1]), hi = fmax(v[j], v[j + 1]);
+            v[j] = lo;
+            v[j + 1] = hi;
+        }
+    }
+    if (act) {
+        double* eo = E.base + view_off(E, k);
+#pragma unroll
+        for (int j = 0; j < NP; ++j)
+            if (j < n) eo[(int64_t)j * E.pitch] = v[j];
     }
 }
 
@@ -2040,6 +2157,17 @@ static int launch_gen_grid_eig(abz_ctx* ctx, const GenSpec& gs, int np, size_t l
     a.herm = gs.herm ? 1 : 0;
     const int64_t blocks = std::min<int64_t>(a.nlines, 256 * 4);
     const bool vec = gs.Uplanes.base != nullptr;
+    // eigenvalues without eigenvectors: the tridiagonals go through scratch to tri_eig_kernel (ABZ_EIG_SPLIT=0: bisection
+    // inside the grid kernel).  (Cutting the grid into four chunks of lines with chunk c's tridiagonal kernel on a second
+    // stream beside chunk c + 1's grid kernel was slower, 0.76 against 0.51 ms at 48^3: four short launches with their own
+    // tails.)
+    const bool split = !vec && gs.Eplanes.base && abz_switch(SW_EIG_SPLIT) != 0;
+    if (split) {
+        a.tri_nk = (gs.nnodes + 63) / 64 * 64;
+        int rc = ctx->scratch[4].reserve(sizeof(double) * (size_t)(2 * np) * (size_t)a.tri_nk);
+        if (rc) return rc;
+        a.tri = ctx->scratch[4].as<double>();
+    }
     ProfScope ps(ctx, ABZ_K_EVAL);
     // eigenvalues only: Householder + Sturm bisection (TRI); with eigenvectors: the parallel-order Jacobi up to 8 bands,
     // inverse iteration on the zero-padded layout for 9...16 (the 16-row Jacobi with accumulated rotations spilled 4.6 KB)
@@ -2061,6 +2189,13 @@ static int launch_gen_grid_eig(abz_ctx* ctx, const GenSpec& gs, int np, size_t l
         ABZ_GE3(16, true, true, true)  // gen_grid_eig_supported: pad is set
     }
 #undef ABZ_GE3
+    if (split) {
+        const unsigned tb = (unsigned)cdiv2(gs.nnodes, 64);
+        if (np == 8)
+            hipLaunchKernelGGL(tri_eig_kernel<8>, dim3(tb), dim3(64), 0, ctx->stream, a.tri, a.tri_nk, gs.nnodes, gs.n, gs.Eplanes);
+        else
+            hipLaunchKernelGGL(tri_eig_kernel<16>, dim3(tb), dim3(64), 0, ctx->stream, a.tri, a.tri_nk, gs.nnodes, gs.n, gs.Eplanes);
+    }
     ABZ_HIP(hipGetLastError());
     return ABZ_OK;
 }
