@@ -2031,7 +2031,7 @@ __global__ __launch_bounds__(256, (TRI && !VEC) ? 2 : 1) void gen_grid_eig_kerne
 // ------------------------------------------------------------------------------------------
 template <int NP>
 __global__ __launch_bounds__(64) void tri_eig_kernel(const double* __restrict__ tri, int64_t tri_nk, int64_t nk, int n, PlaneView E) {
-    __shared__ double ld[NP][64], le[NP][64];
+    __shared__ double ld[NP + 2][64], le[NP + 2][64];
     const int lane = threadIdx.x;
     const int64_t k = (int64_t)blockIdx.x * 64 + lane;
     const bool act = k < nk;
@@ -2051,41 +2051,51 @@ __global__ __launch_bounds__(64) void tri_eig_kernel(const double* __restrict__ 
     int budget = 30 * n;  // dsterf's iteration limit
     while (__any(L > 0 && budget > 0)) {
         if (L > 0 && budget > 0) {
-            const double dL = ld[L][lane], dm = ld[L - 1][lane], eb = le[L - 1][lane];
-            if (eb <= eps2 * fabs(dL * dm) + floor2) {
+            // deflate as far as it goes, THEN sweep: every pass of the wave's loop is a sweep for every lane that is not
+            // finished (a pass that only deflated would sit out the other lanes' sweep)
+            double dL = ld[L][lane], dm = ld[L - 1][lane], eb = le[L - 1][lane];
+            while (eb <= eps2 * fabs(dL * dm) + floor2) {
                 le[L - 1][lane] = 0.0;
                 --L;
-            } else {
+                if (L == 0) break;
+                dL = dm;
+                dm = ld[L - 1][lane];
+                eb = le[L - 1][lane];
+            }
+            if (L > 0) {
                 --budget;
                 // shift: the eigenvalue of the bottom 2 x 2 closer to d_L
                 const double rte = sqrt(eb);
                 double sg = (dm - dL) / (2.0 * rte);
                 const double rr = sqrt(fma(sg, sg, 1.0));
                 sg = dL - rte / (sg + copysign(rr, sg));
-                // The sweep is one dependent chain per lane (and the kernel has under two waves per SIMD to hide it behind):
-                // reciprocals by estimate + Newton instead of IEEE division sequences, 1 / c = r / p_old beside 1 / r
-                // instead of after it, and the next step's two LDS reads issued before this step's arithmetic.
+                // The sweep: ~35 instructions per rotation on the common path -- ONE reciprocal (estimate + Newton) of r p
+                // serves c = p / r, s = b / r and 1 / c = r / p; the next step's two LDS reads are issued before this step's
+                // arithmetic, unconditionally (rows NP, NP + 1 of the arrays exist for that); LAPACK's special cases
+                // (p = 0, r = 0, and anything near the ends of the double range) take a wave-uniform branch to the same
+                // quantities by true divisions.
                 double c = 1.0, sn = 0.0, gamma = ld[0][lane] - sg, pp = gamma * gamma;
                 double bb = le[0][lane], alpha = ld[1][lane];
                 for (int i = 0; i < L; ++i) {
-                    double bbn = 0.0, alphan = 0.0;
-                    if (i + 1 < L) {
-                        bbn = le[i + 1][lane];
-                        alphan = ld[i + 2][lane];
-                    }
+                    const double bbn = le[i + 1][lane], alphan = ld[i + 2][lane];
                     const double r2 = pp + bb;
                     if (i != 0) le[i - 1][lane] = sn * r2;
-                    const double oldc = c;
-                    const bool fast = pp >= 1e-280 && r2 <= 1e280;  // (else: the same quantities by true divisions)
-                    const double ir = fast ? rcp_nr(r2) : (r2 != 0.0 ? 1.0 / r2 : 0.0);
-                    const double ip = fast ? rcp_nr(pp) : 0.0;
-                    c = r2 != 0.0 ? pp * ir : 1.0;
-                    sn = bb * ir;
                     const double oldgam = gamma;
-                    gamma = c * (alpha - sg) - sn * oldgam;
+                    if (!__any(!(pp >= 1e-140 && r2 <= 1e140))) {
+                        const double t = rcp_nr(r2 * pp);
+                        const double ppt = pp * t;
+                        c = pp * ppt;
+                        sn = bb * ppt;
+                        gamma = c * (alpha - sg) - sn * oldgam;
+                        pp = (gamma * gamma) * (r2 * (r2 * t));
+                    } else {
+                        const double oldc = c;
+                        c = r2 != 0.0 ? pp / r2 : 1.0;
+                        sn = r2 != 0.0 ? bb / r2 : 0.0;
+                        gamma = c * (alpha - sg) - sn * oldgam;
+                        pp = c != 0.0 ? (gamma * gamma) / c : oldc * bb;
+                    }
                     ld[i][lane] = oldgam + (alpha - gamma);
-                    const double g2 = gamma * gamma;
-                    pp = fast ? g2 * (r2 * ip) : (c != 0.0 ? g2 / c : oldc * bb);
                     bb = bbn;
                     alpha = alphan;
                 }
