@@ -56,6 +56,7 @@ enum Switch {
     SW_IAI_PANELS,       // ABZ_IAI_PANELS      level above the innermost: panels, not nodes, cross PCIe (0: nodes)
     SW_IAI_STATS,        // ABZ_IAI_STATS       per-solve statistics of the IAI driver on stderr
     SW_HOST_THREADS,     // ABZ_HOST_THREADS    host threads for the per-integral bookkeeping of IAI sweeps
+    SW_EIG_FOLD,         // ABZ_EIG_FOLD        5...16-band rule builds of Hermitian series: folded level-1 series
     SW_EIG_SPLIT,        // ABZ_EIG_SPLIT       5...16-band eigenvalue builds: tridiagonal eigenvalues in a kernel of their own
     SW_IAI_LANES,        // ABZ_IAI_LANES       lanes (host thread + stream each) an IAI sweep is split over
     SW_IAI_LANE_MIN,     // ABZ_IAI_LANE_MIN    solves a lane needs before a sweep is split further

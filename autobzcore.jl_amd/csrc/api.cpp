@@ -52,6 +52,7 @@ const SwitchDef g_switches[SW_COUNT] = {
     {"ABZ_IAI_PANELS", 1, "0: the level above the innermost one ships nodes instead of panels (GK rule of that level on the host)"},
     {"ABZ_IAI_STATS", 0, "1: per-solve statistics of the IAI driver on stderr"},
     {"ABZ_HOST_THREADS", 8, "host threads for the per-integral bookkeeping of IAI sweeps (capped at half the cores)"},
+    {"ABZ_EIG_FOLD", 1, "0: 5...16-band rule builds evaluate the full level-1 series of a Hermitian model instead of the folded one"},
     {"ABZ_EIG_SPLIT", 1, "0: eigenvalues of 5...16-band rules by bisection inside the grid kernel instead of the per-lane QR kernel"},
     {"ABZ_IAI_LANES", 4, "lanes (host thread + stream each) a sweep of independent IAI solves is split over; 1: off"},
     {"ABZ_IAI_LANE_MIN", 16, "solves per lane below which a sweep is not split further"},

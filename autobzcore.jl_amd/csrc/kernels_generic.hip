@@ -1239,6 +1239,7 @@ struct GenEigArgs {
     int herm = 0;  // Hermitian series: H(k) leaves the kernel as its upper triangle (mirrored into the full layout's lower planes)
     double* tri = nullptr;  // eigenvalues only: the tridiagonals (d | |e|^2, [2 NP][tri_nk]) for tri_eig_kernel instead of E
     int64_t tri_nk = 0;
+    int fold = 0;  // Hermitian level-1 sets with first = -(M - 1) / 2: the series from c_0 and c_f +- c_f^T (half the FMAs)
 };
 
 
@@ -1857,7 +1858,10 @@ __global__ __launch_bounds__(256, (TRI && !VEC) ? 2 : 1) void gen_grid_eig_kerne
     if (fm < 0) fm += a.npt;
     for (int64_t line = blockIdx.x; line < a.nlines; line += gridDim.x) {
         __syncthreads();
-        panel_stage<NP, PAD>(coef, a.src + line * ((int64_t)M * nn), n, M);
+        if (PAD && a.fold)
+            panel_stage_fold<NP>(coef, a.src + line * ((int64_t)M * nn), n, M, 0.0, 0.0);
+        else
+            panel_stage<NP, PAD>(coef, a.src + line * ((int64_t)M * nn), n, M);
         __syncthreads();
         // nodes of this coefficient set: the whole grid line, or its run of an irregular (symmetric-rule) list
         const int64_t kbase = a.run_start ? a.run_start[line] : line * a.npt;
@@ -1875,10 +1879,13 @@ __global__ __launch_bounds__(256, (TRI && !VEC) ? 2 : 1) void gen_grid_eig_kerne
                 const int ic = a.gi ? a.gi[kbase + ii] : ii;
                 const double2 z = a.tab[ic];
                 const double2 w = a.tab[(int)(((unsigned)fm * (unsigned)ic) % (unsigned)a.npt)];
-                panel_series_row<NP, PAD>(coef, n, M, z.x, z.y, w.x, w.y, r, hr, hi);  // row r of -H(k)
+                if (PAD && a.fold)
+                    panel_series_row_fold<NP>(coef, M, z.x, z.y, r, hr, hi);  // row r of -H(k) (its padding diagonal: 1)
+                else
+                    panel_series_row<NP, PAD>(coef, n, M, z.x, z.y, w.x, w.y, r, hr, hi);  // row r of -H(k)
 #pragma unroll
                 for (int j = 0; j < NP; ++j) {
-                    const bool real = PAD || (r < n && j < n);
+                    const bool real = (PAD && !a.fold) || (r < n && j < n);
                     hr[j] = real ? -hr[j] : 0.0;
                     hi[j] = real ? -hi[j] : 0.0;
                 }
@@ -2165,6 +2172,7 @@ static int launch_gen_grid_eig(abz_ctx* ctx, const GenSpec& gs, int np, size_t l
     a.first = gs.first;
     a.npt = gs.npt;
     a.herm = gs.herm ? 1 : 0;
+    a.fold = (gs.herm && pad && (gs.M & 1) && gs.first == -((gs.M - 1) / 2) && abz_switch(SW_EIG_FOLD) != 0) ? 1 : 0;
     const int64_t blocks = std::min<int64_t>(a.nlines, 256 * 4);
     const bool vec = gs.Uplanes.base != nullptr;
     // eigenvalues without eigenvectors: the tridiagonals go through scratch to tri_eig_kernel (ABZ_EIG_SPLIT=0: bisection
