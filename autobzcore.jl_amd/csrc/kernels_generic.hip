@@ -1331,9 +1331,21 @@ __device__ __forceinline__ void hh_step(int n, int r, double (&ar)[NP], double (
             // v = x + phase ||x|| e_1 (no cancellation), beta = 2 / ||v||^2 = 1 / (||x|| (||x|| + |x_1|)); sigma = 0: beta = 0, a
             // no-op.  With s = ||x|| |x_1| = sqrt(sigma |x_1|^2):  v_1 = x_1 (1 + s / |x_1|^2),  1 / beta = sigma + s -- one
             // square root per step; x_1 = 0 (v_1 = ||x||) takes a second one under a uniform branch.
+            // (the square root and the two reciprocals by estimate + Newton: these scalars sit on the critical path of a
+            // step that has two waves per SIMD to hide behind; magnitudes outside [1e-140, 1e140] take the library routines)
             const double a1sq = x1r * x1r + x1i * x1i;
-            const double sx = sqrt(sigma * a1sq);
-            const double fac = a1sq > 0.0 ? 1.0 + sx / a1sq : 0.0;
+            const double y = sigma * a1sq;
+            double sx, fac, beta;
+            if (!__any(!(a1sq >= 1e-140 && sigma <= 1e140))) {
+                sx = y * rsqrt_nr(y);
+                fac = fma(sx, rcp_nr(a1sq), 1.0);
+                beta = rcp_nr(sigma + sx);
+            } else {
+                sx = sqrt(y);
+                fac = a1sq > 0.0 ? 1.0 + sx / a1sq : 0.0;
+                const double den = sigma + sx;
+                beta = den > 0.0 ? 1.0 / den : 0.0;
+            }
             double v1r = x1r * fac, v1i = x1i * fac;
             if (__any(a1sq == 0.0 && sigma > 0.0)) {
                 const double nrm = sqrt(sigma);
@@ -1341,8 +1353,6 @@ __device__ __forceinline__ void hh_step(int n, int r, double (&ar)[NP], double (
                 v1i = a1sq == 0.0 ? 0.0 : v1i;
             }
             const double vr = (r == K + 1) ? v1r : xr, vi = (r == K + 1) ? v1i : xi;
-            const double den = sigma + sx;
-            const double beta = den > 0.0 ? 1.0 / den : 0.0;
             double vjr[NP], vji[NP];
             double pr = 0.0, pi = 0.0;  // p_r = beta sum_{j > K} A[r][j] v_j
             hh_cols_p<NP, K>(ar, ai, vr, vi, vjr, vji, pr, pi, std::make_integer_sequence<int, NP - K - 1>());
@@ -2072,10 +2082,17 @@ __global__ __launch_bounds__(64) void tri_eig_kernel(const double* __restrict__ 
             if (L > 0) {
                 --budget;
                 // shift: the eigenvalue of the bottom 2 x 2 closer to d_L
-                const double rte = sqrt(eb);
-                double sg = (dm - dL) / (2.0 * rte);
-                const double rr = sqrt(fma(sg, sg, 1.0));
-                sg = dL - rte / (sg + copysign(rr, sg));
+                double sg;
+                if (!__any(!(eb >= 1e-140 && eb <= 1e140 && fabs(dm - dL) <= 1e30))) {  // (estimate + Newton, as in the sweep)
+                    const double irte = rsqrt_nr(eb), rte = eb * irte;
+                    const double s0 = 0.5 * (dm - dL) * irte;
+                    const double w = fma(s0, s0, 1.0);
+                    sg = dL - rte * rcp_nr(s0 + copysign(w * rsqrt_nr(w), s0));
+                } else {
+                    const double rte = sqrt(eb);
+                    const double s0 = (dm - dL) / (2.0 * rte);
+                    sg = dL - rte / (s0 + copysign(sqrt(fma(s0, s0, 1.0)), s0));
+                }
                 // The sweep: ~35 instructions per rotation on the common path -- ONE reciprocal (estimate + Newton) of r p
                 // serves c = p / r, s = b / r and 1 / c = r / p; the next step's two LDS reads are issued before this step's
                 // arithmetic, unconditionally (rows NP, NP + 1 of the arrays exist for that); LAPACK's special cases
