@@ -56,6 +56,7 @@ enum Switch {
     SW_IAI_PANELS,       // ABZ_IAI_PANELS      level above the innermost: panels, not nodes, cross PCIe (0: nodes)
     SW_IAI_STATS,        // ABZ_IAI_STATS       per-solve statistics of the IAI driver on stderr
     SW_HOST_THREADS,     // ABZ_HOST_THREADS    host threads for the per-integral bookkeeping of IAI sweeps
+    SW_AUTO_SWEEP_MAPPED,  // ABZ_AUTO_SWEEP_MAPPED  AutoPTR solves of <= 8 values: swept values read from pinned host memory
     SW_EIG_FOLD,         // ABZ_EIG_FOLD        5...16-band rule builds of Hermitian series: folded level-1 series
     SW_EIG_SPLIT,        // ABZ_EIG_SPLIT       5...16-band eigenvalue builds: tridiagonal eigenvalues in a kernel of their own
     SW_IAI_LANES,        // ABZ_IAI_LANES       lanes (host thread + stream each) an IAI sweep is split over
@@ -202,6 +203,8 @@ struct abz_series {
     std::vector<abz::SeriesRule> kept_rules;  // rules of abz_autoptr_solve*, most recently used last
     uint64_t kept_stamp = 0;
     std::vector<int> summed_once;             // full grids beyond `keepmost` that were summed on the fly once already
+    uint64_t auto_hint_key = 0;               // the last abz_autoptr_solve* call's sequence / integrand ...
+    int auto_hint_grids = 0;                  // ... and how many grids it needed (scans launched ahead next time)
     abz::DevBuf auto_io;                      // swept values in / sums out of abz_autoptr_solve*
     void* auto_pin = nullptr;                 // ... and their pinned, device-visible host block (zero-copy results)
     void* auto_pin_dev = nullptr;
