@@ -84,6 +84,7 @@ void dev_free(void* p, size_t cap);
 struct DevBuf {
     void* p = nullptr;
     size_t cap = 0;
+    bool view = false;  // p points into a block owned elsewhere (release only forgets it)
     int reserve(size_t bytes);
     void release();
     template <class T>
@@ -116,6 +117,7 @@ struct SymTables {
     int64_t nk = 0;
     int64_t nitems[ABZ_MAX_DIM + 1] = {0, 0, 0, 0};
     DevBuf arena;                    // one allocation; the tables below are views into it
+    size_t arena_bytes = 0;          // its used length (a rule takes its own copy of the tables with ONE device copy)
     int32_t* idx = nullptr;          // [d][nk]
     double* w = nullptr;             // [nk]
     int32_t* gi[ABZ_MAX_DIM + 1] = {nullptr, nullptr, nullptr, nullptr};      // [0] i_1 of the nodes, [L] i_{L+1} of the level-L items
@@ -236,6 +238,7 @@ struct abz_rule {
     double* w = nullptr;   // [nk] weights (symmetric rules)
     int32_t* idx = nullptr;  // [d][nk] grid indices (symmetric rules)
     void* plan = nullptr;    // abz::RulePlan (api.cpp): contraction plan + phase table, device resident
+    bool tables_view = false;  // w and idx point into the plan's copy of the symmetric-rule tables
 };
 
 namespace abz {

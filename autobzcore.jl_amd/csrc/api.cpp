@@ -233,7 +233,7 @@ int stage_d2h(abz_ctx* ctx, void* dst, const void* src, size_t bytes) {
 }
 
 int DevBuf::reserve(size_t bytes) {
-    if (bytes <= cap) return ABZ_OK;
+    if (!view && bytes <= cap) return ABZ_OK;
     release();
     const size_t want = bytes + (bytes >> 2) + 256;  // grow geometrically
     int rc = dev_alloc(&p, want, &cap);
@@ -246,9 +246,10 @@ int DevBuf::reserve(size_t bytes) {
 }
 
 void DevBuf::release() {
-    dev_free(p, cap);
+    if (!view) dev_free(p, cap);
     p = nullptr;
     cap = 0;
+    view = false;
 }
 
 ProfScope::ProfScope(abz_ctx* c, int kernel_id) : ctx(c), id(kernel_id) {
@@ -395,8 +396,10 @@ struct PlanDev {
     DevBuf gi[ABZ_MAX_DIM + 1], xs[ABZ_MAX_DIM + 1], parent[ABZ_MAX_DIM + 1];
     DevBuf phg[ABZ_MAX_DIM + 1];  // full grids: phase table [npt][M_{L+1}] of the contraction at level L
     DevBuf runs;                  // irregular lists: run_start
+    DevBuf arena;                 // symmetric rules: the copy of the cached tables that gi / parent / runs (and the rule's w, idx) point into
     void release() {
         runs.release();
+        arena.release();
         for (int i = 0; i <= ABZ_MAX_DIM; ++i) {
             gi[i].release();
             xs[i].release();
@@ -851,8 +854,10 @@ struct RulePlan {
 static void rule_free(abz_rule* r) {
     if (!r) return;
     dev_free(r->vals, r->vals_cap);
-    dev_free(r->w, r->w_cap);
-    dev_free(r->idx, r->idx_cap);
+    if (!r->tables_view) {
+        dev_free(r->w, r->w_cap);
+        dev_free(r->idx, r->idx_cap);
+    }
     if (r->plan) {
         RulePlan* rp = static_cast<RulePlan*>(r->plan);
         rp->pd.release();
@@ -1016,7 +1021,7 @@ static int rule_fill(abz_rule* r) {
     } while (0)
 
 static int rule_build(abz_series* s, int npt, int64_t nirr, const int32_t* irr_idx, const int64_t* wsym, int want,
-                      int outer0, int outer_n, abz_rule** out, const SymTables* st = nullptr) {
+                      int outer0, int outer_n, abz_rule** out, const SymTables* st = nullptr, bool wait = true) {
     int rc = check_series(s);
     if (rc) return rc;
     ABZ_REQUIRE(out, "null out");
@@ -1092,21 +1097,23 @@ static int rule_build(abz_series* s, int npt, int64_t nirr, const int32_t* irr_i
     // no better in the real kernel; PlaneView still carries both strides)
     const int64_t tile = (int64_t)r->planes * pitch;
     const int pstride = pitch;  // plane to plane
-    if (st) {  // device-to-device copies of the cached tables: the rule owns its plan like any other
-        auto d2d = [&](DevBuf& dst, const void* src, size_t bytes) -> int {
-            if (bytes == 0) return ABZ_OK;
-            int rc_ = dst.reserve(bytes);
-            if (rc_) return rc_;
-            ABZ_HIP(hipMemcpyAsync(dst.p, src, bytes, hipMemcpyDeviceToDevice, ctx->stream));
-            return ABZ_OK;
+    if (st) {  // ONE device-to-device copy of the cached tables (a single block): the rule owns its plan like any other
+        RULE_TRY(rp->pd.arena.reserve(st->arena_bytes));
+        RULE_HIP(hipMemcpyAsync(rp->pd.arena.p, st->arena.p, st->arena_bytes, hipMemcpyDeviceToDevice, ctx->stream));
+        auto at = [&](const void* q) -> void* { return static_cast<char*>(rp->pd.arena.p) + (static_cast<const char*>(q) - static_cast<const char*>(st->arena.p)); };
+        auto view = [&](DevBuf& b, const void* q) {
+            b.release();
+            b.p = at(q);
+            b.view = true;
         };
-        RULE_TRY(d2d(rp->pd.gi[0], st->gi[0], sizeof(int32_t) * (size_t)st->nk));
-        RULE_TRY(d2d(rp->pd.parent[0], st->parent[0], sizeof(int64_t) * (size_t)st->nk));
-        for (int L = 1; L < d; ++L) {
-            RULE_TRY(d2d(rp->pd.gi[L], st->gi[L], sizeof(int32_t) * (size_t)st->nitems[L]));
-            RULE_TRY(d2d(rp->pd.parent[L], st->parent[L], sizeof(int64_t) * (size_t)st->nitems[L]));
+        for (int L = 0; L < d; ++L) {
+            view(rp->pd.gi[L], st->gi[L]);
+            view(rp->pd.parent[L], st->parent[L]);
         }
-        if (d >= 2) RULE_TRY(d2d(rp->pd.runs, st->runs, sizeof(int64_t) * (size_t)(st->nitems[1] + 1)));
+        if (d >= 2) view(rp->pd.runs, st->runs);
+        r->w = static_cast<double*>(at(st->w));
+        r->idx = static_cast<int32_t*>(at(st->idx));
+        r->tables_view = true;
     } else {
         RULE_TRY(plan_upload(ctx, plan, rp->pd));
     }
@@ -1160,10 +1167,7 @@ static int rule_build(abz_series* s, int npt, int64_t nirr, const int32_t* irr_i
     r->E = mkview(pH, pE > 0);
     r->V = mkview(pH + pE, pV > 0);
     if (st) {
-        RULE_TRY(dev_alloc((void**)&r->w, sizeof(double) * (size_t)st->nk, &r->w_cap));
-        RULE_HIP(hipMemcpyAsync(r->w, st->w, sizeof(double) * (size_t)st->nk, hipMemcpyDeviceToDevice, ctx->stream));
-        RULE_TRY(dev_alloc((void**)&r->idx, sizeof(int32_t) * (size_t)(st->nk * d), &r->idx_cap));
-        RULE_HIP(hipMemcpyAsync(r->idx, st->idx, sizeof(int32_t) * (size_t)(st->nk * d), hipMemcpyDeviceToDevice, ctx->stream));
+        // (w and idx came with the plan's copy of the tables)
     } else if (!r->full) {
         std::vector<double> wd(std::max<int64_t>(nirr, 1));
         for (int64_t k = 0; k < nirr; ++k) wd[k] = (double)wsym[k];
@@ -1182,7 +1186,9 @@ static int rule_build(abz_series* s, int npt, int64_t nirr, const int32_t* irr_i
     }
     lap("alloc+w/idx");
     RULE_TRY(rule_fill(r));
-    RULE_HIP(hipStreamSynchronize(ctx->stream));
+    // the C-ABI hands out a finished rule (a client may read its values from another stream); the library's own solve
+    // loops (series_rule) keep going: the scan of the rule is ordered behind its fill on the context's stream
+    if (wait || dbg) RULE_HIP(hipStreamSynchronize(ctx->stream));
     lap("fill");
     if (want & ABZ_WANT_VEL) {  // keep the big temporaries only while a rebuild needs them
         rp->tmpU.release();
@@ -1200,7 +1206,11 @@ int abz_ptr_rule_build(abz_series* s, int npt, int64_t nirr, const int32_t* irr_
     return rule_build(s, npt, nirr, irr_idx, wsym, want, 0, npt, out);
 }
 
+static int rule_build_sym(abz_series* s, int npt, const int32_t* syms, int nsyms, int want, abz_rule** out, bool wait);
 int abz_ptr_rule_build_sym(abz_series* s, int npt, const int32_t* syms, int nsyms, int want, abz_rule** out) {
+    return rule_build_sym(s, npt, syms, nsyms, want, out, true);
+}
+static int rule_build_sym(abz_series* s, int npt, const int32_t* syms, int nsyms, int want, abz_rule** out, bool wait) {
     int rc = check_series(s);
     if (rc) return rc;
     ABZ_REQUIRE(out && syms && nsyms >= 1 && npt >= 1, "abz_ptr_rule_build_sym: bad arguments");
@@ -1240,7 +1250,7 @@ int abz_ptr_rule_build_sym(abz_series* s, int npt, const int32_t* syms, int nsym
         delete old;
     }
     ABZ_REQUIRE(st->nk > 0, "the symmetry set leaves no node");
-    return rule_build(s, npt, 0, nullptr, nullptr, want, 0, npt, out, st);
+    return rule_build(s, npt, 0, nullptr, nullptr, want, 0, npt, out, st, wait);
 }
 
 int abz_ptr_rule_build_slab(abz_series* s, int npt, int outer_begin, int outer_end, int want, abz_rule** out) {
@@ -1516,7 +1526,7 @@ static int series_rule(abz_series* s, int npt, const int32_t* syms, int nsyms, i
         return ABZ_OK;
     }
     abz_rule* r = nullptr;
-    int rc = syms ? abz_ptr_rule_build_sym(s, npt, syms, nsyms, want, &r) : rule_build(s, npt, 0, nullptr, nullptr, want, 0, npt, &r);
+    int rc = syms ? rule_build_sym(s, npt, syms, nsyms, want, &r, false) : rule_build(s, npt, 0, nullptr, nullptr, want, 0, npt, &r, nullptr, false);
     if (rc) return rc;
     s->refs -= 1;  // owned by the series or by the caller of this function: no reference cycle
     if (keep) {

@@ -523,6 +523,7 @@ int sym_tables_device(abz_ctx* ctx, int npt, int d, const int32_t* syms, int nsy
             st.release();
             return rc;
         }
+        st.arena_bytes = p_end;
         char* const ab = static_cast<char*>(st.arena.p);
         st.idx = reinterpret_cast<int32_t*>(ab + p_idx);
         st.w = reinterpret_cast<double*>(ab + p_w);
