@@ -1419,7 +1419,7 @@ __device__ __forceinline__ double rows_eigvals_tridiag(int n, int r, double (&ar
     // count of eigenvalues below x and the value p_n(x) of the characteristic polynomial (free: the last minor).  The
     // signs of the minors are shifted into one word (v_alignbit_b32: one instruction per step) and their changes counted
     // at the end: 4 instructions per step (subtract, multiply, FMA, shift)
-    const unsigned smask = ((1u << n) - 1u) >> 1;  // n - 1 neighbouring pairs of n signs (n <= 16)
+    const unsigned smask = n >= 32 ? 0x7fffffffu : ((1u << n) - 1u) >> 1;  // n - 1 neighbouring pairs of n signs
     auto sturm = [&](double x, int& cnt, double& pv) {
         double pm = 1.0, p = ds[0] - x;
         unsigned bits = (unsigned)__double2hiint(p) >> 31;
@@ -1511,7 +1511,7 @@ struct GenSumTriArgs {
     int64_t nlines;
     int n, M, first, npt, nw, is_dos;
     double eta;
-    double sweep[16];
+    double sweep[32];
 };
 
 template <int NP, bool PAD>
@@ -1526,7 +1526,7 @@ __global__ __launch_bounds__(256) void gen_grid_sum_tri_kernel(GenSumTriArgs a) 
     if (fm < 0) fm += a.npt;
     double mysw = 0.0;  // this lane's swept value (lane r of the node takes value r)
 #pragma unroll
-    for (int q = 0; q < 16; ++q) mysw = (q == r) ? a.sweep[q] : mysw;
+    for (int q = 0; q < NP; ++q) mysw = (q == r) ? a.sweep[q] : mysw;
     const bool lane_act = r < a.nw;
     double accr = 0.0, acci = 0.0;
     for (int64_t line = blockIdx.x; line < a.nlines; line += gridDim.x) {
@@ -1608,23 +1608,24 @@ __global__ __launch_bounds__(256) void gen_grid_sum_tri_kernel(GenSumTriArgs a) 
     }
 }
 
-// sweeps of at least 3 values on 5..16 bands take the tridiagonal route
+// sweeps of at least 3 values on 5..32 bands take the tridiagonal route
 static bool gen_sum_tri_wanted(const SumSpec& ss) {
-    return abz_switch(SW_GEN_SUM_TRI) && ss.n > 4 && ss.n <= 16 && ss.n_sweep >= 3;
+    // (17...32 bands, two nodes per wave: the tridiagonal route wins for a single value as well -- 0.9 against 4.2 ms at 32^3)
+    return abz_switch(SW_GEN_SUM_TRI) && ss.n > 4 && ss.n <= 32 && (ss.n_sweep >= 3 || ss.n > 16);
 }
 
 static int launch_gen_sum_tri(abz_ctx* ctx, const SumSpec& ss, double* out_reim) {
     const int n = ss.n, M = ss.M;
-    const int np = n <= 8 ? 8 : 16;
+    const int np = n <= 8 ? 8 : (n <= 16 ? 16 : 32);
     const size_t rest = sizeof(double2) * (size_t)256;  // [SLOTS][NP] partial sums
     size_t lds = sizeof(double2) * (size_t)M * np * np + rest;
     const bool pad = lds <= 150 * 1024;
     if (!pad) lds = sizeof(double2) * (size_t)M * n * n + rest;
     if (lds > 150 * 1024) return ABZ_ERR_UNSUPPORTED;
     const int64_t blocks = std::min<int64_t>(ss.nlines, 256 * 4);
-    int rc = ctx->scratch[1].reserve(sizeof(double2) * (size_t)(blocks * 16));
+    int rc = ctx->scratch[1].reserve(sizeof(double2) * (size_t)(blocks * 32));
     if (rc) return rc;
-    if ((rc = ctx->scratch[2].reserve(sizeof(double2) * 16))) return rc;
+    if ((rc = ctx->scratch[2].reserve(sizeof(double2) * 32))) return rc;
     GenSumTriArgs a;
     a.src = ss.src;
     a.tab = ss.tab;
@@ -1638,10 +1639,18 @@ static int launch_gen_sum_tri(abz_ctx* ctx, const SumSpec& ss, double* out_reim)
     a.eta = ss.params[0];
     for (int s0 = 0; s0 < ss.n_sweep; s0 += np) {
         a.nw = std::min(np, ss.n_sweep - s0);
-        for (int q = 0; q < 16; ++q) a.sweep[q] = q < a.nw ? ss.sweep_host[s0 + q] : 0.0;
+        for (int q = 0; q < 32; ++q) a.sweep[q] = q < a.nw ? ss.sweep_host[s0 + q] : 0.0;
         {
             ProfScope ps(ctx, ABZ_K_EVAL);
-            if (np == 8) {
+            if (np == 32) {  // 17...32 bands: two nodes per wave
+                if (pad) {
+                    ABZ_HIP(hipFuncSetAttribute((const void*)gen_grid_sum_tri_kernel<32, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                    hipLaunchKernelGGL((gen_grid_sum_tri_kernel<32, true>), dim3((unsigned)blocks), dim3(256), lds, ctx->stream, a);
+                } else {
+                    ABZ_HIP(hipFuncSetAttribute((const void*)gen_grid_sum_tri_kernel<32, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                    hipLaunchKernelGGL((gen_grid_sum_tri_kernel<32, false>), dim3((unsigned)blocks), dim3(256), lds, ctx->stream, a);
+                }
+            } else if (np == 8) {
                 if (pad) {
                     ABZ_HIP(hipFuncSetAttribute((const void*)gen_grid_sum_tri_kernel<8, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
                     hipLaunchKernelGGL((gen_grid_sum_tri_kernel<8, true>), dim3((unsigned)blocks), dim3(256), lds, ctx->stream, a);
@@ -1854,12 +1863,12 @@ static bool launch_gen_velocity_rows(abz_ctx* ctx, int n, PlaneView U, PlaneView
 // TRI: eigenvalues only by Householder + Sturm bisection (its own instance: the Jacobi path of the same kernel costs
 // it 90 more registers and the second wave per SIMD)
 template <int NP, bool PAD, bool VEC, bool TRI>
-__global__ __launch_bounds__(256, (TRI && !VEC) ? 2 : 1) void gen_grid_eig_kernel(GenEigArgs a) {
+__global__ __launch_bounds__(256, (TRI && !VEC && NP <= 16) ? 2 : 1) void gen_grid_eig_kernel(GenEigArgs a) {
     static_assert(!(VEC && TRI) || PAD, "inverse iteration works on the zero-padded layout");
     extern __shared__ double2 lds_ge[];
     constexpr int SLOTS = 256 / NP;
     constexpr int TS = SLOTS + 1;        // tile row stride (doubles): one bank further per plane
-    constexpr int PC = NP == 16 ? 144 : 64;  // planes per tile pass: columns 0...11 of 16 rows (16 nodes) / all 64 of 8 rows (32 nodes)
+    constexpr int PC = NP == 32 ? 176 : (NP == 16 ? 144 : 64);  // planes per tile pass: columns 0...11 of 16 rows (16 nodes) / all 64 of 8 rows (32 nodes) / at most 171 of 32 rows (8 nodes)
     const int n = a.n, nn = n * n, M = a.M;
     double2* coef = lds_ge;
     double* const tile = reinterpret_cast<double*>(coef + (size_t)M * (PAD ? NP * NP : nn));  // [PC][TS]
@@ -1945,7 +1954,15 @@ __global__ __launch_bounds__(256, (TRI && !VEC) ? 2 : 1) void gen_grid_eig_kerne
                     }
                     __syncthreads();
                 };
-                if constexpr (NP == 16) {
+                if constexpr (NP == 32) {  // 17...32 bands: seven passes of <= 171 planes
+                    pass(std::integral_constant<int, 0>{}, std::integral_constant<int, 12>{});
+                    pass(std::integral_constant<int, 12>{}, std::integral_constant<int, 17>{});
+                    pass(std::integral_constant<int, 17>{}, std::integral_constant<int, 21>{});
+                    pass(std::integral_constant<int, 21>{}, std::integral_constant<int, 24>{});
+                    pass(std::integral_constant<int, 24>{}, std::integral_constant<int, 27>{});
+                    pass(std::integral_constant<int, 27>{}, std::integral_constant<int, 30>{});
+                    pass(std::integral_constant<int, 30>{}, std::integral_constant<int, 32>{});
+                } else if constexpr (NP == 16) {
                     pass(std::integral_constant<int, 0>{}, std::integral_constant<int, 12>{});
                     pass(std::integral_constant<int, 12>{}, std::integral_constant<int, 16>{});
                 } else {
@@ -1992,7 +2009,7 @@ __global__ __launch_bounds__(256, (TRI && !VEC) ? 2 : 1) void gen_grid_eig_kerne
                         a.tri[(int64_t)r * a.tri_nk + k] = dr;
                         a.tri[(int64_t)(NP + r) * a.tri_nk + k] = er;
                     }
-                } else {
+                } else if constexpr (NP <= 16) {
                     dg = rows_eigvals_tridiag<NP>(n, r, hr, hi);  // Householder + Sturm bisection, lane r gets eigenvalue r
                     rank = r;
                 }
@@ -2154,9 +2171,11 @@ static bool gen_grid_eig_supported(const GenSpec& gs, int* np_out, size_t* lds_o
     if (!(gs.grid || runs) || gs.deriv || gs.values || gs.Haos || gs.Eaos || !(gs.Eplanes.base || gs.Hplanes.base)) return false;
     if (gs.Eplanes.base && !gs.herm) return false;  // the Jacobi works on full rows: H(k) must be Hermitian to rounding
     // 9..16 bands with eigenvectors: inverse iteration (needs the zero-padded layout, checked below)
-    if (gs.n <= 4 || gs.n > 16 || gs.npt < 1 || gs.npt >= 65536) return false;
-    const int np = gs.n <= 8 ? 8 : 16;
-    const size_t tile_bytes = sizeof(double) * (size_t)(np == 16 ? 144 : 64) * (size_t)(256 / np + 1);  // the store tile [PC][TS]
+    if (gs.n <= 4 || gs.n > 32 || gs.npt < 1 || gs.npt >= 65536) return false;
+    // 17...32 bands (two nodes per wave): H and eigenvalues -- through the tridiagonal kernel -- only
+    if (gs.n > 16 && (gs.Uplanes.base || (gs.Eplanes.base && abz_switch(SW_EIG_SPLIT) == 0))) return false;
+    const int np = gs.n <= 8 ? 8 : (gs.n <= 16 ? 16 : 32);
+    const size_t tile_bytes = sizeof(double) * (size_t)(np == 32 ? 176 : (np == 16 ? 144 : 64)) * (size_t)(256 / np + 1);  // the store tile [PC][TS]
     size_t lds = sizeof(double2) * (size_t)gs.M * np * np + tile_bytes;
     *pad_out = lds <= 150 * 1024;
     if (!*pad_out) lds = sizeof(double2) * (size_t)gs.M * gs.n * gs.n + tile_bytes;
@@ -2215,6 +2234,8 @@ static int launch_gen_grid_eig(abz_ctx* ctx, const GenSpec& gs, int np, size_t l
     if (!vec) {
         if (np == 8 && pad) ABZ_GE3(8, true, false, true)
         else if (np == 8) ABZ_GE3(8, false, false, true)
+        else if (np == 32 && pad) ABZ_GE3(32, true, false, true)
+        else if (np == 32) ABZ_GE3(32, false, false, true)
         else if (pad) ABZ_GE3(16, true, false, true)
         else ABZ_GE3(16, false, false, true)
     } else if (np == 8) {
@@ -2228,6 +2249,8 @@ static int launch_gen_grid_eig(abz_ctx* ctx, const GenSpec& gs, int np, size_t l
         const unsigned tb = (unsigned)cdiv2(gs.nnodes, 64);
         if (np == 8)
             hipLaunchKernelGGL(tri_eig_kernel<8>, dim3(tb), dim3(64), 0, ctx->stream, a.tri, a.tri_nk, gs.nnodes, gs.n, gs.Eplanes);
+        else if (np == 32)
+            hipLaunchKernelGGL(tri_eig_kernel<32>, dim3(tb), dim3(64), 0, ctx->stream, a.tri, a.tri_nk, gs.nnodes, gs.n, gs.Eplanes);
         else
             hipLaunchKernelGGL(tri_eig_kernel<16>, dim3(tb), dim3(64), 0, ctx->stream, a.tri, a.tri_nk, gs.nnodes, gs.n, gs.Eplanes);
     }

@@ -779,7 +779,7 @@ def test_plain_c_client_of_the_abi(tmp_path):
     assert run.returncode == 0 and "abi_smoke ok" in run.stdout, run.stdout + run.stderr
 
 
-@pytest.mark.parametrize("d,n,npt", [(1, 6, 40), (2, 12, 21), (2, 20, 9), (3, 16, 7)])
+@pytest.mark.parametrize("d,n,npt", [(1, 6, 40), (2, 12, 21), (2, 20, 9), (3, 16, 7), (3, 27, 8)])
 def test_store_free_rule_value_generic_n(abz, d, n, npt):
     """abz_ptr_sum for 5..32 bands (gen_grid_sum_kernel): equals the reduction of the materialised rule, for
     sweeps longer than one launch (4 values) and through the solver, which prefers it for n > 4."""
@@ -811,6 +811,30 @@ def test_store_free_rule_value_generic_n(abz, d, n, npt):
     full = abz.DeviceRule(dev, npt, None, L.WANT_H)
     ref = full.reduce(L.F_DOS, [0.3], [0.2])[0, 0].real * abs(np.linalg.det(bz.B))
     assert abs(val - ref) <= 1e-12 * abs(ref)
+
+
+def test_store_free_16_band_3d_against_the_oracle(abz):
+    """The route config 5's full-size check leans on (16 bands, 3 variables, store-free PTR: one value by the Gauss-Jordan
+    trace, sweeps by the tridiagonal resolvent) against the ORACLE's PTR at a size beyond the 7^3 of the layout tests:
+    npt = 20 (8 000 nodes) on a random Hermitian series, and the synthetic Wannier model of config 5 itself (2 197 R) at
+    npt = 6."""
+    L = abz._lib
+    rng = np.random.default_rng(4242)
+    c, first = rand_series(rng, (3, 3, 3), 16, hermitian=True)
+    s, so = both(abz, c / 4.0, first)
+    bz, bzo = abz.load_bz(abz.FBZ(), np.eye(3)), orc.load_bz("FBZ", np.eye(3))
+    om = [-0.7, 0.0, 0.4, 1.1, 1.9]
+    got1 = s.device().ptr_sum(20, L.F_DOS, [0.1], om[:1])[:, 0].real
+    got5 = s.device().ptr_sum(20, L.F_DOS, [0.1], om)[:, 0].real
+    for i, w in enumerate(om):
+        ref = orc.solve_ptr(so, bzo, orc.f_dos(0.1, w), npt=20).u / abs(np.linalg.det(bzo.B))
+        assert abs(got5[i] - ref) <= 1e-11 * abs(ref), (w, got5[i], ref)
+        if i == 0:
+            assert abs(got1[0] - ref) <= 1e-11 * abs(ref)
+    sw, swo = abz.synthetic_wannier(), orc.synthetic_wannier()
+    got = sw.device().ptr_sum(6, L.F_DOS, [0.05], [0.2])[0, 0].real
+    ref = orc.solve_ptr(swo, bzo, orc.f_dos(0.05, 0.2), npt=6).u / abs(np.linalg.det(bzo.B))
+    assert abs(got - ref) <= 1e-11 * abs(ref)
 
 
 @pytest.mark.parametrize("n,eta", [(16, 0.05), (11, 0.3), (6, 0.01)])
@@ -857,7 +881,7 @@ def test_store_free_sweep_by_tridiagonal_resolvent(abz, monkeypatch, n, eta):
 
 
 # ------------------------------------------------------------------ generic n (wave-per-node kernels)
-@pytest.mark.parametrize("d,n", [(1, 5), (2, 8), (3, 6), (3, 16)])
+@pytest.mark.parametrize("d,n", [(1, 5), (2, 8), (3, 6), (3, 16), (2, 17), (3, 24), (2, 32)])
 def test_generic_n_eval_and_rules(abz, d, n):
     rng = np.random.default_rng(1000 + 10 * d + n)
     dims = (3, 5, 3)[:d]
@@ -892,9 +916,9 @@ def test_generic_n_eval_and_rules(abz, d, n):
         assert np.abs(g[i].reshape(n, n).T - G).max() <= 1e-10 * np.abs(G).max()
 
 
-@pytest.mark.parametrize("n3,copies", [(3, 2), (5, 3), (2, 8)])
+@pytest.mark.parametrize("n3,copies", [(3, 2), (5, 3), (2, 8), (3, 7), (4, 8)])
 def test_generic_n_eigenvalues_degenerate_and_diagonal(abz, n3, copies):
-    """The row-layout Jacobi of rule builds for 5..16 bands on exactly degenerate spectra (block-diagonal copies of
+    """The eigenvalue builds of rules for 5..32 bands (Householder in the row layout + the per-lane QR kernel) on exactly degenerate spectra (block-diagonal copies of
     one series: every eigenvalue `copies`-fold) and on an already diagonal H(k)."""
     rng = np.random.default_rng(31 + n3)
     c3, first = rand_series(rng, (3, 5), n3, hermitian=True)
@@ -1274,6 +1298,12 @@ def test_autoptr_loop_inside_the_library(abz, kind, d, monkeypatch):
     solver = abz.IntegralSolver(f, bz, abz.EvalCounter(alg), abstol=tol)
     batch = abz.batchsolve(solver, np.array(omegas))
     assert all(abs(batch[i] - lib[i].u) <= 1e-13 * abs(lib[i].u) for i in range(len(omegas)))
+    # the same sweep again: the scans of the kept grids beyond the second are launched ahead of the decisions (the solves of
+    # the batch stop at different grids, so the sums launched ahead are picked per active solve) -- the same bits
+    meta = []
+    batch2 = abz.batchsolve(solver, np.array(omegas), callback=lambda s_, i, k, p, sol, t: meta.append((int(np.ravel(i)[0]), sol.numevals, sol.extra["npt"])))
+    assert np.array_equal(np.asarray(batch), np.asarray(batch2))
+    assert sorted(meta) == [(i, lib[i].numevals, lib[i].extra["npt"]) for i in range(len(omegas))]
     # keepmost = 0 (nothing kept: every grid on the fly or built and dropped) and a large one: the same numbers
     for km in (0, 9):
         alg2 = abz.AutoPTR(a=1.0, keepmost=km, **seq)
