@@ -2584,7 +2584,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 4))) voi
 // 256 omega at 16 bands: 4 passes over the rule and ~(4 x 2.5 k + 256 / 16 x 250) instructions per four nodes instead
 // of 64 passes and 256 x 1.3 k.
 template <int NP>
-__global__ __launch_bounds__(256, 2) void gen_rows_reduce_tri_kernel(GenRowsReduceArgs a) {
+__global__ __launch_bounds__(256, NP <= 16 ? 2 : 1) void gen_rows_reduce_tri_kernel(GenRowsReduceArgs a) {
     constexpr int SLOTS = 256 / NP;
     __shared__ double2 red[SLOTS * 4 * NP];
     const int n = a.n;
@@ -2748,8 +2748,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 4))) voi
 }
 
 static bool gen_rows_reduce_supported(const ReduceSpec& rs) {
-    return rs.herm && rs.H.base && rs.n > 4 && rs.n <= 16 &&
-           (rs.integrand == ABZ_F_DOS || rs.integrand == ABZ_F_TRGLOC || rs.integrand == ABZ_F_GLOC);
+    // 17...32 bands (two nodes per wave): resolvent traces through the tridiagonal kernel; matrix-valued scans stay wave-per-node
+    return rs.herm && rs.H.base && rs.n > 4 &&
+           (rs.n <= 16 ? (rs.integrand == ABZ_F_DOS || rs.integrand == ABZ_F_TRGLOC || rs.integrand == ABZ_F_GLOC)
+                       : (rs.n <= 32 && !rs.H.compact && (rs.integrand == ABZ_F_DOS || rs.integrand == ABZ_F_TRGLOC)));
 }
 
 static int launch_gen_rows_gloc(abz_ctx* ctx, const ReduceSpec& rs, double* out_reim) {
@@ -2795,7 +2797,7 @@ static int launch_gen_rows_gloc(abz_ctx* ctx, const ReduceSpec& rs, double* out_
 
 static int launch_gen_rows_reduce(abz_ctx* ctx, const ReduceSpec& rs, double* out_reim) {
     if (rs.integrand == ABZ_F_GLOC) return launch_gen_rows_gloc(ctx, rs, out_reim);
-    const int np = rs.n <= 8 ? 8 : 16;
+    const int np = rs.n <= 8 ? 8 : (rs.n <= 16 ? 16 : 32);
     const int64_t blocks = std::min<int64_t>(cdiv2(rs.nk, 256 / np), 256 * 2);
     int rc = ctx->scratch[1].reserve(sizeof(double2) * (size_t)(blocks * rs.n_sweep));
     if (rc) return rc;
@@ -2813,8 +2815,10 @@ static int launch_gen_rows_reduce(abz_ctx* ctx, const ReduceSpec& rs, double* ou
     double2* outd = ctx->scratch[2].as<double2>();
     {
         ProfScope ps(ctx, ABZ_K_REDUCE);
-        const bool tri = abz_switch(SW_GEN_SUM_TRI) && rs.n_sweep >= 3;  // sweeps: tridiagonalise once, p'/p per swept value
-        if (tri && np == 8)
+        const bool tri = (abz_switch(SW_GEN_SUM_TRI) && rs.n_sweep >= 3) || np == 32;  // sweeps: tridiagonalise once, p'/p per swept value
+        if (np == 32)
+            hipLaunchKernelGGL(gen_rows_reduce_tri_kernel<32>, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, a);
+        else if (tri && np == 8)
             hipLaunchKernelGGL(gen_rows_reduce_tri_kernel<8>, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, a);
         else if (tri)
             hipLaunchKernelGGL(gen_rows_reduce_tri_kernel<16>, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, a);

@@ -4,7 +4,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import numpy as np
 import autobzcore.jl_amd as abz
-for n, rmax, npt in ((6, 2, 24), (8, 2, 24), (16, 3, 24)):
+for n, rmax, npt in ((6, 2, 24), (8, 2, 24), (16, 3, 24), (17, 2, 24), (24, 2, 24)):
     s = abz.synthetic_wannier(n=n, rmax=rmax, seed=7)
     dev = s.device()
     rule = dev.rule(npt, None, want=2 | 4)
