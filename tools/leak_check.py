@@ -36,7 +36,16 @@ for it in range(120):
         abz.IntegralSolver(abz.FourierIntegrand(abz.DOSIntegrand(), s, 0.4), bz, alg, abstol=1e-2)(0.1)
     if it % 10 == 0:
         r = abz.DeviceRule(svo.device(), 150, None, 3); r.rebuild(); r.close()
+    if it % 10 == 5:  # sweep lanes (views of the series on contexts of their own) and the library's AutoPTR loop (kept rules)
+        fi = abz.FourierIntegrand(abz.DOSIntegrand(), s, 0.4)
+        abz.batchsolve(abz.IntegralSolver(fi, bz, abz.IAI(), abstol=1e-2), np.linspace(-1.0, 1.0, 40))
+        # (on the full BZ: the orbit tables of symmetric grids stay in the context's cache of eight by design)
+        abz.IntegralSolver(fi, abz.load_bz(abz.FBZ(), np.eye(d)), abz.AutoPTR(), abstol=1e-2)(0.1)
+        del fi
     del s
+    if os.environ.get("ABZ_LEAK_TRACE"):
+        gc.collect()
+        print(f"  it {it} d={d} n={n} dims={dims}: {lib_mb()}", flush=True)
     if it % 30 == 29:
         gc.collect()
         marks.append(free_gb())
