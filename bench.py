@@ -1096,6 +1096,35 @@ def extras(a, abz, L, s, ctx, out, nk):
         out["bands16_fixed_grids"] = b16
     except Exception as e:
         out["bands16_fixed_grids"] = {"error": str(e)}
+    # 17...32 bands: the same row kernels with two nodes per wave (round 4; wave-per-node kernels before: a 100x step at 17 bands)
+    try:
+        b24 = {}
+        rng24 = np.random.default_rng(24)
+        c24 = rng24.standard_normal((5, 5, 5, 24, 24)) + 1j * rng24.standard_normal((5, 5, 5, 24, 24))
+        c24 = (c24 + np.conj(np.swapaxes(c24[::-1, ::-1, ::-1], -1, -2))) / 24.0
+        s24 = abz.FourierSeries(c24, period=1.0, first=(-2, -2, -2))
+        dev24 = s24.device()
+        r24 = abz.DeviceRule(dev24, 32, None, L.WANT_H | L.WANT_EIG)
+        for _ in range(2):
+            r24.rebuild()
+        dev24.ctx.sync()
+        t0 = time.perf_counter()
+        for _ in range(5):
+            r24.rebuild()
+        dev24.ctx.sync()
+        dt = (time.perf_counter() - t0) / 5
+        b24["rule_32cubed_H_and_eig"] = {"seconds": dt, "kpoints_per_sec": 32**3 / dt, "before_round4_seconds": 0.0548}
+        r24.close()
+        om24 = np.linspace(-1.0, 1.0, 16)
+        dev24.ptr_sum(32, L.F_DOS, [0.05], om24)
+        t0 = time.perf_counter()
+        dev24.ptr_sum(32, L.F_DOS, [0.05], om24)
+        dt = time.perf_counter() - t0
+        b24["store_free_32cubed_16_omega"] = {"seconds": dt, "kpoint_omega_per_sec": 32**3 * 16 / dt, "before_round4_seconds": 0.0650}
+        b24["model"] = "random Hermitian 24-band series, 5^3 coefficients"
+        out["bands24_fixed_grids"] = b24
+    except Exception as e:
+        out["bands24_fixed_grids"] = {"error": str(e)}
 
 
 def main():
