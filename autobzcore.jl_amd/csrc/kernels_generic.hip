@@ -1862,8 +1862,12 @@ static bool launch_gen_velocity_rows(abz_ctx* ctx, int n, PlaneView U, PlaneView
 
 // TRI: eigenvalues only by Householder + Sturm bisection (its own instance: the Jacobi path of the same kernel costs
 // it 90 more registers and the second wave per SIMD)
-template <int NP, bool PAD, bool VEC, bool TRI>
+// SPLIT: the tridiagonals go to tri_eig_kernel (an instance of its own: with the bisection beside it the kernel spilled 33
+// registers)
+template <int NP, bool PAD, bool VEC, bool TRI, bool SPLIT = false>
 __global__ __launch_bounds__(256, (TRI && !VEC && NP <= 16) ? 2 : 1) void gen_grid_eig_kernel(GenEigArgs a) {
+    static_assert(!SPLIT || (TRI && !VEC), "the split build computes eigenvalues only");
+    static_assert(NP <= 16 || SPLIT || !TRI, "17...32 bands: eigenvalues through the tridiagonal kernel");
     static_assert(!(VEC && TRI) || PAD, "inverse iteration works on the zero-padded layout");
     extern __shared__ double2 lds_ge[];
     constexpr int SLOTS = 256 / NP;
@@ -1993,7 +1997,7 @@ __global__ __launch_bounds__(256, (TRI && !VEC && NP <= 16) ? 2 : 1) void gen_gr
                 rank = r;
                 rows_eigvecs_invit<NP>(n, r, lane, hr, hi, dg, vr, vi);
             } else if constexpr (TRI) {  // eigenvalues only
-                if (a.tri) {
+                if constexpr (SPLIT) {
                     // Householder here, the eigenvalues of the tridiagonals in tri_eig_kernel (one LANE per matrix there: a
                     // fraction of the instructions of the bisection below, which keeps 16 lanes busy per matrix)
                     double e2[NP], d[NP];
@@ -2009,7 +2013,7 @@ __global__ __launch_bounds__(256, (TRI && !VEC && NP <= 16) ? 2 : 1) void gen_gr
                         a.tri[(int64_t)r * a.tri_nk + k] = dr;
                         a.tri[(int64_t)(NP + r) * a.tri_nk + k] = er;
                     }
-                } else if constexpr (NP <= 16) {
+                } else {
                     dg = rows_eigvals_tridiag<NP>(n, r, hr, hi);  // Householder + Sturm bisection, lane r gets eigenvalue r
                     rank = r;
                 }
@@ -2017,9 +2021,7 @@ __global__ __launch_bounds__(256, (TRI && !VEC && NP <= 16) ? 2 : 1) void gen_gr
                 rows_eig<NP, VEC>(n, r, lane, hr, hi, vr, vi, dg, rank);
             }
             }
-            if constexpr (TRI && !VEC) {
-                if (a.tri) continue;  // (uniform over the block: no barrier below is skipped by a part of it)
-            }
+            if constexpr (SPLIT) continue;  // (the whole block: no barrier below is skipped by a part of it)
             {  // eigenvalue planes: through the tile as well ([band][node] -> SLOTS consecutive nodes per band)
                 if (wave_on && wr) tile[rank * TS + slot] = dg;
                 __syncthreads();
@@ -2225,17 +2227,23 @@ static int launch_gen_grid_eig(abz_ctx* ctx, const GenSpec& gs, int np, size_t l
     ProfScope ps(ctx, ABZ_K_EVAL);
     // eigenvalues only: Householder + Sturm bisection (TRI); with eigenvectors: the parallel-order Jacobi up to 8 bands,
     // inverse iteration on the zero-padded layout for 9...16 (the 16-row Jacobi with accumulated rotations spilled 4.6 KB)
-#define ABZ_GE3(NPV, PV, VV, TV)                                                                                              \
-    {                                                                                                                         \
-        ABZ_HIP(hipFuncSetAttribute((const void*)gen_grid_eig_kernel<NPV, PV, VV, TV>, hipFuncAttributeMaxDynamicSharedMemorySize, \
-                                    (int)lds));                                                                               \
-        hipLaunchKernelGGL((gen_grid_eig_kernel<NPV, PV, VV, TV>), dim3((unsigned)blocks), dim3(256), lds, ctx->stream, a);   \
+#define ABZ_GE4(NPV, PV, VV, TV, SV)                                                                                              \
+    {                                                                                                                             \
+        ABZ_HIP(hipFuncSetAttribute((const void*)gen_grid_eig_kernel<NPV, PV, VV, TV, SV>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                    (int)lds));                                                                                   \
+        hipLaunchKernelGGL((gen_grid_eig_kernel<NPV, PV, VV, TV, SV>), dim3((unsigned)blocks), dim3(256), lds, ctx->stream, a);   \
     }
-    if (!vec) {
+#define ABZ_GE3(NPV, PV, VV, TV) ABZ_GE4(NPV, PV, VV, TV, false)
+    if (!vec && (split || !gs.Eplanes.base)) {  // (H only: the lean instance as well -- it never reaches the eigenvalue stage)
+        if (np == 8 && pad) ABZ_GE4(8, true, false, true, true)
+        else if (np == 8) ABZ_GE4(8, false, false, true, true)
+        else if (np == 32 && pad) ABZ_GE4(32, true, false, true, true)
+        else if (np == 32) ABZ_GE4(32, false, false, true, true)
+        else if (pad) ABZ_GE4(16, true, false, true, true)
+        else ABZ_GE4(16, false, false, true, true)
+    } else if (!vec) {
         if (np == 8 && pad) ABZ_GE3(8, true, false, true)
         else if (np == 8) ABZ_GE3(8, false, false, true)
-        else if (np == 32 && pad) ABZ_GE3(32, true, false, true)
-        else if (np == 32) ABZ_GE3(32, false, false, true)
         else if (pad) ABZ_GE3(16, true, false, true)
         else ABZ_GE3(16, false, false, true)
     } else if (np == 8) {
@@ -2245,6 +2253,7 @@ static int launch_gen_grid_eig(abz_ctx* ctx, const GenSpec& gs, int np, size_t l
         ABZ_GE3(16, true, true, true)  // gen_grid_eig_supported: pad is set
     }
 #undef ABZ_GE3
+#undef ABZ_GE4
     if (split) {
         const unsigned tb = (unsigned)cdiv2(gs.nnodes, 64);
         if (np == 8)
