@@ -64,6 +64,24 @@ int main(void) {
         fprintf(stderr, "iai_solve: %.17g err %g numevals %lld\n", out[0], err, (long long)nev);
         return 5;
     }
+    /* a sweep of 40 swept values through ONE handle: the library deals them to its lanes (views of the series on streams of
+     * their own, ABZ_IAI_LANES); every result is the one of the solve run alone */
+    {
+        double sw[40], outs[80], errs[40], one[2], e1 = 0.0;
+        int64_t nevs[40], n1 = 0;
+        const double eta[1] = {0.3};
+        for (int i = 0; i < 40; ++i) sw[i] = -0.9 + 0.045 * i;
+        CHECK(abz_iai_solve_many(s, ABZ_LIMS_CUBIC, a, b, ABZ_F_DOS, eta, 1, sw, 40, 1e-8, -1.0, 0, 0, outs, errs, nevs, NULL, 0, NULL));
+        const int probe[3] = {0, 17, 39};
+        for (int k = 0; k < 3; ++k) {
+            const int i = probe[k];
+            CHECK(abz_iai_solve(s, ABZ_LIMS_CUBIC, a, b, ABZ_F_DOS, eta, 1, sw[i], 1e-8, -1.0, 0, 0, one, &e1, &n1, NULL, 0, NULL));
+            if (one[0] != outs[2 * i] || one[1] != outs[2 * i + 1] || e1 != errs[i] || n1 != nevs[i]) {
+                fprintf(stderr, "iai_solve_many[%d]: %.17g vs %.17g, numevals %lld vs %lld\n", i, outs[2 * i], one[0], (long long)nevs[i], (long long)n1);
+                return 7;
+            }
+        }
+    }
     /* AutoPTR: the whole p-adaptive loop in the library (grids 50, 100, ...): twice, the second solve from the kept rules */
     int64_t nev_auto = 0;
     int32_t npt_last = 0;
