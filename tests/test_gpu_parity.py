@@ -916,6 +916,30 @@ def test_generic_n_eval_and_rules(abz, d, n):
         assert np.abs(g[i].reshape(n, n).T - G).max() <= 1e-10 * np.abs(G).max()
 
 
+def test_generic_n_unpadded_32_lane_layout(abz):
+    """17...32 bands with a level-1 set too long for the zero-padded LDS layout (11 coefficients x 32 x 32 x 16 B = 180 KB):
+    the unpadded instances of the 32-lane row kernels -- rule values and eigenvalues against the oracle, the store-free
+    sweep (tridiagonal resolvent) against the scan of the rule."""
+    rng = np.random.default_rng(2024)
+    n, npt = 20, 9
+    c, first = rand_series(rng, (11, 3), n, hermitian=True)
+    s, so = both(abz, c / np.sqrt(n), first)
+    L = abz._lib
+    rule = s.device().rule(npt, None, want=3)
+    out = rule.export(H=True, eig=True)
+    vals = orc.fourier_ptr(so, npt)
+    ref = np.transpose(vals, (1, 0, 2, 3)).reshape(-1, n, n)
+    assert np.abs(out["H"] - ref).max() <= 1e-12 * np.abs(ref).max()
+    assert np.abs(out["eig"] - np.linalg.eigvalsh(ref, UPLO="U")).max() <= 1e-11 * np.abs(ref).max()
+    om = np.linspace(-1.0, 1.0, 5)
+    for fid in (L.F_DOS, L.F_TRGLOC):
+        a = rule.reduce(fid, [0.2], om)
+        b = s.device().ptr_sum(npt, fid, [0.2], om)
+        assert np.abs(a - b).max() <= 1e-12 * np.abs(a).max()
+    r0, _ = orc._ptr_rule_sum(so, npt, None, orc.f_dos(0.2, om[1]))
+    assert abs(rule.reduce(L.F_DOS, [0.2], om)[1, 0].real - r0) <= 1e-10 * abs(r0)
+
+
 @pytest.mark.parametrize("n3,copies", [(3, 2), (5, 3), (2, 8), (3, 7), (4, 8)])
 def test_generic_n_eigenvalues_degenerate_and_diagonal(abz, n3, copies):
     """The eigenvalue builds of rules for 5..32 bands (Householder in the row layout + the per-lane QR kernel) on exactly degenerate spectra (block-diagonal copies of
