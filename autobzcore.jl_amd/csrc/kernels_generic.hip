@@ -819,6 +819,10 @@ __device__ __forceinline__ void panel_trace(const double (&ar)[NP], const double
     }
 }
 
+template <int NP>
+__device__ __forceinline__ void rows_trace_resolvent_tri(int n, int r, double (&hr)[NP], double (&hi)[NP], double sw, double eta, double& tr,
+                                                         double& ti);  // (defined with the Householder code below)
+
 template <int NP, bool PAD>
 __global__ __launch_bounds__(256) void gen_panel_kernel(GenArgs a) {
     extern __shared__ double2 lds_p[];
@@ -838,6 +842,30 @@ __global__ __launch_bounds__(256) void gen_panel_kernel(GenArgs a) {
             const bool act = q < 15;
             const int64_t k = node0 + (act ? q : 0);
             const double sw = a.sweep_per_node ? a.sweep_per_node[k] : a.sweep0;
+            if constexpr (NP == 32) {
+                if (a.integrand != ABZ_F_GLOC) {  // (uniform) 17...32 bands, traces: from the tridiagonal form, see rows_trace_resolvent_tri
+                    double hr[NP], hi[NP];
+                    double zr, zi, pr, pi, tr, ti;
+                    const double xx = a.x[k] * a.inv_period;
+                    sincospi(2.0 * xx, &zi, &zr);
+                    sincospi(2.0 * ((double)a.first * xx), &pi, &pr);
+                    panel_series_row<NP, PAD>(coef, n, M, zr, zi, pr, pi, r, hr, hi);
+                    if (!PAD) {
+#pragma unroll
+                        for (int j = 0; j < NP; ++j) {
+                            const bool real = r < n && j < n;
+                            hr[j] = real ? hr[j] : 0.0;
+                            hi[j] = real ? hi[j] : 0.0;
+                        }
+                    }
+                    rows_trace_resolvent_tri<NP>(n, r, hr, hi, sw, a.p[0], tr, ti);
+                    if (act && r == 0)
+                        a.values[k * a.ncomp] = (a.integrand == ABZ_F_DOS)
+                                                    ? make_double2(-ti * 0.31830988618379067153776752674503, 0.0)
+                                                    : make_double2(tr, ti);
+                    continue;
+                }
+            }
             double ar[NP], ai[NP];
             panel_inverse_row<NP, PAD>(coef, n, M, a.first, a.x[k] * a.inv_period, sw, a.p[0], r, ar, ai);
             if (a.integrand == ABZ_F_GLOC) {
@@ -1493,6 +1521,54 @@ __device__ __forceinline__ double rows_eigvals_tridiag(int n, int r, double (&ar
     return 0.5 * (lo + hi) * span;
 }
 
+
+// tr inv((sw + i eta) I - H) of the Hermitian matrix whose NEGATED row r this lane holds (hr, hi = row r of -H; rows /
+// columns >= n: zero): Householder tridiagonalisation, then p'(z) / p(z) by the three-term recurrence of the tridiagonal
+// (see the sweep kernel below, which runs the same recurrence for many values).  Every lane of the node gets the trace.
+// The 32-lane instances of the IAI kernels use it instead of the Gauss-Jordan inverse: the unrolled elimination of a
+// 32 x 32 matrix leaves most of the row arrays in scratch memory (7 M nodes/s), and the trace needs no inverse.
+template <int NP>
+__device__ __forceinline__ void rows_trace_resolvent_tri(int n, int r, double (&hr)[NP], double (&hi)[NP], double sw, double eta, double& tr,
+                                                         double& ti) {
+    double e2[NP], b[NP];
+    hh_steps<NP>(n, r, hr, hi, e2, std::make_integer_sequence<int, NP>());
+    diag_gather<NP>(hr, b, std::make_integer_sequence<int, NP>());
+    double rad = 0.0, eprev = 0.0;
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+        if (i < n) {
+            const double en = (i + 1 < n) ? sqrt(e2[i]) : 0.0;
+            rad = fmax(rad, fabs(b[i]) + eprev + en);
+            eprev = en;
+        }
+    }
+    const double sc = rcp_nr(rad + fabs(sw) + eta);
+    const double zr = sw * sc, zi = eta * sc;
+    double p0r = 1.0, p0i = 0.0, p1r = fma(b[0], sc, zr), p1i = zi;
+    double q0r = 0.0, q0i = 0.0, q1r = 1.0, q1i = 0.0;
+#pragma unroll
+    for (int i = 1; i < NP; ++i) {
+        if (i < n) {  // uniform
+            const double ar = fma(b[i], sc, zr), ai = zi;
+            const double ee = e2[i - 1] * sc * sc;
+            const double npr = fma(ar, p1r, fma(-ai, p1i, -ee * p0r));
+            const double npi = fma(ar, p1i, fma(ai, p1r, -ee * p0i));
+            const double nqr = p1r + fma(ar, q1r, fma(-ai, q1i, -ee * q0r));
+            const double nqi = p1i + fma(ar, q1i, fma(ai, q1r, -ee * q0i));
+            p0r = p1r;
+            p0i = p1i;
+            p1r = npr;
+            p1i = npi;
+            q0r = q1r;
+            q0i = q1i;
+            q1r = nqr;
+            q1i = nqi;
+        }
+    }
+    const double ip = rcp_nr(p1r * p1r + p1i * p1i) * sc;
+    tr = (q1r * p1r + q1i * p1i) * ip;
+    ti = (q1i * p1r - q1r * p1i) * ip;
+}
 
 // ------------------------------------------------------------------------------------------
 // Store-free PTR sums of resolvent traces for MANY swept values (5..16 bands, Hermitian series): one Householder
@@ -3084,6 +3160,21 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(WPE ? WPE : 
                         panel_invert_rows<NP, PAD>(n, r, ar, ai);
                         panel_trace<NP>(ar, ai, n, r, tr, ti);
                     }
+                } else if constexpr (NP == 32) {  // 17...32 bands: the trace from the tridiagonal form (no inverse)
+                    double hr[NP], hi[NP];
+                    double zr, zi, pr, pi;
+                    sincospi(2.0 * (x * a.inv_period), &zi, &zr);
+                    sincospi(2.0 * ((double)a.first * (x * a.inv_period)), &pi, &pr);
+                    panel_series_row<NP, PAD>(coef, n, M, zr, zi, pr, pi, r, hr, hi);  // row r of -H
+                    if (!PAD) {
+#pragma unroll
+                        for (int j = 0; j < NP; ++j) {
+                            const bool real = r < n && j < n;
+                            hr[j] = real ? hr[j] : 0.0;
+                            hi[j] = real ? hi[j] : 0.0;
+                        }
+                    }
+                    rows_trace_resolvent_tri<NP>(n, r, hr, hi, swq, a.p[0], tr, ti);
                 } else {
                     double ar[NP], ai[NP];
                     panel_inverse_row<NP, PAD>(coef, n, M, a.first, x * a.inv_period, swq, a.p[0], r, ar, ai);
@@ -3195,9 +3286,9 @@ int launch_gen_inner_adaptive(abz_ctx* ctx, const InnerSpec& is) {
     } else if (np == 16) {
         if (pad) ABZ_IPANEL3(16, true, 512, 4)
         else ABZ_IPANEL3(16, false, 512, 4)
-    } else {
-        if (pad) ABZ_IPANEL3(32, true, 512, 0)
-        else ABZ_IPANEL3(32, false, 512, 0)
+    } else {  // 17...32 bands: 256 threads = 8 nodes of 32 lanes, one wave per SIMD (the Householder rows take ~300 registers)
+        if (pad) ABZ_IPANEL3(32, true, 256, 0)
+        else ABZ_IPANEL3(32, false, 256, 0)
     }
 #undef ABZ_IPANEL3
     ABZ_HIP(hipGetLastError());
