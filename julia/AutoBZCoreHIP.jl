@@ -377,6 +377,51 @@ end
 "Drop the rules the library keeps with the series for `abz_autoptr_solve*`."
 drop_rules!(hs::HIPSeries) = check(ccall((:abz_series_drop_rules, libabz), Cint, (Ptr{Cvoid},), hs.h))
 
+# ---------------------------------------------------------------- IAI building blocks (a host-language adaptive loop)
+# What `abz_iai_solve*` is built from, for a client that keeps its own heaps (e.g. a custom error norm or termination):
+# contract the outermost remaining variable at a batch of nodes, evaluate the integrand on innermost lines, apply the
+# GK(7,15) rule to batches of panels.  Replaces workspace_contract! / workspace_evaluate! (src/fourier.jl:445-478) and
+# QuadGK.evalrule on a batch.
+"15 Kronrod nodes of the panel `(a, b)` in the library's (and the reference's) order."
+function gk15_nodes(a::Real, b::Real)
+    x = Vector{Float64}(undef, 15)
+    check(ccall((:abz_gk15_nodes, libabz), Cint, (Cdouble, Cdouble, Ptr{Float64}), a, b, x))
+    return x
+end
+
+"GK(7,15) on `npanels` panels: `ab` is 2 x npanels, `values` ncomp x 15 x npanels -> `(I :: ncomp x npanels, E)`."
+function gk15_batch(ab::Matrix{Float64}, values::Array{ComplexF64,3})
+    ncomp, np = size(values, 1), size(values, 3)
+    (size(ab) == (2, np) && size(values, 2) == 15) || throw(ArgumentError("gk15_batch: ab is 2 x npanels, values ncomp x 15 x npanels"))
+    I = Matrix{ComplexF64}(undef, ncomp, np); E = Vector{Float64}(undef, np)
+    GC.@preserve ab values I E check(ccall((:abz_gk15_batch, libabz), Cint,
+        (Ptr{Float64}, Ptr{ComplexF64}, Int64, Cint, Ptr{ComplexF64}, Ptr{Float64}), ab, values, np, ncomp, I, E))
+    return I, E
+end
+
+"Contract the outermost remaining variable of the level-`src_level` sets `parents` (slot 0 at level d = the series) at `x`: slots of the new sets."
+function contract_nodes(hs::HIPSeries, src_level::Integer, parents::Vector{Int64}, x::Vector{Float64})
+    length(parents) == length(x) || throw(ArgumentError("contract_nodes: one parent per node"))
+    slots = Vector{Int64}(undef, length(x))
+    GC.@preserve parents x slots check(ccall((:abz_contract_nodes, libabz), Cint,
+        (Ptr{Cvoid}, Cint, Ptr{Int64}, Ptr{Float64}, Int64, Ptr{Int64}), hs.h, src_level, parents, x, length(x), slots))
+    return slots
+end
+
+"Integrand values at innermost nodes `x` of the level-1 sets `parents` (`tail`: (d-1) x nnodes outer coordinates, for `F_LINEAR_X` only)."
+function eval_line_nodes(hs::HIPSeries, parents::Vector{Int64}, x::Vector{Float64}, f::HIPIntegrand, params::Vector{Float64}, sweep::Real,
+                         ncomp::Integer; tail::Union{Nothing,Matrix{Float64}}=nothing)
+    vals = Matrix{ComplexF64}(undef, ncomp, length(x))
+    tp = tail === nothing ? Ptr{Float64}(C_NULL) : pointer(tail)
+    GC.@preserve parents x params vals tail check(ccall((:abz_eval_line_nodes, libabz), Cint,
+        (Ptr{Cvoid}, Ptr{Int64}, Ptr{Float64}, Ptr{Float64}, Int64, Cint, Ptr{Float64}, Cint, Cdouble, Ptr{ComplexF64}),
+        hs.h, parents, x, tp, length(x), fid(f), params, length(params), sweep, vals))
+    return vals
+end
+
+"Drop every contracted set below `level` (the client's loop is done with them)."
+release_level!(hs::HIPSeries, level::Integer) = check(ccall((:abz_release_level, libabz), Cint, (Ptr{Cvoid}, Cint), hs.h, level))
+
 # ---------------------------------------------------------------- the rest of abzhip.h (housekeeping)
 """(live device bytes, cached device bytes, this context's scratch bytes, its pinned host bytes, live blocks)"""
 function mem_info(; ctx::HIPContext=context())
