@@ -1206,7 +1206,13 @@ __device__ __forceinline__ double dpp_perm_f64(double v) {
 }
 template <int NP>
 __device__ __forceinline__ double group_sum(double v) {
-    if constexpr (NP == 16 || NP == 8) {
+    if constexpr (NP == 32) {  // two DPP rows: each row's sum as for 16 lanes, then the other row's through the crossbar
+        v += dpp_perm_f64<0x140>(v);
+        v += dpp_perm_f64<0x141>(v);
+        v += dpp_perm_f64<0x1b>(v);
+        v += dpp_perm_f64<0xb1>(v);
+        return v + __shfl_xor(v, 16, 64);
+    } else if constexpr (NP == 16 || NP == 8) {
         if constexpr (NP == 16) v += dpp_perm_f64<0x140>(v);  // row_mirror
         v += dpp_perm_f64<0x141>(v);                          // row_half_mirror
         v += dpp_perm_f64<0x1b>(v);                           // quad_perm [3, 2, 1, 0]
@@ -1289,18 +1295,38 @@ struct GenEigArgs {
 // 16 lanes: v_j and q_j are read from lane j INSIDE the FMAs (`v_fmac_f64_dpp ... row_newbcast:j`, see fmac_col_bcast
 // above for the idiom and its wait states): 12 instructions per complex column instead of 4 broadcasts + 16, and no
 // registers for the broadcast copies of v.
+// 32 lanes (two DPP rows per node): after one exchange with the partner lane of the other row every lane holds v_c in `lo`
+// and v_{c+16} in `hi` (c = its position in its row), so that column j reads v_j from lane j mod 16 of its OWN row out of
+// `lo` (j < 16) or `hi` -- the same FMA-with-broadcast columns as with 16 lanes instead of two crossbar swizzles per value.
+struct HhPair {
+    double lor, loi, hir, hii;
+};
+template <int NP>
+__device__ __forceinline__ HhPair hh_pair(int r, double vr, double vi) {
+    HhPair h = {vr, vi, vr, vi};
+    if constexpr (NP == 32) {
+        const double xr = __shfl_xor(vr, 16, 64), xi = __shfl_xor(vi, 16, 64);
+        const bool row0 = r < 16;
+        h.lor = row0 ? vr : xr;
+        h.loi = row0 ? vi : xi;
+        h.hir = row0 ? xr : vr;
+        h.hii = row0 ? xi : vi;
+    }
+    return h;
+}
 template <int NP, int J>
-__device__ __forceinline__ void hh_col_p(const double (&ar)[NP], const double (&ai)[NP], double vr, double vi, double (&vjr)[NP],
-                                         double (&vji)[NP], double& pr, double& pi) {
-    if constexpr (NP == 16) {
+__device__ __forceinline__ void hh_col_p(const double (&ar)[NP], const double (&ai)[NP], double vr, double vi, const HhPair& vp,
+                                         double (&vjr)[NP], double (&vji)[NP], double& pr, double& pi) {
+    if constexpr (NP == 16 || NP == 32) {
         // p += A[r][J] v_J:  pr += vJr ar - vJi ai,  pi += vJi ar + vJr ai
+        const double sr = (NP == 16) ? vr : (J < 16 ? vp.lor : vp.hir), si = (NP == 16) ? vi : (J < 16 ? vp.loi : vp.hii);
         asm("s_nop 1\n\t"
             "v_fmac_f64_dpp %0, %2, %4 row_newbcast:%6 row_mask:0xf bank_mask:0xf\n\t"
             "v_fmac_f64_dpp %0, %3, -%5 row_newbcast:%6 row_mask:0xf bank_mask:0xf\n\t"
             "v_fmac_f64_dpp %1, %3, %4 row_newbcast:%6 row_mask:0xf bank_mask:0xf\n\t"
             "v_fmac_f64_dpp %1, %2, %5 row_newbcast:%6 row_mask:0xf bank_mask:0xf"
             : "+v"(pr), "+v"(pi)
-            : "v"(vr), "v"(vi), "v"(ar[J]), "v"(ai[J]), "n"(J));
+            : "v"(sr), "v"(si), "v"(ar[J]), "v"(ai[J]), "n"(J % 16));
     } else {
         vjr[J] = group_bcast<NP, J>(vr);
         vji[J] = group_bcast<NP, J>(vi);
@@ -1311,22 +1337,25 @@ __device__ __forceinline__ void hh_col_p(const double (&ar)[NP], const double (&
     }
 }
 template <int NP, int J>
-__device__ __forceinline__ void hh_col_upd(double (&ar)[NP], double (&ai)[NP], double vr, double vi, double qr, double qi,
-                                           const double (&vjr)[NP], const double (&vji)[NP]) {
-    if constexpr (NP == 16) {
+__device__ __forceinline__ void hh_col_upd(double (&ar)[NP], double (&ai)[NP], double vr, double vi, double qr, double qi, const HhPair& vp,
+                                           const HhPair& qp, const double (&vjr)[NP], const double (&vji)[NP]) {
+    if constexpr (NP == 16 || NP == 32) {
         // A[r][J] -= v_r conj(q_J) + q_r conj(v_J):
         //   ar -= qJr vr + qJi vi + vJr qr + vJi qi,   ai -= qJr vi - qJi vr + vJr qi - vJi qr
+        // (operands 6...9: the registers v_J and q_J are read from, lane J mod 16 of the row; 16 lanes: v and q themselves)
+        const double svr = (NP == 16) ? vr : (J < 16 ? vp.lor : vp.hir), svi = (NP == 16) ? vi : (J < 16 ? vp.loi : vp.hii);
+        const double sqr = (NP == 16) ? qr : (J < 16 ? qp.lor : qp.hir), sqi = (NP == 16) ? qi : (J < 16 ? qp.loi : qp.hii);
         asm("s_nop 1\n\t"
-            "v_fmac_f64_dpp %0, %4, -%2 row_newbcast:%6 row_mask:0xf bank_mask:0xf\n\t"
-            "v_fmac_f64_dpp %1, %4, -%3 row_newbcast:%6 row_mask:0xf bank_mask:0xf\n\t"
-            "v_fmac_f64_dpp %0, %5, -%3 row_newbcast:%6 row_mask:0xf bank_mask:0xf\n\t"
-            "v_fmac_f64_dpp %1, %5, %2 row_newbcast:%6 row_mask:0xf bank_mask:0xf\n\t"
-            "v_fmac_f64_dpp %0, %2, -%4 row_newbcast:%6 row_mask:0xf bank_mask:0xf\n\t"
-            "v_fmac_f64_dpp %1, %2, -%5 row_newbcast:%6 row_mask:0xf bank_mask:0xf\n\t"
-            "v_fmac_f64_dpp %0, %3, -%5 row_newbcast:%6 row_mask:0xf bank_mask:0xf\n\t"
-            "v_fmac_f64_dpp %1, %3, %4 row_newbcast:%6 row_mask:0xf bank_mask:0xf"
+            "v_fmac_f64_dpp %0, %8, -%2 row_newbcast:%10 row_mask:0xf bank_mask:0xf\n\t"
+            "v_fmac_f64_dpp %1, %8, -%3 row_newbcast:%10 row_mask:0xf bank_mask:0xf\n\t"
+            "v_fmac_f64_dpp %0, %9, -%3 row_newbcast:%10 row_mask:0xf bank_mask:0xf\n\t"
+            "v_fmac_f64_dpp %1, %9, %2 row_newbcast:%10 row_mask:0xf bank_mask:0xf\n\t"
+            "v_fmac_f64_dpp %0, %6, -%4 row_newbcast:%10 row_mask:0xf bank_mask:0xf\n\t"
+            "v_fmac_f64_dpp %1, %6, -%5 row_newbcast:%10 row_mask:0xf bank_mask:0xf\n\t"
+            "v_fmac_f64_dpp %0, %7, -%5 row_newbcast:%10 row_mask:0xf bank_mask:0xf\n\t"
+            "v_fmac_f64_dpp %1, %7, %4 row_newbcast:%10 row_mask:0xf bank_mask:0xf"
             : "+v"(ar[J]), "+v"(ai[J])
-            : "v"(vr), "v"(vi), "v"(qr), "v"(qi), "n"(J));
+            : "v"(vr), "v"(vi), "v"(qr), "v"(qi), "v"(svr), "v"(svi), "v"(sqr), "v"(sqi), "n"(J % 16));
     } else {
         const double qjr = group_bcast<NP, J>(qr), qji = group_bcast<NP, J>(qi);
         ar[J] -= (vr * qjr + vi * qji) + (qr * vjr[J] + qi * vji[J]);
@@ -1334,14 +1363,15 @@ __device__ __forceinline__ void hh_col_upd(double (&ar)[NP], double (&ai)[NP], d
     }
 }
 template <int NP, int K, int... JJ>
-__device__ __forceinline__ void hh_cols_p(const double (&ar)[NP], const double (&ai)[NP], double vr, double vi, double (&vjr)[NP],
-                                          double (&vji)[NP], double& pr, double& pi, std::integer_sequence<int, JJ...>) {
-    (hh_col_p<NP, K + 1 + JJ>(ar, ai, vr, vi, vjr, vji, pr, pi), ...);
+__device__ __forceinline__ void hh_cols_p(const double (&ar)[NP], const double (&ai)[NP], double vr, double vi, const HhPair& vp,
+                                          double (&vjr)[NP], double (&vji)[NP], double& pr, double& pi, std::integer_sequence<int, JJ...>) {
+    (hh_col_p<NP, K + 1 + JJ>(ar, ai, vr, vi, vp, vjr, vji, pr, pi), ...);
 }
 template <int NP, int K, int... JJ>
-__device__ __forceinline__ void hh_cols_upd(double (&ar)[NP], double (&ai)[NP], double vr, double vi, double qr, double qi,
-                                            const double (&vjr)[NP], const double (&vji)[NP], std::integer_sequence<int, JJ...>) {
-    (hh_col_upd<NP, K + 1 + JJ>(ar, ai, vr, vi, qr, qi, vjr, vji), ...);
+__device__ __forceinline__ void hh_cols_upd(double (&ar)[NP], double (&ai)[NP], double vr, double vi, double qr, double qi, const HhPair& vp,
+                                            const HhPair& qp, const double (&vjr)[NP], const double (&vji)[NP],
+                                            std::integer_sequence<int, JJ...>) {
+    (hh_col_upd<NP, K + 1 + JJ>(ar, ai, vr, vi, qr, qi, vp, qp, vjr, vji), ...);
 }
 
 template <int NP, int K>
@@ -1383,7 +1413,8 @@ __device__ __forceinline__ void hh_step(int n, int r, double (&ar)[NP], double (
             const double vr = (r == K + 1) ? v1r : xr, vi = (r == K + 1) ? v1i : xi;
             double vjr[NP], vji[NP];
             double pr = 0.0, pi = 0.0;  // p_r = beta sum_{j > K} A[r][j] v_j
-            hh_cols_p<NP, K>(ar, ai, vr, vi, vjr, vji, pr, pi, std::make_integer_sequence<int, NP - K - 1>());
+            const HhPair vp = hh_pair<NP>(r, vr, vi);
+            hh_cols_p<NP, K>(ar, ai, vr, vi, vp, vjr, vji, pr, pi, std::make_integer_sequence<int, NP - K - 1>());
             pr *= beta;
             pi *= beta;
             // kappa = (beta / 2) v^H p (real for Hermitian A up to rounding; the imaginary part is kept for the non-ideal case)
@@ -1391,7 +1422,8 @@ __device__ __forceinline__ void hh_step(int n, int r, double (&ar)[NP], double (
             const double ki = 0.5 * beta * group_sum<NP>(vr * pi - vi * pr);
             const double qr = pr - (kr * vr - ki * vi), qi = pi - (kr * vi + ki * vr);
             // A[r][j] -= v_r conj(q_j) + q_r conj(v_j), j > K
-            hh_cols_upd<NP, K>(ar, ai, vr, vi, qr, qi, vjr, vji, std::make_integer_sequence<int, NP - K - 1>());
+            const HhPair qp = hh_pair<NP>(r, qr, qi);
+            hh_cols_upd<NP, K>(ar, ai, vr, vi, qr, qi, vp, qp, vjr, vji, std::make_integer_sequence<int, NP - K - 1>());
         }
     }
 }
