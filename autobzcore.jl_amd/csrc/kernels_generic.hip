@@ -971,7 +971,7 @@ bool gen_sum_supported(int n, int M, int npt, int integrand, bool herm) {
     if (!(integrand == ABZ_F_DOS || integrand == ABZ_F_TRGLOC)) return false;
     const int np = n <= 8 ? 8 : (n <= 16 ? 16 : 32);
     const size_t rest = sizeof(double2) * (size_t)(256 / np) * 4;
-    return sizeof(double2) * (size_t)M * n * n + rest <= 150 * 1024;
+    return sizeof(double2) * (size_t)M * n * n + rest <= (n > 16 ? 159 : 150) * 1024;  // (17...32 bands go through the tridiagonal kernel: its budget)
 }
 
 static bool gen_sum_tri_wanted(const SumSpec& ss);
@@ -1729,7 +1729,7 @@ static int launch_gen_sum_tri(abz_ctx* ctx, const SumSpec& ss, double* out_reim)
     size_t lds = sizeof(double2) * (size_t)M * np * np + rest;
     const bool pad = lds <= 150 * 1024;
     if (!pad) lds = sizeof(double2) * (size_t)M * n * n + rest;
-    if (lds > 150 * 1024) return ABZ_ERR_UNSUPPORTED;
+    if (lds > 160 * 1024) return ABZ_ERR_UNSUPPORTED;  // (unpadded: up to the whole LDS of a CU, one workgroup per CU then)
     const int64_t blocks = std::min<int64_t>(ss.nlines, 256 * 4);
     int rc = ctx->scratch[1].reserve(sizeof(double2) * (size_t)(blocks * 32));
     if (rc) return rc;
@@ -2289,7 +2289,7 @@ static bool gen_grid_eig_supported(const GenSpec& gs, int* np_out, size_t* lds_o
     size_t lds = sizeof(double2) * (size_t)gs.M * np * np + tile_bytes;
     *pad_out = lds <= 150 * 1024;
     if (!*pad_out) lds = sizeof(double2) * (size_t)gs.M * gs.n * gs.n + tile_bytes;
-    if (lds > 150 * 1024) return false;
+    if (lds > 160 * 1024) return false;  // (unpadded: up to the whole LDS of a CU, one workgroup per CU then)
     if (gs.Uplanes.base && gs.n > 8 && !*pad_out) return false;
     *np_out = np;
     *lds_out = lds;

@@ -916,6 +916,26 @@ def test_generic_n_eval_and_rules(abz, d, n):
         assert np.abs(g[i].reshape(n, n).T - G).max() <= 1e-10 * np.abs(G).max()
 
 
+def test_generic_n_set_above_150_kb_of_lds(abz):
+    """28 bands x 11 coefficients: the unpadded level-1 set + store tile take 150.7 KB of LDS -- above the 150 KB the padded
+    layouts are held to, inside the 160 KB of a CU that the unpadded 32-lane kernels may use (one workgroup per CU)."""
+    rng = np.random.default_rng(2828)
+    n, npt = 28, 7
+    c, first = rand_series(rng, (11, 3), n, hermitian=True)
+    s, so = both(abz, c / np.sqrt(n), first)
+    L = abz._lib
+    rule = s.device().rule(npt, None, want=3)
+    out = rule.export(H=True, eig=True)
+    vals = orc.fourier_ptr(so, npt)
+    ref = np.transpose(vals, (1, 0, 2, 3)).reshape(-1, n, n)
+    assert np.abs(out["H"] - ref).max() <= 1e-12 * np.abs(ref).max()
+    assert np.abs(out["eig"] - np.linalg.eigvalsh(ref, UPLO="U")).max() <= 1e-11 * np.abs(ref).max()
+    om = np.linspace(-1.0, 1.0, 4)
+    a = rule.reduce(L.F_DOS, [0.2], om)
+    b = s.device().ptr_sum(npt, L.F_DOS, [0.2], om)
+    assert np.abs(a - b).max() <= 1e-12 * np.abs(a).max()
+
+
 def test_generic_n_unpadded_32_lane_layout(abz):
     """17...32 bands with a level-1 set too long for the zero-padded LDS layout (11 coefficients x 32 x 32 x 16 B = 180 KB):
     the unpadded instances of the 32-lane row kernels -- rule values and eigenvalues against the oracle, the store-free
