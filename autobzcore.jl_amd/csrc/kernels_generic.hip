@@ -472,6 +472,31 @@ __device__ __forceinline__ void panel_series_row(const double2* coef, int n, int
     }
 }
 
+// The same for a CHUNK of the set (unpadded layout [mc][n*n], blocks m0 ... m0 + mc - 1 of the M): the row accumulates over
+// the chunks of a set that does not fit the LDS whole, the phase (pr, pi) = w z^m0 is carried from chunk to chunk.
+template <int NP>
+__device__ __forceinline__ void panel_series_row_chunk(const double2* coef, int n, int mc, double zr, double zi, double& pr, double& pi, int r,
+                                                       double (&ar)[NP], double (&ai)[NP]) {
+    const int nn = n * n;
+    const int rr = r < n ? r : n - 1;
+    for (int m = 0; m < mc; ++m) {
+        const double2* __restrict__ cm = coef + (size_t)m * nn + rr;
+#pragma unroll
+        for (int j = 0; j < NP; ++j) {
+            if (j < n) {  // uniform
+                const double2 c = cm[n * j];
+                ar[j] = fma(-c.x, pr, ar[j]);
+                ar[j] = fma(c.y, pi, ar[j]);
+                ai[j] = fma(-c.x, pi, ai[j]);
+                ai[j] = fma(-c.y, pr, ai[j]);
+            }
+        }
+        const double nr = pr * zr - pi * zi, ni = pr * zi + pi * zr;
+        pr = nr;
+        pi = ni;
+    }
+}
+
 // row r of A = (sw + i eta) I - H from the row of -H; padding rows become identity rows
 template <int NP, bool PAD>
 __device__ __forceinline__ void panel_shift_row(int n, double sw, double eta, int r, double (&ar)[NP], double (&ai)[NP]) {
@@ -971,7 +996,9 @@ bool gen_sum_supported(int n, int M, int npt, int integrand, bool herm) {
     if (!(integrand == ABZ_F_DOS || integrand == ABZ_F_TRGLOC)) return false;
     const int np = n <= 8 ? 8 : (n <= 16 ? 16 : 32);
     const size_t rest = sizeof(double2) * (size_t)(256 / np) * 4;
-    return sizeof(double2) * (size_t)M * n * n + rest <= (n > 16 ? 159 : 150) * 1024;  // (17...32 bands go through the tridiagonal kernel: its budget)
+    // (17...32 bands go through the tridiagonal kernel, which stages a set that does not fit the LDS in chunks)
+    return n > 16 ? abz_switch(SW_GEN_SUM_TRI) != 0 || sizeof(double2) * (size_t)M * n * n + rest <= 159 * 1024
+                  : sizeof(double2) * (size_t)M * n * n + rest <= 150 * 1024;
 }
 
 static bool gen_sum_tri_wanted(const SumSpec& ss);
@@ -988,6 +1015,7 @@ int launch_gen_sum(abz_ctx* ctx, const SumSpec& ss, double* out_reim) {
     size_t lds = sizeof(double2) * (size_t)M * np * np + rest;
     const bool pad = lds <= 150 * 1024;
     if (!pad) lds = sizeof(double2) * (size_t)M * n * n + rest;
+    if (lds > 160 * 1024) return ABZ_ERR_UNSUPPORTED;
     const int64_t blocks = std::min<int64_t>(ss.nlines, 256 * 2);
     int rc = ctx->scratch[1].reserve(sizeof(double2) * (size_t)(blocks * 4));
     if (rc) return rc;
@@ -1274,6 +1302,7 @@ struct GenEigArgs {
     double* tri = nullptr;  // eigenvalues only: the tridiagonals (d | |e|^2, [2 NP][tri_nk]) for tri_eig_kernel instead of E
     int64_t tri_nk = 0;
     int fold = 0;  // Hermitian level-1 sets with first = -(M - 1) / 2: the series from c_0 and c_f +- c_f^T (half the FMAs)
+    int mc = 0;    // > 0 (unpadded layout): the set is staged mc coefficients at a time, per group of nodes (it does not fit the LDS whole)
 };
 
 
@@ -1618,6 +1647,7 @@ struct GenSumTriArgs {
     double2* partial;  // [gridDim.x][nw]
     int64_t nlines;
     int n, M, first, npt, nw, is_dos;
+    int mc = 0;  // > 0 (unpadded layout): the set is staged mc coefficients at a time, per group of nodes (it does not fit the LDS whole)
     double eta;
     double sweep[32];
 };
@@ -1628,7 +1658,7 @@ __global__ __launch_bounds__(256) void gen_grid_sum_tri_kernel(GenSumTriArgs a) 
     constexpr int SLOTS = 256 / NP;
     const int n = a.n, nn = n * n, M = a.M;
     double2* coef = lds_gt;
-    double2* red = coef + (size_t)M * (PAD ? NP * NP : nn);  // [SLOTS][NP]
+    double2* red = coef + (size_t)((!PAD && a.mc > 0) ? a.mc : M) * (PAD ? NP * NP : nn);  // [SLOTS][NP]
     const int slot = threadIdx.x / NP, r = threadIdx.x % NP;
     int fm = a.first % a.npt;
     if (fm < 0) fm += a.npt;
@@ -1637,19 +1667,40 @@ __global__ __launch_bounds__(256) void gen_grid_sum_tri_kernel(GenSumTriArgs a) 
     for (int q = 0; q < NP; ++q) mysw = (q == r) ? a.sweep[q] : mysw;
     const bool lane_act = r < a.nw;
     double accr = 0.0, acci = 0.0;
+    const bool chunked = !PAD && a.mc > 0;
     for (int64_t line = blockIdx.x; line < a.nlines; line += gridDim.x) {
-        __syncthreads();
-        panel_stage<NP, PAD>(coef, a.src + line * ((int64_t)M * nn), n, M);
-        __syncthreads();
+        if (!chunked) {
+            __syncthreads();
+            panel_stage<NP, PAD>(coef, a.src + line * ((int64_t)M * nn), n, M);
+            __syncthreads();
+        }
         for (int i0 = 0; i0 < a.npt; i0 += SLOTS) {
-            if (i0 + (int)(threadIdx.x >> 6) * (64 / NP) >= a.npt) continue;  // no node for this wave (wave-level sync only below)
+            const bool wave_on = i0 + (int)(threadIdx.x >> 6) * (64 / NP) < a.npt;
+            if (!chunked && !wave_on) continue;  // no node for this wave (wave-level sync only below; chunked: the staging barriers need every wave)
             const int i1 = i0 + slot;
             const bool act = i1 < a.npt;
             const int ic = act ? i1 : 0;
             const double2 z = a.tab[ic];
             const double2 w = a.tab[(int)(((unsigned)fm * (unsigned)ic) % (unsigned)a.npt)];
             double hr[NP], hi[NP];
-            panel_series_row<NP, PAD>(coef, n, M, z.x, z.y, w.x, w.y, r, hr, hi);  // row r of B = -H(k)
+            if (chunked) {
+                double pr = w.x, pi = w.y;
+#pragma unroll
+                for (int j = 0; j < NP; ++j) {
+                    hr[j] = 0.0;
+                    hi[j] = 0.0;
+                }
+                for (int m0 = 0; m0 < M; m0 += a.mc) {
+                    const int mcur = min(a.mc, M - m0);
+                    __syncthreads();  // the previous chunk's readers are done
+                    panel_stage<NP, false>(coef, a.src + line * ((int64_t)M * nn) + (int64_t)m0 * nn, n, mcur);
+                    __syncthreads();
+                    if (wave_on) panel_series_row_chunk<NP>(coef, n, mcur, z.x, z.y, pr, pi, r, hr, hi);
+                }
+                if (!wave_on) continue;
+            } else {
+                panel_series_row<NP, PAD>(coef, n, M, z.x, z.y, w.x, w.y, r, hr, hi);  // row r of B = -H(k)
+            }
             if (!PAD) {
 #pragma unroll
                 for (int j = 0; j < NP; ++j) {
@@ -1729,7 +1780,12 @@ static int launch_gen_sum_tri(abz_ctx* ctx, const SumSpec& ss, double* out_reim)
     size_t lds = sizeof(double2) * (size_t)M * np * np + rest;
     const bool pad = lds <= 150 * 1024;
     if (!pad) lds = sizeof(double2) * (size_t)M * n * n + rest;
-    if (lds > 160 * 1024) return ABZ_ERR_UNSUPPORTED;  // (unpadded: up to the whole LDS of a CU, one workgroup per CU then)
+    int mc = 0;
+    if (lds > 160 * 1024) {  // the set does not fit the LDS whole: staged in chunks of mc coefficients (two workgroups per CU)
+        mc = (int)((72 * 1024 - rest) / (sizeof(double2) * (size_t)n * n));
+        if (mc < 1) return ABZ_ERR_UNSUPPORTED;
+        lds = sizeof(double2) * (size_t)mc * n * n + rest;
+    }
     const int64_t blocks = std::min<int64_t>(ss.nlines, 256 * 4);
     int rc = ctx->scratch[1].reserve(sizeof(double2) * (size_t)(blocks * 32));
     if (rc) return rc;
@@ -1745,6 +1801,7 @@ static int launch_gen_sum_tri(abz_ctx* ctx, const SumSpec& ss, double* out_reim)
     a.npt = ss.npt;
     a.is_dos = ss.integrand == ABZ_F_DOS ? 1 : 0;
     a.eta = ss.params[0];
+    a.mc = mc;
     for (int s0 = 0; s0 < ss.n_sweep; s0 += np) {
         a.nw = std::min(np, ss.n_sweep - s0);
         for (int q = 0; q < 32; ++q) a.sweep[q] = q < a.nw ? ss.sweep_host[s0 + q] : 0.0;
@@ -1983,17 +2040,20 @@ __global__ __launch_bounds__(256, (TRI && !VEC && NP <= 16) ? 2 : 1) void gen_gr
     constexpr int PC = NP == 32 ? 176 : (NP == 16 ? 144 : 64);  // planes per tile pass: columns 0...11 of 16 rows (16 nodes) / all 64 of 8 rows (32 nodes) / at most 171 of 32 rows (8 nodes)
     const int n = a.n, nn = n * n, M = a.M;
     double2* coef = lds_ge;
-    double* const tile = reinterpret_cast<double*>(coef + (size_t)M * (PAD ? NP * NP : nn));  // [PC][TS]
+    const bool chunked = !PAD && a.mc > 0;
+    double* const tile = reinterpret_cast<double*>(coef + (size_t)(chunked ? a.mc : M) * (PAD ? NP * NP : nn));  // [PC][TS]
     const int slot = threadIdx.x / NP, r = threadIdx.x % NP, lane = threadIdx.x & 63;
     int fm = a.first % a.npt;
     if (fm < 0) fm += a.npt;
     for (int64_t line = blockIdx.x; line < a.nlines; line += gridDim.x) {
-        __syncthreads();
-        if (PAD && a.fold)
-            panel_stage_fold<NP>(coef, a.src + line * ((int64_t)M * nn), n, M, 0.0, 0.0);
-        else
-            panel_stage<NP, PAD>(coef, a.src + line * ((int64_t)M * nn), n, M);
-        __syncthreads();
+        if (!chunked) {
+            __syncthreads();
+            if (PAD && a.fold)
+                panel_stage_fold<NP>(coef, a.src + line * ((int64_t)M * nn), n, M, 0.0, 0.0);
+            else
+                panel_stage<NP, PAD>(coef, a.src + line * ((int64_t)M * nn), n, M);
+            __syncthreads();
+        }
         // nodes of this coefficient set: the whole grid line, or its run of an irregular (symmetric-rule) list
         const int64_t kbase = a.run_start ? a.run_start[line] : line * a.npt;
         const int count = a.run_start ? (int)(a.run_start[line + 1] - kbase) : a.npt;
@@ -2006,7 +2066,30 @@ __global__ __launch_bounds__(256, (TRI && !VEC && NP <= 16) ? 2 : 1) void gen_gr
             const int64_t k = kbase + ii;
             const bool wr = act && r < n;
             double hr[NP], hi[NP];
-            if (wave_on) {
+            if (chunked) {  // the set in chunks of a.mc coefficients, staged per group of nodes: every wave keeps the barriers
+                const int ic = a.gi ? a.gi[kbase + ii] : ii;
+                const double2 z = a.tab[ic];
+                const double2 w = a.tab[(int)(((unsigned)fm * (unsigned)ic) % (unsigned)a.npt)];
+                double pr = w.x, pi = w.y;
+#pragma unroll
+                for (int j = 0; j < NP; ++j) {
+                    hr[j] = 0.0;
+                    hi[j] = 0.0;
+                }
+                for (int m0 = 0; m0 < M; m0 += a.mc) {
+                    const int mcur = min(a.mc, M - m0);
+                    __syncthreads();
+                    panel_stage<NP, false>(coef, a.src + line * ((int64_t)M * nn) + (int64_t)m0 * nn, n, mcur);
+                    __syncthreads();
+                    if (wave_on) panel_series_row_chunk<NP>(coef, n, mcur, z.x, z.y, pr, pi, r, hr, hi);
+                }
+#pragma unroll
+                for (int j = 0; j < NP; ++j) {
+                    const bool real = r < n && j < n;
+                    hr[j] = real ? -hr[j] : 0.0;
+                    hi[j] = real ? -hi[j] : 0.0;
+                }
+            } else if (wave_on) {
                 const int ic = a.gi ? a.gi[kbase + ii] : ii;
                 const double2 z = a.tab[ic];
                 const double2 w = a.tab[(int)(((unsigned)fm * (unsigned)ic) % (unsigned)a.npt)];
@@ -2289,7 +2372,12 @@ static bool gen_grid_eig_supported(const GenSpec& gs, int* np_out, size_t* lds_o
     size_t lds = sizeof(double2) * (size_t)gs.M * np * np + tile_bytes;
     *pad_out = lds <= 150 * 1024;
     if (!*pad_out) lds = sizeof(double2) * (size_t)gs.M * gs.n * gs.n + tile_bytes;
-    if (lds > 160 * 1024) return false;  // (unpadded: up to the whole LDS of a CU, one workgroup per CU then)
+    if (lds > 160 * 1024) {  // (unpadded: up to the whole LDS of a CU; beyond it the set is staged in chunks, two workgroups per CU)
+        if (gs.Uplanes.base) return false;
+        const int mc = (int)((72 * 1024 - tile_bytes) / (sizeof(double2) * (size_t)gs.n * gs.n));
+        if (mc < 1) return false;
+        lds = sizeof(double2) * (size_t)mc * gs.n * gs.n + tile_bytes;
+    }
     if (gs.Uplanes.base && gs.n > 8 && !*pad_out) return false;
     *np_out = np;
     *lds_out = lds;
@@ -2319,6 +2407,11 @@ static int launch_gen_grid_eig(abz_ctx* ctx, const GenSpec& gs, int np, size_t l
     a.npt = gs.npt;
     a.herm = gs.herm ? 1 : 0;
     a.fold = (gs.herm && pad && (gs.M & 1) && gs.first == -((gs.M - 1) / 2) && abz_switch(SW_EIG_FOLD) != 0) ? 1 : 0;
+    {
+        const size_t tile_bytes = sizeof(double) * (size_t)(np == 32 ? 176 : (np == 16 ? 144 : 64)) * (size_t)(256 / np + 1);
+        if (!pad && sizeof(double2) * (size_t)gs.M * gs.n * gs.n + tile_bytes > 160 * 1024)  // gen_grid_eig_supported's chunk length
+            a.mc = (int)((72 * 1024 - tile_bytes) / (sizeof(double2) * (size_t)gs.n * gs.n));
+    }
     const int64_t blocks = std::min<int64_t>(a.nlines, 256 * 4);
     const bool vec = gs.Uplanes.base != nullptr;
     // eigenvalues without eigenvectors: the tridiagonals go through scratch to tri_eig_kernel (ABZ_EIG_SPLIT=0: bisection

@@ -936,6 +936,29 @@ def test_generic_n_set_above_150_kb_of_lds(abz):
     assert np.abs(a - b).max() <= 1e-12 * np.abs(a).max()
 
 
+def test_generic_n_set_staged_in_chunks(abz):
+    """A level-1 set that does not fit the LDS at all (20 bands x 45 coefficients = 288 KB): the rule-build and sweep kernels
+    stage it in chunks per group of nodes, the phase carried from chunk to chunk -- values and eigenvalues against the
+    oracle, the store-free sweep against the scan of the rule and the oracle's rule sum."""
+    rng = np.random.default_rng(4520)
+    n, npt = 20, 7
+    c, first = rand_series(rng, (45, 3), n, hermitian=True)
+    s, so = both(abz, c / np.sqrt(n), first)
+    L = abz._lib
+    rule = s.device().rule(npt, None, want=3)
+    out = rule.export(H=True, eig=True)
+    vals = orc.fourier_ptr(so, npt)
+    ref = np.transpose(vals, (1, 0, 2, 3)).reshape(-1, n, n)
+    assert np.abs(out["H"] - ref).max() <= 1e-12 * np.abs(ref).max()
+    assert np.abs(out["eig"] - np.linalg.eigvalsh(ref, UPLO="U")).max() <= 1e-11 * np.abs(ref).max()
+    om = np.linspace(-1.0, 1.0, 4)
+    a = rule.reduce(L.F_DOS, [0.2], om)
+    b = s.device().ptr_sum(npt, L.F_DOS, [0.2], om)
+    assert np.abs(a - b).max() <= 1e-12 * np.abs(a).max()
+    r0, _ = orc._ptr_rule_sum(so, npt, None, orc.f_dos(0.2, om[2]))
+    assert abs(b[2, 0].real - r0) <= 1e-10 * abs(r0)
+
+
 def test_generic_n_unpadded_32_lane_layout(abz):
     """17...32 bands with a level-1 set too long for the zero-padded LDS layout (11 coefficients x 32 x 32 x 16 B = 180 KB):
     the unpadded instances of the 32-lane row kernels -- rule values and eigenvalues against the oracle, the store-free
