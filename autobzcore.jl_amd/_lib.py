@@ -71,7 +71,7 @@ WANT_H_COMPACT = 8  # with WANT_H on a Hermitian series of n <= 4 bands: upper-t
 F_ONE, F_LINEAR, F_LINEAR_X, F_DOS, F_TRGLOC, F_GLOC, F_DOS_EIG = range(7)
 LIMS_CUBIC, LIMS_TETRAHEDRAL, LIMS_POLYHEDRAL, LIMS_POLYGON = 0, 1, 2, 3
 K_CONTRACT, K_EVAL, K_REDUCE, K_GGR, K_EIG, K_GGRBUILD = range(6)
-ERR_ARG, ERR_HIP, ERR_NOGPU, ERR_UNSUPPORTED, ERR_NOMEM = -1, -2, -3, -4, -5
+ERR_ARG, ERR_HIP, ERR_NOGPU, ERR_UNSUPPORTED, ERR_NOMEM, ERR_INTERNAL = -1, -2, -3, -4, -5, -6
 
 
 # all-gather hook of a sharded IAI solve: int fn(void* user, double* buf, int64_t per_rank)

@@ -13,6 +13,12 @@
 namespace abz {
 
 void set_error(const char* fmt, ...);
+int catch_status() noexcept;  // status + abz_last_error message of the exception in flight
+
+// Every extern "C" entry point is a function-try-block closed by this: std::bad_alloc -> ABZ_ERR_NOMEM, anything else ->
+// ABZ_ERR_INTERNAL, the text in abz_last_error().
+#define ABZ_CATCH_ALL \
+    catch (...) { return abz::catch_status(); }
 
 #define ABZ_HIP(call)                                                                      \
     do {                                                                                   \

@@ -23,6 +23,31 @@ void set_error(const char* fmt, ...) {
     g_err = buf;
 }
 
+// The status of the exception in flight (called from the catch-all of every entry point: no C++ exception crosses the C ABI).
+int catch_status() noexcept {
+    try {
+        throw;
+    } catch (const std::bad_alloc&) {
+        try {
+            set_error("out of host memory (std::bad_alloc)");
+        } catch (...) {
+        }
+        return ABZ_ERR_NOMEM;
+    } catch (const std::exception& e) {
+        try {
+            set_error("internal error: %s", e.what());
+        } catch (...) {
+        }
+        return ABZ_ERR_INTERNAL;
+    } catch (...) {
+        try {
+            set_error("internal error: unknown C++ exception");
+        } catch (...) {
+        }
+        return ABZ_ERR_INTERNAL;
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // Environment switches: the one place the library reads the environment (abz_internal.h: enum Switch).
 // ------------------------------------------------------------------------------------------
@@ -587,7 +612,7 @@ extern "C" {
 const char* abz_last_error(void) { return g_err.c_str(); }
 int abz_version(void) { return ABZ_VERSION; }
 
-int abz_device_count(int* n) {
+int abz_device_count(int* n) try {
     int c = 0;
     hipError_t e = hipGetDeviceCount(&c);
     if (n) *n = (e == hipSuccess) ? c : 0;
@@ -597,13 +622,13 @@ int abz_device_count(int* n) {
         return ABZ_ERR_NOGPU;
     }
     return ABZ_OK;
-}
+} ABZ_CATCH_ALL
 
 static int ctx_create(int device, hipStream_t borrowed, bool borrow, abz_ctx** out);
-int abz_ctx_create(int device, abz_ctx** out) { return ctx_create(device, nullptr, false, out); }
-int abz_ctx_create_on_stream(int device, void* hip_stream, abz_ctx** out) {
+int abz_ctx_create(int device, abz_ctx** out) try { return ctx_create(device, nullptr, false, out); } ABZ_CATCH_ALL
+int abz_ctx_create_on_stream(int device, void* hip_stream, abz_ctx** out) try {
     return ctx_create(device, static_cast<hipStream_t>(hip_stream), true, out);
-}
+} ABZ_CATCH_ALL
 
 static int ctx_create(int device, hipStream_t borrowed, bool borrow, abz_ctx** out) {
     ABZ_REQUIRE(out != nullptr, "abz_ctx_create: null out");
@@ -639,27 +664,27 @@ static int ctx_create(int device, hipStream_t borrowed, bool borrow, abz_ctx** o
     return ABZ_OK;
 }
 
-int abz_ctx_destroy(abz_ctx* ctx) {
+int abz_ctx_destroy(abz_ctx* ctx) try {
     if (!ctx || ctx->closed) return ABZ_OK;
     ctx->closed = true;
     ctx_release(ctx);  // freed once the last series created on it is gone
     return ABZ_OK;
-}
+} ABZ_CATCH_ALL
 
-int abz_ctx_sync(abz_ctx* ctx) {
+int abz_ctx_sync(abz_ctx* ctx) try {
     ABZ_REQUIRE(ctx && !ctx->closed, "null or destroyed ctx");
     ABZ_HIP(hipStreamSynchronize(ctx->stream));
     return ABZ_OK;
-}
+} ABZ_CATCH_ALL
 
-int abz_prof_enable(abz_ctx* ctx, int on) {
+int abz_prof_enable(abz_ctx* ctx, int on) try {
     ABZ_REQUIRE(ctx, "null ctx");
     // on = 1: every kernel id; on > 1: bit mask (bit k+1 selects kernel id k), e.g. 1 << (ABZ_K_EVAL + 1)
     ctx->prof = on == 0 ? 0u : (on == 1 ? 0xffffffffu : ((unsigned)on >> 1));
     return ABZ_OK;
-}
+} ABZ_CATCH_ALL
 
-int abz_mem_info(abz_ctx* ctx, int64_t* info) {
+int abz_mem_info(abz_ctx* ctx, int64_t* info) try {
     ABZ_REQUIRE(info, "abz_mem_info: null info");
     {
         std::lock_guard<std::mutex> lk(g_pool_mutex);
@@ -674,9 +699,9 @@ int abz_mem_info(abz_ctx* ctx, int64_t* info) {
         info[3] = (int64_t)ctx->pin_cap;
     }
     return ABZ_OK;
-}
+} ABZ_CATCH_ALL
 
-int abz_prof_reset(abz_ctx* ctx) {
+int abz_prof_reset(abz_ctx* ctx) try {
     ABZ_REQUIRE(ctx, "null ctx");
     int rc = prof_collect(ctx);
     for (auto& sl : ctx->prof_slots) {
@@ -684,22 +709,22 @@ int abz_prof_reset(abz_ctx* ctx) {
         sl.launches = 0;
     }
     return rc;
-}
+} ABZ_CATCH_ALL
 
-int abz_prof_read(abz_ctx* ctx, int kernel_id, double* total_ms, int64_t* launches) {
+int abz_prof_read(abz_ctx* ctx, int kernel_id, double* total_ms, int64_t* launches) try {
     ABZ_REQUIRE(ctx && kernel_id >= 0 && kernel_id < ABZ_K_COUNT, "bad profile slot");
     int rc = prof_collect(ctx);
     if (rc) return rc;
     if (total_ms) *total_ms = ctx->prof_slots[kernel_id].ms;
     if (launches) *launches = ctx->prof_slots[kernel_id].launches;
     return ABZ_OK;
-}
+} ABZ_CATCH_ALL
 
 // ---------------------------------------------------------------- series
 static bool detect_hermitian(const abz_series* s, const double* coef_reim);
 
 int abz_series_create(abz_ctx* ctx, const double* coef_reim, int d, const int32_t* dims, const int32_t* first,
-                      const double* period, int n, abz_series** out) {
+                      const double* period, int n, abz_series** out) try {
     ABZ_REQUIRE(ctx && coef_reim && dims && first && period && out, "abz_series_create: null argument");
     ABZ_REQUIRE(!ctx->closed, "abz_series_create: the context was destroyed");
     ABZ_REQUIRE(d >= 1 && d <= ABZ_MAX_DIM, "series dimension d = %d not in 1..%d", d, ABZ_MAX_DIM);
@@ -736,7 +761,7 @@ int abz_series_create(abz_ctx* ctx, const double* coef_reim, int d, const int32_
     ctx->refs += 1;
     *out = s;
     return ABZ_OK;
-}
+} ABZ_CATCH_ALL
 
 // c(-R) == c(R)^dagger for every R (exact comparison) and symmetric frequency ranges
 static bool detect_hermitian(const abz_series* s, const double* coef_reim) {
@@ -767,7 +792,7 @@ static bool detect_hermitian(const abz_series* s, const double* coef_reim) {
     return true;
 }
 
-int abz_series_update(abz_series* s, const double* coef_reim) {
+int abz_series_update(abz_series* s, const double* coef_reim) try {
     int rc = check_series(s);
     if (rc) return rc;
     ABZ_REQUIRE(coef_reim, "null coefficients");
@@ -784,7 +809,7 @@ int abz_series_update(abz_series* s, const double* coef_reim) {
         v->generation += 1;
     }
     return ABZ_OK;
-}
+} ABZ_CATCH_ALL
 
 }  // extern "C"
 
@@ -825,20 +850,20 @@ static void series_drop_kept_rules(abz_series* s) {
     s->summed_once.clear();
 }
 
-int abz_series_destroy(abz_series* s) {
+int abz_series_destroy(abz_series* s) try {
     if (!s || s->closed) return ABZ_OK;
     series_drop_kept_rules(s);
     s->closed = true;
     series_release(s);  // freed once the last rule built from it is gone
     return ABZ_OK;
-}
+} ABZ_CATCH_ALL
 
-int abz_series_drop_rules(abz_series* s) {
+int abz_series_drop_rules(abz_series* s) try {
     int rc = check_series(s);
     if (rc) return rc;
     series_drop_kept_rules(s);
     return ABZ_OK;
-}
+} ABZ_CATCH_ALL
 
 // ---------------------------------------------------------------- rules
 namespace abz {
@@ -871,7 +896,7 @@ static void rule_free(abz_rule* r) {
     delete r;
 }
 
-int abz_rule_destroy(abz_rule* r) {
+int abz_rule_destroy(abz_rule* r) try {
     if (!r) return ABZ_OK;
     abz_series* s = r->s;
     (void)hipSetDevice(s->ctx->device);
@@ -879,7 +904,7 @@ int abz_rule_destroy(abz_rule* r) {
     rule_free(r);
     series_release(s);
     return ABZ_OK;
-}
+} ABZ_CATCH_ALL
 
 // eigenvalues + velocities only, Hermitian series, n <= 4: the fused GGR build applies
 static bool rule_ggr_fused(const abz_rule* r) {
@@ -1202,14 +1227,14 @@ static int rule_build(abz_series* s, int npt, int64_t nirr, const int32_t* irr_i
 #undef RULE_HIP
 
 int abz_ptr_rule_build(abz_series* s, int npt, int64_t nirr, const int32_t* irr_idx, const int64_t* wsym, int want,
-                       abz_rule** out) {
+                       abz_rule** out) try {
     return rule_build(s, npt, nirr, irr_idx, wsym, want, 0, npt, out);
-}
+} ABZ_CATCH_ALL
 
 static int rule_build_sym(abz_series* s, int npt, const int32_t* syms, int nsyms, int want, abz_rule** out, bool wait);
-int abz_ptr_rule_build_sym(abz_series* s, int npt, const int32_t* syms, int nsyms, int want, abz_rule** out) {
+int abz_ptr_rule_build_sym(abz_series* s, int npt, const int32_t* syms, int nsyms, int want, abz_rule** out) try {
     return rule_build_sym(s, npt, syms, nsyms, want, out, true);
-}
+} ABZ_CATCH_ALL
 static int rule_build_sym(abz_series* s, int npt, const int32_t* syms, int nsyms, int want, abz_rule** out, bool wait) {
     int rc = check_series(s);
     if (rc) return rc;
@@ -1253,16 +1278,16 @@ static int rule_build_sym(abz_series* s, int npt, const int32_t* syms, int nsyms
     return rule_build(s, npt, 0, nullptr, nullptr, want, 0, npt, out, st, wait);
 }
 
-int abz_ptr_rule_build_slab(abz_series* s, int npt, int outer_begin, int outer_end, int want, abz_rule** out) {
+int abz_ptr_rule_build_slab(abz_series* s, int npt, int outer_begin, int outer_end, int want, abz_rule** out) try {
     int rc = check_series(s);
     if (rc) return rc;
     ABZ_REQUIRE(s->d >= 2, "a slab needs at least two variables (d = %d)", s->d);
     ABZ_REQUIRE(0 <= outer_begin && outer_begin < outer_end && outer_end <= npt,
                 "slab [%d, %d) outside the grid of %d points", outer_begin, outer_end, npt);
     return rule_build(s, npt, 0, nullptr, nullptr, want, outer_begin, outer_end - outer_begin, out);
-}
+} ABZ_CATCH_ALL
 
-int abz_rule_rebuild(abz_rule* r) {
+int abz_rule_rebuild(abz_rule* r) try {
     int rc0 = check_rule(r);
     if (rc0) return rc0;
     abz_ctx* ctx = r->s->ctx;
@@ -1275,9 +1300,9 @@ int abz_rule_rebuild(abz_rule* r) {
         if ((rc = rp->tmpD.reserve(tb))) return rc;
     }
     return rule_fill(r);
-}
+} ABZ_CATCH_ALL
 
-int abz_rule_info(const abz_rule* r, int64_t* nk, int* n, int* d, int* npt, int* want) {
+int abz_rule_info(const abz_rule* r, int64_t* nk, int* n, int* d, int* npt, int* want) try {
     ABZ_REQUIRE(r, "null rule");
     if (nk) *nk = r->nk;
     if (n) *n = r->s->n;
@@ -1285,9 +1310,9 @@ int abz_rule_info(const abz_rule* r, int64_t* nk, int* n, int* d, int* npt, int*
     if (npt) *npt = r->npt;
     if (want) *want = r->want;
     return ABZ_OK;
-}
+} ABZ_CATCH_ALL
 
-int abz_rule_export(abz_rule* r, double* x, double* w, double* H, double* eig, double* vel) {
+int abz_rule_export(abz_rule* r, double* x, double* w, double* H, double* eig, double* vel) try {
     int rc0 = check_rule(r);
     if (rc0) return rc0;
     abz_ctx* ctx = r->s->ctx;
@@ -1333,28 +1358,28 @@ int abz_rule_export(abz_rule* r, double* x, double* w, double* H, double* eig, d
         if (rc) return rc;
     }
     return ABZ_OK;
-}
+} ABZ_CATCH_ALL
 
 static int rule_reduce(abz_rule* r, int integrand, const double* params, int nparams, const double* sweep, int n_sweep,
                        int nsyms, double* out_reim, bool device_io, double2* map_dev = nullptr);
 
 int abz_rule_reduce(abz_rule* r, int integrand, const double* params, int nparams, const double* sweep, int n_sweep,
-                    int nsyms, double* out_reim) {
+                    int nsyms, double* out_reim) try {
     return rule_reduce(r, integrand, params, nparams, sweep, n_sweep, nsyms, out_reim, false);
-}
+} ABZ_CATCH_ALL
 
 int abz_rule_reduce_device(abz_rule* r, int integrand, const double* params, int nparams, const double* sweep_dev,
-                           int n_sweep, int nsyms, double* out_dev_reim) {
+                           int n_sweep, int nsyms, double* out_dev_reim) try {
     return rule_reduce(r, integrand, params, nparams, sweep_dev, n_sweep, nsyms, out_dev_reim, true);
-}
+} ABZ_CATCH_ALL
 
-int abz_rule_values_ptr(const abz_rule* r, void** base, int64_t* nbytes) {
+int abz_rule_values_ptr(const abz_rule* r, void** base, int64_t* nbytes) try {
     int rc0 = check_rule(r);
     if (rc0) return rc0;
     if (base) *base = r->vals;
     if (nbytes) *nbytes = (int64_t)sizeof(double) * r->ntiles * r->planes * (r->H.base ? r->H.row : r->E.row);
     return ABZ_OK;
-}
+} ABZ_CATCH_ALL
 
 // device_io: `sweep` and `out_reim` are device pointers, nothing is synchronised; with `map_dev` (n <= 4) the sums are
 // written by the last kernel straight into that device-visible host address instead of `out_reim`
@@ -1427,7 +1452,7 @@ static int rule_reduce(abz_rule* r, int integrand, const double* params, int npa
 }
 
 int abz_ptr_sum(abz_series* s, int npt, int outer_begin, int outer_end, int integrand, const double* params, int nparams,
-                const double* sweep, int n_sweep, int nsyms, double* out_reim) {
+                const double* sweep, int n_sweep, int nsyms, double* out_reim) try {
     int rc = check_series(s);
     if (rc) return rc;
     ABZ_REQUIRE(out_reim, "null out");
@@ -1500,7 +1525,7 @@ int abz_ptr_sum(abz_series* s, int npt, int outer_begin, int outer_end, int inte
     rc = generic ? launch_gen_sum(ctx, ss, out_reim) : launch_eval_sum(ctx, ss, out_reim);
     (void)hipStreamSynchronize(ctx->stream);
     return done(rc);
-}
+} ABZ_CATCH_ALL
 
 // ---------------------------------------------------------------- whole AutoPTR solves
 // The rule of grid `npt` kept by the series (built on first use, refilled after abz_series_update).  `keep` = false: a
@@ -1559,7 +1584,7 @@ static size_t rule_value_bytes(const abz_series* s, int npt, int64_t nk, int wan
 int abz_autoptr_solve_many(abz_series* s, const int32_t* syms, int nsyms, int integrand, const double* params, int nparams,
                            const double* sweeps, int n_sweep, int n0, int dn, double abstol, double reltol, int64_t maxevals,
                            int keepmost, double value_factor, double* out_reim, double* err_out, int64_t* numevals_out,
-                           int32_t* npt_out) {
+                           int32_t* npt_out) try {
     int rc = check_series(s);
     if (rc) return rc;
     ABZ_REQUIRE(out_reim && n_sweep >= 1 && n0 >= 1 && dn >= 1, "abz_autoptr_solve_many: bad arguments (n0 = %d, dn = %d, n_sweep = %d)", n0, dn, n_sweep);
@@ -1827,16 +1852,16 @@ int abz_autoptr_solve_many(abz_series* s, const int32_t* syms, int nsyms, int in
     s->auto_hint_key = hint_key;
     s->auto_hint_grids = gindex + 1;
     return ABZ_OK;
-}
+} ABZ_CATCH_ALL
 
 int abz_autoptr_solve(abz_series* s, const int32_t* syms, int nsyms, int integrand, const double* params, int nparams, double sweep,
                       int n0, int dn, double abstol, double reltol, int64_t maxevals, int keepmost, double value_factor,
-                      double* out_reim, double* err_out, int64_t* numevals_out, int32_t* npt_out) {
+                      double* out_reim, double* err_out, int64_t* numevals_out, int32_t* npt_out) try {
     return abz_autoptr_solve_many(s, syms, nsyms, integrand, params, nparams, &sweep, 1, n0, dn, abstol, reltol, maxevals, keepmost,
                                   value_factor, out_reim, err_out, numevals_out, npt_out);
-}
+} ABZ_CATCH_ALL
 
-int abz_rule_ggr(abz_rule* r, const double* E, int nE, double* out) {
+int abz_rule_ggr(abz_rule* r, const double* E, int nE, double* out) try {
     int rc0 = check_rule(r);
     if (rc0) return rc0;
     ABZ_REQUIRE(E && out && nE >= 1, "abz_rule_ggr: bad arguments");
@@ -1844,10 +1869,10 @@ int abz_rule_ggr(abz_rule* r, const double* E, int nE, double* out) {
     abz_ctx* ctx = r->s->ctx;
     ABZ_HIP(hipSetDevice(ctx->device));
     return launch_ggr(ctx, r->s->n, r->s->d, r->npt, r->E, r->V, r->w, r->nk, E, nE, out);
-}
+} ABZ_CATCH_ALL
 
 // ---------------------------------------------------------------- arbitrary nodes
-int abz_eval_nodes(abz_series* s, const double* k, int64_t nk, int want, double* H_out, double* eig_out) {
+int abz_eval_nodes(abz_series* s, const double* k, int64_t nk, int want, double* H_out, double* eig_out) try {
     int rc = check_series(s);
     if (rc) return rc;
     ABZ_REQUIRE(k || nk == 0, "null nodes");
@@ -1919,6 +1944,6 @@ int abz_eval_nodes(abz_series* s, const double* k, int64_t nk, int want, double*
     Ed.release();
     pd.release();
     return status;
-}
+} ABZ_CATCH_ALL
 
 }  // extern "C"

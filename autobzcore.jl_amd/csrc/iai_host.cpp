@@ -18,6 +18,7 @@
 #include <cmath>
 #include <complex>
 #include <deque>
+#include <exception>
 #include <memory>
 #include <cstdlib>
 #include <cstring>
@@ -65,12 +66,28 @@ public:
         cv_.notify_all();
         share(0);
         while (pending_.load(std::memory_order_acquire) != 0) std::this_thread::yield();
+        if (failed_.load(std::memory_order_acquire)) {  // a share threw (std::bad_alloc ...): rethrow on the caller's thread,
+            std::exception_ptr e;                         // where the entry point's catch-all turns it into a status
+            {
+                std::lock_guard<std::mutex> lk(m_);
+                e = error_;
+                error_ = nullptr;
+                failed_.store(false, std::memory_order_relaxed);
+            }
+            if (e) std::rethrow_exception(e);
+        }
     }
 
 private:
     void share(int t) {
         const int64_t b = count_ * t / n_, e = count_ * (t + 1) / n_;
-        if (e > b) (*fn_)(b, e, t);
+        try {
+            if (e > b) (*fn_)(b, e, t);
+        } catch (...) {  // never out of a worker thread (that is std::terminate)
+            std::lock_guard<std::mutex> lk(m_);
+            if (!error_) error_ = std::current_exception();
+            failed_.store(true, std::memory_order_release);
+        }
     }
     void loop(int t) {
         uint64_t seen = 0;
@@ -94,6 +111,8 @@ private:
     const std::function<void(int64_t, int64_t, int)>* fn_ = nullptr;
     int64_t count_ = 0;
     std::atomic<int> pending_{0};
+    std::atomic<bool> failed_{false};
+    std::exception_ptr error_;
 };
 
 void gk15_nodes(double a, double b, double* x) {
@@ -1405,20 +1424,20 @@ using namespace abz;
 
 extern "C" {
 
-int abz_gk15_nodes(double a, double b, double* x15) {
+int abz_gk15_nodes(double a, double b, double* x15) try {
     ABZ_REQUIRE(x15, "null output");
     gk15_nodes(a, b, x15);
     return ABZ_OK;
-}
+} ABZ_CATCH_ALL
 
-int abz_gk15_batch(const double* ab, const double* values_reim, int64_t npanels, int ncomp, double* I_reim, double* E) {
+int abz_gk15_batch(const double* ab, const double* values_reim, int64_t npanels, int ncomp, double* I_reim, double* E) try {
     ABZ_REQUIRE(ab && values_reim && I_reim && E && npanels >= 0 && ncomp >= 1, "abz_gk15_batch: bad arguments");
     const cd* fv = reinterpret_cast<const cd*>(values_reim);
     cd* I = reinterpret_cast<cd*>(I_reim);
     for (int64_t p = 0; p < npanels; ++p)
         gk15_evalrule(fv + (size_t)p * 15 * ncomp, ncomp, ab[2 * p], ab[2 * p + 1], I + (size_t)p * ncomp, E + p);
     return ABZ_OK;
-}
+} ABZ_CATCH_ALL
 
 static int iai_solve_lane(abz_series* s, int lims_kind, const double* lim_a, const double* lim_b, int integrand,
                           const double* params, int nparams, const double* sweeps, int n_sweep, double abstol, double reltol,
@@ -1555,7 +1574,7 @@ static int iai_solve_lane(abz_series* s, int lims_kind, const double* lim_a, con
 int abz_iai_solve_many(abz_series* s, int lims_kind, const double* lim_a, const double* lim_b, int integrand,
                        const double* params, int nparams, const double* sweeps, int n_sweep, double abstol, double reltol,
                        int64_t maxevals, int64_t max_batch, double* out_reim, double* err, int64_t* numevals,
-                       double* panels, int64_t max_panels, int64_t* npanels) {
+                       double* panels, int64_t max_panels, int64_t* npanels) try {
     int lanes = 1, ncomp = 0;
     if (s && s->ctx && !s->closed && !s->ctx->closed && sweeps && out_reim && lim_a && !panels && !s->ex_fn && !s->coef_borrowed &&
         (ncomp = integrand_ncomp(integrand, s->n, s->d)) > 0)
@@ -1575,17 +1594,34 @@ int abz_iai_solve_many(abz_series* s, int lims_kind, const double* lim_a, const 
     auto run = [&](int j) {
         LaneJob& q = jobs[(size_t)j];
         const int m = (int)q.sw.size();
-        q.out.resize((size_t)m * ncomp * 2);
-        q.err.resize((size_t)m);
-        q.nev.resize((size_t)m);
-        q.rc = iai_solve_lane(j == 0 ? s : s->lanes[(size_t)j - 1], lims_kind, lim_a, lim_b, integrand, params, nparams, q.sw.data(), m,
-                              abstol, reltol, maxevals, max_batch, q.out.data(), q.err.data(), q.nev.data(), nullptr, 0,
-                              j == 0 ? npanels : nullptr);
-        if (q.rc) q.msg = abz_last_error();  // (the message is per thread)
+        try {
+            q.out.resize((size_t)m * ncomp * 2);
+            q.err.resize((size_t)m);
+            q.nev.resize((size_t)m);
+            q.rc = iai_solve_lane(j == 0 ? s : s->lanes[(size_t)j - 1], lims_kind, lim_a, lim_b, integrand, params, nparams, q.sw.data(), m,
+                                  abstol, reltol, maxevals, max_batch, q.out.data(), q.err.data(), q.nev.data(), nullptr, 0,
+                                  j == 0 ? npanels : nullptr);
+        } catch (...) {  // a lane is a std::thread: an exception leaving it would be std::terminate
+            q.rc = catch_status();
+        }
+        if (q.rc) {
+            try {
+                q.msg = abz_last_error();  // (the message is per thread)
+            } catch (...) {
+            }
+        }
     };
     std::vector<std::thread> th;
-    for (int j = 1; j < lanes; ++j) th.emplace_back(run, j);
-    run(0);
+    th.reserve((size_t)lanes);
+    std::vector<int> inline_lanes{0};
+    for (int j = 1; j < lanes; ++j) {
+        try {
+            th.emplace_back(run, j);
+        } catch (...) {  // no thread to be had: that lane runs on the caller's thread after lane 0
+            inline_lanes.push_back(j);
+        }
+    }
+    for (int j : inline_lanes) run(j);
     for (auto& t : th) t.join();
     for (auto& q : jobs)
         if (q.rc) {
@@ -1600,19 +1636,19 @@ int abz_iai_solve_many(abz_series* s, int lims_kind, const double* lim_a, const 
         if (numevals) numevals[r] = q.nev[i];
     }
     return ABZ_OK;
-}
+} ABZ_CATCH_ALL
 
 int abz_iai_solve(abz_series* s, int lims_kind, const double* lim_a, const double* lim_b, int integrand,
                   const double* params, int nparams, double sweep, double abstol, double reltol, int64_t maxevals,
                   int64_t max_batch, double* out_reim, double* err, int64_t* numevals, double* panels,
-                  int64_t max_panels, int64_t* npanels) {
+                  int64_t max_panels, int64_t* npanels) try {
     return abz_iai_solve_many(s, lims_kind, lim_a, lim_b, integrand, params, nparams, &sweep, 1, abstol, reltol, maxevals,
                               max_batch, out_reim, err, numevals, panels, max_panels, npanels);
-}
+} ABZ_CATCH_ALL
 
 // ---- building blocks for a host-language (Julia) adaptive loop -------------------------------
 int abz_contract_nodes(abz_series* s, int src_level, const int64_t* parents, const double* x, int64_t nnodes,
-                       int64_t* slots_out) {
+                       int64_t* slots_out) try {
     ABZ_REQUIRE(s && s->ctx && !s->closed && !s->ctx->closed && parents && x && slots_out, "abz_contract_nodes: null argument");
     ABZ_REQUIRE(src_level >= 2 && src_level <= s->d, "src_level = %d must be in 2..d", src_level);
     ABZ_HIP(hipSetDevice(s->ctx->device));
@@ -1645,10 +1681,10 @@ int abz_contract_nodes(abz_series* s, int src_level, const int64_t* parents, con
     for (int64_t i = 0; i < nnodes; ++i) slots_out[i] = base + i;
     s->iai_used[src_level - 1] = base + nnodes;
     return ABZ_OK;
-}
+} ABZ_CATCH_ALL
 
 int abz_eval_line_nodes(abz_series* s, const int64_t* parents, const double* x, const double* tail, int64_t nnodes,
-                        int integrand, const double* params, int nparams, double sweep, double* values_reim) {
+                        int integrand, const double* params, int nparams, double sweep, double* values_reim) try {
     ABZ_REQUIRE(s && s->ctx && !s->closed && !s->ctx->closed && parents && x && values_reim, "abz_eval_line_nodes: null argument");
     ABZ_REQUIRE(nparams >= 0 && nparams <= 4, "nparams = %d not in 0..4", nparams);
     ABZ_HIP(hipSetDevice(s->ctx->device));
@@ -1672,9 +1708,9 @@ int abz_eval_line_nodes(abz_series* s, const int64_t* parents, const double* x, 
     if (rc) return rc;
     std::memcpy(values_reim, drv.h_values.data(), sizeof(double2) * (size_t)(nnodes * drv.ncomp));
     return ABZ_OK;
-}
+} ABZ_CATCH_ALL
 
-int abz_iai_set_exchange(abz_series* s, abz_exchange_fn fn, void* user, int rank, int world) {
+int abz_iai_set_exchange(abz_series* s, abz_exchange_fn fn, void* user, int rank, int world) try {
     ABZ_REQUIRE(s && s->ctx && !s->closed, "abz_iai_set_exchange: null or destroyed series");
     ABZ_REQUIRE(fn == nullptr || (world >= 1 && rank >= 0 && rank < world), "rank %d of %d", rank, world);
     s->ex_fn = fn;  // world == 1 keeps the hook: a one-rank rehearsal of the exchange (the collective is then the identity)
@@ -1682,12 +1718,12 @@ int abz_iai_set_exchange(abz_series* s, abz_exchange_fn fn, void* user, int rank
     s->ex_rank = s->ex_fn ? rank : 0;
     s->ex_world = s->ex_fn ? world : 1;
     return ABZ_OK;
-}
+} ABZ_CATCH_ALL
 
-int abz_release_level(abz_series* s, int level) {
+int abz_release_level(abz_series* s, int level) try {
     ABZ_REQUIRE(s && level >= 1 && level <= s->d, "abz_release_level: bad level");
     for (int L = 1; L < level && L <= ABZ_MAX_DIM; ++L) s->iai_used[L] = 0;
     return ABZ_OK;
-}
+} ABZ_CATCH_ALL
 
 }  // extern "C"

@@ -578,7 +578,7 @@ int sym_tables_device(abz_ctx* ctx, int npt, int d, const int32_t* syms, int nsy
 }  // namespace abz
 
 extern "C" int abz_symptr_rule_device(abz_ctx* ctx, int npt, int d, const int32_t* syms, int nsyms, int64_t* nirr,
-                                      int32_t* irr_idx, int64_t* wsym) {
+                                      int32_t* irr_idx, int64_t* wsym) try {
     ABZ_REQUIRE(ctx, "null ctx");
     ABZ_REQUIRE(npt >= 1 && d >= 1 && d <= ABZ_MAX_DIM, "symptr_rule: npt = %d, d = %d invalid", npt, d);
     ABZ_REQUIRE(syms && nsyms >= 1 && nirr, "symptr_rule: null argument");
@@ -606,4 +606,4 @@ extern "C" int abz_symptr_rule_device(abz_ctx* ctx, int npt, int d, const int32_
     }
     *nirr = n;
     return ABZ_OK;
-}
+} ABZ_CATCH_ALL

@@ -19,7 +19,7 @@ thread_local SymptrCache g_cache;
 }  // namespace
 
 extern "C" int abz_symptr_rule(int npt, int d, const int32_t* syms, int nsyms, int64_t* nirr, int32_t* irr_idx,
-                               int64_t* wsym) {
+                               int64_t* wsym) try {
     ABZ_REQUIRE(npt >= 1 && d >= 1 && d <= ABZ_MAX_DIM, "symptr_rule: npt = %d, d = %d invalid", npt, d);
     ABZ_REQUIRE(syms && nsyms >= 1 && nirr, "symptr_rule: null argument");
     ABZ_REQUIRE((irr_idx == nullptr) == (wsym == nullptr), "irr_idx and wsym must be given together");
@@ -77,4 +77,4 @@ extern "C" int abz_symptr_rule(int npt, int d, const int32_t* syms, int nsyms, i
     }
     *nirr = n;
     return ABZ_OK;
-}
+} ABZ_CATCH_ALL

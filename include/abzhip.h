@@ -41,6 +41,7 @@ extern "C" {
 #define ABZ_ERR_NOGPU (-3)   /* no usable gfx950 device: the product has NO CPU fallback */
 #define ABZ_ERR_UNSUPPORTED (-4)
 #define ABZ_ERR_NOMEM (-5)
+#define ABZ_ERR_INTERNAL (-6) /* a C++ exception was caught at the boundary (none crosses it); text in abz_last_error() */
 
 #define ABZ_MAX_DIM 3        /* BZ dimension d = 1..3 (ref tests: test/fourier.jl:10,43) */
 #define ABZ_MAX_BANDS 32     /* n x n Hamiltonians up to n = 32 */
@@ -53,11 +54,11 @@ typedef struct abz_rule abz_rule;     /* device-resident cached rule values (Fou
 #define ABZ_WANT_H 1    /* series values H(k): FourierValue.s, ref src/fourier.jl:111-114 */
 #define ABZ_WANT_EIG 2  /* ascending eigenvalues of Hermitian(H(k)) (upper triangle), ref src/dos_ggr.jl:19,34 */
 #define ABZ_WANT_VEL 4  /* band velocities Re diag(U' dH/dk_j U) * t_j, ref src/dos_ggr.jl:20,35 (implies EIG) */
-/* With ABZ_WANT_H, for a Hermitian series of n <= 4 bands: keep H(k) as its UPPER TRIANGLE only (what Hermitian(h) reads,
+/* With ABZ_WANT_H, for a Hermitian series of n <= 16 bands: keep H(k) as its UPPER TRIANGLE only (what Hermitian(h) reads,
  * src/dos_ggr.jl:19,34) -- n^2 value planes instead of 2 n^2, e.g. 96 instead of 168 bytes per k-point for 3 bands + eig.
  * The lower triangle is the conjugate of the upper one bit for bit, so nothing is lost: abz_rule_export still returns
  * the full matrices and every built-in integrand reads the compact planes.  Ignored (full layout) for series that are
- * not Hermitian or have more than 4 bands; abz_rule_info reports the bit only when the rule really is compact.
+ * not Hermitian or have more than 16 bands; abz_rule_info reports the bit only when the rule really is compact.
  * Plane order inside a tile: Re H[a][b], Im H[a][b] for a < b at planes b^2 + 2a, b^2 + 2a + 1; H[b][b] at b^2 + 2b. */
 #define ABZ_WANT_H_COMPACT 8
 

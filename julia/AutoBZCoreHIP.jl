@@ -153,6 +153,14 @@ bind(::Union{DOSIntegrand,TrGlocIntegrand,GlocIntegrand}, p::MixedParameters) =
 bind(::LinearIntegrand, p::MixedParameters) = (Float64[p[1], getfield(p, :kwargs).b], 0.0)
 bind(::UnitIntegrand, p) = (Float64[], 0.0)
 
+"Components of a device integrand's value (the library's integrand_ncomp): the buffers below are sized with it."
+ncomp(::GlocIntegrand, n::Int, d::Int) = n * n
+ncomp(::HIPIntegrand, n::Int, d::Int) = 1
+"complex [ncomp] from the device -> the value the reference integrand returns (real only where the integrand is real)."
+shape_value(::Union{DOSIntegrand,UnitIntegrand}, v::AbstractVector{ComplexF64}, n::Int) = real(v[1])
+shape_value(::GlocIntegrand, v::AbstractVector{ComplexF64}, n::Int) = n == 1 ? v[1] : SMatrix{n,n,ComplexF64,n * n}(v)  # column-major block
+shape_value(::HIPIntegrand, v::AbstractVector{ComplexF64}, n::Int) = v[1]          # TrGloc, Linear: complex scalars
+
 const HIPFourierIntegrand = FourierIntegrand{<:HIPIntegrand}
 
 "rule(f, B) = quadsum(...) (src/fourier.jl:204-207,289-292) for all sweep values in one pass."
@@ -171,13 +179,13 @@ end
 # src/interfaces.jl:174-179 nothing is rebuilt per solver call.
 AutoBZCore.init_cacheval(f::HIPFourierIntegrand, bz::SymmetricBZ, p, ::Union{PTR,AutoPTR,IAI}) = HIPSeries(f.w.series)
 
-function AutoBZCore.do_solve(f::HIPFourierIntegrand, bz::SymmetricBZ, p, alg::PTR, hs::HIPSeries;
-    abstol=nothing, reltol=nothing, maxiters=typemax(Int))
+function AutoBZCore.do_solve(f::HIPFourierIntegrand, bz::SymmetricBZ, p, alg::PTR, hs::HIPSeries{d};
+    abstol=nothing, reltol=nothing, maxiters=typemax(Int)) where {d}
     j = abs(det(bz.B))                                   # src/brillouin.jl:340
     r = rule!(hs, alg.npt, bz.syms, WANT_HC)
     params, omega = bind(f.f.f, merge(f.f.p, p))
-    u = reduce_rule(r, f.f.f, params, [omega], 1)[1, 1]
-    return IntegralSolution(j * nsyms(bz) * real(u), nothing, true, r.nk)   # TrivialRep: src/brillouin.jl:107
+    u = reduce_rule(r, f.f.f, params, [omega], ncomp(f.f.f, hs.n, d))
+    return IntegralSolution(j * nsyms(bz) * shape_value(f.f.f, view(u, :, 1), hs.n), nothing, true, r.nk)   # TrivialRep: src/brillouin.jl:107
 end
 
 """
@@ -192,8 +200,8 @@ function autoptr_solve(hs::HIPSeries{d}, f::HIPIntegrand, params::Vector{Float64
     dn = clamp(round(Int, alg.Δn / alg.a), alg.nmin, alg.nmax)
     syms = bz.syms === nothing ? Cint[] : Cint[round(Int, M[a, b]) for M in bz.syms for a in 1:d for b in 1:d]
     ns = bz.syms === nothing ? 0 : length(bz.syms)
-    nsolve = length(omegas)
-    out = Vector{ComplexF64}(undef, nsolve); err = Vector{Float64}(undef, nsolve)
+    nsolve = length(omegas); nc = ncomp(f, hs.n, d)
+    out = Vector{ComplexF64}(undef, nc * nsolve); err = Vector{Float64}(undef, nsolve)   # the library writes nc values per solve
     nev = Vector{Int64}(undef, nsolve); npt = Vector{Cint}(undef, nsolve)
     GC.@preserve syms params omegas out err nev npt begin
         check(ccall((:abz_autoptr_solve_many, libabz), Cint,
@@ -205,13 +213,34 @@ function autoptr_solve(hs::HIPSeries{d}, f::HIPIntegrand, params::Vector{Float64
             Float64(nsyms(bz)),                                      # TrivialRep inside every rule: src/brillouin.jl:127-130
             out, err, nev, npt))
     end
-    return [IntegralSolution(real(out[i]) * j, err[i] * j, true, Int(nev[i])) for i in 1:nsolve]
+    vals = reshape(out, nc, nsolve)
+    return [IntegralSolution(shape_value(f, view(vals, :, i), hs.n) * j, err[i] * j, true, Int(nev[i])) for i in 1:nsolve]
+end
+
+"One AutoPTR solve through the single-value entry point (abz_autoptr_solve): what `do_solve(::AutoPTR)` calls."
+function autoptr_solve(hs::HIPSeries{d}, f::HIPIntegrand, params::Vector{Float64}, omega::Float64, bz::SymmetricBZ,
+    alg::AutoPTR; abstol=nothing, reltol=nothing, maxiters=typemax(Int)) where {d}
+    j = abs(det(bz.B))
+    n0 = clamp(round(Int, alg.n₀ / alg.a), alg.nmin, alg.nmax)
+    dn = clamp(round(Int, alg.Δn / alg.a), alg.nmin, alg.nmax)
+    syms = bz.syms === nothing ? Cint[] : Cint[round(Int, M[a, b]) for M in bz.syms for a in 1:d for b in 1:d]
+    ns = bz.syms === nothing ? 0 : length(bz.syms)
+    out = Vector{ComplexF64}(undef, ncomp(f, hs.n, d)); err = Ref{Float64}(0); nev = Ref{Int64}(0); npt = Ref{Cint}(0)
+    GC.@preserve syms params out begin
+        check(ccall((:abz_autoptr_solve, libabz), Cint,
+            (Ptr{Cvoid}, Ptr{Cint}, Cint, Cint, Ptr{Float64}, Cint, Float64, Cint, Cint, Float64, Float64, Int64, Cint,
+             Float64, Ptr{ComplexF64}, Ptr{Float64}, Ptr{Int64}, Ptr{Cint}),
+            hs.h, ns == 0 ? C_NULL : pointer(syms), ns, fid(f), params, length(params), omega, n0, dn,
+            abstol === nothing ? -1.0 : abstol / j, reltol === nothing ? -1.0 : reltol,
+            min(maxiters, typemax(Int64) >> 1), alg.keepmost, Float64(nsyms(bz)), out, err, nev, npt))
+    end
+    return IntegralSolution(shape_value(f, out, hs.n) * j, err[] * j, true, Int(nev[]))
 end
 
 function AutoBZCore.do_solve(f::HIPFourierIntegrand, bz::SymmetricBZ, p, alg::AutoPTR, hs::HIPSeries;
     abstol=nothing, reltol=nothing, maxiters=typemax(Int))
     params, omega = bind(f.f.f, merge(f.f.p, p))
-    return autoptr_solve(hs, f.f.f, params, [omega], bz, alg; abstol, reltol, maxiters)[1]
+    return autoptr_solve(hs, f.f.f, params, omega, bz, alg; abstol, reltol, maxiters)
 end
 
 function AutoBZCore.do_solve(f::HIPFourierIntegrand, bz::SymmetricBZ, p, alg::IAI, hs::HIPSeries{d};
@@ -219,8 +248,8 @@ function AutoBZCore.do_solve(f::HIPFourierIntegrand, bz::SymmetricBZ, p, alg::IA
     j = abs(det(bz.B)); ns = nsyms(bz)
     params, omega = bind(f.f.f, merge(f.f.p, p))
     kind, a, b = pack_limits(bz.lims)
-    out = Ref{ComplexF64}(0); err = Ref{Float64}(0); nev = Ref{Int64}(0); npan = Ref{Int64}(0)
-    GC.@preserve params a b begin
+    out = Vector{ComplexF64}(undef, ncomp(f.f.f, hs.n, d)); err = Ref{Float64}(0); nev = Ref{Int64}(0); npan = Ref{Int64}(0)
+    GC.@preserve params a b out begin
         check(ccall((:abz_iai_solve, libabz), Cint,
             (Ptr{Cvoid}, Cint, Ptr{Float64}, Ptr{Float64}, Cint, Ptr{Float64}, Cint, Float64, Float64, Float64, Int64, Int64,
              Ptr{ComplexF64}, Ptr{Float64}, Ptr{Int64}, Ptr{Float64}, Int64, Ptr{Int64}),
@@ -229,7 +258,7 @@ function AutoBZCore.do_solve(f::HIPFourierIntegrand, bz::SymmetricBZ, p, alg::IA
             reltol === nothing ? -1.0 : Float64(reltol), min(maxiters, typemax(Int64) >> 1), 0,
             out, err, nev, C_NULL, 0, npan))
     end
-    return IntegralSolution(j * ns * real(out[]), j * ns * err[], true, nev[])
+    return IntegralSolution(j * ns * shape_value(f.f.f, out, hs.n), j * ns * err[], true, nev[])
 end
 
 # ---------------------------------------------------------------- BatchIntegrand body for user closures
@@ -261,8 +290,8 @@ function AutoBZCore.batchsolve(s::IntegralSolver{<:HIPFourierIntegrand,<:Symmetr
     hs = HIPSeries(f.w.series)
     r = rule!(hs, s.alg.npt, bz.syms, WANT_HC)
     params, _ = bind(f.f.f, merge(f.f.p, MixedParameters(first(omegas))))
-    u = reduce_rule(r, f.f.f, params, Float64.(omegas), 1)
-    return abs(det(bz.B)) * nsyms(bz) .* real.(vec(u))
+    u = reduce_rule(r, f.f.f, params, Float64.(omegas), ncomp(f.f.f, hs.n, ndims(f.w.series.c)))
+    return [abs(det(bz.B)) * nsyms(bz) * shape_value(f.f.f, view(u, :, i), hs.n) for i in axes(u, 2)]
 end
 
 "batchsolve for a HIP integrand under AutoPTR: the solves refine in lock-step, every grid is visited once for all that are still active."
@@ -283,7 +312,8 @@ function AutoBZCore.batchsolve(s::IntegralSolver{<:HIPFourierIntegrand,<:Symmetr
     params, _ = bind(f.f.f, merge(f.f.p, MixedParameters(first(omegas))))
     kind, a, b = pack_limits(bz.lims)
     abstol = get(s.kwargs, :abstol, nothing); reltol = get(s.kwargs, :reltol, nothing)
-    sw = Float64.(omegas); out = Vector{ComplexF64}(undef, m); err = Vector{Float64}(undef, m); nev = Vector{Int64}(undef, m)
+    nc = ncomp(f.f.f, hs.n, ndims(f.w.series.c))
+    sw = Float64.(omegas); out = Vector{ComplexF64}(undef, nc * m); err = Vector{Float64}(undef, m); nev = Vector{Int64}(undef, m)
     npan = Ref{Int64}(0)
     GC.@preserve params a b sw out err nev begin
         check(ccall((:abz_iai_solve_many, libabz), Cint,
@@ -293,17 +323,20 @@ function AutoBZCore.batchsolve(s::IntegralSolver{<:HIPFourierIntegrand,<:Symmetr
             abstol === nothing ? -1.0 : abstol / (j * ns), reltol === nothing ? -1.0 : Float64(reltol),
             typemax(Int64) >> 1, 0, out, err, nev, C_NULL, 0, npan))
     end
-    return j * ns .* real.(out)
+    vals = reshape(out, nc, m)
+    return [j * ns * shape_value(f.f.f, view(vals, :, i), hs.n) for i in 1:m]
 end
 
 # ---------------------------------------------------------------- store-free rule value
 "rule(f, B) on the full npt^d grid without materialising FourierPTR (abz_ptr_sum): grids used once or beyond HBM."
-function ptr_sum(hs::HIPSeries, npt::Integer, f, params::Vector{Float64}, omegas::Vector{Float64}; z0=0, z1=npt, nsyms=1)
-    out = Vector{ComplexF64}(undef, length(omegas))
+function ptr_sum(hs::HIPSeries{d}, npt::Integer, f::HIPIntegrand, params::Vector{Float64}, omegas::Vector{Float64};
+    z0=0, z1=npt, nsyms::Integer=1) where {d}
+    nc = ncomp(f, hs.n, d)
+    out = Vector{ComplexF64}(undef, nc * length(omegas))                 # [ncomp, n_sweep] like reduce_rule
     GC.@preserve params omegas out check(ccall((:abz_ptr_sum, libabz), Cint,
         (Ptr{Cvoid}, Cint, Cint, Cint, Cint, Ptr{Float64}, Cint, Ptr{Float64}, Cint, Cint, Ptr{ComplexF64}),
         hs.h, npt, z0, z1, fid(f), params, length(params), omegas, length(omegas), nsyms, out))
-    return out
+    return nc == 1 ? out : reshape(out, nc, :)
 end
 
 # ---------------------------------------------------------------- k-sharded rules (one solve on several GPUs)
@@ -361,17 +394,6 @@ function rule_sum(f, r::HIPRule, hs::HIPSeries{d}, args...; kws...) where {d}
     ex = export_rule(r, hs)
     acc = sum(ex.w[i] * f(FourierValue(ex.x[i], ex.H[i]), args...; kws...) for i in eachindex(ex.x))
     return acc / (r.npt^d * r.nsyms)
-end
-
-"Store-free rule value (abz_ptr_sum): the number `reduce_rule` gives on the full grid, without materialising H(k)."
-function ptr_sum(hs::HIPSeries, npt::Integer, f::HIPIntegrand, params::Vector{Float64}, sweep::Vector{Float64}; nsyms::Integer=1)
-    out = Vector{ComplexF64}(undef, length(sweep))
-    GC.@preserve params sweep out begin
-        check(ccall((:abz_ptr_sum, libabz), Cint,
-            (Ptr{Cvoid}, Cint, Cint, Cint, Cint, Ptr{Float64}, Cint, Ptr{Float64}, Cint, Cint, Ptr{ComplexF64}),
-            hs.h, npt, 0, npt, fid(f), params, length(params), sweep, length(sweep), nsyms, out))
-    end
-    return out
 end
 
 "Drop the rules the library keeps with the series for `abz_autoptr_solve*`."

@@ -241,7 +241,7 @@ def test_dos3_sweep_kernel_against_oracle_and_generic_scan(abz, monkeypatch):
         rule.close()
 
 
-@pytest.mark.parametrize("n", [2, 3])
+@pytest.mark.parametrize("n", [2, 3, 6, 12])
 def test_rule_reduce_non_hermitian_series(abz, n):
     """A series that is NOT Hermitian (e.g. H + a k-dependent self-energy) takes the general paths:
     full-matrix Fourier evaluation and the complex characteristic polynomial in the scan.  The decay of
@@ -1483,7 +1483,7 @@ def test_ggr_velocities_match_oracle(abz, svo):
     assert np.abs(out["vel"].sum(axis=2) - v.sum(axis=2)).max() < 1e-8
 
 
-@pytest.mark.parametrize("n", [6, 12, 16])
+@pytest.mark.parametrize("n", [6, 12, 16, 17, 24, 32])
 def test_ggr_more_than_four_bands(abz, n):
     """GGR for n > 4 (ref: src/dos_ggr.jl:1-44 falls back to LAPACK's eigen there): eigenvalues, band velocities
     and the scanned DOS of 6-, 12- and 16-band models against the oracle (up to 8 bands: row-layout Jacobi with accumulated
