@@ -375,6 +375,21 @@ bool ggr_build_supported(int n, int d, int M, int npt, bool herm);
 bool ggr_build_can_fuse(int n, int d, int M, int M2, int npt);
 size_t ggr_build_pack2_elems(int n, int d, int M, int M2, int64_t nparents);
 int launch_ggr_build(abz_ctx* ctx, const GgrBuildSpec& gs);
+// The same for 5...32 bands in the row layout (kernels_ggr_rows.hip): Householder + per-lane tridiagonal eigenvectors +
+// back-transformation + quadratic forms, one kernel, only (e, v) stored.
+struct GgrRowsSpec {
+    int n, d;
+    int M, first;  // variable 1
+    int npt;
+    const double2* tab;
+    PlaneView E, V;
+    int64_t nlines = 0;                  // level-1 sets: grid lines, or runs of a node list
+    const int64_t* run_start = nullptr;  // node lists: first node of every run (+ nk at the end); nullptr: full grid lines
+    const int32_t* gi = nullptr;         // node lists: grid index i_1 of every node
+    const double2* src[3] = {nullptr, nullptr, nullptr};  // level-1 families: plain, derivative on variable 2, on variable 3
+};
+bool ggr_rows_supported(int n, int d, int M, int npt, bool herm);
+int launch_ggr_rows(abz_ctx* ctx, const GgrRowsSpec& gs);
 int launch_ggr(abz_ctx* ctx, int n, int d, int npt, PlaneView E, PlaneView V, const double* w, int64_t nk,
                const double* Es_host, int nE, double* out_host);
 

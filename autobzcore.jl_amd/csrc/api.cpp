@@ -906,11 +906,22 @@ int abz_rule_destroy(abz_rule* r) try {
     return ABZ_OK;
 } ABZ_CATCH_ALL
 
-// eigenvalues + velocities only, Hermitian series, n <= 4: the fused GGR build applies
+// eigenvalues + velocities only, Hermitian series, 5...32 bands, full grids or node lists whose nodes come in runs per
+// level-1 set: the fused build in the row layout (kernels_ggr_rows.hip).  ABZ_GGR_FUSED=0: the unfused build (tests compare)
+static bool rule_ggr_rows(const abz_rule* r) {
+    const abz_series* s = r->s;
+    const RulePlan* rp = static_cast<const RulePlan*>(r->plan);
+    if (!(r->want & ABZ_WANT_VEL) || (r->want & ABZ_WANT_H) || !rp || !abz_switch(SW_GGR_FUSED)) return false;
+    if (!r->full && !(s->d >= 2 && rp->plan.nruns > 0 && !rp->plan.coords)) return false;
+    return ggr_rows_supported(s->n, s->d, s->dims[0], r->npt, s->hermitian);
+}
+
+// eigenvalues + velocities only, Hermitian series: one of the fused GGR builds applies (n <= 4: kernels_ggr.hip)
 static bool rule_ggr_fused(const abz_rule* r) {
     const abz_series* s = r->s;
-    return (r->want & ABZ_WANT_VEL) && !(r->want & ABZ_WANT_H) &&
-           ggr_build_supported(s->n, s->d, s->dims[0], r->npt, s->hermitian);
+    return ((r->want & ABZ_WANT_VEL) && !(r->want & ABZ_WANT_H) &&
+            ggr_build_supported(s->n, s->d, s->dims[0], r->npt, s->hermitian)) ||
+           rule_ggr_rows(r);
 }
 
 // launches only: contraction chain(s) + innermost evaluation (+ velocities)
@@ -925,6 +936,30 @@ static int rule_fill(abz_rule* r) {
     if (r->H.compact && !s->hermitian) {
         set_error("the rule keeps H(k) as an upper triangle (ABZ_WANT_H_COMPACT) and the series is no longer Hermitian: build a new rule");
         return ABZ_ERR_ARG;
+    }
+    if (rule_ggr_rows(r)) {
+        // 5...32 bands: H, every dH/dk_j, eigenvalues, eigenvectors and velocities of a node in the registers of its lanes
+        GgrRowsSpec gs;
+        gs.n = n;
+        gs.d = d;
+        gs.M = s->dims[0];
+        gs.first = s->first[0];
+        gs.npt = r->npt;
+        gs.tab = tab;
+        gs.E = r->E;
+        gs.V = r->V;
+        if (r->full) {
+            gs.nlines = d == 1 ? 1 : plan.nitems[1];
+        } else {
+            gs.nlines = plan.nruns;
+            gs.run_start = rp->pd.runs.as<int64_t>();
+            gs.gi = rp->pd.gi[0].as<int32_t>();
+        }
+        int rc;
+        if ((rc = build_chain(s, plan, rp->pd, tab, 0, &gs.src[0]))) return rc;
+        for (int j = 2; j <= d; ++j)
+            if ((rc = build_chain(s, plan, rp->pd, tab, j, &gs.src[j - 1], 1, &rp->fam[j - 2]))) return rc;
+        return launch_ggr_rows(ctx, gs);
     }
     if (rule_ggr_fused(r)) {
         // Fused GGR build (kernels_ggr.hip): H, every dH/dk_j, the eigensolve and the velocities in one kernel; only

@@ -1,0 +1,535 @@
+// Fused GGR build for 5...32 bands (ref: src/dos_ggr.jl:14-44 -- `e, U = eigen(Hermitian(h))`, `v_j = Re diag(U' dH/dk_j U) t_j`,
+// LAPACK there): ONE kernel per build, row layout (NP = 8 / 16 / 32 lanes per node), only (e, v) reach HBM.
+//
+// Per node, with lane r of its NP lanes owning row r of every matrix in registers:
+//   (1) H(k) from the line's level-1 coefficient set staged in LDS (rows_device.h);
+//   (2) Householder tridiagonalisation, the reflectors KEPT: lane r holds component r of every v_K, beta_K lives in lane
+//       K + 1, the accumulated phase of the complex subdiagonal in the lane of its row (T_complex = P T_real P^H);
+//   (3) eigenvalue b of the real tridiagonal in lane b: Sturm bisection + interpolation (tri_eigval_bisect);
+//   (4) its eigenvector IN THE SAME LANE, no cross-lane traffic: inverse iteration on T - lambda_b I with the pivoted LU of
+//       LAPACK's dlagtf / dlagts (dstein's scheme: three solves from a lane-dependent start vector, tiny pivots replaced by
+//       eps ||T||); members of a cluster (chain of gaps <= 1e-5 ||T||: degenerate levels, where ANY orthonormal basis of the
+//       eigenspace is an answer) are perturbed apart by 10 eps like dstein does and re-orthogonalised, lowest first, in
+//       wave-uniform rounds that run only when a wave holds a cluster;
+//   (5) back-transformation u_b = H_0 ... H_{n-3} P z_b: lane b owns COLUMN b of U, the reflector components come from the
+//       lanes that hold them by broadcast (group_bcast);
+//   (6) per direction j: the line's level-1 set of dH/dk_j is staged (variable 1: the same set with the factor 2 pi i f
+//       applied on its way into LDS; variables 2, 3: families contracted with the factor on that variable), row r of it
+//       evaluated in lane r, and v_b = u_b^H D u_b = sum_r D_rr |u_r|^2 + 2 Re sum_{r<c} conj(u_r) D_rc u_c with D_rc
+//       broadcast from lane r -- n^2 / 2 broadcasts per direction, no matrix leaves the registers;
+//   (7) e and v leave through an LDS tile [plane][node] as whole 128-B lines of the rule's planes.
+// The round-4 route for these band counts wrote U and every dH/dk_j to HBM (4 KB per node and matrix at 16 bands), found
+// the eigenvectors by n dense inverse iterations (n^4) and, above 16 bands, fell back to one wave per node:
+// 24^3 nodes: 16 bands 1.54 ms, 17 bands 13.8 ms, 32 bands 29.5 ms.
+#include <utility>
+
+#include "abz_internal.h"
+#include "rows_device.h"
+
+namespace abz {
+
+namespace {
+
+constexpr double TWO_PI_R = 6.283185307179586476925286766559;
+
+struct GgrRowsArgs {
+    const double2* src[3];  // level-1 sets [line][M][n * n]: plain, derivative factor on variable 2, on variable 3
+    const double2* tab;     // e^{2 pi i j / npt}
+    PlaneView E, V;
+    int64_t nlines;
+    const int64_t* run_start;  // irregular lists: line l owns nodes [run_start[l], run_start[l + 1]) with grid indices gi
+    const int32_t* gi;
+    int n, M, first, npt, d;
+    int mc;  // coefficients staged at a time (= M when the set fits the LDS whole)
+};
+
+// what the Householder steps leave behind (rows_device.h: hh_step)
+template <int NP>
+struct HhKeep {
+    double svr[NP], svi[NP];  // component r (this lane's row) of the reflector of step K
+    double beta = 0.0;        // lane K + 1: beta of step K
+    double phr = 1.0, phi = 0.0;  // lane j: accumulated phase p_j of the subdiagonal (p_0 = 1, p_{K+1} = p_K e_K / |e_K|)
+    double cr = 1.0, ci = 0.0;    // the running product (uniform inside the node)
+    template <int NPX, int K>
+    __device__ __forceinline__ void reflect(int r, double vr, double vi, double b, double x1r, double x1i, double a1sq, double sigma) {
+        svr[K] = vr;
+        svi[K] = vi;
+        beta = (r == K + 1) ? b : beta;
+        // e_K = -(x1 / |x1|) sqrt(sigma); x1 = 0: -sqrt(sigma); sigma = 0: no coupling, phase 1
+        double ur = -1.0, ui = 0.0;
+        if (a1sq > 0.0) {
+            const double inv = a1sq >= 1e-280 ? rsqrt_nr(a1sq) : 1.0 / sqrt(a1sq);
+            ur = -x1r * inv;
+            ui = -x1i * inv;
+        }
+        if (!(sigma > 0.0)) {
+            ur = 1.0;
+            ui = 0.0;
+        }
+        const double nr = cr * ur - ci * ui, ni = cr * ui + ci * ur;
+        cr = nr;
+        ci = ni;
+        phr = (r == K + 1) ? cr : phr;
+        phi = (r == K + 1) ? ci : phi;
+    }
+    template <int NPX, int K>
+    __device__ __forceinline__ void last(int r, double xr, double xi) {
+        if constexpr (K < NPX) {
+            svr[K] = 0.0;
+            svi[K] = 0.0;
+        }
+        if constexpr (K + 1 < NPX) {
+            const double x1r = group_bcast<NPX, K + 1>(xr), x1i = group_bcast<NPX, K + 1>(xi);
+            const double a1sq = x1r * x1r + x1i * x1i;
+            double ur = 1.0, ui = 0.0;
+            if (a1sq > 0.0) {
+                const double inv = 1.0 / sqrt(a1sq);
+                ur = x1r * inv;
+                ui = x1i * inv;
+            }
+            const double nr = cr * ur - ci * ui, ni = cr * ui + ci * ur;
+            cr = nr;
+            ci = ni;
+            phr = (r == K + 1) ? cr : phr;
+            phi = (r == K + 1) ? ci : phi;
+        }
+    }
+};
+
+// ---- eigenvector of the real symmetric tridiagonal (d, |e|^2) for this lane's eigenvalue `lam`: everything in the lane's own
+// registers, all indices compile-time.  Scaled to unit Gershgorin radius like the bisection.
+template <int NP>
+struct TriLU {
+    double a[NP], b[NP], dd[NP], c[NP], ia[NP];  // U: diagonal, first and second superdiagonal; multipliers of L; 1 / pivots
+    unsigned swapped = 0;                        // bit k: rows k, k + 1 were interchanged
+};
+
+template <int NP>
+__device__ __forceinline__ void tri_factor(int n, const double (&ds)[NP], const double (&off)[NP], double lam, TriLU<NP>& f) {
+#pragma unroll
+    for (int k = 0; k < NP; ++k) {
+        f.a[k] = ds[k] - lam;
+        f.b[k] = off[k];
+        f.c[k] = off[k];
+        f.dd[k] = 0.0;
+    }
+    f.swapped = 0;
+    double scale1 = fabs(f.a[0]) + (n > 1 ? fabs(f.b[0]) : 0.0);
+#pragma unroll
+    for (int k = 0; k + 1 < NP; ++k) {
+        if (k + 1 < n) {  // uniform
+            const double bk1 = (k + 2 < NP && k + 2 < n) ? f.b[k + 1] : 0.0;
+            const double ak = f.a[k], ak1 = f.a[k + 1], ck = f.c[k], bk = f.b[k];
+            const double scale2 = fabs(ck) + fabs(ak1) + fabs(bk1);
+            // dlagtf: interchange when |c| / scale2 > |a| / scale1 (c is never zero here: the couplings are floored)
+            const bool sw = fabs(ck) * scale1 > fabs(ak) * scale2;
+            const double piv = sw ? ck : ak;
+            const double ip = rcp_nr(piv);
+            const double mult = (sw ? ak : ck) * ip;
+            // no interchange: a[k+1] -= mult b[k].   interchange: a[k] = c, a[k+1] = b[k] - mult a[k+1], d[k] = b[k+1],
+            // b[k+1] = -mult b[k+1], b[k] = old a[k+1]
+            f.a[k] = piv;
+            f.a[k + 1] = sw ? fma(-mult, ak1, bk) : fma(-mult, bk, ak1);
+            f.b[k] = sw ? ak1 : bk;
+            f.dd[k] = sw ? bk1 : 0.0;
+            f.b[k + 1] = sw ? -mult * bk1 : f.b[k + 1];
+            f.c[k] = mult;
+            f.swapped |= sw ? (1u << k) : 0u;
+            scale1 = sw ? scale1 : scale2;
+        }
+    }
+    // reciprocal pivots; a pivot below eps (unit scale) is replaced by +-eps as dlagts does with job = -1
+#pragma unroll
+    for (int k = 0; k < NP; ++k) {
+        const double ak = f.a[k];
+        const double pk = fabs(ak) < 2.3e-16 ? (ak < 0.0 ? -2.3e-16 : 2.3e-16) : ak;
+        f.ia[k] = (k < n) ? rcp_nr(pk) : 0.0;
+    }
+}
+
+// y <- inv(T - lam I) y, then y scaled to unit maximum norm
+template <int NP>
+__device__ __forceinline__ void tri_solve(int n, const TriLU<NP>& f, double (&y)[NP]) {
+#pragma unroll
+    for (int k = 0; k + 1 < NP; ++k) {
+        if (k + 1 < n) {
+            const bool sw = (f.swapped >> k) & 1u;
+            const double yk = y[k], yk1 = y[k + 1];
+            y[k] = sw ? yk1 : yk;
+            y[k + 1] = sw ? fma(-f.c[k], yk1, yk) : fma(-f.c[k], yk, yk1);
+        }
+    }
+#pragma unroll
+    for (int k = NP - 1; k >= 0; --k) {
+        if (k < n) {
+            double t = y[k];
+            if (k + 1 < NP && k + 1 < n) t = fma(-f.b[k], y[k + 1 < NP ? k + 1 : k], t);
+            if (k + 2 < NP && k + 2 < n) t = fma(-f.dd[k], y[k + 2 < NP ? k + 2 : k], t);
+            y[k] = t * f.ia[k];
+        }
+    }
+    double mx = 0.0;
+#pragma unroll
+    for (int k = 0; k < NP; ++k) mx = (k < n) ? fmax(mx, fabs(y[k])) : mx;
+    const double s = (mx > 0.0 && mx < 1e300) ? 1.0 / mx : 1.0;
+#pragma unroll
+    for (int k = 0; k < NP; ++k) y[k] = (k < n) ? y[k] * s : 0.0;
+}
+
+template <int NP>
+__device__ __forceinline__ void unit2(int n, double (&y)[NP]) {
+    double nn = 0.0;
+#pragma unroll
+    for (int k = 0; k < NP; ++k) nn = (k < n) ? fma(y[k], y[k], nn) : nn;
+    const double s = nn > 0.0 ? 1.0 / sqrt(nn) : 0.0;
+#pragma unroll
+    for (int k = 0; k < NP; ++k) y[k] *= s;
+}
+
+template <int NP>
+__device__ __forceinline__ void tri_eigvec(int n, int r, int lane, const double (&d)[NP], const double (&e2)[NP], double lam, double (&z)[NP]) {
+    double lo = d[0], hi = d[0], eprev = 0.0;
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+        if (i < n) {
+            const double en = (i + 1 < n) ? sqrt(e2[i]) : 0.0;
+            lo = fmin(lo, d[i] - eprev - en);
+            hi = fmax(hi, d[i] + eprev + en);
+            eprev = en;
+        }
+    }
+    const double span = fmax(fabs(lo), fabs(hi));
+    const double sc = span > 0.0 ? 1.0 / span : 1.0;
+    double ds[NP], off[NP];
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+        ds[i] = d[i] * sc;
+        const double y = fmax(e2[i] * sc * sc, 4.9e-32);  // the floor of the bisection: the matrix it found the eigenvalues of
+        off[i] = y * rsqrt_nr(y);
+    }
+    const double lams = lam * sc;
+    // clusters: lane r is linked to lane r - 1 when their eigenvalues are within 1e-5 of the scale; pos = links below it
+    const double lprev = __shfl(lams, lane > 0 ? lane - 1 : 0, 64);
+    const bool link = r > 0 && r < n && (lams - lprev) <= 1e-5;
+    const unsigned long long links = __builtin_amdgcn_ballot_w64(link);
+    const unsigned long long below = (~links) & ((2ull << lane) - 1ull);  // (bit of the node's first lane is always set)
+    const int pos = lane - (63 - __builtin_clzll(below));
+    TriLU<NP> f;
+    tri_factor<NP>(n, ds, off, lams + 2.3e-15 * (double)pos, f);
+    // start vector: lane dependent, no zeros, no symmetry
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+        const unsigned h = (unsigned)(r * 40503 + i * 30011 + 12345) * 2654435761u;
+        z[i] = (i < n) ? (double)((h >> 8) & 0xffffu) * (1.0 / 65536.0) + 0.25 : 0.0;
+        z[i] = ((h >> 30) & 1u) ? -z[i] : z[i];
+    }
+    tri_solve<NP>(n, f, z);
+    tri_solve<NP>(n, f, z);
+    tri_solve<NP>(n, f, z);
+    unit2<NP>(n, z);
+    // cluster members, lowest first: Gram-Schmidt against the members below (final by then), two more solves each
+    for (int p = 1; __builtin_amdgcn_ballot_w64(pos >= p) != 0ull; ++p) {  // wave-uniform; not entered without a cluster
+        for (int it = 0; it < 3; ++it) {
+            double y[NP];
+#pragma unroll
+            for (int i = 0; i < NP; ++i) y[i] = z[i];
+            if (it > 0) tri_solve<NP>(n, f, y);
+            for (int t = 1; t <= p; ++t) {
+                double zc[NP], dot = 0.0;
+                const int src = lane - t >= 0 ? lane - t : 0;
+#pragma unroll
+                for (int i = 0; i < NP; ++i) {
+                    zc[i] = __shfl(z[i], src, 64);
+                    dot = fma(zc[i], y[i], dot);
+                }
+                if (t <= pos) {
+#pragma unroll
+                    for (int i = 0; i < NP; ++i) y[i] = fma(-dot, zc[i], y[i]);
+                }
+            }
+            unit2<NP>(n, y);
+            if (pos == p) {
+#pragma unroll
+                for (int i = 0; i < NP; ++i) z[i] = y[i];
+            }
+        }
+    }
+}
+
+// y = P z (complex), then u = H_0 ... H_{n-3} y.  Lane b works on its own column; v_K[i] comes from lane i.
+template <int NP, int K, int... I>
+__device__ __forceinline__ void back_step(int n, const HhKeep<NP>& kp, double (&ur)[NP], double (&ui)[NP], std::integer_sequence<int, I...>) {
+    if (K + 2 >= n) return;  // uniform: no reflector for this step
+    const double beta = group_bcast<NP, K + 1>(kp.beta);
+    double vr[NP], vi[NP];
+    double wr = 0.0, wi = 0.0;  // w = v^H u
+    ((void)([&] {
+         constexpr int i = K + 1 + I;
+         if (i < n) {
+             vr[i] = group_bcast<NP, i>(kp.svr[K]);
+             vi[i] = group_bcast<NP, i>(kp.svi[K]);
+             wr = fma(vr[i], ur[i], wr);
+             wr = fma(vi[i], ui[i], wr);
+             wi = fma(vr[i], ui[i], wi);
+             wi = fma(-vi[i], ur[i], wi);
+         }
+     }()),
+     ...);
+    wr *= beta;
+    wi *= beta;
+    ((void)([&] {
+         constexpr int i = K + 1 + I;
+         if (i < n) {  // u_i -= w v_i
+             ur[i] = fma(-wr, vr[i], ur[i]);
+             ur[i] = fma(wi, vi[i], ur[i]);
+             ui[i] = fma(-wr, vi[i], ui[i]);
+             ui[i] = fma(-wi, vr[i], ui[i]);
+         }
+     }()),
+     ...);
+}
+template <int NP, int... KK>
+__device__ __forceinline__ void back_steps(int n, const HhKeep<NP>& kp, double (&ur)[NP], double (&ui)[NP], std::integer_sequence<int, KK...>) {
+    // K = NP - 3 - KK: the last reflector first
+    (back_step<NP, NP - 3 - KK>(n, kp, ur, ui, std::make_integer_sequence<int, NP - (NP - 3 - KK) - 1>()), ...);
+}
+template <int NP, int... J>
+__device__ __forceinline__ void phase_apply(int n, const HhKeep<NP>& kp, const double (&z)[NP], double (&ur)[NP], double (&ui)[NP],
+                                            std::integer_sequence<int, J...>) {
+    ((void)([&] {
+         const double pr = group_bcast<NP, J>(kp.phr), pi = group_bcast<NP, J>(kp.phi);
+         ur[J] = (J < n) ? pr * z[J] : 0.0;
+         ui[J] = (J < n) ? pi * z[J] : 0.0;
+     }()),
+     ...);
+}
+
+// eigenvalue b (ascending) and column b of U in lane b, from the rows (ar, ai) of the Hermitian matrix (destroyed)
+template <int NP>
+__device__ __forceinline__ void rows_eigh_columns(int n, int r, int lane, double (&ar)[NP], double (&ai)[NP], double& myeig, double (&ur)[NP],
+                                                  double (&ui)[NP]) {
+    HhKeep<NP> kp;
+#pragma unroll
+    for (int j = 0; j < NP; ++j) {
+        kp.svr[j] = 0.0;
+        kp.svi[j] = 0.0;
+    }
+    double e2[NP], d[NP];
+    hh_steps_keep<NP>(n, r, ar, ai, e2, kp, std::make_integer_sequence<int, NP>());
+    diag_gather<NP>(ar, d, std::make_integer_sequence<int, NP>());
+    myeig = tri_eigval_bisect<NP>(n, r, d, e2);
+    double z[NP];
+    tri_eigvec<NP>(n, r, lane, d, e2, myeig, z);
+    phase_apply<NP>(n, kp, z, ur, ui, std::make_integer_sequence<int, NP>());
+    if constexpr (NP >= 3) back_steps<NP>(n, kp, ur, ui, std::make_integer_sequence<int, NP - 2>());
+}
+
+// u^H D u for this lane's column u, D Hermitian with row r in lane r
+template <int NP, int R, int... CC>
+__device__ __forceinline__ void quad_row(int n, const double (&dr)[NP], const double (&di)[NP], const double (&ur)[NP], const double (&ui)[NP],
+                                         double& diag, double& offd, std::integer_sequence<int, CC...>) {
+    if (R >= n) return;  // uniform
+    diag = fma(group_bcast<NP, R>(dr[R]), fma(ur[R], ur[R], ui[R] * ui[R]), diag);
+    ((void)([&] {
+         constexpr int c = R + 1 + CC;
+         if (c < n) {
+             const double xr = group_bcast<NP, R>(dr[c]), xi = group_bcast<NP, R>(di[c]);
+             const double tr = fma(ur[R], ur[c], ui[R] * ui[c]);   // conj(u_R) u_c
+             const double ti = fma(ur[R], ui[c], -ui[R] * ur[c]);
+             offd = fma(xr, tr, offd);
+             offd = fma(-xi, ti, offd);
+         }
+     }()),
+     ...);
+}
+template <int NP, int... RR>
+__device__ __forceinline__ double quad_form(int n, const double (&dr)[NP], const double (&di)[NP], const double (&ur)[NP], const double (&ui)[NP],
+                                            std::integer_sequence<int, RR...>) {
+    double diag = 0.0, offd = 0.0;
+    (quad_row<NP, RR>(n, dr, di, ur, ui, diag, offd, std::make_integer_sequence<int, NP - RR - 1>()), ...);
+    return fma(2.0, offd, diag);
+}
+
+// stage coefficients [m0, m0 + mcur) of one level-1 set; DERIV: times 2 pi i (first + m) on the way (d/dk_1)
+template <int NP, bool PAD>
+__device__ __forceinline__ void ggr_stage(double2* coef, const double2* __restrict__ src, int n, int m0, int mcur, int first, bool deriv) {
+    const int nn = n * n;
+    if constexpr (PAD) {
+        for (int t = threadIdx.x; t < mcur * NP * NP; t += blockDim.x) {
+            const int m = t / (NP * NP), e = t - m * (NP * NP);
+            const int rr = e % NP, j = e / NP;
+            double2 c = (rr < n && j < n) ? src[(size_t)(m0 + m) * nn + rr + n * j] : make_double2(0.0, 0.0);
+            if (deriv) {
+                const double tf = TWO_PI_R * (double)(first + m0 + m);
+                c = make_double2(-tf * c.y, tf * c.x);
+            }
+            coef[t] = c;
+        }
+    } else {
+        for (int t = threadIdx.x; t < mcur * nn; t += blockDim.x) {
+            double2 c = src[(size_t)m0 * nn + t];
+            if (deriv) {
+                const double tf = TWO_PI_R * (double)(first + m0 + t / nn);
+                c = make_double2(-tf * c.y, tf * c.x);
+            }
+            coef[t] = c;
+        }
+    }
+}
+
+template <int NP, bool PAD>
+__global__ __launch_bounds__(256) void ggr_rows_kernel(GgrRowsArgs a) {
+    extern __shared__ double2 lds_gr[];
+    constexpr int SLOTS = 256 / NP;
+    constexpr int TS = SLOTS + 1;
+    const int n = a.n, nn = n * n, M = a.M, mc = a.mc, d = a.d;
+    double2* const coef = lds_gr;
+    double* const tile = reinterpret_cast<double*>(coef + (size_t)mc * (PAD ? NP * NP : nn));  // [(1 + d) NP][TS]
+    const int slot = threadIdx.x / NP, r = threadIdx.x % NP, lane = threadIdx.x & 63;
+    int fm = a.first % a.npt;
+    if (fm < 0) fm += a.npt;
+    for (int64_t line = blockIdx.x; line < a.nlines; line += gridDim.x) {
+        const int64_t kbase = a.run_start ? a.run_start[line] : line * a.npt;
+        const int count = a.run_start ? (int)(a.run_start[line + 1] - kbase) : a.npt;
+        for (int i0 = 0; i0 < count; i0 += SLOTS) {
+            // a wave without a node in this pass computes nothing but keeps the block's barriers
+            const bool wave_on = i0 + (int)(threadIdx.x >> 6) * (64 / NP) < count;
+            const int i1 = i0 + slot;
+            const bool act = i1 < count;
+            const int ii = act ? i1 : 0;
+            const int ic = a.gi ? a.gi[kbase + ii] : ii;
+            const double2 z = a.tab[ic];
+            const double2 w = a.tab[(int)(((unsigned)fm * (unsigned)ic) % (unsigned)a.npt)];
+            double hr[NP], hi[NP];
+            // row r of the series of family `fam` (deriv1: d/dk_1 of the plain family); every thread keeps the barriers
+            auto series = [&](int fam, bool deriv1) {
+                const double2* __restrict__ src = a.src[fam] + line * ((int64_t)M * nn);
+                double pr = w.x, pi = w.y;
+#pragma unroll
+                for (int j = 0; j < NP; ++j) {
+                    hr[j] = 0.0;
+                    hi[j] = 0.0;
+                }
+                for (int m0 = 0; m0 < M; m0 += mc) {
+                    const int mcur = min(mc, M - m0);
+                    __syncthreads();
+                    ggr_stage<NP, PAD>(coef, src, n, m0, mcur, a.first, deriv1);
+                    __syncthreads();
+                    if (wave_on) {
+                        if constexpr (PAD)  // (the padded set is always staged whole: one chunk)
+                            panel_series_row<NP, true>(coef, n, mcur, z.x, z.y, pr, pi, r, hr, hi);
+                        else
+                            panel_series_row_chunk<NP>(coef, n, mcur, z.x, z.y, pr, pi, r, hr, hi);
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < NP; ++j) {  // the series routines accumulate -H; rows / columns >= n: zero
+                    const bool real = r < n && j < n;
+                    hr[j] = real ? -hr[j] : 0.0;
+                    hi[j] = real ? -hi[j] : 0.0;
+                }
+            };
+            series(0, false);
+            double myeig = 0.0, ur[NP], ui[NP];
+#pragma unroll
+            for (int j = 0; j < NP; ++j) {
+                ur[j] = 0.0;
+                ui[j] = 0.0;
+            }
+            if (wave_on) rows_eigh_columns<NP>(n, r, lane, hr, hi, myeig, ur, ui);
+            const bool keep = act && r < n;
+            if (keep) tile[r * TS + slot] = myeig;
+            for (int j = 0; j < d; ++j) {
+                series(j, j == 0);
+                if (wave_on) {
+                    const double v = quad_form<NP>(n, hr, hi, ur, ui, std::make_integer_sequence<int, NP>());
+                    if (keep) tile[((1 + j) * NP + r) * TS + slot] = v;
+                }
+            }
+            __syncthreads();
+            const int nplanes = (1 + d) * n;
+            for (int idx = threadIdx.x; idx < nplanes * SLOTS; idx += 256) {
+                const int pl = idx / SLOTS, sl = idx - pl * SLOTS;
+                if (i0 + sl >= count) continue;
+                const int64_t k = kbase + i0 + sl;
+                if (pl < n) {
+                    a.E.base[view_off(a.E, k) + (int64_t)pl * a.E.pitch] = tile[pl * TS + sl];
+                } else {
+                    const int q = pl - n, j = q / n, b = q - j * n;
+                    a.V.base[view_off(a.V, k) + (int64_t)(j * n + b) * a.V.pitch] = tile[((1 + j) * NP + b) * TS + sl];
+                }
+            }
+            // (the next pass begins with a barrier before it touches the LDS again)
+        }
+    }
+}
+
+size_t ggr_rows_tile_bytes(int np, int d) { return sizeof(double) * (size_t)((1 + d) * np) * (size_t)(256 / np + 1); }
+
+}  // namespace
+
+// Hermitian series of 5...32 bands, full grids or node lists that come in runs per level-1 set (d >= 2)
+bool ggr_rows_supported(int n, int d, int M, int npt, bool herm) {
+    if (!herm || n <= 4 || n > 32 || d < 1 || d > 3 || npt < 1 || npt >= 65536 || M < 1) return false;
+    const int np = n <= 8 ? 8 : (n <= 16 ? 16 : 32);
+    return sizeof(double2) * (size_t)n * n + ggr_rows_tile_bytes(np, d) <= 150 * 1024;  // one coefficient at a time always fits
+}
+
+int launch_ggr_rows(abz_ctx* ctx, const GgrRowsSpec& gs) {
+    if (gs.nlines <= 0) return ABZ_OK;
+    GgrRowsArgs a;
+    for (int j = 0; j < 3; ++j) a.src[j] = gs.src[j];
+    a.tab = gs.tab;
+    a.E = gs.E;
+    a.V = gs.V;
+    a.nlines = gs.nlines;
+    a.run_start = gs.run_start;
+    a.gi = gs.gi;
+    a.n = gs.n;
+    a.M = gs.M;
+    a.first = gs.first;
+    a.npt = gs.npt;
+    a.d = gs.d;
+    const int np = gs.n <= 8 ? 8 : (gs.n <= 16 ? 16 : 32);
+    const size_t tile = ggr_rows_tile_bytes(np, gs.d);
+    // the zero-padded set whole when two workgroups per CU still fit (<= 72 KB each); otherwise unpadded, as many coefficients
+    // at a time as fit (whole up to 150 KB)
+    bool pad = sizeof(double2) * (size_t)gs.M * np * np + tile <= 72 * 1024;
+    size_t lds;
+    if (pad) {
+        a.mc = gs.M;
+        lds = sizeof(double2) * (size_t)gs.M * np * np + tile;
+    } else {
+        const size_t per = sizeof(double2) * (size_t)gs.n * gs.n;
+        const size_t whole = per * (size_t)gs.M + tile;
+        if (whole <= 150 * 1024) {
+            a.mc = gs.M;
+        } else {
+            a.mc = (int)((72 * 1024 - tile) / per);
+            if (a.mc < 1) a.mc = (int)((150 * 1024 - tile) / per);
+            if (a.mc < 1) {
+                set_error("GGR build: one %d-band coefficient block does not fit the LDS", gs.n);
+                return ABZ_ERR_UNSUPPORTED;
+            }
+        }
+        lds = per * (size_t)a.mc + tile;
+    }
+    const int64_t blocks = std::min<int64_t>(gs.nlines, 256 * 4);
+    ProfScope ps(ctx, ABZ_K_EVAL);
+#define ABZ_GR(NPV, PV)                                                                                                              \
+    {                                                                                                                                \
+        ABZ_HIP(hipFuncSetAttribute((const void*)ggr_rows_kernel<NPV, PV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));   \
+        hipLaunchKernelGGL((ggr_rows_kernel<NPV, PV>), dim3((unsigned)blocks), dim3(256), lds, ctx->stream, a);                      \
+    }
+    if (np == 8 && pad) ABZ_GR(8, true)
+    else if (np == 8) ABZ_GR(8, false)
+    else if (np == 16 && pad) ABZ_GR(16, true)
+    else if (np == 16) ABZ_GR(16, false)
+    else if (pad) ABZ_GR(32, true)
+    else ABZ_GR(32, false)
+#undef ABZ_GR
+    ABZ_HIP(hipGetLastError());
+    return ABZ_OK;
+}
+
+}  // namespace abz

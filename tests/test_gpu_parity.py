@@ -1484,26 +1484,65 @@ def test_ggr_velocities_match_oracle(abz, svo):
 
 
 @pytest.mark.parametrize("n", [6, 12, 16, 17, 24, 32])
-def test_ggr_more_than_four_bands(abz, n):
+def test_ggr_more_than_four_bands(abz, n, monkeypatch):
     """GGR for n > 4 (ref: src/dos_ggr.jl:1-44 falls back to LAPACK's eigen there): eigenvalues, band velocities
     and the scanned DOS of 6-, 12- and 16-band models against the oracle (up to 8 bands: row-layout Jacobi with accumulated
     rotations; 9..16: Householder + bisection eigenvalues and inverse-iteration eigenvectors)."""
     so = orc.synthetic_wannier(n=n, rmax=2, seed=7)
     s = abz.FourierSeries(so.c, period=1.0, first=so.first, ndim=3)
-    rule = s.device().rule(6, None, want=2 | 4)
-    out = rule.export(eig=True, vel=True)
     w, e, v = orc.get_ggr_data(so, 6, None)
-    assert np.abs(out["eig"] - e).max() < 1e-11
     ok = np.min(np.diff(e, axis=1), axis=1) > 1e-6
     assert ok.sum() > 100
-    assert np.abs(out["vel"][ok] - v[ok]).max() < 1e-8
-    assert np.abs(out["vel"].sum(axis=2) - v.sum(axis=2)).max() < 1e-8
+    # the fused row-layout build (kernels_ggr_rows.hip) and the unfused one (eigenvectors + a velocity launch per variable)
+    for env in ({}, {"ABZ_GGR_FUSED": "0"}):
+        for k_, v_ in env.items():
+            monkeypatch.setenv(k_, v_)
+        rule = abz.DeviceRule(s.device(), 6, None, 2 | 4)
+        out = rule.export(eig=True, vel=True)
+        rule.close()
+        for k_ in env:
+            monkeypatch.delenv(k_)
+        assert np.abs(out["eig"] - e).max() < 1e-11, env
+        assert np.abs(out["vel"][ok] - v[ok]).max() < 1e-8, env
+        assert np.abs(out["vel"].sum(axis=2) - v.sum(axis=2)).max() < 1e-8, env
     Es = np.linspace(-2.0, 2.0, 9)
     for kind, bzk in (("FBZ", abz.FBZ()), ("InversionSymIBZ", abz.InversionSymIBZ())):
         u = abz.dos.solve(abz.DOSProblem(s, Es, abz.load_bz(bzk, np.eye(3))), abz.GGR(npt=10)).u
         ref = orc.dos_ggr(so, orc.load_bz(kind, np.eye(3)), Es, npt=10)
         assert np.abs(ref).max() > 0.1
         assert np.abs(u - ref).max() <= 1e-9 * max(1.0, np.abs(ref).max())
+
+
+@pytest.mark.parametrize("n3,mult", [(3, 2), (2, 4), (3, 4), (5, 2), (3, 8), (7, 4)])
+def test_ggr_rows_degenerate_bands(abz, n3, mult):
+    """Exactly degenerate levels everywhere (H = Q (I_mult x h(k)) Q^H with a fixed unitary Q): the per-lane inverse iteration
+    of the row-layout GGR build must return an orthonormal basis of every eigenspace -- eigenvalues against LAPACK, velocity
+    SUMS over each degenerate set against the oracle (any basis of the set is an answer, ref src/dos_ggr.jl:31-44), and the
+    scanned DOS; grid sizes that leave waves without nodes and lines shorter / longer than a pass."""
+    rng = np.random.default_rng(7 * n3 + mult)
+    c3, first = rand_series(rng, (3, 3, 3), n3, hermitian=True)
+    n = n3 * mult
+    q, _ = np.linalg.qr(rng.standard_normal((n, n)) + 1j * rng.standard_normal((n, n)))
+    c = np.einsum("ab,...bc,dc->...ad", q, np.kron(np.eye(mult), c3), q.conj())
+    s, so = both(abz, c, first)
+    for npt in (5, 19):
+        w, e, v = orc.get_ggr_data(so, npt, None)
+        rule = abz.DeviceRule(s.device(), npt, None, 2 | 4)
+        out = rule.export(eig=True, vel=True)
+        rule.close()
+        scale, vscale = np.abs(e).max(), np.abs(v).max()
+        assert np.abs(out["eig"] - e).max() <= 1e-11 * scale
+        grp = lambda a: a.reshape(a.shape[0], a.shape[1], n3, mult).sum(axis=3) if a.ndim == 3 else None
+        # bands come in runs of `mult` equal values: sums over each run (distinct levels separated by > 1e-6 only)
+        e3 = e.reshape(len(e), n3, mult)[:, :, 0]
+        sep = np.min(np.diff(e3, axis=1), axis=1) > 1e-6 * scale if n3 > 1 else np.ones(len(e), dtype=bool)
+        assert sep.mean() > 0.9
+        assert np.abs(grp(out["vel"])[sep] - grp(v)[sep]).max() <= 1e-8 * vscale * mult
+        assert np.abs(out["vel"].sum(axis=2) - v.sum(axis=2)).max() <= 1e-8 * vscale * n
+    Es = np.linspace(-3.0, 3.0, 7)
+    u = abz.dos.solve(abz.DOSProblem(s, Es, abz.load_bz(abz.FBZ(), np.eye(3))), abz.GGR(npt=12)).u
+    ref = orc.dos_ggr(so, orc.load_bz("FBZ", np.eye(3)), Es, npt=12)
+    assert np.abs(u - ref).max() <= 1e-8 * max(1.0, np.abs(ref).max())
 
 
 def _ggr_rule_data(abz, s, npt, syms=None):
