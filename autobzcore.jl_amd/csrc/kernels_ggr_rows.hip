@@ -405,10 +405,16 @@ __global__ __launch_bounds__(256, NP <= 16 ? 2 : 1) void ggr_rows_kernel(GgrRows
     double2* const park = coef + (size_t)slot * PARK_STRIDE<NP>;
     int fm = a.first % a.npt;
     if (fm < 0) fm += a.npt;
-    for (int64_t line = blockIdx.x; line < a.nlines; line += gridDim.x) {
+    // work item = one pass (SLOTS nodes) of one line: the room of the coefficient set is reused between the series
+    // evaluations, so every pass stages its sets anyway, and items of this size let the hardware's workgroup scheduler balance
+    // a small grid (24^3 nodes, 16 bands: 576 lines = 1.1 rounds of workgroups when a workgroup took a whole line)
+    const int ppl = (a.npt + SLOTS - 1) / SLOTS;  // passes per line (node lists: runs are at most npt long)
+    for (int64_t item = blockIdx.x; item < a.nlines * ppl; item += gridDim.x) {
+        const int64_t line = item / ppl;
         const int64_t kbase = a.run_start ? a.run_start[line] : line * a.npt;
         const int count = a.run_start ? (int)(a.run_start[line + 1] - kbase) : a.npt;
-        for (int i0 = 0; i0 < count; i0 += SLOTS) {
+        const int i0 = (int)(item - line * ppl) * SLOTS;
+        if (i0 < count) {  // (uniform)
             // n and r go through an opaque move once per pass: everything derived from them alone -- dozens of uniform
             // comparisons with n, the start vectors of the inverse iteration -- was hoisted out of both loops and lived (or
             // was spilled: 1.9 KB of scratch per lane) through the whole kernel
@@ -545,7 +551,7 @@ int launch_ggr_rows(abz_ctx* ctx, const GgrRowsSpec& gs) {
     elems = std::max(elems, park);
     a.coef_elems = (int)elems;
     const size_t lds = sizeof(double2) * elems + tile;
-    const int64_t blocks = std::min<int64_t>(gs.nlines, 256 * 4);
+    const int64_t blocks = std::min<int64_t>(gs.nlines * ((gs.npt + 256 / np - 1) / (256 / np)), 256 * 64);
     ProfScope ps(ctx, ABZ_K_EVAL);
 #define ABZ_GR(NPV, PV)                                                                                                              \
     {                                                                                                                                \

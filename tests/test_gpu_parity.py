@@ -1545,6 +1545,35 @@ def test_ggr_rows_degenerate_bands(abz, n3, mult):
     assert np.abs(u - ref).max() <= 1e-8 * max(1.0, np.abs(ref).max())
 
 
+@pytest.mark.parametrize("d,n,dims", [(1, 8, (5,)), (2, 6, (3, 5)), (2, 12, (5, 3)), (3, 7, (3, 3, 5)), (3, 32, (11, 3, 3)), (3, 20, (13, 3, 3))])
+def test_ggr_rows_dimensions_and_chunked_sets(abz, d, n, dims):
+    """The row-layout GGR build in 1, 2 and 3 dimensions (ref: src/dos_ggr.jl:14-44 for any N), with periods other than one
+    (the velocities carry the period, src/dos_ggr.jl:20,35), on full grids and on an inversion-symmetric node list, and for
+    level-1 sets that do not fit the LDS whole (32 bands x 11 coefficients: staged in chunks) -- against the oracle."""
+    rng = np.random.default_rng(1000 * d + n)
+    c, first = rand_series(rng, dims, n, hermitian=True)
+    period = (1.0, 2.0, 0.5)[:d]
+    s, so = both(abz, c, first, period, ndim=d)
+    for npt in ((9, 40) if d == 1 else (7,)):
+        w, e, v = orc.get_ggr_data(so, npt, None)
+        rule = abz.DeviceRule(s.device(), npt, None, 2 | 4)
+        out = rule.export(eig=True, vel=True)
+        rule.close()
+        scale, vscale = np.abs(e).max(), np.abs(v).max()
+        ok = np.min(np.diff(e, axis=1), axis=1) > 1e-6 * scale
+        assert ok.mean() > 0.9
+        assert np.abs(out["eig"] - e).max() <= 1e-11 * scale
+        assert np.abs(out["vel"][ok] - v[ok]).max() <= 1e-8 * vscale
+        assert np.abs(out["vel"].sum(axis=2) - v.sum(axis=2)).max() <= 1e-9 * vscale * n
+    if d >= 2 and n <= 12:  # BZ solves: period one (the reference's BZ integrals assume it, SURVEY A.1)
+        s, so = both(abz, c, first, 1.0, ndim=d)
+        Es = np.linspace(-4.0, 4.0, 5)
+        for kind, bzk in (("FBZ", abz.FBZ()), ("InversionSymIBZ", abz.InversionSymIBZ())):
+            u = abz.dos.solve(abz.DOSProblem(s, Es, abz.load_bz(bzk, np.eye(d))), abz.GGR(npt=8)).u
+            ref = orc.dos_ggr(so, orc.load_bz(kind, np.eye(d)), Es, npt=8)
+            assert np.abs(u - ref).max() <= 1e-9 * max(1.0, np.abs(ref).max()), kind
+
+
 def _ggr_rule_data(abz, s, npt, syms=None):
     from autobzcore.jl_amd import _lib as L
     rule = abz.DeviceRule(s.device(), npt, syms, L.WANT_EIG | L.WANT_VEL)
