@@ -136,6 +136,19 @@ __device__ __forceinline__ double row16_bcast_dpp(double v) {
 template <int NP, int C>
 __device__ __forceinline__ double group_bcast(double v) {
     if constexpr (NP == 16) return row16_bcast_dpp<C>(v);
+    if constexpr (NP == 8) {
+        // two nodes share a DPP row: lanes 0...7 take lane C, lanes 8...15 lane C + 8 -- two `v_mov_b64_dpp row_newbcast`
+        // with bank masks (a bank = four lanes of the row) on the VALU instead of two `ds_swizzle_b32` through the LDS
+        // crossbar and their wait (round 5: the 5...8-band kernels cost 15x a 4-band one per node)
+#if defined(__HIP_DEVICE_COMPILE__)
+        const long long x = __builtin_bit_cast(long long, v);
+        long long t = __builtin_amdgcn_update_dpp(x, x, 0x150 + C, 0xf, 0x3, false);
+        t = __builtin_amdgcn_update_dpp(t, x, 0x150 + C + 8, 0xf, 0xc, false);
+        return __builtin_bit_cast(double, t);
+#else
+        return v;
+#endif
+    }
     constexpr int pattern = ((32 - NP) & 0x1f) | (C << 5);  // and_mask | or_mask << 5, xor_mask 0
     const int lo = __builtin_amdgcn_ds_swizzle(__double2loint(v), pattern);
     const int hi = __builtin_amdgcn_ds_swizzle(__double2hiint(v), pattern);

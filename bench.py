@@ -181,6 +181,92 @@ def cpu_baseline(npt, s, eta, budget_s=25.0):
     return res
 
 
+def cpu_baseline_legs(out, abz, s, npt, eta, cores, c5_abstol):
+    """The C port (oracle/abz_oracle.c, kind 'port') beside the IAI and GGR legs of the line: the reference's nested
+    GK(7,15) loop (src/fourier.jl:432-510) and get_ggr_data + sum_ggr (src/dos_ggr.jl:14-65), on bounded samples."""
+    native = os.path.join(ROOT, "oracle", "_build", "liboracle_native.so")
+    lib = ctypes.CDLL(native if os.path.exists(native) else os.path.join(ROOT, "oracle", "_build", "liboracle.so"))
+    lib.orc_num_threads.restype = ctypes.c_int
+    lib.orc_set_threads(cores)
+    P = ctypes.c_void_p
+    from autobzcore.jl_amd.series import julia_coefficient_order
+    lib.orc_iai_dos3.restype = ctypes.c_double
+    lib.orc_iai_dos3.argtypes = [P, P, P, ctypes.c_int, P, P, ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.c_double,
+                                 ctypes.c_int64, P, P]
+
+    def iai(series, eta_, omega, abstol):
+        coef = np.ascontiguousarray(julia_coefficient_order(series.c, 3))
+        dims, first = np.array(series.dims, dtype=np.int32), np.array(series.first, dtype=np.int32)
+        lo, hi = np.zeros(3), np.ones(3)
+        err, nev = ctypes.c_double(0), ctypes.c_int64(0)
+        t0 = time.perf_counter()
+        u = lib.orc_iai_dos3(coef.ctypes.data_as(P), dims.ctypes.data_as(P), first.ctypes.data_as(P), series.n, lo.ctypes.data_as(P),
+                             hi.ctypes.data_as(P), eta_, omega, abstol, -1.0, 2**62, ctypes.byref(err), ctypes.byref(nev))
+        return u, nev.value, time.perf_counter() - t0
+
+    what = ("C port of the reference's nested adaptive GK(7,15) loop (depth first, scalar refinement, abstol / len per level; the "
+            "nodes of an outermost round dealt to threads like NestedBatchIntegrand's workers), gcc -O3 -fopenmp")
+    ex = out.get("iai_example", {}).get("FBZ") if isinstance(out.get("iai_example"), dict) else None
+    if isinstance(ex, dict) and "numevals" in ex:
+        try:  # the reference example's own solve (aps_example/aps_example.jl:29-34: eta = 0.01 eV, abstol 1e-3) in full
+            j = abs(np.linalg.det(2 * np.pi * np.linalg.inv(3.85856 * np.eye(3)).T))
+            u, nev, dt = iai(s, 0.01, ex.get("omega", 12.5), 1e-3 / j)
+            ex["cpu_baseline"] = {"kind": "port", "cores": cores, "seconds": dt, "numevals": nev, "nodes_per_sec": nev / dt, "u": u * j,
+                                  "same_numevals_as_gpu": bool(nev == ex["numevals"]), "gpu_over_cpu": dt / ex["seconds"],
+                                  "sample": "the whole solve; " + what}
+        except Exception as e:
+            ex["cpu_baseline"] = {"error": repr(e)}
+    c5 = out.get("iai_config5")
+    if isinstance(c5, dict) and "nodes_per_sec" in c5:
+        try:  # config 5 at a looser tolerance (the node rate does not depend on it): a bounded sample
+            s16 = abz.synthetic_wannier()
+            j16 = (2 * np.pi) ** 3  # |det B| of load_bz(FBZ, I): do_solve hands abstol / |det B| to the nested quadrature
+            atol = 64.0  # tightened until the sample lasts a few seconds (never beyond the GPU leg's own tolerance)
+            while True:
+                atol = max(atol / 2, c5_abstol)
+                u, nev, dt = iai(s16, 0.05, 0.2, atol / j16)
+                if dt >= 3.0 or atol <= c5_abstol:
+                    break
+            c5["cpu_baseline"] = {"kind": "port", "cores": cores, "abstol_of_the_sample": atol, "seconds": dt, "numevals": nev,
+                                  "nodes_per_sec": nev / dt, "gpu_over_cpu": c5["nodes_per_sec"] / (nev / dt),
+                                  "sample": f"config 5 (synthetic 16-band IAI on the FBZ) at abstol {atol:g} instead of {c5_abstol:g}: nodes/s "
+                                            "against nodes/s; " + what + "; Gauss-Jordan inverse with partial pivoting per node"}
+        except Exception as e:
+            c5["cpu_baseline"] = {"error": repr(e)}
+    g = out.get("ggr")
+    if isinstance(g, dict) and "build_seconds" in g:
+        try:
+            coef = np.ascontiguousarray(julia_coefficient_order(s.c, 3))
+            dims, first, per = np.array(s.dims, dtype=np.int32), np.array(s.first, dtype=np.int32), np.ones(3)
+            nk = npt**3
+            eig, vel = np.empty(nk * 3), np.empty(nk * 9)
+            args = (coef.ctypes.data_as(P), dims.ctypes.data_as(P), first.ctypes.data_as(P), 3, npt, per.ctypes.data_as(P),
+                    eig.ctypes.data_as(P), vel.ctypes.data_as(P))
+            lib.orc_ggr_data(*args)
+            t0 = time.perf_counter()
+            reps = 0
+            while reps < 2 or time.perf_counter() - t0 < 4.0:
+                lib.orc_ggr_data(*args)
+                reps += 1
+            tb = (time.perf_counter() - t0) / reps
+            nE = 32
+            Es = np.linspace(10.0, 15.0, 256)[:: 256 // nE]
+            o = np.empty(nE)
+            lib.orc_sum_ggr3.argtypes = [ctypes.c_int, P, ctypes.c_int, ctypes.c_int64, ctypes.c_int, P, P, P]
+            t0 = time.perf_counter()
+            lib.orc_sum_ggr3(npt, Es.ctypes.data_as(P), nE, nk, 3, eig.ctypes.data_as(P), vel.ctypes.data_as(P), o.ctypes.data_as(P))
+            tsc = (time.perf_counter() - t0) / nE
+            g["cpu_baseline"] = {"kind": "port", "cores": cores, "build_seconds": tb, "build_kpoints_per_sec": nk / tb,
+                                 "scan_seconds_per_energy": tsc, "scan_kE_per_sec": nk / tsc,
+                                 "gpu_over_cpu": tb / g["build_seconds"], "gpu_over_cpu_scan_256_energies": 256 * tsc / g["scan_seconds"],
+                                 "sample": f"get_ggr_data on the same {npt}^3 grid ({reps} builds) + sum_ggr for {nE} of the 256 energies; C port: "
+                                           "JacobianSeries contracted hierarchically, closed-form 3x3 eigenvalues, eigenvectors from cross "
+                                           "products (StaticArrays' route), threads over the outermost grid index and over the nodes of a scan "
+                                           "(the reference's own eigen loop and sum_ggr are serial)"}
+        except Exception as e:
+            g["cpu_baseline"] = {"error": repr(e)}
+
+
 def rank_main(a):
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -574,6 +660,8 @@ def rank_main(a):
                     out["dos_sweep_256_omega"] = {"gpu_seconds": t_n1, "cpu_port_seconds": cpu_job, "speedup": cpu_job / t_n1,
                                                   "note": f"rule build + 256-omega scan of the same {npt}^3 grid: GPU measured end to end; CPU port "
                                                           f"build measured on this grid, its scan measured for 32 of the 256 omegas (per-omega cost is constant) x 8"}
+                    if not a.no_extras:
+                        cpu_baseline_legs(out, abz, s, npt, a.eta, cb["cores"], a.c5_abstol)
             except Exception as e:  # the baseline never blocks the GPU number
                 out["cpu_baseline"] = {"error": str(e)}
         print(json.dumps(flat_first(out)), flush=True)
@@ -1129,6 +1217,31 @@ def extras(a, abz, L, s, ctx, out, nk):
         out["bands16_fixed_grids"] = b16
     except Exception as e:
         out["bands16_fixed_grids"] = {"error": str(e)}
+    # GGR builds of 5...32 bands (round 5: one row-layout kernel, kernels_ggr_rows.hip; ref src/dos_ggr.jl:14-44 calls LAPACK there)
+    try:
+        gb = {"what": "rule build with eigenvalues + band velocities (abz_ptr_rule_build, ABZ_WANT_EIG | ABZ_WANT_VEL) of synthetic Hermitian "
+                      "models on the 24^3 full-BZ grid: contraction chains of H and of the d derivative families + one fused kernel; "
+                      "round 4 (eigenvectors and every dH/dk_j through HBM; wave-per-node above 16 bands): 16 bands 1.54 ms, 17 bands 13.8 ms, 24 bands 29.5 ms",
+              "npt": 24}
+        for nb, rmax in ((5, 2), (8, 2), (12, 2), (16, 3), (16, 6), (17, 2), (24, 2), (32, 2)):
+            sg = abz.synthetic_wannier(n=nb, rmax=rmax, seed=7) if (nb, rmax) != (16, 6) else s16
+            rr = abz.DeviceRule(sg.device(), 24, None, L.WANT_EIG | L.WANT_VEL)
+            for _ in range(3):
+                rr.rebuild()
+            ctx.sync()
+            ts_ = []
+            for _ in range(10):
+                t0 = time.perf_counter()
+                rr.rebuild()
+                ctx.sync()
+                ts_.append(time.perf_counter() - t0)
+            rr.close()
+            if sg is not s16:
+                sg.device().close() if hasattr(sg.device(), "close") else None
+            gb[f"bands{nb}_M{2 * rmax + 1}"] = {"seconds": min(ts_), "nodes_per_sec": 24**3 / min(ts_)}
+        out["ggr_bands_5_to_32"] = gb
+    except Exception as e:
+        out["ggr_bands_5_to_32"] = {"error": repr(e)}
     # 17...32 bands: the same row kernels with two nodes per wave (round 4; wave-per-node kernels before: a 100x step at 17 bands)
     try:
         b24 = {}

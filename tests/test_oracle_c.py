@@ -100,3 +100,74 @@ def test_c_oracle_fixed_size_3band_paths(clib):
         e = np.empty(3)
         clib.orc_eig3_closed(a.ctypes.data_as(P), e.ctypes.data_as(P))
         assert np.abs(e - np.sort(lam)).max() < 2e-7
+
+
+def _herm_series(rng, dims, n, scale=1.0):
+    c = rng.standard_normal(dims + (n, n)) + 1j * rng.standard_normal(dims + (n, n))
+    flip = c[tuple(slice(None, None, -1) for _ in dims)]
+    c = 0.5 * scale * (c + np.conj(np.swapaxes(flip, -1, -2)))
+    first = tuple(-(m // 2) for m in dims)
+    d = len(dims)
+    coef = np.ascontiguousarray(np.transpose(c, tuple(range(d - 1, -1, -1)) + (d + 1, d))).reshape(-1)
+    return c, first, coef
+
+
+@pytest.mark.parametrize("n,threads", [(3, 1), (3, 3), (5, 2)])
+def test_c_oracle_iai_is_the_numpy_oracles_panel_tree(clib, n, threads):
+    """orc_iai_dos3 (the nested GK(7,15) loop timed as the CPU baseline of the IAI legs; ref src/fourier.jl:432-510) against
+    oracle/abz_oracle.py::solve_iai: the same value to rounding and the SAME number of integrand evaluations, whatever
+    the number of threads the outermost nodes are dealt to."""
+    rng = np.random.default_rng(40 + n)
+    dims = (3, 3, 3)
+    c, first, coef = _herm_series(rng, dims, n, scale=0.5)
+    so = orc.FourierSeries(c, period=1.0, first=first, ndim=3)
+    eta, omega, abstol = 0.5, 0.3, 5e-4
+    bz = orc.load_bz("FBZ", 2 * np.pi * np.eye(3))  # B = I: |det B| = 1, the nested tolerance is abstol itself
+    assert abs(abs(np.linalg.det(bz.B)) - 1.0) < 1e-12
+    ref = orc.solve_iai(so, bz, orc.f_dos(eta, omega), abstol=abstol)
+    P = ctypes.c_void_p
+    dm, fr = np.array(dims, dtype=np.int32), np.array(first, dtype=np.int32)
+    lo, hi = np.zeros(3), np.ones(3)
+    err, nev = ctypes.c_double(0), ctypes.c_int64(0)
+    clib.orc_iai_dos3.restype = ctypes.c_double
+    clib.orc_iai_dos3.argtypes = [P, P, P, ctypes.c_int, P, P, ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.c_double,
+                                  ctypes.c_int64, P, P]
+    clib.orc_set_threads(threads)
+    got = clib.orc_iai_dos3(coef.ctypes.data_as(P), dm.ctypes.data_as(P), fr.ctypes.data_as(P), n, lo.ctypes.data_as(P),
+                            hi.ctypes.data_as(P), eta, omega, abstol, -1.0, 2**62, ctypes.byref(err), ctypes.byref(nev))
+    assert nev.value == ref.numevals and nev.value > 15**3
+    assert abs(got - ref.u) <= 1e-12 * abs(ref.u)
+    assert abs(err.value - ref.resid) <= 1e-9 * abs(ref.resid) + 1e-18
+
+
+@pytest.mark.parametrize("n", [3, 4])
+def test_c_oracle_ggr(clib, n):
+    """orc_ggr_data + orc_sum_ggr3 (the CPU baseline of the GGR leg; ref src/dos_ggr.jl:14-65,90-104) against the numpy
+    oracle's get_ggr_data / sum_ggr, with periods other than one."""
+    rng = np.random.default_rng(50 + n)
+    dims = (3, 5, 3)
+    c, first, coef = _herm_series(rng, dims, n)
+    period = (1.0, 2.0, 0.5)
+    so = orc.FourierSeries(c, period=period, first=first, ndim=3)
+    npt = 6
+    w, e, v = orc.get_ggr_data(so, npt, None)
+    nk = npt**3
+    eig, vel = np.empty(nk * n), np.empty(nk * 3 * n)
+    P = ctypes.c_void_p
+    dm, fr, per = np.array(dims, dtype=np.int32), np.array(first, dtype=np.int32), np.array(period)
+    clib.orc_ggr_data(coef.ctypes.data_as(P), dm.ctypes.data_as(P), fr.ctypes.data_as(P), n, npt, per.ctypes.data_as(P),
+                      eig.ctypes.data_as(P), vel.ctypes.data_as(P))
+    eig, vel = eig.reshape(nk, n), vel.reshape(nk, 3, n)
+    scale, vscale = np.abs(e).max(), np.abs(v).max()
+    assert np.abs(eig - e).max() <= 1e-11 * scale
+    ok = np.min(np.diff(e, axis=1), axis=1) > 1e-5 * scale
+    assert ok.mean() > 0.9
+    assert np.abs(vel[ok] - v[ok]).max() <= 1e-8 * vscale
+    assert np.abs(vel.sum(axis=2) - v.sum(axis=2)).max() <= 1e-9 * vscale * n
+    Es = np.linspace(-3.0, 3.0, 7)
+    out = np.empty(len(Es))
+    clib.orc_sum_ggr3.argtypes = [ctypes.c_int, P, ctypes.c_int, ctypes.c_int64, ctypes.c_int, P, P, P]
+    clib.orc_sum_ggr3(npt, Es.ctypes.data_as(P), len(Es), nk, n, eig.ctypes.data_as(P), vel.ctypes.data_as(P), out.ctypes.data_as(P))
+    ref = np.array([orc.sum_ggr(3, npt, E, w, e, v) for E in Es])
+    assert np.abs(ref).max() > 0
+    assert np.abs(out - ref).max() <= 1e-8 * np.abs(ref).max()
