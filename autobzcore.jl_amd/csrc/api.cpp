@@ -1707,7 +1707,7 @@ int abz_autoptr_solve_many(abz_series* s, const int32_t* syms, int nsyms, int in
         const bool sum_ok = !syms && (n > 4 ? gen_sum_supported(n, s->dims[0], npt, integrand, s->hermitian)
                                             : eval_sum_supported(n, s->dims[0], npt, integrand, s->hermitian));
         const size_t rbytes = rule_value_bytes(s, npt, nk_full, want);  // upper bound for symmetric rules
-        if (!have && free_b == 0) (void)hipMemGetInfo(&free_b, &total_b);
+        if (!have) (void)hipMemGetInfo(&free_b, &total_b);  // (per grid: an earlier build of this call has taken its share)
         const bool fits = have || rbytes < free_b / 2;
         // kept: the first `keepmost` grids like the reference's cache, and any further one while the series' kept rules
         // stay below a quarter of the device memory (288 GB of HBM are there to keep rule values resident: a sweep or a
@@ -1801,8 +1801,22 @@ int abz_autoptr_solve_many(abz_series* s, const int32_t* syms, int nsyms, int in
     // A solve like the last one (same grid sequence, same integrand) that went BEYOND two grids, with those grids' rules
     // kept: their scans are launched now as well, so the whole solve waits for the device once (a cached three-grid solve
     // of config 3: 0.126 -> 0.10 ms).  If the solve stops earlier the extra sums are dropped and the hint shrinks.
-    const uint64_t hint_key = ((uint64_t)(uint32_t)n0 << 40) ^ ((uint64_t)(uint32_t)dn << 20) ^ ((uint64_t)(uint32_t)integrand << 8) ^ (uint64_t)(uint32_t)ns_eff ^
-                              ((uint64_t)(uint32_t)n_sweep << 52);
+    // (the key covers what decides how far a solve goes: the grid sequence, the integrand and its parameters, the symmetry
+    // set, the tolerances -- a looser or differently parametrised call does not inherit the extra scans of a long one)
+    uint64_t hint_key = ((uint64_t)(uint32_t)n0 << 40) ^ ((uint64_t)(uint32_t)dn << 20) ^ ((uint64_t)(uint32_t)integrand << 8) ^ (uint64_t)(uint32_t)ns_eff ^
+                        ((uint64_t)(uint32_t)n_sweep << 52);
+    {
+        auto mix = [&](uint64_t v) { hint_key = (hint_key ^ v) * 0x9E3779B97F4A7C15ull + 0x7F4A7C15ull; };
+        auto mixd = [&](double v) {
+            uint64_t b;
+            std::memcpy(&b, &v, sizeof b);
+            mix(b);
+        };
+        mixd(atol);
+        mixd(rtol);
+        for (int i = 0; i < nparams && i < 4; ++i) mixd(params ? params[i] : 0.0);
+        for (size_t i = 0; syms && i < (size_t)nsyms * d * d; ++i) mix((uint64_t)(uint32_t)syms[i]);
+    }
     int nspec = 0;  // grids 2 ... 1 + nspec are pending in slots 2 ...
     int64_t nk_spec[NSLOT] = {0, 0, 0, 0};
     if (p0.pending && p1.pending && s->auto_hint_key == hint_key && s->auto_hint_grids > 2 && n_sweep <= 8) {

@@ -777,9 +777,9 @@ bool gen_sum_supported(int n, int M, int npt, int integrand, bool herm) {
     if (!(integrand == ABZ_F_DOS || integrand == ABZ_F_TRGLOC)) return false;
     const int np = n <= 8 ? 8 : (n <= 16 ? 16 : 32);
     const size_t rest = sizeof(double2) * (size_t)(256 / np) * 4;
-    // (17...32 bands go through the tridiagonal kernel, which stages a set that does not fit the LDS in chunks)
+    // (17...32 bands, and any set that does not fit the LDS whole, go through the tridiagonal kernel, which stages in chunks)
     return n > 16 ? abz_switch(SW_GEN_SUM_TRI) != 0 || sizeof(double2) * (size_t)M * n * n + rest <= 159 * 1024
-                  : sizeof(double2) * (size_t)M * n * n + rest <= 150 * 1024;
+                  : abz_switch(SW_GEN_SUM_TRI) != 0 || sizeof(double2) * (size_t)M * n * n + rest <= 150 * 1024;
 }
 
 static bool gen_sum_tri_wanted(const SumSpec& ss);
@@ -1236,7 +1236,9 @@ __global__ __launch_bounds__(256) void gen_grid_sum_tri_kernel(GenSumTriArgs a) 
 // sweeps of at least 3 values on 5..32 bands take the tridiagonal route
 static bool gen_sum_tri_wanted(const SumSpec& ss) {
     // (17...32 bands, two nodes per wave: the tridiagonal route wins for a single value as well -- 0.9 against 4.2 ms at 32^3)
-    return abz_switch(SW_GEN_SUM_TRI) && ss.n > 4 && ss.n <= 32 && (ss.n_sweep >= 3 || ss.n > 16);
+    const int np = ss.n <= 8 ? 8 : 16;
+    const bool whole = sizeof(double2) * (size_t)ss.M * ss.n * ss.n + sizeof(double2) * (size_t)(256 / np) * 4 <= 150 * 1024;  // gen_sum_supported's bound
+    return abz_switch(SW_GEN_SUM_TRI) && ss.n > 4 && ss.n <= 32 && (ss.n_sweep >= 3 || ss.n > 16 || !whole);
 }
 
 static int launch_gen_sum_tri(abz_ctx* ctx, const SumSpec& ss, double* out_reim) {
@@ -1804,9 +1806,12 @@ __global__ __launch_bounds__(64) void tri_eig_kernel(const double* __restrict__ 
             }
         }
     }
+    // A block that is still coupled when the budget runs out (LAPACK's dsterf returns info > 0 there) must not leave as
+    // plausible numbers: the node's eigenvalues become NaN, which every sum over the rule carries to the caller.
+    const bool failed = L > 0;
     double v[NP];
 #pragma unroll
-    for (int j = 0; j < NP; ++j) v[j] = j < n ? ld[j][lane] : __builtin_huge_val();
+    for (int j = 0; j < NP; ++j) v[j] = j < n ? (failed ? __builtin_nan("") : ld[j][lane]) : __builtin_huge_val();
 #pragma unroll
     for (int pass = 0; pass < NP; ++pass) {
 #pragma unroll

@@ -959,6 +959,40 @@ def test_generic_n_set_staged_in_chunks(abz):
     assert abs(b[2, 0].real - r0) <= 1e-10 * abs(r0)
 
 
+@pytest.mark.parametrize("n,M,npt", [(20, 45, 11), (32, 13, 19), (16, 45, 19), (8, 171, 35)])
+def test_generic_n_chunked_sets_second_groups_idle_waves_and_node_lists(abz, n, M, npt):
+    """The chunked staging (sets beyond the LDS) where the round-4 test did not reach: grids longer than one group of nodes
+    and not a multiple of it (a line's chunks are staged again for its second group; the last group leaves waves
+    without a node that only keep the staging barriers), the 8- and 16-lane instances, and the runs of an
+    inversion-symmetric node list through the same branch -- values, eigenvalues and sums against the oracle."""
+    rng = np.random.default_rng(100 * n + M)
+    c, first = rand_series(rng, (M, 3), n, hermitian=True)
+    s, so = both(abz, c / np.sqrt(n * M / 10), first)
+    L = abz._lib
+    rule = s.device().rule(npt, None, want=3)
+    out = rule.export(H=True, eig=True)
+    vals = orc.fourier_ptr(so, npt)
+    ref = np.transpose(vals, (1, 0, 2, 3)).reshape(-1, n, n)
+    assert np.abs(out["H"] - ref).max() <= 1e-12 * np.abs(ref).max()
+    assert np.abs(out["eig"] - np.linalg.eigvalsh(ref, UPLO="U")).max() <= 1e-11 * np.abs(ref).max()
+    om = np.linspace(-1.0, 1.0, 5)
+    a = rule.reduce(L.F_DOS, [0.2], om)
+    b = s.device().ptr_sum(npt, L.F_DOS, [0.2], om)
+    assert np.abs(a - b).max() <= 1e-11 * np.abs(a).max()
+    r0, _ = orc._ptr_rule_sum(so, npt, None, orc.f_dos(0.2, om[2]))
+    assert abs(b[2, 0].real - r0) <= 1e-10 * abs(r0)
+    # the symmetric (inversion) node list of the same series: runs of nodes per level-1 set
+    bzo = orc.load_bz("InversionSymIBZ", np.eye(2))
+    rs = s.device().rule(npt, bzo.syms, want=3)
+    outs = rs.export(x=True, w=True, H=True, eig=True)
+    Ho = orc.evaluate_many(so, outs["x"])
+    assert np.abs(outs["H"] - Ho).max() <= 1e-12 * np.abs(Ho).max()
+    assert np.abs(outs["eig"] - np.linalg.eigvalsh(Ho, UPLO="U")).max() <= 1e-11 * np.abs(Ho).max()
+    rsum, _ = orc._ptr_rule_sum(so, npt, bzo.syms, orc.f_dos(0.2, om[1]))
+    got = rs.reduce(L.F_DOS, [0.2], om[1:2])[0, 0].real
+    assert abs(got - rsum) <= 1e-10 * abs(rsum)
+
+
 def test_generic_n_unpadded_32_lane_layout(abz):
     """17...32 bands with a level-1 set too long for the zero-padded LDS layout (11 coefficients x 32 x 32 x 16 B = 180 KB):
     the unpadded instances of the 32-lane row kernels -- rule values and eigenvalues against the oracle, the store-free
