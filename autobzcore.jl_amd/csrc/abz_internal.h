@@ -63,6 +63,7 @@ enum Switch {
     SW_IAI_STATS,        // ABZ_IAI_STATS       per-solve statistics of the IAI driver on stderr
     SW_HOST_THREADS,     // ABZ_HOST_THREADS    host threads for the per-integral bookkeeping of IAI sweeps
     SW_AUTO_SWEEP_MAPPED,  // ABZ_AUTO_SWEEP_MAPPED  AutoPTR solves of <= 8 values: swept values read from pinned host memory
+    SW_BIG_MFMA,         // ABZ_BIG_MFMA        33...64 bands: level-1 evaluation of grid lines as a real GEMM on v_mfma_f64_16x16x4_f64
     SW_EIG_FOLD,         // ABZ_EIG_FOLD        5...16-band rule builds of Hermitian series: folded level-1 series
     SW_EIG_SPLIT,        // ABZ_EIG_SPLIT       5...16-band eigenvalue builds: tridiagonal eigenvalues in a kernel of their own
     SW_IAI_LANES,        // ABZ_IAI_LANES       lanes (host thread + stream each) an IAI sweep is split over
@@ -154,7 +155,7 @@ struct abz_ctx {
     unsigned prof = 0;  // bit k set: record HIP events around launches of kernel id k
     abz::ProfSlot prof_slots[ABZ_K_COUNT];
     std::vector<hipEvent_t> event_pool;
-    abz::DevBuf scratch[6];  // phases, partials, staging...
+    abz::DevBuf scratch[8];  // phases, partials, staging...
     void* pin = nullptr;     // pinned host staging buffer (hipHostMalloc), grown on demand
     size_t pin_cap = 0;
     // small pinned, device-visible mailbox: swept values go in through it without a synchronising pageable copy, and the
@@ -411,6 +412,7 @@ struct NodeEvalSpec {
     const double* sweep_arr = nullptr;  // device [nnodes]: per-node sweep value (overrides `sweep`)
     bool panels15 = false;  // every aligned run of 15 nodes is one GK(7,15) panel (same parent)
     bool packed = false;  // `src` holds PACKED Hermitian level-1 sets (packed_herm.h), n <= 4
+    bool herm = false;    // the series is Hermitian (33...64 bands: resolvent traces come from the tridiagonal of Hermitian(h))
 };
 int launch_node_integrand(abz_ctx* ctx, const NodeEvalSpec& ns, double2* values_dev);
 
@@ -536,6 +538,13 @@ bool gen_sum_supported(int n, int M, int npt, int integrand, bool herm);
 // kernel gen_grid_eig_kernel fills it (and every scan of kernels_generic.hip reads either layout)
 bool gen_compact_supported(int n, int M, int npt);
 int launch_gen_sum(abz_ctx* ctx, const SumSpec& ss, double* out_reim);
+// 33...64 bands (kernels_big.hip): wave-per-node Householder with the matrix in LDS, eigenvalues by bisection, resolvent
+// traces from the tridiagonal
+bool big_supported(int n);
+bool big_sum_supported(int n, int M, int npt, int integrand, bool herm);
+int launch_big_nodes(abz_ctx* ctx, const GenSpec& gs);
+int launch_big_sum(abz_ctx* ctx, const SumSpec& ss, double* out_reim);
+int launch_big_reduce(abz_ctx* ctx, const ReduceSpec& rs, double* out_reim);
 int launch_gen_reduce(abz_ctx* ctx, const ReduceSpec& rs, double* out_reim);
 
 }  // namespace abz

@@ -691,6 +691,7 @@ int IaiDriver::eval_nodes(int64_t nn) {
     ns.period = s->period[0];
     ns.src = (d == 1) ? top_coef() : s->iai_pool[1].as<double2>();
     ns.packed = pk;
+    ns.herm = s->hermitian;
     ns.parents = s->iai_io[0].as<int64_t>();
     ns.x = s->iai_io[1].as<double>();
     ns.tail = need_tail ? s->iai_io[2].as<double>() : nullptr;

@@ -2195,6 +2195,7 @@ int launch_node_integrand(abz_ctx* ctx, const NodeEvalSpec& ns, double2* values_
         gs.tab = nullptr;
         gs.deriv = false;
         gs.panels15 = ns.panels15;
+        gs.herm = ns.herm;
         gs.nnodes = ns.nnodes;
         gs.Hplanes = PlaneView();
         gs.Eplanes = PlaneView();

@@ -1,0 +1,693 @@
+// 33...64 bands (ref: src/fourier.jl:22-58 is generic in the matrix size; eigen(Hermitian(h)) goes through LAPACK there,
+// src/dos_ggr.jl:19): the row layout of kernels_generic.hip ends at 32 lanes per node (two DPP rows, 512 registers for a
+// 32 x 32 complex row block), so these sizes take a third route, generic in n at run time:
+//   big_series_kernel      H(k) of a chunk of nodes into a scratch array [node][n * n] -- the level-1 evaluation
+//                          [nodes x M] . [M x n^2] as plain FMAs (a tile of nodes shares every coefficient read) or, on full grid
+//                          lines, as a real GEMM [16 nodes x 2M] . [2M x 16 columns] on v_mfma_f64_16x16x4_f64
+//                          (ABZ_BIG_MFMA; measured in profiles/r05_big_series_mfma_vs_fma.txt -- f64 MFMA and f64 FMA share
+//                          the DP units);
+//   big_tridiag_kernel     Householder tridiagonalisation, ONE WAVE PER NODE, the matrix in a wave-private LDS slab
+//                          (lane r owns row r: no lane reads LDS bytes another lane wrote except the reflector v and q);
+//   big_bisect_kernel      eigenvalue b of the tridiagonal by Sturm bisection, one thread per (node, band);
+//   big_trace_kernel       tr inv((w + i eta) I - H) = p'(z) / p(z) from the three-term recurrence of the tridiagonal, one
+//                          thread per (node, swept value): node values (IAI) or weighted partial sums (rules, store-free sums).
+// Serves abz_eval_nodes, rule builds (H and / or eigenvalues, full layout), scans of cached rules (DOS / tr G from the
+// matrices or the eigenvalues), store-free PTR sums and the IAI node path.  Matrix-valued G, velocities (GGR) and the
+// Hermitian-compact layout stay at <= 32 bands.
+#include <utility>
+
+#include "abz_internal.h"
+
+namespace abz {
+
+namespace {
+
+constexpr int BIG_NP = 64;  // rows of the tridiagonal scratch [2 BIG_NP][tri_nk]
+constexpr int BIG_TN = 8;   // nodes per tile of the FMA series kernel
+
+static inline int64_t cdivb(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+__device__ __forceinline__ int64_t bview_off(const PlaneView& v, int64_t k) {
+    const int64_t line = k / v.line_len;
+    return line * v.tile + (k - line * v.line_len);
+}
+__device__ __forceinline__ double bwsum(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+__device__ __forceinline__ void bwave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+struct BigSeriesArgs {
+    const double2* src;      // level-1 sets [item][M][n * n]
+    const int64_t* parents;  // node -> item (nullptr: grid lines, item = node / npt)
+    const int32_t* gi;       // node -> grid index of variable 1 (nullptr with grid: node % npt)
+    const double* x;         // explicit coordinate of variable 1 (then gi is ignored)
+    const double2* tab;      // e^{2 pi i j / npt}
+    int64_t node0, nnodes;   // this chunk: nodes [node0, node0 + nnodes)
+    int n, M, first, npt, grid;
+    double inv_period;
+    double2* Hbuf;           // [nnodes][n * n], element (a, b) at a + n b like the coefficient blocks
+};
+
+__device__ __forceinline__ double2 big_phase(const BigSeriesArgs& a, int64_t k, int m) {
+    const int f = a.first + m;
+    if (a.x) {
+        double s, c;
+        sincospi(2.0 * ((double)f * a.x[k] * a.inv_period), &s, &c);
+        return make_double2(c, s);
+    }
+    const int64_t i1 = a.gi ? (int64_t)a.gi[k] : k % a.npt;
+    int64_t fm = f % a.npt;
+    if (fm < 0) fm += a.npt;
+    return a.tab[(fm * i1) % a.npt];
+}
+
+// tile of BIG_TN consecutive nodes: they share the coefficient reads when they share their item (grid lines: a tile never
+// crosses a line; node lists: checked per tile, otherwise node by node)
+__global__ __launch_bounds__(256) void big_series_kernel(BigSeriesArgs a, int tiles_per_line) {
+    __shared__ double2 ph[BIG_TN][64];  // [node][m], M <= 64
+    __shared__ int64_t item_s[BIG_TN];
+    const int nn = a.n * a.n;
+    int64_t t0;
+    int cnt;
+    if (a.grid) {
+        const int64_t line = blockIdx.x / tiles_per_line;  // (of this chunk: node0 is a multiple of npt in grid mode)
+        const int tl = (int)(blockIdx.x - line * tiles_per_line);
+        t0 = line * a.npt + (int64_t)tl * BIG_TN;
+        cnt = min(BIG_TN, a.npt - tl * BIG_TN);
+    } else {
+        t0 = (int64_t)blockIdx.x * BIG_TN;
+        cnt = (int)min((int64_t)BIG_TN, a.nnodes - t0);
+    }
+    if (cnt <= 0) return;
+    for (int t = threadIdx.x; t < cnt * a.M; t += 256) {
+        const int j = t / a.M, m = t - j * a.M;
+        ph[j][m] = big_phase(a, a.node0 + t0 + j, m);
+    }
+    if (threadIdx.x < cnt) {
+        const int64_t k = a.node0 + t0 + threadIdx.x;
+        item_s[threadIdx.x] = a.parents ? a.parents[k] : (a.grid ? k / a.npt : 0);  // (node lists without parents: d = 1, one set)
+    }
+    __syncthreads();
+    bool same = true;
+    for (int j = 1; j < cnt; ++j) same = same && item_s[j] == item_s[0];
+    if (same) {
+        const double2* __restrict__ c1 = a.src + item_s[0] * ((int64_t)a.M * nn);
+        for (int e = threadIdx.x; e < nn; e += 256) {
+            double ar[BIG_TN], ai[BIG_TN];
+#pragma unroll
+            for (int j = 0; j < BIG_TN; ++j) {
+                ar[j] = 0.0;
+                ai[j] = 0.0;
+            }
+            for (int m = 0; m < a.M; ++m) {
+                const double2 c = c1[(int64_t)m * nn + e];
+#pragma unroll
+                for (int j = 0; j < BIG_TN; ++j) {
+                    const double2 p = ph[j][m];
+                    ar[j] = fma(c.x, p.x, ar[j]);
+                    ar[j] = fma(-c.y, p.y, ar[j]);
+                    ai[j] = fma(c.x, p.y, ai[j]);
+                    ai[j] = fma(c.y, p.x, ai[j]);
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < BIG_TN; ++j)
+                if (j < cnt) a.Hbuf[(t0 + j) * nn + e] = make_double2(ar[j], ai[j]);
+        }
+    } else {
+        for (int j = 0; j < cnt; ++j) {
+            const double2* __restrict__ c1 = a.src + item_s[j] * ((int64_t)a.M * nn);
+            for (int e = threadIdx.x; e < nn; e += 256) {
+                double ar = 0.0, ai = 0.0;
+                for (int m = 0; m < a.M; ++m) {
+                    const double2 c = c1[(int64_t)m * nn + e], p = ph[j][m];
+                    ar = fma(c.x, p.x, ar);
+                    ar = fma(-c.y, p.y, ar);
+                    ai = fma(c.x, p.y, ai);
+                    ai = fma(c.y, p.x, ai);
+                }
+                a.Hbuf[(t0 + j) * nn + e] = make_double2(ar, ai);
+            }
+        }
+    }
+}
+
+// The same on the matrix cores, full grid lines only: a workgroup takes 16 consecutive nodes of a line; wave w the column
+// blocks e0 = 16 (w + 4 i) of the n^2 elements.  Real GEMM over k = (m, part):  Re H = sum_m c.re p.re - c.im p.im,
+// Im H = sum_m c.re p.im + c.im p.re, i.e. two accumulations D_re, D_im that share the B operand (the coefficients).
+// v_mfma_f64_16x16x4_f64 operands (one double per lane): A[i = lane % 16][k = lane / 16], B[k = lane / 16][j = lane % 16],
+// D: four doubles per lane, D[i = lane / 16 + 4 r][j = lane % 16] (found by the parity test: the other blocking fails it).
+typedef double bdouble4 __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void big_series_mfma_kernel(BigSeriesArgs a, int tiles_per_line) {
+    __shared__ double2 ph[16][64];
+    const int nn = a.n * a.n;
+    const int64_t line = blockIdx.x / tiles_per_line;
+    const int tl = (int)(blockIdx.x - line * tiles_per_line);
+    const int64_t t0 = line * a.npt + (int64_t)tl * 16;
+    const int cnt = min(16, a.npt - tl * 16);
+    for (int t = threadIdx.x; t < 16 * a.M; t += 256) {
+        const int j = t / a.M, m = t - j * a.M;
+        ph[j][m] = j < cnt ? big_phase(a, a.node0 + t0 + j, m) : make_double2(0.0, 0.0);
+    }
+    __syncthreads();
+    const double2* __restrict__ c1 = a.src + ((a.node0 + t0) / a.npt) * ((int64_t)a.M * nn);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int li = lane & 15, lk = lane >> 4;  // operand row / column, k inside a group of four
+    const int K = 2 * a.M;
+    for (int e0 = 16 * wave; e0 < nn; e0 += 64) {
+        bdouble4 dre = {0.0, 0.0, 0.0, 0.0}, dim = {0.0, 0.0, 0.0, 0.0};
+        for (int k0 = 0; k0 < K; k0 += 4) {
+            const int k = k0 + lk;            // this lane's k: coefficient m = k / 2, part = k % 2 (0: re, 1: im)
+            const int m = k >> 1, part = k & 1;
+            const bool in = k < K;
+            const int mm = in ? m : 0;
+            const double2 p = ph[li][mm];     // A operand: node li
+            const double2 c = (e0 + li < nn) ? c1[(int64_t)mm * nn + e0 + li] : make_double2(0.0, 0.0);  // B operand: column li
+            const double bv = in ? (part ? c.y : c.x) : 0.0;
+            const double are = in ? (part ? -p.y : p.x) : 0.0;  // Re H: + c.re p.re - c.im p.im
+            const double aim = in ? (part ? p.x : p.y) : 0.0;   // Im H: + c.re p.im + c.im p.re
+#if defined(__HIP_DEVICE_COMPILE__)
+            dre = __builtin_amdgcn_mfma_f64_16x16x4f64(are, bv, dre, 0, 0, 0);
+            dim = __builtin_amdgcn_mfma_f64_16x16x4f64(aim, bv, dim, 0, 0, 0);
+#endif
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int node = lk + 4 * r;
+            if (node < cnt && e0 + li < nn) a.Hbuf[(t0 + node) * nn + e0 + li] = make_double2(dre[r], dim[r]);
+        }
+    }
+}
+
+// Hbuf -> the rule's planes (full layout: plane 2 (a + n b) + {0, 1}) and / or the AoS array of abz_eval_nodes
+__global__ __launch_bounds__(256) void big_store_h_kernel(const double2* __restrict__ Hbuf, int64_t node0, int64_t nnodes, int n, PlaneView H,
+                                                          double2* Haos) {
+    const int nn = n * n;
+    const int64_t total = (nnodes + 63) / 64 * 64 * nn;  // (groups of 64 nodes, the last one padded)
+    for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += (int64_t)gridDim.x * 256) {
+        // plane-major inside a group of 64 nodes: consecutive threads write consecutive nodes of one plane
+        const int64_t grp = t / (64 * nn);
+        const int64_t rem = t - grp * (64 * nn);
+        const int e = (int)(rem / 64);
+        const int64_t node = grp * 64 + (rem & 63);
+        if (node >= nnodes) continue;
+        const double2 v = Hbuf[node * nn + e];
+        if (H.base) {
+            double* ho = H.base + bview_off(H, node0 + node);
+            ho[(int64_t)(2 * e) * H.pitch] = v.x;
+            ho[(int64_t)(2 * e + 1) * H.pitch] = v.y;
+        }
+        if (Haos) Haos[(node0 + node) * nn + e] = v;
+    }
+}
+
+// a cached rule's planes -> Hbuf (scans of the matrices)
+__global__ __launch_bounds__(256) void big_load_h_kernel(double2* __restrict__ Hbuf, int64_t node0, int64_t nnodes, int n, PlaneView H) {
+    const int nn = n * n;
+    const int64_t total = (nnodes + 63) / 64 * 64 * nn;
+    for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += (int64_t)gridDim.x * 256) {
+        const int64_t grp = t / (64 * nn);
+        const int64_t rem = t - grp * (64 * nn);
+        const int e = (int)(rem / 64);
+        const int64_t node = grp * 64 + (rem & 63);
+        if (node >= nnodes) continue;
+        const double* hi = H.base + bview_off(H, node0 + node);
+        Hbuf[node * nn + e] = make_double2(hi[(int64_t)(2 * e) * H.pitch], hi[(int64_t)(2 * e + 1) * H.pitch]);
+    }
+}
+
+// Householder tridiagonalisation of Hermitian(h) (the upper triangle of each n x n block of Hbuf, like the reference's
+// Hermitian wrapper): d_j -> tri[j][t], |e_j|^2 -> tri[BIG_NP + j][t], t = t0 + node.  One wave per node; lane r owns row r.
+__global__ __launch_bounds__(64) void big_tridiag_kernel(const double2* __restrict__ Hbuf, int64_t nnodes, int n, double* __restrict__ tri,
+                                                         int64_t tri_nk, int64_t t0) {
+    extern __shared__ double2 lds_bt[];  // A [n][n] (element (i, j) at i + n j), then v [n], q [n]
+    double2* const A = lds_bt;
+    double2* const vv = lds_bt + (size_t)n * n;
+    double2* const qq = vv + n;
+    const int lane = threadIdx.x, i = lane;
+    const bool row = i < n;
+    for (int64_t node = blockIdx.x; node < nnodes; node += gridDim.x) {
+        const double2* __restrict__ h = Hbuf + node * ((int64_t)n * n);
+        bwave_sync();
+        for (int e = lane; e < n * n; e += 64) {
+            const int r = e % n, c = e / n;
+            double2 v = r <= c ? h[r + n * c] : h[c + n * r];
+            if (r > c) v.y = -v.y;
+            if (r == c) v.y = 0.0;
+            A[e] = v;
+        }
+        bwave_sync();
+        for (int k = 0; k + 1 < n; ++k) {
+            const bool below = row && i > k;
+            const double2 x = below ? A[i + n * k] : make_double2(0.0, 0.0);
+            const double sigma = bwsum(x.x * x.x + x.y * x.y);
+            if (lane == k) {
+                tri[(int64_t)k * tri_nk + t0 + node] = A[k + n * k].x;
+                tri[(int64_t)(BIG_NP + k) * tri_nk + t0 + node] = sigma;
+            }
+            if (k + 2 >= n || !(sigma > 0.0)) continue;  // uniform
+            const double x1r = __shfl(x.x, k + 1, 64), x1i = __shfl(x.y, k + 1, 64);
+            const double a1sq = x1r * x1r + x1i * x1i;
+            // v = x + (x1 / |x1|) ||x|| e_1, beta = 1 / (sigma + ||x|| |x1|)
+            const double nrm = sqrt(sigma), a1 = sqrt(a1sq);
+            double v1r, v1i;
+            if (a1 > 0.0) {
+                const double fac = 1.0 + nrm / a1;
+                v1r = x1r * fac;
+                v1i = x1i * fac;
+            } else {
+                v1r = nrm;
+                v1i = 0.0;
+            }
+            const double beta = 1.0 / (sigma + nrm * a1);
+            const double2 v = (i == k + 1) ? make_double2(v1r, v1i) : x;  // zero in rows <= k and >= n
+            if (row) vv[i] = v;
+            bwave_sync();
+            // p_i = beta sum_{j > k} A[i][j] v_j
+            double pr = 0.0, pi = 0.0;
+            if (below) {
+                for (int j = k + 1; j < n; ++j) {
+                    const double2 aij = A[i + n * j], vj = vv[j];
+                    pr = fma(aij.x, vj.x, pr);
+                    pr = fma(-aij.y, vj.y, pr);
+                    pi = fma(aij.x, vj.y, pi);
+                    pi = fma(aij.y, vj.x, pi);
+                }
+            }
+            pr *= beta;
+            pi *= beta;
+            // kappa = (beta / 2) v^H p;  q = p - kappa v
+            const double kr = 0.5 * beta * bwsum(v.x * pr + v.y * pi);
+            const double ki = 0.5 * beta * bwsum(v.x * pi - v.y * pr);
+            const double qr = pr - (kr * v.x - ki * v.y), qi = pi - (kr * v.y + ki * v.x);
+            if (row) qq[i] = make_double2(qr, qi);
+            bwave_sync();
+            // A[i][j] -= v_i conj(q_j) + q_i conj(v_j), i, j > k
+            if (below) {
+                for (int j = k + 1; j < n; ++j) {
+                    const double2 vj = vv[j], qj = qq[j];
+                    double2 aij = A[i + n * j];
+                    aij.x -= (v.x * qj.x + v.y * qj.y) + (qr * vj.x + qi * vj.y);
+                    aij.y -= (v.y * qj.x - v.x * qj.y) + (qi * vj.x - qr * vj.y);
+                    A[i + n * j] = aij;
+                }
+            }
+            bwave_sync();
+        }
+        if (lane == n - 1) {
+            tri[(int64_t)(n - 1) * tri_nk + t0 + node] = A[(n - 1) + n * (n - 1)].x;
+            tri[(int64_t)(BIG_NP + n - 1) * tri_nk + t0 + node] = 0.0;
+        }
+    }
+}
+
+// eigenvalue `band` (ascending) of each tridiagonal: bisection on the Sturm count (ratio form with LAPACK's pivot guard),
+// 4 nodes x 64 bands per workgroup
+__global__ __launch_bounds__(256) void big_bisect_kernel(const double* __restrict__ tri, int64_t tri_nk, int64_t t0, int64_t node0, int64_t nnodes,
+                                                         int n, PlaneView E, double* __restrict__ Eaos) {
+    __shared__ double ds[4][BIG_NP], es[4][BIG_NP];
+    const int slot = threadIdx.x >> 6, band = threadIdx.x & 63;
+    const int64_t node = (int64_t)blockIdx.x * 4 + slot;
+    const bool act = node < nnodes;
+    const int64_t kk = act ? node : nnodes - 1;
+    ds[slot][band] = band < n ? tri[(int64_t)band * tri_nk + t0 + kk] : 0.0;
+    es[slot][band] = band + 1 < n ? tri[(int64_t)(BIG_NP + band) * tri_nk + t0 + kk] : 0.0;
+    __syncthreads();
+    const double* __restrict__ d = ds[slot];
+    const double* __restrict__ e2 = es[slot];
+    double lo = d[0], hi = d[0], eprev = 0.0, emax = 0.0;
+    for (int j = 0; j < n; ++j) {
+        const double en = j + 1 < n ? sqrt(e2[j]) : 0.0;
+        lo = fmin(lo, d[j] - eprev - en);
+        hi = fmax(hi, d[j] + eprev + en);
+        emax = fmax(emax, e2[j]);
+        eprev = en;
+    }
+    const double span = fmax(fabs(lo), fabs(hi));
+    lo -= 2.3e-16 * span * n + 4.9e-324;
+    hi += 2.3e-16 * span * n + 4.9e-324;
+    const double pivmin = fmax(2.3e-308 * fmax(emax, 1.0), 4.9e-324);
+    const int want = band < n ? band : n - 1;
+    for (int it = 0; it < 120; ++it) {
+        const double mid = 0.5 * (lo + hi);
+        if (!(mid > lo && mid < hi)) break;
+        int cnt = 0;
+        double q = d[0] - mid;
+        if (fabs(q) < pivmin) q = -pivmin;
+        cnt += q < 0.0;
+        for (int j = 1; j < n; ++j) {
+            q = d[j] - mid - e2[j - 1] / q;
+            if (fabs(q) < pivmin) q = -pivmin;
+            cnt += q < 0.0;
+        }
+        if (cnt > want)
+            hi = mid;
+        else
+            lo = mid;
+    }
+    if (act && band < n) {
+        const double ev = 0.5 * (lo + hi);
+        if (E.base) E.base[bview_off(E, node0 + node) + (int64_t)band * E.pitch] = ev;
+        if (Eaos) Eaos[(node0 + node) * n + band] = ev;
+    }
+}
+
+// tr inv((w + i eta) I - H) from the tridiagonal: p_0 = 1, p_1 = z - d_0, p_{j+1} = (z - d_j) p_j - |e_{j-1}|^2 p_{j-1}, the
+// same recurrence for p'; scaled to unit Gershgorin radius (rows_trace_resolvent_tri of rows_device.h does the same for <= 32)
+struct BigTraceArgs {
+    const double* tri;
+    int64_t tri_nk, t0, node0, nnodes;
+    int n, n_sweep, is_dos;
+    double eta;
+    const double* sweep;           // device [n_sweep] (or null: sweep0)
+    const double* sweep_per_node;  // device [all nodes]: one value per node
+    double sweep0;
+    const double* w;               // weights of the nodes (sum mode) or null
+    double2* values;               // node mode: [node][n_sweep]
+    double2* partial;              // sum mode: [gridDim.x][n_sweep]
+};
+__global__ __launch_bounds__(256) void big_trace_kernel(BigTraceArgs a) {
+    __shared__ double red[2][4];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    for (int s = 0; s < a.n_sweep; ++s) {
+        double accr = 0.0, acci = 0.0;
+        for (int64_t node = (int64_t)blockIdx.x * 256 + threadIdx.x; node < a.nnodes; node += (int64_t)gridDim.x * 256) {
+            const double sw = a.sweep_per_node ? a.sweep_per_node[a.node0 + node] : (a.sweep ? a.sweep[s] : a.sweep0);
+            const double* __restrict__ d = a.tri + a.t0 + node;
+            double rad = 0.0, eprev = 0.0;
+            for (int j = 0; j < a.n; ++j) {
+                const double en = j + 1 < a.n ? sqrt(d[(int64_t)(BIG_NP + j) * a.tri_nk]) : 0.0;
+                rad = fmax(rad, fabs(d[(int64_t)j * a.tri_nk]) + eprev + en);
+                eprev = en;
+            }
+            const double sc = 1.0 / (rad + fabs(sw) + a.eta);
+            const double zr = sw * sc, zi = a.eta * sc;
+            double p0r = 1.0, p0i = 0.0, p1r = zr - d[0] * sc, p1i = zi;
+            double q0r = 0.0, q0i = 0.0, q1r = 1.0, q1i = 0.0;
+            for (int j = 1; j < a.n; ++j) {
+                const double ar = zr - d[(int64_t)j * a.tri_nk] * sc, ai = zi;
+                const double ee = d[(int64_t)(BIG_NP + j - 1) * a.tri_nk] * sc * sc;
+                const double npr = fma(ar, p1r, fma(-ai, p1i, -ee * p0r));
+                const double npi = fma(ar, p1i, fma(ai, p1r, -ee * p0i));
+                const double nqr = p1r + fma(ar, q1r, fma(-ai, q1i, -ee * q0r));
+                const double nqi = p1i + fma(ar, q1i, fma(ai, q1r, -ee * q0i));
+                p0r = p1r;
+                p0i = p1i;
+                p1r = npr;
+                p1i = npi;
+                q0r = q1r;
+                q0i = q1i;
+                q1r = nqr;
+                q1i = nqi;
+            }
+            const double ip = sc / (p1r * p1r + p1i * p1i);
+            double tr = (q1r * p1r + q1i * p1i) * ip, ti = (q1i * p1r - q1r * p1i) * ip;
+            if (a.is_dos) {
+                tr = -ti * 0.31830988618379067153776752674503;
+                ti = 0.0;
+            }
+            if (a.values) {
+                a.values[(a.node0 + node) * a.n_sweep + s] = make_double2(tr, ti);
+            } else {
+                const double wk = a.w ? a.w[a.node0 + node] : 1.0;
+                accr = fma(wk, tr, accr);
+                acci = fma(wk, ti, acci);
+            }
+        }
+        if (a.partial) {
+            __syncthreads();
+            accr = bwsum(accr);
+            acci = bwsum(acci);
+            if (lane == 0) {
+                red[0][wave] = accr;
+                red[1][wave] = acci;
+            }
+            __syncthreads();
+            if (threadIdx.x == 0)
+                a.partial[(int64_t)blockIdx.x * a.n_sweep + s] =
+                    make_double2((red[0][0] + red[0][1]) + (red[0][2] + red[0][3]), (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]));
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void big_accumulate_kernel(double2* __restrict__ total, const double2* __restrict__ part, int n) {
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t < n) {
+        total[t].x += part[t].x;
+        total[t].y += part[t].y;
+    }
+}
+
+struct BigWork {
+    double2* Hbuf = nullptr;
+    double* tri = nullptr;
+    int64_t chunk = 0, tri_nk = 0;
+};
+
+int big_reserve(abz_ctx* ctx, int n, int npt_or_zero, int64_t nnodes, BigWork& w) {
+    // chunks of nodes: <= 256 MB of matrices, whole grid lines in grid mode
+    int64_t c = std::max<int64_t>(1, (int64_t)(256ull << 20) / ((int64_t)sizeof(double2) * n * n));
+    if (npt_or_zero > 0) c = std::max<int64_t>(1, c / npt_or_zero) * npt_or_zero;
+    c = std::min(c, nnodes);
+    w.chunk = c;
+    w.tri_nk = (c + 63) / 64 * 64;
+    int rc = ctx->scratch[6].reserve(sizeof(double2) * (size_t)c * n * n);
+    if (rc) return rc;
+    if ((rc = ctx->scratch[4].reserve(sizeof(double) * (size_t)(2 * BIG_NP) * (size_t)w.tri_nk))) return rc;
+    w.Hbuf = ctx->scratch[6].as<double2>();
+    w.tri = ctx->scratch[4].as<double>();
+    return ABZ_OK;
+}
+
+int big_tridiag(abz_ctx* ctx, const BigWork& w, int n, int64_t cn) {
+    const size_t lds = sizeof(double2) * ((size_t)n * n + 2 * (size_t)n);
+    ABZ_HIP(hipFuncSetAttribute((const void*)big_tridiag_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const int64_t blocks = std::min<int64_t>(cn, 256 * 8);
+    hipLaunchKernelGGL(big_tridiag_kernel, dim3((unsigned)blocks), dim3(64), lds, ctx->stream, w.Hbuf, cn, n, w.tri, w.tri_nk, (int64_t)0);
+    ABZ_HIP(hipGetLastError());
+    return ABZ_OK;
+}
+
+int big_series(abz_ctx* ctx, BigSeriesArgs& sa, int64_t c0, int64_t cn) {
+    sa.node0 = c0;
+    sa.nnodes = cn;
+    if (sa.grid) {
+        const int64_t lines = cn / sa.npt;
+        if (abz_switch(SW_BIG_MFMA)) {
+            const int tpl = (sa.npt + 15) / 16;
+            hipLaunchKernelGGL(big_series_mfma_kernel, dim3((unsigned)(lines * tpl)), dim3(256), 0, ctx->stream, sa, tpl);
+        } else {
+            const int tpl = (sa.npt + BIG_TN - 1) / BIG_TN;
+            hipLaunchKernelGGL(big_series_kernel, dim3((unsigned)(lines * tpl)), dim3(256), 0, ctx->stream, sa, tpl);
+        }
+    } else {
+        hipLaunchKernelGGL(big_series_kernel, dim3((unsigned)cdivb(cn, BIG_TN)), dim3(256), 0, ctx->stream, sa, 0);
+    }
+    ABZ_HIP(hipGetLastError());
+    return ABZ_OK;
+}
+
+}  // namespace
+
+bool big_supported(int n) { return n > 32 && n <= ABZ_MAX_BANDS; }
+
+// abz_eval_nodes, rule builds (full layout) and the IAI node path
+int launch_big_nodes(abz_ctx* ctx, const GenSpec& gs) {
+    if (gs.nnodes == 0) return ABZ_OK;
+    if (gs.deriv || gs.Uplanes.base || gs.Hplanes.compact) {
+        set_error("n = %d bands: derivative series / eigenvectors / the upper-triangle layout are built for n <= 32", gs.n);
+        return ABZ_ERR_UNSUPPORTED;
+    }
+    if (gs.M > 64) {
+        set_error("n = %d bands: at most 64 coefficients per variable (got %d)", gs.n, gs.M);
+        return ABZ_ERR_UNSUPPORTED;
+    }
+    if (gs.values && !(gs.integrand == ABZ_F_DOS || gs.integrand == ABZ_F_TRGLOC)) {
+        set_error("n = %d bands: integrand %d is built for n <= 32 (DOS and tr G are available)", gs.n, gs.integrand);
+        return ABZ_ERR_UNSUPPORTED;
+    }
+    if (gs.values && !gs.herm) {  // (eigenvalues are those of Hermitian(h), the upper triangle, whatever the series)
+        set_error("n = %d bands: resolvent traces need a Hermitian series", gs.n);
+        return ABZ_ERR_UNSUPPORTED;
+    }
+    BigWork w;
+    int rc = big_reserve(ctx, gs.n, gs.grid ? gs.npt : 0, gs.nnodes, w);
+    if (rc) return rc;
+    BigSeriesArgs sa;
+    sa.src = gs.src;
+    sa.parents = gs.grid ? nullptr : gs.parents;
+    sa.gi = gs.grid ? nullptr : gs.gi;
+    sa.x = gs.x;
+    sa.tab = gs.tab;
+    sa.n = gs.n;
+    sa.M = gs.M;
+    sa.first = gs.first;
+    sa.npt = gs.npt > 0 ? gs.npt : 1;
+    sa.grid = gs.grid ? 1 : 0;
+    sa.inv_period = 1.0 / gs.period;
+    sa.Hbuf = w.Hbuf;
+    ProfScope ps(ctx, ABZ_K_EVAL);
+    for (int64_t c0 = 0; c0 < gs.nnodes; c0 += w.chunk) {
+        const int64_t cn = std::min(w.chunk, gs.nnodes - c0);
+        if ((rc = big_series(ctx, sa, c0, cn))) return rc;
+        if (gs.Hplanes.base || gs.Haos) {
+            hipLaunchKernelGGL(big_store_h_kernel, dim3((unsigned)std::min<int64_t>(cdivb((cn + 63) / 64 * 64 * gs.n * gs.n, 256), 256 * 16)), dim3(256), 0, ctx->stream,
+                               w.Hbuf, c0, cn, gs.n, gs.Hplanes, gs.Haos);
+            ABZ_HIP(hipGetLastError());
+        }
+        if (!(gs.Eplanes.base || gs.Eaos || gs.values)) continue;
+        if ((rc = big_tridiag(ctx, w, gs.n, cn))) return rc;
+        if (gs.Eplanes.base || gs.Eaos) {
+            hipLaunchKernelGGL(big_bisect_kernel, dim3((unsigned)cdivb(cn, 4)), dim3(256), 0, ctx->stream, w.tri, w.tri_nk, (int64_t)0, c0, cn, gs.n,
+                               gs.Eplanes, gs.Eaos);
+            ABZ_HIP(hipGetLastError());
+        }
+        if (gs.values) {
+            BigTraceArgs ta;
+            ta.tri = w.tri;
+            ta.tri_nk = w.tri_nk;
+            ta.t0 = 0;
+            ta.node0 = c0;
+            ta.nnodes = cn;
+            ta.n = gs.n;
+            ta.n_sweep = gs.n_sweep > 0 ? gs.n_sweep : 1;
+            ta.is_dos = gs.integrand == ABZ_F_DOS ? 1 : 0;
+            ta.eta = gs.params[0];
+            ta.sweep = gs.sweep_dev;
+            ta.sweep_per_node = gs.sweep_per_node;
+            ta.sweep0 = gs.sweep0;
+            ta.w = nullptr;
+            ta.values = gs.values;
+            ta.partial = nullptr;
+            hipLaunchKernelGGL(big_trace_kernel, dim3((unsigned)std::min<int64_t>(cdivb(cn, 256), 256 * 4)), dim3(256), 0, ctx->stream, ta);
+            ABZ_HIP(hipGetLastError());
+        }
+    }
+    return ABZ_OK;
+}
+
+// sums of resolvent traces over tridiagonals of chunks: shared by the store-free sums and the scans of cached matrices
+static int big_sum_chunk(abz_ctx* ctx, const BigWork& w, int n, int64_t c0, int64_t cn, int is_dos, double eta, const double* sweep_dev, int n_sweep,
+                         const double* weights, double2* total, bool first) {
+    const int64_t blocks = std::max<int64_t>(1, std::min<int64_t>(cdivb(cn, 256), 256 * 2));
+    int rc = ctx->scratch[1].reserve(sizeof(double2) * (size_t)(blocks * n_sweep + n_sweep));
+    if (rc) return rc;
+    BigTraceArgs ta;
+    ta.tri = w.tri;
+    ta.tri_nk = w.tri_nk;
+    ta.t0 = 0;
+    ta.node0 = c0;
+    ta.nnodes = cn;
+    ta.n = n;
+    ta.n_sweep = n_sweep;
+    ta.is_dos = is_dos;
+    ta.eta = eta;
+    ta.sweep = sweep_dev;
+    ta.sweep_per_node = nullptr;
+    ta.sweep0 = 0.0;
+    ta.w = weights;
+    ta.values = nullptr;
+    ta.partial = ctx->scratch[1].as<double2>();
+    hipLaunchKernelGGL(big_trace_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, ta);
+    ABZ_HIP(hipGetLastError());
+    double2* part = ta.partial + blocks * n_sweep;
+    if ((rc = launch_final_reduce(ctx, ta.partial, blocks, n_sweep, 1.0, first ? total : part))) return rc;
+    if (!first) {
+        hipLaunchKernelGGL(big_accumulate_kernel, dim3((unsigned)cdivb(n_sweep, 256)), dim3(256), 0, ctx->stream, total, part, n_sweep);
+        ABZ_HIP(hipGetLastError());
+    }
+    return ABZ_OK;
+}
+
+__global__ __launch_bounds__(256) void big_scale_kernel(double2* v, int n, double s) {
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t < n) {
+        v[t].x *= s;
+        v[t].y *= s;
+    }
+}
+
+bool big_sum_supported(int n, int M, int npt, int integrand, bool herm) {
+    return big_supported(n) && herm && M <= 64 && npt >= 1 && npt < 65536 && (integrand == ABZ_F_DOS || integrand == ABZ_F_TRGLOC);
+}
+
+// store-free PTR sums (abz_ptr_sum)
+int launch_big_sum(abz_ctx* ctx, const SumSpec& ss, double* out_reim) {
+    const int64_t nnodes = ss.nlines * ss.npt;
+    BigWork w;
+    int rc = big_reserve(ctx, ss.n, ss.npt, nnodes, w);
+    if (rc) return rc;
+    if ((rc = ctx->scratch[2].reserve(sizeof(double2) * (size_t)ss.n_sweep))) return rc;
+    if ((rc = ctx->scratch[5].reserve(sizeof(double) * (size_t)ss.n_sweep))) return rc;
+    double* sw = ctx->scratch[5].as<double>();
+    ABZ_HIP(hipMemcpyAsync(sw, ss.sweep_host, sizeof(double) * (size_t)ss.n_sweep, hipMemcpyHostToDevice, ctx->stream));
+    double2* total = ctx->scratch[2].as<double2>();
+    BigSeriesArgs sa;
+    sa.src = ss.src;
+    sa.parents = nullptr;
+    sa.gi = nullptr;
+    sa.x = nullptr;
+    sa.tab = ss.tab;
+    sa.n = ss.n;
+    sa.M = ss.M;
+    sa.first = ss.first;
+    sa.npt = ss.npt;
+    sa.grid = 1;
+    sa.inv_period = 1.0;
+    sa.Hbuf = w.Hbuf;
+    ProfScope ps(ctx, ABZ_K_EVAL);
+    for (int64_t c0 = 0; c0 < nnodes; c0 += w.chunk) {
+        const int64_t cn = std::min(w.chunk, nnodes - c0);
+        if ((rc = big_series(ctx, sa, c0, cn))) return rc;
+        if ((rc = big_tridiag(ctx, w, ss.n, cn))) return rc;
+        if ((rc = big_sum_chunk(ctx, w, ss.n, c0, cn, ss.integrand == ABZ_F_DOS, ss.params[0], sw, ss.n_sweep, nullptr, total, c0 == 0))) return rc;
+    }
+    hipLaunchKernelGGL(big_scale_kernel, dim3((unsigned)cdivb(ss.n_sweep, 256)), dim3(256), 0, ctx->stream, total, ss.n_sweep, ss.scale);
+    ABZ_HIP(hipGetLastError());
+    ABZ_HIP(hipMemcpyAsync(out_reim, total, sizeof(double2) * (size_t)ss.n_sweep, hipMemcpyDeviceToHost, ctx->stream));
+    ABZ_HIP(hipStreamSynchronize(ctx->stream));
+    return ABZ_OK;
+}
+
+// scans of a cached rule: DOS / tr G from the matrices (tridiagonalised chunk by chunk); the eigenvalue form goes through
+// gen_eig_dos_kernel (kernels_generic.hip), which is generic in n
+int launch_big_reduce(abz_ctx* ctx, const ReduceSpec& rs, double* out_reim) {
+    if (!(rs.integrand == ABZ_F_DOS || rs.integrand == ABZ_F_TRGLOC) || !rs.H.base || rs.H.compact || !rs.herm) {
+        set_error("n = %d bands: scans of a cached rule offer DOS / tr G of Hermitian matrices (full layout) and DOS from eigenvalues", rs.n);
+        return ABZ_ERR_UNSUPPORTED;
+    }
+    BigWork w;
+    int rc = big_reserve(ctx, rs.n, 0, rs.nk, w);
+    if (rc) return rc;
+    if ((rc = ctx->scratch[2].reserve(sizeof(double2) * (size_t)rs.n_sweep))) return rc;
+    double2* total = ctx->scratch[2].as<double2>();
+    {
+        ProfScope ps(ctx, ABZ_K_REDUCE);
+        for (int64_t c0 = 0; c0 < rs.nk; c0 += w.chunk) {
+            const int64_t cn = std::min(w.chunk, rs.nk - c0);
+            hipLaunchKernelGGL(big_load_h_kernel, dim3((unsigned)std::min<int64_t>(cdivb((cn + 63) / 64 * 64 * rs.n * rs.n, 256), 256 * 16)), dim3(256), 0, ctx->stream,
+                               w.Hbuf, c0, cn, rs.n, rs.H);
+            ABZ_HIP(hipGetLastError());
+            if ((rc = big_tridiag(ctx, w, rs.n, cn))) return rc;
+            if ((rc = big_sum_chunk(ctx, w, rs.n, c0, cn, rs.integrand == ABZ_F_DOS, rs.params[0], rs.sweep_dev, rs.n_sweep, rs.w, total, c0 == 0)))
+                return rc;
+        }
+        hipLaunchKernelGGL(big_scale_kernel, dim3((unsigned)cdivb(rs.n_sweep, 256)), dim3(256), 0, ctx->stream, total, rs.n_sweep, rs.scale);
+        ABZ_HIP(hipGetLastError());
+    }
+    if (rs.out_dev) {
+        ABZ_HIP(hipMemcpyAsync(rs.out_dev, total, sizeof(double2) * (size_t)rs.n_sweep, hipMemcpyDeviceToDevice, ctx->stream));
+        return ABZ_OK;
+    }
+    ABZ_HIP(hipMemcpyAsync(out_reim, total, sizeof(double2) * (size_t)rs.n_sweep, hipMemcpyDeviceToHost, ctx->stream));
+    ABZ_HIP(hipStreamSynchronize(ctx->stream));
+    return ABZ_OK;
+}
+
+}  // namespace abz

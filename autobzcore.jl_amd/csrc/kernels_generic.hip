@@ -773,6 +773,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 4))) voi
 }
 
 bool gen_sum_supported(int n, int M, int npt, int integrand, bool herm) {
+    if (big_supported(n)) return big_sum_supported(n, M, npt, integrand, herm);
     if (n <= 4 || n > ABZ_MAX_BANDS || !herm || npt < 1 || npt >= 65536) return false;
     if (!(integrand == ABZ_F_DOS || integrand == ABZ_F_TRGLOC)) return false;
     const int np = n <= 8 ? 8 : (n <= 16 ? 16 : 32);
@@ -786,6 +787,7 @@ static bool gen_sum_tri_wanted(const SumSpec& ss);
 static int launch_gen_sum_tri(abz_ctx* ctx, const SumSpec& ss, double* out_reim);
 
 int launch_gen_sum(abz_ctx* ctx, const SumSpec& ss, double* out_reim) {
+    if (big_supported(ss.n)) return launch_big_sum(ctx, ss, out_reim);
     if (gen_sum_tri_wanted(ss)) {
         const int rc = launch_gen_sum_tri(ctx, ss, out_reim);
         if (rc != ABZ_ERR_UNSUPPORTED) return rc;
@@ -1964,6 +1966,7 @@ static int gen_waves_per_block(int n, int M) {
 
 int launch_gen_nodes(abz_ctx* ctx, const GenSpec& gs) {
     if (gs.nnodes == 0) return ABZ_OK;
+    if (big_supported(gs.n)) return launch_big_nodes(ctx, gs);  // 33...64 bands: kernels_big.hip
     if (gs.n > ABZ_MAX_BANDS) {
         set_error("n = %d bands exceeds ABZ_MAX_BANDS", gs.n);
         return ABZ_ERR_UNSUPPORTED;
@@ -2611,6 +2614,7 @@ static int launch_gen_eig_dos(abz_ctx* ctx, const ReduceSpec& rs, double* out_re
 int launch_gen_reduce(abz_ctx* ctx, const ReduceSpec& rs, double* out_reim) {
     if (gen_rows_reduce_supported(rs)) return launch_gen_rows_reduce(ctx, rs, out_reim);
     if (rs.integrand == ABZ_F_DOS_EIG && rs.E.base && rs.sweep_dev && rs.n_sweep >= 1) return launch_gen_eig_dos(ctx, rs, out_reim);
+    if (big_supported(rs.n)) return launch_big_reduce(ctx, rs, out_reim);  // 33...64 bands: kernels_big.hip
     const int ncomp = integrand_ncomp(rs.integrand, rs.n, rs.d);
     if (ncomp < 0 || rs.integrand == ABZ_F_LINEAR || rs.integrand == ABZ_F_LINEAR_X) {
         set_error("integrand %d is not available for n = %d bands", rs.integrand, rs.n);
@@ -2805,7 +2809,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(WPE ? WPE : 
 }
 
 static bool gen_inner_panel_fits(int n, int M, int integrand, int* np_out, size_t* lds_out, bool* pad_out) {
-    if (!(integrand == ABZ_F_DOS || integrand == ABZ_F_TRGLOC)) return false;
+    if (!(integrand == ABZ_F_DOS || integrand == ABZ_F_TRGLOC) || n > 32) return false;  // (33...64 bands: the host-driven node path)
     const int np = n <= 8 ? 8 : (n <= 16 ? 16 : 32);
     const size_t rest = sizeof(double) * ((size_t)inner_group_doubles(1, ABZ_PANEL_MAXSEG) + ABZ_PANEL_MAXSEG);  // + heapE
     size_t lds = sizeof(double2) * (size_t)M * np * np + rest;  // zero-padded set

@@ -916,6 +916,71 @@ def test_generic_n_eval_and_rules(abz, d, n):
         assert np.abs(g[i].reshape(n, n).T - G).max() <= 1e-10 * np.abs(G).max()
 
 
+@pytest.mark.parametrize("d,n", [(2, 33), (3, 48), (2, 64), (1, 40)])
+def test_more_than_32_bands(abz, d, n, monkeypatch):
+    """33...64 bands (ref: src/fourier.jl:22-58 is generic in the matrix size, eigen(Hermitian(h)) is LAPACK there,
+    src/dos_ggr.jl:19): kernels_big.hip -- series values and eigenvalues at arbitrary nodes and on PTR rules (full grid and an
+    inversion-symmetric node list), DOS / tr G scans of the cached matrices and eigenvalues, store-free sums, with the
+    level-1 evaluation on the vector units and on the matrix cores (ABZ_BIG_MFMA=1) -- against the oracle; 65 bands: ArgumentError."""
+    L = abz._lib
+    rng = np.random.default_rng(3000 + 10 * d + n)
+    dims = (3, 5, 3)[:d] if d > 1 else (7,)
+    c, first = rand_series(rng, dims, n, hermitian=True)
+    c = c / np.sqrt(n)
+    s, so = both(abz, c, first)
+    k = rng.uniform(0, 1, size=(37, d))
+    H, E = s.device().eval_nodes(k, want=3)
+    Ho = orc.evaluate_many(so, k)
+    scale = np.abs(Ho).max()
+    assert np.abs(H - Ho).max() <= 1e-12 * scale
+    assert np.abs(E - np.linalg.eigvalsh(Ho, UPLO="U")).max() <= 1e-10 * scale
+    npt = 5 if d == 3 else (9 if d == 2 else 21)
+    vals = orc.fourier_ptr(so, npt)
+    perm = tuple(range(d - 1, -1, -1))
+    ref = np.transpose(vals, perm + (d, d + 1)).reshape(-1, n, n)
+    omegas = np.array([-0.4, 0.3, 0.9])
+    eta = 0.25
+    refs = [orc._ptr_rule_sum(so, npt, None, orc.f_gloc(eta, om))[0] for om in omegas]
+    for mfma in ("0", "1"):
+        monkeypatch.setenv("ABZ_BIG_MFMA", mfma)
+        rule = abz.DeviceRule(s.device(), npt, None, 3)
+        out = rule.export(H=True, eig=True)
+        assert np.abs(out["H"] - ref).max() <= 1e-12 * np.abs(ref).max(), mfma
+        assert np.abs(out["eig"] - np.linalg.eigvalsh(ref, UPLO="U")).max() <= 1e-10 * np.abs(ref).max(), mfma
+        dos = rule.reduce(L.F_DOS, [eta], omegas)[:, 0].real
+        dose = rule.reduce(L.F_DOS_EIG, [eta], omegas)[:, 0].real
+        trg = rule.reduce(L.F_TRGLOC, [eta], omegas)[:, 0]
+        sf = s.device().ptr_sum(npt, L.F_TRGLOC, [eta], omegas)[:, 0]
+        for i in range(len(omegas)):
+            t = np.trace(refs[i])
+            assert abs(trg[i] - t) <= 1e-10 * abs(t) and abs(sf[i] - t) <= 1e-10 * abs(t), mfma
+            assert abs(dos[i] + t.imag / np.pi) <= 1e-10 * abs(t) and abs(dose[i] + t.imag / np.pi) <= 1e-9 * abs(t), mfma
+        rule.close()
+    monkeypatch.delenv("ABZ_BIG_MFMA")
+    if d >= 2:  # a symmetric node list
+        bzo = orc.load_bz("InversionSymIBZ", np.eye(d))
+        rs = s.device().rule(npt, bzo.syms, want=3)
+        outs = rs.export(x=True, w=True, H=True, eig=True)
+        Hs = orc.evaluate_many(so, outs["x"])
+        assert np.abs(outs["H"] - Hs).max() <= 1e-12 * np.abs(Hs).max()
+        assert np.abs(outs["eig"] - np.linalg.eigvalsh(Hs, UPLO="U")).max() <= 1e-10 * np.abs(Hs).max()
+        rsum, _ = orc._ptr_rule_sum(so, npt, bzo.syms, orc.f_dos(eta, omegas[1]))
+        assert abs(rs.reduce(L.F_DOS, [eta], omegas[1:2])[0, 0].real - rsum) <= 1e-10 * abs(rsum)
+    if d == 2:  # IAI through the node path
+        bz = abz.load_bz(abz.FBZ(), np.eye(2))
+        sol = abz.do_solve(abz.FourierIntegrand(abz.DOSIntegrand(), s, 0.5), bz, abz.MixedParameters(0.2), abz.EvalCounter(abz.IAI()),
+                           abstol=1e-2)
+        refi = orc.solve_iai(so, orc.load_bz("FBZ", np.eye(2)), orc.f_dos(0.5, 0.2), abstol=1e-2)
+        assert sol.numevals == refi.numevals and abs(sol.u - refi.u) <= 1e-9 * abs(refi.u)
+
+
+def test_more_than_64_bands_is_an_argument_error(abz):
+    rng = np.random.default_rng(65)
+    c, first = rand_series(rng, (3,), 65, hermitian=True)
+    with pytest.raises(ValueError):
+        abz.FourierSeries(c, period=1.0, first=first).device()
+
+
 def test_generic_n_set_above_150_kb_of_lds(abz):
     """28 bands x 11 coefficients: the unpadded level-1 set + store tile take 150.7 KB of LDS -- above the 150 KB the padded
     layouts are held to, inside the 160 KB of a CU that the unpadded 32-lane kernels may use (one workgroup per CU)."""
@@ -1606,6 +1671,32 @@ def test_ggr_rows_dimensions_and_chunked_sets(abz, d, n, dims):
             u = abz.dos.solve(abz.DOSProblem(s, Es, abz.load_bz(bzk, np.eye(d))), abz.GGR(npt=8)).u
             ref = orc.dos_ggr(so, orc.load_bz(kind, np.eye(d)), Es, npt=8)
             assert np.abs(u - ref).max() <= 1e-9 * max(1.0, np.abs(ref).max()), kind
+
+
+def test_config4_share_at_full_size_three_forms_agree(abz):
+    """BASELINE configs[3] at the size the bench runs it (SVO, 150^3 PTR grid, 256 omega in [10, 15] eV, eta = 0.1): the sweep
+    from the cached matrices (the reference's own form, src/fourier.jl:204-207), from the cached eigenvalues, and over the
+    cubic IBZ (48 symmetries, weights from symptr_rule, src/fourier.jl:289-292) must be the same 256 numbers -- a
+    size-independent property of the path, checked where the oracle is too slow to follow."""
+    L = abz._lib
+    s = abz.load_w90_series(os.path.join(GOLD, "svo_hr.dat.gz"))
+    dev = s.device()
+    om = np.linspace(10.0, 15.0, 256)
+    rule = dev.rule(150, None, want=L.WANT_H | L.WANT_EIG)
+    a = rule.reduce(L.F_DOS, [0.1], om)[:, 0].real
+    b = rule.reduce(L.F_DOS_EIG, [0.1], om)[:, 0].real
+    cub = abz.load_bz(abz.CubicSymIBZ(), 3.85856 * np.eye(3))
+    rs = dev.rule(150, cub.syms, want=L.WANT_H | L.WANT_EIG)
+    assert rs.nk_local == 76076  # C(npt // 2 + 3, 3) irreducible nodes (SURVEY 8c)
+    c = rs.reduce(L.F_DOS, [0.1], om)[:, 0].real
+    scale = np.abs(a).max()
+    assert scale > 0.1
+    assert np.abs(a - b).max() <= 1e-10 * scale
+    assert np.abs(a - c).max() <= 1e-10 * scale
+    # and the store-free sum of the same grid (abz_ptr_sum) for a few of the values
+    d_ = dev.ptr_sum(150, L.F_DOS, [0.1], om[::37])[:, 0].real
+    assert np.abs(d_ - a[::37]).max() <= 1e-10 * scale
+    dev.drop_rules()
 
 
 def _ggr_rule_data(abz, s, npt, syms=None):
