@@ -227,9 +227,11 @@ __global__ __launch_bounds__(256) void big_load_h_kernel(double2* __restrict__ H
 __global__ __launch_bounds__(64) void big_tridiag_kernel(const double2* __restrict__ Hbuf, int64_t nnodes, int n, double* __restrict__ tri,
                                                          int64_t tri_nk, int64_t t0) {
     extern __shared__ double2 lds_bt[];  // A [n][n] (element (i, j) at i + n j), then v [n], q [n]
-    double2* const A = lds_bt;
-    double2* const vv = lds_bt + (size_t)n * n;
-    double2* const qq = vv + n;
+    // (restrict: the rows of A and the two vectors never overlap -- without it every write of the update loop orders the next
+    // iteration's reads of v and q behind it, one LDS round trip per element)
+    double2* __restrict__ const A = lds_bt;
+    double2* __restrict__ const vv = lds_bt + (size_t)n * n;
+    double2* __restrict__ const qq = vv + n;
     const int lane = threadIdx.x, i = lane;
     const bool row = i < n;
     for (int64_t node = blockIdx.x; node < nnodes; node += gridDim.x) {
@@ -272,6 +274,7 @@ __global__ __launch_bounds__(64) void big_tridiag_kernel(const double2* __restri
             // p_i = beta sum_{j > k} A[i][j] v_j
             double pr = 0.0, pi = 0.0;
             if (below) {
+#pragma unroll 4
                 for (int j = k + 1; j < n; ++j) {
                     const double2 aij = A[i + n * j], vj = vv[j];
                     pr = fma(aij.x, vj.x, pr);
@@ -290,6 +293,7 @@ __global__ __launch_bounds__(64) void big_tridiag_kernel(const double2* __restri
             bwave_sync();
             // A[i][j] -= v_i conj(q_j) + q_i conj(v_j), i, j > k
             if (below) {
+#pragma unroll 4
                 for (int j = k + 1; j < n; ++j) {
                     const double2 vj = vv[j], qj = qq[j];
                     double2 aij = A[i + n * j];

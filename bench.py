@@ -1242,6 +1242,30 @@ def extras(a, abz, L, s, ctx, out, nk):
         out["ggr_bands_5_to_32"] = gb
     except Exception as e:
         out["ggr_bands_5_to_32"] = {"error": repr(e)}
+    # 33...64 bands (round 5, kernels_big.hip: wave-per-node Householder in LDS; ABZ_MAX_BANDS was 32)
+    try:
+        b48 = {"what": "synthetic Hermitian models on the 24^3 full-BZ grid: rule build with H(k) + eigenvalues, a 16-omega store-free DOS sweep"}
+        for nb in (48, 64):
+            sg = abz.synthetic_wannier(n=nb, rmax=2, seed=7)
+            dg = sg.device()
+            rr = abz.DeviceRule(dg, 24, None, L.WANT_H | L.WANT_EIG)
+            ts_ = []
+            for _ in range(4):
+                t0 = time.perf_counter()
+                rr.rebuild()
+                ctx.sync()
+                ts_.append(time.perf_counter() - t0)
+            rr.close()
+            om = np.linspace(-1.0, 1.0, 16)
+            dg.ptr_sum(24, L.F_DOS, [0.05], om)
+            t0 = time.perf_counter()
+            dg.ptr_sum(24, L.F_DOS, [0.05], om)
+            b48[f"bands{nb}"] = {"rule_24cubed_H_and_eig_seconds": min(ts_), "kpoints_per_sec": 24**3 / min(ts_),
+                                 "store_free_16_omega_seconds": time.perf_counter() - t0}
+        b48["mfma_vs_fma"] = "profiles/r05_big_series_mfma_vs_fma.txt: the level-1 GEMM on v_mfma_f64_16x16x4_f64 is 0-25 % slower than the vector form"
+        out["bands48_64_fixed_grids"] = b48
+    except Exception as e:
+        out["bands48_64_fixed_grids"] = {"error": repr(e)}
     # 17...32 bands: the same row kernels with two nodes per wave (round 4; wave-per-node kernels before: a 100x step at 17 bands)
     try:
         b24 = {}
