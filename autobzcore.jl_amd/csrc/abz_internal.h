@@ -63,6 +63,7 @@ enum Switch {
     SW_IAI_STATS,        // ABZ_IAI_STATS       per-solve statistics of the IAI driver on stderr
     SW_HOST_THREADS,     // ABZ_HOST_THREADS    host threads for the per-integral bookkeeping of IAI sweeps
     SW_AUTO_SWEEP_MAPPED,  // ABZ_AUTO_SWEEP_MAPPED  AutoPTR solves of <= 8 values: swept values read from pinned host memory
+    SW_LANE_KERNELS,     // ABZ_LANE_KERNELS    5...8 bands on full grids: one node per lane (kernels_lane.hip) instead of the 8-lane row kernels
     SW_BIG_MFMA,         // ABZ_BIG_MFMA        33...64 bands: level-1 evaluation of grid lines as a real GEMM on v_mfma_f64_16x16x4_f64
     SW_EIG_FOLD,         // ABZ_EIG_FOLD        5...16-band rule builds of Hermitian series: folded level-1 series
     SW_EIG_SPLIT,        // ABZ_EIG_SPLIT       5...16-band eigenvalue builds: tridiagonal eigenvalues in a kernel of their own
@@ -540,6 +541,13 @@ bool gen_compact_supported(int n, int M, int npt);
 int launch_gen_sum(abz_ctx* ctx, const SumSpec& ss, double* out_reim);
 // 33...64 bands (kernels_big.hip): wave-per-node Householder with the matrix in LDS, eigenvalues by bisection, resolvent
 // traces from the tridiagonal
+// 5...8 bands on full grids, one node per lane (kernels_lane.hip)
+bool lane_grid_supported(const GenSpec& gs);
+int launch_lane_grid(abz_ctx* ctx, const GenSpec& gs);
+bool lane_sum_supported(int n, int M, int first, int npt, int integrand, int n_sweep);
+int launch_lane_sum(abz_ctx* ctx, const SumSpec& ss, double* out_reim);
+bool lane_scan_supported(const ReduceSpec& rs);
+int launch_lane_scan(abz_ctx* ctx, const ReduceSpec& rs, double* out_reim);
 bool big_supported(int n);
 bool big_sum_supported(int n, int M, int npt, int integrand, bool herm);
 int launch_big_nodes(abz_ctx* ctx, const GenSpec& gs);

@@ -78,6 +78,7 @@ const SwitchDef g_switches[SW_COUNT] = {
     {"ABZ_IAI_STATS", 0, "1: per-solve statistics of the IAI driver on stderr"},
     {"ABZ_HOST_THREADS", 8, "host threads for the per-integral bookkeeping of IAI sweeps (capped at half the cores)"},
     {"ABZ_AUTO_SWEEP_MAPPED", 1, "0: abz_autoptr_solve* uploads its swept values instead of letting the kernels read the pinned host copy"},
+    {"ABZ_LANE_KERNELS", 1, "0: 5...8-band rule builds / store-free sums on full grids through the 8-lane row kernels (test: same values)"},
     {"ABZ_BIG_MFMA", 0, "1: 33...64 bands: the level-1 evaluation of full grid lines as a real GEMM on v_mfma_f64_16x16x4_f64 (test: same values)"},
     {"ABZ_EIG_FOLD", 1, "0: 5...16-band rule builds evaluate the full level-1 series of a Hermitian model instead of the folded one"},
     {"ABZ_EIG_SPLIT", 1, "0: eigenvalues of 5...16-band rules by bisection inside the grid kernel instead of the per-lane QR kernel"},

@@ -788,6 +788,7 @@ static int launch_gen_sum_tri(abz_ctx* ctx, const SumSpec& ss, double* out_reim)
 
 int launch_gen_sum(abz_ctx* ctx, const SumSpec& ss, double* out_reim) {
     if (big_supported(ss.n)) return launch_big_sum(ctx, ss, out_reim);
+    if (lane_sum_supported(ss.n, ss.M, ss.first, ss.npt, ss.integrand, ss.n_sweep)) return launch_lane_sum(ctx, ss, out_reim);
     if (gen_sum_tri_wanted(ss)) {
         const int rc = launch_gen_sum_tri(ctx, ss, out_reim);
         if (rc != ABZ_ERR_UNSUPPORTED) return rc;
@@ -1742,72 +1743,7 @@ __global__ __launch_bounds__(64) void tri_eig_kernel(const double* __restrict__ 
         le[j][lane] = ej;
         anorm2 = fmax(anorm2, fmax(dj * dj, ej));
     }
-    const double eps2 = 1.2325951644078309e-32;  // (2^-53)^2
-    const double floor2 = eps2 * 1e-2 * anorm2;  // |e| <= 0.1 eps ||T||: a coupling that small moves no eigenvalue by more than that
-    int L = n - 1;        // bottom of the block that is still coupled
-    int budget = 30 * n;  // dsterf's iteration limit
-    while (__any(L > 0 && budget > 0)) {
-        if (L > 0 && budget > 0) {
-            // deflate as far as it goes, THEN sweep: every pass of the wave's loop is a sweep for every lane that is not
-            // finished (a pass that only deflated would sit out the other lanes' sweep)
-            double dL = ld[L][lane], dm = ld[L - 1][lane], eb = le[L - 1][lane];
-            while (eb <= eps2 * fabs(dL * dm) + floor2) {
-                le[L - 1][lane] = 0.0;
-                --L;
-                if (L == 0) break;
-                dL = dm;
-                dm = ld[L - 1][lane];
-                eb = le[L - 1][lane];
-            }
-            if (L > 0) {
-                --budget;
-                // shift: the eigenvalue of the bottom 2 x 2 closer to d_L
-                double sg;
-                if (!__any(!(eb >= 1e-140 && eb <= 1e140 && fabs(dm - dL) <= 1e30))) {  // (estimate + Newton, as in the sweep)
-                    const double irte = rsqrt_nr(eb), rte = eb * irte;
-                    const double s0 = 0.5 * (dm - dL) * irte;
-                    const double w = fma(s0, s0, 1.0);
-                    sg = dL - rte * rcp_nr(s0 + copysign(w * rsqrt_nr(w), s0));
-                } else {
-                    const double rte = sqrt(eb);
-                    const double s0 = (dm - dL) / (2.0 * rte);
-                    sg = dL - rte / (s0 + copysign(sqrt(fma(s0, s0, 1.0)), s0));
-                }
-                // The sweep: ~35 instructions per rotation on the common path -- ONE reciprocal (estimate + Newton) of r p
-                // serves c = p / r, s = b / r and 1 / c = r / p; the next step's two LDS reads are issued before this step's
-                // arithmetic, unconditionally (rows NP, NP + 1 of the arrays exist for that); LAPACK's special cases
-                // (p = 0, r = 0, and anything near the ends of the double range) take a wave-uniform branch to the same
-                // quantities by true divisions.
-                double c = 1.0, sn = 0.0, gamma = ld[0][lane] - sg, pp = gamma * gamma;
-                double bb = le[0][lane], alpha = ld[1][lane];
-                for (int i = 0; i < L; ++i) {
-                    const double bbn = le[i + 1][lane], alphan = ld[i + 2][lane];
-                    const double r2 = pp + bb;
-                    if (i != 0) le[i - 1][lane] = sn * r2;
-                    const double oldgam = gamma;
-                    if (!__any(!(pp >= 1e-140 && r2 <= 1e140))) {
-                        const double t = rcp_nr(r2 * pp);
-                        const double ppt = pp * t;
-                        c = pp * ppt;
-                        sn = bb * ppt;
-                        gamma = c * (alpha - sg) - sn * oldgam;
-                        pp = (gamma * gamma) * (r2 * (r2 * t));
-                    } else {
-                        const double oldc = c;
-                        c = r2 != 0.0 ? pp / r2 : 1.0;
-                        sn = r2 != 0.0 ? bb / r2 : 0.0;
-                        gamma = c * (alpha - sg) - sn * oldgam;
-                        pp = c != 0.0 ? (gamma * gamma) / c : oldc * bb;
-                    }
-                    ld[i][lane] = oldgam + (alpha - gamma);
-                    bb = bbn;
-                    alpha = alphan;
-                }
-                le[L - 1][lane] = sn * pp;
-                ld[L][lane] = sg + gamma;
-            }
-        }
-    }
+    int L = tri_qr_lane(ld, le, n, lane, anorm2);
     // A block that is still coupled when the budget runs out (LAPACK's dsterf returns info > 0 there) must not leave as
     // plausible numbers: the node's eigenvalues become NaN, which every sum over the rule carries to the caller.
     const bool failed = L > 0;
@@ -1967,6 +1903,7 @@ static int gen_waves_per_block(int n, int M) {
 int launch_gen_nodes(abz_ctx* ctx, const GenSpec& gs) {
     if (gs.nnodes == 0) return ABZ_OK;
     if (big_supported(gs.n)) return launch_big_nodes(ctx, gs);  // 33...64 bands: kernels_big.hip
+    if (lane_grid_supported(gs)) return launch_lane_grid(ctx, gs);  // 5...8 bands on full grids: one node per lane
     if (gs.n > ABZ_MAX_BANDS) {
         set_error("n = %d bands exceeds ABZ_MAX_BANDS", gs.n);
         return ABZ_ERR_UNSUPPORTED;
@@ -2612,6 +2549,7 @@ static int launch_gen_eig_dos(abz_ctx* ctx, const ReduceSpec& rs, double* out_re
 }
 
 int launch_gen_reduce(abz_ctx* ctx, const ReduceSpec& rs, double* out_reim) {
+    if (lane_scan_supported(rs)) return launch_lane_scan(ctx, rs, out_reim);  // 5...8 bands, DOS / tr G: one node per lane
     if (gen_rows_reduce_supported(rs)) return launch_gen_rows_reduce(ctx, rs, out_reim);
     if (rs.integrand == ABZ_F_DOS_EIG && rs.E.base && rs.sweep_dev && rs.n_sweep >= 1) return launch_gen_eig_dos(ctx, rs, out_reim);
     if (big_supported(rs.n)) return launch_big_reduce(ctx, rs, out_reim);  // 33...64 bands: kernels_big.hip

@@ -595,4 +595,78 @@ __device__ __forceinline__ double tri_eigval_bisect(int n, int r, const double (
     return 0.5 * (lo + hi) * span;
 }
 
+// Eigenvalues of a real symmetric tridiagonal (d, |e|^2), ONE LANE PER MATRIX: the root-free QR iteration of Pal, Walker
+// and Kahan as LAPACK's dsterf runs it (see tri_eig_kernel in kernels_generic.hip).  The arrays of a lane live in LDS
+// ([j][lane], rows n and n + 1 exist: the sweep reads ahead); on return ld[0 .. n-1][lane] holds the eigenvalues, unsorted.
+// Returns the bottom index of the block that was still coupled when the iteration budget ran out (0: converged).
+__device__ __forceinline__ int tri_qr_lane(double (*ld)[64], double (*le)[64], int n, int lane, double anorm2) {
+    const double eps2 = 1.2325951644078309e-32;  // (2^-53)^2
+    const double floor2 = eps2 * 1e-2 * anorm2;  // |e| <= 0.1 eps ||T||: a coupling that small moves no eigenvalue by more than that
+    int L = n - 1;        // bottom of the block that is still coupled
+    int budget = 30 * n;  // dsterf's iteration limit
+    while (__any(L > 0 && budget > 0)) {
+        if (L > 0 && budget > 0) {
+            // deflate as far as it goes, THEN sweep: every pass of the wave's loop is a sweep for every lane that is not
+            // finished (a pass that only deflated would sit out the other lanes' sweep)
+            double dL = ld[L][lane], dm = ld[L - 1][lane], eb = le[L - 1][lane];
+            while (eb <= eps2 * fabs(dL * dm) + floor2) {
+                le[L - 1][lane] = 0.0;
+                --L;
+                if (L == 0) break;
+                dL = dm;
+                dm = ld[L - 1][lane];
+                eb = le[L - 1][lane];
+            }
+            if (L > 0) {
+                --budget;
+                // shift: the eigenvalue of the bottom 2 x 2 closer to d_L
+                double sg;
+                if (!__any(!(eb >= 1e-140 && eb <= 1e140 && fabs(dm - dL) <= 1e30))) {  // (estimate + Newton, as in the sweep)
+                    const double irte = rsqrt_nr(eb), rte = eb * irte;
+                    const double s0 = 0.5 * (dm - dL) * irte;
+                    const double w = fma(s0, s0, 1.0);
+                    sg = dL - rte * rcp_nr(s0 + copysign(w * rsqrt_nr(w), s0));
+                } else {
+                    const double rte = sqrt(eb);
+                    const double s0 = (dm - dL) / (2.0 * rte);
+                    sg = dL - rte / (s0 + copysign(sqrt(fma(s0, s0, 1.0)), s0));
+                }
+                // The sweep: ~35 instructions per rotation on the common path -- ONE reciprocal (estimate + Newton) of r p
+                // serves c = p / r, s = b / r and 1 / c = r / p; the next step's two LDS reads are issued before this step's
+                // arithmetic, unconditionally (rows NP, NP + 1 of the arrays exist for that); LAPACK's special cases
+                // (p = 0, r = 0, and anything near the ends of the double range) take a wave-uniform branch to the same
+                // quantities by true divisions.
+                double c = 1.0, sn = 0.0, gamma = ld[0][lane] - sg, pp = gamma * gamma;
+                double bb = le[0][lane], alpha = ld[1][lane];
+                for (int i = 0; i < L; ++i) {
+                    const double bbn = le[i + 1][lane], alphan = ld[i + 2][lane];
+                    const double r2 = pp + bb;
+                    if (i != 0) le[i - 1][lane] = sn * r2;
+                    const double oldgam = gamma;
+                    if (!__any(!(pp >= 1e-140 && r2 <= 1e140))) {
+                        const double t = rcp_nr(r2 * pp);
+                        const double ppt = pp * t;
+                        c = pp * ppt;
+                        sn = bb * ppt;
+                        gamma = c * (alpha - sg) - sn * oldgam;
+                        pp = (gamma * gamma) * (r2 * (r2 * t));
+                    } else {
+                        const double oldc = c;
+                        c = r2 != 0.0 ? pp / r2 : 1.0;
+                        sn = r2 != 0.0 ? bb / r2 : 0.0;
+                        gamma = c * (alpha - sg) - sn * oldgam;
+                        pp = c != 0.0 ? (gamma * gamma) / c : oldc * bb;
+                    }
+                    ld[i][lane] = oldgam + (alpha - gamma);
+                    bb = bbn;
+                    alpha = alphan;
+                }
+                le[L - 1][lane] = sn * pp;
+                ld[L][lane] = sg + gamma;
+            }
+        }
+    }
+    return L;
+}
+
 }  // namespace abz

@@ -916,6 +916,67 @@ def test_generic_n_eval_and_rules(abz, d, n):
         assert np.abs(g[i].reshape(n, n).T - G).max() <= 1e-10 * np.abs(G).max()
 
 
+@pytest.mark.parametrize("n", [5, 6, 7, 8])
+def test_lane_kernels_5_to_8_bands(abz, n, monkeypatch):
+    """5...8 bands on full grids, one node per lane (kernels_lane.hip: LAPACK's zhetd2 unrolled in the lane's registers + the
+    per-lane QR iteration; ref src/fourier.jl:127-174, eigen(Hermitian(h)) src/dos_ggr.jl:19): H in both layouts, eigenvalues,
+    store-free sums of 1 ... 70 swept values -- against the oracle and against the 8-lane row kernels (ABZ_LANE_KERNELS=0), on
+    grids shorter and longer than a wave, with 3 to 13 coefficients per variable; degenerate and diagonal matrices included."""
+    L = abz._lib
+    rng = np.random.default_rng(500 + n)
+    for dims, npt in (((3, 3), 5), ((5, 3, 3), 9), ((13, 3), 70), ((7,), 130)):
+        d = len(dims)
+        c, first = rand_series(rng, dims, n, hermitian=True)
+        s, so = both(abz, c / np.sqrt(n), first)
+        vals = orc.fourier_ptr(so, npt)
+        perm = tuple(range(d - 1, -1, -1))
+        ref = np.transpose(vals, perm + (d, d + 1)).reshape(-1, n, n)
+        eref = np.linalg.eigvalsh(ref, UPLO="U")
+        om = np.linspace(-1.5, 1.5, 70 if d == 2 and npt == 70 else 3)
+        got = {}
+        for lane in ("1", "0"):
+            monkeypatch.setenv("ABZ_LANE_KERNELS", lane)
+            for want in (L.WANT_H | L.WANT_EIG | L.WANT_H_COMPACT, L.WANT_H | L.WANT_EIG, L.WANT_EIG, L.WANT_H):
+                rule = abz.DeviceRule(s.device(), npt, None, want)
+                out = rule.export(H=bool(want & L.WANT_H), eig=bool(want & L.WANT_EIG))
+                rule.close()
+                if want & L.WANT_H:
+                    assert np.abs(out["H"] - ref).max() <= 1e-12 * np.abs(ref).max(), (lane, want, dims)
+                if want & L.WANT_EIG:
+                    assert np.abs(out["eig"] - eref).max() <= 1e-11 * np.abs(ref).max(), (lane, want, dims)
+            got[lane] = (s.device().ptr_sum(npt, L.F_TRGLOC, [0.2], om)[:, 0], s.device().ptr_sum(npt, L.F_DOS, [0.2], om[:1])[:, 0].real)
+            # scans of cached rules (either layout; a symmetric node list where the dimension has one) through lane_scan_kernel
+            for want in (L.WANT_H | L.WANT_H_COMPACT, L.WANT_H):
+                rule = abz.DeviceRule(s.device(), npt, None, want)
+                sc = rule.reduce(L.F_TRGLOC, [0.2], om)[:, 0]
+                assert np.abs(sc - got[lane][0]).max() <= 1e-11 * np.abs(sc).max(), (lane, want, dims)
+                dd = rule.reduce(L.F_DOS, [0.2], om[:2])[:, 0].real
+                assert np.abs(dd + sc[:2].imag / np.pi).max() <= 1e-12 * np.abs(sc).max()
+                rule.close()
+            if d >= 2:
+                bzo = orc.load_bz("InversionSymIBZ", np.eye(d))
+                rs_ = s.device().rule(npt, bzo.syms, want=L.WANT_H)
+                r0, _ = orc._ptr_rule_sum(so, npt, bzo.syms, orc.f_dos(0.2, om[1]))
+                assert abs(rs_.reduce(L.F_DOS, [0.2], om[1:2])[0, 0].real - r0) <= 1e-10 * abs(r0), (lane, dims)
+        monkeypatch.delenv("ABZ_LANE_KERNELS")
+        assert np.abs(got["1"][0] - got["0"][0]).max() <= 1e-11 * np.abs(got["0"][0]).max(), dims
+        assert np.abs(got["1"][1] - got["0"][1]).max() <= 1e-11 * np.abs(got["0"][1]).max(), dims
+        t, _ = orc._ptr_rule_sum(so, npt, None, orc.f_gloc(0.2, om[1]))
+        assert abs(got["1"][0][1] - np.trace(t)) <= 1e-10 * abs(np.trace(t)), dims
+    # degenerate / diagonal / zero matrices (constant series): the reflector-free branches of zlarfg and the QR deflation
+    mats = [np.diag(np.arange(n, dtype=float)).astype(complex), np.zeros((n, n), dtype=complex), np.eye(n, dtype=complex) * 2.5]
+    q, _ = np.linalg.qr(rng.standard_normal((n, n)) + 1j * rng.standard_normal((n, n)))
+    mats.append((q * np.array([1.0] * (n - 2) + [2.0, 2.0])) @ q.conj().T)
+    mats.append((q * np.array([-1.0, -1.0 + 1e-13] + [0.5] * (n - 2))) @ q.conj().T)
+    for A in mats:
+        A = 0.5 * (A + A.conj().T)
+        s1 = abz.FourierSeries(A[None, :, :], period=1.0, first=(0,))
+        rule = abz.DeviceRule(s1.device(), 7, None, L.WANT_EIG)
+        E = rule.export(eig=True)["eig"]
+        rule.close()
+        assert np.abs(E - np.linalg.eigvalsh(A)[None, :]).max() <= 1e-12 * max(1.0, np.abs(A).max())
+
+
 @pytest.mark.parametrize("d,n", [(2, 33), (3, 48), (2, 64), (1, 40)])
 def test_more_than_32_bands(abz, d, n, monkeypatch):
     """33...64 bands (ref: src/fourier.jl:22-58 is generic in the matrix size, eigen(Hermitian(h)) is LAPACK there,
@@ -1688,7 +1749,8 @@ def test_config4_share_at_full_size_three_forms_agree(abz):
     cub = abz.load_bz(abz.CubicSymIBZ(), 3.85856 * np.eye(3))
     rs = dev.rule(150, cub.syms, want=L.WANT_H | L.WANT_EIG)
     assert rs.nk_local == 76076  # C(npt // 2 + 3, 3) irreducible nodes
-    c = rs.reduce(L.F_DOS, [0.1], om)[:, 0].real
+    # (a symmetric rule's value carries dvol = 1 / (npt^d nsyms), src/fourier.jl:289-292; TrivialRep multiplies by nsyms, src/brillouin.jl:107)
+    c = rs.reduce(L.F_DOS, [0.1], om)[:, 0].real * len(cub.syms)
     scale = np.abs(a).max()
     assert scale > 0.1
     assert np.abs(a - b).max() <= 1e-10 * scale
