@@ -12,8 +12,9 @@
 //                 (d, e^2) the lane has just produced -- nothing goes through HBM;
 //   sums          tr inv(z I - H) = p'(z) / p(z) from the tridiagonal for every swept value, wave-reduced per value into
 //                 a wave-private accumulator row: any number of values in one pass over the grid.
-// Serves rule builds (H in either layout and / or eigenvalues) and store-free sums of Hermitian series with a symmetric
-// frequency range on full grids; node lists (symmetric rules) and the IAI panels stay on the row kernels.
+// Serves rule builds (H in either layout and / or eigenvalues; full grids and the runs of a symmetric node list), store-free
+// sums and DOS / tr G scans of cached rules for Hermitian series with a symmetric frequency range; matrix-valued scans, GGR
+// builds and the IAI panels stay on the row kernels.
 #include <utility>
 
 #include "abz_internal.h"
@@ -35,6 +36,8 @@ struct LaneArgs {
     PlaneView H, E;
     int64_t nlines;
     int npt, M, first;
+    const int64_t* run_start;  // node lists: line l owns nodes [run_start[l], run_start[l + 1]) with grid indices gi (null: full grid lines)
+    const int32_t* gi;
     // sums
     const double* sweep;  // device [n_sweep]
     int n_sweep, is_dos;
@@ -278,12 +281,14 @@ __global__ __launch_bounds__(256) void lane_grid_kernel(LaneArgs a) {
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             staged = line;
         }
-        const int i1 = i0 + lane;
-        const bool act = i1 < a.npt;
-        const double2 z = a.tab[act ? i1 : 0];
+        const int64_t kbase = a.run_start ? a.run_start[line] : line * a.npt;
+        const int count = a.run_start ? (int)(a.run_start[line + 1] - kbase) : a.npt;
+        if (i0 >= count) continue;  // (node lists: a run is at most npt long, usually shorter)
+        const bool act = i0 + lane < count;
+        const int64_t k = kbase + (act ? i0 + lane : 0);
+        const double2 z = a.tab[a.gi ? a.gi[k] : (int)(k - kbase)];
         double hr[P], hi[P];
         lane_series<N>(slab, a.M, z.x, z.y, hr, hi);
-        const int64_t k = line * a.npt + (act ? i1 : 0);
         if constexpr (MODE & 1) {
             if (act) {
                 double* __restrict__ ho = a.H.base + view_off(a.H, k);
@@ -453,7 +458,8 @@ bool lane_shape_ok(int n, int M, int first, int npt, bool herm) {
 
 // rule builds on full grids: H (either layout) and / or eigenvalues
 bool lane_grid_supported(const GenSpec& gs) {
-    if (!gs.grid || gs.deriv || gs.values || gs.Haos || gs.Eaos || gs.Uplanes.base || !(gs.Hplanes.base || gs.Eplanes.base)) return false;
+    const bool runs = !gs.grid && gs.run_start && gs.gi && !gs.x && gs.nruns > 0;  // symmetric rules: runs of grid-index nodes
+    if (!(gs.grid || runs) || gs.deriv || gs.values || gs.Haos || gs.Eaos || gs.Uplanes.base || !(gs.Hplanes.base || gs.Eplanes.base)) return false;
     if (!lane_shape_ok(gs.n, gs.M, gs.first, gs.npt, gs.herm)) return false;
     const int mode = (gs.Hplanes.base ? 1 : 0) | (gs.Eplanes.base ? 2 : 0);
     return 4 * lane_wave_bytes(gs.n, gs.M, mode, 0) <= 150 * 1024;
@@ -465,10 +471,12 @@ int launch_lane_grid(abz_ctx* ctx, const GenSpec& gs) {
     a.tab = gs.tab;
     a.H = gs.Hplanes;
     a.E = gs.Eplanes;
-    a.nlines = gs.nnodes / gs.npt;
+    a.nlines = gs.grid ? gs.nnodes / gs.npt : gs.nruns;
     a.npt = gs.npt;
     a.M = gs.M;
     a.first = gs.first;
+    a.run_start = gs.grid ? nullptr : gs.run_start;
+    a.gi = gs.grid ? nullptr : gs.gi;
     a.sweep = nullptr;
     a.n_sweep = 0;
     a.is_dos = 0;
@@ -504,6 +512,8 @@ int launch_lane_sum(abz_ctx* ctx, const SumSpec& ss, double* out_reim) {
     a.npt = ss.npt;
     a.M = ss.M;
     a.first = ss.first;
+    a.run_start = nullptr;
+    a.gi = nullptr;
     a.sweep = sw;
     a.n_sweep = ss.n_sweep;
     a.is_dos = ss.integrand == ABZ_F_DOS ? 1 : 0;

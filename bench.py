@@ -643,6 +643,23 @@ def rank_main(a):
                          # Hermitian rule: the scan reads the upper triangle only, n^2 doubles per k-point
                          "reduce_read_GBs": nk * (8 * n * n) / ((red_ms / max(red_n, 1)) * 1e-3) / 1e9 if red_n else None},
         }
+        if world > 1:
+            # the measured speed-ups of this run beside the one-GPU model's predictions for 8 ranks (profiles/scaling_model_latest.json,
+            # written by tools/save_scaling_model.py from an N = 1 line): the first real multi-GPU run reads as a check of the model
+            try:
+                with open(os.path.join(ROOT, "profiles", "scaling_model_latest.json")) as fh:
+                    sm = json.load(fh)
+                meas = {"job_256_omega_k_sharded": (jobs or {}).get("k_sharded", {}).get("speedup_vs_n1"),
+                        "job_256_omega_fine_grid_k_sharded": ((big_job or {}).get("k_sharded") or {}).get("speedup_vs_n1") if isinstance(big_job, dict) else None,
+                        "iai_config5_one_solve_sharded": (c5_job or {}).get("speedup_vs_n1") if isinstance(c5_job, dict) else None,
+                        "iai_sweep_432_omega_sharded": (iai_job or {}).get("speedup_vs_n1") if isinstance(iai_job, dict) else None}
+                out["scaling_model_check"] = {"world": world, "note": "model = shares of 8 virtual ranks timed on ONE GPU (MODEL, NOT MEASUREMENT); it "
+                                              "predicts world = 8 only -- at other sizes the columns are not comparable",
+                                              "jobs": {k: {"measured_speedup_vs_n1": v, "model_predicted_speedup_8_at_30us": (sm.get(k) or {}).get("predicted_speedup_8_at_30us"),
+                                                           "model_predicted_speedup_8_at_measured_1rank_latency": (sm.get(k) or {}).get("predicted_speedup_8_at_measured_1rank_latency")}
+                                                       for k, v in meas.items()}}
+            except Exception as e:
+                out["scaling_model_check"] = {"error": repr(e)}
         if world == 1 and not a.no_extras and not a.force_dist:
             extras(a, abz, L, s, ctx, out, nk)
             if not a.no_scaling_model:

@@ -953,11 +953,16 @@ def test_lane_kernels_5_to_8_bands(abz, n, monkeypatch):
                 dd = rule.reduce(L.F_DOS, [0.2], om[:2])[:, 0].real
                 assert np.abs(dd + sc[:2].imag / np.pi).max() <= 1e-12 * np.abs(sc).max()
                 rule.close()
-            if d >= 2:
+            if d >= 2:  # the runs of a symmetric node list through the lane kernel: values, eigenvalues, the scan
                 bzo = orc.load_bz("InversionSymIBZ", np.eye(d))
-                rs_ = s.device().rule(npt, bzo.syms, want=L.WANT_H)
+                rs_ = abz.DeviceRule(s.device(), npt, bzo.syms, L.WANT_H | L.WANT_EIG)
+                outs = rs_.export(x=True, w=True, H=True, eig=True)
+                Hs = orc.evaluate_many(so, outs["x"])
+                assert np.abs(outs["H"] - Hs).max() <= 1e-12 * np.abs(Hs).max(), (lane, dims)
+                assert np.abs(outs["eig"] - np.linalg.eigvalsh(Hs, UPLO="U")).max() <= 1e-11 * np.abs(Hs).max(), (lane, dims)
                 r0, _ = orc._ptr_rule_sum(so, npt, bzo.syms, orc.f_dos(0.2, om[1]))
                 assert abs(rs_.reduce(L.F_DOS, [0.2], om[1:2])[0, 0].real - r0) <= 1e-10 * abs(r0), (lane, dims)
+                rs_.close()
         monkeypatch.delenv("ABZ_LANE_KERNELS")
         assert np.abs(got["1"][0] - got["0"][0]).max() <= 1e-11 * np.abs(got["0"][0]).max(), dims
         assert np.abs(got["1"][1] - got["0"][1]).max() <= 1e-11 * np.abs(got["0"][1]).max(), dims
