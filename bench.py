@@ -91,7 +91,7 @@ def pmc_traffic(npt, compact=False):
     (profiles/r04_traffic_compact.json / r03_traffic.json (or an earlier round's), written by tools/collect_profiles.sh: WRITE_SIZE and
     FETCH_SIZE in separate --pmc runs, FETCH_SIZE doubled per the gfx950 correction), for the rule layout that was
     timed.  None if not collected for this grid size: counters cannot be read from inside an un-profiled bench run."""
-    names = ("r04_traffic_compact.json", "r03_traffic_compact.json") if compact else ("r03_traffic.json", "r02_traffic.json", "r01_traffic.json")
+    names = ("r05_traffic_compact.json", "r04_traffic_compact.json", "r03_traffic_compact.json") if compact else ("r03_traffic.json", "r02_traffic.json", "r01_traffic.json")
     for name in names:
         try:
             t = json.load(open(os.path.join(ROOT, "profiles", name)))
@@ -623,7 +623,7 @@ def rank_main(a):
                          "store_pattern_note": "reference layout: bare store pattern of this kernel's tiled planar layout without any compute "
                                                "(tools/micro/placement.hip, profiles/r02_placement_microbench.txt): 6.2 TB/s = 5.83 TB/s of useful bytes with temporal stores, "
                                                "5.2-5.6 TB/s with the non-temporal stores the kernel needs (allocation-dependent); a linear memset 8.2 TB/s",
-                         "traffic_note": f"HBM bytes per launch from rocprofv3 PMC passes (profiles/{'r04_traffic_compact' if compact else 'r03_traffic'}.json); "
+                         "traffic_note": f"HBM bytes per launch from rocprofv3 PMC passes (profiles/{'r05_traffic_compact' if compact else 'r03_traffic'}.json); "
                                          f"algorithmic bytes per launch = nk*{bpk}",
                          "reference_layout": ref_layout,
                          # flat copies: the driver's parsed view keeps scalars of this block and drops nested ones

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define ABZ_VERSION 401
+#define ABZ_VERSION 501
 
 /* status codes */
 #define ABZ_OK 0
