@@ -6,9 +6,11 @@
 //                          lines, as a real GEMM [16 nodes x 2M] . [2M x 16 columns] on v_mfma_f64_16x16x4_f64
 //                          (ABZ_BIG_MFMA; measured in profiles/r05_big_series_mfma_vs_fma.txt -- f64 MFMA and f64 FMA share
 //                          the DP units);
-//   big_tridiag_kernel     Householder tridiagonalisation, ONE WAVE PER NODE, the matrix in a wave-private LDS slab
-//                          (lane r owns row r: no lane reads LDS bytes another lane wrote except the reflector v and q);
-//   big_bisect_kernel      eigenvalue b of the tridiagonal by Sturm bisection, one thread per (node, band);
+//   big_tridiag_kernel     Householder tridiagonalisation, ONE WAVE PER NODE, the lower triangle of the matrix packed in a
+//                          wave-private LDS slab, lane r owning row r (the part right of the diagonal is read as the
+//                          conjugate of column r);
+//   big_qr_kernel          the eigenvalues of 64 tridiagonals per workgroup by the per-lane root-free QR iteration of
+//                          tri_eig_kernel (big_bisect_kernel, one thread per (node, band), serves the AoS output);
 //   big_trace_kernel       tr inv((w + i eta) I - H) = p'(z) / p(z) from the three-term recurrence of the tridiagonal, one
 //                          thread per (node, swept value): node values (IAI) or weighted partial sums (rules, store-free sums).
 // Serves abz_eval_nodes, rule builds (H and / or eigenvalues, full layout), scans of cached rules (DOS / tr G from the
@@ -17,6 +19,7 @@
 #include <utility>
 
 #include "abz_internal.h"
+#include "rows_device.h"
 
 namespace abz {
 
@@ -223,34 +226,40 @@ __global__ __launch_bounds__(256) void big_load_h_kernel(double2* __restrict__ H
 }
 
 // Householder tridiagonalisation of Hermitian(h) (the upper triangle of each n x n block of Hbuf, like the reference's
-// Hermitian wrapper): d_j -> tri[j][t], |e_j|^2 -> tri[BIG_NP + j][t], t = t0 + node.  One wave per node; lane r owns row r.
+// Hermitian wrapper): d_j -> tri[j][t], |e_j|^2 -> tri[BIG_NP + j][t], t = t0 + node.  One wave per node; lane i owns row i of
+// the LOWER triangle, packed row by row (L(i, j), j <= i, at i (i + 1) / 2 + j): half the LDS of a full matrix -- twice the
+// waves per CU under these latency-bound row loops -- and half the rank-2 update; the part of row i right of the diagonal is
+// read as the conjugate of column i (consecutive lanes, consecutive addresses).
 __global__ __launch_bounds__(64) void big_tridiag_kernel(const double2* __restrict__ Hbuf, int64_t nnodes, int n, double* __restrict__ tri,
                                                          int64_t tri_nk, int64_t t0) {
-    extern __shared__ double2 lds_bt[];  // A [n][n] (element (i, j) at i + n j), then v [n], q [n]
-    // (restrict: the rows of A and the two vectors never overlap -- without it every write of the update loop orders the next
-    // iteration's reads of v and q behind it, one LDS round trip per element)
+    extern __shared__ double2 lds_bt[];  // L [n (n + 1) / 2], then v [n], q [n]
+    const int np = n * (n + 1) / 2;
     double2* __restrict__ const A = lds_bt;
-    double2* __restrict__ const vv = lds_bt + (size_t)n * n;
+    double2* __restrict__ const vv = lds_bt + np;
     double2* __restrict__ const qq = vv + n;
     const int lane = threadIdx.x, i = lane;
     const bool row = i < n;
+    const int ri = i * (i + 1) / 2;  // start of this lane's row
     for (int64_t node = blockIdx.x; node < nnodes; node += gridDim.x) {
         const double2* __restrict__ h = Hbuf + node * ((int64_t)n * n);
         bwave_sync();
-        for (int e = lane; e < n * n; e += 64) {
-            const int r = e % n, c = e / n;
-            double2 v = r <= c ? h[r + n * c] : h[c + n * r];
-            if (r > c) v.y = -v.y;
-            if (r == c) v.y = 0.0;
+        for (int e = lane; e < np; e += 64) {
+            // packed index e -> (r, c), c <= r
+            int r = (int)((sqrtf(8.0f * (float)e + 1.0f) - 1.0f) * 0.5f);
+            while ((r + 1) * (r + 2) / 2 <= e) ++r;
+            while (r * (r + 1) / 2 > e) --r;
+            const int c = e - r * (r + 1) / 2;
+            double2 v = h[c + n * r];  // H(c, r), c <= r: the upper triangle; L(r, c) = conj
+            v.y = r == c ? 0.0 : -v.y;
             A[e] = v;
         }
         bwave_sync();
         for (int k = 0; k + 1 < n; ++k) {
             const bool below = row && i > k;
-            const double2 x = below ? A[i + n * k] : make_double2(0.0, 0.0);
+            const double2 x = below ? A[ri + k] : make_double2(0.0, 0.0);
             const double sigma = bwsum(x.x * x.x + x.y * x.y);
             if (lane == k) {
-                tri[(int64_t)k * tri_nk + t0 + node] = A[k + n * k].x;
+                tri[(int64_t)k * tri_nk + t0 + node] = A[ri + k].x;
                 tri[(int64_t)(BIG_NP + k) * tri_nk + t0 + node] = sigma;
             }
             if (k + 2 >= n || !(sigma > 0.0)) continue;  // uniform
@@ -271,12 +280,15 @@ __global__ __launch_bounds__(64) void big_tridiag_kernel(const double2* __restri
             const double2 v = (i == k + 1) ? make_double2(v1r, v1i) : x;  // zero in rows <= k and >= n
             if (row) vv[i] = v;
             bwave_sync();
-            // p_i = beta sum_{j > k} A[i][j] v_j
+            // p_i = beta sum_{j > k} A(i, j) v_j:  A(i, j) = L(i, j) for j <= i, conj L(j, i) for j > i
             double pr = 0.0, pi = 0.0;
             if (below) {
 #pragma unroll 4
                 for (int j = k + 1; j < n; ++j) {
-                    const double2 aij = A[i + n * j], vj = vv[j];
+                    const bool own = j <= i;
+                    double2 aij = A[own ? ri + j : j * (j + 1) / 2 + i];
+                    aij.y = own ? aij.y : -aij.y;
+                    const double2 vj = vv[j];
                     pr = fma(aij.x, vj.x, pr);
                     pr = fma(-aij.y, vj.y, pr);
                     pi = fma(aij.x, vj.y, pi);
@@ -291,21 +303,21 @@ __global__ __launch_bounds__(64) void big_tridiag_kernel(const double2* __restri
             const double qr = pr - (kr * v.x - ki * v.y), qi = pi - (kr * v.y + ki * v.x);
             if (row) qq[i] = make_double2(qr, qi);
             bwave_sync();
-            // A[i][j] -= v_i conj(q_j) + q_i conj(v_j), i, j > k
+            // L(i, j) -= v_i conj(q_j) + q_i conj(v_j), k < j <= i (this lane's own row)
             if (below) {
 #pragma unroll 4
-                for (int j = k + 1; j < n; ++j) {
+                for (int j = k + 1; j <= i; ++j) {
                     const double2 vj = vv[j], qj = qq[j];
-                    double2 aij = A[i + n * j];
+                    double2 aij = A[ri + j];
                     aij.x -= (v.x * qj.x + v.y * qj.y) + (qr * vj.x + qi * vj.y);
                     aij.y -= (v.y * qj.x - v.x * qj.y) + (qi * vj.x - qr * vj.y);
-                    A[i + n * j] = aij;
+                    A[ri + j] = aij;
                 }
             }
             bwave_sync();
         }
         if (lane == n - 1) {
-            tri[(int64_t)(n - 1) * tri_nk + t0 + node] = A[(n - 1) + n * (n - 1)].x;
+            tri[(int64_t)(n - 1) * tri_nk + t0 + node] = A[ri + (n - 1)].x;
             tri[(int64_t)(BIG_NP + n - 1) * tri_nk + t0 + node] = 0.0;
         }
     }
@@ -359,6 +371,38 @@ __global__ __launch_bounds__(256) void big_bisect_kernel(const double* __restric
         const double ev = 0.5 * (lo + hi);
         if (E.base) E.base[bview_off(E, node0 + node) + (int64_t)band * E.pitch] = ev;
         if (Eaos) Eaos[(node0 + node) * n + band] = ev;
+    }
+}
+
+// The eigenvalues of 64 tridiagonals per workgroup by the per-lane root-free QR iteration (tri_qr_lane, rows_device.h: what
+// tri_eig_kernel runs for <= 32 bands) -- O(n^2) per matrix where the bisection above spends O(n^2) per EIGENVALUE; sorted by
+// an odd-even transposition in the lane's LDS column.  Rule planes only (the AoS output keeps the bisection kernel).
+__global__ __launch_bounds__(64) void big_qr_kernel(const double* __restrict__ tri, int64_t tri_nk, int64_t node0, int64_t nnodes, int n, PlaneView E) {
+    extern __shared__ double lds_bq[];  // ld [n + 2][64] | le [n + 2][64]
+    double(*const ld)[64] = reinterpret_cast<double(*)[64]>(lds_bq);
+    double(*const le)[64] = ld + (n + 2);
+    const int lane = threadIdx.x;
+    const int64_t k = (int64_t)blockIdx.x * 64 + lane;
+    const bool act = k < nnodes;
+    const int64_t kk = act ? k : nnodes - 1;
+    double anorm2 = 0.0;
+    for (int j = 0; j < n + 2; ++j) {
+        const double dj = j < n ? tri[(int64_t)j * tri_nk + kk] : 0.0;
+        const double ej = j + 1 < n ? tri[(int64_t)(BIG_NP + j) * tri_nk + kk] : 0.0;
+        ld[j][lane] = dj;
+        le[j][lane] = ej;
+        anorm2 = fmax(anorm2, fmax(dj * dj, ej));
+    }
+    const int left = tri_qr_lane(ld, le, n, lane, anorm2);
+    for (int pass = 0; pass < n; ++pass)
+        for (int j = pass & 1; j + 1 < n; j += 2) {
+            const double a = ld[j][lane], b = ld[j + 1][lane];
+            ld[j][lane] = fmin(a, b);
+            ld[j + 1][lane] = fmax(a, b);
+        }
+    if (act) {
+        double* __restrict__ eo = E.base + bview_off(E, node0 + k);
+        for (int j = 0; j < n; ++j) eo[(int64_t)j * E.pitch] = left > 0 ? __builtin_nan("") : ld[j][lane];
     }
 }
 
@@ -470,7 +514,7 @@ int big_reserve(abz_ctx* ctx, int n, int npt_or_zero, int64_t nnodes, BigWork& w
 }
 
 int big_tridiag(abz_ctx* ctx, const BigWork& w, int n, int64_t cn) {
-    const size_t lds = sizeof(double2) * ((size_t)n * n + 2 * (size_t)n);
+    const size_t lds = sizeof(double2) * ((size_t)n * (n + 1) / 2 + 2 * (size_t)n);
     ABZ_HIP(hipFuncSetAttribute((const void*)big_tridiag_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const int64_t blocks = std::min<int64_t>(cn, 256 * 8);
     hipLaunchKernelGGL(big_tridiag_kernel, dim3((unsigned)blocks), dim3(64), lds, ctx->stream, w.Hbuf, cn, n, w.tri, w.tri_nk, (int64_t)0);
@@ -547,7 +591,14 @@ int launch_big_nodes(abz_ctx* ctx, const GenSpec& gs) {
         }
         if (!(gs.Eplanes.base || gs.Eaos || gs.values)) continue;
         if ((rc = big_tridiag(ctx, w, gs.n, cn))) return rc;
-        if (gs.Eplanes.base || gs.Eaos) {
+        // (one lane per matrix: the QR kernel wants >= 64 matrices per CU's worth of workgroups; a small chunk of the largest
+        // matrices is faster by bisection, one thread per eigenvalue)
+        if (gs.Eplanes.base && !gs.Eaos && (gs.n <= 56 || cn >= 64 * 512)) {
+            const size_t qlds = sizeof(double) * 2 * (size_t)(gs.n + 2) * 64;
+            ABZ_HIP(hipFuncSetAttribute((const void*)big_qr_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)qlds));
+            hipLaunchKernelGGL(big_qr_kernel, dim3((unsigned)cdivb(cn, 64)), dim3(64), qlds, ctx->stream, w.tri, w.tri_nk, c0, cn, gs.n, gs.Eplanes);
+            ABZ_HIP(hipGetLastError());
+        } else if (gs.Eplanes.base || gs.Eaos) {
             hipLaunchKernelGGL(big_bisect_kernel, dim3((unsigned)cdivb(cn, 4)), dim3(256), 0, ctx->stream, w.tri, w.tri_nk, (int64_t)0, c0, cn, gs.n,
                                gs.Eplanes, gs.Eaos);
             ABZ_HIP(hipGetLastError());
