@@ -591,6 +591,26 @@ def test_kshard_partial_rules_sum_to_the_full_rule(abz, svo):
         finally:
             sdev.kshard, sdev.allreduce = None, None
     assert np.allclose(tot, ref, rtol=1e-12)
+    # round 5: the same through the kernels of 5...8 bands (one node per lane), 9...32 (row-layout GGR build) and 33...64
+    # (kernels_big.hip): slabs of a full grid and blocks of a symmetric node list reproduce the rows of the whole rule
+    for nb, sy in ((6, None), (6, syms), (12, None), (12, syms), (40, None)):
+        cb, fb = rand_series(np.random.default_rng(300 + nb), (3, 3, 3), nb, hermitian=True)
+        sb = abz.FourierSeries(cb / np.sqrt(nb), period=1.0, first=fb)
+        db = sb.device()
+        want = (L.WANT_H | L.WANT_EIG) if nb > 32 else (L.WANT_EIG | L.WANT_VEL)
+        fullb = db.rule(8, sy, want)
+        expf = fullb.export(x=True, w=True, H=bool(want & L.WANT_H), eig=True, vel=bool(want & L.WANT_VEL))
+        partsb = []
+        for r in range(3):
+            db.kshard, db.allreduce = (r, 3), (lambda a: a)
+            try:
+                pb = db.rule(8, sy, want)
+                partsb.append(pb.export(x=True, w=True, H=bool(want & L.WANT_H), eig=True, vel=bool(want & L.WANT_VEL)))
+            finally:
+                db.kshard, db.allreduce = None, None
+        for key in expf:
+            if expf[key] is not None:
+                assert np.array_equal(np.concatenate([e[key] for e in partsb]), expf[key]), (nb, sy is not None, key)
     # a whole AutoPTR solve under dist.kshard with a single-rank group degenerates to the plain solve
     from autobzcore.jl_amd.dist import kshard
     bz = abz.load_bz(abz.FBZ(), 3.85856 * np.eye(3))
