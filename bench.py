@@ -225,7 +225,7 @@ def cpu_baseline_legs(out, abz, s, npt, eta, cores, c5_abstol):
             while True:
                 atol = max(atol / 2, c5_abstol)
                 u, nev, dt = iai(s16, 0.05, 0.2, atol / j16)
-                if dt >= 0.8 or atol <= c5_abstol:  # (the next halving costs 10-30x)
+                if dt >= 3.0 or atol <= c5_abstol:  # (a sample of 3 ... 30 s: the next halving costs 3-10x; shorter ones leave most threads idle)
                     break
             c5["cpu_baseline"] = {"kind": "port", "cores": cores, "abstol_of_the_sample": atol, "seconds": dt, "numevals": nev,
                                   "nodes_per_sec": nev / dt, "gpu_over_cpu": c5["nodes_per_sec"] / (nev / dt),
