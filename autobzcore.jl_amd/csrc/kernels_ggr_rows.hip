@@ -50,6 +50,7 @@ struct GgrRowsArgs {
     const int32_t* gi;
     int n, M, first, npt, d;
     int mc;  // coefficients staged at a time (= M when the set fits the LDS whole)
+    int fold;  // padded sets with a symmetric frequency range: staged folded (c_0, c_f +- c_f^T), half the series FMAs
     int coef_elems;  // complex numbers of the coefficient room (>= the staged chunk and >= the nodes' scratchpad rooms)
 };
 
@@ -393,6 +394,34 @@ __device__ __forceinline__ void ggr_stage(double2* coef, const double2* __restri
     }
 }
 
+// the folded form of a set (panel_stage_fold of rows_device.h, here with the derivative factor of variable 1 and no shift):
+// block 0 = -c_0 (zero for d/dk_1), block 2 f - 1 = s_f = c_f + c_f^T, block 2 f = t_f = c_f - c_f^T, c_f times 2 pi i f first
+template <int NP>
+__device__ __forceinline__ void ggr_stage_fold(double2* coef, const double2* __restrict__ src, int n, int M, bool deriv) {
+    const int F = (M - 1) / 2, nn = n * n;
+    for (int t = threadIdx.x; t < M * NP * NP; t += blockDim.x) {
+        const int b = t / (NP * NP), e = t - b * (NP * NP);
+        const int rr = e % NP, j = e / NP;
+        double2 v = make_double2(0.0, 0.0);
+        if (rr < n && j < n) {
+            if (b == 0) {
+                const double2 c = src[(size_t)F * nn + rr + n * j];
+                v = deriv ? v : make_double2(-c.x, -c.y);
+            } else {
+                const int f = (b + 1) >> 1;
+                double2 c = src[(size_t)(F + f) * nn + rr + n * j], cp = src[(size_t)(F + f) * nn + j + n * rr];
+                if (deriv) {
+                    const double tf = TWO_PI_R * (double)f;
+                    c = make_double2(-tf * c.y, tf * c.x);
+                    cp = make_double2(-tf * cp.y, tf * cp.x);
+                }
+                v = (b & 1) ? make_double2(c.x + cp.x, c.y + cp.y) : make_double2(c.x - cp.x, c.y - cp.y);
+            }
+        }
+        coef[t] = v;
+    }
+}
+
 template <int NP, bool PAD>
 __global__ __launch_bounds__(256, NP <= 16 ? 2 : 1) void ggr_rows_kernel(GgrRowsArgs a) {
     extern __shared__ double2 lds_gr[];
@@ -439,7 +468,17 @@ __global__ __launch_bounds__(256, NP <= 16 ? 2 : 1) void ggr_rows_kernel(GgrRows
                     hr[j] = 0.0;
                     hi[j] = 0.0;
                 }
-                for (int m0 = 0; m0 < M; m0 += mc) {
+                bool folded = false;
+                if constexpr (PAD) {
+                    if (a.fold) {  // (uniform) the whole set, folded: rows of -H from half the FMAs
+                        folded = true;
+                        __syncthreads();
+                        ggr_stage_fold<NP>(coef, src, n, M, deriv1);
+                        __syncthreads();
+                        if (wave_on) panel_series_row_fold<NP>(coef, M, z.x, z.y, r, hr, hi);
+                    }
+                }
+                for (int m0 = 0; m0 < M && !folded; m0 += mc) {
                     const int mcur = min(mc, M - m0);
                     __syncthreads();
                     ggr_stage<NP, PAD>(coef, src, n, m0, mcur, a.first, deriv1);
@@ -548,6 +587,7 @@ int launch_ggr_rows(abz_ctx* ctx, const GgrRowsSpec& gs) {
         }
         elems = per * (size_t)a.mc;
     }
+    a.fold = (pad && (gs.M & 1) && gs.first == -((gs.M - 1) / 2) && abz_switch(SW_EIG_FOLD) != 0) ? 1 : 0;
     elems = std::max(elems, park);
     a.coef_elems = (int)elems;
     const size_t lds = sizeof(double2) * elems + tile;
