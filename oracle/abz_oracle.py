@@ -280,7 +280,8 @@ def fourier_symptr_fast(s: FourierSeries, npt: int, syms):
     idx = (lin[:, None] // strides[None, :]) % npt
     u = ptrpoints(npt)
     xs = u[idx]
-    vals = np.concatenate([np.asarray(evaluate_many(s, xs[i:i + 65536])) for i in range(0, len(xs), 65536)]) if len(xs) else np.zeros((0,))
+    xe = xs * np.asarray(s.t)[None, :]  # the rule evaluates the series at period * x (ref: src/fourier.jl:133,149), like fourier_symptr
+    vals = np.concatenate([np.asarray(evaluate_many(s, xe[i:i + 65536])) for i in range(0, len(xs), 65536)]) if len(xs) else np.zeros((0,))
     return wf[lin], xs, vals, idx
 
 
@@ -883,7 +884,7 @@ def get_ggr_data(s: FourierSeries, npt: int, syms):
         Vl = []
         u = ptrpoints(npt)
         for ds in ders:
-            Vl.append(np.asarray(evaluate_many(ds, u[idx])).reshape(len(w), s.n, s.n))
+            Vl.append(np.asarray(evaluate_many(ds, u[idx] * np.asarray(s.t)[None, :])).reshape(len(w), s.n, s.n))
         Hl = np.asarray(Hl).reshape(len(w), s.n, s.n)
     e, U = np.linalg.eigh(Hl, UPLO="U")
     vel = np.empty((len(Hl), d, s.n))

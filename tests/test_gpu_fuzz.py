@@ -187,6 +187,98 @@ def fuzz_many_band_rules_iai_and_symmetric_rules(abz, seed, emit=None, quick=Fal
     return worst, bad
 
 
+def fuzz_round5_kernels(abz, seed, emit=None):
+    """The kernels of round 5 over random shapes: GGR builds of 5...32 bands (kernels_ggr_rows.hip: eigenvalues, band velocities on
+    separated bands, their sums per node everywhere) in 1...3 dimensions on full grids and inversion-symmetric node lists;
+    5...8 bands one node per lane (kernels_lane.hip: values in either layout, eigenvalues, store-free sums, scans); 33...64 bands
+    (kernels_big.hip: values, eigenvalues, tr G sums).  Returns (worst error, failing cases)."""
+    L = abz._lib
+    rng = np.random.default_rng(seed)
+    worst, bad = 0.0, []
+
+    def note(tag, err, bar):
+        nonlocal worst
+        worst = max(worst, err / bar * TOL)
+        if not (err <= bar):
+            bad.append((tag, err))
+        if emit:
+            emit(tag, err)
+
+    # --- GGR builds
+    for _ in range(14):
+        d = int(rng.integers(1, 4))
+        n = int(rng.choice([5, 6, 7, 8, 9, 11, 13, 16, 17, 19, 23, 28, 32]))
+        dims = tuple(int(rng.choice([1, 3, 5, 7] if n <= 16 else [1, 3, 5])) for _ in range(d))
+        npt = int(rng.integers(1, 12 if d == 3 else (20 if d == 2 else 70)))
+        c, first = _herm_series(rng, dims, n, scale=1.0 / np.sqrt(n))
+        per = tuple(float(rng.choice([1.0, 2.0, 0.5])) for _ in range(d))
+        s = abz.FourierSeries(c, period=per, first=first, ndim=d)
+        so = orc.FourierSeries(c, period=per, first=first, ndim=d)
+        syms = orc.load_bz("InversionSymIBZ", np.eye(d)).syms if (d >= 2 and rng.integers(0, 2)) else None
+        w, e, v = orc.get_ggr_data(so, npt, syms)
+        rule = abz.DeviceRule(s.device(), npt, syms, L.WANT_EIG | L.WANT_VEL)
+        out = rule.export(x=False, w=False, eig=True, vel=True)
+        rule.close()
+        scale, vscale = max(np.abs(e).max(), 1e-300), max(np.abs(v).max(), 1e-300)
+        tag = ("ggr", d, n, dims, npt, syms is not None)
+        note(tag + ("eig",), np.abs(out["eig"] - e).max() / scale, 1e-11)
+        note(tag + ("velsum",), np.abs(out["vel"].sum(axis=2) - v.sum(axis=2)).max() / (vscale * n), 1e-9)
+        ok = np.min(np.diff(e, axis=1), axis=1) > 1e-5 * scale
+        if ok.any():
+            note(tag + ("vel",), np.abs(out["vel"][ok] - v[ok]).max() / vscale, 1e-8)
+    # --- 5...8 bands, one node per lane
+    for _ in range(10):
+        d = int(rng.integers(1, 4))
+        n = int(rng.integers(5, 9))
+        dims = tuple(int(rng.choice([1, 3, 5, 7, 9, 11, 13])) for _ in range(d))
+        npt = int(rng.choice([1, 2, 3, 31, 63, 64, 65, 100, 129] if d == 1 else ([1, 2, 9, 33, 64, 70] if d == 2 else [1, 2, 5, 9, 17])))
+        c, first = _herm_series(rng, dims, n, scale=1.0 / np.sqrt(n))
+        s = abz.FourierSeries(c, period=1.0, first=first, ndim=d)
+        so = orc.FourierSeries(c, period=1.0, first=first, ndim=d)
+        ref = _grid_ref(so, npt, d, n)
+        scale = max(np.abs(ref).max(), 1e-300)
+        compact = bool(rng.integers(0, 2))
+        rule = abz.DeviceRule(s.device(), npt, None, L.WANT_H | L.WANT_EIG | (L.WANT_H_COMPACT if compact else 0))
+        ex = rule.export(x=False, w=False, H=True, eig=True)
+        tag = ("lane", d, n, dims, npt, compact)
+        note(tag + ("H",), np.abs(ex["H"].reshape(-1, n, n) - ref).max() / scale, TOL)
+        note(tag + ("eig",), np.abs(ex["eig"] - np.linalg.eigvalsh(ref)).max() / scale, 1e-11)
+        om = rng.uniform(-1.5, 1.5, size=int(rng.integers(1, 40)))
+        eta = float(rng.uniform(0.05, 0.5))
+        z = om[None, :] + 1j * eta
+        tref = (1.0 / (z[:, :, None] - np.linalg.eigvalsh(ref)[:, None, :])).sum(axis=2).mean(axis=0)
+        sc = rule.reduce(L.F_TRGLOC, [eta], om)[:, 0]
+        sf = s.device().ptr_sum(npt, L.F_TRGLOC, [eta], om)[:, 0]
+        rule.close()
+        note(tag + ("scan",), np.abs(sc - tref).max() / np.abs(tref).max(), 1e-10)
+        note(tag + ("sum",), np.abs(sf - tref).max() / np.abs(tref).max(), 1e-10)
+    # --- 33...64 bands
+    for _ in range(5):
+        d = int(rng.integers(1, 3))
+        n = int(rng.integers(33, 65))
+        dims = tuple(int(rng.choice([1, 3, 5])) for _ in range(d))
+        npt = int(rng.integers(1, 9 if d == 2 else 40))
+        c, first = _herm_series(rng, dims, n, scale=1.0 / np.sqrt(n))
+        s = abz.FourierSeries(c, period=1.0, first=first, ndim=d)
+        so = orc.FourierSeries(c, period=1.0, first=first, ndim=d)
+        ref = _grid_ref(so, npt, d, n)
+        scale = max(np.abs(ref).max(), 1e-300)
+        rule = abz.DeviceRule(s.device(), npt, None, L.WANT_H | L.WANT_EIG)
+        ex = rule.export(x=False, w=False, H=True, eig=True)
+        tag = ("big", d, n, dims, npt)
+        note(tag + ("H",), np.abs(ex["H"].reshape(-1, n, n) - ref).max() / scale, TOL)
+        note(tag + ("eig",), np.abs(ex["eig"] - np.linalg.eigvalsh(ref)).max() / scale, 1e-10)
+        om = rng.uniform(-1.5, 1.5, size=3)
+        z = om[None, :] + 0.3j
+        tref = (1.0 / (z[:, :, None] - np.linalg.eigvalsh(ref)[:, None, :])).sum(axis=2).mean(axis=0)
+        sc = rule.reduce(L.F_TRGLOC, [0.3], om)[:, 0]
+        sf = s.device().ptr_sum(npt, L.F_TRGLOC, [0.3], om)[:, 0]
+        rule.close()
+        note(tag + ("scan",), np.abs(sc - tref).max() / np.abs(tref).max(), 1e-10)
+        note(tag + ("sum",), np.abs(sf - tref).max() / np.abs(tref).max(), 1e-10)
+    return worst, bad
+
+
 @pytest.fixture(scope="module")
 def abz():
     import autobzcore.jl_amd as m
@@ -202,3 +294,9 @@ def test_fuzz_small_band_rules(abz):
 def test_fuzz_many_band_rules_iai_and_symmetric_rules(abz):
     worst, bad = fuzz_many_band_rules_iai_and_symmetric_rules(abz, seed=1, quick=True)
     assert not bad, "\n".join(bad)
+
+
+@pytest.mark.parametrize("seed", [501, 502])
+def test_fuzz_round5_kernels(abz, seed):
+    worst, bad = fuzz_round5_kernels(abz, seed)
+    assert not bad, bad
