@@ -1821,7 +1821,9 @@ static int launch_gen_grid_eig(abz_ctx* ctx, const GenSpec& gs, int np, size_t l
         if (!pad && sizeof(double2) * (size_t)gs.M * gs.n * gs.n + tile_bytes > 160 * 1024)  // gen_grid_eig_supported's chunk length
             a.mc = (int)((72 * 1024 - tile_bytes) / (sizeof(double2) * (size_t)gs.n * gs.n));
     }
-    const int64_t blocks = std::min<int64_t>(a.nlines, 256 * 4);
+    // one workgroup per line (or run): the set is staged per line whatever the grid, and the hardware balances a grid that is not a
+    // multiple of the resident workgroups (48^3 x 16 bands: 2 304 lines over 1 024 workgroups left a quarter of the time to a tail)
+    const int64_t blocks = std::min<int64_t>(a.nlines, abz_switch(SW_EIG_SPLIT) != 0 ? (int64_t)1 << 20 : 256 * 4);
     const bool vec = gs.Uplanes.base != nullptr;
     // eigenvalues without eigenvectors: the tridiagonals go through scratch to tri_eig_kernel (ABZ_EIG_SPLIT=0: bisection
     // inside the grid kernel).  (Cutting the grid into four chunks of lines with chunk c's tridiagonal kernel on a second
