@@ -45,7 +45,9 @@ end
 function check(rc::Cint)
     rc == 0 && return nothing
     msg = unsafe_string(ccall((:abz_last_error, libabz), Cstring, ()))
-    rc == -1 ? throw(ArgumentError(msg)) : error("libabzhip error $rc: $msg")
+    rc == -1 && throw(ArgumentError(msg))        # ABZ_ERR_ARG <-> the reference's ArgumentError sites
+    rc == -5 && throw(OutOfMemoryError())          # ABZ_ERR_NOMEM (device allocation, or std::bad_alloc caught at the boundary)
+    error("libabzhip error $rc: $msg")             # -2 HIP, -3 no GPU, -4 unsupported, -6 a C++ exception caught at the boundary
 end
 
 # ---------------------------------------------------------------- handles
