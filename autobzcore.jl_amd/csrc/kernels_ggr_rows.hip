@@ -598,16 +598,12 @@ int launch_ggr_rows(abz_ctx* ctx, const GgrRowsSpec& gs) {
         ABZ_HIP(hipFuncSetAttribute((const void*)ggr_rows_kernel<NPV, PV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));   \
         hipLaunchKernelGGL((ggr_rows_kernel<NPV, PV>), dim3((unsigned)blocks), dim3(256), lds, ctx->stream, a);                      \
     }
-#ifdef GGR_ONLY16
-    ABZ_GR(16, true)
-#else
     if (np == 8 && pad) ABZ_GR(8, true)
     else if (np == 8) ABZ_GR(8, false)
     else if (np == 16 && pad) ABZ_GR(16, true)
     else if (np == 16) ABZ_GR(16, false)
     else if (pad) ABZ_GR(32, true)
     else ABZ_GR(32, false)
-#endif
 #undef ABZ_GR
     ABZ_HIP(hipGetLastError());
     return ABZ_OK;
