@@ -709,6 +709,18 @@ def flat_first(out):
         cb = (out.get(blk) or {}).get("cpu_baseline") if isinstance(out.get(blk), dict) else None
         if isinstance(cb, dict):
             flat[f"{blk}_speedup_vs_cpu_port"] = cb.get("gpu_over_cpu")
+    try:  # the round-5 legs as flat scalars too
+        gb = out.get("ggr_bands_5_to_32") or {}
+        flat["ggr_bands16_seconds_24cubed"] = (gb.get("bands16_M7") or {}).get("seconds")
+        flat["ggr_bands32_seconds_24cubed"] = (gb.get("bands32_M5") or {}).get("seconds")
+        flat["bands48_rule_H_and_eig_seconds_24cubed"] = ((out.get("bands48_64_fixed_grids") or {}).get("bands48") or {}).get("rule_24cubed_H_and_eig_seconds")
+        ex = ((out.get("iai_example") or {}).get("FBZ") or {})
+        flat["iai_example_fbz_seconds"] = ex.get("seconds")
+        flat["iai_example_speedup_vs_cpu_port"] = (ex.get("cpu_baseline") or {}).get("gpu_over_cpu")
+        flat["iai_example_same_numevals_as_cpu_port"] = (ex.get("cpu_baseline") or {}).get("same_numevals_as_gpu")
+        flat["ggr_build_kernel_ms"] = (out.get("ggr") or {}).get("build_kernel_ms")
+    except Exception:
+        pass
     res = {k: out[k] for k in head if k in out}
     res.update({k: v for k, v in flat.items()})
     res.update({k: v for k, v in out.items() if k not in res})
