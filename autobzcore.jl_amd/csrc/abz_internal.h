@@ -388,10 +388,17 @@ struct GgrRowsSpec {
     int64_t nlines = 0;                  // level-1 sets: grid lines, or runs of a node list
     const int64_t* run_start = nullptr;  // node lists: first node of every run (+ nk at the end); nullptr: full grid lines
     const int32_t* gi = nullptr;         // node lists: grid index i_1 of every node
+    const int64_t* parents = nullptr;    // node lists: the level-1 set of every node (33...64 bands, which do not walk runs)
+    int64_t nk = 0;                      // node lists: number of nodes
     const double2* src[3] = {nullptr, nullptr, nullptr};  // level-1 families: plain, derivative on variable 2, on variable 3
 };
 bool ggr_rows_supported(int n, int d, int M, int npt, bool herm);
 int launch_ggr_rows(abz_ctx* ctx, const GgrRowsSpec& gs);
+// 33...64 bands (kernels_big.hip, kernels_big_vec.hip): the same build, one wave per node
+bool big_ggr_supported(int n, int d, int M, int npt, bool herm);
+int launch_big_ggr(abz_ctx* ctx, const GgrRowsSpec& gs);
+int launch_big_vec(abz_ctx* ctx, const double* tri, int64_t tri_nk, const double2* keep, const double2* Dm, int64_t dstride, int64_t node0,
+                   int64_t nnodes, int n, int d, PlaneView E, PlaneView V);
 int launch_ggr(abz_ctx* ctx, int n, int d, int npt, PlaneView E, PlaneView V, const double* w, int64_t nk,
                const double* Es_host, int nE, double* out_host);
 

@@ -915,7 +915,7 @@ static bool rule_ggr_rows(const abz_rule* r) {
     const RulePlan* rp = static_cast<const RulePlan*>(r->plan);
     if (!(r->want & ABZ_WANT_VEL) || (r->want & ABZ_WANT_H) || !rp || !abz_switch(SW_GGR_FUSED)) return false;
     if (!r->full && !(s->d >= 2 && rp->plan.nruns > 0 && !rp->plan.coords)) return false;
-    return ggr_rows_supported(s->n, s->d, s->dims[0], r->npt, s->hermitian);
+    return ggr_rows_supported(s->n, s->d, s->dims[0], r->npt, s->hermitian) || big_ggr_supported(s->n, s->d, s->dims[0], r->npt, s->hermitian);
 }
 
 // eigenvalues + velocities only, Hermitian series: one of the fused GGR builds applies (n <= 4: kernels_ggr.hip)
@@ -956,12 +956,14 @@ static int rule_fill(abz_rule* r) {
             gs.nlines = plan.nruns;
             gs.run_start = rp->pd.runs.as<int64_t>();
             gs.gi = rp->pd.gi[0].as<int32_t>();
+            gs.parents = rp->pd.parent[0].as<int64_t>();
+            gs.nk = r->nk;
         }
         int rc;
         if ((rc = build_chain(s, plan, rp->pd, tab, 0, &gs.src[0]))) return rc;
         for (int j = 2; j <= d; ++j)
             if ((rc = build_chain(s, plan, rp->pd, tab, j, &gs.src[j - 1], 1, &rp->fam[j - 2]))) return rc;
-        return launch_ggr_rows(ctx, gs);
+        return big_supported(n) ? launch_big_ggr(ctx, gs) : launch_ggr_rows(ctx, gs);
     }
     if (rule_ggr_fused(r)) {
         // Fused GGR build (kernels_ggr.hip): H, every dH/dk_j, the eigensolve and the velocities in one kernel; only

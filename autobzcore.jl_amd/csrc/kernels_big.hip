@@ -53,21 +53,29 @@ struct BigSeriesArgs {
     const double2* tab;      // e^{2 pi i j / npt}
     int64_t node0, nnodes;   // this chunk: nodes [node0, node0 + nnodes)
     int n, M, first, npt, grid;
+    int deriv = 0;           // d/dx_1 in units of the period: coefficient f carries the factor 2 pi i f (JacobianSeries, src/dos_ggr.jl:18-20)
     double inv_period;
     double2* Hbuf;           // [nnodes][n * n], element (a, b) at a + n b like the coefficient blocks
 };
 
 __device__ __forceinline__ double2 big_phase(const BigSeriesArgs& a, int64_t k, int m) {
     const int f = a.first + m;
+    double2 p;
     if (a.x) {
         double s, c;
         sincospi(2.0 * ((double)f * a.x[k] * a.inv_period), &s, &c);
-        return make_double2(c, s);
+        p = make_double2(c, s);
+    } else {
+        const int64_t i1 = a.gi ? (int64_t)a.gi[k] : k % a.npt;
+        int64_t fm = f % a.npt;
+        if (fm < 0) fm += a.npt;
+        p = a.tab[(fm * i1) % a.npt];
     }
-    const int64_t i1 = a.gi ? (int64_t)a.gi[k] : k % a.npt;
-    int64_t fm = f % a.npt;
-    if (fm < 0) fm += a.npt;
-    return a.tab[(fm * i1) % a.npt];
+    if (a.deriv) {
+        const double g = 6.283185307179586476925286766559 * (double)f;
+        p = make_double2(-g * p.y, g * p.x);
+    }
+    return p;
 }
 
 // tile of BIG_TN consecutive nodes: they share the coefficient reads when they share their item (grid lines: a tile never
@@ -230,8 +238,11 @@ __global__ __launch_bounds__(256) void big_load_h_kernel(double2* __restrict__ H
 // the LOWER triangle, packed row by row (L(i, j), j <= i, at i (i + 1) / 2 + j): half the LDS of a full matrix -- twice the
 // waves per CU under these latency-bound row loops -- and half the rank-2 update; the part of row i right of the diagonal is
 // read as the conjugate of column i (consecutive lanes, consecutive addresses).
+// `keep` (GGR builds, kernels_big_vec.hip): per node what the steps leave below the diagonal, column by column -- column k is the
+// reflector v_k (its first component v_k[k + 1] replaces the eliminated entry; component i at k n - k (k + 1) / 2 + i - k - 1) --
+// then n pairs (beta_k, 0): H_k = I - beta_k v_k v_k^H.
 __global__ __launch_bounds__(64) void big_tridiag_kernel(const double2* __restrict__ Hbuf, int64_t nnodes, int n, double* __restrict__ tri,
-                                                         int64_t tri_nk, int64_t t0) {
+                                                         int64_t tri_nk, int64_t t0, double2* __restrict__ keep) {
     extern __shared__ double2 lds_bt[];  // L [n (n + 1) / 2], then v [n], q [n]
     const int np = n * (n + 1) / 2;
     double2* __restrict__ const A = lds_bt;
@@ -262,7 +273,10 @@ __global__ __launch_bounds__(64) void big_tridiag_kernel(const double2* __restri
                 tri[(int64_t)k * tri_nk + t0 + node] = A[ri + k].x;
                 tri[(int64_t)(BIG_NP + k) * tri_nk + t0 + node] = sigma;
             }
-            if (k + 2 >= n || !(sigma > 0.0)) continue;  // uniform
+            if (k + 2 >= n || !(sigma > 0.0)) {  // uniform
+                if (keep && lane == 0) keep[node * (int64_t)np + (np - n) + k] = make_double2(0.0, 0.0);
+                continue;
+            }
             const double x1r = __shfl(x.x, k + 1, 64), x1i = __shfl(x.y, k + 1, 64);
             const double a1sq = x1r * x1r + x1i * x1i;
             // v = x + (x1 / |x1|) ||x|| e_1, beta = 1 / (sigma + ||x|| |x1|)
@@ -302,6 +316,10 @@ __global__ __launch_bounds__(64) void big_tridiag_kernel(const double2* __restri
             const double ki = 0.5 * beta * bwsum(v.x * pi - v.y * pr);
             const double qr = pr - (kr * v.x - ki * v.y), qi = pi - (kr * v.y + ki * v.x);
             if (row) qq[i] = make_double2(qr, qi);
+            if (keep && i == k + 1) {
+                A[ri + k] = make_double2(v1r, v1i);
+                keep[node * (int64_t)np + (np - n) + k] = make_double2(beta, 0.0);
+            }
             bwave_sync();
             // L(i, j) -= v_i conj(q_j) + q_i conj(v_j), k < j <= i (this lane's own row)
             if (below) {
@@ -319,6 +337,18 @@ __global__ __launch_bounds__(64) void big_tridiag_kernel(const double2* __restri
         if (lane == n - 1) {
             tri[(int64_t)(n - 1) * tri_nk + t0 + node] = A[ri + (n - 1)].x;
             tri[(int64_t)(BIG_NP + n - 1) * tri_nk + t0 + node] = 0.0;
+            if (keep) keep[node * (int64_t)np + (np - n) + (n - 1)] = make_double2(0.0, 0.0);
+        }
+        if (keep) {
+            bwave_sync();
+            double2* __restrict__ ko = keep + node * (int64_t)np;  // n (n - 1) / 2 components + n betas = np numbers per node
+            for (int e = lane; e < np; e += 64) {
+                int r = (int)((sqrtf(8.0f * (float)e + 1.0f) - 1.0f) * 0.5f);
+                while ((r + 1) * (r + 2) / 2 <= e) ++r;
+                while (r * (r + 1) / 2 > e) --r;
+                const int c = e - r * (r + 1) / 2;
+                if (c < r) ko[c * n - c * (c + 1) / 2 + (r - c - 1)] = A[e];
+            }
         }
     }
 }
@@ -513,11 +543,11 @@ int big_reserve(abz_ctx* ctx, int n, int npt_or_zero, int64_t nnodes, BigWork& w
     return ABZ_OK;
 }
 
-int big_tridiag(abz_ctx* ctx, const BigWork& w, int n, int64_t cn) {
+int big_tridiag(abz_ctx* ctx, const BigWork& w, int n, int64_t cn, double2* keep = nullptr) {
     const size_t lds = sizeof(double2) * ((size_t)n * (n + 1) / 2 + 2 * (size_t)n);
     ABZ_HIP(hipFuncSetAttribute((const void*)big_tridiag_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const int64_t blocks = std::min<int64_t>(cn, 256 * 8);
-    hipLaunchKernelGGL(big_tridiag_kernel, dim3((unsigned)blocks), dim3(64), lds, ctx->stream, w.Hbuf, cn, n, w.tri, w.tri_nk, (int64_t)0);
+    hipLaunchKernelGGL(big_tridiag_kernel, dim3((unsigned)blocks), dim3(64), lds, ctx->stream, w.Hbuf, cn, n, w.tri, w.tri_nk, (int64_t)0, keep);
     ABZ_HIP(hipGetLastError());
     return ABZ_OK;
 }
@@ -544,6 +574,69 @@ int big_series(abz_ctx* ctx, BigSeriesArgs& sa, int64_t c0, int64_t cn) {
 }  // namespace
 
 bool big_supported(int n) { return n > 32 && n <= ABZ_MAX_BANDS; }
+
+// GGR builds (eigenvalues + band velocities, nothing else stored): chunk by chunk H -> tridiagonal with the reflectors kept ->
+// eigenvalues into the rule -> dH/dk_j, j = 1 ... d, side by side -> eigenvectors, back-transformation and the quadratic forms in
+// big_ggr_kernel (kernels_big_vec.hip).  ref: src/dos_ggr.jl:14-44
+bool big_ggr_supported(int n, int d, int M, int npt, bool herm) {
+    return big_supported(n) && herm && d >= 1 && d <= 3 && M >= 1 && M <= 64 && npt >= 1 && npt < 65536;
+}
+
+int launch_big_ggr(abz_ctx* ctx, const GgrRowsSpec& gs) {
+    const bool grid = gs.run_start == nullptr;
+    const int64_t nnodes = grid ? gs.nlines * gs.npt : gs.nk;
+    if (nnodes == 0) return ABZ_OK;
+    const int n = gs.n, nn = n * n, np = n * (n + 1) / 2;
+    // chunks of nodes: <= 256 MB of matrices (H and d derivatives) and kept reflectors, whole grid lines in grid mode
+    int64_t c = std::max<int64_t>(1, (int64_t)(256ull << 20) / ((int64_t)sizeof(double2) * ((int64_t)nn * gs.d + np)));
+    if (grid) c = std::max<int64_t>(1, c / gs.npt) * gs.npt;
+    c = std::min(c, nnodes);
+    BigWork w;
+    w.chunk = c;
+    w.tri_nk = (c + 63) / 64 * 64;
+    int rc;
+    // (H shares its room with the first derivative: it is dead once the tridiagonal is there)
+    if ((rc = ctx->scratch[6].reserve(sizeof(double2) * ((size_t)c * nn * gs.d + 64)))) return rc;
+    if ((rc = ctx->scratch[4].reserve(sizeof(double) * (size_t)(2 * BIG_NP) * (size_t)w.tri_nk))) return rc;
+    if ((rc = ctx->scratch[7].reserve(sizeof(double2) * ((size_t)c * np + 256)))) return rc;
+    w.Hbuf = ctx->scratch[6].as<double2>();
+    w.tri = ctx->scratch[4].as<double>();
+    double2* keep = ctx->scratch[7].as<double2>();
+    BigSeriesArgs sa;
+    sa.parents = grid ? nullptr : gs.parents;
+    sa.gi = grid ? nullptr : gs.gi;
+    sa.x = nullptr;
+    sa.tab = gs.tab;
+    sa.n = n;
+    sa.M = gs.M;
+    sa.first = gs.first;
+    sa.npt = gs.npt;
+    sa.grid = grid ? 1 : 0;
+    sa.inv_period = 1.0;
+    ProfScope ps(ctx, ABZ_K_EVAL);
+    for (int64_t c0 = 0; c0 < nnodes; c0 += w.chunk) {
+        const int64_t cn = std::min(w.chunk, nnodes - c0);
+        sa.src = gs.src[0];
+        sa.deriv = 0;
+        sa.Hbuf = w.Hbuf;
+        if ((rc = big_series(ctx, sa, c0, cn))) return rc;
+        if ((rc = big_tridiag(ctx, w, n, cn, keep))) return rc;
+        {
+            const size_t qlds = sizeof(double) * 2 * (size_t)(n + 2) * 64;
+            ABZ_HIP(hipFuncSetAttribute((const void*)big_qr_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)qlds));
+            hipLaunchKernelGGL(big_qr_kernel, dim3((unsigned)cdivb(cn, 64)), dim3(64), qlds, ctx->stream, w.tri, w.tri_nk, c0, cn, n, gs.E);
+            ABZ_HIP(hipGetLastError());
+        }
+        for (int j = 0; j < gs.d; ++j) {
+            sa.src = gs.src[j];
+            sa.deriv = j == 0 ? 1 : 0;  // (variables 2, 3: the family was contracted with the factor on that variable)
+            sa.Hbuf = w.Hbuf + (int64_t)j * w.chunk * nn;
+            if ((rc = big_series(ctx, sa, c0, cn))) return rc;
+        }
+        if ((rc = launch_big_vec(ctx, w.tri, w.tri_nk, keep, w.Hbuf, w.chunk * nn, c0, cn, n, gs.d, gs.E, gs.V))) return rc;
+    }
+    return ABZ_OK;
+}
 
 // abz_eval_nodes, rule builds (full layout) and the IAI node path
 int launch_big_nodes(abz_ctx* ctx, const GenSpec& gs) {

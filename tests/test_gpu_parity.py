@@ -1698,6 +1698,75 @@ def test_ggr_more_than_four_bands(abz, n, monkeypatch):
         assert np.abs(u - ref).max() <= 1e-9 * max(1.0, np.abs(ref).max())
 
 
+@pytest.mark.parametrize("n", [33, 40, 48, 57, 64])
+def test_ggr_33_to_64_bands(abz, n):
+    """GGR builds for 33...64 bands (ref: src/dos_ggr.jl:14-44, LAPACK there): kernels_big.hip (H, tridiagonal with the
+    reflectors kept, eigenvalues, derivative matrices) + kernels_big_vec.hip (per-lane inverse iteration, back-transformation
+    and quadratic forms, two waves per node) -- eigenvalues, band velocities and the scanned DOS on the full grid and on an
+    inversion-symmetric node list against the oracle."""
+    so = orc.synthetic_wannier(n=n, rmax=2, seed=7)
+    s = abz.FourierSeries(so.c, period=1.0, first=so.first, ndim=3)
+    w, e, v = orc.get_ggr_data(so, 6, None)
+    scale, vscale = np.abs(e).max(), np.abs(v).max()
+    ok = np.min(np.diff(e, axis=1), axis=1) > 1e-6 * scale
+    assert ok.sum() > 100
+    rule = abz.DeviceRule(s.device(), 6, None, 2 | 4)
+    out = rule.export(eig=True, vel=True)
+    rule.close()
+    assert np.abs(out["eig"] - e).max() < 1e-11 * scale
+    assert np.abs(out["vel"][ok] - v[ok]).max() < 1e-8 * vscale
+    assert np.abs(out["vel"].sum(axis=2) - v.sum(axis=2)).max() < 1e-8 * vscale * n
+    Es = np.linspace(-2.0, 2.0, 9)
+    for kind, bzk in (("FBZ", abz.FBZ()), ("InversionSymIBZ", abz.InversionSymIBZ())):
+        u = abz.dos.solve(abz.DOSProblem(s, Es, abz.load_bz(bzk, np.eye(3))), abz.GGR(npt=8)).u
+        ref = orc.dos_ggr(so, orc.load_bz(kind, np.eye(3)), Es, npt=8)
+        assert np.abs(ref).max() > 0.1
+        assert np.abs(u - ref).max() <= 1e-9 * max(1.0, np.abs(ref).max())
+    # one and two dimensions
+    for dims in ((5,), (3, 5)):
+        rng = np.random.default_rng(100 * n + len(dims))
+        c, first = rand_series(rng, dims, n, hermitian=True)
+        s2, so2 = both(abz, c / np.sqrt(n), first)
+        npt = 11 if len(dims) == 1 else 7
+        w2, e2, v2 = orc.get_ggr_data(so2, npt, None)
+        rule = abz.DeviceRule(s2.device(), npt, None, 2 | 4)
+        o2 = rule.export(eig=True, vel=True)
+        rule.close()
+        sep = np.min(np.diff(e2, axis=1), axis=1) > 1e-6 * np.abs(e2).max()
+        assert np.abs(o2["eig"] - e2).max() < 1e-11 * np.abs(e2).max()
+        assert np.abs(o2["vel"][sep] - v2[sep]).max() < 1e-8 * np.abs(v2).max()
+
+
+@pytest.mark.parametrize("n3,mult", [(11, 3), (5, 8), (8, 8), (32, 2)])
+def test_ggr_33_to_64_bands_degenerate(abz, n3, mult):
+    """Exactly degenerate levels everywhere at 33...64 bands (H = Q (I_mult x h(k)) Q^H): the cluster rounds of kernels_big_vec.hip
+    -- eigenvalues, velocity sums over each degenerate set and the scanned DOS against the oracle."""
+    rng = np.random.default_rng(70 * n3 + mult)
+    c3, first = rand_series(rng, (3, 3, 3), n3, hermitian=True)
+    n = n3 * mult
+    q, _ = np.linalg.qr(rng.standard_normal((n, n)) + 1j * rng.standard_normal((n, n)))
+    c = np.einsum("ab,...bc,dc->...ad", q, np.kron(np.eye(mult), c3 / np.sqrt(n3)), q.conj())
+    c = 0.5 * (c + np.conj(np.swapaxes(c[::-1, ::-1, ::-1], -1, -2)))  # c(-R) = c(R)^H to the bit: the Hermitian kernels' condition
+    s, so = both(abz, c, first)
+    npt = 5
+    w, e, v = orc.get_ggr_data(so, npt, None)
+    rule = abz.DeviceRule(s.device(), npt, None, 2 | 4)
+    out = rule.export(eig=True, vel=True)
+    rule.close()
+    scale, vscale = np.abs(e).max(), np.abs(v).max()
+    assert np.abs(out["eig"] - e).max() <= 1e-11 * scale
+    grp = lambda a: a.reshape(a.shape[0], a.shape[1], n3, mult).sum(axis=3)
+    e3 = e.reshape(len(e), n3, mult)[:, :, 0]
+    sep = np.min(np.diff(e3, axis=1), axis=1) > 1e-6 * scale
+    assert sep.mean() > 0.5
+    assert np.abs(grp(out["vel"])[sep] - grp(v)[sep]).max() <= 1e-8 * vscale * mult
+    assert np.abs(out["vel"].sum(axis=2) - v.sum(axis=2)).max() <= 1e-8 * vscale * n
+    Es = np.linspace(-3.0, 3.0, 7)
+    u = abz.dos.solve(abz.DOSProblem(s, Es, abz.load_bz(abz.FBZ(), np.eye(3))), abz.GGR(npt=6)).u
+    ref = orc.dos_ggr(so, orc.load_bz("FBZ", np.eye(3)), Es, npt=6)
+    assert np.abs(u - ref).max() <= 1e-8 * max(1.0, np.abs(ref).max())
+
+
 @pytest.mark.parametrize("n3,mult", [(3, 2), (2, 4), (3, 4), (5, 2), (3, 8), (7, 4)])
 def test_ggr_rows_degenerate_bands(abz, n3, mult):
     """Exactly degenerate levels everywhere (H = Q (I_mult x h(k)) Q^H with a fixed unitary Q): the per-lane inverse iteration
