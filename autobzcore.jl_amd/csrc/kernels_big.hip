@@ -14,8 +14,9 @@
 //   big_trace_kernel       tr inv((w + i eta) I - H) = p'(z) / p(z) from the three-term recurrence of the tridiagonal, one
 //                          thread per (node, swept value): node values (IAI) or weighted partial sums (rules, store-free sums).
 // Serves abz_eval_nodes, rule builds (H and / or eigenvalues, full layout), scans of cached rules (DOS / tr G from the
-// matrices or the eigenvalues), store-free PTR sums and the IAI node path.  Matrix-valued G, velocities (GGR) and the
-// Hermitian-compact layout stay at <= 32 bands.
+// matrices or the eigenvalues), store-free PTR sums and the IAI node path; big_inverse_kernel (one workgroup per node, Gauss-
+// Jordan in LDS) adds matrix-valued G and the traces of series that are not Hermitian; GGR builds (eigenvalues + band
+// velocities): launch_big_ggr below with kernels_big_vec.hip.  Only the Hermitian-compact layout stays at <= 32 bands.
 #include <utility>
 
 #include "abz_internal.h"
@@ -522,6 +523,136 @@ __global__ __launch_bounds__(256) void big_accumulate_kernel(double2* __restrict
     }
 }
 
+// inv((w + i eta) I - H) of a node, ONE WORKGROUP PER NODE: the matrix in LDS, Gauss-Jordan in place without pivoting (what the
+// <= 32-band kernels do: for Hermitian H the matrix is eta I plus a skew-Hermitian part times i -- no small pivots; a general H
+// gets no more here than there).  Per pivot c: column c and the scaled row c go to two buffers, then every thread updates its
+// share of the n^2 entries: two barriers per pivot.  Serves what the tridiagonal cannot: matrix-valued G (ABZ_F_GLOC) and the
+// traces of series that are not Hermitian.  Node mode: values[node][swept value][component]; sum mode: every workgroup adds the
+// weighted values of its nodes (registers) and leaves partial[block][swept value][component] for launch_final_reduce.
+struct BigInvArgs {
+    const double2* Hbuf;  // [nnodes][n n] of this chunk
+    int64_t node0, nnodes;
+    int n, n_sweep, kind;  // kind 0: G (n n components), 1: tr G, 2: DOS = -Im tr G / pi
+    double eta;
+    const double* sweep;           // device [n_sweep] (or null: sweep0)
+    const double* sweep_per_node;  // device [all nodes]
+    double sweep0;
+    const double* w;      // sum mode: weights of all nodes (null: 1)
+    double2* values;      // node mode
+    double2* partial;     // sum mode, ACCUMULATED over chunks (zeroed by the caller)
+    int nodes_per_block;  // sum mode
+};
+__global__ __launch_bounds__(256) void big_inverse_kernel(BigInvArgs a) {
+    extern __shared__ double2 lds_bi[];  // W [n n] | column [n] | row [n]
+    const int n = a.n, nn = n * n, tid = threadIdx.x;
+    double2* __restrict__ const W = lds_bi;
+    double2* __restrict__ const colb = W + nn;
+    double2* __restrict__ const rowb = colb + n;
+    const int ncomp = a.kind == 0 ? nn : 1;
+    const bool sum = a.partial != nullptr;
+    const int64_t k0 = sum ? (int64_t)blockIdx.x * a.nodes_per_block : blockIdx.x;
+    const int64_t k1 = sum ? min(a.nnodes, k0 + a.nodes_per_block) : a.nnodes;
+    const int64_t kstep = sum ? 1 : gridDim.x;
+    for (int s = 0; s < a.n_sweep; ++s) {
+        double2 acc[16];  // sum mode: entries tid + 256 q of the matrix (n <= 64), or the trace in acc[0] of thread 0
+#pragma unroll
+        for (int q = 0; q < 16; ++q) acc[q] = make_double2(0.0, 0.0);
+        for (int64_t k = k0; k < k1; k += kstep) {
+            const double sw = a.sweep_per_node ? a.sweep_per_node[a.node0 + k] : (a.sweep ? a.sweep[s] : a.sweep0);
+            const double2* __restrict__ h = a.Hbuf + k * (int64_t)nn;
+            __syncthreads();
+            for (int t = tid; t < nn; t += 256) {
+                const int r = t % n, c = t / n;
+                const double2 hv = h[t];
+                W[t] = make_double2((r == c ? sw : 0.0) - hv.x, (r == c ? a.eta : 0.0) - hv.y);
+            }
+            __syncthreads();
+            for (int c = 0; c < n; ++c) {
+                const double2 p = W[c + n * c];
+                const double ipn = 1.0 / (p.x * p.x + p.y * p.y);
+                const double ipr = p.x * ipn, ipi = -p.y * ipn;  // 1 / pivot
+                if (tid < n) {
+                    colb[tid] = W[tid + n * c];
+                    const double2 rv = W[c + n * tid];
+                    rowb[tid] = make_double2(rv.x * ipr - rv.y * ipi, rv.x * ipi + rv.y * ipr);
+                }
+                __syncthreads();
+                for (int t = tid; t < nn; t += 256) {
+                    const int r = t % n, j = t / n;
+                    double2 v;
+                    if (r == c && j == c) {
+                        v = make_double2(ipr, ipi);
+                    } else if (r == c) {
+                        v = rowb[j];
+                    } else if (j == c) {
+                        const double2 f = colb[r];
+                        v = make_double2(-(f.x * ipr - f.y * ipi), -(f.x * ipi + f.y * ipr));
+                    } else {
+                        const double2 f = colb[r], g = rowb[j], o = W[t];
+                        v = make_double2(o.x - (f.x * g.x - f.y * g.y), o.y - (f.x * g.y + f.y * g.x));
+                    }
+                    W[t] = v;
+                }
+                __syncthreads();
+            }
+            const double wk = sum ? (a.w ? a.w[a.node0 + k] : 1.0) : 1.0;
+            if (a.kind == 0) {
+                if (sum) {
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) {
+                        const int t = tid + 256 * q;
+                        if (t < nn) {
+                            acc[q].x = fma(wk, W[t].x, acc[q].x);
+                            acc[q].y = fma(wk, W[t].y, acc[q].y);
+                        }
+                    }
+                } else {
+                    double2* __restrict__ vo = a.values + ((a.node0 + k) * a.n_sweep + s) * (int64_t)nn;
+                    for (int t = tid; t < nn; t += 256) vo[t] = W[t];
+                }
+            } else {
+                double tr = 0.0, ti = 0.0;
+                if (tid < n) {
+                    tr = W[tid + n * tid].x;
+                    ti = W[tid + n * tid].y;
+                }
+                if (tid < 64) {  // (n <= 64: the diagonal sits in the first wave)
+                    tr = bwsum(tr);
+                    ti = bwsum(ti);
+                }
+                if (tid == 0) {
+                    if (a.kind == 2) {
+                        tr = -ti * 0.31830988618379067153776752674503;
+                        ti = 0.0;
+                    }
+                    if (sum) {
+                        acc[0].x = fma(wk, tr, acc[0].x);
+                        acc[0].y = fma(wk, ti, acc[0].y);
+                    } else {
+                        a.values[(a.node0 + k) * a.n_sweep + s] = make_double2(tr, ti);
+                    }
+                }
+            }
+        }
+        if (sum) {
+            double2* __restrict__ po = a.partial + ((int64_t)blockIdx.x * a.n_sweep + s) * ncomp;
+            if (a.kind == 0) {
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {
+                    const int t = tid + 256 * q;
+                    if (t < nn) {
+                        po[t].x += acc[q].x;
+                        po[t].y += acc[q].y;
+                    }
+                }
+            } else if (tid == 0) {
+                po[0].x += acc[0].x;
+                po[0].y += acc[0].y;
+            }
+        }
+    }
+}
+
 struct BigWork {
     double2* Hbuf = nullptr;
     double* tri = nullptr;
@@ -551,6 +682,15 @@ int big_tridiag(abz_ctx* ctx, const BigWork& w, int n, int64_t cn, double2* keep
     ABZ_HIP(hipGetLastError());
     return ABZ_OK;
 }
+
+static int big_inverse(abz_ctx* ctx, BigInvArgs& ia, int64_t blocks) {
+    const size_t lds = sizeof(double2) * ((size_t)ia.n * ia.n + 2 * (size_t)ia.n);
+    ABZ_HIP(hipFuncSetAttribute((const void*)big_inverse_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(big_inverse_kernel, dim3((unsigned)blocks), dim3(256), lds, ctx->stream, ia);
+    ABZ_HIP(hipGetLastError());
+    return ABZ_OK;
+}
+static int big_inv_kind(int integrand) { return integrand == ABZ_F_GLOC ? 0 : (integrand == ABZ_F_TRGLOC ? 1 : (integrand == ABZ_F_DOS ? 2 : -1)); }
 
 int big_series(abz_ctx* ctx, BigSeriesArgs& sa, int64_t c0, int64_t cn) {
     sa.node0 = c0;
@@ -587,8 +727,9 @@ int launch_big_ggr(abz_ctx* ctx, const GgrRowsSpec& gs) {
     const int64_t nnodes = grid ? gs.nlines * gs.npt : gs.nk;
     if (nnodes == 0) return ABZ_OK;
     const int n = gs.n, nn = n * n, np = n * (n + 1) / 2;
-    // chunks of nodes: <= 256 MB of matrices (H and d derivatives) and kept reflectors, whole grid lines in grid mode
-    int64_t c = std::max<int64_t>(1, (int64_t)(256ull << 20) / ((int64_t)sizeof(double2) * ((int64_t)nn * gs.d + np)));
+    // chunks of nodes: <= 2 GB of matrices (H and d derivatives) and kept reflectors, whole grid lines in grid mode (a chunk wants
+    // several thousand nodes: the kernels run one wave or one small workgroup per node)
+    int64_t c = std::max<int64_t>(1, (int64_t)(2048ull << 20) / ((int64_t)sizeof(double2) * ((int64_t)nn * gs.d + np)));
     if (grid) c = std::max<int64_t>(1, c / gs.npt) * gs.npt;
     c = std::min(c, nnodes);
     BigWork w;
@@ -649,14 +790,13 @@ int launch_big_nodes(abz_ctx* ctx, const GenSpec& gs) {
         set_error("n = %d bands: at most 64 coefficients per variable (got %d)", gs.n, gs.M);
         return ABZ_ERR_UNSUPPORTED;
     }
-    if (gs.values && !(gs.integrand == ABZ_F_DOS || gs.integrand == ABZ_F_TRGLOC)) {
-        set_error("n = %d bands: integrand %d is built for n <= 32 (DOS and tr G are available)", gs.n, gs.integrand);
+    if (gs.values && big_inv_kind(gs.integrand) < 0) {
+        set_error("n = %d bands: integrand %d is built for n <= 32 (G, tr G and DOS are available)", gs.n, gs.integrand);
         return ABZ_ERR_UNSUPPORTED;
     }
-    if (gs.values && !gs.herm) {  // (eigenvalues are those of Hermitian(h), the upper triangle, whatever the series)
-        set_error("n = %d bands: resolvent traces need a Hermitian series", gs.n);
-        return ABZ_ERR_UNSUPPORTED;
-    }
+    // values: the traces of a Hermitian series come from the tridiagonal; matrix-valued G and series that are not Hermitian
+    // from the inverse (eigenvalues are those of Hermitian(h), the upper triangle, whatever the series)
+    const bool inv_values = gs.values && (gs.integrand == ABZ_F_GLOC || !gs.herm);
     BigWork w;
     int rc = big_reserve(ctx, gs.n, gs.grid ? gs.npt : 0, gs.nnodes, w);
     if (rc) return rc;
@@ -682,7 +822,25 @@ int launch_big_nodes(abz_ctx* ctx, const GenSpec& gs) {
                                w.Hbuf, c0, cn, gs.n, gs.Hplanes, gs.Haos);
             ABZ_HIP(hipGetLastError());
         }
-        if (!(gs.Eplanes.base || gs.Eaos || gs.values)) continue;
+        if (inv_values) {
+            BigInvArgs ia;
+            ia.Hbuf = w.Hbuf;
+            ia.node0 = c0;
+            ia.nnodes = cn;
+            ia.n = gs.n;
+            ia.n_sweep = gs.n_sweep > 0 ? gs.n_sweep : 1;
+            ia.kind = big_inv_kind(gs.integrand);
+            ia.eta = gs.params[0];
+            ia.sweep = gs.sweep_dev;
+            ia.sweep_per_node = gs.sweep_per_node;
+            ia.sweep0 = gs.sweep0;
+            ia.w = nullptr;
+            ia.values = gs.values;
+            ia.partial = nullptr;
+            ia.nodes_per_block = 0;
+            if ((rc = big_inverse(ctx, ia, std::min<int64_t>(cn, 256 * 8)))) return rc;
+        }
+        if (!(gs.Eplanes.base || gs.Eaos || (gs.values && !inv_values))) continue;
         if ((rc = big_tridiag(ctx, w, gs.n, cn))) return rc;
         // (one lane per matrix: the QR kernel wants >= 64 matrices per CU's worth of workgroups; a small chunk of the largest
         // matrices is faster by bisection, one thread per eigenvalue)
@@ -696,7 +854,7 @@ int launch_big_nodes(abz_ctx* ctx, const GenSpec& gs) {
                                gs.Eplanes, gs.Eaos);
             ABZ_HIP(hipGetLastError());
         }
-        if (gs.values) {
+        if (gs.values && !inv_values) {
             BigTraceArgs ta;
             ta.tri = w.tri;
             ta.tri_nk = w.tri_nk;
@@ -806,13 +964,63 @@ int launch_big_sum(abz_ctx* ctx, const SumSpec& ss, double* out_reim) {
 // scans of a cached rule: DOS / tr G from the matrices (tridiagonalised chunk by chunk); the eigenvalue form goes through
 // gen_eig_dos_kernel (kernels_generic.hip), which is generic in n
 int launch_big_reduce(abz_ctx* ctx, const ReduceSpec& rs, double* out_reim) {
-    if (!(rs.integrand == ABZ_F_DOS || rs.integrand == ABZ_F_TRGLOC) || !rs.H.base || rs.H.compact || !rs.herm) {
-        set_error("n = %d bands: scans of a cached rule offer DOS / tr G of Hermitian matrices (full layout) and DOS from eigenvalues", rs.n);
+    if (big_inv_kind(rs.integrand) < 0 || !rs.H.base || rs.H.compact) {
+        set_error("n = %d bands: scans of a cached rule offer G, tr G and DOS from the matrices (full layout) and DOS from eigenvalues", rs.n);
         return ABZ_ERR_UNSUPPORTED;
     }
     BigWork w;
     int rc = big_reserve(ctx, rs.n, 0, rs.nk, w);
     if (rc) return rc;
+    if (rs.integrand == ABZ_F_GLOC || !rs.herm) {
+        // matrix-valued G, or matrices that are not Hermitian: the inverse of every node (big_inverse_kernel), a group of swept
+        // values per pass so that the workgroups' partial sums stay under 256 MB
+        const int nn = rs.n * rs.n, kind = big_inv_kind(rs.integrand);
+        const int64_t ncomp = kind == 0 ? nn : 1;
+        const int64_t blocks = std::max<int64_t>(1, std::min<int64_t>(rs.nk, 256 * 2));
+        const int group = (int)std::max<int64_t>(1, std::min<int64_t>(rs.n_sweep, (256ll << 20) / (int64_t)(sizeof(double2) * blocks * ncomp)));
+        if ((rc = ctx->scratch[1].reserve(sizeof(double2) * (size_t)(blocks * group * ncomp)))) return rc;
+        if ((rc = ctx->scratch[2].reserve(sizeof(double2) * (size_t)(group * ncomp)))) return rc;
+        double2* partial = ctx->scratch[1].as<double2>();
+        double2* outd = ctx->scratch[2].as<double2>();
+        for (int s0 = 0; s0 < rs.n_sweep; s0 += group) {
+            const int ns = std::min(group, rs.n_sweep - s0);
+            {
+                ProfScope ps(ctx, ABZ_K_REDUCE);
+                ABZ_HIP(hipMemsetAsync(partial, 0, sizeof(double2) * (size_t)(blocks * ns * ncomp), ctx->stream));
+                for (int64_t c0 = 0; c0 < rs.nk; c0 += w.chunk) {
+                    const int64_t cn = std::min(w.chunk, rs.nk - c0);
+                    hipLaunchKernelGGL(big_load_h_kernel, dim3((unsigned)std::min<int64_t>(cdivb((cn + 63) / 64 * 64 * nn, 256), 256 * 16)), dim3(256), 0,
+                                       ctx->stream, w.Hbuf, c0, cn, rs.n, rs.H);
+                    ABZ_HIP(hipGetLastError());
+                    BigInvArgs ia;
+                    ia.Hbuf = w.Hbuf;
+                    ia.node0 = c0;
+                    ia.nnodes = cn;
+                    ia.n = rs.n;
+                    ia.n_sweep = ns;
+                    ia.kind = kind;
+                    ia.eta = rs.params[0];
+                    ia.sweep = rs.sweep_dev + s0;
+                    ia.sweep_per_node = nullptr;
+                    ia.sweep0 = 0.0;
+                    ia.w = rs.w;
+                    ia.values = nullptr;
+                    ia.partial = partial;
+                    ia.nodes_per_block = (int)cdivb(cn, blocks);
+                    if ((rc = big_inverse(ctx, ia, cdivb(cn, ia.nodes_per_block)))) return rc;
+                }
+                if ((rc = launch_final_reduce(ctx, partial, blocks, (int64_t)ns * ncomp, rs.scale, outd))) return rc;
+            }
+            if (rs.out_dev) {
+                ABZ_HIP(hipMemcpyAsync(rs.out_dev + 2 * (size_t)s0 * ncomp, outd, sizeof(double2) * (size_t)ns * ncomp, hipMemcpyDeviceToDevice,
+                                       ctx->stream));
+                continue;
+            }
+            ABZ_HIP(hipMemcpyAsync(out_reim + 2 * (size_t)s0 * ncomp, outd, sizeof(double2) * (size_t)ns * ncomp, hipMemcpyDeviceToHost, ctx->stream));
+            ABZ_HIP(hipStreamSynchronize(ctx->stream));
+        }
+        return ABZ_OK;
+    }
     if ((rc = ctx->scratch[2].reserve(sizeof(double2) * (size_t)rs.n_sweep))) return rc;
     double2* total = ctx->scratch[2].as<double2>();
     {

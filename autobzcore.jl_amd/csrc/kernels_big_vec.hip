@@ -11,15 +11,18 @@
 //       checkpoint before it substitutes them;
 //   (2) u_b = H_0 ... H_{n-3} P z_b with the rows split between the waves in chunks of eight (wave w: chunks w, w + 2, ...: the
 //       triangle of reflector x row work is shared evenly, 2 x 32 doubles per lane), the two partial sums v_K^H u meeting in LDS,
-//       one barrier per reflector.  The reflectors v_K (kept by big_tridiag_kernel, column-packed) are the same for all lanes
-//       and arrive through the scalar cache (s_load, operands of the FMAs in scalar registers): LDS broadcast reads of 16 B per
-//       64 lanes would bound the CU at half its FMA rate;
+//       one barrier per reflector.  The reflectors v_K (kept by big_tridiag_kernel, column-packed) are the same for all lanes:
+//       staged in LDS once, read back by broadcast;
 //   (3) v_{b,j} = Re u_b^H D_j u_b = sum_r [Re u_r t1_r + Im u_r (t2_r + 2 t4_r)], t1 = Re D Re u, t2 = Re D Im u, t4 = Im D Re u
-//       (D_j Hermitian: three real FMAs per matrix element instead of four), D_j of the node read through the scalar cache
-//       as well (column r of the stored matrix is the conjugate of row r); every wave sums over its own columns, the partial
-//       t of eight rows at a time go to the wave that owns those rows (LDS, one barrier), whose u_r come out of the register
-//       file by a uniform switch.
+//       (D_j Hermitian: three real FMAs per matrix element instead of four).  Eight rows of D_j at a time are staged in LDS
+//       (column r of the stored matrix is the conjugate of row r; the next eight are in flight meanwhile) and read by
+//       broadcast; every wave sums over its own columns, the partial t of the eight rows go to the wave that owns them (LDS),
+//       whose u_r come out of the register file by a uniform switch.
+//       (First version: reflectors and D_j as scalar-cache operands of the FMAs -- no LDS traffic, but a 64-B s_load feeds twelve
+//       FMAs, every one misses the 16-KB scalar cache, and ~100 SGPRs hold too few of them in flight: 1.8 ms per 1 152 nodes
+//       of 64 bands, nine times the issue time of its instructions.)
 // Only (e, v) reach the rule; nothing of U is stored.
+#include <cstdlib>
 #include <utility>
 
 #include "abz_internal.h"
@@ -31,8 +34,6 @@ namespace {
 
 constexpr int NM = 64;
 constexpr int BIG_NP_V = 64;  // rows of the tridiagonal scratch (kernels_big.hip: BIG_NP)
-
-typedef const __attribute__((address_space(4))) double* kdouble;  // uniform addresses: loads go through the scalar cache
 
 __device__ __forceinline__ void vwave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -191,22 +192,33 @@ __device__ __forceinline__ void own_chunks(int n8, F&& f, std::integer_sequence<
     ((void)((8 * (2 * LC + W) < n8) ? (f(std::integral_constant<int, LC>()), 0) : 0), ...);
 }
 
-// exchange rooms in LDS (doubles)
-constexpr int XW = 2 * 2 * 2 * 64;   // [parity][wave][re, im][lane]: the partial v_K^H u
-constexpr int PB = 2 * 24 * 64;      // [parity][8 rows x (t1, t2, t4)][lane]: the partial rows of D u
+// rooms in LDS (doubles)
+constexpr int XW = 2 * 2 * 2 * 64;  // [parity][wave][re, im][lane]: the partial v_K^H u
+constexpr int STG = 8 * NM * 2;     // eight rows of D_j, complex, zero beyond n
+constexpr int PB = 24 * 64;         // [8 rows x (t1, t2, t4)][lane]: the partial rows of D u of the wave that does not own the rows
+
+struct BigVecLds {
+    double sd[NM + 2], so[NM + 2], sbeta[NM], spr[NM], spi[NM];
+    double xw[XW];
+    // the eigenvectors of the tridiagonal [row][lane]; then the reflectors (column K: rows K + 1 ... n8 - 1 at K n8 - K (K + 1) / 2
+    // + i - K - 1, complex, zero beyond n); then the staged rows of D_j and the partial rows of D u
+    double big[NM * 64];
+    double accx[64];
+};
+static_assert(STG + PB <= NM * 64 && (NM * (NM - 1) / 2) * 2 <= NM * 64, "the rooms that share BigVecLds::big");
 
 // u <- H_K u for the reflectors K of block KB (K = 8 KB + 7 ... 8 KB), rolled over K; this wave's rows i > 8 KB, compile-time.
-// Reflector K: components i = K + 1 ... n - 1 at kc[K n - K (K + 1) / 2 - K - 1 + i] (complex), beta_K in LDS.
+// The reflectors are the same for all lanes: broadcast reads from LDS.
 template <int W, int KB>
-__device__ __forceinline__ void back_block(int n, int n8, int lane, kdouble kc, const double* sbeta, double* xw, int& xp, double (&ur)[NH],
-                                           double (&ui)[NH]) {
+__device__ __forceinline__ void back_block(int n, int n8, int lane, const double2* refl, const double* sbeta, double* xw, int& xp,
+                                           double (&ur)[NH], double (&ui)[NH]) {
 #pragma unroll 1
     for (int kk = 7; kk >= 0; --kk) {
         const int K = 8 * KB + kk;
         if (K + 2 >= n) continue;  // uniform in the workgroup
         const double beta = sbeta[K];
         if (beta == 0.0) continue;  // (a column that was zero already: no reflector)
-        kdouble vk = kc + 2 * ((int64_t)K * n - (int64_t)K * (K + 1) / 2 - K - 1);
+        const double2* vk = refl + (K * n8 - K * (K + 1) / 2 - K - 1);
         double wr[2] = {0.0, 0.0}, wi[2] = {0.0, 0.0};
         own_chunks<W>(
             n8,
@@ -216,15 +228,14 @@ __device__ __forceinline__ void back_block(int n, int n8, int lane, kdouble kc, 
 #pragma unroll
                     for (int j = 0; j < 8; ++j) {
                         const int i = 8 * C + j;
-                        if (i <= 8 * KB) continue;  // (compile time)
-                        const bool on = i > K && i < n;
-                        const double lr = vk[2 * i], li = vk[2 * i + 1];  // (the room is padded: an address outside the column is still inside it)
-                        const double vr = on ? lr : 0.0, vi = on ? li : 0.0;
+                        if (C == KB && i <= 8 * KB) continue;  // (compile time)
+                        double2 v = vk[(C == KB && i <= K) ? K + 1 : i];
+                        if (C == KB && i <= K) v = make_double2(0.0, 0.0);
                         // w += conj(v_i) u_i
-                        wr[j & 1] = fma(vr, ur[8 * LC + j], wr[j & 1]);
-                        wr[j & 1] = fma(vi, ui[8 * LC + j], wr[j & 1]);
-                        wi[j & 1] = fma(vr, ui[8 * LC + j], wi[j & 1]);
-                        wi[j & 1] = fma(-vi, ur[8 * LC + j], wi[j & 1]);
+                        wr[j & 1] = fma(v.x, ur[8 * LC + j], wr[j & 1]);
+                        wr[j & 1] = fma(v.y, ui[8 * LC + j], wr[j & 1]);
+                        wi[j & 1] = fma(v.x, ui[8 * LC + j], wi[j & 1]);
+                        wi[j & 1] = fma(-v.y, ur[8 * LC + j], wi[j & 1]);
                     }
                 }
             },
@@ -245,15 +256,14 @@ __device__ __forceinline__ void back_block(int n, int n8, int lane, kdouble kc, 
 #pragma unroll
                     for (int j = 0; j < 8; ++j) {
                         const int i = 8 * C + j;
-                        if (i <= 8 * KB) continue;
-                        const bool on = i > K && i < n;
-                        const double lr = vk[2 * i], li = vk[2 * i + 1];
-                        const double vr = on ? lr : 0.0, vi = on ? li : 0.0;
+                        if (C == KB && i <= 8 * KB) continue;
+                        double2 v = vk[(C == KB && i <= K) ? K + 1 : i];
+                        if (C == KB && i <= K) v = make_double2(0.0, 0.0);
                         // u_i -= w v_i
-                        ur[8 * LC + j] = fma(-wwr, vr, ur[8 * LC + j]);
-                        ur[8 * LC + j] = fma(wwi, vi, ur[8 * LC + j]);
-                        ui[8 * LC + j] = fma(-wwr, vi, ui[8 * LC + j]);
-                        ui[8 * LC + j] = fma(-wwi, vr, ui[8 * LC + j]);
+                        ur[8 * LC + j] = fma(-wwr, v.x, ur[8 * LC + j]);
+                        ur[8 * LC + j] = fma(wwi, v.y, ur[8 * LC + j]);
+                        ui[8 * LC + j] = fma(-wwr, v.y, ui[8 * LC + j]);
+                        ui[8 * LC + j] = fma(-wwi, v.x, ui[8 * LC + j]);
                     }
                 }
             },
@@ -262,10 +272,10 @@ __device__ __forceinline__ void back_block(int n, int n8, int lane, kdouble kc, 
 }
 
 template <int W, int... KB>
-__device__ __forceinline__ void back_blocks(int n, int n8, int lane, kdouble kc, const double* sbeta, double* xw, int& xp, double (&ur)[NH],
-                                            double (&ui)[NH], std::integer_sequence<int, KB...>) {
+__device__ __forceinline__ void back_blocks(int n, int n8, int lane, const double2* refl, const double* sbeta, double* xw, int& xp,
+                                            double (&ur)[NH], double (&ui)[NH], std::integer_sequence<int, KB...>) {
     // the last reflector first
-    ((void)((8 * (NM / 8 - 1 - KB) + 2 < n) ? (back_block<W, NM / 8 - 1 - KB>(n, n8, lane, kc, sbeta, xw, xp, ur, ui), 0) : 0), ...);
+    ((void)((8 * (NM / 8 - 1 - KB) + 2 < n) ? (back_block<W, NM / 8 - 1 - KB>(n, n8, lane, refl, sbeta, xw, xp, ur, ui), 0) : 0), ...);
 }
 
 template <int LC>
@@ -277,57 +287,59 @@ __device__ __forceinline__ void take8(const double (&ur)[NH], const double (&ui)
     }
 }
 
-// This wave's share of Re u^H D u for the Hermitian matrix whose element (a, b) sits at D[a + n b] (complex): row r is read as the
-// conjugate of column r, contiguous.  Returns the sum over the rows this wave owns (the other wave returns the rest).
+// rows 8 rb ... 8 rb + 7 of the Hermitian matrix whose element (a, b) sits at D[a + n b]: row r is read as the conjugate of column
+// r (contiguous); thread t of the 128 takes the elements t, t + 128, ... of the [8][NM] block, zero beyond n
+__device__ __forceinline__ void stage_load(const double2* __restrict__ D, int n, int rb, int tid, double2 (&g)[4]) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int e = tid + 128 * q, jr = e >> 6, c = e & 63, r = 8 * rb + jr;
+        g[q] = (r < n && c < n) ? D[c + n * r] : make_double2(0.0, 0.0);
+    }
+}
+
+// This wave's share of Re u^H D u.  Returns the sum over the rows this wave owns (the other wave returns the rest).
 template <int W>
-__device__ __forceinline__ double quad_form_k(kdouble D, int n, int n8, int lane, double* pb, int& pp, const double (&ur)[NH],
-                                              const double (&ui)[NH]) {
+__device__ __forceinline__ double quad_form_k(const double2* __restrict__ D, int n, int n8, int tid, int lane, double2* stage, double* pb,
+                                              const double (&ur)[NH], const double (&ui)[NH]) {
     double acc = 0.0;
+    double2 g[4];
+    stage_load(D, n, 0, tid, g);
 #pragma unroll 1
     for (int rb = 0; 8 * rb < n; ++rb) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) stage[tid + 128 * q] = g[q];
+        __syncthreads();
+        if (8 * (rb + 1) < n) stage_load(D, n, rb + 1, tid, g);  // in flight during the sums
         double t1[8], t2[8], t4[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             t1[j] = 0.0;
             t2[j] = 0.0;
             t4[j] = 0.0;
-            const int r = 8 * rb + j;
-            if (r < n) {  // uniform
-                kdouble col = D + 2 * (int64_t)n * r;
-                own_chunks<W>(
-                    n8,
-                    [&](auto lc) {
-                        constexpr int LC = decltype(lc)::value, c0 = 8 * (2 * LC + W);
-                        if (c0 + 8 <= n) {
-#pragma unroll
-                            for (int c = 0; c < 8; ++c) {
-                                const double dr = col[2 * (c0 + c)], di = col[2 * (c0 + c) + 1];  // D_rc = (dr, -di)
-                                t1[j] = fma(dr, ur[8 * LC + c], t1[j]);
-                                t2[j] = fma(dr, ui[8 * LC + c], t2[j]);
-                                t4[j] = fma(-di, ur[8 * LC + c], t4[j]);
-                            }
-                        } else {  // the last, partial chunk: u_c = 0 beyond n, the reads stay inside the column
-#pragma unroll
-                            for (int c = 0; c < 8; ++c) {
-                                const int cc = c0 + c < n ? c0 + c : n - 1;
-                                const double dr = col[2 * cc], di = col[2 * cc + 1];
-                                t1[j] = fma(dr, ur[8 * LC + c], t1[j]);
-                                t2[j] = fma(dr, ui[8 * LC + c], t2[j]);
-                                t4[j] = fma(-di, ur[8 * LC + c], t4[j]);
-                            }
-                        }
-                    },
-                    HalfChunks());
-            }
         }
+        own_chunks<W>(
+            n8,
+            [&](auto lc) {
+                constexpr int LC = decltype(lc)::value, c0 = 8 * (2 * LC + W);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) {
+                        const double2 dv = stage[j * NM + c0 + c];  // D_rc = (dv.x, -dv.y)
+                        t1[j] = fma(dv.x, ur[8 * LC + c], t1[j]);
+                        t2[j] = fma(dv.x, ui[8 * LC + c], t2[j]);
+                        t4[j] = fma(-dv.y, ur[8 * LC + c], t4[j]);
+                    }
+                }
+            },
+            HalfChunks());
         const bool mine = (rb & 1) == W;  // uniform: the rows of chunk rb live in wave rb & 1
-        double* room = pb + pp * (24 * 64);
         if (!mine) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                room[(3 * j + 0) * 64 + lane] = t1[j];
-                room[(3 * j + 1) * 64 + lane] = t2[j];
-                room[(3 * j + 2) * 64 + lane] = t4[j];
+                pb[(3 * j + 0) * 64 + lane] = t1[j];
+                pb[(3 * j + 1) * 64 + lane] = t2[j];
+                pb[(3 * j + 2) * 64 + lane] = t4[j];
             }
         }
         __syncthreads();
@@ -341,14 +353,13 @@ __device__ __forceinline__ double quad_form_k(kdouble D, int n, int n8, int lane
             }
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                const double s1 = t1[j] + room[(3 * j + 0) * 64 + lane];
-                const double s2 = t2[j] + room[(3 * j + 1) * 64 + lane];
-                const double s4 = t4[j] + room[(3 * j + 2) * 64 + lane];
+                const double s1 = t1[j] + pb[(3 * j + 0) * 64 + lane];
+                const double s2 = t2[j] + pb[(3 * j + 1) * 64 + lane];
+                const double s4 = t4[j] + pb[(3 * j + 2) * 64 + lane];
                 acc = fma(ar[j], s1, acc);  // (rows >= n: u_r = 0)
                 acc = fma(ai[j], fma(2.0, s4, s2), acc);
             }
         }
-        pp ^= 1;
     }
     return acc;
 }
@@ -356,20 +367,14 @@ __device__ __forceinline__ double quad_form_k(kdouble D, int n, int n8, int lane
 struct BigVecArgs {
     int64_t tri_nk, node0, nnodes, dstride;  // dstride: complex numbers from one matrix array to the next
     int n, d;
+    int phases;  // (timing experiments: bit 0 inverse iteration, 1 back-transformation, 2 quadratic forms; 7 in production)
     PlaneView E, V;
-};
-
-struct BigVecLds {
-    double sd[NM + 2], so[NM + 2], sbeta[NM], spr[NM], spi[NM];
-    double xw[XW];
-    double zl[NM * 64];  // the eigenvectors of the tridiagonal [row][lane]; later the rooms of the partial D u
-    double accx[64];
 };
 
 template <int W>
 __device__ __forceinline__ void big_vec_wave(const BigVecArgs& a, BigVecLds& L, int lane, int64_t node, const double2* __restrict__ kn,
                                              const double2* __restrict__ Dm) {
-    const int n = a.n, n8 = (n + 7) & ~7;
+    const int n = a.n, n8 = (n + 7) & ~7, tid = lane + 64 * W;
     // ---- this wave's rows of P z
     double ur[NH], ui[NH];
     own_chunks<W>(
@@ -379,22 +384,38 @@ __device__ __forceinline__ void big_vec_wave(const BigVecArgs& a, BigVecLds& L, 
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const int i = 8 * C + j;
-                const double zv = (i < n) ? L.zl[i * 64 + lane] : 0.0;
+                const double zv = (i < n) ? L.big[i * 64 + lane] : 0.0;
                 ur[8 * LC + j] = L.spr[i] * zv;
                 ui[8 * LC + j] = L.spi[i] * zv;
             }
         },
         HalfChunks());
-    __syncthreads();  // zl is free from here on
+    __syncthreads();  // the room of z is free from here on: the reflectors move in
+    double2* refl = reinterpret_cast<double2*>(L.big);
+    for (int K0 = 0; K0 + 2 < n; K0 += 8) {  // (eight columns' loads in flight)
+        double2 g[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int K = K0 + q, i = K + 1 + tid;
+            g[q] = (K + 2 < n && i < n) ? kn[K * n - K * (K + 1) / 2 + (i - K - 1)] : make_double2(0.0, 0.0);
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int K = K0 + q, i = K + 1 + tid;
+            if (K + 2 < n && i < n8) refl[K * n8 - K * (K + 1) / 2 + (i - K - 1)] = g[q];
+        }
+    }
+    __syncthreads();
     // ---- u = H_0 ... H_{n-3} (P z)
     int xp = 0;
-    kdouble kc = (kdouble)(const double*)kn;
-    back_blocks<W>(n, n8, lane, kc, L.sbeta, L.xw, xp, ur, ui, Chunks());
+    if (a.phases & 2) back_blocks<W>(n, n8, lane, refl, L.sbeta, L.xw, xp, ur, ui, Chunks());
+    __syncthreads();
     // ---- velocities
-    int pp = 0;
+    double2* stage = reinterpret_cast<double2*>(L.big);
+    double* pb = L.big + STG;
     for (int j = 0; j < a.d; ++j) {
-        kdouble D = (kdouble)(const double*)(Dm + (int64_t)j * a.dstride + node * (int64_t)n * n);
-        const double part = quad_form_k<W>(D, n, n8, lane, L.zl, pp, ur, ui);
+        const double2* __restrict__ D = Dm + (int64_t)j * a.dstride + node * (int64_t)n * n;
+        const double part = (a.phases & 4) ? quad_form_k<W>(D, n, n8, tid, lane, stage, pb, ur, ui) : ur[0];
         if (W == 1) L.accx[lane] = part;
         __syncthreads();
         if (W == 0 && lane < n)
@@ -406,7 +427,6 @@ __device__ __forceinline__ void big_vec_wave(const BigVecArgs& a, BigVecLds& L, 
 __global__ __launch_bounds__(128, 2) void big_ggr_kernel(const double* __restrict__ tri, const double2* __restrict__ keep,
                                                          const double2* __restrict__ Dm, BigVecArgs a) {
     __shared__ BigVecLds L;
-    static_assert(PB <= NM * 64, "the partial rows of D u reuse the room of the tridiagonal's eigenvectors");
     const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), n = a.n;
     const int n8 = (n + 7) & ~7;
     const int np = n * (n + 1) / 2, ncol = np - n;
@@ -482,12 +502,14 @@ __global__ __launch_bounds__(128, 2) void big_ggr_kernel(const double* __restric
                 const double v = (i < n) ? (double)((h >> 8) & 0xffffu) * (1.0 / 65536.0) + 0.25 : 0.0;
                 z[i] = ((h >> 30) & 1u) ? -v : v;
             }
-            tri_fsolve(L.sd, L.so, n8, lamp, z);
-            tri_fsolve(L.sd, L.so, n8, lamp, z);
-            tri_fsolve(L.sd, L.so, n8, lamp, z);
+            if (a.phases & 1) {
+                tri_fsolve(L.sd, L.so, n8, lamp, z);
+                tri_fsolve(L.sd, L.so, n8, lamp, z);
+                tri_fsolve(L.sd, L.so, n8, lamp, z);
+            }
             unit2v(n8, z);
 #pragma unroll
-            for (int i = 0; i < NM; ++i) L.zl[i * 64 + lane] = z[i];
+            for (int i = 0; i < NM; ++i) L.big[i * 64 + lane] = z[i];
             vwave_sync();
             // cluster members, lowest first: Gram-Schmidt against the members below (final by then), two more solves each
             for (int p = 1; __builtin_amdgcn_ballot_w64(pos >= p) != 0ull; ++p) {  // wave-uniform; not entered without a cluster
@@ -497,20 +519,20 @@ __global__ __launch_bounds__(128, 2) void big_ggr_kernel(const double* __restric
                         const int src = lane - t >= 0 ? lane - t : 0;
                         double dot = 0.0;
 #pragma unroll
-                        for (int i = 0; i < NM; ++i) dot = fma(L.zl[i * 64 + src], z[i], dot);
+                        for (int i = 0; i < NM; ++i) dot = fma(L.big[i * 64 + src], z[i], dot);
                         dot = (t <= pos) ? dot : 0.0;
 #pragma unroll
-                        for (int i = 0; i < NM; ++i) z[i] = fma(-dot, L.zl[i * 64 + src], z[i]);
+                        for (int i = 0; i < NM; ++i) z[i] = fma(-dot, L.big[i * 64 + src], z[i]);
                     }
                     unit2v(n8, z);
                     vwave_sync();
                     if (pos == p) {
 #pragma unroll
-                        for (int i = 0; i < NM; ++i) L.zl[i * 64 + lane] = z[i];
+                        for (int i = 0; i < NM; ++i) L.big[i * 64 + lane] = z[i];
                     }
                     vwave_sync();
 #pragma unroll
-                    for (int i = 0; i < NM; ++i) z[i] = L.zl[i * 64 + lane];  // (the others: their vector as it was)
+                    for (int i = 0; i < NM; ++i) z[i] = L.big[i * 64 + lane];  // (the others: their vector as it was)
                 }
             }
         }
@@ -536,6 +558,10 @@ int launch_big_vec(abz_ctx* ctx, const double* tri, int64_t tri_nk, const double
     a.dstride = dstride;
     a.n = n;
     a.d = d;
+    {
+        const char* ph = getenv("ABZ_BIG_VEC_PHASES");
+        a.phases = ph ? atoi(ph) : 7;
+    }
     a.E = E;
     a.V = V;
     const int64_t blocks = std::min<int64_t>(nnodes, 256 * 4 * 4);

@@ -1060,6 +1060,53 @@ def test_more_than_32_bands(abz, d, n, monkeypatch):
         assert sol.numevals == refi.numevals and abs(sol.u - refi.u) <= 1e-9 * abs(refi.u)
 
 
+@pytest.mark.parametrize("n", [33, 48, 64])
+def test_more_than_32_bands_matrix_valued_and_non_hermitian(abz, n):
+    """33...64 bands, what the tridiagonal cannot serve (big_inverse_kernel: one workgroup per node, Gauss-Jordan in LDS): the
+    matrix-valued Green's function of a Hermitian series and G, tr G, DOS of a series that is NOT Hermitian -- scans of a cached
+    rule (full grid and weighted node list) and IAI through the node path, against the oracle.
+    ref: src/fourier.jl:22-58 with the integrands of test/fourier.jl."""
+    L = abz._lib
+    rng = np.random.default_rng(4000 + n)
+    c, first = rand_series(rng, (3, 3), n, hermitian=True)
+    extra, _ = rand_series(rng, (3, 3), n, hermitian=False)
+    omegas = np.array([-0.7, 0.2, 1.1])
+    eta = 0.5
+    for herm in (True, False):
+        s, so = both(abz, (c + (0.0 if herm else 0.05) * extra) / np.sqrt(n), first)
+        npt = 7
+        refs = [orc._ptr_rule_sum(so, npt, None, orc.f_gloc(eta, om))[0] for om in omegas]
+        rule = s.device().rule(npt, None, want=1)
+        g = rule.reduce(L.F_GLOC, [eta], omegas)
+        tr = rule.reduce(L.F_TRGLOC, [eta], omegas)[:, 0]
+        dos = rule.reduce(L.F_DOS, [eta], omegas)[:, 0].real
+        for i in range(len(omegas)):
+            t = np.trace(refs[i])
+            assert np.abs(g[i].reshape(n, n).T - refs[i]).max() <= 1e-10 * np.abs(refs[i]).max(), herm
+            assert abs(tr[i] - t) <= 1e-10 * abs(t), herm
+            assert abs(dos[i] + t.imag / np.pi) <= 1e-10 * abs(t), herm
+        rule.close()
+        bzo = orc.load_bz("InversionSymIBZ", np.eye(2))
+        rs = s.device().rule(npt, bzo.syms, want=1)
+        gs = rs.reduce(L.F_GLOC, [eta], omegas[:1])
+        rsum, _ = orc._ptr_rule_sum(so, npt, bzo.syms, orc.f_gloc(eta, omegas[0]))
+        assert np.abs(gs[0].reshape(n, n).T - rsum).max() <= 1e-10 * np.abs(rsum).max(), herm
+        rs.close()
+    # IAI, one dimension: G(omega) of the Hermitian series (n^2 components), tr G of the other
+    c1, first1 = rand_series(rng, (5,), n, hermitian=True)
+    e1, _ = rand_series(rng, (5,), n, hermitian=False)
+    bz = abz.load_bz(abz.FBZ(), np.eye(1))
+    s1, so1 = both(abz, c1 / np.sqrt(n), first1)
+    sol = abz.do_solve(abz.FourierIntegrand(abz.GlocIntegrand(), s1, eta), bz, abz.MixedParameters(0.2), abz.EvalCounter(abz.IAI()), abstol=1e-3)
+    ref = orc.solve_iai(so1, orc.load_bz("FBZ", np.eye(1)), orc.f_gloc(eta, 0.2), abstol=1e-3)
+    assert sol.numevals == ref.numevals and np.abs(np.asarray(sol.u) - ref.u).max() <= 1e-9 * np.abs(ref.u).max()
+    s2, so2 = both(abz, (c1 + 0.05 * e1) / np.sqrt(n), first1)
+    sol = abz.do_solve(abz.FourierIntegrand(abz.TrGlocIntegrand(), s2, eta), bz, abz.MixedParameters(0.2), abz.EvalCounter(abz.IAI()), abstol=1e-3)
+    f_tr = lambda x, h: np.trace(orc.f_gloc(eta, 0.2)(x, h), axis1=-2, axis2=-1)
+    ref = orc.solve_iai(so2, orc.load_bz("FBZ", np.eye(1)), f_tr, abstol=1e-3)
+    assert sol.numevals == ref.numevals and abs(sol.u - ref.u) <= 1e-9 * abs(ref.u)
+
+
 def test_more_than_64_bands_is_an_argument_error(abz):
     rng = np.random.default_rng(65)
     c, first = rand_series(rng, (3,), 65, hermitian=True)
