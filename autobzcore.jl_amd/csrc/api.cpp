@@ -913,9 +913,14 @@ int abz_rule_destroy(abz_rule* r) try {
 static bool rule_ggr_rows(const abz_rule* r) {
     const abz_series* s = r->s;
     const RulePlan* rp = static_cast<const RulePlan*>(r->plan);
-    if (!(r->want & ABZ_WANT_VEL) || (r->want & ABZ_WANT_H) || !rp || !abz_switch(SW_GGR_FUSED)) return false;
+    if (!(r->want & ABZ_WANT_VEL) || !rp) return false;
+    if (big_supported(s->n)) {  // 33...64 bands: the only velocity build there is; H, when wanted as well, by the plain build after it
+        if (!r->full && !(s->d >= 2 && !rp->plan.coords)) return false;
+        return big_ggr_supported(s->n, s->d, s->dims[0], r->npt, s->hermitian);
+    }
+    if ((r->want & ABZ_WANT_H) || !abz_switch(SW_GGR_FUSED)) return false;
     if (!r->full && !(s->d >= 2 && rp->plan.nruns > 0 && !rp->plan.coords)) return false;
-    return ggr_rows_supported(s->n, s->d, s->dims[0], r->npt, s->hermitian) || big_ggr_supported(s->n, s->d, s->dims[0], r->npt, s->hermitian);
+    return ggr_rows_supported(s->n, s->d, s->dims[0], r->npt, s->hermitian);
 }
 
 // eigenvalues + velocities only, Hermitian series: one of the fused GGR builds applies (n <= 4: kernels_ggr.hip)
@@ -939,6 +944,7 @@ static int rule_fill(abz_rule* r) {
         set_error("the rule keeps H(k) as an upper triangle (ABZ_WANT_H_COMPACT) and the series is no longer Hermitian: build a new rule");
         return ABZ_ERR_ARG;
     }
+    bool vel_done = false;
     if (rule_ggr_rows(r)) {
         // 5...32 bands: H, every dH/dk_j, eigenvalues, eigenvectors and velocities of a node in the registers of its lanes
         GgrRowsSpec gs;
@@ -954,7 +960,7 @@ static int rule_fill(abz_rule* r) {
             gs.nlines = d == 1 ? 1 : plan.nitems[1];
         } else {
             gs.nlines = plan.nruns;
-            gs.run_start = rp->pd.runs.as<int64_t>();
+            gs.run_start = rp->pd.runs.as<int64_t>();  // (33...64 bands: only "a node list" is read from it)
             gs.gi = rp->pd.gi[0].as<int32_t>();
             gs.parents = rp->pd.parent[0].as<int64_t>();
             gs.nk = r->nk;
@@ -963,9 +969,11 @@ static int rule_fill(abz_rule* r) {
         if ((rc = build_chain(s, plan, rp->pd, tab, 0, &gs.src[0]))) return rc;
         for (int j = 2; j <= d; ++j)
             if ((rc = build_chain(s, plan, rp->pd, tab, j, &gs.src[j - 1], 1, &rp->fam[j - 2]))) return rc;
-        return big_supported(n) ? launch_big_ggr(ctx, gs) : launch_ggr_rows(ctx, gs);
+        if (!big_supported(n)) return launch_ggr_rows(ctx, gs);
+        if ((rc = launch_big_ggr(ctx, gs)) || !(r->want & ABZ_WANT_H)) return rc;
+        vel_done = true;  // the matrices as well: the plain build below, without its eigenvalues
     }
-    if (rule_ggr_fused(r)) {
+    if (!vel_done && rule_ggr_fused(r)) {
         // Fused GGR build (kernels_ggr.hip): H, every dH/dk_j, the eigensolve and the velocities in one kernel; only
         // (e, v) reach HBM.  ref: src/dos_ggr.jl:14-44
         GgrBuildSpec gs;
@@ -1009,7 +1017,7 @@ static int rule_fill(abz_rule* r) {
     }
     // temporaries of a velocity build: eigenvectors and one derivative matrix, tiled like H alone
     PlaneView Uv, Dv;
-    if (r->want & ABZ_WANT_VEL) {
+    if ((r->want & ABZ_WANT_VEL) && !vel_done) {
         Uv.base = rp->tmpU.as<double>();
         Uv.pitch = r->H.row ? r->H.row : r->E.row;  // temporaries are tiled whatever the rule's layout
         Uv.row = Uv.pitch;
@@ -1050,8 +1058,8 @@ static int rule_fill(abz_rule* r) {
     const double2* level1 = nullptr;
     int rc;
     if ((rc = build_chain(s, plan, rp->pd, tab, 0, &level1, 1, nullptr, packed_chain))) return rc;
-    if ((rc = run_eval(level1, false, r->H, r->E, Uv))) return rc;
-    if (r->want & ABZ_WANT_VEL) {
+    if ((rc = run_eval(level1, false, r->H, vel_done ? PlaneView() : r->E, Uv))) return rc;
+    if ((r->want & ABZ_WANT_VEL) && !vel_done) {
         // d/dx_1 reuses the level-1 sets; d/dx_j (j >= 2) rebuilds the chain with the derivative
         // factor on variable j (JacobianSeries, ref src/dos_ggr.jl:6-7)
         for (int j = 1; j <= d; ++j) {

@@ -1763,6 +1763,13 @@ def test_ggr_33_to_64_bands(abz, n):
     assert np.abs(out["eig"] - e).max() < 1e-11 * scale
     assert np.abs(out["vel"][ok] - v[ok]).max() < 1e-8 * vscale
     assert np.abs(out["vel"].sum(axis=2) - v.sum(axis=2)).max() < 1e-8 * vscale * n
+    if n in (33, 64):  # the matrices as well (a rule that serves G scans and GGR)
+        rule = abz.DeviceRule(s.device(), 6, None, 1 | 2 | 4)
+        o7 = rule.export(H=True, eig=True, vel=True)
+        rule.close()
+        href = np.transpose(orc.fourier_ptr(so, 6), (2, 1, 0, 3, 4)).reshape(-1, n, n)
+        assert np.abs(o7["H"] - href).max() <= 1e-12 * np.abs(href).max()
+        assert np.array_equal(o7["eig"], out["eig"]) and np.array_equal(o7["vel"], out["vel"])
     Es = np.linspace(-2.0, 2.0, 9)
     for kind, bzk in (("FBZ", abz.FBZ()), ("InversionSymIBZ", abz.InversionSymIBZ())):
         u = abz.dos.solve(abz.DOSProblem(s, Es, abz.load_bz(bzk, np.eye(3))), abz.GGR(npt=8)).u
