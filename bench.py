@@ -714,6 +714,7 @@ def flat_first(out):
         flat["ggr_bands16_seconds_24cubed"] = (gb.get("bands16_M7") or {}).get("seconds")
         flat["ggr_bands32_seconds_24cubed"] = (gb.get("bands32_M5") or {}).get("seconds")
         flat["bands48_rule_H_and_eig_seconds_24cubed"] = ((out.get("bands48_64_fixed_grids") or {}).get("bands48") or {}).get("rule_24cubed_H_and_eig_seconds")
+        flat["bands48_ggr_build_seconds_24cubed"] = ((out.get("bands48_64_fixed_grids") or {}).get("bands48") or {}).get("ggr_build_24cubed_seconds")
         ex = ((out.get("iai_example") or {}).get("FBZ") or {})
         flat["iai_example_fbz_seconds"] = ex.get("seconds")
         flat["iai_example_speedup_vs_cpu_port"] = (ex.get("cpu_baseline") or {}).get("gpu_over_cpu")
@@ -1273,7 +1274,7 @@ def extras(a, abz, L, s, ctx, out, nk):
         out["ggr_bands_5_to_32"] = {"error": repr(e)}
     # 33...64 bands (round 5, kernels_big.hip: wave-per-node Householder in LDS; ABZ_MAX_BANDS was 32)
     try:
-        b48 = {"what": "synthetic Hermitian models on the 24^3 full-BZ grid: rule build with H(k) + eigenvalues, a 16-omega store-free DOS sweep"}
+        b48 = {"what": "synthetic Hermitian models on the 24^3 full-BZ grid: rule build with H(k) + eigenvalues, a 16-omega store-free DOS sweep, GGR build (eigenvalues + band velocities)"}
         for nb in (48, 64):
             sg = abz.synthetic_wannier(n=nb, rmax=2, seed=7)
             dg = sg.device()
@@ -1289,8 +1290,17 @@ def extras(a, abz, L, s, ctx, out, nk):
             dg.ptr_sum(24, L.F_DOS, [0.05], om)
             t0 = time.perf_counter()
             dg.ptr_sum(24, L.F_DOS, [0.05], om)
+            dt_sum = time.perf_counter() - t0
+            rg = abz.DeviceRule(dg, 24, None, L.WANT_EIG | L.WANT_VEL)  # GGR build: eigenvalues + band velocities (kernels_big_vec.hip)
+            tg_ = []
+            for _ in range(4):
+                t0 = time.perf_counter()
+                rg.rebuild()
+                ctx.sync()
+                tg_.append(time.perf_counter() - t0)
+            rg.close()
             b48[f"bands{nb}"] = {"rule_24cubed_H_and_eig_seconds": min(ts_), "kpoints_per_sec": 24**3 / min(ts_),
-                                 "store_free_16_omega_seconds": time.perf_counter() - t0}
+                                 "store_free_16_omega_seconds": dt_sum, "ggr_build_24cubed_seconds": min(tg_)}
         b48["mfma_vs_fma"] = "profiles/r05_big_series_mfma_vs_fma.txt: the level-1 GEMM on v_mfma_f64_16x16x4_f64 is 0-25 % slower than the vector form"
         out["bands48_64_fixed_grids"] = b48
     except Exception as e:

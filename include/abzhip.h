@@ -44,7 +44,7 @@ extern "C" {
 #define ABZ_ERR_INTERNAL (-6) /* a C++ exception was caught at the boundary (none crosses it); text in abz_last_error() */
 
 #define ABZ_MAX_DIM 3        /* BZ dimension d = 1..3 (ref tests: test/fourier.jl:10,43) */
-#define ABZ_MAX_BANDS 64     /* n x n Hamiltonians up to n = 64 (33...64: values, eigenvalues, DOS / tr G; kernels_big.hip) */
+#define ABZ_MAX_BANDS 64     /* n x n Hamiltonians up to n = 64 (33...64: kernels_big.hip, kernels_big_vec.hip) */
 
 typedef struct abz_ctx abz_ctx;       /* device + stream + scratch + profiling */
 typedef struct abz_series abz_series; /* device-resident Fourier coefficients (FourierSeries / FourierWorkspace) */
