@@ -191,7 +191,7 @@ def fuzz_round5_kernels(abz, seed, emit=None):
     """The kernels of round 5 over random shapes: GGR builds of 5...32 bands (kernels_ggr_rows.hip: eigenvalues, band velocities on
     separated bands, their sums per node everywhere) in 1...3 dimensions on full grids and inversion-symmetric node lists;
     5...8 bands one node per lane (kernels_lane.hip: values in either layout, eigenvalues, store-free sums, scans); 33...64 bands
-    (kernels_big.hip: values, eigenvalues, tr G sums).  Returns (worst error, failing cases)."""
+    (kernels_big.hip: values, eigenvalues, tr G sums, the matrix-valued G; GGR builds there through kernels_big_vec.hip).  Returns (worst error, failing cases)."""
     L = abz._lib
     rng = np.random.default_rng(seed)
     worst, bad = 0.0, []
@@ -207,9 +207,9 @@ def fuzz_round5_kernels(abz, seed, emit=None):
     # --- GGR builds
     for _ in range(14):
         d = int(rng.integers(1, 4))
-        n = int(rng.choice([5, 6, 7, 8, 9, 11, 13, 16, 17, 19, 23, 28, 32]))
+        n = int(rng.choice([5, 6, 7, 8, 9, 11, 13, 16, 17, 19, 23, 28, 32, 33, 41, 47, 56, 63]))  # (> 32: kernels_big_vec.hip)
         dims = tuple(int(rng.choice([1, 3, 5, 7] if n <= 16 else [1, 3, 5])) for _ in range(d))
-        npt = int(rng.integers(1, 12 if d == 3 else (20 if d == 2 else 70)))
+        npt = int(rng.integers(1, (12 if n <= 32 else 7) if d == 3 else (20 if d == 2 else 70)))
         c, first = _herm_series(rng, dims, n, scale=1.0 / np.sqrt(n))
         per = tuple(float(rng.choice([1.0, 2.0, 0.5])) for _ in range(d))
         s = abz.FourierSeries(c, period=per, first=first, ndim=d)
@@ -273,7 +273,10 @@ def fuzz_round5_kernels(abz, seed, emit=None):
         tref = (1.0 / (z[:, :, None] - np.linalg.eigvalsh(ref)[:, None, :])).sum(axis=2).mean(axis=0)
         sc = rule.reduce(L.F_TRGLOC, [0.3], om)[:, 0]
         sf = s.device().ptr_sum(npt, L.F_TRGLOC, [0.3], om)[:, 0]
+        g = rule.reduce(L.F_GLOC, [0.3], om[:1])[0].reshape(n, n).T  # the full inverse (big_inverse_kernel)
+        gref = np.linalg.inv((om[0] + 0.3j) * np.eye(n)[None] - ref).mean(axis=0)
         rule.close()
+        note(tag + ("gloc",), np.abs(g - gref).max() / np.abs(gref).max(), 1e-10)
         note(tag + ("scan",), np.abs(sc - tref).max() / np.abs(tref).max(), 1e-10)
         note(tag + ("sum",), np.abs(sf - tref).max() / np.abs(tref).max(), 1e-10)
     return worst, bad
