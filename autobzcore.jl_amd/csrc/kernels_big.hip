@@ -354,6 +354,128 @@ __global__ __launch_bounds__(64) void big_tridiag_kernel(const double2* __restri
     }
 }
 
+// The same with NW waves per node (a workgroup of 64 NW threads; lane i of every wave stands for row i): the sums over j of a step
+// -- p = A v and the rank-2 update of a row -- are dealt to the waves by j mod NW, the partial p meet in LDS.  Four block barriers
+// per step instead of three wave barriers, but NW times the waves in flight per matrix held in LDS: one wave per node leaves a CU
+// with four waves at 64 bands (33 KB per matrix), all of them waiting on their own LDS round trips.
+template <int NW>
+__global__ __launch_bounds__(64 * NW) void big_tridiag_mw_kernel(const double2* __restrict__ Hbuf, int64_t nnodes, int n, double* __restrict__ tri,
+                                                                 int64_t tri_nk, int64_t t0, double2* __restrict__ keep) {
+    extern __shared__ double2 lds_bt[];  // L [n (n + 1) / 2], then v [n], q [n], partial p [NW][64]
+    const int np = n * (n + 1) / 2;
+    double2* __restrict__ const A = lds_bt;
+    double2* __restrict__ const vv = lds_bt + np;
+    double2* __restrict__ const qq = vv + n;
+    double2* __restrict__ const part = qq + n;
+    const int tid = threadIdx.x, lane = tid & 63, i = lane, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool row = i < n;
+    const int ri = i * (i + 1) / 2;  // start of this lane's row
+    for (int64_t node = blockIdx.x; node < nnodes; node += gridDim.x) {
+        const double2* __restrict__ h = Hbuf + node * ((int64_t)n * n);
+        __syncthreads();
+        for (int e = tid; e < np; e += 64 * NW) {
+            int r = (int)((sqrtf(8.0f * (float)e + 1.0f) - 1.0f) * 0.5f);
+            while ((r + 1) * (r + 2) / 2 <= e) ++r;
+            while (r * (r + 1) / 2 > e) --r;
+            const int c = e - r * (r + 1) / 2;
+            double2 v = h[c + n * r];  // H(c, r), c <= r: the upper triangle; L(r, c) = conj
+            v.y = r == c ? 0.0 : -v.y;
+            A[e] = v;
+        }
+        __syncthreads();
+        for (int k = 0; k + 1 < n; ++k) {
+            const bool below = row && i > k;
+            const double2 x = below ? A[ri + k] : make_double2(0.0, 0.0);  // (every wave: the same values)
+            const double sigma = bwsum(x.x * x.x + x.y * x.y);
+            if (w == 0 && lane == k) {
+                tri[(int64_t)k * tri_nk + t0 + node] = A[ri + k].x;
+                tri[(int64_t)(BIG_NP + k) * tri_nk + t0 + node] = sigma;
+            }
+            if (k + 2 >= n || !(sigma > 0.0)) {  // uniform in the workgroup
+                if (keep && tid == 0) keep[node * (int64_t)np + (np - n) + k] = make_double2(0.0, 0.0);
+                continue;
+            }
+            const double x1r = __shfl(x.x, k + 1, 64), x1i = __shfl(x.y, k + 1, 64);
+            const double a1sq = x1r * x1r + x1i * x1i;
+            const double nrm = sqrt(sigma), a1 = sqrt(a1sq);
+            double v1r, v1i;
+            if (a1 > 0.0) {
+                const double fac = 1.0 + nrm / a1;
+                v1r = x1r * fac;
+                v1i = x1i * fac;
+            } else {
+                v1r = nrm;
+                v1i = 0.0;
+            }
+            const double beta = 1.0 / (sigma + nrm * a1);
+            const double2 v = (i == k + 1) ? make_double2(v1r, v1i) : x;  // zero in rows <= k and >= n
+            if (w == 0 && row) vv[i] = v;
+            __syncthreads();
+            double pr = 0.0, pi = 0.0;
+            if (below) {
+#pragma unroll 2
+                for (int j = k + 1 + w; j < n; j += NW) {
+                    const bool own = j <= i;
+                    double2 aij = A[own ? ri + j : j * (j + 1) / 2 + i];
+                    aij.y = own ? aij.y : -aij.y;
+                    const double2 vj = vv[j];
+                    pr = fma(aij.x, vj.x, pr);
+                    pr = fma(-aij.y, vj.y, pr);
+                    pi = fma(aij.x, vj.y, pi);
+                    pi = fma(aij.y, vj.x, pi);
+                }
+            }
+            part[w * 64 + lane] = make_double2(pr, pi);
+            __syncthreads();
+            pr = 0.0;
+            pi = 0.0;
+#pragma unroll
+            for (int u = 0; u < NW; ++u) {  // (the same order in every wave: the same q everywhere)
+                pr += part[u * 64 + lane].x;
+                pi += part[u * 64 + lane].y;
+            }
+            pr *= beta;
+            pi *= beta;
+            const double kr = 0.5 * beta * bwsum(v.x * pr + v.y * pi);
+            const double ki = 0.5 * beta * bwsum(v.x * pi - v.y * pr);
+            const double qr = pr - (kr * v.x - ki * v.y), qi = pi - (kr * v.y + ki * v.x);
+            if (w == 0 && row) qq[i] = make_double2(qr, qi);
+            if (keep && w == 0 && i == k + 1) {
+                A[ri + k] = make_double2(v1r, v1i);
+                keep[node * (int64_t)np + (np - n) + k] = make_double2(beta, 0.0);
+            }
+            __syncthreads();
+            if (below) {
+#pragma unroll 2
+                for (int j = k + 1 + w; j <= i; j += NW) {
+                    const double2 vj = vv[j], qj = qq[j];
+                    double2 aij = A[ri + j];
+                    aij.x -= (v.x * qj.x + v.y * qj.y) + (qr * vj.x + qi * vj.y);
+                    aij.y -= (v.y * qj.x - v.x * qj.y) + (qi * vj.x - qr * vj.y);
+                    A[ri + j] = aij;
+                }
+            }
+            __syncthreads();
+        }
+        if (w == 0 && lane == n - 1) {
+            tri[(int64_t)(n - 1) * tri_nk + t0 + node] = A[ri + (n - 1)].x;
+            tri[(int64_t)(BIG_NP + n - 1) * tri_nk + t0 + node] = 0.0;
+            if (keep) keep[node * (int64_t)np + (np - n) + (n - 1)] = make_double2(0.0, 0.0);
+        }
+        if (keep) {
+            __syncthreads();
+            double2* __restrict__ ko = keep + node * (int64_t)np;
+            for (int e = tid; e < np; e += 64 * NW) {
+                int r = (int)((sqrtf(8.0f * (float)e + 1.0f) - 1.0f) * 0.5f);
+                while ((r + 1) * (r + 2) / 2 <= e) ++r;
+                while (r * (r + 1) / 2 > e) --r;
+                const int c = e - r * (r + 1) / 2;
+                if (c < r) ko[c * n - c * (c + 1) / 2 + (r - c - 1)] = A[e];
+            }
+        }
+    }
+}
+
 // eigenvalue `band` (ascending) of each tridiagonal: bisection on the Sturm count (ratio form with LAPACK's pivot guard),
 // 4 nodes x 64 bands per workgroup
 __global__ __launch_bounds__(256) void big_bisect_kernel(const double* __restrict__ tri, int64_t tri_nk, int64_t t0, int64_t node0, int64_t nnodes,
@@ -675,10 +797,22 @@ int big_reserve(abz_ctx* ctx, int n, int npt_or_zero, int64_t nnodes, BigWork& w
 }
 
 int big_tridiag(abz_ctx* ctx, const BigWork& w, int n, int64_t cn, double2* keep = nullptr) {
-    const size_t lds = sizeof(double2) * ((size_t)n * (n + 1) / 2 + 2 * (size_t)n);
-    ABZ_HIP(hipFuncSetAttribute((const void*)big_tridiag_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    // one wave per node while the CU holds six matrices or more (<= 56 bands); four above (24^3 nodes, H + eig: 64 bands 11.0 ms
+    // with one wave, 8.4 with two, 7.8 with four; 48 bands 3.86 / 4.04 / 4.14; 33 bands 1.64 / 1.57 / 1.98)
+    const int sw = abz_switch(SW_BIG_TRI_WAVES);
+    const int nw = sw > 0 ? sw : (n > 56 ? 4 : 1);
+    const size_t lds = sizeof(double2) * ((size_t)n * (n + 1) / 2 + 2 * (size_t)n + (nw > 1 ? 64 * (size_t)nw : 0));
     const int64_t blocks = std::min<int64_t>(cn, 256 * 8);
-    hipLaunchKernelGGL(big_tridiag_kernel, dim3((unsigned)blocks), dim3(64), lds, ctx->stream, w.Hbuf, cn, n, w.tri, w.tri_nk, (int64_t)0, keep);
+    if (nw >= 4) {
+        ABZ_HIP(hipFuncSetAttribute((const void*)big_tridiag_mw_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(big_tridiag_mw_kernel<4>, dim3((unsigned)blocks), dim3(256), lds, ctx->stream, w.Hbuf, cn, n, w.tri, w.tri_nk, (int64_t)0, keep);
+    } else if (nw >= 2) {
+        ABZ_HIP(hipFuncSetAttribute((const void*)big_tridiag_mw_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(big_tridiag_mw_kernel<2>, dim3((unsigned)blocks), dim3(128), lds, ctx->stream, w.Hbuf, cn, n, w.tri, w.tri_nk, (int64_t)0, keep);
+    } else {
+        ABZ_HIP(hipFuncSetAttribute((const void*)big_tridiag_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(big_tridiag_kernel, dim3((unsigned)blocks), dim3(64), lds, ctx->stream, w.Hbuf, cn, n, w.tri, w.tri_nk, (int64_t)0, keep);
+    }
     ABZ_HIP(hipGetLastError());
     return ABZ_OK;
 }
