@@ -24,6 +24,7 @@
  */
 #include <complex.h>
 #include <math.h>
+#include <time.h>
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
@@ -433,6 +434,18 @@ static void heap_up(seg_t* xs, int i, seg_t x) {
 
 typedef void (*batch_fn)(void* ctx, const double* xs, int n, double* out);
 
+/* A wall-clock budget for bench.py's bounded CPU samples (not part of the algorithm: with a deadline set, every level stops
+ * refining once it has passed; the evaluations made until then are counted as usual, so nodes / second stays meaningful and
+ * the value does not).  0: none. */
+static double orc_deadline = 0.0;
+static double orc_now(void) {
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
+void orc_set_deadline(double seconds_from_now) { orc_deadline = seconds_from_now > 0.0 ? orc_now() + seconds_from_now : 0.0; }
+int orc_deadline_passed(void) { return orc_deadline > 0.0 && orc_now() > orc_deadline; }
+
 /* auxquadgk on [a, b], scalar refinement; returns I, *Eout the error estimate */
 static double adapt_gk(batch_fn f, void* ctx, double a, double b, double atol, double rtol, int64_t maxevals, double* Eout) {
     int cap = 64, len = 1;
@@ -446,7 +459,7 @@ static double adapt_gk(batch_fn f, void* ctx, double a, double b, double atol, d
     double Iv = xs[0].v, E = xs[0].E;
     int64_t numevals = 15;
     if (!(E <= fmax(atol, rtol * fabs(Iv)) || numevals >= maxevals)) {
-        while (E > fmax(atol, rtol * fabs(Iv)) && numevals < maxevals) {
+        while (E > fmax(atol, rtol * fabs(Iv)) && numevals < maxevals && !orc_deadline_passed()) {
             const seg_t s = xs[0];
             const seg_t y = xs[--len];
             if (len > 0) heap_down(xs, 0, y, len);
