@@ -65,6 +65,7 @@ enum Switch {
     SW_AUTO_SWEEP_MAPPED,  // ABZ_AUTO_SWEEP_MAPPED  AutoPTR solves of <= 8 values: swept values read from pinned host memory
     SW_LANE_KERNELS,     // ABZ_LANE_KERNELS    5...8 bands on full grids: one node per lane (kernels_lane.hip) instead of the 8-lane row kernels
     SW_BIG_MFMA,         // ABZ_BIG_MFMA        33...64 bands: level-1 evaluation of grid lines as a real GEMM on v_mfma_f64_16x16x4_f64
+    SW_BIG_CHUNK_MB,     // ABZ_BIG_CHUNK_MB    33...64 bands: scratch for the matrices of a chunk of nodes (0: 256 MB, GGR builds 2 GB)
     SW_BIG_TRI_WAVES,    // ABZ_BIG_TRI_WAVES   33...64 bands: waves per node of the Householder tridiagonalisation (1, 2 or 4)
     SW_EIG_FOLD,         // ABZ_EIG_FOLD        5...16-band rule builds of Hermitian series: folded level-1 series
     SW_EIG_SPLIT,        // ABZ_EIG_SPLIT       5...16-band eigenvalue builds: tridiagonal eigenvalues in a kernel of their own

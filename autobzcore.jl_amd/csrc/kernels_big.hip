@@ -783,7 +783,8 @@ struct BigWork {
 
 int big_reserve(abz_ctx* ctx, int n, int npt_or_zero, int64_t nnodes, BigWork& w) {
     // chunks of nodes: <= 256 MB of matrices, whole grid lines in grid mode
-    int64_t c = std::max<int64_t>(1, (int64_t)(256ull << 20) / ((int64_t)sizeof(double2) * n * n));
+    const int64_t mb = abz_switch(SW_BIG_CHUNK_MB) > 0 ? abz_switch(SW_BIG_CHUNK_MB) : 256;
+    int64_t c = std::max<int64_t>(1, (mb << 20) / ((int64_t)sizeof(double2) * n * n));
     if (npt_or_zero > 0) c = std::max<int64_t>(1, c / npt_or_zero) * npt_or_zero;
     c = std::min(c, nnodes);
     w.chunk = c;
@@ -863,7 +864,8 @@ int launch_big_ggr(abz_ctx* ctx, const GgrRowsSpec& gs) {
     const int n = gs.n, nn = n * n, np = n * (n + 1) / 2;
     // chunks of nodes: <= 2 GB of matrices (H and d derivatives) and kept reflectors, whole grid lines in grid mode (a chunk wants
     // several thousand nodes: the kernels run one wave or one small workgroup per node)
-    int64_t c = std::max<int64_t>(1, (int64_t)(2048ull << 20) / ((int64_t)sizeof(double2) * ((int64_t)nn * gs.d + np)));
+    const int64_t mb = abz_switch(SW_BIG_CHUNK_MB) > 0 ? abz_switch(SW_BIG_CHUNK_MB) : 2048;
+    int64_t c = std::max<int64_t>(1, (mb << 20) / ((int64_t)sizeof(double2) * ((int64_t)nn * gs.d + np)));
     if (grid) c = std::max<int64_t>(1, c / gs.npt) * gs.npt;
     c = std::min(c, nnodes);
     BigWork w;

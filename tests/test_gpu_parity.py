@@ -1791,6 +1791,39 @@ def test_ggr_33_to_64_bands(abz, n):
         assert np.abs(o2["vel"][sep] - v2[sep]).max() < 1e-8 * np.abs(v2).max()
 
 
+def test_33_to_64_bands_in_many_chunks(abz, monkeypatch):
+    """33...64 bands work through their nodes in chunks that fit a scratch budget (ABZ_BIG_CHUNK_MB: 256 MB, 2 GB for GGR builds --
+    more than any other test's grid needs): with 1 MB -- a few grid lines per chunk, and for the node list chunks that end inside
+    a run -- every node's values must be those of a single chunk, bit for bit, and the sums equal to rounding (tridiagonalisation
+    with one and with four waves)."""
+    L = abz._lib
+    so = orc.synthetic_wannier(n=40, rmax=1, seed=11)
+    s = abz.FourierSeries(so.c, period=1.0, first=so.first, ndim=3)
+    syms = orc.load_bz("InversionSymIBZ", np.eye(3)).syms
+    om = np.array([-0.5, 0.4])
+
+    def everything():
+        res = []
+        for sy in (None, syms):
+            r = abz.DeviceRule(s.device(), 7, sy, 1 | 2 | 4)
+            o = r.export(H=True, eig=True, vel=True)
+            res += [o["H"], o["eig"], o["vel"], r.reduce(L.F_GLOC, [0.3], om), r.reduce(L.F_TRGLOC, [0.3], om)]
+            r.close()
+        res.append(s.device().ptr_sum(7, L.F_DOS, [0.3], om))
+        return res
+
+    for waves in ("1", "4"):
+        monkeypatch.setenv("ABZ_BIG_TRI_WAVES", waves)
+        monkeypatch.delenv("ABZ_BIG_CHUNK_MB", raising=False)
+        whole = everything()
+        monkeypatch.setenv("ABZ_BIG_CHUNK_MB", "1")
+        parts = everything()
+        for a, b in zip(whole, parts):  # values per node: the same bits; sums: another order of the partial sums
+            assert np.array_equal(a, b) if a.shape[0] > 2 else np.abs(a - b).max() <= 1e-13 * np.abs(a).max(), waves
+    w, e, v = orc.get_ggr_data(so, 7, None)
+    assert np.abs(whole[1] - e).max() < 1e-11 * np.abs(e).max()
+
+
 @pytest.mark.parametrize("n3,mult", [(11, 3), (5, 8), (8, 8), (32, 2)])
 def test_ggr_33_to_64_bands_degenerate(abz, n3, mult):
     """Exactly degenerate levels everywhere at 33...64 bands (H = Q (I_mult x h(k)) Q^H): the cluster rounds of kernels_big_vec.hip
