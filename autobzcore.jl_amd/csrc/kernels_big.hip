@@ -40,6 +40,11 @@ __device__ __forceinline__ double bwsum(double v) {
     for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
     return v;
 }
+__device__ __forceinline__ double brl(double v, int lane) {  // lane: uniform
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+    return __hiloint2double(hi, lo);
+}
 __device__ __forceinline__ void bwave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -664,85 +669,102 @@ struct BigInvArgs {
     double2* partial;     // sum mode, ACCUMULATED over chunks (zeroed by the caller)
     int nodes_per_block;  // sum mode
 };
+// One block of four pivots c = 4 CQ ... 4 CQ + 3 of the register-resident Gauss-Jordan (big_inverse_kernel).  Column c -- the
+// f = A(r, c) of every row -- lives in wave c & 3 and reaches the other waves through LDS (two rooms in turn, one barrier per
+// pivot); row c -- A(c, j) of this wave's sixteen columns -- lives in lane c of THIS wave: v_readlane, scalar operands of the FMAs.
+template <int CQ>
+__device__ __forceinline__ void big_inv_pivot4(int n, int r, int jq, double2 (*colb)[64], double2 (&W)[16]) {
+#pragma unroll 1
+    for (int cm = 0; cm < 4; ++cm) {
+        const int c = 4 * CQ + cm;
+        if (c >= n) break;  // uniform
+        const int pb = c & 1;
+        if (jq == cm) colb[pb][r] = W[CQ];
+        __syncthreads();
+        const double2 p = colb[pb][c], f = colb[pb][r];
+        const double ipn = 1.0 / (p.x * p.x + p.y * p.y);
+        const double ipr = p.x * ipn, ipi = -p.y * ipn;  // 1 / pivot
+        const bool prow = r == c;
+        const double qr = f.x * ipr - f.y * ipi, qi = f.x * ipi + f.y * ipr;  // f / pivot
+        // one straight line for every entry: A(r, j) - (f / p) A(c, j); in the pivot row itself 0 + (1 / p) A(c, j)
+        const double fr = prow ? -ipr : qr, fi = prow ? -ipi : qi;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const double gx = brl(W[q].x, c), gy = brl(W[q].y, c);  // A(c, jq + 4 q) before the step
+            const double ox = prow ? 0.0 : W[q].x, oy = prow ? 0.0 : W[q].y;
+            W[q] = make_double2(ox - (fr * gx - fi * gy), oy - (fr * gy + fi * gx));
+        }
+        if (jq == cm) W[CQ] = prow ? make_double2(ipr, ipi) : make_double2(-qr, -qi);  // the pivot column: -f / p, the pivot 1 / p
+    }
+}
+template <int... CQ>
+__device__ __forceinline__ void big_inv_pivots(int n, int r, int jq, double2 (*colb)[64], double2 (&W)[16], std::integer_sequence<int, CQ...>) {
+    ((void)((4 * CQ < n) ? (big_inv_pivot4<CQ>(n, r, jq, colb, W), 0) : 0), ...);
+}
+
 __global__ __launch_bounds__(256) void big_inverse_kernel(BigInvArgs a) {
-    extern __shared__ double2 lds_bi[];  // W [n n] | column [n] | row [n]
+    // The matrix lives in REGISTERS: lane r of wave jq holds the entries (r, jq + 4 q), q = 0 ... 15 (big_inv_pivot4 above).
+    __shared__ double2 colb[2][64];
+    __shared__ double2 trb[4];
     const int n = a.n, nn = n * n, tid = threadIdx.x;
-    double2* __restrict__ const W = lds_bi;
-    double2* __restrict__ const colb = W + nn;
-    double2* __restrict__ const rowb = colb + n;
+    const int r = tid & 63, jq = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool rowon = r < n;
     const int ncomp = a.kind == 0 ? nn : 1;
     const bool sum = a.partial != nullptr;
     const int64_t k0 = sum ? (int64_t)blockIdx.x * a.nodes_per_block : blockIdx.x;
     const int64_t k1 = sum ? min(a.nnodes, k0 + a.nodes_per_block) : a.nnodes;
     const int64_t kstep = sum ? 1 : gridDim.x;
     for (int s = 0; s < a.n_sweep; ++s) {
-        double2 acc[16];  // sum mode: entries tid + 256 q of the matrix (n <= 64), or the trace in acc[0] of thread 0
+        double2 acc[16];  // sum mode: the weighted sum of this thread's entries, or the trace in acc[0] of thread 0
 #pragma unroll
         for (int q = 0; q < 16; ++q) acc[q] = make_double2(0.0, 0.0);
         for (int64_t k = k0; k < k1; k += kstep) {
             const double sw = a.sweep_per_node ? a.sweep_per_node[a.node0 + k] : (a.sweep ? a.sweep[s] : a.sweep0);
             const double2* __restrict__ h = a.Hbuf + k * (int64_t)nn;
-            __syncthreads();
-            for (int t = tid; t < nn; t += 256) {
-                const int r = t % n, c = t / n;
-                const double2 hv = h[t];
-                W[t] = make_double2((r == c ? sw : 0.0) - hv.x, (r == c ? a.eta : 0.0) - hv.y);
-            }
-            __syncthreads();
-            for (int c = 0; c < n; ++c) {
-                const double2 p = W[c + n * c];
-                const double ipn = 1.0 / (p.x * p.x + p.y * p.y);
-                const double ipr = p.x * ipn, ipi = -p.y * ipn;  // 1 / pivot
-                if (tid < n) {
-                    colb[tid] = W[tid + n * c];
-                    const double2 rv = W[c + n * tid];
-                    rowb[tid] = make_double2(rv.x * ipr - rv.y * ipi, rv.x * ipi + rv.y * ipr);
+            double2 W[16];
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const int j = jq + 4 * q;
+                W[q] = make_double2(0.0, 0.0);
+                if (rowon && j < n) {
+                    const double2 hv = h[r + n * j];
+                    W[q] = make_double2((r == j ? sw : 0.0) - hv.x, (r == j ? a.eta : 0.0) - hv.y);
                 }
-                __syncthreads();
-                for (int t = tid; t < nn; t += 256) {
-                    const int r = t % n, j = t / n;
-                    double2 v;
-                    if (r == c && j == c) {
-                        v = make_double2(ipr, ipi);
-                    } else if (r == c) {
-                        v = rowb[j];
-                    } else if (j == c) {
-                        const double2 f = colb[r];
-                        v = make_double2(-(f.x * ipr - f.y * ipi), -(f.x * ipi + f.y * ipr));
-                    } else {
-                        const double2 f = colb[r], g = rowb[j], o = W[t];
-                        v = make_double2(o.x - (f.x * g.x - f.y * g.y), o.y - (f.x * g.y + f.y * g.x));
-                    }
-                    W[t] = v;
-                }
-                __syncthreads();
             }
+            // pivots c = 4 cq + cm: cq unrolled (the entry of column c in its wave's registers is W[cq], a static index), cm rolled
+            big_inv_pivots(n, r, jq, colb, W, std::make_integer_sequence<int, 16>());
             const double wk = sum ? (a.w ? a.w[a.node0 + k] : 1.0) : 1.0;
             if (a.kind == 0) {
                 if (sum) {
 #pragma unroll
                     for (int q = 0; q < 16; ++q) {
-                        const int t = tid + 256 * q;
-                        if (t < nn) {
-                            acc[q].x = fma(wk, W[t].x, acc[q].x);
-                            acc[q].y = fma(wk, W[t].y, acc[q].y);
-                        }
+                        acc[q].x = fma(wk, W[q].x, acc[q].x);
+                        acc[q].y = fma(wk, W[q].y, acc[q].y);
                     }
-                } else {
+                } else if (rowon) {
                     double2* __restrict__ vo = a.values + ((a.node0 + k) * a.n_sweep + s) * (int64_t)nn;
-                    for (int t = tid; t < nn; t += 256) vo[t] = W[t];
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) {
+                        const int j = jq + 4 * q;
+                        if (j < n) vo[r + n * j] = W[q];
+                    }
                 }
             } else {
+                // the diagonal entry (r, r) sits in wave r & 3 at q = r >> 2: partial traces per wave, met in LDS
                 double tr = 0.0, ti = 0.0;
-                if (tid < n) {
-                    tr = W[tid + n * tid].x;
-                    ti = W[tid + n * tid].y;
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {
+                    const bool d = rowon && (jq + 4 * q) == r;
+                    tr += d ? W[q].x : 0.0;
+                    ti += d ? W[q].y : 0.0;
                 }
-                if (tid < 64) {  // (n <= 64: the diagonal sits in the first wave)
-                    tr = bwsum(tr);
-                    ti = bwsum(ti);
-                }
+                tr = bwsum(tr);
+                ti = bwsum(ti);
+                if (r == 0) trb[jq] = make_double2(tr, ti);
+                __syncthreads();
                 if (tid == 0) {
+                    tr = (trb[0].x + trb[1].x) + (trb[2].x + trb[3].x);
+                    ti = (trb[0].y + trb[1].y) + (trb[2].y + trb[3].y);
                     if (a.kind == 2) {
                         tr = -ti * 0.31830988618379067153776752674503;
                         ti = 0.0;
@@ -754,6 +776,7 @@ __global__ __launch_bounds__(256) void big_inverse_kernel(BigInvArgs a) {
                         a.values[(a.node0 + k) * a.n_sweep + s] = make_double2(tr, ti);
                     }
                 }
+                __syncthreads();
             }
         }
         if (sum) {
@@ -761,10 +784,10 @@ __global__ __launch_bounds__(256) void big_inverse_kernel(BigInvArgs a) {
             if (a.kind == 0) {
 #pragma unroll
                 for (int q = 0; q < 16; ++q) {
-                    const int t = tid + 256 * q;
-                    if (t < nn) {
-                        po[t].x += acc[q].x;
-                        po[t].y += acc[q].y;
+                    const int j = jq + 4 * q;
+                    if (rowon && j < n) {
+                        po[r + n * j].x += acc[q].x;
+                        po[r + n * j].y += acc[q].y;
                     }
                 }
             } else if (tid == 0) {
@@ -819,9 +842,7 @@ int big_tridiag(abz_ctx* ctx, const BigWork& w, int n, int64_t cn, double2* keep
 }
 
 static int big_inverse(abz_ctx* ctx, BigInvArgs& ia, int64_t blocks) {
-    const size_t lds = sizeof(double2) * ((size_t)ia.n * ia.n + 2 * (size_t)ia.n);
-    ABZ_HIP(hipFuncSetAttribute((const void*)big_inverse_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(big_inverse_kernel, dim3((unsigned)blocks), dim3(256), lds, ctx->stream, ia);
+    hipLaunchKernelGGL(big_inverse_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, ia);
     ABZ_HIP(hipGetLastError());
     return ABZ_OK;
 }

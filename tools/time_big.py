@@ -26,6 +26,12 @@ for n, rmax in ((32, 2), (33, 2), (48, 2), (64, 2), (48, 6)):
     om = np.linspace(-1, 1, 16)
     dev.ptr_sum(npt, L.F_DOS, [0.05], om)
     t0 = time.perf_counter(); dev.ptr_sum(npt, L.F_DOS, [0.05], om); row.append(f"sum[16w] {1e3*(time.perf_counter()-t0):8.3f} ms")
+    if n > 32 and rmax == 2:  # the matrix-valued Green's function of a cached rule (big_inverse_kernel): 4 omega
+        r = abz.DeviceRule(dev, npt, None, L.WANT_H); ctx.sync()
+        om4 = np.linspace(-1, 1, 4)
+        r.reduce(L.F_GLOC, [0.05], om4)
+        t0 = time.perf_counter(); r.reduce(L.F_GLOC, [0.05], om4); row.append(f"G scan[4w] {1e3*(time.perf_counter()-t0):8.3f} ms")
+        r.close()
     if rmax == 2:
         f = abz.FourierIntegrand(abz.DOSIntegrand(), s, 0.1)
         prob = abz.IntegralProblem(f, abz.load_bz(abz.FBZ(), np.eye(3)), abz.MixedParameters(0.2))
