@@ -672,8 +672,8 @@ struct BigInvArgs {
 // One block of four pivots c = 4 CQ ... 4 CQ + 3 of the register-resident Gauss-Jordan (big_inverse_kernel).  Column c -- the
 // f = A(r, c) of every row -- lives in wave c & 3 and reaches the other waves through LDS (two rooms in turn, one barrier per
 // pivot); row c -- A(c, j) of this wave's sixteen columns -- lives in lane c of THIS wave: v_readlane, scalar operands of the FMAs.
-template <int CQ>
-__device__ __forceinline__ void big_inv_pivot4(int n, int r, int jq, double2 (*colb)[64], double2 (&W)[16]) {
+template <int NQ, int CQ>
+__device__ __forceinline__ void big_inv_pivot4(int n, int r, int jq, double2 (*colb)[64], double2 (&W)[NQ]) {
 #pragma unroll 1
     for (int cm = 0; cm < 4; ++cm) {
         const int c = 4 * CQ + cm;
@@ -689,7 +689,7 @@ __device__ __forceinline__ void big_inv_pivot4(int n, int r, int jq, double2 (*c
         // one straight line for every entry: A(r, j) - (f / p) A(c, j); in the pivot row itself 0 + (1 / p) A(c, j)
         const double fr = prow ? -ipr : qr, fi = prow ? -ipi : qi;
 #pragma unroll
-        for (int q = 0; q < 16; ++q) {
+        for (int q = 0; q < NQ; ++q) {
             const double gx = brl(W[q].x, c), gy = brl(W[q].y, c);  // A(c, jq + 4 q) before the step
             const double ox = prow ? 0.0 : W[q].x, oy = prow ? 0.0 : W[q].y;
             W[q] = make_double2(ox - (fr * gx - fi * gy), oy - (fr * gy + fi * gx));
@@ -697,11 +697,13 @@ __device__ __forceinline__ void big_inv_pivot4(int n, int r, int jq, double2 (*c
         if (jq == cm) W[CQ] = prow ? make_double2(ipr, ipi) : make_double2(-qr, -qi);  // the pivot column: -f / p, the pivot 1 / p
     }
 }
-template <int... CQ>
-__device__ __forceinline__ void big_inv_pivots(int n, int r, int jq, double2 (*colb)[64], double2 (&W)[16], std::integer_sequence<int, CQ...>) {
-    ((void)((4 * CQ < n) ? (big_inv_pivot4<CQ>(n, r, jq, colb, W), 0) : 0), ...);
+template <int NQ, int... CQ>
+__device__ __forceinline__ void big_inv_pivots(int n, int r, int jq, double2 (*colb)[64], double2 (&W)[NQ], std::integer_sequence<int, CQ...>) {
+    ((void)((4 * CQ < n) ? (big_inv_pivot4<NQ, CQ>(n, r, jq, colb, W), 0) : 0), ...);
 }
 
+// NQ: column groups of four the instance holds (n <= 4 NQ)
+template <int NQ>
 __global__ __launch_bounds__(256) void big_inverse_kernel(BigInvArgs a) {
     // The matrix lives in REGISTERS: lane r of wave jq holds the entries (r, jq + 4 q), q = 0 ... 15 (big_inv_pivot4 above).
     __shared__ double2 colb[2][64];
@@ -715,15 +717,15 @@ __global__ __launch_bounds__(256) void big_inverse_kernel(BigInvArgs a) {
     const int64_t k1 = sum ? min(a.nnodes, k0 + a.nodes_per_block) : a.nnodes;
     const int64_t kstep = sum ? 1 : gridDim.x;
     for (int s = 0; s < a.n_sweep; ++s) {
-        double2 acc[16];  // sum mode: the weighted sum of this thread's entries, or the trace in acc[0] of thread 0
+        double2 acc[NQ];  // sum mode: the weighted sum of this thread's entries, or the trace in acc[0] of thread 0
 #pragma unroll
-        for (int q = 0; q < 16; ++q) acc[q] = make_double2(0.0, 0.0);
+        for (int q = 0; q < NQ; ++q) acc[q] = make_double2(0.0, 0.0);
         for (int64_t k = k0; k < k1; k += kstep) {
             const double sw = a.sweep_per_node ? a.sweep_per_node[a.node0 + k] : (a.sweep ? a.sweep[s] : a.sweep0);
             const double2* __restrict__ h = a.Hbuf + k * (int64_t)nn;
-            double2 W[16];
+            double2 W[NQ];
 #pragma unroll
-            for (int q = 0; q < 16; ++q) {
+            for (int q = 0; q < NQ; ++q) {
                 const int j = jq + 4 * q;
                 W[q] = make_double2(0.0, 0.0);
                 if (rowon && j < n) {
@@ -732,19 +734,19 @@ __global__ __launch_bounds__(256) void big_inverse_kernel(BigInvArgs a) {
                 }
             }
             // pivots c = 4 cq + cm: cq unrolled (the entry of column c in its wave's registers is W[cq], a static index), cm rolled
-            big_inv_pivots(n, r, jq, colb, W, std::make_integer_sequence<int, 16>());
+            big_inv_pivots<NQ>(n, r, jq, colb, W, std::make_integer_sequence<int, NQ>());
             const double wk = sum ? (a.w ? a.w[a.node0 + k] : 1.0) : 1.0;
             if (a.kind == 0) {
                 if (sum) {
 #pragma unroll
-                    for (int q = 0; q < 16; ++q) {
+                    for (int q = 0; q < NQ; ++q) {
                         acc[q].x = fma(wk, W[q].x, acc[q].x);
                         acc[q].y = fma(wk, W[q].y, acc[q].y);
                     }
                 } else if (rowon) {
                     double2* __restrict__ vo = a.values + ((a.node0 + k) * a.n_sweep + s) * (int64_t)nn;
 #pragma unroll
-                    for (int q = 0; q < 16; ++q) {
+                    for (int q = 0; q < NQ; ++q) {
                         const int j = jq + 4 * q;
                         if (j < n) vo[r + n * j] = W[q];
                     }
@@ -753,7 +755,7 @@ __global__ __launch_bounds__(256) void big_inverse_kernel(BigInvArgs a) {
                 // the diagonal entry (r, r) sits in wave r & 3 at q = r >> 2: partial traces per wave, met in LDS
                 double tr = 0.0, ti = 0.0;
 #pragma unroll
-                for (int q = 0; q < 16; ++q) {
+                for (int q = 0; q < NQ; ++q) {
                     const bool d = rowon && (jq + 4 * q) == r;
                     tr += d ? W[q].x : 0.0;
                     ti += d ? W[q].y : 0.0;
@@ -783,7 +785,7 @@ __global__ __launch_bounds__(256) void big_inverse_kernel(BigInvArgs a) {
             double2* __restrict__ po = a.partial + ((int64_t)blockIdx.x * a.n_sweep + s) * ncomp;
             if (a.kind == 0) {
 #pragma unroll
-                for (int q = 0; q < 16; ++q) {
+                for (int q = 0; q < NQ; ++q) {
                     const int j = jq + 4 * q;
                     if (rowon && j < n) {
                         po[r + n * j].x += acc[q].x;
@@ -842,7 +844,14 @@ int big_tridiag(abz_ctx* ctx, const BigWork& w, int n, int64_t cn, double2* keep
 }
 
 static int big_inverse(abz_ctx* ctx, BigInvArgs& ia, int64_t blocks) {
-    hipLaunchKernelGGL(big_inverse_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, ia);
+    if (ia.n <= 40)
+        hipLaunchKernelGGL(big_inverse_kernel<10>, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, ia);
+    else if (ia.n <= 48)
+        hipLaunchKernelGGL(big_inverse_kernel<12>, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, ia);
+    else if (ia.n <= 56)
+        hipLaunchKernelGGL(big_inverse_kernel<14>, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, ia);
+    else
+        hipLaunchKernelGGL(big_inverse_kernel<16>, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, ia);
     ABZ_HIP(hipGetLastError());
     return ABZ_OK;
 }
