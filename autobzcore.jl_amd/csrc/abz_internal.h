@@ -493,7 +493,7 @@ struct PanelRuleSpec {
     int* p_status;             // device [npanels] out: != 0 if any of its innermost integrals overflowed the device store
 };
 int launch_panel_rule(abz_ctx* ctx, const PanelRuleSpec& ps);
-bool gen_inner_panel_supported(int n, int M, int integrand);  // n > 4: one workgroup per 1-D integral, set in LDS
+bool gen_inner_panel_supported(int n, int M, int integrand, bool herm);  // n > 4: one workgroup per 1-D integral, set in LDS
 int launch_gen_inner_adaptive(abz_ctx* ctx, const InnerSpec& is);
 
 // ---- generic n (5..32 bands): wave-per-node kernels (kernels_generic.hip)
@@ -558,6 +558,7 @@ int launch_lane_sum(abz_ctx* ctx, const SumSpec& ss, double* out_reim);
 bool lane_scan_supported(const ReduceSpec& rs);
 int launch_lane_scan(abz_ctx* ctx, const ReduceSpec& rs, double* out_reim);
 bool big_supported(int n);
+bool big_inverse_wanted(int n, int integrand, bool herm);  // 17...64 bands: G / traces through big_inverse_kernel
 bool big_sum_supported(int n, int M, int npt, int integrand, bool herm);
 int launch_big_nodes(abz_ctx* ctx, const GenSpec& gs);
 int launch_big_sum(abz_ctx* ctx, const SumSpec& ss, double* out_reim);

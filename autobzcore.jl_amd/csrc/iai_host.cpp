@@ -1501,7 +1501,7 @@ static int iai_solve_lane(abz_series* s, int lims_kind, const double* lim_a, con
     {
         // n > 4: the workgroup-per-integral kernel (coefficient set in LDS); ABZ_IAI_DEVICE_INNER=0 forces the host loop
         // at every level
-        const bool ok = s->n > 4 ? gen_inner_panel_supported(s->n, s->dims[0], integrand)
+        const bool ok = s->n > 4 ? gen_inner_panel_supported(s->n, s->dims[0], integrand, s->hermitian)
                                  : inner_adaptive_supported(s->n, s->dims[0], integrand);
         drv.device_inner = max_batch <= 0 && s->d >= 2 && ok && abz_switch(SW_IAI_DEVICE_INNER) != 0;
     }

@@ -844,7 +844,15 @@ int big_tridiag(abz_ctx* ctx, const BigWork& w, int n, int64_t cn, double2* keep
 }
 
 static int big_inverse(abz_ctx* ctx, BigInvArgs& ia, int64_t blocks) {
-    if (ia.n <= 40)
+    if (ia.n <= 20)
+        hipLaunchKernelGGL(big_inverse_kernel<5>, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, ia);
+    else if (ia.n <= 24)
+        hipLaunchKernelGGL(big_inverse_kernel<6>, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, ia);
+    else if (ia.n <= 28)
+        hipLaunchKernelGGL(big_inverse_kernel<7>, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, ia);
+    else if (ia.n <= 32)
+        hipLaunchKernelGGL(big_inverse_kernel<8>, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, ia);
+    else if (ia.n <= 40)
         hipLaunchKernelGGL(big_inverse_kernel<10>, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, ia);
     else if (ia.n <= 48)
         hipLaunchKernelGGL(big_inverse_kernel<12>, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, ia);
@@ -879,6 +887,12 @@ int big_series(abz_ctx* ctx, BigSeriesArgs& sa, int64_t c0, int64_t cn) {
 }  // namespace
 
 bool big_supported(int n) { return n > 32 && n <= ABZ_MAX_BANDS; }
+
+// 17...32 bands borrow big_inverse_kernel for what their row kernels do not serve (the wave-per-node Gauss-Jordan in LDS took
+// 21 ms for a 4-omega G scan of 24^3 nodes at 32 bands; 3.8 ms at 33 bands here): matrix-valued G and series that are not Hermitian
+bool big_inverse_wanted(int n, int integrand, bool herm) {
+    return n > 16 && n <= ABZ_MAX_BANDS && big_inv_kind(integrand) >= 0 && (integrand == ABZ_F_GLOC || !herm);
+}
 
 // GGR builds (eigenvalues + band velocities, nothing else stored): chunk by chunk H -> tridiagonal with the reflectors kept ->
 // eigenvalues into the rule -> dH/dk_j, j = 1 ... d, side by side -> eigenvectors, back-transformation and the quadratic forms in

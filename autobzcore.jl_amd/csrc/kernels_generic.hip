@@ -1884,6 +1884,7 @@ static bool gen_panel_supported(const GenSpec& gs, int* np_out, size_t* lds_out,
     if (gs.n_sweep > 1 || gs.sweep_dev) return false;
     if (!(gs.integrand == ABZ_F_DOS || gs.integrand == ABZ_F_TRGLOC || gs.integrand == ABZ_F_GLOC)) return false;
     if (gs.Hplanes.base || gs.Eplanes.base || gs.Uplanes.base || gs.Haos || gs.Eaos) return false;
+    if (gs.n > 16 && gs.integrand != ABZ_F_GLOC && !gs.herm) return false;  // (the 32-lane instance takes traces from the tridiagonal of Hermitian(h))
     const int np = gs.n <= 8 ? 8 : (gs.n <= 16 ? 16 : 32);
     size_t lds = sizeof(double2) * (size_t)gs.M * np * np;  // zero-padded set
     *pad_out = lds <= 150 * 1024;
@@ -1905,6 +1906,9 @@ static int gen_waves_per_block(int n, int M) {
 int launch_gen_nodes(abz_ctx* ctx, const GenSpec& gs) {
     if (gs.nnodes == 0) return ABZ_OK;
     if (big_supported(gs.n)) return launch_big_nodes(ctx, gs);  // 33...64 bands: kernels_big.hip
+    if (gs.values && big_inverse_wanted(gs.n, gs.integrand, gs.herm) && !gs.Hplanes.base && !gs.Haos && !gs.Eplanes.base && !gs.Eaos &&
+        !gs.Uplanes.base && !gs.deriv && gs.M <= 64)
+        return launch_big_nodes(ctx, gs);  // 17...32 bands, values only (IAI node path): the inverse of every node in registers
     if (lane_grid_supported(gs)) return launch_lane_grid(ctx, gs);  // 5...8 bands on full grids: one node per lane
     if (gs.n > ABZ_MAX_BANDS) {
         set_error("n = %d bands exceeds ABZ_MAX_BANDS", gs.n);
@@ -2555,6 +2559,7 @@ int launch_gen_reduce(abz_ctx* ctx, const ReduceSpec& rs, double* out_reim) {
     if (gen_rows_reduce_supported(rs)) return launch_gen_rows_reduce(ctx, rs, out_reim);
     if (rs.integrand == ABZ_F_DOS_EIG && rs.E.base && rs.sweep_dev && rs.n_sweep >= 1) return launch_gen_eig_dos(ctx, rs, out_reim);
     if (big_supported(rs.n)) return launch_big_reduce(ctx, rs, out_reim);  // 33...64 bands: kernels_big.hip
+    if (big_inverse_wanted(rs.n, rs.integrand, rs.herm) && rs.H.base && !rs.H.compact) return launch_big_reduce(ctx, rs, out_reim);
     const int ncomp = integrand_ncomp(rs.integrand, rs.n, rs.d);
     if (ncomp < 0 || rs.integrand == ABZ_F_LINEAR || rs.integrand == ABZ_F_LINEAR_X) {
         set_error("integrand %d is not available for n = %d bands", rs.integrand, rs.n);
@@ -2763,8 +2768,10 @@ static bool gen_inner_panel_fits(int n, int M, int integrand, int* np_out, size_
 }
 
 // the block-per-integral kernel is the one worth running by default (see iai_host.cpp)
-bool gen_inner_panel_supported(int n, int M, int integrand) {
-    return n > 4 && n <= ABZ_MAX_BANDS && gen_inner_panel_fits(n, M, integrand, nullptr, nullptr, nullptr);
+bool gen_inner_panel_supported(int n, int M, int integrand, bool herm) {
+    // (17...32 bands: the 32-lane instance takes the trace from the tridiagonal form of Hermitian(h); a series that is not
+    // Hermitian goes through the host-driven node path and big_inverse_kernel)
+    return n > 4 && n <= ABZ_MAX_BANDS && (n <= 16 || herm) && gen_inner_panel_fits(n, M, integrand, nullptr, nullptr, nullptr);
 }
 
 int launch_gen_inner_adaptive(abz_ctx* ctx, const InnerSpec& is) {

@@ -241,7 +241,7 @@ def test_dos3_sweep_kernel_against_oracle_and_generic_scan(abz, monkeypatch):
         rule.close()
 
 
-@pytest.mark.parametrize("n", [2, 3, 6, 12])
+@pytest.mark.parametrize("n", [2, 3, 6, 12, 20, 32])
 def test_rule_reduce_non_hermitian_series(abz, n):
     """A series that is NOT Hermitian (e.g. H + a k-dependent self-energy) takes the general paths:
     full-matrix Fourier evaluation and the complex characteristic polynomial in the scan.  The decay of
