@@ -279,6 +279,40 @@ def fuzz_round5_kernels(abz, seed, emit=None):
         note(tag + ("gloc",), np.abs(g - gref).max() / np.abs(gref).max(), 1e-10)
         note(tag + ("scan",), np.abs(sc - tref).max() / np.abs(tref).max(), 1e-10)
         note(tag + ("sum",), np.abs(sf - tref).max() / np.abs(tref).max(), 1e-10)
+    # --- series that are NOT Hermitian, 2...64 bands: G, tr G and DOS of cached rules (full grids and inversion-symmetric lists)
+    # against plain inverses, IAI in one and two dimensions against the oracle's adaptive loop (equal numevals)
+    for it in range(10):
+        d = int(rng.integers(1, 3))
+        n = int(rng.choice([2, 3, 4, 5, 7, 8, 9, 13, 16, 17, 21, 29, 32, 33, 45, 64]))
+        dims = tuple(int(rng.choice([1, 3, 5])) for _ in range(d))
+        npt = int(rng.integers(1, 9 if d == 2 else 30))
+        c, first = _herm_series(rng, dims, n, scale=1.0 / np.sqrt(n))
+        c = c + 0.05 / np.sqrt(n) * (rng.standard_normal(c.shape) + 1j * rng.standard_normal(c.shape))
+        s = abz.FourierSeries(c, period=1.0, first=first, ndim=d)
+        so = orc.FourierSeries(c, period=1.0, first=first, ndim=d)
+        om = rng.uniform(-1.0, 1.0, size=2)
+        eta = float(rng.uniform(0.4, 0.8))
+        syms = orc.load_bz("InversionSymIBZ", np.eye(d)).syms if (d == 2 and rng.integers(0, 2)) else None
+        rule = s.device().rule(npt, syms, want=1)
+        g = rule.reduce(L.F_GLOC, [eta], om)
+        tr = rule.reduce(L.F_TRGLOC, [eta], om)[:, 0]
+        dos = rule.reduce(L.F_DOS, [eta], om)[:, 0].real
+        rule.close()
+        tag = ("nonherm", d, n, dims, npt, syms is not None)
+        for i in range(2):
+            gref, _ = orc._ptr_rule_sum(so, npt, syms, orc.f_gloc(eta, om[i]))
+            t = np.trace(gref)
+            note(tag + ("gloc", i), np.abs(g[i].reshape(n, n).T - gref).max() / np.abs(gref).max(), 1e-10)
+            note(tag + ("trg", i), abs(tr[i] - t) / abs(t), 1e-10)
+            note(tag + ("dos", i), abs(dos[i] + t.imag / np.pi) / abs(t), 1e-10)
+        if it < 5:
+            bz = abz.load_bz(abz.FBZ(), np.eye(d))
+            sol = abz.do_solve(abz.FourierIntegrand(abz.TrGlocIntegrand(), s, eta), bz, abz.MixedParameters(float(om[0])),
+                               abz.EvalCounter(abz.IAI()), abstol=1e-2)
+            f_tr = lambda x, h: np.trace(orc.f_gloc(eta, float(om[0]))(x, h), axis1=-2, axis2=-1)
+            ref = orc.solve_iai(so, orc.load_bz("FBZ", np.eye(d)), f_tr, abstol=1e-2)
+            note(tag + ("iai numevals",), float(abs(sol.numevals - ref.numevals)), 0.5)
+            note(tag + ("iai",), abs(sol.u - ref.u) / abs(ref.u), 1e-9)
     return worst, bad
 
 
