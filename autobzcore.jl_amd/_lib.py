@@ -68,6 +68,7 @@ PROTOTYPES = {
 # constants of include/abzhip.h
 WANT_H, WANT_EIG, WANT_VEL = 1, 2, 4
 WANT_H_COMPACT = 8  # with WANT_H on a Hermitian series of n <= 4 bands: upper-triangle planes only (abzhip.h)
+WANT_H_ROW_MAJOR = 16  # abz_eval_nodes: matrices row-major in H_out (numpy's order; abzhip.h)
 F_ONE, F_LINEAR, F_LINEAR_X, F_DOS, F_TRGLOC, F_GLOC, F_DOS_EIG = range(7)
 LIMS_CUBIC, LIMS_TETRAHEDRAL, LIMS_POLYHEDRAL, LIMS_POLYGON = 0, 1, 2, 3
 K_CONTRACT, K_EVAL, K_REDUCE, K_GGR, K_EIG, K_GGRBUILD = range(6)

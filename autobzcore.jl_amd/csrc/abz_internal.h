@@ -405,7 +405,7 @@ int launch_ggr(abz_ctx* ctx, int n, int d, int npt, PlaneView E, PlaneView V, co
                const double* Es_host, int nE, double* out_host);
 
 // tiled planar (ncomp planes of the view) -> AoS [nk][ncomp] on the host
-int export_planes(abz_ctx* ctx, PlaneView v, int ncomp, int64_t nk, double* host_out);
+int export_planes(abz_ctx* ctx, PlaneView v, int ncomp, int64_t nk, double* host_out, int row_major_n = 0);
 
 // IAI innermost nodes: values[node][ncomp] complex
 struct NodeEvalSpec {

@@ -1999,7 +1999,7 @@ int abz_eval_nodes(abz_series* s, const double* k, int64_t nk, int want, double*
         es.U = PlaneView();
         if ((status = launch_eval(ctx, es))) break;
         if (want & ABZ_WANT_H)
-            if ((status = export_planes(ctx, Hv, 2 * n * n, m, H_out + k0 * 2 * n * n))) break;
+            if ((status = export_planes(ctx, Hv, 2 * n * n, m, H_out + k0 * 2 * n * n, (want & ABZ_WANT_H_ROW_MAJOR) ? n : 0))) break;
         if (want & ABZ_WANT_EIG)
             if ((status = export_planes(ctx, Ev, n, m, eig_out + k0 * n))) break;
     }

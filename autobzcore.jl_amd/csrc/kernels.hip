@@ -2042,11 +2042,17 @@ int launch_reduce(abz_ctx* ctx, const ReduceSpec& rs, double* out_reim) {
 // ------------------------------------------------------------------------------------------
 // export planar -> AoS
 // ------------------------------------------------------------------------------------------
-__global__ void export_kernel(PlaneView v, int ncomp, int64_t nk, double* __restrict__ out) {
+// row_major_n > 0 (matrix planes, abz_eval_nodes with ABZ_WANT_H_ROW_MAJOR): component 2 (a n + b) + {re, im} of the output is the
+// matrix element (a, b), i.e. plane 2 (a + n b) + {re, im}
+__global__ void export_kernel(PlaneView v, int ncomp, int64_t nk, double* __restrict__ out, int row_major_n) {
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= nk * ncomp) return;
     const int64_t k = t / ncomp;
-    const int c = (int)(t - k * ncomp);
+    int c = (int)(t - k * ncomp);
+    if (row_major_n > 0) {
+        const int im = c & 1, ab = c >> 1, a = ab / row_major_n, b = ab - a * row_major_n;
+        c = 2 * (a + row_major_n * b) + im;
+    }
     if (v.compact) {  // upper-triangle planes -> the full matrix in the reference's order, component 2 (a + n b) + {re, im}
         const int n = v.compact, im = c & 1, ab = c >> 1;
         const int a = ab % n, b = ab / n;
@@ -2059,13 +2065,13 @@ __global__ void export_kernel(PlaneView v, int ncomp, int64_t nk, double* __rest
     out[t] = v.base[view_off(v, k) + (int64_t)c * v.pitch];
 }
 
-int export_planes(abz_ctx* ctx, PlaneView v, int ncomp, int64_t nk, double* host_out) {
+int export_planes(abz_ctx* ctx, PlaneView v, int ncomp, int64_t nk, double* host_out, int row_major_n) {
     if (nk == 0) return ABZ_OK;
     const size_t bytes = sizeof(double) * (size_t)nk * ncomp;
     int rc = ctx->scratch[3].reserve(bytes);
     if (rc) return rc;
     double* stg = ctx->scratch[3].as<double>();
-    hipLaunchKernelGGL(export_kernel, dim3((unsigned)cdiv(nk * ncomp, 256)), dim3(256), 0, ctx->stream, v, ncomp, nk, stg);
+    hipLaunchKernelGGL(export_kernel, dim3((unsigned)cdiv(nk * ncomp, 256)), dim3(256), 0, ctx->stream, v, ncomp, nk, stg, row_major_n);
     ABZ_HIP(hipGetLastError());
     return stage_d2h(ctx, host_out, stg, bytes);  // large: through the pinned staging buffer
 }

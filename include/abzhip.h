@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define ABZ_VERSION 501
+#define ABZ_VERSION 502
 
 /* status codes */
 #define ABZ_OK 0
@@ -61,6 +61,10 @@ typedef struct abz_rule abz_rule;     /* device-resident cached rule values (Fou
  * not Hermitian or have more than 16 bands; abz_rule_info reports the bit only when the rule really is compact.
  * Plane order inside a tile: Re H[a][b], Im H[a][b] for a < b at planes b^2 + 2a, b^2 + 2a + 1; H[b][b] at b^2 + 2b. */
 #define ABZ_WANT_H_COMPACT 8
+/* abz_eval_nodes only: H_out holds every matrix ROW-major (element (a, b) at 2 (a n + b) + {re, im}) instead of the reference's
+ * column-major blocks -- for hosts whose arrays are row-major (the Python mirror: transposing 4 096 matrices of 32 x 32 on the
+ * host took longer than evaluating them). */
+#define ABZ_WANT_H_ROW_MAJOR 16
 
 /* built-in device integrands f(FourierValue(k, H(k)), params...; sweep) -- the integrands that
  * appear in the reference's tests, docs and example (user closures cannot cross a C ABI; they get

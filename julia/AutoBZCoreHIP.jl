@@ -26,6 +26,7 @@ const WANT_H, WANT_EIG, WANT_VEL = Cint(1), Cint(2), Cint(4)
 # rules of a Hermitian series (n <= 4) keep H(k) as its upper triangle: n^2 value planes instead of 2 n^2; ignored otherwise.
 # Device integrands read those planes, abz_rule_export still returns full matrices (abzhip.h).
 const WANT_H_COMPACT = Cint(8)
+const WANT_H_ROW_MAJOR = Cint(16)  # abz_eval_nodes: row-major matrices (not for Julia arrays; listed for completeness)
 const WANT_HC = WANT_H | WANT_H_COMPACT
 const F_ONE, F_LINEAR, F_LINEAR_X, F_DOS, F_TRGLOC, F_GLOC, F_DOS_EIG = Cint.(0:6)
 const LIMS_CUBIC, LIMS_TETRAHEDRAL, LIMS_POLYHEDRAL, LIMS_POLYGON = Cint(0), Cint(1), Cint(2), Cint(3)

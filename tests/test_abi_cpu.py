@@ -26,7 +26,7 @@ def test_header_symbols_exported_and_bound(abz):
     h = _lib.lib()
     for name in declared:
         assert hasattr(h, name)
-    assert h.abz_version() == 501  # round 5: ABZ_MAX_BANDS 64, ABZ_ERR_INTERNAL (every entry point catches C++ exceptions); round 4: abz_autoptr_solve(_many), abz_series_drop_rules; round 3: abz_mem_info, fused GGR build (ABZ_K_GGRBUILD), status word in the IAI exchange; 301: ABZ_WANT_H_COMPACT
+    assert h.abz_version() == 502  # 502: ABZ_WANT_H_ROW_MAJOR (abz_eval_nodes); round 5: ABZ_MAX_BANDS 64, ABZ_ERR_INTERNAL (every entry point catches C++ exceptions); round 4: abz_autoptr_solve(_many), abz_series_drop_rules; round 3: abz_mem_info, fused GGR build (ABZ_K_GGRBUILD), status word in the IAI exchange; 301: ABZ_WANT_H_COMPACT
 
 
 def test_header_constants_match_the_bindings(abz):
@@ -40,7 +40,7 @@ def test_header_constants_match_the_bindings(abz):
     assert ids == [L.F_ONE, L.F_LINEAR, L.F_LINEAR_X, L.F_DOS, L.F_TRGLOC, L.F_GLOC, L.F_DOS_EIG] == list(range(7))
     jl = open(os.path.join(ROOT, "julia", "AutoBZCoreHIP.jl")).read()
     assert "const WANT_H, WANT_EIG, WANT_VEL = Cint(1), Cint(2), Cint(4)" in jl and "const WANT_H_COMPACT = Cint(8)" in jl
-    assert defs["ABZ_VERSION"] == 501
+    assert defs["ABZ_VERSION"] == 502
 
 
 def test_fails_loudly_without_gpu(abz):
