@@ -823,10 +823,11 @@ int big_reserve(abz_ctx* ctx, int n, int npt_or_zero, int64_t nnodes, BigWork& w
 }
 
 int big_tridiag(abz_ctx* ctx, const BigWork& w, int n, int64_t cn, double2* keep = nullptr) {
-    // one wave per node while the CU holds six matrices or more (<= 56 bands); four above (24^3 nodes, H + eig: 64 bands 11.0 ms
-    // with one wave, 8.4 with two, 7.8 with four; 48 bands 3.86 / 4.04 / 4.14; 33 bands 1.64 / 1.57 / 1.98)
+    // one wave per node while the CU holds seven matrices or more (<= 48 bands); four above (24^3 nodes, H + eig with one / two /
+    // four waves: 64 bands 11.0 / 8.4 / 7.8 ms, 56 bands 7.6 / 6.0 / 5.9, 52 bands 6.6 / 5.3 / 5.3, 48 bands 3.83 / 3.97 / 4.15,
+    // 40 bands 2.87 / 2.61 / 3.16, 33 bands 1.64 / 1.57 / 1.98)
     const int sw = abz_switch(SW_BIG_TRI_WAVES);
-    const int nw = sw > 0 ? sw : (n > 56 ? 4 : 1);
+    const int nw = sw > 0 ? sw : (n > 48 ? 4 : 1);
     const size_t lds = sizeof(double2) * ((size_t)n * (n + 1) / 2 + 2 * (size_t)n + (nw > 1 ? 64 * (size_t)nw : 0));
     const int64_t blocks = std::min<int64_t>(cn, 256 * 8);
     if (nw >= 4) {

@@ -1908,7 +1908,7 @@ int launch_gen_nodes(abz_ctx* ctx, const GenSpec& gs) {
     if (big_supported(gs.n)) return launch_big_nodes(ctx, gs);  // 33...64 bands: kernels_big.hip
     // arbitrary nodes (abz_eval_nodes) with eigenvalues, 9...32 bands: Householder + QR through the kernels of kernels_big.hip (generic in
     // n) instead of the wave-per-node Jacobi below (4 096 nodes of 32 bands: 18 ms of kernels; a rule build of 13 824 nodes 0.8 ms)
-    if (!gs.grid && gs.x && !gs.values && (gs.Eplanes.base || gs.Eaos) && !gs.Uplanes.base && !gs.deriv && !gs.Hplanes.compact && gs.n > 8 &&
+    if (!gs.grid && gs.x && !gs.values && (gs.Eplanes.base || gs.Eaos) && !gs.Uplanes.base && !gs.deriv && !gs.Hplanes.compact && gs.n > 4 &&
         gs.M <= 64)
         return launch_big_nodes(ctx, gs);
     if (gs.values && big_inverse_wanted(gs.n, gs.integrand, gs.herm) && !gs.Hplanes.base && !gs.Haos && !gs.Eplanes.base && !gs.Eaos &&
