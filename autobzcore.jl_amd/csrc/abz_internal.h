@@ -343,6 +343,9 @@ struct ReduceSpec {
     const double* sweep_dev;  // device [n_sweep]
     int n_sweep;
     double scale;
+    double* tri_cache = nullptr;  // 33...64 bands: the rule's room for the tridiagonal forms of its nodes [2 x 64][tri_nk] ...
+    int64_t tri_nk = 0;
+    int* tri_state = nullptr;     // ... and whether it holds them (set by the scan that fills it)
     double* out_dev = nullptr;  // device [n_sweep][ncomp][2]: leave the result in HBM, no host synchronisation
     double2* out_map_dev = nullptr;         // host-io calls: device view of the pinned mailbox region the sums are written to ...
     const double2* out_map_host = nullptr;  // ... and its host view (read after the stream synchronisation; null with

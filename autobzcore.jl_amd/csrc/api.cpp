@@ -877,6 +877,10 @@ struct RulePlan {
     DevBuf tab;
     DevBuf tmpU, tmpD;  // eigenvector / derivative planes while velocities are built (unfused build)
     DevBuf fam[2];      // fused GGR build: coefficient sets with the derivative factor on variable 2 / 3
+    // 33...64 bands, Hermitian rules with cached H(k): the tridiagonal form (d, |e|^2) of every node, 1 KB per node, filled by the
+    // first DOS / tr G scan -- later scans of the same values skip the Householder pass, which is most of a scan
+    DevBuf tri;
+    int tri_state = 0;  // 0: not filled for the current values
 };
 }  // namespace abz
 
@@ -895,6 +899,7 @@ static void rule_free(abz_rule* r) {
         rp->tmpD.release();
         rp->fam[0].release();
         rp->fam[1].release();
+        rp->tri.release();
         delete rp;
     }
     delete r;
@@ -942,6 +947,7 @@ static int rule_fill(abz_rule* r) {
     const int d = s->d, n = s->n;
     const double2* tab = rp->tab.as<double2>();
     r->herm = s->hermitian;
+    rp->tri_state = 0;  // new values: the cached tridiagonal forms are stale
     if (r->H.compact && !s->hermitian) {
         set_error("the rule keeps H(k) as an upper triangle (ABZ_WANT_H_COMPACT) and the series is no longer Hermitian: build a new rule");
         return ABZ_ERR_ARG;
@@ -1464,6 +1470,15 @@ static int rule_reduce(abz_rule* r, int integrand, const double* params, int npa
     rs.idx = r->idx;
     rs.k_offset = r->k_offset;
     rs.herm = r->herm;
+    if (big_supported(rs.n) && r->herm && r->H.base && !r->H.compact && r->plan && (integrand == ABZ_F_DOS || integrand == ABZ_F_TRGLOC)) {
+        RulePlan* rp = static_cast<RulePlan*>(r->plan);
+        const int64_t tnk = (r->nk + 63) / 64 * 64;
+        if (rp->tri.reserve(sizeof(double) * 2 * 64 * (size_t)tnk) == ABZ_OK) {  // (no room: the scan tridiagonalises on the fly)
+            rs.tri_cache = rp->tri.as<double>();
+            rs.tri_nk = tnk;
+            rs.tri_state = &rp->tri_state;
+        }
+    }
     for (int i = 0; i < 4; ++i) rs.params[i] = (i < nparams) ? params[i] : 0.0;
     rs.n_sweep = ns;
     rs.sweep_dev = nullptr;

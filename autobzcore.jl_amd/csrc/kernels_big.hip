@@ -822,7 +822,11 @@ int big_reserve(abz_ctx* ctx, int n, int npt_or_zero, int64_t nnodes, BigWork& w
     return ABZ_OK;
 }
 
-int big_tridiag(abz_ctx* ctx, const BigWork& w, int n, int64_t cn, double2* keep = nullptr) {
+// (tri_to / tri_nk_to / t0: write the tridiagonal forms into another array at node offset t0 -- a rule's cache)
+int big_tridiag(abz_ctx* ctx, const BigWork& w, int n, int64_t cn, double2* keep = nullptr, double* tri_to = nullptr, int64_t tri_nk_to = 0,
+                int64_t t0 = 0) {
+    double* const tri = tri_to ? tri_to : w.tri;
+    const int64_t tri_nk = tri_to ? tri_nk_to : w.tri_nk;
     // one wave per node while the CU holds seven matrices or more (<= 48 bands); four above (24^3 nodes, H + eig with one / two /
     // four waves: 64 bands 11.0 / 8.4 / 7.8 ms, 56 bands 7.6 / 6.0 / 5.9, 52 bands 6.6 / 5.3 / 5.3, 48 bands 3.83 / 3.97 / 4.15,
     // 40 bands 2.87 / 2.61 / 3.16, 33 bands 1.64 / 1.57 / 1.98)
@@ -832,13 +836,13 @@ int big_tridiag(abz_ctx* ctx, const BigWork& w, int n, int64_t cn, double2* keep
     const int64_t blocks = std::min<int64_t>(cn, 256 * 8);
     if (nw >= 4) {
         ABZ_HIP(hipFuncSetAttribute((const void*)big_tridiag_mw_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(big_tridiag_mw_kernel<4>, dim3((unsigned)blocks), dim3(256), lds, ctx->stream, w.Hbuf, cn, n, w.tri, w.tri_nk, (int64_t)0, keep);
+        hipLaunchKernelGGL(big_tridiag_mw_kernel<4>, dim3((unsigned)blocks), dim3(256), lds, ctx->stream, w.Hbuf, cn, n, tri, tri_nk, t0, keep);
     } else if (nw >= 2) {
         ABZ_HIP(hipFuncSetAttribute((const void*)big_tridiag_mw_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(big_tridiag_mw_kernel<2>, dim3((unsigned)blocks), dim3(128), lds, ctx->stream, w.Hbuf, cn, n, w.tri, w.tri_nk, (int64_t)0, keep);
+        hipLaunchKernelGGL(big_tridiag_mw_kernel<2>, dim3((unsigned)blocks), dim3(128), lds, ctx->stream, w.Hbuf, cn, n, tri, tri_nk, t0, keep);
     } else {
         ABZ_HIP(hipFuncSetAttribute((const void*)big_tridiag_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(big_tridiag_kernel, dim3((unsigned)blocks), dim3(64), lds, ctx->stream, w.Hbuf, cn, n, w.tri, w.tri_nk, (int64_t)0, keep);
+        hipLaunchKernelGGL(big_tridiag_kernel, dim3((unsigned)blocks), dim3(64), lds, ctx->stream, w.Hbuf, cn, n, tri, tri_nk, t0, keep);
     }
     ABZ_HIP(hipGetLastError());
     return ABZ_OK;
@@ -1205,7 +1209,26 @@ int launch_big_reduce(abz_ctx* ctx, const ReduceSpec& rs, double* out_reim) {
     }
     if ((rc = ctx->scratch[2].reserve(sizeof(double2) * (size_t)rs.n_sweep))) return rc;
     double2* total = ctx->scratch[2].as<double2>();
-    {
+    if (rs.tri_cache && rs.tri_state) {
+        // the rule keeps the tridiagonal forms of its nodes: tridiagonalise once per fill of the rule, then every scan is the p'/p pass
+        ProfScope ps(ctx, ABZ_K_REDUCE);
+        if (*rs.tri_state == 0) {
+            for (int64_t c0 = 0; c0 < rs.nk; c0 += w.chunk) {
+                const int64_t cn = std::min(w.chunk, rs.nk - c0);
+                hipLaunchKernelGGL(big_load_h_kernel, dim3((unsigned)std::min<int64_t>(cdivb((cn + 63) / 64 * 64 * rs.n * rs.n, 256), 256 * 16)), dim3(256), 0,
+                                   ctx->stream, w.Hbuf, c0, cn, rs.n, rs.H);
+                ABZ_HIP(hipGetLastError());
+                if ((rc = big_tridiag(ctx, w, rs.n, cn, nullptr, rs.tri_cache, rs.tri_nk, c0))) return rc;
+            }
+            *rs.tri_state = 1;
+        }
+        BigWork wc = w;
+        wc.tri = rs.tri_cache;
+        wc.tri_nk = rs.tri_nk;
+        if ((rc = big_sum_chunk(ctx, wc, rs.n, 0, rs.nk, rs.integrand == ABZ_F_DOS, rs.params[0], rs.sweep_dev, rs.n_sweep, rs.w, total, true))) return rc;
+        hipLaunchKernelGGL(big_scale_kernel, dim3((unsigned)cdivb(rs.n_sweep, 256)), dim3(256), 0, ctx->stream, total, rs.n_sweep, rs.scale);
+        ABZ_HIP(hipGetLastError());
+    } else {
         ProfScope ps(ctx, ABZ_K_REDUCE);
         for (int64_t c0 = 0; c0 < rs.nk; c0 += w.chunk) {
             const int64_t cn = std::min(w.chunk, rs.nk - c0);

@@ -1107,6 +1107,44 @@ def test_more_than_32_bands_matrix_valued_and_non_hermitian(abz, n):
     assert sol.numevals == ref.numevals and abs(sol.u - ref.u) <= 1e-9 * abs(ref.u)
 
 
+def test_more_than_32_bands_cached_tridiagonal_follows_the_values(abz):
+    """33...64 bands: a rule of a Hermitian series keeps the tridiagonal forms of its nodes after its first DOS / tr G scan (the
+    Householder pass is most of a scan).  Scans repeat to the bit; new coefficients + rebuild must be seen by the next scan;
+    a series that stops being Hermitian must leave the cached route."""
+    L = abz._lib
+    rng = np.random.default_rng(4242)
+    n, npt, eta = 40, 9, 0.3
+    c, first = rand_series(rng, (3, 3), n, hermitian=True)
+    c = c / np.sqrt(n)
+    s, so = both(abz, c, first)
+    om = np.array([-0.6, 0.1, 0.8])
+    rule = s.device().rule(npt, None, want=1)
+    ref = lambda so_: np.array([np.trace(orc._ptr_rule_sum(so_, npt, None, orc.f_gloc(eta, w))[0]) for w in om])
+    a1 = rule.reduce(L.F_TRGLOC, [eta], om)[:, 0]
+    a2 = rule.reduce(L.F_TRGLOC, [eta], om)[:, 0]
+    d1 = rule.reduce(L.F_DOS, [eta], om)[:, 0].real
+    t = ref(so)
+    assert np.array_equal(a1, a2) and np.abs(a1 - t).max() <= 1e-10 * np.abs(t).max()
+    assert np.abs(d1 + t.imag / np.pi).max() <= 1e-10 * np.abs(t).max()
+    c2 = c.copy()
+    c2[1, 1] += np.diag(np.linspace(-0.2, 0.2, n))  # R = 0: stays Hermitian
+    s.device().update(c2)
+    rule.rebuild()
+    so2 = orc.FourierSeries(c2, period=1.0, first=first, ndim=2)
+    b1 = rule.reduce(L.F_TRGLOC, [eta], om)[:, 0]
+    t2 = ref(so2)
+    assert np.abs(b1 - t2).max() <= 1e-10 * np.abs(t2).max() and np.abs(b1 - a1).max() > 1e-6 * np.abs(t).max()
+    extra, _ = rand_series(rng, (3, 3), n, hermitian=False)
+    c3 = c2 + 0.05 / np.sqrt(n) * extra
+    s.device().update(c3)
+    rule.rebuild()
+    so3 = orc.FourierSeries(c3, period=1.0, first=first, ndim=2)
+    e1 = rule.reduce(L.F_TRGLOC, [eta], om)[:, 0]
+    t3 = ref(so3)
+    assert np.abs(e1 - t3).max() <= 1e-10 * np.abs(t3).max()
+    rule.close()
+
+
 def test_more_than_64_bands_is_an_argument_error(abz):
     rng = np.random.default_rng(65)
     c, first = rand_series(rng, (3,), 65, hermitian=True)
