@@ -1145,6 +1145,31 @@ def test_more_than_32_bands_cached_tridiagonal_follows_the_values(abz):
     rule.close()
 
 
+@pytest.mark.parametrize("n", [20, 40])
+def test_autoptr_many_bands_through_the_library_loop(abz, n):
+    """AutoPTR on 20- and 40-band models (kept rules, repeated scans of the same rule -- above 32 bands through its cached
+    tridiagonal forms --, full BZ and inversion-symmetric zone), DOS, tr G and the matrix-valued G against the oracle's
+    autosymptr: equal numevals, values to 1e-10.  ref: src/algorithms.jl:418-432"""
+    rng = np.random.default_rng(900 + n)
+    c, first = rand_series(rng, (3, 3), n, hermitian=True)
+    s, so = both(abz, c / np.sqrt(n), first)
+    eta, seq = 0.4, dict(nmin=4, nmax=40, n0=6.0, dn=4.0)
+    for kind, bzk in (("FBZ", abz.FBZ()), ("InversionSymIBZ", abz.InversionSymIBZ())):
+        bz, bzo = abz.load_bz(bzk, np.eye(2)), orc.load_bz(kind, np.eye(2))
+        alg = abz.AutoPTR(a=1.0, **seq)
+        for fi, fo in ((abz.DOSIntegrand(), lambda om: orc.f_dos(eta, om)),
+                       (abz.TrGlocIntegrand(), lambda om: (lambda x, h: np.trace(orc.f_gloc(eta, om)(x, h), axis1=-2, axis2=-1))),
+                       (abz.GlocIntegrand(), lambda om: orc.f_gloc(eta, om))):
+            if kind != "FBZ" and isinstance(fi, abz.GlocIntegrand):
+                continue  # (a matrix-valued integrand without a SymRep is repeated on the full zone: src/brillouin.jl:76-108)
+            f = abz.FourierIntegrand(fi, s, eta)
+            for om in (-0.3, 0.2, 0.7):  # (the second and third solves scan rules the first one left behind)
+                got = abz.solve(abz.IntegralProblem(f, bz, abz.MixedParameters(om)), abz.EvalCounter(alg), abstol=1e-3)
+                ref = orc.solve_autoptr(so, bzo, fo(om), abstol=1e-3, **seq)
+                assert got.numevals == ref.numevals, (kind, type(fi).__name__, om)
+                assert np.abs(np.asarray(got.u) - ref.u).max() <= 1e-10 * np.abs(ref.u).max(), (kind, type(fi).__name__, om)
+
+
 def test_more_than_64_bands_is_an_argument_error(abz):
     rng = np.random.default_rng(65)
     c, first = rand_series(rng, (3,), 65, hermitian=True)
