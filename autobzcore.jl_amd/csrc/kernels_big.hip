@@ -671,17 +671,20 @@ struct BigInvArgs {
 };
 // One block of four pivots c = 4 CQ ... 4 CQ + 3 of the register-resident Gauss-Jordan (big_inverse_kernel).  Column c -- the
 // f = A(r, c) of every row -- lives in wave c & 3 and reaches the other waves through LDS (two rooms in turn, one barrier per
-// pivot); row c -- A(c, j) of this wave's sixteen columns -- lives in lane c of THIS wave: v_readlane, scalar operands of the FMAs.
-template <int NQ, int CQ>
-__device__ __forceinline__ void big_inv_pivot4(int n, int r, int jq, double2 (*colb)[64], double2 (&W)[NQ]) {
+// pivot); row c -- A(c, j) of this wave's sixteen columns -- lives in lane c of THIS wave: v_readlane, scalar operands of the FMAs
+// (SUBS = 2, two nodes of <= 32 bands side by side in the halves of every wave: lane c of the lane's own half, a shuffle).
+template <int NQ, int CQ, int SUBS>
+__device__ __forceinline__ void big_inv_pivot4(int n, int lane, int r, int jq, double2 (*colb)[64], double2 (&W)[NQ]) {
+    constexpr int LW = 64 / SUBS;
 #pragma unroll 1
     for (int cm = 0; cm < 4; ++cm) {
         const int c = 4 * CQ + cm;
         if (c >= n) break;  // uniform
         const int pb = c & 1;
-        if (jq == cm) colb[pb][r] = W[CQ];
+        if (jq == cm) colb[pb][lane] = W[CQ];
         __syncthreads();
-        const double2 p = colb[pb][c], f = colb[pb][r];
+        const int lc = (lane & ~(LW - 1)) + c;  // the lane that holds row c of this lane's node
+        const double2 p = colb[pb][lc], f = colb[pb][lane];
         const double ipn = 1.0 / (p.x * p.x + p.y * p.y);
         const double ipr = p.x * ipn, ipi = -p.y * ipn;  // 1 / pivot
         const bool prow = r == c;
@@ -690,26 +693,36 @@ __device__ __forceinline__ void big_inv_pivot4(int n, int r, int jq, double2 (*c
         const double fr = prow ? -ipr : qr, fi = prow ? -ipi : qi;
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
-            const double gx = brl(W[q].x, c), gy = brl(W[q].y, c);  // A(c, jq + 4 q) before the step
+            double gx, gy;  // A(c, jq + 4 q) before the step
+            if constexpr (SUBS == 1) {
+                gx = brl(W[q].x, c);
+                gy = brl(W[q].y, c);
+            } else {
+                gx = __shfl(W[q].x, lc, 64);
+                gy = __shfl(W[q].y, lc, 64);
+            }
             const double ox = prow ? 0.0 : W[q].x, oy = prow ? 0.0 : W[q].y;
             W[q] = make_double2(ox - (fr * gx - fi * gy), oy - (fr * gy + fi * gx));
         }
         if (jq == cm) W[CQ] = prow ? make_double2(ipr, ipi) : make_double2(-qr, -qi);  // the pivot column: -f / p, the pivot 1 / p
     }
 }
-template <int NQ, int... CQ>
-__device__ __forceinline__ void big_inv_pivots(int n, int r, int jq, double2 (*colb)[64], double2 (&W)[NQ], std::integer_sequence<int, CQ...>) {
-    ((void)((4 * CQ < n) ? (big_inv_pivot4<NQ, CQ>(n, r, jq, colb, W), 0) : 0), ...);
+template <int NQ, int SUBS, int... CQ>
+__device__ __forceinline__ void big_inv_pivots(int n, int lane, int r, int jq, double2 (*colb)[64], double2 (&W)[NQ],
+                                               std::integer_sequence<int, CQ...>) {
+    ((void)((4 * CQ < n) ? (big_inv_pivot4<NQ, CQ, SUBS>(n, lane, r, jq, colb, W), 0) : 0), ...);
 }
 
-// NQ: column groups of four the instance holds (n <= 4 NQ)
-template <int NQ>
+// NQ: column groups of four the instance holds (n <= 4 NQ); SUBS: nodes side by side in a wave (2: n <= 32, rows in 32 lanes)
+template <int NQ, int SUBS>
 __global__ __launch_bounds__(256) void big_inverse_kernel(BigInvArgs a) {
-    // The matrix lives in REGISTERS: lane r of wave jq holds the entries (r, jq + 4 q), q = 0 ... 15 (big_inv_pivot4 above).
+    // The matrix lives in REGISTERS: lane r of wave jq holds the entries (r, jq + 4 q), q < NQ (big_inv_pivot4 above).
+    static_assert(SUBS == 1 || 4 * NQ <= 32, "two nodes per wave: 32 lanes of rows each");
+    constexpr int LW = 64 / SUBS;
     __shared__ double2 colb[2][64];
-    __shared__ double2 trb[4];
+    __shared__ double2 trb[4][2];
     const int n = a.n, nn = n * n, tid = threadIdx.x;
-    const int r = tid & 63, jq = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63, r = lane & (LW - 1), sub = lane / LW, jq = __builtin_amdgcn_readfirstlane(tid >> 6);
     const bool rowon = r < n;
     const int ncomp = a.kind == 0 ? nn : 1;
     const bool sum = a.partial != nullptr;
@@ -717,25 +730,28 @@ __global__ __launch_bounds__(256) void big_inverse_kernel(BigInvArgs a) {
     const int64_t k1 = sum ? min(a.nnodes, k0 + a.nodes_per_block) : a.nnodes;
     const int64_t kstep = sum ? 1 : gridDim.x;
     for (int s = 0; s < a.n_sweep; ++s) {
-        double2 acc[NQ];  // sum mode: the weighted sum of this thread's entries, or the trace in acc[0] of thread 0
+        double2 acc[NQ];  // sum mode: the weighted sum of this thread's entries, or the trace in acc[0] of the node's first lane
 #pragma unroll
         for (int q = 0; q < NQ; ++q) acc[q] = make_double2(0.0, 0.0);
-        for (int64_t k = k0; k < k1; k += kstep) {
-            const double sw = a.sweep_per_node ? a.sweep_per_node[a.node0 + k] : (a.sweep ? a.sweep[s] : a.sweep0);
-            const double2* __restrict__ h = a.Hbuf + k * (int64_t)nn;
+        for (int64_t kb = k0; kb < k1; kb += kstep * SUBS) {
+            const int64_t k = kb + sub * kstep;
+            const bool valid = k < k1;  // (the second half of a wave may be without a node: it inverts z I)
+            const int64_t kk = valid ? k : kb;
+            const double sw = a.sweep_per_node ? a.sweep_per_node[a.node0 + kk] : (a.sweep ? a.sweep[s] : a.sweep0);
+            const double2* __restrict__ h = a.Hbuf + kk * (int64_t)nn;
             double2 W[NQ];
 #pragma unroll
             for (int q = 0; q < NQ; ++q) {
                 const int j = jq + 4 * q;
                 W[q] = make_double2(0.0, 0.0);
                 if (rowon && j < n) {
-                    const double2 hv = h[r + n * j];
+                    const double2 hv = valid ? h[r + n * j] : make_double2(0.0, 0.0);
                     W[q] = make_double2((r == j ? sw : 0.0) - hv.x, (r == j ? a.eta : 0.0) - hv.y);
                 }
             }
             // pivots c = 4 cq + cm: cq unrolled (the entry of column c in its wave's registers is W[cq], a static index), cm rolled
-            big_inv_pivots<NQ>(n, r, jq, colb, W, std::make_integer_sequence<int, NQ>());
-            const double wk = sum ? (a.w ? a.w[a.node0 + k] : 1.0) : 1.0;
+            big_inv_pivots<NQ, SUBS>(n, lane, r, jq, colb, W, std::make_integer_sequence<int, NQ>());
+            const double wk = (sum && valid) ? (a.w ? a.w[a.node0 + k] : 1.0) : (valid ? 1.0 : 0.0);
             if (a.kind == 0) {
                 if (sum) {
 #pragma unroll
@@ -743,7 +759,7 @@ __global__ __launch_bounds__(256) void big_inverse_kernel(BigInvArgs a) {
                         acc[q].x = fma(wk, W[q].x, acc[q].x);
                         acc[q].y = fma(wk, W[q].y, acc[q].y);
                     }
-                } else if (rowon) {
+                } else if (rowon && valid) {
                     double2* __restrict__ vo = a.values + ((a.node0 + k) * a.n_sweep + s) * (int64_t)nn;
 #pragma unroll
                     for (int q = 0; q < NQ; ++q) {
@@ -752,7 +768,7 @@ __global__ __launch_bounds__(256) void big_inverse_kernel(BigInvArgs a) {
                     }
                 }
             } else {
-                // the diagonal entry (r, r) sits in wave r & 3 at q = r >> 2: partial traces per wave, met in LDS
+                // the diagonal entry (r, r) sits in wave r & 3 at q = r >> 2: partial traces per wave and node, met in LDS
                 double tr = 0.0, ti = 0.0;
 #pragma unroll
                 for (int q = 0; q < NQ; ++q) {
@@ -760,13 +776,16 @@ __global__ __launch_bounds__(256) void big_inverse_kernel(BigInvArgs a) {
                     tr += d ? W[q].x : 0.0;
                     ti += d ? W[q].y : 0.0;
                 }
-                tr = bwsum(tr);
-                ti = bwsum(ti);
-                if (r == 0) trb[jq] = make_double2(tr, ti);
+#pragma unroll
+                for (int off = LW / 2; off > 0; off >>= 1) {
+                    tr += __shfl_xor(tr, off, 64);
+                    ti += __shfl_xor(ti, off, 64);
+                }
+                if (r == 0) trb[jq][sub] = make_double2(tr, ti);
                 __syncthreads();
-                if (tid == 0) {
-                    tr = (trb[0].x + trb[1].x) + (trb[2].x + trb[3].x);
-                    ti = (trb[0].y + trb[1].y) + (trb[2].y + trb[3].y);
+                if (jq == 0 && r == 0) {
+                    tr = (trb[0][sub].x + trb[1][sub].x) + (trb[2][sub].x + trb[3][sub].x);
+                    ti = (trb[0][sub].y + trb[1][sub].y) + (trb[2][sub].y + trb[3][sub].y);
                     if (a.kind == 2) {
                         tr = -ti * 0.31830988618379067153776752674503;
                         ti = 0.0;
@@ -774,7 +793,7 @@ __global__ __launch_bounds__(256) void big_inverse_kernel(BigInvArgs a) {
                     if (sum) {
                         acc[0].x = fma(wk, tr, acc[0].x);
                         acc[0].y = fma(wk, ti, acc[0].y);
-                    } else {
+                    } else if (valid) {
                         a.values[(a.node0 + k) * a.n_sweep + s] = make_double2(tr, ti);
                     }
                 }
@@ -783,11 +802,18 @@ __global__ __launch_bounds__(256) void big_inverse_kernel(BigInvArgs a) {
         }
         if (sum) {
             double2* __restrict__ po = a.partial + ((int64_t)blockIdx.x * a.n_sweep + s) * ncomp;
+            if constexpr (SUBS == 2) {  // the two nodes' sums of the same entries
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) {
+                    acc[q].x += __shfl_xor(acc[q].x, 32, 64);
+                    acc[q].y += __shfl_xor(acc[q].y, 32, 64);
+                }
+            }
             if (a.kind == 0) {
 #pragma unroll
                 for (int q = 0; q < NQ; ++q) {
                     const int j = jq + 4 * q;
-                    if (rowon && j < n) {
+                    if (rowon && sub == 0 && j < n) {
                         po[r + n * j].x += acc[q].x;
                         po[r + n * j].y += acc[q].y;
                     }
@@ -849,22 +875,23 @@ int big_tridiag(abz_ctx* ctx, const BigWork& w, int n, int64_t cn, double2* keep
 }
 
 static int big_inverse(abz_ctx* ctx, BigInvArgs& ia, int64_t blocks) {
+    if (ia.n <= 32 && !ia.partial) blocks = std::max<int64_t>(1, std::min<int64_t>(blocks, (ia.nnodes + 1) / 2));  // (two nodes per workgroup pass)
     if (ia.n <= 20)
-        hipLaunchKernelGGL(big_inverse_kernel<5>, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, ia);
+        hipLaunchKernelGGL((big_inverse_kernel<5, 2>), dim3((unsigned)blocks), dim3(256), 0, ctx->stream, ia);
     else if (ia.n <= 24)
-        hipLaunchKernelGGL(big_inverse_kernel<6>, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, ia);
+        hipLaunchKernelGGL((big_inverse_kernel<6, 2>), dim3((unsigned)blocks), dim3(256), 0, ctx->stream, ia);
     else if (ia.n <= 28)
-        hipLaunchKernelGGL(big_inverse_kernel<7>, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, ia);
+        hipLaunchKernelGGL((big_inverse_kernel<7, 2>), dim3((unsigned)blocks), dim3(256), 0, ctx->stream, ia);
     else if (ia.n <= 32)
-        hipLaunchKernelGGL(big_inverse_kernel<8>, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, ia);
+        hipLaunchKernelGGL((big_inverse_kernel<8, 2>), dim3((unsigned)blocks), dim3(256), 0, ctx->stream, ia);
     else if (ia.n <= 40)
-        hipLaunchKernelGGL(big_inverse_kernel<10>, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, ia);
+        hipLaunchKernelGGL((big_inverse_kernel<10, 1>), dim3((unsigned)blocks), dim3(256), 0, ctx->stream, ia);
     else if (ia.n <= 48)
-        hipLaunchKernelGGL(big_inverse_kernel<12>, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, ia);
+        hipLaunchKernelGGL((big_inverse_kernel<12, 1>), dim3((unsigned)blocks), dim3(256), 0, ctx->stream, ia);
     else if (ia.n <= 56)
-        hipLaunchKernelGGL(big_inverse_kernel<14>, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, ia);
+        hipLaunchKernelGGL((big_inverse_kernel<14, 1>), dim3((unsigned)blocks), dim3(256), 0, ctx->stream, ia);
     else
-        hipLaunchKernelGGL(big_inverse_kernel<16>, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, ia);
+        hipLaunchKernelGGL((big_inverse_kernel<16, 1>), dim3((unsigned)blocks), dim3(256), 0, ctx->stream, ia);
     ABZ_HIP(hipGetLastError());
     return ABZ_OK;
 }
