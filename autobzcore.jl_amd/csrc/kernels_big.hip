@@ -15,7 +15,7 @@
 //                          thread per (node, swept value): node values (IAI) or weighted partial sums (rules, store-free sums).
 // Serves abz_eval_nodes, rule builds (H and / or eigenvalues, full layout), scans of cached rules (DOS / tr G from the
 // matrices or the eigenvalues), store-free PTR sums and the IAI node path; big_inverse_kernel (one workgroup per node, Gauss-
-// Jordan in LDS) adds matrix-valued G and the traces of series that are not Hermitian; GGR builds (eigenvalues + band
+// Jordan in registers) adds matrix-valued G and the traces of series that are not Hermitian; GGR builds (eigenvalues + band
 // velocities): launch_big_ggr below with kernels_big_vec.hip.  Only the Hermitian-compact layout stays at <= 32 bands.
 #include <utility>
 
@@ -650,12 +650,12 @@ __global__ __launch_bounds__(256) void big_accumulate_kernel(double2* __restrict
     }
 }
 
-// inv((w + i eta) I - H) of a node, ONE WORKGROUP PER NODE: the matrix in LDS, Gauss-Jordan in place without pivoting (what the
-// <= 32-band kernels do: for Hermitian H the matrix is eta I plus a skew-Hermitian part times i -- no small pivots; a general H
-// gets no more here than there).  Per pivot c: column c and the scaled row c go to two buffers, then every thread updates its
-// share of the n^2 entries: two barriers per pivot.  Serves what the tridiagonal cannot: matrix-valued G (ABZ_F_GLOC) and the
-// traces of series that are not Hermitian.  Node mode: values[node][swept value][component]; sum mode: every workgroup adds the
-// weighted values of its nodes (registers) and leaves partial[block][swept value][component] for launch_final_reduce.
+// inv((w + i eta) I - H) of a node, ONE WORKGROUP OF FOUR WAVES PER NODE (two nodes up to 32 bands), the matrix in registers,
+// Gauss-Jordan in place without pivoting (what the <= 32-band kernels do: for Hermitian H the matrix is eta I plus a skew-
+// Hermitian part times i -- no small pivots; a general H gets no more here than there); big_inv_pivot4 below has the step.
+// Serves what the tridiagonal cannot: matrix-valued G (ABZ_F_GLOC) and the traces of series that are not Hermitian.  Node mode:
+// values[node][swept value][component]; sum mode: every workgroup adds the weighted values of its nodes (registers) and leaves
+// partial[block][swept value][component] for launch_final_reduce.
 struct BigInvArgs {
     const double2* Hbuf;  // [nnodes][n n] of this chunk
     int64_t node0, nnodes;
