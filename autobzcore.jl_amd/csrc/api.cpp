@@ -81,7 +81,7 @@ const SwitchDef g_switches[SW_COUNT] = {
     {"ABZ_LANE_KERNELS", 1, "0: 5...8-band rule builds / store-free sums on full grids through the 8-lane row kernels (test: same values)"},
     {"ABZ_BIG_MFMA", 0, "1: 33...64 bands: the level-1 evaluation of full grid lines as a real GEMM on v_mfma_f64_16x16x4_f64 (test: same values)"},
     {"ABZ_BIG_CHUNK_MB", 0, "33...64 bands: MB of scratch for the matrices of a chunk of nodes (0: 256, GGR builds 2048; tests set 1 to walk many chunks)"},
-    {"ABZ_BIG_TRI_WAVES", 0, "33...64 bands: waves per node of the Householder tridiagonalisation (1, 2, 4: the same reflectors, another summation order; 0: four above 48 bands, else one)"},
+    {"ABZ_BIG_TRI_WAVES", 0, "33...64 bands: waves per node of the Householder tridiagonalisation (1, 2, 4: the same reflectors, another summation order; 0: two up to 44 bands, one up to 48, four above)"},
     {"ABZ_EIG_FOLD", 1, "0: 5...16-band rule builds evaluate the full level-1 series of a Hermitian model instead of the folded one"},
     {"ABZ_EIG_SPLIT", 1, "0: eigenvalues of 5...16-band rules by bisection inside the grid kernel instead of the per-lane QR kernel"},
     {"ABZ_IAI_LANES", 4, "lanes (host thread + stream each) a sweep of independent IAI solves is split over; 1: off"},

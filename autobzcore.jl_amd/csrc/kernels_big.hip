@@ -853,11 +853,11 @@ int big_tridiag(abz_ctx* ctx, const BigWork& w, int n, int64_t cn, double2* keep
                 int64_t t0 = 0) {
     double* const tri = tri_to ? tri_to : w.tri;
     const int64_t tri_nk = tri_to ? tri_nk_to : w.tri_nk;
-    // one wave per node while the CU holds seven matrices or more (<= 48 bands); four above (24^3 nodes, H + eig with one / two /
-    // four waves: 64 bands 11.0 / 8.4 / 7.8 ms, 56 bands 7.6 / 6.0 / 5.9, 52 bands 6.6 / 5.3 / 5.3, 48 bands 3.83 / 3.97 / 4.15,
-    // 40 bands 2.87 / 2.61 / 3.16, 33 bands 1.64 / 1.57 / 1.98)
+    // two waves per node up to 44 bands, one up to 48, four above (24^3 nodes, H + eig with one / two / four waves: 64 bands
+    // 11.0 / 8.4 / 7.8 ms, 56 bands 7.6 / 6.0 / 5.9, 52 bands 6.6 / 5.3 / 5.3, 48 bands 3.83 / 4.01 / 4.15, 46 bands 3.47 / 3.55,
+    // 44 bands 3.31 / 2.97, 40 bands 2.83 / 2.59 / 3.16, 36 bands 2.37 / 2.22, 33 bands 1.66 / 1.57 / 1.98)
     const int sw = abz_switch(SW_BIG_TRI_WAVES);
-    const int nw = sw > 0 ? sw : (n > 48 ? 4 : 1);
+    const int nw = sw > 0 ? sw : (n > 48 ? 4 : (n <= 44 ? 2 : 1));
     const size_t lds = sizeof(double2) * ((size_t)n * (n + 1) / 2 + 2 * (size_t)n + (nw > 1 ? 64 * (size_t)nw : 0));
     const int64_t blocks = std::min<int64_t>(cn, 256 * 8);
     if (nw >= 4) {
