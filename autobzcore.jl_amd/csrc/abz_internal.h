@@ -540,6 +540,7 @@ struct SumSpec {
     const double* sweep_host;
     double params[4];
     double scale;
+    bool herm = true;  // the series is Hermitian (n > 16: a series that is not goes through the inverse of every node)
 };
 
 bool eval_sum_supported(int n, int M, int npt, int integrand, bool herm);

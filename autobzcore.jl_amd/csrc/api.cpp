@@ -1580,6 +1580,7 @@ int abz_ptr_sum(abz_series* s, int npt, int outer_begin, int outer_end, int inte
     ss.line0 = (int64_t)(d >= 2 ? outer_begin : 0);
     for (int j = 0; j + 2 < d; ++j) ss.line0 *= npt;  // lines per outer index: npt^(d-2)
     ss.integrand = integrand;
+    ss.herm = s->hermitian;
     ss.n_sweep = n_sweep;
     ss.sweep_host = sweep;
     for (int i = 0; i < 4; ++i) ss.params[i] = (i < nparams && params) ? params[i] : 0.0;

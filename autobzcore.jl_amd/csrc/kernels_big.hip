@@ -1133,7 +1133,9 @@ __global__ __launch_bounds__(256) void big_scale_kernel(double2* v, int n, doubl
 }
 
 bool big_sum_supported(int n, int M, int npt, int integrand, bool herm) {
-    return big_supported(n) && herm && M <= 64 && npt >= 1 && npt < 65536 && (integrand == ABZ_F_DOS || integrand == ABZ_F_TRGLOC);
+    if (M > 64 || npt < 1 || npt >= 65536) return false;
+    if (big_inverse_wanted(n, integrand, herm)) return true;  // G, or a series that is not Hermitian: n > 16, the inverse of every node
+    return big_supported(n) && herm && (integrand == ABZ_F_DOS || integrand == ABZ_F_TRGLOC);
 }
 
 // store-free PTR sums (abz_ptr_sum)
@@ -1160,6 +1162,47 @@ int launch_big_sum(abz_ctx* ctx, const SumSpec& ss, double* out_reim) {
     sa.grid = 1;
     sa.inv_period = 1.0;
     sa.Hbuf = w.Hbuf;
+    if (big_inverse_wanted(ss.n, ss.integrand, ss.herm)) {
+        // matrix-valued G, or a series that is not Hermitian: H(k) of a chunk, the inverse of every node, weighted sums in registers;
+        // a group of swept values per pass (the workgroups' partial sums stay under 256 MB), the chunks re-evaluated per group
+        const int nn = ss.n * ss.n, kind = big_inv_kind(ss.integrand);
+        const int64_t ncomp = kind == 0 ? nn : 1;
+        const int64_t blocks = std::max<int64_t>(1, std::min<int64_t>(nnodes, 256 * 2));
+        const int group = (int)std::max<int64_t>(1, std::min<int64_t>(ss.n_sweep, (256ll << 20) / (int64_t)(sizeof(double2) * blocks * ncomp)));
+        if ((rc = ctx->scratch[1].reserve(sizeof(double2) * (size_t)(blocks * group * ncomp)))) return rc;
+        if ((rc = ctx->scratch[2].reserve(sizeof(double2) * (size_t)(group * ncomp)))) return rc;
+        double2* partial = ctx->scratch[1].as<double2>();
+        double2* outd = ctx->scratch[2].as<double2>();
+        ProfScope ps(ctx, ABZ_K_EVAL);
+        for (int s0 = 0; s0 < ss.n_sweep; s0 += group) {
+            const int ns = std::min(group, ss.n_sweep - s0);
+            ABZ_HIP(hipMemsetAsync(partial, 0, sizeof(double2) * (size_t)(blocks * ns * ncomp), ctx->stream));
+            for (int64_t c0 = 0; c0 < nnodes; c0 += w.chunk) {
+                const int64_t cn = std::min(w.chunk, nnodes - c0);
+                if ((rc = big_series(ctx, sa, c0, cn))) return rc;
+                BigInvArgs ia;
+                ia.Hbuf = w.Hbuf;
+                ia.node0 = c0;
+                ia.nnodes = cn;
+                ia.n = ss.n;
+                ia.n_sweep = ns;
+                ia.kind = kind;
+                ia.eta = ss.params[0];
+                ia.sweep = sw + s0;
+                ia.sweep_per_node = nullptr;
+                ia.sweep0 = 0.0;
+                ia.w = nullptr;
+                ia.values = nullptr;
+                ia.partial = partial;
+                ia.nodes_per_block = (int)cdivb(cn, blocks);
+                if ((rc = big_inverse(ctx, ia, cdivb(cn, ia.nodes_per_block)))) return rc;
+            }
+            if ((rc = launch_final_reduce(ctx, partial, blocks, (int64_t)ns * ncomp, ss.scale, outd))) return rc;
+            ABZ_HIP(hipMemcpyAsync(out_reim + 2 * (size_t)s0 * ncomp, outd, sizeof(double2) * (size_t)ns * ncomp, hipMemcpyDeviceToHost, ctx->stream));
+            ABZ_HIP(hipStreamSynchronize(ctx->stream));
+        }
+        return ABZ_OK;
+    }
     ProfScope ps(ctx, ABZ_K_EVAL);
     for (int64_t c0 = 0; c0 < nnodes; c0 += w.chunk) {
         const int64_t cn = std::min(w.chunk, nnodes - c0);

@@ -257,6 +257,10 @@ def test_rule_reduce_non_hermitian_series(abz, n):
     got = rule.reduce(abz._lib.F_DOS, [eta], omegas)[:, 0].real
     tr = rule.reduce(abz._lib.F_TRGLOC, [eta], omegas)[:, 0]
     g = rule.reduce(abz._lib.F_GLOC, [eta], omegas[:1])
+    if n > 16:  # store-free sums through the inverse of every node (kernels_big.hip)
+        gsf = s.device().ptr_sum(9, abz._lib.F_GLOC, [eta], omegas[:1])
+        dsf = s.device().ptr_sum(9, abz._lib.F_DOS, [eta], omegas)[:, 0].real
+        assert np.abs(gsf - g).max() <= 1e-11 * np.abs(g).max() and np.abs(dsf - got).max() <= 1e-11 * np.abs(got).max()
     for i, om in enumerate(omegas):
         ref, _ = orc._ptr_rule_sum(so, 9, None, orc.f_gloc(eta, om))
         assert abs(tr[i] - np.trace(ref)) <= 1e-11 * abs(np.trace(ref))
@@ -1080,10 +1084,14 @@ def test_more_than_32_bands_matrix_valued_and_non_hermitian(abz, n):
         g = rule.reduce(L.F_GLOC, [eta], omegas)
         tr = rule.reduce(L.F_TRGLOC, [eta], omegas)[:, 0]
         dos = rule.reduce(L.F_DOS, [eta], omegas)[:, 0].real
+        assert s.device().ptr_sum_supported(npt, L.F_GLOC) and s.device().ptr_sum_supported(npt, L.F_TRGLOC)
+        gsf = s.device().ptr_sum(npt, L.F_GLOC, [eta], omegas)  # store-free: no rule, the inverse of every node of a chunk
+        tsf = s.device().ptr_sum(npt, L.F_TRGLOC, [eta], omegas)[:, 0]
         for i in range(len(omegas)):
             t = np.trace(refs[i])
             assert np.abs(g[i].reshape(n, n).T - refs[i]).max() <= 1e-10 * np.abs(refs[i]).max(), herm
-            assert abs(tr[i] - t) <= 1e-10 * abs(t), herm
+            assert np.abs(gsf[i].reshape(n, n).T - refs[i]).max() <= 1e-10 * np.abs(refs[i]).max(), herm
+            assert abs(tr[i] - t) <= 1e-10 * abs(t) and abs(tsf[i] - t) <= 1e-10 * abs(t), herm
             assert abs(dos[i] + t.imag / np.pi) <= 1e-10 * abs(t), herm
         rule.close()
         bzo = orc.load_bz("InversionSymIBZ", np.eye(2))
