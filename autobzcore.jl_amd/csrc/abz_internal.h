@@ -562,7 +562,8 @@ int launch_lane_sum(abz_ctx* ctx, const SumSpec& ss, double* out_reim);
 bool lane_scan_supported(const ReduceSpec& rs);
 int launch_lane_scan(abz_ctx* ctx, const ReduceSpec& rs, double* out_reim);
 bool big_supported(int n);
-bool big_inverse_wanted(int n, int integrand, bool herm);  // 17...64 bands: G / traces through big_inverse_kernel
+bool big_inverse_wanted(int n, int integrand, bool herm);  // 5...64 bands: G / traces through big_inverse_kernel (scans, node values)
+bool big_inverse_sum_wanted(int n, int integrand, bool herm);  // ... store-free sums
 bool big_sum_supported(int n, int M, int npt, int integrand, bool herm);
 int launch_big_nodes(abz_ctx* ctx, const GenSpec& gs);
 int launch_big_sum(abz_ctx* ctx, const SumSpec& ss, double* out_reim);

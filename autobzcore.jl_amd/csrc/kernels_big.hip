@@ -672,7 +672,7 @@ struct BigInvArgs {
 // One block of four pivots c = 4 CQ ... 4 CQ + 3 of the register-resident Gauss-Jordan (big_inverse_kernel).  Column c -- the
 // f = A(r, c) of every row -- lives in wave c & 3 and reaches the other waves through LDS (two rooms in turn, one barrier per
 // pivot); row c -- A(c, j) of this wave's sixteen columns -- lives in lane c of THIS wave: v_readlane, scalar operands of the FMAs
-// (SUBS = 2, two nodes of <= 32 bands side by side in the halves of every wave: lane c of the lane's own half, a shuffle).
+// (SUBS = 2, 4, 8: that many nodes of <= 32, 16, 8 bands side by side in every wave: lane c of the lane's own part, a shuffle).
 template <int NQ, int CQ, int SUBS>
 __device__ __forceinline__ void big_inv_pivot4(int n, int lane, int r, int jq, double2 (*colb)[64], double2 (&W)[NQ]) {
     constexpr int LW = 64 / SUBS;
@@ -717,10 +717,10 @@ __device__ __forceinline__ void big_inv_pivots(int n, int lane, int r, int jq, d
 template <int NQ, int SUBS>
 __global__ __launch_bounds__(256) void big_inverse_kernel(BigInvArgs a) {
     // The matrix lives in REGISTERS: lane r of wave jq holds the entries (r, jq + 4 q), q < NQ (big_inv_pivot4 above).
-    static_assert(SUBS == 1 || 4 * NQ <= 32, "two nodes per wave: 32 lanes of rows each");
+    static_assert(4 * NQ <= 64 / SUBS, "SUBS nodes per wave: 64 / SUBS lanes of rows each");
     constexpr int LW = 64 / SUBS;
     __shared__ double2 colb[2][64];
-    __shared__ double2 trb[4][2];
+    __shared__ double2 trb[4][8];
     const int n = a.n, nn = n * n, tid = threadIdx.x;
     const int lane = tid & 63, r = lane & (LW - 1), sub = lane / LW, jq = __builtin_amdgcn_readfirstlane(tid >> 6);
     const bool rowon = r < n;
@@ -802,11 +802,14 @@ __global__ __launch_bounds__(256) void big_inverse_kernel(BigInvArgs a) {
         }
         if (sum) {
             double2* __restrict__ po = a.partial + ((int64_t)blockIdx.x * a.n_sweep + s) * ncomp;
-            if constexpr (SUBS == 2) {  // the two nodes' sums of the same entries
+            if constexpr (SUBS > 1) {  // the nodes' sums of the same entries
 #pragma unroll
                 for (int q = 0; q < NQ; ++q) {
-                    acc[q].x += __shfl_xor(acc[q].x, 32, 64);
-                    acc[q].y += __shfl_xor(acc[q].y, 32, 64);
+#pragma unroll
+                    for (int off = LW; off < 64; off <<= 1) {
+                        acc[q].x += __shfl_xor(acc[q].x, off, 64);
+                        acc[q].y += __shfl_xor(acc[q].y, off, 64);
+                    }
                 }
             }
             if (a.kind == 0) {
@@ -875,8 +878,17 @@ int big_tridiag(abz_ctx* ctx, const BigWork& w, int n, int64_t cn, double2* keep
 }
 
 static int big_inverse(abz_ctx* ctx, BigInvArgs& ia, int64_t blocks) {
-    if (ia.n <= 32 && !ia.partial) blocks = std::max<int64_t>(1, std::min<int64_t>(blocks, (ia.nnodes + 1) / 2));  // (two nodes per workgroup pass)
-    if (ia.n <= 20)
+    if (ia.n <= 32 && !ia.partial) {  // (several nodes per workgroup pass)
+        const int subs = ia.n <= 8 ? 8 : (ia.n <= 16 ? 4 : 2);
+        blocks = std::max<int64_t>(1, std::min<int64_t>(blocks, (ia.nnodes + subs - 1) / subs));
+    }
+    if (ia.n <= 8)
+        hipLaunchKernelGGL((big_inverse_kernel<2, 8>), dim3((unsigned)blocks), dim3(256), 0, ctx->stream, ia);
+    else if (ia.n <= 12)
+        hipLaunchKernelGGL((big_inverse_kernel<3, 4>), dim3((unsigned)blocks), dim3(256), 0, ctx->stream, ia);
+    else if (ia.n <= 16)
+        hipLaunchKernelGGL((big_inverse_kernel<4, 4>), dim3((unsigned)blocks), dim3(256), 0, ctx->stream, ia);
+    else if (ia.n <= 20)
         hipLaunchKernelGGL((big_inverse_kernel<5, 2>), dim3((unsigned)blocks), dim3(256), 0, ctx->stream, ia);
     else if (ia.n <= 24)
         hipLaunchKernelGGL((big_inverse_kernel<6, 2>), dim3((unsigned)blocks), dim3(256), 0, ctx->stream, ia);
@@ -920,10 +932,15 @@ int big_series(abz_ctx* ctx, BigSeriesArgs& sa, int64_t c0, int64_t cn) {
 
 bool big_supported(int n) { return n > 32 && n <= ABZ_MAX_BANDS; }
 
-// 17...32 bands borrow big_inverse_kernel for what their row kernels do not serve (the wave-per-node Gauss-Jordan in LDS took
-// 21 ms for a 4-omega G scan of 24^3 nodes at 32 bands; 3.8 ms at 33 bands here): matrix-valued G and series that are not Hermitian
+// 5...32 bands borrow big_inverse_kernel for what their row kernels do not serve (the wave-per-node Gauss-Jordan in LDS took
+// 21 ms for a 4-omega G scan of 24^3 nodes at 32 bands; 3.8 ms at 33 bands here): series that are not Hermitian, and from 17
+// bands on the matrix-valued G (up to 16 bands the 16-lane row kernel inverts in registers)
 bool big_inverse_wanted(int n, int integrand, bool herm) {
-    return n > 16 && n <= ABZ_MAX_BANDS && big_inv_kind(integrand) >= 0 && (integrand == ABZ_F_GLOC || !herm);
+    return n > 4 && n <= ABZ_MAX_BANDS && big_inv_kind(integrand) >= 0 && (!herm || (integrand == ABZ_F_GLOC && n > 16));
+}
+// store-free sums have no row kernel for G at all: 5 bands and more
+bool big_inverse_sum_wanted(int n, int integrand, bool herm) {
+    return n > 4 && n <= ABZ_MAX_BANDS && big_inv_kind(integrand) >= 0 && (!herm || integrand == ABZ_F_GLOC);
 }
 
 // GGR builds (eigenvalues + band velocities, nothing else stored): chunk by chunk H -> tridiagonal with the reflectors kept ->
@@ -1134,7 +1151,7 @@ __global__ __launch_bounds__(256) void big_scale_kernel(double2* v, int n, doubl
 
 bool big_sum_supported(int n, int M, int npt, int integrand, bool herm) {
     if (M > 64 || npt < 1 || npt >= 65536) return false;
-    if (big_inverse_wanted(n, integrand, herm)) return true;  // G, or a series that is not Hermitian: n > 16, the inverse of every node
+    if (big_inverse_sum_wanted(n, integrand, herm)) return true;  // G, or a series that is not Hermitian: the inverse of every node
     return big_supported(n) && herm && (integrand == ABZ_F_DOS || integrand == ABZ_F_TRGLOC);
 }
 
@@ -1162,7 +1179,7 @@ int launch_big_sum(abz_ctx* ctx, const SumSpec& ss, double* out_reim) {
     sa.grid = 1;
     sa.inv_period = 1.0;
     sa.Hbuf = w.Hbuf;
-    if (big_inverse_wanted(ss.n, ss.integrand, ss.herm)) {
+    if (big_inverse_sum_wanted(ss.n, ss.integrand, ss.herm)) {
         // matrix-valued G, or a series that is not Hermitian: H(k) of a chunk, the inverse of every node, weighted sums in registers;
         // a group of swept values per pass (the workgroups' partial sums stay under 256 MB), the chunks re-evaluated per group
         const int nn = ss.n * ss.n, kind = big_inv_kind(ss.integrand);

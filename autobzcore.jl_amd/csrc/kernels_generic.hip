@@ -773,7 +773,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 4))) voi
 }
 
 bool gen_sum_supported(int n, int M, int npt, int integrand, bool herm) {
-    if (big_supported(n) || big_inverse_wanted(n, integrand, herm)) return big_sum_supported(n, M, npt, integrand, herm);
+    if (big_supported(n) || big_inverse_sum_wanted(n, integrand, herm)) return big_sum_supported(n, M, npt, integrand, herm);
     if (n <= 4 || n > ABZ_MAX_BANDS || !herm || npt < 1 || npt >= 65536) return false;
     if (!(integrand == ABZ_F_DOS || integrand == ABZ_F_TRGLOC)) return false;
     const int np = n <= 8 ? 8 : (n <= 16 ? 16 : 32);
@@ -787,7 +787,7 @@ static bool gen_sum_tri_wanted(const SumSpec& ss);
 static int launch_gen_sum_tri(abz_ctx* ctx, const SumSpec& ss, double* out_reim);
 
 int launch_gen_sum(abz_ctx* ctx, const SumSpec& ss, double* out_reim) {
-    if (big_supported(ss.n) || big_inverse_wanted(ss.n, ss.integrand, ss.herm)) return launch_big_sum(ctx, ss, out_reim);
+    if (big_supported(ss.n) || big_inverse_sum_wanted(ss.n, ss.integrand, ss.herm)) return launch_big_sum(ctx, ss, out_reim);
     if (lane_sum_supported(ss.n, ss.M, ss.first, ss.npt, ss.integrand, ss.n_sweep)) return launch_lane_sum(ctx, ss, out_reim);
     if (gen_sum_tri_wanted(ss)) {
         const int rc = launch_gen_sum_tri(ctx, ss, out_reim);
@@ -1911,7 +1911,7 @@ int launch_gen_nodes(abz_ctx* ctx, const GenSpec& gs) {
     if (!gs.grid && gs.x && !gs.values && (gs.Eplanes.base || gs.Eaos) && !gs.Uplanes.base && !gs.deriv && !gs.Hplanes.compact && gs.n > 4 &&
         gs.M <= 64)
         return launch_big_nodes(ctx, gs);
-    if (gs.values && big_inverse_wanted(gs.n, gs.integrand, gs.herm) && !gs.Hplanes.base && !gs.Haos && !gs.Eplanes.base && !gs.Eaos &&
+    if (gs.values && gs.n > 16 && big_inverse_wanted(gs.n, gs.integrand, gs.herm) && !gs.Hplanes.base && !gs.Haos && !gs.Eplanes.base && !gs.Eaos &&
         !gs.Uplanes.base && !gs.deriv && gs.M <= 64)
         return launch_big_nodes(ctx, gs);  // 17...32 bands, values only (IAI node path): the inverse of every node in registers
     if (lane_grid_supported(gs)) return launch_lane_grid(ctx, gs);  // 5...8 bands on full grids: one node per lane
