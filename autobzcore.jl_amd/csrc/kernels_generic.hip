@@ -2763,8 +2763,11 @@ static bool gen_inner_panel_fits(int n, int M, int integrand, int* np_out, size_
     const int np = n <= 8 ? 8 : (n <= 16 ? 16 : 32);
     const size_t rest = sizeof(double) * ((size_t)inner_group_doubles(1, ABZ_PANEL_MAXSEG) + ABZ_PANEL_MAXSEG);  // + heapE
     size_t lds = sizeof(double2) * (size_t)M * np * np + rest;  // zero-padded set
-    const bool pad = lds <= 150 * 1024;
-    if (!pad) lds = sizeof(double2) * (size_t)M * n * n + rest;
+    // 17...32 bands: the kernel fits 256 registers, so two workgroups share a CU when their sets do -- the set without its zero
+    // padding if that is what it takes (17 bands x 5 coefficients: 80 KB padded, 23 KB without; IAI 55 -> 72 M nodes/s)
+    const size_t bare = sizeof(double2) * (size_t)M * n * n + rest;
+    const bool pad = np == 32 ? (lds <= 72 * 1024 || bare > 72 * 1024) && lds <= 150 * 1024 : lds <= 150 * 1024;
+    if (!pad) lds = bare;
     if (lds > 150 * 1024) return false;
     if (np_out) *np_out = np;
     if (lds_out) *lds_out = lds;
@@ -2838,8 +2841,11 @@ int launch_gen_inner_adaptive(abz_ctx* ctx, const InnerSpec& is) {
     } else if (np == 16) {
         if (pad) ABZ_IPANEL3(16, true, 512, 4)
         else ABZ_IPANEL3(16, false, 512, 4)
-    } else {  // 17...32 bands: 256 threads = 8 nodes of 32 lanes, one wave per SIMD (the Householder rows take ~300 registers)
-        if (pad) ABZ_IPANEL3(32, true, 256, 0)
+    } else {  // 17...32 bands: 256 threads = 8 nodes of 32 lanes
+        const bool two = plds <= 72 * 1024;  // (two workgroups per CU: hold the kernel to 256 registers)
+        if (pad && two) ABZ_IPANEL3(32, true, 256, 2)
+        else if (pad) ABZ_IPANEL3(32, true, 256, 0)
+        else if (two) ABZ_IPANEL3(32, false, 256, 2)
         else ABZ_IPANEL3(32, false, 256, 0)
     }
 #undef ABZ_IPANEL3
