@@ -1249,8 +1249,10 @@ static int launch_gen_sum_tri(abz_ctx* ctx, const SumSpec& ss, double* out_reim)
     const int np = n <= 8 ? 8 : (n <= 16 ? 16 : 32);
     const size_t rest = sizeof(double2) * (size_t)256;  // [SLOTS][NP] partial sums
     size_t lds = sizeof(double2) * (size_t)M * np * np + rest;
-    const bool pad = lds <= 150 * 1024;
-    if (!pad) lds = sizeof(double2) * (size_t)M * n * n + rest;
+    // (17...32 bands: the kernel fits 256 registers -- the set without its zero padding when that lets two workgroups share a CU)
+    const size_t bare = sizeof(double2) * (size_t)M * n * n + rest;
+    const bool pad = np == 32 ? (lds <= 72 * 1024 || bare > 72 * 1024) && lds <= 150 * 1024 : lds <= 150 * 1024;
+    if (!pad) lds = bare;
     int mc = 0;
     if (lds > 160 * 1024) {  // the set does not fit the LDS whole: staged in chunks of mc coefficients (two workgroups per CU)
         mc = (int)((72 * 1024 - rest) / (sizeof(double2) * (size_t)n * n));
