@@ -7,6 +7,7 @@
 #include <map>
 #include <mutex>
 #include <numeric>
+#include <thread>
 
 #include "abz_internal.h"
 
@@ -252,11 +253,38 @@ int stage_d2h(abz_ctx* ctx, void* dst, const void* src, size_t bytes) {
     }
     int rc = stage_reserve(ctx, std::min(bytes, STAGE_MAX));
     if (rc) return rc;
-    for (size_t off = 0; off < bytes; off += ctx->pin_cap) {
-        const size_t n = std::min(ctx->pin_cap, bytes - off);
-        ABZ_HIP(hipMemcpyAsync(ctx->pin, (const char*)src + off, n, hipMemcpyDeviceToHost, ctx->stream));
-        ABZ_HIP(hipStreamSynchronize(ctx->stream));
-        std::memcpy((char*)dst + off, ctx->pin, n);
+    // two halves of the pinned buffer in turn: the DMA of a piece runs while the host copies the piece before it into the
+    // caller's (pageable) array; that copy takes longer than the DMA and is dealt to up to four threads when a piece is large
+    const size_t piece = std::max<size_t>((ctx->pin_cap / 2) & ~(size_t)4095, 4096);
+    auto host_copy = [](char* d, const char* s_, size_t n) {
+        const int nt = n >= ((size_t)8 << 20) ? 4 : 1;
+        if (nt == 1) {
+            std::memcpy(d, s_, n);
+            return;
+        }
+        std::thread th[3];
+        const size_t share = (n / nt + 63) & ~(size_t)63;
+        for (int t = 1; t < nt; ++t) {
+            const size_t o = std::min(n, share * t), m = std::min(n, share * (t + 1)) - o;
+            th[t - 1] = std::thread([=] { std::memcpy(d + o, s_ + o, m); });
+        }
+        std::memcpy(d, s_, std::min(n, share));
+        for (int t = 1; t < nt; ++t) th[t - 1].join();
+    };
+    size_t off = 0, prev_off = 0, prev_n = 0;
+    int buf = 0;
+    while (off < bytes || prev_n) {
+        size_t n = 0;
+        if (off < bytes) {
+            n = std::min(piece, bytes - off);
+            ABZ_HIP(hipMemcpyAsync((char*)ctx->pin + (size_t)buf * piece, (const char*)src + off, n, hipMemcpyDeviceToHost, ctx->stream));
+        }
+        if (prev_n) host_copy((char*)dst + prev_off, (const char*)ctx->pin + (size_t)(buf ^ 1) * piece, prev_n);  // (its DMA was waited for below)
+        if (n) ABZ_HIP(hipStreamSynchronize(ctx->stream));
+        prev_off = off;
+        prev_n = n;
+        off += n;
+        buf ^= 1;
     }
     return ABZ_OK;
 }
