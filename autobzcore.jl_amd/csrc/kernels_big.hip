@@ -16,7 +16,7 @@
 // Serves abz_eval_nodes, rule builds (H and / or eigenvalues, full layout), scans of cached rules (DOS / tr G from the
 // matrices or the eigenvalues), store-free PTR sums and the IAI node path; big_inverse_kernel (one workgroup per node, Gauss-
 // Jordan in registers) adds matrix-valued G and the traces of series that are not Hermitian; GGR builds (eigenvalues + band
-// velocities): launch_big_ggr below with kernels_big_vec.hip.  Only the Hermitian-compact layout stays at <= 32 bands.
+// velocities): launch_big_ggr below with kernels_big_vec.hip.  (The Hermitian-compact layout ends at 16 bands.)
 #include <utility>
 
 #include "abz_internal.h"
