@@ -540,7 +540,8 @@ struct SumSpec {
     const double* sweep_host;
     double params[4];
     double scale;
-    bool herm = true;  // the series is Hermitian (n > 16: a series that is not goes through the inverse of every node)
+    bool herm = true;  // the series is Hermitian (a series that is not goes through the inverse of every node)
+    bool force_inverse = false;  // n <= 4 without a closed-form store-free kernel for this case: the inverse of every node as well
 };
 
 bool eval_sum_supported(int n, int M, int npt, int integrand, bool herm);

@@ -1554,9 +1554,13 @@ int abz_ptr_sum(abz_series* s, int npt, int outer_begin, int outer_end, int inte
     ABZ_REQUIRE(0 <= outer_begin && outer_begin < outer_end && outer_end <= npt, "slab [%d, %d) outside the grid of %d points",
                 outer_begin, outer_end, npt);
     ABZ_REQUIRE(d >= 2 || (outer_begin == 0 && outer_end == npt), "a slab needs at least two variables");
-    const bool generic = n > 4;
-    if (!(generic ? gen_sum_supported(n, s->dims[0], npt, integrand, s->hermitian)
-                  : eval_sum_supported(n, s->dims[0], npt, integrand, s->hermitian))) {
+    // n <= 4 without a closed-form store-free kernel for this case (a series that is not Hermitian, a short grid line): the
+    // inverse of every node like the larger matrices (kernels_big.hip), for the integrands it serves
+    const bool inv_small = n <= 4 && !eval_sum_supported(n, s->dims[0], npt, integrand, s->hermitian) && s->dims[0] <= 64 &&
+                           (integrand == ABZ_F_DOS || integrand == ABZ_F_TRGLOC || integrand == ABZ_F_GLOC);
+    const bool generic = n > 4 || inv_small;
+    if (!inv_small && !(generic ? gen_sum_supported(n, s->dims[0], npt, integrand, s->hermitian)
+                                : eval_sum_supported(n, s->dims[0], npt, integrand, s->hermitian))) {
         set_error("store-free sum not available for this series / grid / integrand (use a rule)");
         return ABZ_ERR_UNSUPPORTED;
     }
@@ -1609,13 +1613,14 @@ int abz_ptr_sum(abz_series* s, int npt, int outer_begin, int outer_end, int inte
     for (int j = 0; j + 2 < d; ++j) ss.line0 *= npt;  // lines per outer index: npt^(d-2)
     ss.integrand = integrand;
     ss.herm = s->hermitian;
+    ss.force_inverse = inv_small;
     ss.n_sweep = n_sweep;
     ss.sweep_host = sweep;
     for (int i = 0; i < 4; ++i) ss.params[i] = (i < nparams && params) ? params[i] : 0.0;
     double vol = 1.0;
     for (int j = 0; j < d; ++j) vol *= (double)npt;
     ss.scale = 1.0 / (vol * (double)nsyms);
-    rc = generic ? launch_gen_sum(ctx, ss, out_reim) : launch_eval_sum(ctx, ss, out_reim);
+    rc = inv_small ? launch_big_sum(ctx, ss, out_reim) : (generic ? launch_gen_sum(ctx, ss, out_reim) : launch_eval_sum(ctx, ss, out_reim));
     (void)hipStreamSynchronize(ctx->stream);
     return done(rc);
 } ABZ_CATCH_ALL

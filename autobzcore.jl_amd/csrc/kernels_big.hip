@@ -882,7 +882,9 @@ static int big_inverse(abz_ctx* ctx, BigInvArgs& ia, int64_t blocks) {
         const int subs = ia.n <= 8 ? 8 : (ia.n <= 16 ? 4 : 2);
         blocks = std::max<int64_t>(1, std::min<int64_t>(blocks, (ia.nnodes + subs - 1) / subs));
     }
-    if (ia.n <= 8)
+    if (ia.n <= 4)
+        hipLaunchKernelGGL((big_inverse_kernel<1, 8>), dim3((unsigned)blocks), dim3(256), 0, ctx->stream, ia);
+    else if (ia.n <= 8)
         hipLaunchKernelGGL((big_inverse_kernel<2, 8>), dim3((unsigned)blocks), dim3(256), 0, ctx->stream, ia);
     else if (ia.n <= 12)
         hipLaunchKernelGGL((big_inverse_kernel<3, 4>), dim3((unsigned)blocks), dim3(256), 0, ctx->stream, ia);
@@ -1179,7 +1181,7 @@ int launch_big_sum(abz_ctx* ctx, const SumSpec& ss, double* out_reim) {
     sa.grid = 1;
     sa.inv_period = 1.0;
     sa.Hbuf = w.Hbuf;
-    if (big_inverse_sum_wanted(ss.n, ss.integrand, ss.herm)) {
+    if (big_inverse_sum_wanted(ss.n, ss.integrand, ss.herm) || (ss.force_inverse && big_inv_kind(ss.integrand) >= 0)) {
         // matrix-valued G, or a series that is not Hermitian: H(k) of a chunk, the inverse of every node, weighted sums in registers;
         // a group of swept values per pass (the workgroups' partial sums stay under 256 MB), the chunks re-evaluated per group
         const int nn = ss.n * ss.n, kind = big_inv_kind(ss.integrand);

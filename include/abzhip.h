@@ -236,8 +236,10 @@ int abz_series_drop_rules(abz_series* s);
  * [outer_begin, outer_end) of its outermost variable), computed without materialising H(k): the
  * Fourier evaluation feeds the integrand directly and only the sums leave the kernel.  For grids that are
  * used once (an AutoPTR refinement step) or do not fit in HBM (1000^3 k-points = 168 GB of rule values).
- * Hermitian series; n <= 4 with npt > 128 (any integrand), or 5..32 bands (resolvent traces DOS / TRGLOC,
- * any npt); ABZ_ERR_UNSUPPORTED otherwise (build a rule instead).
+ * DOS, TRGLOC and GLOC: every series and grid up to ABZ_MAX_BANDS bands (Hermitian series: closed forms up to 4 bands on lines of
+ * more than 128 points, the tridiagonal form of every node above; GLOC above 4 bands, series that are not Hermitian and short
+ * lines: the inverse of every node, chunk by chunk).  Other integrands: Hermitian series of n <= 4 bands with npt > 128;
+ * ABZ_ERR_UNSUPPORTED otherwise (build a rule instead).
  * Replaces: FourierPTR ctor + rule(f, B) back to back (src/fourier.jl:166-207). */
 int abz_ptr_sum(abz_series* s, int npt, int outer_begin, int outer_end, int integrand,
                 const double* params, int nparams, const double* sweep, int n_sweep, int nsyms,
