@@ -599,8 +599,11 @@ def _ptr_rule_values(f: FourierIntegrand, dev, npt, syms, plist):
         n, d = f.w.n, f.w.d
         nk = int(npt) ** d
         rule_bytes = nk * (16 * n * n if want & L.WANT_H else 8 * n)
-        # (more than 4 bands: the store-free panel kernels beat building + scanning a rule at any size)
-        stream = (syms is None and (rule_bytes > dev.stream_above_bytes or n > 4) and
+        # (more than 4 bands: the store-free kernels beat building + scanning a rule at any size -- except the matrix-valued G
+        # of a Hermitian series up to 16 bands, whose cached rule is scanned by the 16-lane row kernel at half the cost of the
+        # store-free inverse: kept as a rule unless it is too large)
+        prefer_stream = n > 4 and not (fi.fid == L.F_GLOC and n <= 16 and dev.hermitian())
+        stream = (syms is None and (rule_bytes > dev.stream_above_bytes or prefer_stream) and
                   not dev.has_rule(npt, syms, want) and dev.ptr_sum_supported(npt, fi.fid))
         rule = None
         for params, idxs in groups.items():
