@@ -950,7 +950,7 @@ static bool rule_ggr_rows(const abz_rule* r) {
     const RulePlan* rp = static_cast<const RulePlan*>(r->plan);
     if (!(r->want & ABZ_WANT_VEL) || !rp) return false;
     if (big_supported(s->n)) {  // 33...64 bands: the only velocity build there is; H, when wanted as well, by the plain build after it
-        if (!r->full && !(s->d >= 2 && !rp->plan.coords)) return false;
+        if (!r->full && rp->plan.coords) return false;  // (lists of grid nodes; explicit coordinates have no velocity build)
         return big_ggr_supported(s->n, s->d, s->dims[0], r->npt, s->hermitian);
     }
     if ((r->want & ABZ_WANT_H) || !abz_switch(SW_GGR_FUSED)) return false;
@@ -998,7 +998,7 @@ static int rule_fill(abz_rule* r) {
             gs.nlines = plan.nruns;
             gs.run_start = rp->pd.runs.as<int64_t>();  // (33...64 bands: only "a node list" is read from it)
             gs.gi = rp->pd.gi[0].as<int32_t>();
-            gs.parents = rp->pd.parent[0].as<int64_t>();
+            gs.parents = d >= 2 ? rp->pd.parent[0].as<int64_t>() : nullptr;  // (one variable: one level-1 set)
             gs.nk = r->nk;
         }
         int rc;

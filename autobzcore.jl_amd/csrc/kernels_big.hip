@@ -953,7 +953,7 @@ bool big_ggr_supported(int n, int d, int M, int npt, bool herm) {
 }
 
 int launch_big_ggr(abz_ctx* ctx, const GgrRowsSpec& gs) {
-    const bool grid = gs.parents == nullptr;  // (node lists of d >= 2 variables come with the level-1 set of every node)
+    const bool grid = gs.nk == 0;  // (node lists: nk nodes with their grid indices and, for d >= 2, the level-1 set of every node)
     const int64_t nnodes = grid ? gs.nlines * gs.npt : gs.nk;
     if (nnodes == 0) return ABZ_OK;
     const int n = gs.n, nn = n * n, np = n * (n + 1) / 2;

@@ -1870,6 +1870,15 @@ def test_ggr_33_to_64_bands(abz, n):
         sep = np.min(np.diff(e2, axis=1), axis=1) > 1e-6 * np.abs(e2).max()
         assert np.abs(o2["eig"] - e2).max() < 1e-11 * np.abs(e2).max()
         assert np.abs(o2["vel"][sep] - v2[sep]).max() < 1e-8 * np.abs(v2).max()
+        # ... and the inversion-symmetric node list in the same dimension (one variable: a list without level-1 parents)
+        sy = orc.load_bz("InversionSymIBZ", np.eye(len(dims))).syms
+        w3, e3, v3 = orc.get_ggr_data(so2, npt, sy)
+        rule = abz.DeviceRule(s2.device(), npt, sy, 2 | 4)
+        o3 = rule.export(eig=True, vel=True)
+        rule.close()
+        sep3 = np.min(np.diff(e3, axis=1), axis=1) > 1e-6 * np.abs(e3).max()
+        assert np.abs(o3["eig"] - e3).max() < 1e-11 * np.abs(e3).max()
+        assert np.abs(o3["vel"][sep3] - v3[sep3]).max() < 1e-8 * np.abs(v3).max()
 
 
 def test_33_to_64_bands_in_many_chunks(abz, monkeypatch):
