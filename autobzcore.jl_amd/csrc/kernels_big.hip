@@ -1015,7 +1015,7 @@ int launch_big_nodes(abz_ctx* ctx, const GenSpec& gs) {
     if (gs.nnodes == 0) return ABZ_OK;
     if (gs.deriv || gs.Uplanes.base || gs.Hplanes.compact) {
         set_error("n = %d bands: stored eigenvectors, derivative matrices and the upper-triangle layout are built for n <= 32 (band velocities "
-                  "of 33...64 bands: rules of full grids, or of node lists in two or three dimensions, with ABZ_WANT_VEL)", gs.n);
+                  "of 33...64 bands: rules of full grids or of lists of grid nodes with ABZ_WANT_VEL)", gs.n);
         return ABZ_ERR_UNSUPPORTED;
     }
     if (gs.M > 64) {
