@@ -303,8 +303,25 @@ __global__ __launch_bounds__(64) void big_tridiag_kernel(const double2* __restri
             // p_i = beta sum_{j > k} A(i, j) v_j:  A(i, j) = L(i, j) for j <= i, conj L(j, i) for j > i
             double pr = 0.0, pi = 0.0;
             if (below) {
-#pragma unroll 4
-                for (int j = k + 1; j < n; ++j) {
+                double pr2 = 0.0, pi2 = 0.0;  // (two chains: the FMAs of consecutive j do not wait for one another)
+                int j = k + 1;
+#pragma unroll 2
+                for (; j + 1 < n; j += 2) {
+                    const bool own0 = j <= i, own1 = j + 1 <= i;
+                    double2 a0 = A[own0 ? ri + j : j * (j + 1) / 2 + i], a1 = A[own1 ? ri + j + 1 : (j + 1) * (j + 2) / 2 + i];
+                    a0.y = own0 ? a0.y : -a0.y;
+                    a1.y = own1 ? a1.y : -a1.y;
+                    const double2 v0 = vv[j], v1 = vv[j + 1];
+                    pr = fma(a0.x, v0.x, pr);
+                    pr2 = fma(a1.x, v1.x, pr2);
+                    pi = fma(a0.x, v0.y, pi);
+                    pi2 = fma(a1.x, v1.y, pi2);
+                    pr = fma(-a0.y, v0.y, pr);
+                    pr2 = fma(-a1.y, v1.y, pr2);
+                    pi = fma(a0.y, v0.x, pi);
+                    pi2 = fma(a1.y, v1.x, pi2);
+                }
+                if (j < n) {
                     const bool own = j <= i;
                     double2 aij = A[own ? ri + j : j * (j + 1) / 2 + i];
                     aij.y = own ? aij.y : -aij.y;
@@ -314,6 +331,8 @@ __global__ __launch_bounds__(64) void big_tridiag_kernel(const double2* __restri
                     pi = fma(aij.x, vj.y, pi);
                     pi = fma(aij.y, vj.x, pi);
                 }
+                pr += pr2;
+                pi += pi2;
             }
             pr *= beta;
             pi *= beta;
@@ -418,8 +437,25 @@ __global__ __launch_bounds__(64 * NW) void big_tridiag_mw_kernel(const double2* 
             __syncthreads();
             double pr = 0.0, pi = 0.0;
             if (below) {
-#pragma unroll 2
-                for (int j = k + 1 + w; j < n; j += NW) {
+                double pr2 = 0.0, pi2 = 0.0;  // (two chains)
+                int j = k + 1 + w;
+                for (; j + NW < n; j += 2 * NW) {
+                    const int j1 = j + NW;
+                    const bool own0 = j <= i, own1 = j1 <= i;
+                    double2 a0 = A[own0 ? ri + j : j * (j + 1) / 2 + i], a1 = A[own1 ? ri + j1 : j1 * (j1 + 1) / 2 + i];
+                    a0.y = own0 ? a0.y : -a0.y;
+                    a1.y = own1 ? a1.y : -a1.y;
+                    const double2 v0 = vv[j], v1 = vv[j1];
+                    pr = fma(a0.x, v0.x, pr);
+                    pr2 = fma(a1.x, v1.x, pr2);
+                    pi = fma(a0.x, v0.y, pi);
+                    pi2 = fma(a1.x, v1.y, pi2);
+                    pr = fma(-a0.y, v0.y, pr);
+                    pr2 = fma(-a1.y, v1.y, pr2);
+                    pi = fma(a0.y, v0.x, pi);
+                    pi2 = fma(a1.y, v1.x, pi2);
+                }
+                if (j < n) {
                     const bool own = j <= i;
                     double2 aij = A[own ? ri + j : j * (j + 1) / 2 + i];
                     aij.y = own ? aij.y : -aij.y;
@@ -429,6 +465,8 @@ __global__ __launch_bounds__(64 * NW) void big_tridiag_mw_kernel(const double2* 
                     pi = fma(aij.x, vj.y, pi);
                     pi = fma(aij.y, vj.x, pi);
                 }
+                pr += pr2;
+                pi += pi2;
             }
             part[w * 64 + lane] = make_double2(pr, pi);
             __syncthreads();
