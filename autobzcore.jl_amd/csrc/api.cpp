@@ -1556,7 +1556,7 @@ int abz_ptr_sum(abz_series* s, int npt, int outer_begin, int outer_end, int inte
     ABZ_REQUIRE(d >= 2 || (outer_begin == 0 && outer_end == npt), "a slab needs at least two variables");
     // n <= 4 without a closed-form store-free kernel for this case (a series that is not Hermitian, a short grid line): the
     // inverse of every node like the larger matrices (kernels_big.hip), for the integrands it serves
-    const bool inv_small = n <= 4 && !eval_sum_supported(n, s->dims[0], npt, integrand, s->hermitian) && s->dims[0] <= 64 &&
+    const bool inv_small = n <= 4 && !eval_sum_supported(n, s->dims[0], npt, integrand, s->hermitian) &&
                            (integrand == ABZ_F_DOS || integrand == ABZ_F_TRGLOC || integrand == ABZ_F_GLOC);
     const bool generic = n > 4 || inv_small;
     if (!inv_small && !(generic ? gen_sum_supported(n, s->dims[0], npt, integrand, s->hermitian)

@@ -87,7 +87,7 @@ __device__ __forceinline__ double2 big_phase(const BigSeriesArgs& a, int64_t k, 
 // tile of BIG_TN consecutive nodes: they share the coefficient reads when they share their item (grid lines: a tile never
 // crosses a line; node lists: checked per tile, otherwise node by node)
 __global__ __launch_bounds__(256) void big_series_kernel(BigSeriesArgs a, int tiles_per_line) {
-    __shared__ double2 ph[BIG_TN][64];  // [node][m], M <= 64
+    __shared__ double2 ph[BIG_TN][64];  // [node][m] of a piece of <= 64 coefficients
     __shared__ int64_t item_s[BIG_TN];
     const int nn = a.n * a.n;
     int64_t t0;
@@ -102,54 +102,61 @@ __global__ __launch_bounds__(256) void big_series_kernel(BigSeriesArgs a, int ti
         cnt = (int)min((int64_t)BIG_TN, a.nnodes - t0);
     }
     if (cnt <= 0) return;
-    for (int t = threadIdx.x; t < cnt * a.M; t += 256) {
-        const int j = t / a.M, m = t - j * a.M;
-        ph[j][m] = big_phase(a, a.node0 + t0 + j, m);
-    }
     if (threadIdx.x < cnt) {
         const int64_t k = a.node0 + t0 + threadIdx.x;
         item_s[threadIdx.x] = a.parents ? a.parents[k] : (a.grid ? k / a.npt : 0);  // (node lists without parents: d = 1, one set)
     }
-    __syncthreads();
-    bool same = true;
-    for (int j = 1; j < cnt; ++j) same = same && item_s[j] == item_s[0];
-    if (same) {
-        const double2* __restrict__ c1 = a.src + item_s[0] * ((int64_t)a.M * nn);
-        for (int e = threadIdx.x; e < nn; e += 256) {
-            double ar[BIG_TN], ai[BIG_TN];
-#pragma unroll
-            for (int j = 0; j < BIG_TN; ++j) {
-                ar[j] = 0.0;
-                ai[j] = 0.0;
-            }
-            for (int m = 0; m < a.M; ++m) {
-                const double2 c = c1[(int64_t)m * nn + e];
+    // coefficients in pieces of 64 (the room of the phases): a later piece adds to what the earlier ones left in Hbuf
+    for (int m0 = 0; m0 < a.M; m0 += 64) {
+        const int mc = min(64, a.M - m0);
+        __syncthreads();
+        for (int t = threadIdx.x; t < cnt * mc; t += 256) {
+            const int j = t / mc, m = t - j * mc;
+            ph[j][m] = big_phase(a, a.node0 + t0 + j, m0 + m);
+        }
+        __syncthreads();
+        bool same = true;
+        for (int j = 1; j < cnt; ++j) same = same && item_s[j] == item_s[0];
+        if (same) {
+            const double2* __restrict__ c1 = a.src + item_s[0] * ((int64_t)a.M * nn) + (int64_t)m0 * nn;
+            for (int e = threadIdx.x; e < nn; e += 256) {
+                double ar[BIG_TN], ai[BIG_TN];
 #pragma unroll
                 for (int j = 0; j < BIG_TN; ++j) {
-                    const double2 p = ph[j][m];
-                    ar[j] = fma(c.x, p.x, ar[j]);
-                    ar[j] = fma(-c.y, p.y, ar[j]);
-                    ai[j] = fma(c.x, p.y, ai[j]);
-                    ai[j] = fma(c.y, p.x, ai[j]);
+                    const double2 h0 = (m0 > 0 && j < cnt) ? a.Hbuf[(t0 + j) * nn + e] : make_double2(0.0, 0.0);
+                    ar[j] = h0.x;
+                    ai[j] = h0.y;
                 }
-            }
+                for (int m = 0; m < mc; ++m) {
+                    const double2 c = c1[(int64_t)m * nn + e];
 #pragma unroll
-            for (int j = 0; j < BIG_TN; ++j)
-                if (j < cnt) a.Hbuf[(t0 + j) * nn + e] = make_double2(ar[j], ai[j]);
-        }
-    } else {
-        for (int j = 0; j < cnt; ++j) {
-            const double2* __restrict__ c1 = a.src + item_s[j] * ((int64_t)a.M * nn);
-            for (int e = threadIdx.x; e < nn; e += 256) {
-                double ar = 0.0, ai = 0.0;
-                for (int m = 0; m < a.M; ++m) {
-                    const double2 c = c1[(int64_t)m * nn + e], p = ph[j][m];
-                    ar = fma(c.x, p.x, ar);
-                    ar = fma(-c.y, p.y, ar);
-                    ai = fma(c.x, p.y, ai);
-                    ai = fma(c.y, p.x, ai);
+                    for (int j = 0; j < BIG_TN; ++j) {
+                        const double2 p = ph[j][m];
+                        ar[j] = fma(c.x, p.x, ar[j]);
+                        ar[j] = fma(-c.y, p.y, ar[j]);
+                        ai[j] = fma(c.x, p.y, ai[j]);
+                        ai[j] = fma(c.y, p.x, ai[j]);
+                    }
                 }
-                a.Hbuf[(t0 + j) * nn + e] = make_double2(ar, ai);
+#pragma unroll
+                for (int j = 0; j < BIG_TN; ++j)
+                    if (j < cnt) a.Hbuf[(t0 + j) * nn + e] = make_double2(ar[j], ai[j]);
+            }
+        } else {
+            for (int j = 0; j < cnt; ++j) {
+                const double2* __restrict__ c1 = a.src + item_s[j] * ((int64_t)a.M * nn) + (int64_t)m0 * nn;
+                for (int e = threadIdx.x; e < nn; e += 256) {
+                    const double2 h0 = m0 > 0 ? a.Hbuf[(t0 + j) * nn + e] : make_double2(0.0, 0.0);
+                    double ar = h0.x, ai = h0.y;
+                    for (int m = 0; m < mc; ++m) {
+                        const double2 c = c1[(int64_t)m * nn + e], p = ph[j][m];
+                        ar = fma(c.x, p.x, ar);
+                        ar = fma(-c.y, p.y, ar);
+                        ai = fma(c.x, p.y, ai);
+                        ai = fma(c.y, p.x, ai);
+                    }
+                    a.Hbuf[(t0 + j) * nn + e] = make_double2(ar, ai);
+                }
             }
         }
     }
@@ -954,7 +961,7 @@ int big_series(abz_ctx* ctx, BigSeriesArgs& sa, int64_t c0, int64_t cn) {
     sa.nnodes = cn;
     if (sa.grid) {
         const int64_t lines = cn / sa.npt;
-        if (abz_switch(SW_BIG_MFMA)) {
+        if (abz_switch(SW_BIG_MFMA) && sa.M <= 64) {
             const int tpl = (sa.npt + 15) / 16;
             hipLaunchKernelGGL(big_series_mfma_kernel, dim3((unsigned)(lines * tpl)), dim3(256), 0, ctx->stream, sa, tpl);
         } else {
@@ -987,7 +994,7 @@ bool big_inverse_sum_wanted(int n, int integrand, bool herm) {
 // eigenvalues into the rule -> dH/dk_j, j = 1 ... d, side by side -> eigenvectors, back-transformation and the quadratic forms in
 // big_ggr_kernel (kernels_big_vec.hip).  ref: src/dos_ggr.jl:14-44
 bool big_ggr_supported(int n, int d, int M, int npt, bool herm) {
-    return big_supported(n) && herm && d >= 1 && d <= 3 && M >= 1 && M <= 64 && npt >= 1 && npt < 65536;
+    return big_supported(n) && herm && d >= 1 && d <= 3 && M >= 1 && npt >= 1 && npt < 65536;
 }
 
 int launch_big_ggr(abz_ctx* ctx, const GgrRowsSpec& gs) {
@@ -1054,10 +1061,6 @@ int launch_big_nodes(abz_ctx* ctx, const GenSpec& gs) {
     if (gs.deriv || gs.Uplanes.base || gs.Hplanes.compact) {
         set_error("n = %d bands: stored eigenvectors, derivative matrices and the upper-triangle layout are built for n <= 32 (band velocities "
                   "of 33...64 bands: rules of full grids or of lists of grid nodes with ABZ_WANT_VEL)", gs.n);
-        return ABZ_ERR_UNSUPPORTED;
-    }
-    if (gs.M > 64) {
-        set_error("n = %d bands: at most 64 coefficients per variable (got %d)", gs.n, gs.M);
         return ABZ_ERR_UNSUPPORTED;
     }
     if (gs.values && big_inv_kind(gs.integrand) < 0) {
@@ -1190,7 +1193,7 @@ __global__ __launch_bounds__(256) void big_scale_kernel(double2* v, int n, doubl
 }
 
 bool big_sum_supported(int n, int M, int npt, int integrand, bool herm) {
-    if (M > 64 || npt < 1 || npt >= 65536) return false;
+    if (npt < 1 || npt >= 65536) return false;
     if (big_inverse_sum_wanted(n, integrand, herm)) return true;  // G, or a series that is not Hermitian: the inverse of every node
     return big_supported(n) && herm && (integrand == ABZ_F_DOS || integrand == ABZ_F_TRGLOC);
 }

@@ -1910,11 +1910,10 @@ int launch_gen_nodes(abz_ctx* ctx, const GenSpec& gs) {
     if (big_supported(gs.n)) return launch_big_nodes(ctx, gs);  // 33...64 bands: kernels_big.hip
     // arbitrary nodes (abz_eval_nodes) with eigenvalues, 9...32 bands: Householder + QR through the kernels of kernels_big.hip (generic in
     // n) instead of the wave-per-node Jacobi below (4 096 nodes of 32 bands: 18 ms of kernels; a rule build of 13 824 nodes 0.8 ms)
-    if (!gs.grid && gs.x && !gs.values && (gs.Eplanes.base || gs.Eaos) && !gs.Uplanes.base && !gs.deriv && !gs.Hplanes.compact && gs.n > 4 &&
-        gs.M <= 64)
+    if (!gs.grid && gs.x && !gs.values && (gs.Eplanes.base || gs.Eaos) && !gs.Uplanes.base && !gs.deriv && !gs.Hplanes.compact && gs.n > 4)
         return launch_big_nodes(ctx, gs);
     if (gs.values && gs.n > 16 && big_inverse_wanted(gs.n, gs.integrand, gs.herm) && !gs.Hplanes.base && !gs.Haos && !gs.Eplanes.base && !gs.Eaos &&
-        !gs.Uplanes.base && !gs.deriv && gs.M <= 64)
+        !gs.Uplanes.base && !gs.deriv)
         return launch_big_nodes(ctx, gs);  // 17...32 bands, values only (IAI node path): the inverse of every node in registers
     if (lane_grid_supported(gs)) return launch_lane_grid(ctx, gs);  // 5...8 bands on full grids: one node per lane
     if (gs.n > ABZ_MAX_BANDS) {

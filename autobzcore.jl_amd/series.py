@@ -186,7 +186,7 @@ class DeviceSeries:
         if s.n > 4:  # generic-n kernels: resolvent traces of Hermitian series from the tridiagonal form; G, and series that are not Hermitian, from the inverse of every node
             if fid in (L.F_DOS, L.F_TRGLOC) and self.hermitian():
                 return True
-            return fid in (L.F_DOS, L.F_TRGLOC, L.F_GLOC) and int(s.dims[0]) <= 64
+            return fid in (L.F_DOS, L.F_TRGLOC, L.F_GLOC)
         return (npt > 128 and self.hermitian() and
                 not (fid in (L.F_LINEAR, L.F_LINEAR_X) and s.n != 1))
 

@@ -1188,6 +1188,32 @@ def test_autoptr_many_bands_through_the_library_loop(abz, n):
                 assert np.abs(np.asarray(got.u) - ref.u).max() <= 1e-10 * np.abs(ref.u).max(), (kind, type(fi).__name__, om)
 
 
+def test_more_than_32_bands_and_more_than_64_coefficients(abz):
+    """33...64 bands with more than 64 coefficients along a variable (big_series_kernel adds them up in pieces of 64): values,
+    eigenvalues, band velocities, the matrix-valued G and a store-free sum against the oracle."""
+    L = abz._lib
+    rng = np.random.default_rng(6464)
+    n, npt = 34, 9
+    c, first = rand_series(rng, (131,), n, hermitian=True)
+    c = c * np.exp(-0.05 * np.abs(np.arange(131) - 65))[:, None, None] / np.sqrt(n)
+    s, so = both(abz, c, first)
+    w, e, v = orc.get_ggr_data(so, npt, None)
+    rule = abz.DeviceRule(s.device(), npt, None, 1 | 2 | 4)
+    o = rule.export(H=True, eig=True, vel=True)
+    href = orc.fourier_ptr(so, npt).reshape(-1, n, n)
+    assert np.abs(o["H"] - href).max() <= 1e-12 * np.abs(href).max()
+    assert np.abs(o["eig"] - e).max() <= 1e-11 * np.abs(e).max()
+    sep = np.min(np.diff(e, axis=1), axis=1) > 1e-6 * np.abs(e).max()
+    assert np.abs(o["vel"][sep] - v[sep]).max() <= 1e-8 * np.abs(v).max()
+    om = np.array([0.15])
+    gref, _ = orc._ptr_rule_sum(so, npt, None, orc.f_gloc(0.3, om[0]))
+    g = rule.reduce(L.F_GLOC, [0.3], om)[0].reshape(n, n).T
+    rule.close()
+    assert np.abs(g - gref).max() <= 1e-10 * np.abs(gref).max()
+    t = s.device().ptr_sum(npt, L.F_TRGLOC, [0.3], om)[0, 0]
+    assert abs(t - np.trace(gref)) <= 1e-10 * abs(np.trace(gref))
+
+
 def test_more_than_64_bands_is_an_argument_error(abz):
     rng = np.random.default_rng(65)
     c, first = rand_series(rng, (3,), 65, hermitian=True)
